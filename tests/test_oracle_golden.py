@@ -1,0 +1,99 @@
+"""Pins the CPU oracle (oracle/em_oracle.py) against the golden vectors produced by RUNNING the reference
+(tests/golden/make_golden.py).  The oracle follows the reference's op order, so equality is bit-exact."""
+import glob
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import em_oracle as eo
+
+GOLDEN = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
+assert GOLDEN, "golden fixtures missing"
+
+
+def load(path):
+    fx = np.load(path)
+    prob, params = eo.problem_from_fixture(fx)
+    ts = torch.from_numpy(fx["ts"])
+    x0 = torch.from_numpy(fx["x0"])
+    noise = torch.from_numpy(fx["noise"])
+    return fx, prob, params, ts, x0, noise
+
+
+@pytest.fixture(autouse=True)
+def _one_thread():
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)  # fixtures were generated single-threaded (reduction order)
+    yield
+    torch.set_num_threads(n)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_time_grid(path):
+    fx, prob, *_ = load(path)
+    assert torch.equal(prob.grid(), torch.from_numpy(fx["ts"]))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_eval_passes_bit_exact(path):
+    fx, prob, params, ts, x0, noise = load(path)
+    r1 = prob.eval(ts, x0, noise, compute_weights=True, return_traj="eval1/xs" in fx.files)
+    assert np.array_equal(r1["samples"].numpy(), fx["eval1/x_T"])
+    assert np.array_equal(r1["rnd"].numpy(), fx["eval1/rnd"])
+    assert np.array_equal(r1["weights"].numpy(), fx["eval1/weights"])
+    assert r1["log_norm_const_lb_ito"] == float(fx["eval1/log_norm_const_lb_ito"])
+    assert r1["log_norm_const_is"] == float(fx["eval1/log_norm_const_is"])
+    assert r1["lv_loss"] == float(fx["eval1/lv_loss"])
+    if "eval1/xs" in fx.files:
+        assert np.array_equal(r1["xs"].numpy(), fx["eval1/xs"])
+    r2 = prob.eval(ts, x0, noise, compute_weights=False)
+    assert np.array_equal(r2["samples"].numpy(), fx["eval2/x_T"])
+    assert np.array_equal(r2["rnd"].numpy(), fx["eval2/rnd"])
+    assert r2["log_norm_const_lb"] == float(fx["eval2/log_norm_const_lb"])
+
+
+@pytest.mark.parametrize("method", ["kl", "lv"])
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_train_loss_and_grads_bit_exact(path, method):
+    fx, prob, params, ts, x0, noise = load(path)
+    names = [k for k in params if not k.endswith("timestep_coeff")]
+    for k in names:
+        params[k].requires_grad_(True)
+    loss, n_filtered, _, _ = prob.train_loss(ts, x0, noise, method=method)
+    loss.backward()
+    assert loss.item() == float(fx[f"train_{method}/loss"])
+    assert n_filtered == int(fx[f"train_{method}/n_filtered"])
+    for k in names:
+        ref = fx[f"train_{method}/grad/{k}"]
+        got = params[k].grad.numpy() if params[k].grad is not None else np.zeros_like(ref)
+        assert np.array_equal(got, ref), k
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_density_known_answers(path):
+    """Reference KAT (tests/distr_eval.py:45-55): analytic score == autograd score, rtol=atol=1e-4; plus
+    bit-exact log-density / score vectors captured from the reference."""
+    fx, prob, *_ = load(path)
+    x = torch.from_numpy(fx["kat/x"])
+    assert np.array_equal(prob.target.unnorm_log_prob(x).numpy(), fx["kat/target_unnorm_log_prob"])
+    assert np.array_equal(prob.target.score(x.clone()).numpy(), fx["kat/target_score"])
+    assert np.array_equal(prob.second.log_prob(x).numpy(), fx["kat/second_log_prob"])
+    if "kat/prior_score" in fx.files:
+        assert np.array_equal(prob.prior.score(x).numpy(), fx["kat/prior_score"])
+    torch.testing.assert_close(prob.target.score(x.clone()), prob.target.autograd_score(x.clone()), rtol=1e-4, atol=1e-4)
+    if "kat/prior_score" in fx.files:
+        torch.testing.assert_close(prob.prior.score(x.clone()), prob.prior.autograd_score(x.clone()), rtol=1e-4, atol=1e-4)
+
+
+def test_noise_free_path_draws_from_global_rng():
+    fx, prob, params, ts, x0, noise = load(GOLDEN[0])
+    meta = json.loads(bytes(fx["meta"]).decode())
+    torch.manual_seed(meta["seed"])
+    _ = torch.randn_like(x0) if meta["prior"]["kind"] != "delta" else None  # consume the prior draw
+    a = prob.eval(ts, x0, None, compute_weights=False)
+    b = prob.eval(ts, x0, noise, compute_weights=False)
+    # (x0 was drawn with prior.sample == loc + scale*randn for the untruncated prior, so the streams line up)
+    assert np.array_equal(a["samples"].numpy(), b["samples"].numpy())

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: trajectory-steps/s of the fused Euler-Maruyama engine on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json metric "trajectory-steps/sec ... GMM-40 d=50"): target = 40-mode GMM in d=50
+(fab means in the first two coordinates, scale softplus(1)), solver basic_pis (ScoreCtrl + FourierMLP C=64/4 layers
+GELU, Delta prior, ScaledBM(sqrt 0.2, T=5)), batch 65 536 trajectories PER GPU, T = 100 steps, fp32, in-kernel
+Philox noise, random-init weights (last layers N(0, 0.05^2)), x0 resident in HBM.
+One "step" = one pass of the hot path over the batch with the reference's `eval/sample_time` semantics
+(solver/oc.py:88-97): loss.eval(ts, x, ..., compute_weights=False, return_traj=False) under no_grad, i.e. the
+trajectory kernel + the log-Z lower-bound reduction (+ the 8-float all-gather when N > 1).
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+WORKLOAD = "gmm50_pis_headline"
+PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA (= fp32 vector) dense peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def flops_per_traj_step(d: int, c: int, lh: int, k: int) -> float:
+    """F(d,C,Lh,K) = 4dC + 2 Lh C^2 (MLP, time embedding hoisted) + 6dK + 4K (GMM score) + 20d."""
+    return 4 * d * c + 2 * lh * c * c + 6 * d * k + 4 * k + 20 * d
+
+
+def cpu_baseline(spec, prob_cpu_state, budget_s: float = 20.0) -> dict:
+    """The reference's CPU path (oracle = op-for-op PyTorch-CPU restatement) on a bounded sample of the workload."""
+    from oracle import em_oracle as eo
+
+    params, tt = prob_cpu_state
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    oracle = eo.Problem(spec, params, tt)
+    ts = oracle.grid()
+    T, d = ts.numel() - 1, spec["target"]["dim"]
+    # probe to size the sample for ~budget_s of CPU work
+    xb = torch.zeros(512, d)
+    t0 = time.perf_counter()
+    oracle.eval(ts[:11], xb, None, compute_weights=False)
+    rate = 512 * 10 / (time.perf_counter() - t0)
+    batch = int(min(spec["batch"], max(1024, 2 ** int((rate * budget_s / T)).bit_length() // 2)))
+    x0 = torch.zeros(batch, d)  # Delta prior: x0 = 0 (distr/delta.py:25-28)
+    torch.manual_seed(7)
+    t0 = time.perf_counter()
+    res = oracle.eval(ts, x0, None, compute_weights=False)
+    dt = time.perf_counter() - t0
+    return {"value": batch * T / dt, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/em_oracle.py (PyTorch-CPU restatement of the reference loop), same workload, "
+                      f"B={batch} of {spec['batch']}, T={T}, {cores} torch threads, {dt:.1f} s, "
+                      f"log_norm_const_lb={res['log_norm_const_lb']:.4f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the workload's 65 536)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-check", action="store_true",
+                    help="also report |d logZ| of the HIP path vs the oracle on identical noise (B=4096)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec(WORKLOAD)
+    if args.batch:
+        spec["batch"] = args.batch
+    prob = problems.build(spec)
+    cpu_state = ({k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()},
+                 dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(),
+                      mixture_weights=prob.target.mixture_weights.clone()))
+    prob.to(device)
+    B, T, d = spec["batch"], prob.ts.numel() - 1, spec["target"]["dim"]
+    torch.manual_seed(1 + rank)
+    x0 = prob.prior.sample((B,))
+    prob.loss.row_offset = rank * B
+    prob.loss.engine.timing = True
+
+    def step():
+        return prob.eval(x0, compute_weights=False, return_traj=False)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        kernel_ms.append(prob.loss.engine.last_kernel_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # quality: log Z from one weighted evaluation (in-kernel noise), global over all ranks
+    full = prob.eval(x0, compute_weights=True, return_traj=False)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    flops = flops_per_traj_step(d, 64, spec["net"]["num_layers"] - 2, 40)
+    k_ms = sum(kernel_ms) / len(kernel_ms)
+    achieved = flops * B * T / (k_ms * 1e-3) / 1e12
+    out = {
+        "metric": "trajectory-steps/sec (batch x steps / s), GMM-40 d=50",
+        "value": world * B * T * args.steps / elapsed,
+        "unit": "trajectory-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{WORKLOAD}: GMM-40 d=50 (explicit loc/scale), basic_pis (ScoreCtrl, FourierMLP C=64 "
+                               f"L=4 GELU, Delta prior, ScaledBM sqrt(0.2) T=5), eval sample_time semantics",
+                   "batch_per_gpu": B, "global_batch": world * B, "em_steps": T, "dim": d, "gmm_components": 40,
+                   "noise": "in-kernel Philox4x32-10 + Box-Muller", "parallelism": f"batch-sharded x{world}"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                     "kernel": "sdeh::traj_kernel<50,64,false>", "kernel_ms": k_ms,
+                     "flops_per_traj_step": flops},
+        "log_z": {"log_norm_const_is": full.log_norm_const_preds["log_norm_const_is"],
+                  "log_norm_const_lb_ito": full.log_norm_const_preds["log_norm_const_lb_ito"],
+                  "log_norm_const_lb": res.log_norm_const_preds["log_norm_const_lb"],
+                  "true_log_norm_const": 0.0},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spec, cpu_state)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if world == 1 and args.parity_check:
+        from oracle import em_oracle as eo
+
+        nb = 4096
+        torch.manual_seed(7)
+        xb = torch.zeros(nb, d)
+        noise = torch.randn(T, nb, d)
+        ref = eo.Problem(spec, *cpu_state).eval(prob.ts.cpu(), xb, noise, compute_weights=True)
+        got = prob.eval(xb.to(device), compute_weights=True, noise=noise.to(device))
+        out["parity"] = {"batch": nb,
+                         "abs_d_log_norm_const_is": abs(got.log_norm_const_preds["log_norm_const_is"] - ref["log_norm_const_is"]),
+                         "abs_d_log_norm_const_lb_ito": abs(got.log_norm_const_preds["log_norm_const_lb_ito"] - ref["log_norm_const_lb_ito"]),
+                         "max_abs_d_x_T": (got.samples.cpu() - ref["samples"]).abs().max().item()}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,217 @@
+/*
+ * sdeh.h -- C ABI of libsdeh.so, the MI355X (gfx950) Euler-Maruyama trajectory engine.
+ *
+ * This is the drop-in boundary for ONE path of juliusberner/sde_sampler: the `simulate()` loops of the
+ * optimal-control losses.  The reference has no FFI (it is pure Python; its plugin mechanism is Hydra
+ * `_target_` class paths), so every entry point below cites the reference *Python* interface
+ * it replaces; INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.  All `const float*` / `float*` tensor arguments are
+ *     DEVICE pointers to contiguous row-major fp32 (the reference's layout: x[B,d], rnd[B,1], xs[T+1,B,d],
+ *     nn.Linear.weight[out,in]).  Struct fields that are pointers are device pointers as well; the structs
+ *     themselves live in host memory.
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the null stream), never
+ *     synchronises, never allocates after sdeh_plan_create, never retains caller buffers.
+ *   - return value: 0 on success, a negative SdehStatus otherwise (never throws across the ABI);
+ *     sdeh_last_error() returns a thread-local message for the last failure.
+ *   - parameters are re-read from the given pointers on EVERY call (the reference swaps EMA weights in and
+ *     out around evaluation, solver/base.py:335-346, and mutates clip values in place, base.py:586-597).
+ */
+#ifndef SDEH_H_
+#define SDEH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDEH_ABI_VERSION 1
+#define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
+
+typedef enum {
+  SDEH_OK = 0,
+  SDEH_ERR_INVALID = -1,     /* bad argument (null pointer, negative size, unknown enum) */
+  SDEH_ERR_UNSUPPORTED = -2, /* valid in the reference but not built into this engine (see message) */
+  SDEH_ERR_HIP = -3,         /* a HIP runtime call failed */
+  SDEH_ERR_CAPACITY = -4     /* problem larger than what the plan was created for */
+} SdehStatus;
+
+/* losses/oc.py: TimeReversalLoss (140-278), ReferenceSDELoss (281-391), ExponentialIntegratorSDELoss (394-505) */
+typedef enum { SDEH_LOSS_TIME_REVERSAL = 0, SDEH_LOSS_REFERENCE_SDE = 1, SDEH_LOSS_EXPONENTIAL = 2 } SdehLossKind;
+/* models/reparam.py: ClippedCtrl 13-36, ScoreCtrl 39-83, LerpCtrl 113-162, LerpTargetCtrl 184-200, LerpPriorCtrl 165-181 */
+typedef enum {
+  SDEH_CTRL_CLIPPED = 0, SDEH_CTRL_SCORE = 1, SDEH_CTRL_LERP = 2, SDEH_CTRL_LERP_TARGET = 3, SDEH_CTRL_LERP_PRIOR = 4
+} SdehCtrlKind;
+/* eq/sdes.py: VP 191-269; ConstOU 125-172 (ScaledBM 175-188 == ConstOU with drift_coeff 0); NONE for DDS */
+typedef enum { SDEH_SDE_NONE = 0, SDEH_SDE_VP = 1, SDEH_SDE_CONST_OU = 2 } SdehSdeKind;
+/* distr/gauss.py GMM 66-155 / Gauss 158-183 / IsotropicGauss 186-242 / delta.py; double_well.py 14-100,103-193; funnel.py */
+typedef enum {
+  SDEH_DENS_NONE = 0,
+  SDEH_DENS_GMM = 1,        /* loc[K,d], scale[K,d], mixture_weights[K] (unnormalised, as given to Categorical) */
+  SDEH_DENS_DIAG_GAUSS = 2, /* loc[d], scale[d]   (Gauss / IsotropicGauss / Delta / sde.marginal_distr) */
+  SDEH_DENS_MULTI_WELL = 3, /* n_components double wells then (dim-n_components) unit Gaussians at `shift`;
+                               DoubleWell == {dim 1, n_components 1} */
+  SDEH_DENS_FUNNEL = 4      /* p0 = variance of the first coordinate (default dim-1) */
+} SdehDensityKind;
+/* activation callable injected by conf/model/base/fouriermlp.yaml:5-6 (default torch.nn.GELU, exact erf) */
+typedef enum { SDEH_ACT_GELU_ERF = 0, SDEH_ACT_SILU = 1, SDEH_ACT_RELU = 2 } SdehActivation;
+
+/* flags of simulate(): losses/oc.py:156-166 (train, compute_ito_int, change_sde_ctrl, return_traj) */
+enum {
+  SDEH_FLAG_TRAIN = 1,           /* TimeReversalLoss only: skip `rnd -= sde.drift_div_int` (oc.py:210-211) */
+  SDEH_FLAG_ITO = 2,             /* add the Ito integral  sum(u . dB)            (oc.py:218-219,330-331,440-443) */
+  SDEH_FLAG_CHANGE_SDE_CTRL = 4, /* log-variance form of the running cost        (oc.py:204-206,319-321,418-422) */
+  SDEH_FLAG_INIT_LOGP = 8,       /* rnd starts at second.log_prob(x0) instead of 0 (oc.py:168-172) */
+  SDEH_FLAG_TERMINAL_TARGET = 16,/* subtract clip(target.unnorm_log_prob(x_T), clip_target) in-kernel (oc.py:225) */
+  SDEH_FLAG_TERMINAL_SECOND = 32,/* add second.log_prob(x_T) in-kernel (oc.py:337,449-450) */
+  SDEH_FLAG_REFERENCE_CTRL = 64  /* ReferenceSDELoss.reference_ctrl = sigma(t) * prior.score(x) (solver/oc.py:305-306) */
+};
+
+typedef struct {
+  int32_t kind;         /* SdehDensityKind */
+  int32_t dim;
+  int32_t n_components; /* GMM: K; MULTI_WELL: n_double_wells */
+  int32_t reserved;
+  float log_norm_const; /* Distribution.log_norm_const (0 when None) -- added by unnorm_log_prob where the reference does */
+  float p0;             /* MULTI_WELL: separation;  FUNNEL: variance of x_0 */
+  float p1;             /* MULTI_WELL: shift */
+  float p2;
+  const float* loc;
+  const float* scale;
+  const float* mixture_weights; /* GMM only; NULL == single component */
+} SdehDensity;
+
+/* models/mlp.py:43-82 TimeEmbed.  hidden_w[0] is [C,2C]; hidden_w[i>0] are [C,C]; out_w is [dim_out,C]. */
+typedef struct {
+  int32_t channels;
+  int32_t n_hidden; /* len(hidden_layer) = num_layers-1 >= 1;  0 == module absent (score_model=None) */
+  int32_t dim_out;
+  int32_t reserved;
+  const float* coeff; /* timestep_coeff [C] */
+  const float* phase; /* timestep_phase [C] */
+  const float* hidden_w[SDEH_MAX_HIDDEN];
+  const float* hidden_b[SDEH_MAX_HIDDEN];
+  const float* out_w;
+  const float* out_b;
+} SdehTimeEmbed;
+
+/* models/mlp.py:85-122 FourierMLP.  input_w [C,d]; hidden_w[i] [C,C] (num_layers-2 of them); out_w [d,C]. */
+typedef struct {
+  int32_t dim;
+  int32_t channels;
+  int32_t n_hidden;
+  int32_t activation; /* SdehActivation, shared with the time embeddings (same callable in the reference) */
+  const float* input_w;
+  const float* input_b;
+  const float* hidden_w[SDEH_MAX_HIDDEN];
+  const float* hidden_b[SDEH_MAX_HIDDEN];
+  const float* out_w;
+  const float* out_b;
+  SdehTimeEmbed timestep_embed; /* FourierMLP.timestep_embed (num_layers=2, dim_out=C) */
+} SdehFourierMLP;
+
+/* One evaluation problem == what the reference loss object + its collaborators hold. */
+typedef struct {
+  int32_t loss_kind; /* SdehLossKind */
+  int32_t ctrl_kind; /* SdehCtrlKind */
+  int32_t sde_kind;  /* SdehSdeKind */
+  int32_t flags;     /* SDEH_FLAG_* */
+  /* generative_ctrl attributes (reparam.py): +INF == None */
+  float clip_model, clip_score, scale_score;
+  float clip_target; /* solver/oc.py:48-54, +INF == None */
+  /* sde (eq/sdes.py), generative=True (sign=+1) */
+  float terminal_t;
+  float vp_beta_min, vp_beta_max, vp_scale; /* VP: diff_coeff_sq_min/max, scale_diff_coeff */
+  float ou_drift, ou_diff;                  /* ConstOU / ScaledBM: drift_coeff, diff_coeff */
+  float exp_alpha, exp_sigma;               /* ExponentialIntegratorSDELoss.alpha / .sigma */
+  SdehFourierMLP base_model;                /* generative_ctrl.base_model */
+  SdehTimeEmbed score_model;                /* generative_ctrl.score_model (gamma(t); dim_out 1 or d) */
+  SdehDensity target;                       /* target (score + terminal log-density) */
+  SdehDensity prior;                        /* prior_score of Lerp*Ctrl / reference_ctrl */
+  SdehDensity second;                       /* initial_log_prob (DIS) or reference_log_prob (PIS/DDS) density */
+} SdehProblem;
+
+typedef struct {
+  int32_t dim;         /* d */
+  int32_t channels;    /* C (multiple of 32) */
+  int32_t max_hidden;  /* largest n_hidden of base_model */
+  int32_t max_steps;   /* largest T = len(ts)-1 */
+  int32_t max_components; /* largest GMM K (0 if unused) */
+  int32_t device;      /* HIP device ordinal */
+} SdehPlanDesc;
+
+typedef struct SdehPlan SdehPlan;
+
+/* ABI version of the loaded library (== SDEH_ABI_VERSION it was built with). */
+int32_t sdeh_abi_version(void);
+/* Thread-local description of the last non-zero status. */
+const char* sdeh_last_error(void);
+
+/* Allocates the plan's device workspace (packed weights, per-step tables, estimator scratch).
+ * Replaces: nothing in the reference (loss objects are plain Python, losses/oc.py:13-48). */
+int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** plan);
+void sdeh_plan_destroy(SdehPlan* plan);
+
+/* Measurement hooks (reference analogue: the wall-clock `eval/sample_time`, solver/oc.py:88-97).  When enabled,
+ * every sdeh_simulate_fwd records HIP events immediately before and after the TRAJECTORY kernel on the stream
+ * it is launched on; sdeh_plan_last_kernel_ms waits for the stop event and returns the elapsed time. */
+int32_t sdeh_plan_set_timing(SdehPlan* plan, int32_t enable);
+int32_t sdeh_plan_last_kernel_ms(SdehPlan* plan, float* ms);
+
+/*
+ * The hot path.  Replaces {TimeReversalLoss,ReferenceSDELoss,ExponentialIntegratorSDELoss}.simulate
+ * (losses/oc.py:156-230, 286-343, 400-457) including, per step, generative_ctrl(t,x) (models/reparam.py,
+ * models/mlp.py), sde.diff/drift/drift_div_int (eq/sdes.py), target/prior scores (distr/...py), the Gaussian
+ * draw `torch.randn_like(x)` and the EM / exponential-integrator update; and at the end the terminal
+ * log-densities.
+ *
+ *   ts      [n_steps+1]           time grid (utils/common.py:18-55), device
+ *   x0      [batch, d]            initial states (prior.sample), device
+ *   noise   [n_steps, batch, d]   standard-normal draws to consume INSTEAD of the in-kernel generator
+ *                                 (parity mode: reproduces the reference on identical noise), or NULL:
+ *                                 in-kernel Philox4x32-10 + Box-Muller keyed by (seed, offset) and counted by
+ *                                 (row_offset + row, step, dim/4)  -> results do not depend on batch sharding.
+ *   row_offset                    global index of x0 row 0 (rank * local_batch for sharded runs)
+ *   x_T     [batch, d]   out      terminal states ("samples")
+ *   rnd     [batch]      out      log Radon-Nikodym derivative per trajectory (reference shape [B,1])
+ *   xs      [n_steps+1, batch, d] out or NULL: whole trajectory (return_traj=True)
+ */
+int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
+                          const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                          int64_t row_offset, float* x_T, float* rnd, float* xs, void* stream);
+
+/*
+ * Batch reductions of BaseOCLoss.compute_results / compute_loss (losses/oc.py:72-123), as mergeable partial
+ * statistics so that ranks can combine them with one tiny collective.
+ *   out[0] = n (rows with rnd < max_rnd, or finite rnd when max_rnd = +INF)   out[1] = sum(-rnd)
+ *   out[2] = M2 = sum((rnd-mean)^2)     out[3] = m = max(-rnd)
+ *   out[4] = sum(exp(-rnd-m))           out[5] = sum(exp(2(-rnd-m)))
+ *   out[6] = rows filtered out          out[7] = reserved
+ * Filtering (losses/oc.py:50-58): max_rnd = NaN keeps every row (evaluation), +INF keeps finite rows, a finite
+ * value keeps rows with rnd < max_rnd.  `out` is a device buffer of 8 floats; `scratch` a device buffer of
+ * SDEH_REDUCE_SCRATCH floats owned by the caller (no plan needed).
+ */
+#define SDEH_REDUCE_SCRATCH 8192
+int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, float* scratch, float* out,
+                               void* stream);
+
+/* importance weights exp(-rnd - m) (losses/oc.py:101-103) with a caller-provided global maximum m (device scalar). */
+int32_t sdeh_importance_weights(const float* rnd, int64_t batch, const float* log_weight_max, float* weights,
+                                void* stream);
+
+/* Philox4x32-10 known-answer hook used by the tests: fills out[4*n] with the generator's raw words for
+ * counters (row_offset+i, step, block, offset) and the (seed) key -- the exact stream sdeh_simulate_fwd consumes. */
+int32_t sdeh_debug_philox(uint64_t seed, uint64_t offset, int64_t row_offset, int32_t step, int32_t block,
+                          int64_t n, uint32_t* out, void* stream);
+/* Standard normals exactly as sdeh_simulate_fwd draws them: out[n, d] for one step. */
+int32_t sdeh_debug_normals(uint64_t seed, uint64_t offset, int64_t row_offset, int32_t step, int32_t dim,
+                           int64_t n, float* out, void* stream);
+/* The kernel's branch-free GELU (exact-erf form to fp32 rounding), elementwise on n values. */
+int32_t sdeh_debug_gelu(const float* in, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDEH_H_ */

@@ -1,0 +1,154 @@
+"""ctypes binding of libsdeh.so (the C ABI declared in include/sdeh.h).
+
+There is deliberately NO fallback here: if the HIP library is missing or fails to load, importing the loss
+classes still works (so that CPU-only tooling can introspect them) but the first call into the engine raises
+``SdehLibraryError``.  Nothing in this package imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+SDEH_ABI_VERSION = 1
+SDEH_MAX_HIDDEN = 8
+SDEH_REDUCE_SCRATCH = 8192
+
+# enums (include/sdeh.h)
+LOSS_TIME_REVERSAL, LOSS_REFERENCE_SDE, LOSS_EXPONENTIAL = 0, 1, 2
+CTRL_CLIPPED, CTRL_SCORE, CTRL_LERP, CTRL_LERP_TARGET, CTRL_LERP_PRIOR = 0, 1, 2, 3, 4
+SDE_NONE, SDE_VP, SDE_CONST_OU = 0, 1, 2
+DENS_NONE, DENS_GMM, DENS_DIAG_GAUSS, DENS_MULTI_WELL, DENS_FUNNEL = 0, 1, 2, 3, 4
+ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2
+FLAG_TRAIN, FLAG_ITO, FLAG_CHANGE_SDE_CTRL, FLAG_INIT_LOGP = 1, 2, 4, 8
+FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL = 16, 32, 64
+
+STATUS = {0: "SDEH_OK", -1: "SDEH_ERR_INVALID", -2: "SDEH_ERR_UNSUPPORTED", -3: "SDEH_ERR_HIP", -4: "SDEH_ERR_CAPACITY"}
+
+fp = C.c_void_p  # device pointers travel as integers
+
+
+class SdehDensity(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("dim", C.c_int32), ("n_components", C.c_int32), ("reserved", C.c_int32),
+        ("log_norm_const", C.c_float), ("p0", C.c_float), ("p1", C.c_float), ("p2", C.c_float),
+        ("loc", fp), ("scale", fp), ("mixture_weights", fp),
+    ]
+
+
+class SdehTimeEmbed(C.Structure):
+    _fields_ = [
+        ("channels", C.c_int32), ("n_hidden", C.c_int32), ("dim_out", C.c_int32), ("reserved", C.c_int32),
+        ("coeff", fp), ("phase", fp),
+        ("hidden_w", fp * SDEH_MAX_HIDDEN), ("hidden_b", fp * SDEH_MAX_HIDDEN),
+        ("out_w", fp), ("out_b", fp),
+    ]
+
+
+class SdehFourierMLP(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("channels", C.c_int32), ("n_hidden", C.c_int32), ("activation", C.c_int32),
+        ("input_w", fp), ("input_b", fp),
+        ("hidden_w", fp * SDEH_MAX_HIDDEN), ("hidden_b", fp * SDEH_MAX_HIDDEN),
+        ("out_w", fp), ("out_b", fp),
+        ("timestep_embed", SdehTimeEmbed),
+    ]
+
+
+class SdehProblem(C.Structure):
+    _fields_ = [
+        ("loss_kind", C.c_int32), ("ctrl_kind", C.c_int32), ("sde_kind", C.c_int32), ("flags", C.c_int32),
+        ("clip_model", C.c_float), ("clip_score", C.c_float), ("scale_score", C.c_float), ("clip_target", C.c_float),
+        ("terminal_t", C.c_float),
+        ("vp_beta_min", C.c_float), ("vp_beta_max", C.c_float), ("vp_scale", C.c_float),
+        ("ou_drift", C.c_float), ("ou_diff", C.c_float),
+        ("exp_alpha", C.c_float), ("exp_sigma", C.c_float),
+        ("base_model", SdehFourierMLP), ("score_model", SdehTimeEmbed),
+        ("target", SdehDensity), ("prior", SdehDensity), ("second", SdehDensity),
+    ]
+
+
+class SdehPlanDesc(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("channels", C.c_int32), ("max_hidden", C.c_int32), ("max_steps", C.c_int32),
+        ("max_components", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+class SdehLibraryError(RuntimeError):
+    """libsdeh.so is missing / not loadable / reports an ABI mismatch."""
+
+
+class SdehError(RuntimeError):
+    """A libsdeh call returned a negative status."""
+
+    def __init__(self, status: int, message: str):
+        self.status = status
+        super().__init__(f"{STATUS.get(status, status)}: {message}")
+
+
+class SdehUnsupported(SdehError, NotImplementedError):
+    """The configuration is valid in the reference but not built into the HIP engine."""
+
+
+# every symbol include/sdeh.h declares, with its prototype
+PROTOTYPES = {
+    "sdeh_abi_version": (C.c_int32, []),
+    "sdeh_last_error": (C.c_char_p, []),
+    "sdeh_plan_create": (C.c_int32, [C.POINTER(SdehPlanDesc), C.POINTER(C.c_void_p)]),
+    "sdeh_plan_destroy": (None, [C.c_void_p]),
+    "sdeh_plan_set_timing": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "sdeh_plan_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
+    "sdeh_simulate_fwd": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
+                                      C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, C.c_void_p]),
+    "sdeh_reduce_estimators": (C.c_int32, [fp, C.c_int64, C.c_float, fp, fp, C.c_void_p]),
+    "sdeh_importance_weights": (C.c_int32, [fp, C.c_int64, fp, fp, C.c_void_p]),
+    "sdeh_debug_philox": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, fp, C.c_void_p]),
+    "sdeh_debug_normals": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, fp, C.c_void_p]),
+    "sdeh_debug_gelu": (C.c_int32, [fp, C.c_int64, fp, C.c_void_p]),
+}
+
+_LIB = None
+
+
+def library_path() -> Path:
+    env = os.environ.get("SDEH_LIBRARY")
+    return Path(env) if env else Path(__file__).resolve().parent / "libsdeh.so"
+
+
+def load():
+    """Loads libsdeh.so once (after torch, so that it binds to the HIP runtime torch already loaded)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    import torch  # noqa: F401  (must come first: one HIP runtime per process)
+
+    path = library_path()
+    if not path.exists():
+        raise SdehLibraryError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C sde_sampler_amd/csrc`).  There is no CPU fallback for the trajectory engine.")
+    try:
+        lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL)
+    except OSError as exc:  # pragma: no cover
+        raise SdehLibraryError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise SdehLibraryError(f"{path} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sdeh_abi_version() != SDEH_ABI_VERSION:
+        raise SdehLibraryError(f"ABI mismatch: library {lib.sdeh_abi_version()} != binding {SDEH_ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(status: int):
+    if status == 0:
+        return
+    msg = load().sdeh_last_error().decode(errors="replace")
+    if status == -2:
+        raise SdehUnsupported(status, msg)
+    raise SdehError(status, msg)

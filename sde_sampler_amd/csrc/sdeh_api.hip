@@ -1,0 +1,311 @@
+// Host side of libsdeh.so: the extern "C" entry points of include/sdeh.h, plan/workspace management and the
+// dispatch onto the compiled trajectory-kernel variants.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "sdeh_common.hpp"
+
+namespace sdeh {
+
+// ---- launchers defined in other translation units --------------------------------------------------------
+int launch_prep(const PrepArgs& p, hipStream_t stream);
+int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int nb, float* out, hipStream_t stream);
+int launch_weights(const float* rnd, long long n, const float* mx, float* w, hipStream_t stream);
+
+#define SDEH_DECL(dp, pad) int launch_traj_dp##dp##_c64_p##pad(const TrajArgs& a, hipStream_t stream);
+#include "sdeh_variants.inc"
+#undef SDEH_DECL
+
+struct Variant {
+  int dp;
+  bool pad;
+  TrajLauncher fn;
+};
+static const Variant kVariants[] = {
+#define SDEH_DECL(dp, pad) {dp, pad != 0, &launch_traj_dp##dp##_c64_p##pad},
+#include "sdeh_variants.inc"
+#undef SDEH_DECL
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+static const Variant* pick_variant(int d) {
+  const Variant* best = nullptr;
+  for (const Variant& v : kVariants) {
+    if (!v.pad && v.dp == d) return &v;
+    if (v.pad && v.dp >= d && (best == nullptr || v.dp < best->dp)) best = &v;
+  }
+  return best;
+}
+
+static int align4(int v) { return (v + 3) & ~3; }
+
+// Workspace layout for one problem geometry.
+static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g) {
+  WsLayout L;
+  memset(&L, 0, sizeof(L));
+  L.dp = dp; L.c = c; L.ot = c / 32; L.otd = row_tiles(dp); L.r_in = mregs(dp);
+  L.n_hidden = n_hidden; L.t_max = t_max; L.k_max = k_max; L.g = g;
+  int o = 0;
+  L.w_in = o; o += L.r_in * L.ot * 64;
+  L.w_hid = o; L.w_hid_stride = (c / 2) * L.ot * 64; o += n_hidden * L.w_hid_stride;
+  L.w_out = o; o += (c / 2) * L.otd * 64;
+  L.b_hid = o; o += n_hidden * c;
+  L.b_out = o; o += L.otd * 32;
+  L.lds_floats = align4(o);
+  o = L.lds_floats;
+  L.coef = o; o += t_max * kCoefStride;
+  L.emb = o; o += t_max * c;
+  L.gam = o; o += align4(t_max * g);
+  L.gmm_lg = o; o += k_max * dp * 2;
+  L.gmm_sc = o; o += k_max * dp * 2;
+  L.gmm_c = o; o += align4(k_max);
+  for (int i = 0; i < 3; ++i) { L.dg[i] = o; o += align4(2 * dp + 1); }
+  L.total = align4(o);
+  return L;
+}
+
+}  // namespace sdeh
+
+using namespace sdeh;
+
+struct SdehPlan {
+  SdehPlanDesc desc;
+  int device;
+  const Variant* variant;
+  float* ws;          // workspace
+  size_t ws_floats;
+  bool timing;
+  bool timed;
+  hipEvent_t ev0, ev1;
+};
+static constexpr int kRedBlocks = SDEH_REDUCE_SCRATCH / 8;
+
+extern "C" {
+
+int32_t sdeh_abi_version(void) { return SDEH_ABI_VERSION; }
+const char* sdeh_last_error(void) { return g_err; }
+
+int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
+  if (desc == nullptr || out == nullptr) return fail(SDEH_ERR_INVALID, "plan_create: null argument");
+  *out = nullptr;
+  if (desc->dim < 1) return fail(SDEH_ERR_INVALID, "plan_create: dim=%d", desc->dim);
+  if (desc->channels != 64)
+    return fail(SDEH_ERR_UNSUPPORTED, "plan_create: channels=%d (this build compiles the trajectory kernel for C=64)",
+                desc->channels);
+  if (desc->max_hidden < 0 || desc->max_hidden > SDEH_MAX_HIDDEN)
+    return fail(SDEH_ERR_UNSUPPORTED, "plan_create: %d hidden layers (max %d)", desc->max_hidden, SDEH_MAX_HIDDEN);
+  if (desc->max_steps < 1) return fail(SDEH_ERR_INVALID, "plan_create: max_steps=%d", desc->max_steps);
+  const Variant* v = pick_variant(desc->dim);
+  if (v == nullptr) return fail(SDEH_ERR_UNSUPPORTED, "plan_create: no trajectory kernel compiled for dim=%d", desc->dim);
+  const int k_max = desc->max_components > 0 ? desc->max_components : 0;
+  WsLayout L = make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp);
+  const size_t lds_bytes = ((size_t)L.lds_floats + (size_t)k_max * 256) * sizeof(float);
+  if (lds_bytes > 160 * 1024)
+    return fail(SDEH_ERR_UNSUPPORTED, "plan_create: needs %zu B of LDS (> 160 KiB): hidden=%d K=%d", lds_bytes,
+                desc->max_hidden, k_max);
+  SdehPlan* p = new (std::nothrow) SdehPlan();
+  if (p == nullptr) return fail(SDEH_ERR_INVALID, "plan_create: out of host memory");
+  p->desc = *desc;
+  p->device = desc->device;
+  p->variant = v;
+  p->ws_floats = (size_t)L.total;
+  p->timing = p->timed = false;
+  p->ev0 = p->ev1 = nullptr;
+  int prev = 0;
+  hipError_t e = hipGetDevice(&prev);
+  if (e == hipSuccess) e = hipSetDevice(desc->device);
+  if (e == hipSuccess) e = hipMalloc((void**)&p->ws, p->ws_floats * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(p->ws, 0, p->ws_floats * sizeof(float));
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) {
+    const int rc = fail(SDEH_ERR_HIP, "plan_create: %s", hipGetErrorString(e));
+    if (p->ws) (void)hipFree(p->ws);
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return SDEH_OK;
+}
+
+int32_t sdeh_plan_set_timing(SdehPlan* plan, int32_t enable) {
+  if (plan == nullptr) return fail(SDEH_ERR_INVALID, "plan_set_timing: null plan");
+  if (enable && plan->ev0 == nullptr) {
+    if (hipEventCreate(&plan->ev0) != hipSuccess || hipEventCreate(&plan->ev1) != hipSuccess)
+      return fail(SDEH_ERR_HIP, "plan_set_timing: hipEventCreate failed");
+  }
+  plan->timing = enable != 0;
+  plan->timed = false;
+  return SDEH_OK;
+}
+
+int32_t sdeh_plan_last_kernel_ms(SdehPlan* plan, float* ms) {
+  if (plan == nullptr || ms == nullptr) return fail(SDEH_ERR_INVALID, "plan_last_kernel_ms: null argument");
+  if (!plan->timed) return fail(SDEH_ERR_INVALID, "plan_last_kernel_ms: no timed launch yet");
+  hipError_t e = hipEventSynchronize(plan->ev1);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms, plan->ev0, plan->ev1);
+  return e == hipSuccess ? SDEH_OK : fail(SDEH_ERR_HIP, "plan_last_kernel_ms: %s", hipGetErrorString(e));
+}
+
+void sdeh_plan_destroy(SdehPlan* plan) {
+  if (plan == nullptr) return;
+  if (plan->ev0) (void)hipEventDestroy(plan->ev0);
+  if (plan->ev1) (void)hipEventDestroy(plan->ev1);
+  if (plan->ws) (void)hipFree(plan->ws);
+  delete plan;
+}
+
+static int check_time_embed(const SdehTimeEmbed& te, int channels, const char* what) {
+  if (te.channels != channels) return fail(SDEH_ERR_UNSUPPORTED, "%s: channels=%d != %d", what, te.channels, channels);
+  if (te.n_hidden < 1 || te.n_hidden > SDEH_MAX_HIDDEN) return fail(SDEH_ERR_INVALID, "%s: n_hidden=%d", what, te.n_hidden);
+  if (te.coeff == nullptr || te.phase == nullptr || te.out_w == nullptr || te.out_b == nullptr)
+    return fail(SDEH_ERR_INVALID, "%s: null parameter pointer", what);
+  for (int i = 0; i < te.n_hidden; ++i)
+    if (te.hidden_w[i] == nullptr || te.hidden_b[i] == nullptr) return fail(SDEH_ERR_INVALID, "%s: null hidden layer %d", what, i);
+  return SDEH_OK;
+}
+
+static int check_density(const SdehDensity& D, int d, const char* what, bool allow_none) {
+  switch (D.kind) {
+    case SDEH_DENS_NONE:
+      return allow_none ? SDEH_OK : fail(SDEH_ERR_INVALID, "%s density missing", what);
+    case SDEH_DENS_GMM:
+      if (D.loc == nullptr || D.scale == nullptr || D.n_components < 1) return fail(SDEH_ERR_INVALID, "%s: bad GMM", what);
+      break;
+    case SDEH_DENS_DIAG_GAUSS:
+      if (D.loc == nullptr || D.scale == nullptr) return fail(SDEH_ERR_INVALID, "%s: bad Gaussian", what);
+      break;
+    case SDEH_DENS_MULTI_WELL:
+      if (D.n_components < 1 || D.n_components > d) return fail(SDEH_ERR_INVALID, "%s: n_double_wells=%d", what, D.n_components);
+      break;
+    case SDEH_DENS_FUNNEL:
+      if (!(D.p0 > 0.0f) || d < 2) return fail(SDEH_ERR_INVALID, "%s: bad funnel", what);
+      break;
+    default:
+      return fail(SDEH_ERR_INVALID, "%s: unknown density kind %d", what, D.kind);
+  }
+  if (D.dim != d) return fail(SDEH_ERR_INVALID, "%s: dim=%d != %d", what, D.dim, d);
+  return SDEH_OK;
+}
+
+int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                          float* x_T, float* rnd, float* xs, void* stream) {
+  if (plan == nullptr || pr == nullptr || ts == nullptr || x0 == nullptr || x_T == nullptr || rnd == nullptr)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
+  if (batch < 1 || n_steps < 1) return fail(SDEH_ERR_INVALID, "simulate_fwd: batch=%lld n_steps=%d", (long long)batch, n_steps);
+  const SdehFourierMLP& net = pr->base_model;
+  const int d = net.dim;
+  if (d != plan->desc.dim || net.channels != plan->desc.channels)
+    return fail(SDEH_ERR_CAPACITY, "simulate_fwd: dim/channels (%d,%d) differ from the plan's (%d,%d)", d, net.channels,
+                plan->desc.dim, plan->desc.channels);
+  if (net.n_hidden < 0 || net.n_hidden > plan->desc.max_hidden)
+    return fail(SDEH_ERR_CAPACITY, "simulate_fwd: %d hidden layers > plan max %d", net.n_hidden, plan->desc.max_hidden);
+  if (n_steps > plan->desc.max_steps)
+    return fail(SDEH_ERR_CAPACITY, "simulate_fwd: %d steps > plan max %d", n_steps, plan->desc.max_steps);
+  if (net.activation < SDEH_ACT_GELU_ERF || net.activation > SDEH_ACT_RELU)
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd: activation %d", net.activation);
+  if (net.input_w == nullptr || net.input_b == nullptr || net.out_w == nullptr || net.out_b == nullptr)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd: null base_model parameter");
+  for (int i = 0; i < net.n_hidden; ++i)
+    if (net.hidden_w[i] == nullptr || net.hidden_b[i] == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null hidden layer %d", i);
+  int rc = check_time_embed(net.timestep_embed, net.channels, "base_model.timestep_embed");
+  if (rc != SDEH_OK) return rc;
+  if (net.timestep_embed.dim_out != net.channels) return fail(SDEH_ERR_INVALID, "timestep_embed.dim_out != channels");
+  if (pr->loss_kind < SDEH_LOSS_TIME_REVERSAL || pr->loss_kind > SDEH_LOSS_EXPONENTIAL)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd: loss_kind %d", pr->loss_kind);
+  if (pr->ctrl_kind < SDEH_CTRL_CLIPPED || pr->ctrl_kind > SDEH_CTRL_LERP_PRIOR)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd: ctrl_kind %d", pr->ctrl_kind);
+  if (pr->loss_kind != SDEH_LOSS_EXPONENTIAL && pr->sde_kind == SDEH_SDE_NONE)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd: loss kind %d needs an sde", pr->loss_kind);
+  const bool lerp_family = pr->ctrl_kind >= SDEH_CTRL_LERP;
+  if (lerp_family && pr->sde_kind == SDEH_SDE_NONE) return fail(SDEH_ERR_INVALID, "simulate_fwd: Lerp controls need an sde");
+  int g = 1;
+  if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && pr->score_model.n_hidden > 0) {
+    rc = check_time_embed(pr->score_model, net.channels, "score_model");
+    if (rc != SDEH_OK) return rc;
+    if (pr->score_model.dim_out != 1 && pr->score_model.dim_out != d)
+      return fail(SDEH_ERR_UNSUPPORTED, "score_model.dim_out=%d (1 or dim supported)", pr->score_model.dim_out);
+    g = pr->score_model.dim_out == 1 ? 1 : plan->variant->dp;
+  }
+  const bool need_target_score = pr->ctrl_kind == SDEH_CTRL_SCORE || pr->ctrl_kind == SDEH_CTRL_LERP ||
+                                 pr->ctrl_kind == SDEH_CTRL_LERP_TARGET;
+  const bool need_target = need_target_score || (pr->flags & SDEH_FLAG_TERMINAL_TARGET);
+  rc = check_density(pr->target, d, "target", !need_target);
+  if (rc != SDEH_OK) return rc;
+  const bool refc = (pr->flags & SDEH_FLAG_REFERENCE_CTRL) && pr->loss_kind == SDEH_LOSS_REFERENCE_SDE;
+  const bool need_prior = pr->ctrl_kind == SDEH_CTRL_LERP || pr->ctrl_kind == SDEH_CTRL_LERP_PRIOR || refc;
+  if (need_prior && pr->prior.kind != SDEH_DENS_DIAG_GAUSS)
+    return fail(SDEH_ERR_UNSUPPORTED, "prior score: only Gaussian priors are built in (kind %d)", pr->prior.kind);
+  rc = check_density(pr->prior, d, "prior", true);
+  if (rc != SDEH_OK) return rc;
+  const bool need_second = pr->flags & (SDEH_FLAG_INIT_LOGP | SDEH_FLAG_TERMINAL_SECOND);
+  if (need_second && pr->second.kind != SDEH_DENS_DIAG_GAUSS)
+    return fail(SDEH_ERR_UNSUPPORTED, "initial/reference log-density: only Gaussians are built in (kind %d)", pr->second.kind);
+  rc = check_density(pr->second, d, "second", true);
+  if (rc != SDEH_OK) return rc;
+  const int k = pr->target.kind == SDEH_DENS_GMM ? pr->target.n_components : 0;
+  if (k > plan->desc.max_components)
+    return fail(SDEH_ERR_CAPACITY, "simulate_fwd: GMM with %d components > plan max %d", k, plan->desc.max_components);
+
+  const Variant* v = plan->variant;
+  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g);
+  if ((size_t)L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd: workspace too small");
+
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws;
+  P.lay = L;
+  P.prob = *pr;
+  P.ts = ts;
+  P.n_steps = n_steps;
+  rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "simulate_fwd: prep kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+
+  TrajArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = L;
+  A.x0 = x0; A.noise = noise; A.xT = x_T; A.rnd = rnd; A.xs = xs;
+  A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d;
+  A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = net.activation;
+  A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
+  A.clip_target = pr->clip_target; A.exp_sigma = pr->exp_sigma;
+  A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
+  A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
+  A.second = {pr->second.kind, pr->second.n_components, pr->second.log_norm_const, pr->second.p0, pr->second.p1};
+  A.seed = seed; A.offset = offset;
+  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  rc = v->fn(A, st);
+  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  if (rc != SDEH_OK) return fail(rc, "simulate_fwd: trajectory kernel launch failed (dp=%d)", v->dp);
+  return SDEH_OK;
+}
+
+int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, float* scratch, float* out, void* stream) {
+  if (rnd == nullptr || out == nullptr || scratch == nullptr || batch < 1)
+    return fail(SDEH_ERR_INVALID, "reduce_estimators: bad argument");
+  long long nb = (batch + 255) / 256;
+  if (nb > kRedBlocks) nb = kRedBlocks;
+  const int rc = launch_reduce(rnd, batch, max_rnd, scratch, (int)nb, out, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "reduce_estimators: launch failed");
+}
+
+int32_t sdeh_importance_weights(const float* rnd, int64_t batch, const float* log_weight_max, float* weights,
+                                void* stream) {
+  if (rnd == nullptr || log_weight_max == nullptr || weights == nullptr || batch < 1)
+    return fail(SDEH_ERR_INVALID, "importance_weights: bad argument");
+  const int rc = launch_weights(rnd, batch, log_weight_max, weights, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "importance_weights: launch failed");
+}
+
+}  // extern "C"

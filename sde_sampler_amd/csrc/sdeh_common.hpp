@@ -1,0 +1,121 @@
+// Internal (non-ABI) definitions shared by the prep kernel, the trajectory kernels and the host dispatcher.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sdeh.h"
+
+namespace sdeh {
+
+// ---------------------------------------------------------------------------------------------------------
+// MFMA register geometry.
+//
+// A wavefront owns 64 trajectories.  Elementwise / per-trajectory work runs in the "T layout": lane l holds
+// every coordinate of trajectory l.  The dense layers run on v_mfma_f32_32x32x2_f32 in the "M layout": the
+// wave's 64 trajectories form two 32-column tiles (A: trajectories 0..31, B: 32..63) and lane (j = l&31,
+// h = l>>5) holds, for column j of each tile, the rows  rho(q,h) = (q&3) + 8*(q>>2) + 4*h  (q = accumulator
+// register 0..15) of every 32-row tile -- the C/D fragment map of the 32x32 MFMA.  Because the B-operand map
+// (k = l>>5, column = l&31) is the same as one accumulator register of the D map, a layer's activated output
+// registers feed the next layer's MFMAs directly (the k order of the dot product is permuted, which the
+// packed weight image accounts for).  T <-> M conversion is one v_permlane32_swap per register pair.
+// ---------------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int rho(int q, int h) { return (q & 3) + 8 * (q >> 2) + 4 * h; }
+// coordinate held by M-layout register r (r counts across 32-row tiles) in lane half h
+__host__ __device__ constexpr int mdim(int r, int h) { return 32 * (r / 16) + rho(r % 16, h); }
+__host__ __device__ constexpr int row_tiles(int n) { return (n + 31) / 32; }
+// number of M-layout registers needed to cover coordinates [0, n)
+__host__ __device__ constexpr int mregs(int n) {
+  int c = 0;
+  for (int r = 0; r < 16 * row_tiles(n); ++r)
+    if (mdim(r, 0) < n) ++c;
+  return c;
+}
+
+constexpr int kCoefStride = 16;
+enum CoefSlot {
+  CF_S = 0, CF_T = 1, CF_DT = 2, CF_SQDT = 3, CF_SIGMA = 4, CF_DRIFT = 5, CF_DDIV = 6, CF_W = 7,
+  CF_BETAK = 8, CF_ALPHAK = 9, CF_B2S2 = 10, CF_SBK = 11
+};
+
+// Workspace layout (float offsets from the plan's workspace base).  The first `lds_floats` floats are the
+// "LDS image": every workgroup copies them verbatim into LDS.
+struct WsLayout {
+  int dp, c, ot, otd, r_in, n_hidden, t_max, k_max, g;  // geometry (g = gamma row length: 1 or dp)
+  int lds_floats;
+  int w_in;       // [r_in][ot][64]
+  int w_hid;      // n_hidden x [c/2][ot][64]
+  int w_hid_stride;
+  int w_out;      // [c/2][otd][64]
+  int b_hid;      // n_hidden x [c]   (M order)
+  int b_out;      // [otd*32]         (M order)
+  // global tables
+  int coef;       // [T][16]
+  int emb;        // [T][c]  (M order; FourierMLP.timestep_embed(t) + input_embed.bias)
+  int gam;        // [T][g]  clip(score_model(t), clip_model)
+  int gmm_lg;     // [K][dp][2]  (mu, 1/(2 sigma^2))
+  int gmm_sc;     // [K][dp][2]  (mu/sigma^2, 1/sigma^2)
+  int gmm_c;      // [K]  log_softmax(log w)_k - sum_d (log sigma_kd + 0.5 log 2pi)
+  int dg[3];      // diag-gauss tables for target / prior / second: [dp][2] (mu, 1/sigma^2) then 1 float const
+  int total;
+};
+
+struct DensArgs {
+  int kind, n_comp;
+  float lnc, p0, p1;
+};
+
+struct TrajArgs {
+  const float* ws;
+  WsLayout lay;
+  const float* x0;
+  const float* noise;
+  float* xT;
+  float* rnd;
+  float* xs;
+  long long batch;
+  long long row_offset;
+  int n_steps, d;
+  int loss_kind, ctrl_kind, flags, act;
+  float clip_model, clip_score, scale_score, clip_target;
+  float exp_sigma;
+  DensArgs target, prior, second;
+  unsigned long long seed, offset;
+};
+
+struct PrepArgs {
+  float* ws;
+  WsLayout lay;
+  SdehProblem prob;  // by value: holds the device pointers of all parameters
+  const float* ts;
+  int n_steps;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11).  Key = 64-bit seed; counter = (row, step, block, offset).
+// ---------------------------------------------------------------------------------------------------------
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+__host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c.x;
+    const uint64_t p1 = (uint64_t)M1 * c.z;
+    U4 n;
+    n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+    n.y = (uint32_t)p1;
+    n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.w = (uint32_t)p0;
+    c = n;
+    k0 += W0;
+    k1 += W1;
+  }
+  return c;
+}
+
+// launchers implemented in the per-DP translation units (sdeh_traj_inst.hip)
+typedef int (*TrajLauncher)(const TrajArgs& a, hipStream_t stream);
+
+}  // namespace sdeh

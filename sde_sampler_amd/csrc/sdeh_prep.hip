@@ -1,0 +1,302 @@
+// Per-call preparation kernel: everything that depends on time only (or on parameters only) is computed once
+// per simulate() call for all T steps, so the trajectory kernel's inner loop reads small tables:
+//   * per-step scalar coefficients of the SDE / exponential integrator   (eq/sdes.py, losses/oc.py:428-431)
+//   * FourierMLP.timestep_embed(t) + input_embed.bias for every step      (models/mlp.py:71-82,115-119)
+//   * gamma(t) = clip(score_model(t), clip_model) for every step          (models/reparam.py:68-76)
+//   * the packed MFMA-operand image of the network weights (LDS image), GMM / Gaussian parameter tables
+// The reference recomputes the time embedding for B identical rows at every step (~1/3 of its MLP time).
+#include "sdeh_common.hpp"
+
+namespace sdeh {
+
+__device__ __forceinline__ float actf(float v, int act) {
+  if (act == SDEH_ACT_GELU_ERF) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  if (act == SDEH_ACT_SILU) return v / (1.0f + expf(-v));
+  return fmaxf(v, 0.0f);
+}
+
+__device__ __forceinline__ int morder(int c) {  // channel -> index in the M-layout ordering
+  const int ot = c >> 5, rr = c & 31;
+  const int h = (rr >> 2) & 1, q = (rr & 3) + 4 * (rr >> 3);
+  return (ot * 2 + h) * 16 + q;
+}
+
+// torch.lerp(a, b, w): a + w (b - a) for w < 0.5, else b - (b - a)(1 - w)
+__device__ __forceinline__ float lerpf(float a, float b, float w) {
+  const float diff = b - a;
+  return w < 0.5f ? a + w * diff : b - diff * (1.0f - w);
+}
+
+// TimeEmbed.forward for one scalar t, computed cooperatively by the block (models/mlp.py:71-82).
+// Result (dim_out values) is left in `res` (shared).  sh_in: 2C, sh_a/sh_b: C floats.
+__device__ void time_embed_block(const SdehTimeEmbed& te, int act, float t, float* sh_in, float* sh_a, float* sh_b,
+                                 float* res) {
+  const int C = te.channels, tid = threadIdx.x, nt = blockDim.x;
+  for (int c = tid; c < C; c += nt) {
+    const float arg = te.coeff[c] * t + te.phase[c];
+    sh_in[c] = sinf(arg);
+    sh_in[C + c] = cosf(arg);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += nt) {
+    const float* w = te.hidden_w[0] + (size_t)c * 2 * C;
+    float acc = 0.0f;
+    for (int k = 0; k < 2 * C; ++k) acc = fmaf(w[k], sh_in[k], acc);
+    sh_a[c] = actf(acc + te.hidden_b[0][c], act);
+  }
+  __syncthreads();
+  float* cur = sh_a;
+  float* nxt = sh_b;
+  for (int l = 1; l < te.n_hidden; ++l) {
+    for (int c = tid; c < C; c += nt) {
+      const float* w = te.hidden_w[l] + (size_t)c * C;
+      float acc = 0.0f;
+      for (int k = 0; k < C; ++k) acc = fmaf(w[k], cur[k], acc);
+      nxt[c] = actf(acc + te.hidden_b[l][c], act);
+    }
+    __syncthreads();
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  for (int o = tid; o < te.dim_out; o += nt) {
+    const float* w = te.out_w + (size_t)o * C;
+    float acc = 0.0f;
+    for (int k = 0; k < C; ++k) acc = fmaf(w[k], cur[k], acc);
+    res[o] = acc + te.out_b[o];
+  }
+  __syncthreads();
+}
+
+__device__ void pack_diag_gauss(float* tab, const SdehDensity& D, int dp, int gid, int stride) {
+  if (D.kind != SDEH_DENS_DIAG_GAUSS) return;
+  for (int j = gid; j < dp; j += stride) {
+    const bool ok = j < D.dim;
+    const float s = ok ? D.scale[j] : 1.0f;
+    tab[2 * j] = ok ? D.loc[j] : 0.0f;
+    tab[2 * j + 1] = ok ? 1.0f / (s * s) : 0.0f;
+  }
+  if (gid == 0) {
+    float c = 0.0f;
+    for (int j = 0; j < D.dim; ++j) c += -logf(D.scale[j]) - 0.91893853320467274178f;
+    tab[2 * dp] = c;
+  }
+}
+
+constexpr int kPackBlocks = 32;
+
+__global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
+  __shared__ float sh_in[512], sh_a[256], sh_b[256], sh_res[256];
+  const WsLayout& L = P.lay;
+  const SdehProblem& pr = P.prob;
+  float* ws = P.ws;
+  const int tid = threadIdx.x;
+  const int T = P.n_steps;
+
+  if ((int)blockIdx.x < T) {
+    // ----------------------------------------------------------------- per-step tables for step i
+    const int i = blockIdx.x;
+    const float s = P.ts[i], t = P.ts[i + 1];
+    if (tid == 0) {
+      float* cf = ws + L.coef + i * kCoefStride;
+      const float dt = t - s;
+      float sigma = 0.0f, drift = 0.0f, ddiv = 0.0f, w = 0.0f;
+      if (pr.sde_kind == SDEH_SDE_VP) {  // eq/sdes.py:222-245 (generative: lerp(max, min, t/T), sign +1)
+        const float bs = lerpf(pr.vp_beta_max, pr.vp_beta_min, s / pr.terminal_t);
+        const float bt = lerpf(pr.vp_beta_max, pr.vp_beta_min, t / pr.terminal_t);
+        sigma = pr.vp_scale * sqrtf(bs);
+        drift = 0.5f * bs;
+        ddiv = 0.25f * (bt + bs) * dt * (float)pr.base_model.dim;
+      } else if (pr.sde_kind == SDEH_SDE_CONST_OU) {  // eq/sdes.py:141-155
+        sigma = pr.ou_diff;
+        drift = pr.ou_drift;
+        ddiv = pr.ou_drift * dt * (float)pr.base_model.dim;
+      }
+      if (pr.sde_kind != SDEH_SDE_NONE) w = s / pr.terminal_t;
+      const float bk = fminf(fmaxf(pr.exp_alpha * sqrtf(dt), 0.0f), 1.0f);  // losses/oc.py:429-430
+      cf[CF_S] = s; cf[CF_T] = t; cf[CF_DT] = dt; cf[CF_SQDT] = sqrtf(dt);
+      cf[CF_SIGMA] = sigma; cf[CF_DRIFT] = drift; cf[CF_DDIV] = ddiv; cf[CF_W] = w;
+      cf[CF_BETAK] = bk; cf[CF_ALPHAK] = sqrtf(1.0f - bk * bk);
+      cf[CF_B2S2] = bk * bk * (pr.exp_sigma * pr.exp_sigma);
+      cf[CF_SBK] = pr.exp_sigma * bk;
+      for (int k = 12; k < kCoefStride; ++k) cf[k] = 0.0f;
+    }
+    const int act = pr.base_model.activation;
+    // FourierMLP.timestep_embed(s) + input_embed.bias, stored in M order
+    time_embed_block(pr.base_model.timestep_embed, act, s, sh_in, sh_a, sh_b, sh_res);
+    for (int c = tid; c < L.c; c += blockDim.x)
+      ws[L.emb + i * L.c + morder(c)] = sh_res[c] + pr.base_model.input_b[c];
+    __syncthreads();
+    // gamma(s)
+    if (pr.ctrl_kind != SDEH_CTRL_CLIPPED) {
+      if (pr.score_model.n_hidden > 0) {
+        time_embed_block(pr.score_model, act, s, sh_in, sh_a, sh_b, sh_res);
+        for (int o = tid; o < L.g; o += blockDim.x) {
+          float v = o < pr.score_model.dim_out ? sh_res[o] : 0.0f;
+          v = fminf(fmaxf(v, -pr.clip_model), pr.clip_model);
+          ws[L.gam + i * L.g + o] = v;
+        }
+      } else {
+        for (int o = tid; o < L.g; o += blockDim.x) ws[L.gam + i * L.g + o] = 1.0f;  // score_model=None
+      }
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------- parameter packing
+  const int gid = ((int)blockIdx.x - T) * 256 + tid;
+  const int stride = kPackBlocks * 256;
+  const SdehFourierMLP& net = pr.base_model;
+  const int d = net.dim, C = L.c, OT = L.ot, OTD = L.otd;
+
+  for (int e = gid; e < L.r_in * OT * 64; e += stride) {  // input_embed.weight [C, d]
+    const int lane = e & 63, ot = (e >> 6) % OT, r = (e >> 6) / OT;
+    const int dimidx = mdim(r, lane >> 5);
+    ws[L.w_in + e] = dimidx < d ? net.input_w[(size_t)(32 * ot + (lane & 31)) * d + dimidx] : 0.0f;
+  }
+  for (int l = 0; l < L.n_hidden; ++l) {  // hidden_layer[l].weight [C, C]
+    for (int e = gid; e < (C / 2) * OT * 64; e += stride) {
+      const int lane = e & 63, ot = (e >> 6) % OT, sidx = (e >> 6) / OT;
+      const int chan = mdim(sidx, lane >> 5);
+      ws[L.w_hid + l * L.w_hid_stride + e] = net.hidden_w[l][(size_t)(32 * ot + (lane & 31)) * C + chan];
+    }
+    for (int c = gid; c < C; c += stride) ws[L.b_hid + l * C + morder(c)] = net.hidden_b[l][c];
+  }
+  for (int e = gid; e < (C / 2) * OTD * 64; e += stride) {  // out_layer.weight [d, C]
+    const int lane = e & 63, t = (e >> 6) % OTD, sidx = (e >> 6) / OTD;
+    const int chan = mdim(sidx, lane >> 5);
+    const int row = 32 * t + (lane & 31);
+    ws[L.w_out + e] = row < d ? net.out_w[(size_t)row * C + chan] : 0.0f;
+  }
+  for (int c = gid; c < OTD * 32; c += stride) ws[L.b_out + morder(c)] = c < d ? net.out_b[c] : 0.0f;
+
+  // GMM tables (distr/gauss.py:123-135 via torch.distributions.MixtureSameFamily)
+  if (pr.target.kind == SDEH_DENS_GMM) {
+    const SdehDensity& G = pr.target;
+    const int K = G.n_components, dp = L.dp;
+    for (int e = gid; e < K * dp; e += stride) {
+      const int k = e / dp, j = e % dp;
+      const bool ok = j < G.dim;
+      const float mu = ok ? G.loc[(size_t)k * G.dim + j] : 0.0f;
+      const float sg = ok ? G.scale[(size_t)k * G.dim + j] : 1.0f;
+      const float iv = ok ? 1.0f / (sg * sg) : 0.0f;
+      ws[L.gmm_lg + 2 * e] = mu;
+      ws[L.gmm_lg + 2 * e + 1] = 0.5f * iv;
+      ws[L.gmm_sc + 2 * e] = mu * iv;
+      ws[L.gmm_sc + 2 * e + 1] = iv;
+    }
+    for (int k = gid; k < K; k += stride) {
+      float wsum = 0.0f;
+      if (G.mixture_weights != nullptr)
+        for (int q = 0; q < K; ++q) wsum += G.mixture_weights[q];
+      float c = G.mixture_weights != nullptr ? logf(G.mixture_weights[k]) - logf(wsum) : 0.0f;
+      for (int j = 0; j < G.dim; ++j) c -= logf(G.scale[(size_t)k * G.dim + j]) + 0.91893853320467274178f;
+      ws[L.gmm_c + k] = c;
+    }
+  }
+  pack_diag_gauss(ws + L.dg[0], pr.target, L.dp, gid, stride);
+  pack_diag_gauss(ws + L.dg[1], pr.prior, L.dp, gid, stride);
+  pack_diag_gauss(ws + L.dg[2], pr.second, L.dp, gid, stride);
+}
+
+int launch_prep(const PrepArgs& p, hipStream_t stream) {
+  hipLaunchKernelGGL(prep_kernel, dim3(p.n_steps + kPackBlocks), dim3(256), 0, stream, p);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// estimator partial statistics (losses/oc.py:72-123), mergeable across blocks and across ranks
+// ---------------------------------------------------------------------------------------------------------
+struct Stat {
+  float n, mean, m2, mx, s1, s2, nf;
+};
+
+__device__ __forceinline__ Stat stat_merge(const Stat& a, const Stat& b) {
+  if (b.n == 0.0f) { Stat r = a; r.nf = a.nf + b.nf; return r; }
+  if (a.n == 0.0f) { Stat r = b; r.nf = a.nf + b.nf; return r; }
+  Stat r;
+  r.n = a.n + b.n;
+  const float delta = b.mean - a.mean;
+  r.mean = a.mean + delta * (b.n / r.n);
+  r.m2 = a.m2 + b.m2 + delta * delta * (a.n * b.n / r.n);
+  r.mx = fmaxf(a.mx, b.mx);
+  const float ea = expf(a.mx - r.mx), eb = expf(b.mx - r.mx);
+  r.s1 = a.s1 * ea + b.s1 * eb;
+  r.s2 = a.s2 * ea * ea + b.s2 * eb * eb;
+  r.nf = a.nf + b.nf;
+  return r;
+}
+
+__device__ __forceinline__ Stat stat_shfl_xor(const Stat& a, int mask) {
+  Stat r;
+  r.n = __shfl_xor(a.n, mask); r.mean = __shfl_xor(a.mean, mask); r.m2 = __shfl_xor(a.m2, mask);
+  r.mx = __shfl_xor(a.mx, mask); r.s1 = __shfl_xor(a.s1, mask); r.s2 = __shfl_xor(a.s2, mask);
+  r.nf = __shfl_xor(a.nf, mask);
+  return r;
+}
+
+__device__ Stat block_reduce(Stat v) {
+  __shared__ Stat sh[4];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = stat_merge(v, stat_shfl_xor(v, m));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  Stat r = sh[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = stat_merge(r, sh[w]);
+  return r;
+}
+
+// the values here are of `rnd` (mean, m2) and of `-rnd` (mx, s1, s2)
+__global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __restrict__ rnd, long long n,
+                                                             float max_rnd, float* __restrict__ part) {
+  Stat v = {0.f, 0.f, 0.f, -INFINITY, 0.f, 0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float r = rnd[i];
+    bool keep = true;
+    if (!isnan(max_rnd)) keep = isinf(max_rnd) ? isfinite(r) : (r < max_rnd);
+    Stat o;
+    if (keep) o = {1.f, r, 0.f, -r, 1.f, 1.f, 0.f};
+    else o = {0.f, 0.f, 0.f, -INFINITY, 0.f, 0.f, 1.f};
+    v = stat_merge(v, o);
+  }
+  v = block_reduce(v);
+  if (threadIdx.x == 0) {
+    float* p = part + (size_t)blockIdx.x * 8;
+    p[0] = v.n; p[1] = v.mean; p[2] = v.m2; p[3] = v.mx; p[4] = v.s1; p[5] = v.s2; p[6] = v.nf; p[7] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_final_kernel(const float* __restrict__ part, int nb,
+                                                           float* __restrict__ out) {
+  Stat v = {0.f, 0.f, 0.f, -INFINITY, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    const float* p = part + (size_t)i * 8;
+    Stat o = {p[0], p[1], p[2], p[3], p[4], p[5], p[6]};
+    v = stat_merge(v, o);
+  }
+  v = block_reduce(v);
+  if (threadIdx.x == 0) {
+    out[0] = v.n; out[1] = -v.mean * v.n; out[2] = v.m2; out[3] = v.mx;
+    out[4] = v.s1; out[5] = v.s2; out[6] = v.nf; out[7] = 0.f;
+  }
+}
+
+int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int nb, float* out,
+                  hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_partial_kernel, dim3(nb), dim3(256), 0, stream, rnd, n, max_rnd, part);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, stream, part, nb, out);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+__global__ __launch_bounds__(256) void weights_kernel(const float* __restrict__ rnd, long long n,
+                                                      const float* __restrict__ mx, float* __restrict__ w) {
+  const float m = mx[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    w[i] = expf(-rnd[i] - m);
+}
+
+int launch_weights(const float* rnd, long long n, const float* mx, float* w, hipStream_t stream) {
+  const int nb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(weights_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, stream, rnd, n, mx, w);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+}  // namespace sdeh

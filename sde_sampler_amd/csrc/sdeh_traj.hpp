@@ -1,0 +1,576 @@
+// Persistent Euler-Maruyama trajectory kernel for gfx950 (MI355X).
+//
+// One launch integrates all T steps: each wavefront owns 64 trajectories whose state x[d], running cost rnd
+// and MLP activations never leave registers; the packed network weights sit in LDS for the whole launch;
+// HBM traffic is x0 in, x_T + rnd out (plus noise in parity mode / xs when the trajectory is requested).
+//
+// Replaces the per-step Python loops of the reference (losses/oc.py:176-222, 301-334, 416-446) together with
+// everything they call per step (models/reparam.py forward, models/mlp.py:114-122, eq/sdes.py coefficient
+// functions, distr/*.py scores, torch.randn_like) and the terminal log-densities (oc.py:225,337,449-450).
+#pragma once
+#include "sdeh_common.hpp"
+
+namespace sdeh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Tables that are uniform across the wave are read through the constant address space so that hipcc emits
+// scalar loads (s_load_dwordx*) and feeds them to the VALU as SGPR operands.
+typedef const float __attribute__((address_space(4))) * cfp;
+struct alignas(8) F2 {
+  float x, y;
+};
+typedef const F2 __attribute__((address_space(4))) * cf2p;
+__device__ __forceinline__ cfp as_const(const float* p) { return (cfp)(unsigned long long)p; }
+__device__ __forceinline__ cf2p as_const2(const float* p) { return (cf2p)(unsigned long long)p; }
+
+__device__ __forceinline__ void swap32(float& a, float& b) {
+  // lanes 32..63 of `a` <-> lanes 0..31 of `b`
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float clipf(float v, float m) { return fminf(fmaxf(v, -m), m); }
+
+// GELU(v) = v * Phi(v) with Phi(v) = 0.5 erfc(-v/sqrt2).  Branch-free: erfc(z) = 2^-q(z) for z >= 0 with q a
+// degree-10 polynomial fit of -log2 erfc on [0, 6] (max |error| of GELU vs the exact erf form ~1e-7 |v|, i.e.
+// fp32 rounding level; checked by tests/test_hip_parity.py::test_gelu_accuracy).
+__device__ __forceinline__ float act_gelu(float v) {
+  const float z = fminf(fabsf(v) * 0.70710678118654752440f, 6.0f);
+  float p = 6.603050149e-07f;
+  p = fmaf(p, z, -1.530170759e-05f);
+  p = fmaf(p, z, 1.480139295e-04f);
+  p = fmaf(p, z, -7.626767611e-04f);
+  p = fmaf(p, z, 2.001933838e-03f);
+  p = fmaf(p, z, 3.411742314e-04f);
+  p = fmaf(p, z, -2.809073479e-02f);
+  p = fmaf(p, z, 1.484803495e-01f);
+  p = fmaf(p, z, 9.184024644e-01f);
+  p = fmaf(p, z, 1.627910815e+00f);
+  const float e = __builtin_amdgcn_exp2f(fmaf(-p, z, -1.0f));  // 0.5 erfc(z)
+  return v * (v < 0.0f ? e : 1.0f - e);
+}
+__device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float act_relu(float v) { return fmaxf(v, 0.0f); }
+
+template <int N>
+__device__ __forceinline__ void activate(f32x16 (&a)[N], f32x16 (&b)[N], int act) {
+  if (act == SDEH_ACT_GELU_ERF) {
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { a[t][q] = act_gelu(a[t][q]); b[t][q] = act_gelu(b[t][q]); }
+  } else if (act == SDEH_ACT_SILU) {
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { a[t][q] = act_silu(a[t][q]); b[t][q] = act_silu(b[t][q]); }
+  } else {
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { a[t][q] = act_relu(a[t][q]); b[t][q] = act_relu(b[t][q]); }
+  }
+}
+
+__device__ __forceinline__ f32x16 load16(const float* p) {
+  f32x16 v;
+  const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float4 t = p4[i];
+    v[4 * i + 0] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+  }
+  return v;
+}
+
+#define SDEH_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// Scheduling fence: keeps hipcc from hoisting every LDS weight read of an unrolled layer to its top (which
+// made >500 registers live and spilled to scratch).  In-order issue still overlaps the next group's ds_reads
+// with the MFMAs already queued on the matrix pipe.
+#define SDEH_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// ---------------------------------------------------------------------------------------------------------
+// FourierMLP forward for 64 trajectories (models/mlp.py:114-122).  x, out in the T layout.
+// ---------------------------------------------------------------------------------------------------------
+template <int DP, int C>
+__device__ __forceinline__ void mlp_forward(const float* __restrict__ lds, const WsLayout& L, int act,
+                                            const float* __restrict__ emb_step, const float (&x)[DP],
+                                            float (&out)[DP], int lane) {
+  constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
+  const int h = lane >> 5;
+  f32x16 accA[OT], accB[OT];
+  // e = input_embed(x) + timestep_embed(t): start the accumulators at (time embedding + input bias)
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) accA[ot] = accB[ot] = load16(emb_step + (ot * 2 + h) * 16);
+  {
+    float xa[R], xb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float v0 = x[mdim(r, 0)];
+      float v1 = mdim(r, 1) < DP ? x[mdim(r, 1)] : 0.0f;
+      swap32(v0, v1);
+      xa[r] = v0;
+      xb[r] = v1;
+    }
+    const float* w = lds + L.w_in + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const float a = w[(r * OT + ot) * 64];
+        accA[ot] = SDEH_MFMA(a, xa[r], accA[ot]);
+        accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
+        if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
+      }
+  }
+  f32x16 uA[OTD], uB[OTD];
+  for (int l = 0; l <= L.n_hidden; ++l) {
+    activate<OT>(accA, accB, act);
+    if (l < L.n_hidden) {  // hidden layers: e = layer(act(e))
+      f32x16 nA[OT], nB[OT];
+      const float* bias = lds + L.b_hid + l * C;
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) nA[ot] = nB[ot] = load16(bias + (ot * 2 + h) * 16);
+      const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
+#pragma unroll
+      for (int it = 0; it < OT; ++it)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) {
+            const float a = w[((it * 16 + q) * OT + ot) * 64];
+            nA[ot] = SDEH_MFMA(a, accA[it][q], nA[ot]);
+            nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
+            if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+          }
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) { accA[ot] = nA[ot]; accB[ot] = nB[ot]; }
+    } else {  // out_layer(act(e))
+#pragma unroll
+      for (int t = 0; t < OTD; ++t) uA[t] = uB[t] = load16(lds + L.b_out + (t * 2 + h) * 16);
+      const float* w = lds + L.w_out + lane;
+#pragma unroll
+      for (int it = 0; it < OT; ++it)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int t = 0; t < OTD; ++t) {
+            const float a = w[((it * 16 + q) * OTD + t) * 64];
+            uA[t] = SDEH_MFMA(a, accA[it][q], uA[t]);
+            uB[t] = SDEH_MFMA(a, accB[it][q], uB[t]);
+            if (t == OTD - 1 && (q & 1)) SDEH_FENCE();
+          }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float v0 = uA[r / 16][r % 16];
+    float v1 = uB[r / 16][r % 16];
+    swap32(v0, v1);
+    out[mdim(r, 0)] = v0;
+    if (mdim(r, 1) < DP) out[mdim(r, 1)] = v1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// densities in the T layout (one trajectory per lane, parameters wave-uniform -> scalar loads)
+// ---------------------------------------------------------------------------------------------------------
+// GMM (distr/gauss.py:123-140): log p(x) = logsumexp_k( log w~_k + sum_d Normal(mu_kd, sigma_kd).log_prob(x_d) ).
+// Returns the log-density; when SCORE, also d/dx = sum_k r_k (mu_k - x)/sigma_k^2 (what the reference obtains
+// by autograd, distr/base.py:130-137).  Logits are parked in LDS between the two passes.
+template <int DP, bool SCORE>
+__device__ __forceinline__ float gmm_eval(const float* ws, const WsLayout& L, int K, float* __restrict__ lg_lds,
+                                          const float (&x)[DP], float (&score)[DP]) {
+  cf2p plg = as_const2(ws + L.gmm_lg);
+  cfp pc = as_const(ws + L.gmm_c);
+  float m = -INFINITY;
+  for (int k = 0; k < K; ++k) {
+    cf2p p = plg + k * DP;
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const float t = x[d] - p[d].x;
+      acc = fmaf(t * t, p[d].y, acc);
+    }
+    const float l = pc[k] - acc;
+    lg_lds[k * 256] = l;
+    m = fmaxf(m, l);
+  }
+  float z = 0.0f;
+  if constexpr (SCORE) {
+    cf2p psc = as_const2(ws + L.gmm_sc);
+    float P[DP], Q[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) P[d] = Q[d] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      cf2p p = psc + k * DP;
+      const float e = __expf(lg_lds[k * 256] - m);
+      z += e;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        P[d] = fmaf(e, p[d].x, P[d]);
+        Q[d] = fmaf(e, p[d].y, Q[d]);
+      }
+    }
+    const float iz = 1.0f / z;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) score[d] = (P[d] - x[d] * Q[d]) * iz;
+  } else {
+    for (int k = 0; k < K; ++k) z += __expf(lg_lds[k * 256] - m);
+  }
+  return m + __logf(z);
+}
+
+// Diagonal Gaussian: table [DP][2] = (mu, 1/sigma^2) followed by the scalar  sum_d(-log sigma_d - 0.5 log 2pi).
+template <int DP>
+__device__ __forceinline__ float dgauss_logp(const float* tab, const float (&x)[DP]) {
+  cf2p p = as_const2(tab);
+  float acc = 0.0f;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    const float t = x[d] - p[d].x;
+    acc = fmaf(t * t, p[d].y, acc);
+  }
+  return as_const(tab)[2 * DP] - 0.5f * acc;
+}
+template <int DP>
+__device__ __forceinline__ void dgauss_score(const float* tab, const float (&x)[DP], float (&s)[DP]) {
+  cf2p p = as_const2(tab);
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    s[d] = (p[d].x - x[d]) * p[d].y;
+  }
+}
+
+// MultiWell / DoubleWell (distr/double_well.py:39-45,165-179)
+template <int DP>
+__device__ __forceinline__ float mwell_logp(const DensArgs& D, int dreal, const float (&x)[DP]) {
+  float acc = 0.0f;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    const float y = x[d] - D.p1;
+    const float w = y * y - D.p0;
+    const float v = d < D.n_comp ? w * w : 0.5f * y * y;
+    acc += d < dreal ? v : 0.0f;
+  }
+  return -acc;
+}
+template <int DP>
+__device__ __forceinline__ void mwell_score(const DensArgs& D, int dreal, const float (&x)[DP], float (&s)[DP]) {
+#pragma unroll
+  for (int d = 0; d < DP; ++d) {
+    const float y = x[d] - D.p1;
+    const float v = d < D.n_comp ? -4.0f * (y * y - D.p0) * y : -y;
+    s[d] = d < dreal ? v : 0.0f;
+  }
+}
+
+// Funnel (distr/funnel.py:54-80); p0 = variance of the first coordinate
+template <int DP>
+__device__ __forceinline__ float funnel_logp(const DensArgs& D, int dreal, const float (&x)[DP]) {
+  const float x0 = x[0];
+  float sq = 0.0f;
+#pragma unroll
+  for (int d = 1; d < DP; ++d) sq = fmaf(x[d], x[d], sq);  // padded coordinates are held at 0
+  const float first = -0.5f * __logf(6.283185307179586f * D.p0) - 0.5f * x0 * x0 / D.p0;
+  const float other = -(float)(dreal - 1) * (x0 + 1.8378770664093453f) * 0.5f - 0.5f * sq * __expf(-x0);
+  return first + other + D.lnc;
+}
+template <int DP>
+__device__ __forceinline__ void funnel_score(const DensArgs& D, int dreal, const float (&x)[DP], float (&s)[DP]) {
+  const float x0 = x[0];
+  const float iv = __expf(-x0);
+  float sq = 0.0f;
+#pragma unroll
+  for (int d = 1; d < DP; ++d) {
+    sq = fmaf(x[d], x[d], sq);
+    s[d] = -x[d] * iv;
+  }
+  s[0] = -x0 / D.p0 - 0.5f * (float)(dreal - 1) + 0.5f * sq * iv;
+}
+
+// target.unnorm_log_prob
+template <int DP>
+__device__ __forceinline__ float target_logp(const DensArgs& D, const float* ws, const WsLayout& L, int dreal,
+                                             float* lg_lds, const float (&x)[DP]) {
+  float dummy[DP];
+  switch (D.kind) {
+    case SDEH_DENS_GMM: return gmm_eval<DP, false>(ws, L, D.n_comp, lg_lds, x, dummy) + D.lnc;
+    case SDEH_DENS_DIAG_GAUSS: return dgauss_logp<DP>(ws + L.dg[0], x) + D.lnc;
+    case SDEH_DENS_MULTI_WELL: return mwell_logp<DP>(D, dreal, x);
+    case SDEH_DENS_FUNNEL: return funnel_logp<DP>(D, dreal, x);
+    default: return 0.0f;
+  }
+}
+
+template <int DP>
+__device__ __forceinline__ void target_score(const DensArgs& D, const float* ws, const WsLayout& L, int dreal,
+                                             float* lg_lds, const float (&x)[DP], float (&s)[DP]) {
+  switch (D.kind) {
+    case SDEH_DENS_GMM: (void)gmm_eval<DP, true>(ws, L, D.n_comp, lg_lds, x, s); break;
+    case SDEH_DENS_DIAG_GAUSS: dgauss_score<DP>(ws + L.dg[0], x, s); break;
+    case SDEH_DENS_MULTI_WELL: mwell_score<DP>(D, dreal, x, s); break;
+    case SDEH_DENS_FUNNEL: funnel_score<DP>(D, dreal, x, s); break;
+    default:
+#pragma unroll
+      for (int d = 0; d < DP; ++d) s[d] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Gaussian draws: Philox4x32-10 words -> Box-Muller.  Block j of a step yields coordinates 4j..4j+3.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void box_muller4(const U4& r, float (&n)[4]) {
+  constexpr float S = 5.9604644775390625e-08f;  // 2^-24
+  const float u0 = ((float)(r.x >> 8) + 0.5f) * S;
+  const float u1 = ((float)(r.y >> 8) + 0.5f) * S;
+  const float u2 = ((float)(r.z >> 8) + 0.5f) * S;
+  const float u3 = ((float)(r.w >> 8) + 0.5f) * S;
+  // v_log_f32 is log2:  -2 ln u = -2 ln2 log2 u
+  const float ra = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
+  const float rb = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  // v_sin_f32 / v_cos_f32 take the angle in revolutions
+  n[0] = ra * __builtin_amdgcn_cosf(u1);
+  n[1] = ra * __builtin_amdgcn_sinf(u1);
+  n[2] = rb * __builtin_amdgcn_cosf(u3);
+  n[3] = rb * __builtin_amdgcn_sinf(u3);
+}
+
+__device__ __forceinline__ U4 philox_block(unsigned long long seed, unsigned long long offset,
+                                           unsigned long long row, int step, int block) {
+  U4 c;
+  c.x = (uint32_t)row;
+  c.y = (uint32_t)step;
+  c.z = (uint32_t)block | ((uint32_t)(row >> 32) << 16);
+  c.w = (uint32_t)offset;
+  return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the kernel.  PAD = false: d == DP exactly;  PAD = true: d <= DP, coordinates >= d are held at zero.
+// ---------------------------------------------------------------------------------------------------------
+template <int DP, int C, bool PAD>
+__global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
+                                                   const float* __restrict__ noise, float* __restrict__ xT,
+                                                   float* __restrict__ rnd_out, float* __restrict__ xs,
+                                                   const TrajArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const WsLayout& L = A.lay;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+
+  // stage the packed weights (LDS image) once per workgroup
+  {
+    const float4* src = reinterpret_cast<const float4*>(ws);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < L.lds_floats / 4; i += 256) dst[i] = src[i];
+  }
+  float* lg_lds = lds + L.lds_floats + tid;  // [K][256] logit scratch, column = thread
+  __syncthreads();
+
+  const long long row = (long long)blockIdx.x * 256 + tid;
+  const bool live = row < A.batch;
+  const long long lrow = live ? row : A.batch - 1;  // dead lanes shadow the last row and never store
+  if ((long long)blockIdx.x * 256 + (tid & ~63) >= A.batch) return;  // whole wave out of range
+
+  const int d = PAD ? A.d : DP;
+  float x[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    const float v = x0[lrow * d + (PAD ? min(j, d - 1) : j)];
+    x[j] = (!PAD || j < d) ? v : 0.0f;
+  }
+
+  float rnd = 0.0f;
+  // Distribution.log_prob = unnorm_log_prob - log_norm_const (distr/base.py:116-119): the constants cancel
+  if (A.flags & SDEH_FLAG_INIT_LOGP) rnd = dgauss_logp<DP>(ws + L.dg[2], x);
+
+  if (xs != nullptr && live) {
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+      if (!PAD || j < d) xs[lrow * d + j] = x[j];
+  }
+
+  const int flags = A.flags;
+  const int ctrl_kind = A.ctrl_kind, loss_kind = A.loss_kind;
+  const bool lv = flags & SDEH_FLAG_CHANGE_SDE_CTRL;
+  const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
+  const bool refc = (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
+  const bool need_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR || refc;
+
+  for (int i = 0; i < A.n_steps; ++i) {
+    cfp cf = as_const(ws + L.coef + i * kCoefStride);
+    const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
+
+    // ---- generative_ctrl(s, x) -----------------------------------------------------------------------
+    float u[DP];
+    mlp_forward<DP, C>(lds, L, A.act, ws + L.emb + i * C, x, u, lane);
+
+    SDEH_FENCE();
+    float tsc[DP], psc[DP];
+    if (need_t) target_score<DP>(A.target, ws, L, d, lg_lds, x, tsc);
+    if (need_p) dgauss_score<DP>(ws + L.dg[1], x, psc);
+
+    if (ctrl_kind == SDEH_CTRL_CLIPPED) {  // reparam.py:25-36
+#pragma unroll
+      for (int j = 0; j < DP; ++j) u[j] = clipf(u[j], A.clip_model);
+    } else {
+      const float w = cf[CF_W];
+      float sc[DP];
+      if (ctrl_kind == SDEH_CTRL_SCORE) {  // reparam.py:56-83
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sc[j] = tsc[j];
+      } else if (ctrl_kind == SDEH_CTRL_LERP) {  // reparam.py:131-144; torch.lerp's two-sided formula
+        if (w < 0.5f) {
+#pragma unroll
+          for (int j = 0; j < DP; ++j) sc[j] = psc[j] + w * (tsc[j] - psc[j]);
+        } else {
+          const float w1 = 1.0f - w;
+#pragma unroll
+          for (int j = 0; j < DP; ++j) sc[j] = tsc[j] - (tsc[j] - psc[j]) * w1;
+        }
+      } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {  // reparam.py:185-197
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sc[j] = w * tsc[j];
+      } else {  // SDEH_CTRL_LERP_PRIOR, reparam.py:166-178
+        const float w1 = 1.0f - w;
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sc[j] = w1 * psc[j];
+      }
+      cfp gam = as_const(ws + L.gam + i * L.g);
+      // ScoreCtrl: ctrl + score;  Lerp*: ctrl + sde.diff(t) * score   (reparam.py:78-83,149-162)
+      const float mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;
+      const float g0 = gam[0];
+      if (L.g == 1) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const float s = (A.scale_score * clipf(sc[j], A.clip_score)) * g0;
+          u[j] = clipf(u[j], A.clip_model) + mult * s;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const float s = (A.scale_score * clipf(sc[j], A.clip_score)) * gam[j];
+          u[j] = clipf(u[j], A.clip_model) + mult * s;
+        }
+      }
+    }
+    if (PAD) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) u[j] = j < d ? u[j] : 0.0f;
+    }
+
+    SDEH_FENCE();
+    // ---- running cost (losses/oc.py:204-211, 319-323, 418-431) -----------------------------------------
+    float gm[DP];  // the control entering the Ito term (gen_plus_inf / gen_minus_ref)
+    float cost = 0.0f;
+    if (refc) {
+      if (lv) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          const float r = sig * psc[j];
+          gm[j] = u[j] - r;
+          cost = fmaf(gm[j], u[j] - 0.5f * (r + u[j]), cost);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+          gm[j] = u[j] - sig * psc[j];
+          cost = fmaf(gm[j], gm[j], cost);
+        }
+        cost *= 0.5f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) gm[j] = u[j];
+      if (lv) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) cost = fmaf(u[j], u[j] - 0.5f * u[j], cost);
+      } else {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) cost = fmaf(u[j], u[j], cost);
+        cost *= 0.5f;
+      }
+    }
+    if (loss_kind == SDEH_LOSS_EXPONENTIAL) rnd = fmaf(cf[CF_B2S2], cost, rnd);
+    else rnd = fmaf(cost, dt, rnd);
+    if (loss_kind == SDEH_LOSS_TIME_REVERSAL && !(flags & SDEH_FLAG_TRAIN)) rnd -= cf[CF_DDIV];
+
+    // ---- Gaussian draw + state update + Ito term, streamed four coordinates at a time -------------------
+    SDEH_FENCE();
+    float itosum = 0.0f;
+    const bool expo = loss_kind == SDEH_LOSS_EXPONENTIAL;
+    // exponential integrator (oc.py:428-443):  x <- x a_k + (b_k^2 s^2) u + (s b_k) xi
+    // Euler-Maruyama (oc.py:213-219, 325-331): x <- x + (f x + sig u) dt + sig (xi sqrt(dt))
+    const float c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], dt, 1.0f);
+    const float c_u = expo ? cf[CF_B2S2] : sig * dt;
+    const float c_n = expo ? cf[CF_SBK] : sig * sqdt;
+    const float c_i = expo ? cf[CF_SBK] : sqdt;  // Ito term: sum(g * xi) * c_i
+    const float* __restrict__ np = noise != nullptr ? noise + ((long long)i * A.batch + lrow) * d : nullptr;
+    const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+#pragma unroll
+    for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
+      float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (np != nullptr) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * jb + q < DP) n[q] = np[PAD ? min(4 * jb + q, d - 1) : 4 * jb + q];
+      } else if (!PAD || 4 * jb < d) {
+        box_muller4(philox_block(A.seed, A.offset, grow, i, jb), n);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = 4 * jb + q;
+        if (j < DP) {
+          itosum = fmaf(gm[j], n[q], itosum);
+          x[j] = fmaf(c_n, n[q], fmaf(c_u, u[j], c_x * x[j]));
+        }
+      }
+      SDEH_FENCE();
+    }
+    if (flags & SDEH_FLAG_ITO) rnd = fmaf(itosum, c_i, rnd);
+    if (PAD) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) x[j] = j < d ? x[j] : 0.0f;
+    }
+
+    if (xs != nullptr && live) {
+      float* __restrict__ xp = xs + ((long long)(i + 1) * A.batch + lrow) * d;
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        if (!PAD || j < d) xp[j] = x[j];
+    }
+  }
+
+  // ---- terminal costs (oc.py:225, 337, 449-450) ----------------------------------------------------------
+  if (flags & SDEH_FLAG_TERMINAL_SECOND) rnd += dgauss_logp<DP>(ws + L.dg[2], x);
+  if (flags & SDEH_FLAG_TERMINAL_TARGET) rnd -= clipf(target_logp<DP>(A.target, ws, L, d, lg_lds, x), A.clip_target);
+
+  if (live) {
+    rnd_out[row] = rnd;
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+      if (!PAD || j < d) xT[row * d + j] = x[j];
+  }
+}
+
+template <int DP, int C, bool PAD>
+int launch_traj(const TrajArgs& a, hipStream_t stream) {
+  const int k_scratch = a.lay.k_max > 0 ? a.lay.k_max : 0;
+  const size_t lds_bytes = ((size_t)a.lay.lds_floats + (size_t)k_scratch * 256) * sizeof(float);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_kernel<DP, C, PAD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)((a.batch + 255) / 256);
+  hipLaunchKernelGGL((traj_kernel<DP, C, PAD>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
+                     a.xT, a.rnd, a.xs, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+}  // namespace sdeh

@@ -1,0 +1,386 @@
+"""Bridge between the reference's Python plugin surface and libsdeh.so.
+
+`TrajectoryEngine.simulate(...)` is what the three loss classes call instead of running the per-step Python
+loop.  It introspects the collaborating objects exactly as SURVEY.md 8b lists them -- the `generative_ctrl`
+module (`base_model`, `score_model`, clip values, `target_score`, `prior_score`, `sde`), the SDE object and the
+distributions behind the log-density callables -- by *class name and attribute*, so it works with this package's
+host classes and with the reference's own classes alike, fills an `SdehProblem` (include/sdeh.h) with raw device
+pointers and launches the HIP kernels on torch's current stream.
+
+There is no eager fallback: configurations the kernels do not cover raise `SdehUnsupported`; a missing library
+raises `SdehLibraryError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable
+
+import torch
+
+from . import _lib as L
+from ._lib import SdehUnsupported
+
+_INF = float("inf")
+
+_CTRL_KINDS = {
+    "LerpTargetCtrl": L.CTRL_LERP_TARGET, "LerpPriorCtrl": L.CTRL_LERP_PRIOR, "LerpCtrl": L.CTRL_LERP,
+    "ScoreCtrl": L.CTRL_SCORE, "ClippedCtrl": L.CTRL_CLIPPED,
+}
+_CTRL_UNSUPPORTED = {"CancelDriftCtrl", "PotentialCtrl"}
+_GAUSS_NAMES = {"IsotropicGauss", "Gauss", "Delta"}
+
+
+def _mro_names(obj) -> list[str]:
+    return [c.__name__ for c in type(obj).__mro__]
+
+
+def _unsupported(msg: str):
+    return SdehUnsupported(-2, msg)
+
+
+class _Keep(list):
+    """Holds tensors whose device pointers were handed to C for the duration of one call."""
+
+    def ptr(self, t: torch.Tensor | None, device, what: str) -> int | None:
+        if t is None:
+            return None
+        if not isinstance(t, torch.Tensor):
+            t = torch.as_tensor(t)
+        if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.append(t)
+        return t.data_ptr()
+
+
+def _activation_id(act) -> int:
+    name = type(act).__name__
+    if name == "GELU":
+        if getattr(act, "approximate", "none") != "none":
+            raise _unsupported("GELU(approximate='tanh') is not built in (exact erf GELU is)")
+        return L.ACT_GELU_ERF
+    if name == "SiLU":
+        return L.ACT_SILU
+    if name == "ReLU":
+        return L.ACT_RELU
+    raise _unsupported(f"activation {name} is not built into the trajectory kernel (GELU, SiLU, ReLU are)")
+
+
+def _fill_time_embed(te, out: L.SdehTimeEmbed, keep: _Keep, device, what: str):
+    if "TimeEmbed" not in _mro_names(te):
+        raise _unsupported(f"{what}: expected a TimeEmbed module, got {type(te).__name__}")
+    layers = list(te.hidden_layer)
+    if not 1 <= len(layers) <= L.SDEH_MAX_HIDDEN:
+        raise _unsupported(f"{what}: {len(layers)} hidden layers")
+    out.channels, out.n_hidden, out.dim_out = te.channels, len(layers), te.out_layer.out_features
+    out.coeff = keep.ptr(te.timestep_coeff.reshape(-1), device, what)
+    out.phase = keep.ptr(te.timestep_phase.reshape(-1), device, what)
+    for i, lin in enumerate(layers):
+        out.hidden_w[i] = keep.ptr(lin.weight, device, what)
+        out.hidden_b[i] = keep.ptr(lin.bias, device, what)
+    out.out_w = keep.ptr(te.out_layer.weight, device, what)
+    out.out_b = keep.ptr(te.out_layer.bias, device, what)
+
+
+def _fill_fourier_mlp(net, out: L.SdehFourierMLP, keep: _Keep, device):
+    if "FourierMLP" not in _mro_names(net):
+        raise _unsupported(f"base_model {type(net).__name__}: only FourierMLP is fused (SURVEY.md section 2)")
+    layers = list(net.hidden_layer)
+    if len(layers) > L.SDEH_MAX_HIDDEN:
+        raise _unsupported(f"base_model: {len(layers)} hidden layers > {L.SDEH_MAX_HIDDEN}")
+    out.dim, out.channels, out.n_hidden = net.input_embed.in_features, net.channels, len(layers)
+    out.activation = _activation_id(net.activation)
+    if net.out_layer.out_features != out.dim:
+        raise _unsupported("base_model.dim_out != dim")
+    out.input_w = keep.ptr(net.input_embed.weight, device, "input_embed")
+    out.input_b = keep.ptr(net.input_embed.bias, device, "input_embed")
+    for i, lin in enumerate(layers):
+        out.hidden_w[i] = keep.ptr(lin.weight, device, "hidden_layer")
+        out.hidden_b[i] = keep.ptr(lin.bias, device, "hidden_layer")
+    out.out_w = keep.ptr(net.out_layer.weight, device, "out_layer")
+    out.out_b = keep.ptr(net.out_layer.bias, device, "out_layer")
+    _fill_time_embed(net.timestep_embed, out.timestep_embed, keep, device, "base_model.timestep_embed")
+    if type(net.timestep_embed.activation) is not type(net.activation):
+        raise _unsupported("base_model and its timestep_embed use different activations")
+
+
+def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
+    """Maps a Distribution object (reference or sde_sampler_amd.distr) onto an SdehDensity."""
+    names = _mro_names(dist)
+    lnc = getattr(dist, "log_norm_const", None)
+    out.dim = dist.dim
+    out.log_norm_const = 0.0 if lnc is None else float(lnc)
+    if any(n in _GAUSS_NAMES for n in names) or ("GMM" in names and dist.mixture_weights is None):
+        out.kind = L.DENS_DIAG_GAUSS
+        out.loc = keep.ptr(dist.loc.reshape(-1), device, what)
+        out.scale = keep.ptr(dist.scale.reshape(-1), device, what)
+        if dist.loc.numel() != dist.dim:
+            raise _unsupported(f"{what}: Gaussian with loc of shape {tuple(dist.loc.shape)}")
+    elif "GMM" in names:
+        out.kind = L.DENS_GMM
+        out.n_components = dist.loc.shape[0]
+        out.loc = keep.ptr(dist.loc, device, what)
+        out.scale = keep.ptr(dist.scale, device, what)
+        out.mixture_weights = keep.ptr(dist.mixture_weights, device, what)
+    elif "DoubleWell" in names:
+        out.kind, out.n_components = L.DENS_MULTI_WELL, 1
+        out.p0, out.p1 = float(dist.separation), float(dist.shift)
+        out.log_norm_const = 0.0  # DoubleWell.unnorm_log_prob carries no constant
+    elif "MultiWell" in names:
+        out.kind, out.n_components = L.DENS_MULTI_WELL, dist.n_double_wells
+        out.p0, out.p1 = float(dist.separation), float(dist.double_well.shift)
+        out.log_norm_const = 0.0
+    elif "Funnel" in names:
+        out.kind = L.DENS_FUNNEL
+        out.p0 = float(dist.variance)
+    else:
+        raise _unsupported(f"{what}: distribution {type(dist).__name__} has no fused log-density/score "
+                           "(GMM, Gauss, IsotropicGauss, Delta, DoubleWell, MultiWell, Funnel are built in)")
+
+
+def _known_distribution(obj) -> bool:
+    names = set(_mro_names(obj))
+    return bool(names & (_GAUSS_NAMES | {"GMM", "DoubleWell", "MultiWell", "Funnel"}))
+
+
+def _bound_owner(fn, method: str):
+    """`obj` if `fn` is the bound method `obj.<method>`, else None."""
+    owner = getattr(fn, "__self__", None)
+    return owner if owner is not None and getattr(fn, "__name__", None) == method else None
+
+
+class _Plan:
+    def __init__(self, lib, desc: L.SdehPlanDesc):
+        self.lib, self.handle = lib, C.c_void_p()
+        L.check(lib.sdeh_plan_create(C.byref(desc), C.byref(self.handle)))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.sdeh_plan_destroy(self.handle)
+        except Exception:  # interpreter shutdown
+            pass
+
+
+class TrajectoryEngine:
+    """Owns the libsdeh plans of one loss object and turns `simulate(...)` calls into kernel launches."""
+
+    def __init__(self):
+        self._plans: dict[tuple, _Plan] = {}
+        self.calls = 0  # advances the Philox stream: one `offset` per simulate() call
+        self.timing = False  # record HIP events around the trajectory kernel (bench.py)
+        self._last_plan = None
+
+    # ------------------------------------------------------------------------------------------------------
+    def _plan(self, device, dim, channels, n_hidden, n_steps, k) -> _Plan:
+        key = (device.index, dim, channels)
+        plan = self._plans.get(key)
+        cap = getattr(plan, "cap", None)
+        if plan is None or n_hidden > cap[0] or n_steps > cap[1] or k > cap[2]:
+            cap = (max(n_hidden, cap[0] if cap else 0), max(n_steps, 2 * cap[1] if cap else 512),
+                   max(k, cap[2] if cap else 0))
+            desc = L.SdehPlanDesc(dim=dim, channels=channels, max_hidden=cap[0], max_steps=cap[1],
+                                  max_components=cap[2], device=device.index)
+            plan = _Plan(L.load(), desc)
+            plan.cap = cap
+            self._plans[key] = plan
+        L.check(plan.lib.sdeh_plan_set_timing(plan.handle, 1 if self.timing else 0))
+        self._last_plan = plan
+        return plan
+
+    def last_kernel_ms(self) -> float:
+        """Duration of the last trajectory-kernel launch (HIP events on its stream); needs `timing = True`."""
+        ms = C.c_float()
+        L.check(self._last_plan.lib.sdeh_plan_last_kernel_ms(self._last_plan.handle, C.byref(ms)))
+        return ms.value
+
+    # ------------------------------------------------------------------------------------------------------
+    def build_problem(self, *, loss_kind: int, generative_ctrl, sde, flags: int, device, keep: _Keep,
+                      terminal_target=None, clip_target=None, second=None, reference_prior=None,
+                      alpha: float = 0.0, sigma: float = 0.0) -> L.SdehProblem:
+        pr = L.SdehProblem()
+        pr.loss_kind, pr.flags = loss_kind, flags
+        # ---- control --------------------------------------------------------------------------------------
+        names = _mro_names(generative_ctrl)
+        bad = [n for n in names if n in _CTRL_UNSUPPORTED]
+        if bad:
+            raise _unsupported(f"generative_ctrl {bad[0]} is not fused by the HIP engine")
+        kind = next((_CTRL_KINDS[n] for n in names if n in _CTRL_KINDS), None)
+        if kind is None:
+            raise _unsupported(f"generative_ctrl of type {type(generative_ctrl).__name__} is not a known control module")
+        if getattr(generative_ctrl, "hard_constrain", False):
+            raise _unsupported("hard_constrain=True (dead code in the reference) is not supported")
+        pr.ctrl_kind = kind
+        clip_model = getattr(generative_ctrl, "clip_model", None)
+        clip_score = getattr(generative_ctrl, "clip_score", None)
+        pr.clip_model = _INF if clip_model is None else float(clip_model)
+        pr.clip_score = _INF if clip_score is None else float(clip_score)
+        pr.scale_score = float(getattr(generative_ctrl, "scale_score", 1.0))
+        pr.clip_target = _INF if clip_target is None else float(clip_target)
+        _fill_fourier_mlp(generative_ctrl.base_model, pr.base_model, keep, device)
+        dim = pr.base_model.dim
+        target_obj = terminal_target
+        if kind != L.CTRL_CLIPPED:
+            score_model = getattr(generative_ctrl, "score_model", None)
+            if score_model is not None:
+                _fill_time_embed(score_model, pr.score_model, keep, device, "score_model")
+                if type(score_model.activation) is not type(generative_ctrl.base_model.activation):
+                    raise _unsupported("score_model and base_model use different activations")
+            if kind != L.CTRL_LERP_PRIOR:
+                owner = _bound_owner(generative_ctrl.target_score, "score")
+                if owner is None or not _known_distribution(owner):
+                    raise _unsupported("generative_ctrl.target_score must be the `.score` of a built-in distribution")
+                if target_obj is not None and owner is not target_obj:
+                    raise _unsupported("target_score and terminal_unnorm_log_prob belong to different distributions")
+                target_obj = owner
+            if kind in (L.CTRL_LERP, L.CTRL_LERP_PRIOR):
+                owner = _bound_owner(generative_ctrl.prior_score, "score")
+                if owner is None or not _known_distribution(owner):
+                    raise _unsupported("generative_ctrl.prior_score must be the `.score` of a Gaussian prior")
+                if reference_prior is not None and owner is not reference_prior:
+                    raise _unsupported("prior_score and reference_ctrl use different priors")
+                reference_prior = owner
+            ctrl_sde = getattr(generative_ctrl, "sde", None)
+            if kind >= L.CTRL_LERP and ctrl_sde is not None and ctrl_sde is not sde:
+                raise _unsupported("generative_ctrl.sde differs from the loss's sde")
+        if target_obj is not None:
+            _fill_density(target_obj, pr.target, keep, device, "target")
+            if pr.target.dim != dim:
+                raise ValueError(f"target dim {pr.target.dim} != model dim {dim}")
+        if reference_prior is not None:
+            _fill_density(reference_prior, pr.prior, keep, device, "prior")
+            if pr.prior.kind != L.DENS_DIAG_GAUSS:
+                raise _unsupported("only Gaussian priors have a fused score")
+        if second is not None:
+            _fill_density(second, pr.second, keep, device, "initial/reference density")
+            if pr.second.kind != L.DENS_DIAG_GAUSS:
+                raise _unsupported("only Gaussian initial/reference densities are fused")
+        # ---- sde ------------------------------------------------------------------------------------------
+        if sde is None:
+            pr.sde_kind = L.SDE_NONE
+        else:
+            snames = _mro_names(sde)
+            if not getattr(sde, "generative", True):
+                raise _unsupported("the engine integrates the generative SDE (generative=True)")
+            pr.terminal_t = float(sde.terminal_t)
+            if "VP" in snames:
+                pr.sde_kind = L.SDE_VP
+                pr.vp_beta_min, pr.vp_beta_max = float(sde.diff_coeff_sq_min), float(sde.diff_coeff_sq_max)
+                pr.vp_scale = float(sde.scale_diff_coeff)
+            elif "ConstOU" in snames:
+                pr.sde_kind = L.SDE_CONST_OU
+                pr.ou_drift, pr.ou_diff = float(sde.drift_coeff), float(sde.diff_coeff)
+            else:
+                raise _unsupported(f"sde {type(sde).__name__}: VP, ConstOU and ScaledBM are built in")
+        pr.exp_alpha, pr.exp_sigma = float(alpha), float(sigma)
+        return pr
+
+    # ------------------------------------------------------------------------------------------------------
+    def run(self, pr: L.SdehProblem, ts: torch.Tensor, x: torch.Tensor, *, noise: torch.Tensor | None,
+            return_traj: bool, keep: _Keep, row_offset: int = 0, seed: int | None = None):
+        """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None)."""
+        if not x.is_cuda:
+            raise RuntimeError("the HIP trajectory engine needs CUDA/HIP tensors (got a CPU tensor); "
+                               "there is no CPU path in this package")
+        device = x.device
+        lib = L.load()
+        if x.dim() != 2:
+            raise ValueError(f"x must be [batch, dim], got {tuple(x.shape)}")
+        batch, dim = x.shape
+        if dim != pr.base_model.dim:
+            raise ValueError(f"x has dim {dim}, the model expects {pr.base_model.dim}")
+        n_steps = ts.numel() - 1
+        if n_steps < 1:
+            raise ValueError("need at least two time points")
+        ts_p = keep.ptr(ts.reshape(-1), device, "ts")
+        x_p = keep.ptr(x, device, "x")
+        noise_p = None
+        if noise is not None:
+            if tuple(noise.shape) != (n_steps, batch, dim):
+                raise ValueError(f"noise must be [{n_steps}, {batch}, {dim}], got {tuple(noise.shape)}")
+            noise_p = keep.ptr(noise, device, "noise")
+        x_T = torch.empty((batch, dim), device=device, dtype=torch.float32)
+        rnd = torch.empty((batch, 1), device=device, dtype=torch.float32)
+        xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32) if return_traj else None
+        k = pr.target.n_components if pr.target.kind == L.DENS_GMM else 0
+        plan = self._plan(device, dim, pr.base_model.channels, pr.base_model.n_hidden, n_steps, k)
+        if seed is None:
+            seed = torch.initial_seed()
+        offset = self.calls
+        self.calls += 1
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            L.check(lib.sdeh_simulate_fwd(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
+                                          seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
+                                          rnd.data_ptr(), None if xs is None else xs.data_ptr(), stream))
+        return x_T, rnd, xs
+
+    # ------------------------------------------------------------------------------------------------------
+
+def estimator_stats(rnd: torch.Tensor, max_rnd: float = math.nan) -> torch.Tensor:
+    """8 mergeable partial statistics of `rnd` (include/sdeh.h: sdeh_reduce_estimators), on device."""
+    out = torch.empty(8, device=rnd.device, dtype=torch.float32)
+    scratch = torch.empty(L.SDEH_REDUCE_SCRATCH, device=rnd.device, dtype=torch.float32)
+    rnd = rnd.contiguous()
+    stream = torch.cuda.current_stream(rnd.device).cuda_stream
+    with torch.cuda.device(rnd.device):
+        L.check(L.load().sdeh_reduce_estimators(rnd.data_ptr(), rnd.numel(), max_rnd, scratch.data_ptr(),
+                                                out.data_ptr(), stream))
+    return out
+
+
+def importance_weights(rnd: torch.Tensor, log_weight_max: torch.Tensor) -> torch.Tensor:
+    """exp(-rnd - m) with the (global) maximum m given as a device scalar."""
+    rnd = rnd.contiguous()
+    w = torch.empty_like(rnd)
+    m = log_weight_max.to(device=rnd.device, dtype=torch.float32).reshape(1).contiguous()
+    stream = torch.cuda.current_stream(rnd.device).cuda_stream
+    with torch.cuda.device(rnd.device):
+        L.check(L.load().sdeh_importance_weights(rnd.data_ptr(), rnd.numel(), m.data_ptr(), w.data_ptr(), stream))
+    return w
+
+
+# ----------------------------------------------------------------------------------------------------------
+# mergeable estimator statistics: v = [n, sum(-rnd), M2(rnd), m=max(-rnd), sum e^{-rnd-m}, sum e^{2(-rnd-m)}, n_filtered, 0]
+# ----------------------------------------------------------------------------------------------------------
+def merge_stats(stats: torch.Tensor) -> torch.Tensor:
+    """Combines per-rank statistics [R, 8] into one [8] vector (Chan's parallel variance + rescaled exp-sums).
+    Pure tensor arithmetic on whatever device `stats` lives on (tested on CPU with gloo)."""
+    stats = stats.double()
+    n, s, m2, mx, e1, e2, nf = (stats[:, i] for i in range(7))
+    N = n.sum()
+    valid = n > 0
+    mean_r = torch.where(valid, -s / n.clamp(min=1), torch.zeros_like(s))  # per-rank mean of rnd
+    mean = (mean_r * n).sum() / N.clamp(min=1)
+    M2 = (m2 + n * (mean_r - mean) ** 2).sum()
+    m = torch.where(valid, mx, torch.full_like(mx, -math.inf)).max()
+    scale = torch.where(valid, (mx - m).exp(), torch.zeros_like(mx))
+    out = torch.stack([N, s.sum(), M2, m, (e1 * scale).sum(), (e2 * scale * scale).sum(), nf.sum(),
+                       torch.zeros((), dtype=stats.dtype, device=stats.device)])
+    return out
+
+
+def all_gather_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
+    """The single collective of an evaluation: all-gather 8 floats per rank, then merge locally."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return merge_stats(stats.reshape(1, 8))
+    bucket = [torch.empty_like(stats) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(bucket, stats.contiguous(), group=group)
+    return merge_stats(torch.stack(bucket))
+
+
+def estimators_from_stats(v: torch.Tensor) -> dict:
+    """log_norm_const_lb(_ito) = mean(-rnd); log_norm_const_is = log mean exp(-rnd); lv_loss = var(rnd) (unbiased);
+    ess = (sum w)^2 / sum w^2  (reference: losses/oc.py:94-123, eval/metrics.py:121-126)."""
+    n, s, m2, m, e1, e2, nf = (float(t) for t in v[:7])
+    return {
+        "n": n, "n_filtered": nf,
+        "mean_neg_rnd": s / n if n > 0 else math.nan,
+        "log_norm_const_is": math.log(e1 / n) + m if n > 0 and e1 > 0 else math.nan,
+        "var_rnd": m2 / (n - 1) if n > 1 else math.nan,
+        "mean_rnd": -s / n if n > 0 else math.nan,
+        "log_weight_max": m,
+        "ess": (e1 * e1 / e2) if e2 > 0 else math.nan,
+    }

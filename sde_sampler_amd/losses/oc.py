@@ -1,0 +1,307 @@
+"""Optimal-control losses whose `simulate()` runs on the MI355X trajectory engine (libsdeh.so).
+
+Drop-in for the reference's sde_sampler/losses/oc.py: same class names, constructor keywords, `loss(ts, x, ...)`
+/ `loss.eval(...) -> Results` / `state_dict()` contracts (BaseOCLoss 13-137, TimeReversalLoss 140-278,
+ReferenceSDELoss 281-391, ExponentialIntegratorSDELoss 394-505), selected by pointing a Hydra `_target_` at
+`sde_sampler_amd.losses.oc.<Class>`.  What changes is *how* simulate() is computed:
+
+* the whole time-stepping loop is one persistent HIP kernel launch (sde_sampler_amd/csrc/sdeh_traj.hpp);
+* Gaussian noise comes from the kernel's own Philox4x32-10 stream, keyed by `torch.initial_seed()` and counted
+  per (call, trajectory, step) -- or from an explicit `noise=[T,B,d]` tensor (parity mode), which reproduces
+  the reference's result for the same draws;
+* the batch reductions of `compute_results` run on device and, under `torch.distributed`, merge across ranks
+  with one 8-float all-gather.
+
+Not built in (raises `SdehUnsupported`, never falls back): the Bridge inference control / divergence term,
+`sde_ctrl_noise` / `sde_ctrl_dropout`, and training (`loss(...)` with autograd) -- SURVEY.md 8f rows f1/f2.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Callable
+
+import torch
+
+from sde_sampler_amd import _lib as L
+from sde_sampler_amd import engine as E
+from sde_sampler_amd.utils.common import Results
+
+
+def _resolve_terminal(fn: Callable):
+    """terminal_unnorm_log_prob -> (distribution, clip_target) when it can be fused, else (None, None).
+
+    Recognised: `target.unnorm_log_prob` of a built-in distribution, and the solver's
+    `clipped_target_unnorm_log_prob` (reference solver/oc.py:48-54: clip(target.unnorm_log_prob(x), clip_target))."""
+    owner = getattr(fn, "__self__", None)
+    name = getattr(fn, "__name__", None)
+    if owner is None:
+        return None, None
+    if name == "unnorm_log_prob" and E._known_distribution(owner):
+        return owner, None
+    if name == "clipped_target_unnorm_log_prob" and hasattr(owner, "target") and E._known_distribution(owner.target):
+        return owner.target, getattr(owner, "clip_target", None)
+    return None, None
+
+
+def _resolve_gaussian_log_prob(fn: Callable | None):
+    """initial_log_prob / reference_log_prob -> the Gaussian distribution behind `dist.log_prob`, else None."""
+    owner = E._bound_owner(fn, "log_prob") if fn is not None else None
+    if owner is not None and (set(E._mro_names(owner)) & E._GAUSS_NAMES or
+                              ("GMM" in E._mro_names(owner) and owner.mixture_weights is None)):
+        return owner
+    return None
+
+
+class BaseOCLoss:
+    #: set to a torch.distributed process group (or leave None for the default group); evaluation statistics are
+    #: merged across ranks whenever torch.distributed is initialised with world_size > 1
+    process_group = None
+
+    def __init__(self, generative_ctrl: Callable, sde=None, method: str = "kl", traj_per_sample: int = 1,
+                 filter_samples: Callable | None = None, max_rnd: float | None = None,
+                 sde_ctrl_dropout: float | None = None, sde_ctrl_noise: float | None = None, **kwargs):
+        self.generative_ctrl = generative_ctrl
+        self.sde = sde
+        if method not in ["kl", "kl_ito", "lv", "lv_traj"]:
+            raise ValueError("Unknown loss method.")
+        self.method = method
+        if traj_per_sample == 1 and self.method == "lv_traj":
+            raise ValueError("Cannot compute variance over a single trajectory.")
+        self.traj_per_sample = traj_per_sample
+        self.filter_samples = filter_samples
+        self.max_rnd = max_rnd
+        self.sde_ctrl_noise = sde_ctrl_noise
+        self.sde_ctrl_dropout = sde_ctrl_dropout
+        if self.method in ["kl", "kl_ito"] and (sde_ctrl_noise is not None or sde_ctrl_dropout is not None):
+            logging.warning("sde_ctrl_noise / sde_ctrl_dropout should only be used for the log-variance loss.")
+        self.n_filtered = 0
+        self.engine = E.TrajectoryEngine()
+        #: row index of this rank's first trajectory in the global batch (keeps the Philox streams of data-parallel
+        #: ranks disjoint); set by the caller, e.g. rank * local_batch
+        self.row_offset = 0
+
+    # -- filtering / loss value (reference 50-92) ------------------------------------------------------------
+    def filter(self, rnd: torch.Tensor, samples: torch.Tensor | None = None) -> torch.Tensor:
+        mask = True
+        if samples is not None and self.filter_samples is not None:
+            mask = self.filter_samples(samples)
+        if self.max_rnd is None:
+            return mask & rnd.isfinite()
+        return mask & (rnd < self.max_rnd)
+
+    def compute_loss(self, rnd: torch.Tensor, samples: torch.Tensor | None = None) -> tuple[torch.Tensor, dict]:
+        mask = self.filter(rnd, samples=samples)
+        assert mask.shape == rnd.shape
+        if self.method == "lv_traj":
+            rnd = rnd.reshape(self.traj_per_sample, -1, 1)
+            mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)
+            self.n_filtered += self.traj_per_sample * (mask.numel() - mask.sum()).item()
+            loss = rnd[:, mask].var(dim=0).mean()
+        else:
+            self.n_filtered += (mask.numel() - mask.sum()).item()
+            loss = rnd[mask].var() if self.method == "lv" else rnd[mask].mean()
+        return loss, {"train/n_filtered_cumulative": self.n_filtered}
+
+    # -- evaluation statistics (reference 94-123) ---------------------------------------------------------------
+    @staticmethod
+    def compute_results(rnd: torch.Tensor, compute_weights: bool = False, ts: torch.Tensor | None = None,
+                        samples: torch.Tensor | None = None, xs: torch.Tensor | None = None, group=None) -> Results:
+        """log Z estimators from the per-trajectory `rnd` via one device reduction (+ one 8-float all-gather when
+        running data-parallel).  The values are those of the reference formulas (neg_rnd.mean(), log mean exp,
+        rnd.var()) over the GLOBAL batch; `samples` / `weights` stay rank-local shards."""
+        stats = E.all_gather_stats(E.estimator_stats(rnd), group=group)
+        est = E.estimators_from_stats(stats.cpu())
+        metrics = {}
+        if compute_weights:
+            m = torch.as_tensor(est["log_weight_max"], dtype=torch.float32, device=rnd.device)
+            weights = E.importance_weights(rnd, m)
+            preds = {"log_norm_const_lb_ito": est["mean_neg_rnd"], "log_norm_const_is": est["log_norm_const_is"]}
+            metrics["eval/lv_loss"] = est["var_rnd"]
+        else:
+            weights = None
+            preds = {"log_norm_const_lb": est["mean_neg_rnd"]}
+        return Results(samples=samples, weights=weights, log_norm_const_preds=preds, ts=ts, xs=xs, metrics=metrics)
+
+    def __call__(self, ts: torch.Tensor, x: torch.Tensor, *args, **kwargs):
+        raise NotImplementedError
+
+    def eval(self, ts: torch.Tensor, x: torch.Tensor, *args, **kwargs) -> Results:
+        raise NotImplementedError
+
+    def load_state_dict(self, state_dict: dict):
+        self.n_filtered = state_dict["n_filtered"]
+
+    def state_dict(self) -> dict:
+        return {"n_filtered": self.n_filtered}
+
+    # -- shared plumbing ----------------------------------------------------------------------------------------
+    _LOSS_KIND = None
+
+    def _check_common(self, change_sde_ctrl: bool):
+        if change_sde_ctrl and (self.sde_ctrl_noise is not None or self.sde_ctrl_dropout is not None):
+            raise L.SdehUnsupported(-2, "sde_ctrl_noise / sde_ctrl_dropout are not built into the HIP engine")
+
+    def _launch(self, ts, x, *, flags: int, terminal_unnorm_log_prob: Callable, second_log_prob: Callable | None,
+                second_at_start: bool, second_at_end: bool, return_traj: bool, noise, reference_prior=None,
+                alpha: float = 0.0, sigma: float = 0.0):
+        """Common body of the three simulate() methods: fuse what can be fused, call back what cannot."""
+        keep = E._Keep()
+        target, clip_target = _resolve_terminal(terminal_unnorm_log_prob)
+        second = _resolve_gaussian_log_prob(second_log_prob)
+        if target is not None:
+            flags |= L.FLAG_TERMINAL_TARGET
+        if second is not None:
+            if second_at_start:
+                flags |= L.FLAG_INIT_LOGP
+            if second_at_end:
+                flags |= L.FLAG_TERMINAL_SECOND
+        pr = self.engine.build_problem(loss_kind=self._LOSS_KIND, generative_ctrl=self.generative_ctrl, sde=self.sde,
+                                       flags=flags, device=x.device, keep=keep, terminal_target=target,
+                                       clip_target=clip_target, second=second, reference_prior=reference_prior,
+                                       alpha=alpha, sigma=sigma)
+        x_T, rnd, xs = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
+                                       row_offset=self.row_offset)
+        # user-supplied callables the engine does not recognise are evaluated as given (device tensors in/out)
+        if second is None and second_log_prob is not None:
+            if second_at_start:
+                rnd = rnd + second_log_prob(x)
+            if second_at_end:
+                rnd = rnd + second_log_prob(x_T)
+        if target is None:
+            rnd = rnd - terminal_unnorm_log_prob(x_T)
+        assert rnd.shape == (x.shape[0], 1)
+        return x_T, rnd, xs
+
+    def _train_call(self, ts, x, simulate_kwargs: dict):
+        if self.traj_per_sample != 1:
+            x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
+        needs_graph = torch.is_grad_enabled() and any(
+            p.requires_grad for p in getattr(self.generative_ctrl, "parameters", lambda: [])())
+        if needs_graph:
+            raise L.SdehUnsupported(
+                -2, "training through the fused trajectory kernel (backward pass) is not built yet "
+                    "(SURVEY.md 8f row f1); call under torch.no_grad() for the loss value only")
+        samples, rnd, _ = self.simulate(ts, x, compute_ito_int=self.method != "kl",
+                                        change_sde_ctrl=self.method in ["lv", "lv_traj"], return_traj=False,
+                                        **simulate_kwargs)
+        return self.compute_loss(rnd, samples=samples)
+
+
+class TimeReversalLoss(BaseOCLoss):
+    """DIS (and, once the divergence term exists, Bridge): reference losses/oc.py:140-278."""
+
+    _LOSS_KIND = L.LOSS_TIME_REVERSAL
+
+    def __init__(self, *args, inference_ctrl: Callable | None = None, div_estimator: str | None = None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.inference_ctrl = inference_ctrl
+        self.div_estimator = div_estimator
+        if self.div_estimator is not None and self.inference_ctrl is None:
+            logging.warning("Without inference control the divergence estimator has no effect.")
+
+    def simulate(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None = None,
+                 train: bool = True, compute_ito_int: bool = False, change_sde_ctrl: bool = False,
+                 return_traj: bool = False, *, noise: torch.Tensor | None = None):
+        if self.inference_ctrl is not None:
+            raise L.SdehUnsupported(-2, "TimeReversalLoss with an inference control (Bridge: divergence of the "
+                                        "inference ctrl per step) is not built yet (SURVEY.md 8f row f2)")
+        self._check_common(change_sde_ctrl)
+        flags = (L.FLAG_TRAIN if train else 0) | (L.FLAG_ITO if compute_ito_int else 0) | \
+                (L.FLAG_CHANGE_SDE_CTRL if change_sde_ctrl else 0)
+        with_initial = not (train and self.method in ["kl", "kl_ito"])  # reference 168-172
+        return self._launch(ts, x, flags=flags, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                            second_log_prob=initial_log_prob if with_initial else None, second_at_start=True,
+                            second_at_end=False, return_traj=return_traj, noise=noise)
+
+    def __call__(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None, *, noise=None):
+        return self._train_call(ts, x, dict(terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                            initial_log_prob=initial_log_prob, train=True, noise=noise))
+
+    def eval(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None = None,
+             compute_weights: bool = True, return_traj: bool = True, *, noise=None) -> Results:
+        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                         initial_log_prob=initial_log_prob, compute_ito_int=compute_weights,
+                                         train=False, return_traj=return_traj, noise=noise)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs,
+                                          group=self.process_group)
+
+
+class ReferenceSDELoss(BaseOCLoss):
+    """PIS / EulerDDS: reference losses/oc.py:281-391."""
+
+    _LOSS_KIND = L.LOSS_REFERENCE_SDE
+
+    def __init__(self, *args, reference_ctrl: Callable | None = None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.reference_ctrl = reference_ctrl
+
+    def _reference_prior(self):
+        """EulerDDS passes `solver.reference_ctrl` = sde.diff(t,x) * prior.score(x) (solver/oc.py:305-306)."""
+        if self.reference_ctrl is None:
+            return None
+        owner = getattr(self.reference_ctrl, "__self__", None)
+        prior = getattr(owner, "prior", None)
+        if getattr(self.reference_ctrl, "__name__", None) == "reference_ctrl" and prior is not None and \
+                E._known_distribution(prior):
+            return prior
+        prior = getattr(self.reference_ctrl, "prior", None)  # a callable object carrying its prior
+        if prior is not None and E._known_distribution(prior):
+            return prior
+        raise L.SdehUnsupported(-2, "reference_ctrl must be the solver's `reference_ctrl` (sigma * prior.score) "
+                                    "or expose the Gaussian it uses as `.prior`")
+
+    def simulate(self, ts, x, terminal_unnorm_log_prob: Callable, reference_log_prob: Callable,
+                 compute_ito_int: bool = False, change_sde_ctrl: bool = False, return_traj: bool = False, *,
+                 noise: torch.Tensor | None = None):
+        self._check_common(change_sde_ctrl)
+        prior = self._reference_prior()
+        flags = (L.FLAG_ITO if compute_ito_int else 0) | (L.FLAG_CHANGE_SDE_CTRL if change_sde_ctrl else 0) | \
+                (L.FLAG_REFERENCE_CTRL if prior is not None else 0)
+        return self._launch(ts, x, flags=flags, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                            second_log_prob=reference_log_prob, second_at_start=False, second_at_end=True,
+                            return_traj=return_traj, noise=noise, reference_prior=prior)
+
+    def __call__(self, ts, x, terminal_unnorm_log_prob: Callable, reference_log_prob: Callable, *, noise=None):
+        return self._train_call(ts, x, dict(terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                            reference_log_prob=reference_log_prob, noise=noise))
+
+    def eval(self, ts, x, terminal_unnorm_log_prob: Callable, reference_log_prob: Callable | None = None,
+             compute_weights: bool = True, return_traj: bool = True, *, noise=None) -> Results:
+        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                         reference_log_prob=reference_log_prob, compute_ito_int=compute_weights,
+                                         change_sde_ctrl=False, return_traj=return_traj, noise=noise)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs,
+                                          group=self.process_group)
+
+
+class ExponentialIntegratorSDELoss(BaseOCLoss):
+    """DDS with the exponential integrator of Vargas et al.: reference losses/oc.py:394-505."""
+
+    _LOSS_KIND = L.LOSS_EXPONENTIAL
+
+    def __init__(self, *args, alpha: float, sigma: float, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.alpha = alpha
+        self.sigma = sigma
+
+    def simulate(self, ts, x, terminal_unnorm_log_prob: Callable, reference_log_prob: Callable,
+                 compute_ito_int: bool = False, change_sde_ctrl: bool = False, return_traj: bool = False, *,
+                 noise: torch.Tensor | None = None):
+        self._check_common(change_sde_ctrl)
+        flags = (L.FLAG_ITO if compute_ito_int else 0) | (L.FLAG_CHANGE_SDE_CTRL if change_sde_ctrl else 0)
+        return self._launch(ts, x, flags=flags, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                            second_log_prob=reference_log_prob, second_at_start=False, second_at_end=True,
+                            return_traj=return_traj, noise=noise, alpha=self.alpha, sigma=self.sigma)
+
+    def __call__(self, ts, x, terminal_unnorm_log_prob: Callable, reference_log_prob: Callable, *, noise=None):
+        return self._train_call(ts, x, dict(terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                            reference_log_prob=reference_log_prob, noise=noise))
+
+    def eval(self, ts, x, terminal_unnorm_log_prob: Callable, reference_log_prob: Callable | None = None,
+             compute_weights: bool = True, return_traj: bool = True, *, noise=None) -> Results:
+        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                         reference_log_prob=reference_log_prob, compute_ito_int=compute_weights,
+                                         change_sde_ctrl=False, return_traj=return_traj, noise=noise)
+        return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs,
+                                          group=self.process_group)

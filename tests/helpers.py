@@ -1,0 +1,31 @@
+"""Shared test plumbing: loading golden fixtures into (oracle problem, HIP problem) pairs."""
+import glob
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = Path(__file__).parent / "golden"
+GOLDEN = sorted(glob.glob(str(GOLDEN_DIR / "*.npz")))
+
+
+def load_fixture(path):
+    fx = np.load(path)
+    meta = json.loads(bytes(fx["meta"]).decode())
+    params = {k[len("param/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("param/")}
+    tt = None
+    if meta["target"]["kind"] == "gmm":
+        tt = {k: torch.from_numpy(fx["target/" + k].copy()) for k in ("loc", "scale", "mixture_weights")}
+    return fx, meta, params, tt
+
+
+def hip_problem(meta, params, tt, device="cuda:0"):
+    from sde_sampler_amd import problems
+
+    return problems.build(meta, params, tt, device=device)
+
+
+def close(a, b, atol, rtol=0.0):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b) <= atol + rtol * np.abs(b)

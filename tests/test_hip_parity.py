@@ -1,0 +1,134 @@
+"""GPU parity tests: the HIP trajectory engine (through the C ABI, sde_sampler_amd/libsdeh.so) against
+(a) the golden vectors captured from the reference and (b) the CPU oracle, on identical noise.
+
+Tolerances (fp32, parity mode; SURVEY.md 8d / section 0.6: even re-associating one product in the reference
+itself moves x_T by 5.8e-3 after 100 steps because the dynamics amplify 1-ulp changes):
+  per-row x_T, rnd : median |d| <= 1e-4 (x scale), max |d| <= 1e-2 (+1e-4 relative for large-magnitude rnd)
+  estimators       : |d| <= 1e-3 * max(1, |value|) at the fixtures' small batch sizes
+"""
+import math
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, close, hip_problem, load_fixture
+
+pytestmark = pytest.mark.gpu
+
+ROW_MAX, ROW_MEDIAN, ROW_RTOL = 1e-2, 1e-4, 1e-4
+
+
+def _row_check(name, got, ref):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    err = np.abs(got - ref)
+    scale = np.maximum(1.0, np.abs(ref))
+    assert np.all(err <= ROW_MAX * scale), f"{name}: max err {err.max():.3e} (at |ref|={np.abs(ref).flat[err.argmax()]:.3e})"
+    assert np.median(err / scale) <= ROW_MEDIAN, f"{name}: median err {np.median(err / scale):.3e}"
+
+
+def _est_check(name, got, ref):
+    assert abs(got - ref) <= 1e-3 * max(1.0, abs(ref)), f"{name}: {got} vs {ref}"
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_eval_matches_reference_golden(path):
+    fx, meta, params, tt = load_fixture(path)
+    prob = hip_problem(meta, params, tt)
+    x0 = torch.from_numpy(fx["x0"]).cuda()
+    noise = torch.from_numpy(fx["noise"]).cuda()
+    want_xs = "eval1/xs" in fx.files
+    r1 = prob.eval(x0, compute_weights=True, return_traj=want_xs, noise=noise)
+    _row_check("x_T", r1.samples.cpu().numpy(), fx["eval1/x_T"])
+    _est_check("lb_ito", r1.log_norm_const_preds["log_norm_const_lb_ito"], float(fx["eval1/log_norm_const_lb_ito"]))
+    _est_check("logZ_is", r1.log_norm_const_preds["log_norm_const_is"], float(fx["eval1/log_norm_const_is"]))
+    lv_ref = float(fx["eval1/lv_loss"])
+    assert abs(r1.metrics["eval/lv_loss"] - lv_ref) <= 2e-3 * max(1.0, abs(lv_ref))
+    w, w_ref = r1.weights.cpu().numpy(), fx["eval1/weights"]
+    assert w.shape == w_ref.shape and np.all(np.abs(w - w_ref) <= 2e-2 * np.maximum(w_ref, 1e-3) + 1e-4)
+    if want_xs:
+        xs = r1.xs.cpu().numpy()
+        assert xs.shape == fx["eval1/xs"].shape
+        assert np.array_equal(xs[0], fx["x0"])
+        assert np.array_equal(xs[-1], r1.samples.cpu().numpy())
+        _row_check("xs", xs, fx["eval1/xs"])
+    r2 = prob.eval(x0, compute_weights=False, return_traj=False, noise=noise)
+    _row_check("x_T(pass 2)", r2.samples.cpu().numpy(), fx["eval2/x_T"])
+    _est_check("lb", r2.log_norm_const_preds["log_norm_const_lb"], float(fx["eval2/log_norm_const_lb"]))
+    assert r2.weights is None and r2.xs is None
+    # the Ito integral only enters rnd, never the state
+    assert torch.equal(r1.samples, r2.samples)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_rnd_rows_match_oracle(path):
+    """Per-trajectory rnd (not part of Results) against the oracle on the same noise, both passes + train flags."""
+    from oracle import em_oracle as eo
+
+    fx, meta, params, tt = load_fixture(path)
+    prob = hip_problem(meta, params, tt)
+    oracle, _ = eo.problem_from_fixture(fx)
+    ts, x0, noise = torch.from_numpy(fx["ts"]), torch.from_numpy(fx["x0"]), torch.from_numpy(fx["noise"])
+    args = (prob.ts, x0.cuda(), prob.target.unnorm_log_prob, prob.second_log_prob)
+    with torch.no_grad():
+        for ito in (True, False):
+            kw = dict(compute_ito_int=ito, return_traj=False, noise=noise.cuda())
+            if meta["loss"]["kind"] == "time_reversal":
+                kw["train"] = False
+            _, rnd, _ = prob.loss.simulate(*args, **kw)
+            _row_check(f"rnd(ito={ito})", rnd.cpu().numpy(), fx["eval1/rnd" if ito else "eval2/rnd"])
+        # training-mode forward (log-variance form of the cost, no drift-divergence term), values only
+        for method in ("kl", "lv"):
+            _, rnd_o, _ = oracle.simulate(ts, x0, noise, train=True, compute_ito_int=method != "kl",
+                                          change_sde_ctrl=method == "lv", method=method)
+            prob.loss.method = method
+            kw = dict(compute_ito_int=method != "kl", change_sde_ctrl=method == "lv", noise=noise.cuda())
+            if meta["loss"]["kind"] == "time_reversal":
+                kw["train"] = True
+            _, rnd, _ = prob.loss.simulate(*args, **kw)
+            _row_check(f"train rnd({method})", rnd.cpu().numpy(), rnd_o.detach().numpy())
+            val, met = prob.loss(*args, noise=noise.cuda())
+            ref = float(fx[f"train_{method}/loss"])
+            assert abs(val.item() - ref) <= 2e-3 * max(1.0, abs(ref)), (method, val.item(), ref)
+            assert met["train/n_filtered_cumulative"] >= int(fx[f"train_{method}/n_filtered"])
+
+
+def test_training_with_autograd_fails_loudly():
+    from sde_sampler_amd._lib import SdehUnsupported
+
+    fx, meta, params, tt = load_fixture(GOLDEN[0])
+    prob = hip_problem(meta, params, tt)
+    x0 = torch.from_numpy(fx["x0"]).cuda()
+    with pytest.raises(SdehUnsupported):
+        prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+
+
+def test_unrecognised_callables_are_called_back():
+    """A terminal / initial log-density the engine cannot fuse is evaluated as given (device tensors)."""
+    fx, meta, params, tt = load_fixture([p for p in GOLDEN if "cfg2" in p][0])
+    prob = hip_problem(meta, params, tt)
+    x0 = torch.from_numpy(fx["x0"]).cuda()
+    noise = torch.from_numpy(fx["noise"]).cuda()
+    with torch.no_grad():
+        fused = prob.loss.eval(prob.ts, x0, prob.target.unnorm_log_prob, prob.prior.log_prob, noise=noise, return_traj=False)
+        called = prob.loss.eval(prob.ts, x0, lambda x: prob.target.unnorm_log_prob(x), lambda x: prob.prior.log_prob(x),
+                                noise=noise, return_traj=False)
+    assert torch.equal(fused.samples, called.samples)
+    a, b = fused.log_norm_const_preds, called.log_norm_const_preds
+    assert abs(a["log_norm_const_is"] - b["log_norm_const_is"]) < 1e-4
+    assert abs(a["log_norm_const_lb_ito"] - b["log_norm_const_lb_ito"]) < 1e-4
+
+
+def test_ragged_and_tiny_batches():
+    """Batch sizes that do not fill a wave / workgroup (1, 63, 65, 257) agree row-for-row with a full launch."""
+    fx, meta, params, tt = load_fixture([p for p in GOLDEN if "cfg4" in p][0])
+    prob = hip_problem(meta, params, tt)
+    T, d = fx["noise"].shape[0], fx["noise"].shape[2]
+    torch.manual_seed(3)
+    x0 = torch.randn(300, d).cuda()
+    noise = torch.randn(T, 300, d).cuda()
+    full = prob.eval(x0, compute_weights=True, noise=noise)
+    for b in (1, 63, 65, 257):
+        part = prob.eval(x0[:b], compute_weights=True, noise=noise[:, :b].contiguous())
+        assert torch.equal(part.samples, full.samples[:b]), b

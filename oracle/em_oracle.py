@@ -413,7 +413,7 @@ class Problem:
 
     def grid(self) -> Tensor:
         g = self.meta["grid"]
-        return timesteps(g["start"], g["end"], steps=g["steps"], rescale_t=g["rescale_t"])
+        return timesteps(g["start"], g["end"], steps=g["steps"], rescale_t=g.get("rescale_t"))
 
     # -- the three loops ------------------------------------------------------------------------
     def simulate(self, ts: Tensor, x: Tensor, noise: Tensor | None = None, *, train: bool = False,

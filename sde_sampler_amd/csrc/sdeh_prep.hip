@@ -250,11 +250,10 @@ __global__ __launch_bounds__(256) void reduce_partial_kernel(const float* __rest
   Stat v = {0.f, 0.f, 0.f, -INFINITY, 0.f, 0.f, 0.f};
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float r = rnd[i];
-    bool keep = true;
-    if (!isnan(max_rnd)) keep = isinf(max_rnd) ? isfinite(r) : (r < max_rnd);
-    Stat o;
-    if (keep) o = {1.f, r, 0.f, -r, 1.f, 1.f, 0.f};
-    else o = {0.f, 0.f, 0.f, -INFINITY, 0.f, 0.f, 1.f};
+    // losses/oc.py:50-58: NaN threshold = keep everything; +INF = keep finite rows; else keep rnd < max_rnd
+    const bool keep = (max_rnd != max_rnd) || (max_rnd > 3.0e38f ? fabsf(r) <= 3.4028235e38f : r < max_rnd);
+    const float kf = keep ? 1.0f : 0.0f;
+    const Stat o = {kf, keep ? r : 0.0f, 0.0f, keep ? -r : -INFINITY, kf, kf, 1.0f - kf};
     v = stat_merge(v, o);
   }
   v = block_reduce(v);

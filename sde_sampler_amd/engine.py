@@ -345,8 +345,8 @@ def importance_weights(rnd: torch.Tensor, log_weight_max: torch.Tensor) -> torch
 # ----------------------------------------------------------------------------------------------------------
 def merge_stats(stats: torch.Tensor) -> torch.Tensor:
     """Combines per-rank statistics [R, 8] into one [8] vector (Chan's parallel variance + rescaled exp-sums).
-    Pure tensor arithmetic on whatever device `stats` lives on (tested on CPU with gloo)."""
-    stats = stats.double()
+    Runs on the host in float64: the payload is 8 numbers per rank."""
+    stats = stats.detach().to("cpu", torch.float64).reshape(-1, 8)
     n, s, m2, mx, e1, e2, nf = (stats[:, i] for i in range(7))
     N = n.sum()
     valid = n > 0
@@ -355,20 +355,21 @@ def merge_stats(stats: torch.Tensor) -> torch.Tensor:
     M2 = (m2 + n * (mean_r - mean) ** 2).sum()
     m = torch.where(valid, mx, torch.full_like(mx, -math.inf)).max()
     scale = torch.where(valid, (mx - m).exp(), torch.zeros_like(mx))
-    out = torch.stack([N, s.sum(), M2, m, (e1 * scale).sum(), (e2 * scale * scale).sum(), nf.sum(),
-                       torch.zeros((), dtype=stats.dtype, device=stats.device)])
-    return out
+    return torch.stack([N, s.sum(), M2, m, (e1 * scale).sum(), (e2 * scale * scale).sum(), nf.sum(),
+                        torch.zeros((), dtype=torch.float64)])
 
 
 def all_gather_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
-    """The single collective of an evaluation: all-gather 8 floats per rank, then merge locally."""
+    """The single collective of an evaluation: all-gather 8 floats per rank (RCCL on GPU tensors, gloo on CPU
+    tensors), then merge on the host.  Without an initialised process group this is just the local merge."""
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return merge_stats(stats.reshape(1, 8))
-    bucket = [torch.empty_like(stats) for _ in range(dist.get_world_size(group))]
-    dist.all_gather(bucket, stats.contiguous(), group=group)
-    return merge_stats(torch.stack(bucket))
+        return merge_stats(stats)
+    world = dist.get_world_size(group)
+    bucket = torch.empty(world * 8, dtype=stats.dtype, device=stats.device)
+    dist.all_gather_into_tensor(bucket, stats.contiguous().reshape(8), group=group)
+    return merge_stats(bucket)
 
 
 def estimators_from_stats(v: torch.Tensor) -> dict:

@@ -111,7 +111,7 @@ class BaseOCLoss:
         running data-parallel).  The values are those of the reference formulas (neg_rnd.mean(), log mean exp,
         rnd.var()) over the GLOBAL batch; `samples` / `weights` stay rank-local shards."""
         stats = E.all_gather_stats(E.estimator_stats(rnd), group=group)
-        est = E.estimators_from_stats(stats.cpu())
+        est = E.estimators_from_stats(stats)
         metrics = {}
         if compute_weights:
             m = torch.as_tensor(est["log_weight_max"], dtype=torch.float32, device=rnd.device)

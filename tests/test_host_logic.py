@@ -1,0 +1,218 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/sdeh.h declares, the host
+classes keep the reference's plugin contract, the engine maps objects onto the ABI structs correctly, and the
+product path fails loudly (no CPU fallback, no oracle import)."""
+import ctypes
+import json
+import math
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, load_fixture
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_library_exports_every_declared_symbol():
+    from sde_sampler_amd import _lib as L
+
+    header = (ROOT / "include" / "sdeh.h").read_text()
+    declared = set(re.findall(r"\b(sdeh_[a-z_0-9]+)\s*\(", header))
+    assert declared, "no prototypes found in include/sdeh.h"
+    assert declared == set(L.PROTOTYPES), (declared ^ set(L.PROTOTYPES))
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sdeh_abi_version() == L.SDEH_ABI_VERSION == int(re.search(r"#define SDEH_ABI_VERSION (\d+)", header).group(1))
+    assert int(re.search(r"#define SDEH_MAX_HIDDEN (\d+)", header).group(1)) == L.SDEH_MAX_HIDDEN
+    assert int(re.search(r"#define SDEH_REDUCE_SCRATCH (\d+)", header).group(1)) == L.SDEH_REDUCE_SCRATCH
+
+
+def test_abi_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device (no compute calls are made here)."""
+    from sde_sampler_amd import _lib as L
+
+    lib = L.load()
+    plan = ctypes.c_void_p()
+    assert lib.sdeh_plan_create(None, ctypes.byref(plan)) == -1
+    bad = L.SdehPlanDesc(dim=0, channels=64, max_hidden=2, max_steps=10, max_components=0, device=0)
+    assert lib.sdeh_plan_create(ctypes.byref(bad), ctypes.byref(plan)) == -1
+    assert b"dim=0" in lib.sdeh_last_error()
+    wide = L.SdehPlanDesc(dim=2, channels=128, max_hidden=2, max_steps=10, max_components=0, device=0)
+    assert lib.sdeh_plan_create(ctypes.byref(wide), ctypes.byref(plan)) == -2  # SDEH_ERR_UNSUPPORTED
+    big = L.SdehPlanDesc(dim=100, channels=64, max_hidden=2, max_steps=10, max_components=0, device=0)
+    assert lib.sdeh_plan_create(ctypes.byref(big), ctypes.byref(plan)) == -2
+    assert lib.sdeh_simulate_fwd(None, None, None, 1, None, 1, None, 0, 0, 0, None, None, None, None) == -1
+    assert lib.sdeh_reduce_estimators(None, 1, 0.0, None, None, None) == -1
+    with pytest.raises(L.SdehUnsupported):
+        L.check(-2)
+    with pytest.raises(L.SdehError):
+        L.check(-1)
+
+
+def test_struct_layout_matches_header():
+    """sizeof of the ctypes mirrors == what hipcc/gcc compute for include/sdeh.h."""
+    from sde_sampler_amd import _lib as L
+
+    src = '#include <stdio.h>\n#include "sdeh.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(SdehDensity), ' \
+          'sizeof(SdehTimeEmbed), sizeof(SdehFourierMLP), sizeof(SdehProblem), sizeof(SdehPlanDesc));return 0;}\n'
+    exe = Path(os.environ.get("TMPDIR", "/tmp")) / "sdeh_sizeof"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", str(ROOT / "include"), "-o", str(exe)], input=src.encode(), check=True)
+    sizes = list(map(int, subprocess.run([str(exe)], capture_output=True, check=True).stdout.split()))
+    assert sizes == [ctypes.sizeof(t) for t in (L.SdehDensity, L.SdehTimeEmbed, L.SdehFourierMLP, L.SdehProblem, L.SdehPlanDesc)]
+
+
+def test_product_never_imports_oracle_and_fails_loudly_without_library(tmp_path):
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import sde_sampler_amd.losses.oc, sde_sampler_amd.problems, sde_sampler_amd.engine\n"
+        "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'product imported the oracle'\n"
+        "from sde_sampler_amd import _lib\n"
+        "try:\n    _lib.load()\nexcept _lib.SdehLibraryError as e:\n    print('LOUD:', e)\nelse:\n    raise SystemExit('no error')\n"
+    ) % str(ROOT)
+    env = dict(os.environ, SDEH_LIBRARY=str(tmp_path / "missing.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "LOUD:" in out.stdout and "no CPU fallback" in out.stdout
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for path in list((ROOT / "sde_sampler_amd").rglob("*.py")):
+        assert not pat.search(path.read_text()), f"{path} imports the oracle"
+
+
+def test_cpu_tensors_are_rejected():
+    from sde_sampler_amd import problems
+
+    prob = problems.build(problems.baseline_spec("cfg1_dw_dis_lv"))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        prob.eval(torch.zeros(4, 1))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_engine_introspection(path):
+    """Objects -> SdehProblem mapping for every golden configuration (kinds, sizes, scalars)."""
+    from sde_sampler_amd import _lib as L
+    from sde_sampler_amd import engine as E
+    from sde_sampler_amd import problems
+    from sde_sampler_amd.losses.oc import _resolve_gaussian_log_prob, _resolve_terminal
+
+    fx, meta, params, tt = load_fixture(path)
+    prob = problems.build(meta, params, tt)
+    keep = E._Keep()
+    target, clip = _resolve_terminal(prob.target.unnorm_log_prob)
+    second = _resolve_gaussian_log_prob(prob.second_log_prob)
+    assert target is prob.target and clip is None and second is not None
+    ref_prior = prob.loss._reference_prior() if hasattr(prob.loss, "_reference_prior") else None
+    pr = prob.loss.engine.build_problem(loss_kind=prob.loss._LOSS_KIND, generative_ctrl=prob.ctrl, sde=prob.sde, flags=0,
+                                        device=torch.device("cpu"), keep=keep, terminal_target=target, second=second,
+                                        reference_prior=ref_prior, alpha=getattr(prob.loss, "alpha", 0.0),
+                                        sigma=getattr(prob.loss, "sigma", 0.0))
+    kinds = {"clipped": L.CTRL_CLIPPED, "score": L.CTRL_SCORE, "lerp": L.CTRL_LERP, "lerp_target": L.CTRL_LERP_TARGET,
+             "lerp_prior": L.CTRL_LERP_PRIOR}
+    assert pr.ctrl_kind == kinds[meta["ctrl"]["kind"]]
+    assert pr.base_model.dim == meta["target"]["dim"] and pr.base_model.channels == 64
+    assert pr.base_model.n_hidden == meta["net"]["num_layers"] - 2
+    assert pr.base_model.activation == {"gelu": 0, "silu": 1, "relu": 2}[meta["net"]["activation"]]
+    assert pr.base_model.timestep_embed.n_hidden == 1 and pr.base_model.timestep_embed.dim_out == 64
+    if meta["ctrl"]["kind"] != "clipped":
+        assert pr.score_model.n_hidden == 3 and pr.score_model.dim_out == meta["ctrl"]["gamma_dim"]
+        assert pr.clip_score == pytest.approx(meta["ctrl"]["clip_score"])
+    assert pr.clip_model == pytest.approx(meta["ctrl"]["clip_model"])
+    sde = meta["sde"]
+    assert pr.sde_kind == (0 if sde is None else {"vp": 1, "const_ou": 2, "scaled_bm": 2}[sde["kind"]])
+    if sde and sde["kind"] == "vp":
+        assert (pr.vp_beta_min, pr.vp_beta_max) == pytest.approx((sde["beta_min"], sde["beta_max"]))
+    if sde and sde["kind"] == "scaled_bm":
+        assert pr.ou_drift == 0.0 and pr.ou_diff == pytest.approx(sde["diff_coeff"])
+    tk = {"gmm": L.DENS_GMM, "double_well": L.DENS_MULTI_WELL, "multi_well": L.DENS_MULTI_WELL, "funnel": L.DENS_FUNNEL,
+          "iso_gauss": L.DENS_DIAG_GAUSS}[meta["target"]["kind"]]
+    assert pr.target.kind == tk and pr.target.dim == meta["target"]["dim"]
+    assert pr.second.kind == L.DENS_DIAG_GAUSS
+    if meta["loss"].get("reference_ctrl"):
+        assert pr.prior.kind == L.DENS_DIAG_GAUSS
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in keep)
+
+
+def test_host_modules_reproduce_reference_values():
+    """The host-side nn.Modules (parameter containers) define the same functions as the reference: control output,
+    log-densities and scores against the vectors captured from the reference."""
+    from sde_sampler_amd import problems
+
+    for path in GOLDEN:
+        fx, meta, params, tt = load_fixture(path)
+        prob = problems.build(meta, params, tt)
+        x = torch.from_numpy(fx["kat/x"])
+        np.testing.assert_allclose(prob.target.unnorm_log_prob(x).detach().numpy(), fx["kat/target_unnorm_log_prob"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(prob.target.score(x.clone()).detach().numpy(), fx["kat/target_score"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(prob.second_log_prob(x).detach().numpy(), fx["kat/second_log_prob"], rtol=2e-5, atol=2e-5)
+        assert torch.equal(prob.ts, torch.from_numpy(fx["ts"]))
+
+
+def test_loss_contract():
+    from sde_sampler_amd.losses.oc import BaseOCLoss, ExponentialIntegratorSDELoss, ReferenceSDELoss, TimeReversalLoss
+    from sde_sampler_amd.utils.common import Results
+
+    with pytest.raises(ValueError, match="Unknown loss method"):
+        TimeReversalLoss(generative_ctrl=None, method="foo")
+    with pytest.raises(ValueError, match="single trajectory"):
+        ReferenceSDELoss(generative_ctrl=None, method="lv_traj", traj_per_sample=1)
+    loss = ExponentialIntegratorSDELoss(generative_ctrl=None, alpha=1.0, sigma=2.0, method="lv", max_rnd=1e8, unknown_kw=1)
+    assert loss.state_dict() == {"n_filtered": 0}
+    loss.load_state_dict({"n_filtered": 7})
+    assert loss.n_filtered == 7 and (loss.alpha, loss.sigma) == (1.0, 2.0)
+    rnd = torch.tensor([[1.0], [float("nan")], [2e9], [3.0]])
+    val, met = loss.compute_loss(rnd)
+    assert val.item() == pytest.approx(torch.tensor([1.0, 3.0]).var().item()) and met["train/n_filtered_cumulative"] == 9
+    kl = TimeReversalLoss(generative_ctrl=None, method="kl")
+    val, met = kl.compute_loss(rnd)
+    assert val.item() == pytest.approx((1.0 + 2e9 + 3.0) / 3) and met["train/n_filtered_cumulative"] == 1
+    lvt = TimeReversalLoss(generative_ctrl=None, method="lv_traj", traj_per_sample=2)
+    r2 = torch.tensor([[1.0], [2.0], [3.0], [6.0]])
+    val, _ = lvt.compute_loss(r2)
+    assert val.item() == pytest.approx(((1 - 3) ** 2 / 2 + (2 - 6) ** 2 / 2) / 2)
+    assert Results()._fields == ("samples", "weights", "log_norm_const_preds", "expectation_preds", "ts", "xs", "metrics", "plots")
+    assert issubclass(TimeReversalLoss, BaseOCLoss)
+
+
+def test_time_grids():
+    from sde_sampler_amd.utils.common import get_timesteps
+
+    assert torch.equal(get_timesteps(0.0, 1.0, steps=100), torch.linspace(0, 1, 101))
+    ts = get_timesteps(0.0, 12.8, dt=0.05, rescale_t="cosine")
+    assert ts.shape == (258,) and ts[0] == 0 and abs(ts[-1].item() - 12.8) < 1e-4 and (ts[1:] >= ts[:-1]).all()
+    q = get_timesteps(0.0, torch.tensor(2.0), steps=10, rescale_t="quad")
+    assert q.shape == (11,) and q[-1] == 2.0
+    with pytest.raises(ValueError):
+        get_timesteps(0.0, 1.0)
+    with pytest.raises(ValueError):
+        get_timesteps(0.0, 1.0, steps=3, rescale_t="nope")
+
+
+def test_merge_stats_matches_direct_computation():
+    from sde_sampler_amd import engine as E
+
+    torch.manual_seed(0)
+    rnd = torch.randn(1000, dtype=torch.float64) * 3 + 20
+    chunks = [rnd[:100], rnd[100:101], rnd[101:700], rnd[700:]]
+
+    def stats(v):
+        neg = -v
+        m = neg.max()
+        return torch.stack([torch.tensor(float(len(v))), neg.sum(), ((v - v.mean()) ** 2).sum(), m, (neg - m).exp().sum(),
+                            (2 * (neg - m)).exp().sum(), torch.tensor(0.0), torch.tensor(0.0)])
+
+    merged = E.merge_stats(torch.stack([stats(c) for c in chunks] + [torch.tensor([0, 0, 0, -math.inf, 0, 0, 3.0, 0])]))
+    est = E.estimators_from_stats(merged)
+    neg = -rnd
+    m = neg.max()
+    w = (neg - m).exp()
+    assert est["n"] == 1000 and est["n_filtered"] == 3
+    assert est["mean_neg_rnd"] == pytest.approx(neg.mean().item(), abs=1e-10)
+    assert est["var_rnd"] == pytest.approx(rnd.var().item(), rel=1e-10)
+    assert est["log_norm_const_is"] == pytest.approx((w.mean().log() + m).item(), abs=1e-10)
+    assert est["ess"] == pytest.approx((w.sum() ** 2 / (w**2).sum()).item(), rel=1e-10)

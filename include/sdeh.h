@@ -69,11 +69,16 @@ enum {
   SDEH_FLAG_REFERENCE_CTRL = 64  /* ReferenceSDELoss.reference_ctrl = sigma(t) * prior.score(x) (solver/oc.py:305-306) */
 };
 
+/* GMM only: scale[k,d] == scale[0,d] for every component k (true for every named mixture of the reference,
+ * distr/gauss.py:14-63).  Selects a cheaper evaluation (one table word per (k,d)); results are undefined if the
+ * promise is false -- the Python binding checks the tensor once per (tensor, version) before setting it. */
+#define SDEH_DENS_FLAG_SHARED_SCALE 1
+
 typedef struct {
   int32_t kind;         /* SdehDensityKind */
   int32_t dim;
   int32_t n_components; /* GMM: K; MULTI_WELL: n_double_wells */
-  int32_t reserved;
+  int32_t flags;        /* SDEH_DENS_FLAG_* : promises of the caller about the parameter values */
   float log_norm_const; /* Distribution.log_norm_const (0 when None) -- added by unnorm_log_prob where the reference does */
   float p0;             /* MULTI_WELL: separation;  FUNNEL: variance of x_0 */
   float p1;             /* MULTI_WELL: shift */

@@ -22,6 +22,7 @@ DENS_NONE, DENS_GMM, DENS_DIAG_GAUSS, DENS_MULTI_WELL, DENS_FUNNEL = 0, 1, 2, 3,
 ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2
 FLAG_TRAIN, FLAG_ITO, FLAG_CHANGE_SDE_CTRL, FLAG_INIT_LOGP = 1, 2, 4, 8
 FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL = 16, 32, 64
+DENS_FLAG_SHARED_SCALE = 1
 
 STATUS = {0: "SDEH_OK", -1: "SDEH_ERR_INVALID", -2: "SDEH_ERR_UNSUPPORTED", -3: "SDEH_ERR_HIP", -4: "SDEH_ERR_CAPACITY"}
 
@@ -30,7 +31,7 @@ fp = C.c_void_p  # device pointers travel as integers
 
 class SdehDensity(C.Structure):
     _fields_ = [
-        ("kind", C.c_int32), ("dim", C.c_int32), ("n_components", C.c_int32), ("reserved", C.c_int32),
+        ("kind", C.c_int32), ("dim", C.c_int32), ("n_components", C.c_int32), ("flags", C.c_int32),
         ("log_norm_const", C.c_float), ("p0", C.c_float), ("p1", C.c_float), ("p2", C.c_float),
         ("loc", fp), ("scale", fp), ("mixture_weights", fp),
     ]

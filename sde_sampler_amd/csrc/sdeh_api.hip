@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -15,17 +16,19 @@ int launch_prep(const PrepArgs& p, hipStream_t stream);
 int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int nb, float* out, hipStream_t stream);
 int launch_weights(const float* rnd, long long n, const float* mx, float* w, hipStream_t stream);
 
-#define SDEH_DECL(dp, pad) int launch_traj_dp##dp##_c64_p##pad(const TrajArgs& a, hipStream_t stream);
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act) int launch_traj_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 
 struct Variant {
   int dp;
   bool pad;
+  int loss, ctrl, tgt, gmm, act;  // -1 = run-time switch
   TrajLauncher fn;
+  const char* name;
 };
 static const Variant kVariants[] = {
-#define SDEH_DECL(dp, pad) {dp, pad != 0, &launch_traj_dp##dp##_c64_p##pad},
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act) {dp, pad != 0, loss, ctrl, tgt, gmm, act, &launch_traj_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 };
@@ -39,19 +42,34 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+static bool is_generic(const Variant& v) { return v.loss < 0 && v.ctrl < 0 && v.tgt < 0 && v.gmm < 0 && v.act < 0; }
+
+// generic variant for dimension d: the exact one when compiled, else the smallest padded one
 static const Variant* pick_variant(int d) {
   const Variant* best = nullptr;
   for (const Variant& v : kVariants) {
+    if (!is_generic(v)) continue;
     if (!v.pad && v.dp == d) return &v;
     if (v.pad && v.dp >= d && (best == nullptr || v.dp < best->dp)) best = &v;
   }
   return best;
 }
 
+// specialised variant whose compile-time choices all match the problem, if any
+static const Variant* pick_specialised(int d, int loss, int ctrl, int tgt, int gmm, int act) {
+  for (const Variant& v : kVariants) {
+    if (is_generic(v) || v.pad || v.dp != d) continue;
+    if ((v.loss < 0 || v.loss == loss) && (v.ctrl < 0 || v.ctrl == ctrl) && (v.tgt < 0 || v.tgt == tgt) &&
+        (v.gmm < 0 || v.gmm == gmm) && (v.act < 0 || v.act == act))
+      return &v;
+  }
+  return nullptr;
+}
+
 static int align4(int v) { return (v + 3) & ~3; }
 
 // Workspace layout for one problem geometry.
-static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g) {
+static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g, bool shared_scale = false) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.dp = dp; L.c = c; L.ot = c / 32; L.otd = row_tiles(dp); L.r_in = mregs(dp);
@@ -62,14 +80,35 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   L.w_out = o; o += (c / 2) * L.otd * 64;
   L.b_hid = o; o += n_hidden * c;
   L.b_out = o; o += L.otd * 32;
+  o = align4(o);
+  L.gmm_row = 2 * ((dp + 1) & ~1);
+  const int k_rows = (k_max + 1) & ~1;  // even number of table rows (padding row: logit -inf)
+  const int gmm_floats = 2 * k_rows * L.gmm_row + align4(k_rows);
+  // LDS budget: image + [K][256] logit scratch must stay within 160 KiB
+  L.gmm_lds = (k_max > 0 && ((size_t)(o + gmm_floats) + (size_t)k_max * 256) * sizeof(float) <= 160 * 1024) ? 1 : 0;
+  if (L.gmm_lds && shared_scale) {
+    // shared-scale tables: one word per (k,d), rows of 4*ceil(dp/4) floats, then the two per-coordinate vectors
+    const int rs = 4 * ((dp + 3) / 4);
+    L.gmm_lds = 2;
+    L.gmm_row = rs;
+    L.gmm_lg = o; o += k_rows * rs;
+    L.gmm_sc = o; o += k_rows * rs + 2 * rs;
+    L.gmm_c = o; o += align4(k_rows);
+  } else if (L.gmm_lds) {
+    L.gmm_lg = o; o += k_rows * L.gmm_row;
+    L.gmm_sc = o; o += k_rows * L.gmm_row;
+    L.gmm_c = o; o += align4(k_rows);
+  }
   L.lds_floats = align4(o);
   o = L.lds_floats;
   L.coef = o; o += t_max * kCoefStride;
   L.emb = o; o += t_max * c;
   L.gam = o; o += align4(t_max * g);
-  L.gmm_lg = o; o += k_max * dp * 2;
-  L.gmm_sc = o; o += k_max * dp * 2;
-  L.gmm_c = o; o += align4(k_max);
+  if (!L.gmm_lds) {
+    L.gmm_lg = o; o += k_rows * L.gmm_row;
+    L.gmm_sc = o; o += k_rows * L.gmm_row;
+    L.gmm_c = o; o += align4(k_rows);
+  }
   for (int i = 0; i < 3; ++i) { L.dg[i] = o; o += align4(2 * dp + 1); }
   L.total = align4(o);
   return L;
@@ -259,7 +298,8 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
     return fail(SDEH_ERR_CAPACITY, "simulate_fwd: GMM with %d components > plan max %d", k, plan->desc.max_components);
 
   const Variant* v = plan->variant;
-  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g);
+  const bool shared = pr->target.kind == SDEH_DENS_GMM && (pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE);
+  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared);
   if ((size_t)L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd: workspace too small");
 
   hipStream_t st = (hipStream_t)stream;
@@ -285,6 +325,9 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
   A.second = {pr->second.kind, pr->second.n_components, pr->second.log_norm_const, pr->second.p0, pr->second.p1};
   A.seed = seed; A.offset = offset;
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  static const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing aid: force the generic variants
+  const Variant* sv = no_spec ? nullptr : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds, net.activation);
+  if (sv != nullptr && sv->dp == v->dp) v = sv;
   rc = v->fn(A, st);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd: trajectory kernel launch failed (dp=%d)", v->dp);

@@ -52,8 +52,12 @@ struct WsLayout {
   int coef;       // [T][16]
   int emb;        // [T][c]  (M order; FourierMLP.timestep_embed(t) + input_embed.bias)
   int gam;        // [T][g]  clip(score_model(t), clip_model)
-  int gmm_lg;     // [K][dp][2]  (mu, 1/(2 sigma^2))
-  int gmm_sc;     // [K][dp][2]  (mu/sigma^2, 1/sigma^2)
+  // GMM tables: rows of `gmm_row` floats (dp rounded up to even pairs, so rows are float4-aligned).  They live
+  // inside the LDS image when they fit (gmm_lds = 1: broadcast ds_read_b128, deep VGPR prefetch), else in the
+  // global part of the workspace (scalar loads).
+  int gmm_lds, gmm_row;
+  int gmm_lg;     // [K][gmm_row/2][2]  (mu, 1/(2 sigma^2))
+  int gmm_sc;     // [K][gmm_row/2][2]  (mu/sigma^2, 1/sigma^2)
   int gmm_c;      // [K]  log_softmax(log w)_k - sum_d (log sigma_kd + 0.5 log 2pi)
   int dg[3];      // diag-gauss tables for target / prior / second: [dp][2] (mu, 1/sigma^2) then 1 float const
   int total;

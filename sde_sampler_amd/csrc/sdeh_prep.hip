@@ -171,17 +171,37 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
   // GMM tables (distr/gauss.py:123-135 via torch.distributions.MixtureSameFamily)
   if (pr.target.kind == SDEH_DENS_GMM) {
     const SdehDensity& G = pr.target;
-    const int K = G.n_components, dp = L.dp;
-    for (int e = gid; e < K * dp; e += stride) {
-      const int k = e / dp, j = e % dp;
-      const bool ok = j < G.dim;
-      const float mu = ok ? G.loc[(size_t)k * G.dim + j] : 0.0f;
-      const float sg = ok ? G.scale[(size_t)k * G.dim + j] : 1.0f;
-      const float iv = ok ? 1.0f / (sg * sg) : 0.0f;
-      ws[L.gmm_lg + 2 * e] = mu;
-      ws[L.gmm_lg + 2 * e + 1] = 0.5f * iv;
-      ws[L.gmm_sc + 2 * e] = mu * iv;
-      ws[L.gmm_sc + 2 * e + 1] = iv;
+    const int K = G.n_components;
+    const int K2 = (K + 1) & ~1;  // the LDS paths consume rows in pairs; the padding row has logit -inf
+    if (L.gmm_lds == 2) {  // shared-scale tables (SDEH_DENS_FLAG_SHARED_SCALE)
+      const int rs = L.gmm_row;
+      for (int e = gid; e < K2 * rs; e += stride) {
+        const int k = e / rs, j = e % rs;
+        const bool ok = j < G.dim && k < K;
+        const float mu = ok ? G.loc[(size_t)k * G.dim + j] : 0.0f;
+        const float sg = ok ? G.scale[j] : 1.0f;
+        ws[L.gmm_lg + e] = ok ? mu * (0.70710678118654752440f / sg) : 0.0f;
+        ws[L.gmm_sc + e] = ok ? mu / (sg * sg) : 0.0f;
+      }
+      for (int j = gid; j < rs; j += stride) {
+        const bool ok = j < G.dim;
+        const float sg = ok ? G.scale[j] : 1.0f;
+        ws[L.gmm_sc + K2 * rs + j] = ok ? 0.70710678118654752440f / sg : 0.0f;
+        ws[L.gmm_sc + K2 * rs + rs + j] = ok ? 1.0f / (sg * sg) : 0.0f;
+      }
+    } else {
+      const int npair = L.gmm_row / 2;
+      for (int e = gid; e < K2 * npair; e += stride) {
+        const int k = e / npair, j = e % npair;
+        const bool ok = j < G.dim && k < K;
+        const float mu = ok ? G.loc[(size_t)k * G.dim + j] : 0.0f;
+        const float sg = ok ? G.scale[(size_t)k * G.dim + j] : 1.0f;
+        const float iv = ok ? 1.0f / (sg * sg) : 0.0f;
+        ws[L.gmm_lg + 2 * e] = mu;
+        ws[L.gmm_lg + 2 * e + 1] = 0.5f * iv;
+        ws[L.gmm_sc + 2 * e] = mu * iv;
+        ws[L.gmm_sc + 2 * e + 1] = iv;
+      }
     }
     for (int k = gid; k < K; k += stride) {
       float wsum = 0.0f;
@@ -191,6 +211,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
       for (int j = 0; j < G.dim; ++j) c -= logf(G.scale[(size_t)k * G.dim + j]) + 0.91893853320467274178f;
       ws[L.gmm_c + k] = c;
     }
+    if (gid == 0 && K2 > K) ws[L.gmm_c + K] = -INFINITY;
   }
   pack_diag_gauss(ws + L.dg[0], pr.target, L.dp, gid, stride);
   pack_diag_gauss(ws + L.dg[1], pr.prior, L.dp, gid, stride);

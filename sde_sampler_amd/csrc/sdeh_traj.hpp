@@ -8,11 +8,19 @@
 // everything they call per step (models/reparam.py forward, models/mlp.py:114-122, eq/sdes.py coefficient
 // functions, distr/*.py scores, torch.randn_like) and the terminal log-densities (oc.py:225,337,449-450).
 #pragma once
+#include <type_traits>
+
 #include "sdeh_common.hpp"
 
 namespace sdeh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Ablation switches for tools/ablate.py (never set in the shipped library): 1 = no MLP, 2 = no target score,
+// 4 = no Philox/Box-Muller, 8 = no activation.  Each stub keeps its consumers live (guide rule 17).
+#ifndef SDEH_ABL
+#define SDEH_ABL 0
+#endif
 // Tables that are uniform across the wave are read through the constant address space so that hipcc emits
 // scalar loads (s_load_dwordx*) and feeds them to the VALU as SGPR operands.
 typedef const float __attribute__((address_space(4))) * cfp;
@@ -55,6 +63,7 @@ __device__ __forceinline__ float act_relu(float v) { return fmaxf(v, 0.0f); }
 
 template <int N>
 __device__ __forceinline__ void activate(f32x16 (&a)[N], f32x16 (&b)[N], int act) {
+  if constexpr (SDEH_ABL & 8) return;
   if (act == SDEH_ACT_GELU_ERF) {
 #pragma unroll
     for (int t = 0; t < N; ++t)
@@ -180,13 +189,14 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ lds, const
 // Returns the log-density; when SCORE, also d/dx = sum_k r_k (mu_k - x)/sigma_k^2 (what the reference obtains
 // by autograd, distr/base.py:130-137).  Logits are parked in LDS between the two passes.
 template <int DP, bool SCORE>
-__device__ __forceinline__ float gmm_eval(const float* ws, const WsLayout& L, int K, float* __restrict__ lg_lds,
-                                          const float (&x)[DP], float (&score)[DP]) {
+__device__ __forceinline__ float gmm_eval_smem(const float* ws, const WsLayout& L, int K, float* __restrict__ lg_lds,
+                                               const float (&x)[DP], float (&score)[DP]) {
+  const int npair = L.gmm_row / 2;
   cf2p plg = as_const2(ws + L.gmm_lg);
   cfp pc = as_const(ws + L.gmm_c);
   float m = -INFINITY;
   for (int k = 0; k < K; ++k) {
-    cf2p p = plg + k * DP;
+    cf2p p = plg + k * npair;
     float acc = 0.0f;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
@@ -204,7 +214,7 @@ __device__ __forceinline__ float gmm_eval(const float* ws, const WsLayout& L, in
 #pragma unroll
     for (int d = 0; d < DP; ++d) P[d] = Q[d] = 0.0f;
     for (int k = 0; k < K; ++k) {
-      cf2p p = psc + k * DP;
+      cf2p p = psc + k * npair;
       const float e = __expf(lg_lds[k * 256] - m);
       z += e;
 #pragma unroll
@@ -220,6 +230,177 @@ __device__ __forceinline__ float gmm_eval(const float* ws, const WsLayout& L, in
     for (int k = 0; k < K; ++k) z += __expf(lg_lds[k * 256] - m);
   }
   return m + __logf(z);
+}
+
+// Same computation with the tables resident in LDS: every lane reads the same address (broadcast ds_read_b128,
+// two (k,d) pairs per read), so the loads can be prefetched deep into VGPRs -- scalar loads cannot (SMEM returns
+// out of order, ~100 SGPRs, and with one wave per SIMD nothing hides their L2 latency).
+// ---- LDS-resident tables: every lane reads the same address (broadcast ds_read_b128).  Rows are streamed
+// through two register buffers holding half a row each; the next half-row is in flight while the current one is
+// consumed.  hipcc does not software-pipeline LDS reads by itself (it emits read / s_waitcnt lgkmcnt(0) / use),
+// so the order is pinned with scheduling fences.  Scalar loads cannot be pipelined this deep (SMEM returns out of
+// order, ~100 SGPRs) and with one wave per SIMD nothing else hides their L2 latency.  Tables hold an even
+// number of rows; a padding row carries logit -inf.
+template <int N>
+__device__ __forceinline__ void load_f4(const float4* __restrict__ p, float4 (&q)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) q[j] = p[j];
+}
+
+// Streams `rows` rows of NQ float4 each.  f(row, first_pair_index, buffer) is called for each half row.
+template <int NQ, class F>
+__device__ __forceinline__ void stream_rows(const float4* __restrict__ tab, int rows, F&& f) {
+  constexpr int NA = (NQ + 1) / 2, NB = NQ - NA;
+  float4 qa[NA], qb[NB > 0 ? NB : 1];
+  load_f4<NA>(tab, qa);
+  for (int k = 0; k < rows; ++k) {
+    const float4* __restrict__ row = tab + k * NQ;
+    if constexpr (NB > 0) load_f4<NB>(row + NA, qb);
+    SDEH_FENCE();
+    f(k, std::integral_constant<int, 0>{}, qa);
+    SDEH_FENCE();
+    load_f4<NA>(tab + (k + 1 < rows ? k + 1 : 0) * NQ, qa);
+    SDEH_FENCE();
+    if constexpr (NB > 0) f(k, std::integral_constant<int, NA>{}, qb);
+    SDEH_FENCE();
+  }
+}
+
+// General mixture: rows of (mu, 1/(2 sigma^2)) pairs and (mu/sigma^2, 1/sigma^2) pairs, two pairs per float4.
+template <int DP, bool SCORE>
+__device__ __forceinline__ float gmm_eval_lds(const float* __restrict__ lds, const WsLayout& L, int K,
+                                              float* __restrict__ lg_lds, const float (&x)[DP], float (&score)[DP]) {
+  constexpr int NQ = (DP + 1) / 2;
+  const float* __restrict__ pc = lds + L.gmm_c;
+  const int K2 = (K + 1) & ~1;
+  float m = -INFINITY, acc0 = 0.0f, acc1 = 0.0f;
+  stream_rows<NQ>(reinterpret_cast<const float4*>(lds + L.gmm_lg), K2, [&](int k, auto J0, const auto& q) {
+    constexpr int j0 = decltype(J0)::value;
+    constexpr int n = j0 == 0 ? (NQ + 1) / 2 : NQ - (NQ + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      const int dd = 2 * (j0 + j);
+      const float t0 = x[dd] - q[j].x;
+      acc0 = fmaf(t0 * t0, q[j].y, acc0);
+      if (dd + 1 < DP) {
+        const float t1 = x[dd + 1] - q[j].z;
+        acc1 = fmaf(t1 * t1, q[j].w, acc1);
+      }
+    }
+    if (j0 != 0 || NQ == 1) {  // row complete
+      const float l = pc[k] - (acc0 + acc1);
+      lg_lds[k * 256] = l;
+      m = fmaxf(m, l);
+      acc0 = acc1 = 0.0f;
+    }
+  });
+  float z = 0.0f;
+  if constexpr (SCORE) {
+    float P[DP], Q[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) P[d] = Q[d] = 0.0f;
+    float e = 0.0f;
+    stream_rows<NQ>(reinterpret_cast<const float4*>(lds + L.gmm_sc), K2, [&](int k, auto J0, const auto& q) {
+      constexpr int j0 = decltype(J0)::value;
+      constexpr int n = j0 == 0 ? (NQ + 1) / 2 : NQ - (NQ + 1) / 2;
+      if (j0 == 0) {
+        e = __expf(lg_lds[k * 256] - m);
+        z += e;
+      }
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        const int dd = 2 * (j0 + j);
+        P[dd] = fmaf(e, q[j].x, P[dd]);
+        Q[dd] = fmaf(e, q[j].y, Q[dd]);
+        if (dd + 1 < DP) {
+          P[dd + 1] = fmaf(e, q[j].z, P[dd + 1]);
+          Q[dd + 1] = fmaf(e, q[j].w, Q[dd + 1]);
+        }
+      }
+    });
+    const float iz = 1.0f / z;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) score[d] = (P[d] - x[d] * Q[d]) * iz;
+  } else {
+    for (int k = 0; k < K; ++k) z += __expf(lg_lds[k * 256] - m);
+  }
+  return m + __logf(z);
+}
+
+// Mixture whose scale does not depend on the component (sigma_kd = sigma_d; every named mixture of the
+// reference, distr/gauss.py:14-63): with y_d = x_d / (sqrt2 sigma_d) the logit is c_k - sum_d (y_d - m_kd)^2 and
+// sum_k r_k / sigma_d^2 = 1 / sigma_d^2, so each (k,d) costs one table word and 2 + 1 VALU ops instead of 4 and 3 + 2.
+// Tables: gmm_lg rows m_kd = mu_kd / (sqrt2 sigma_d); gmm_sc rows mu_kd / sigma_d^2; then 1/(sqrt2 sigma_d), 1/sigma_d^2.
+template <int DP, bool SCORE>
+__device__ __forceinline__ float gmm_eval_lds_shared(const float* __restrict__ lds, const WsLayout& L, int K,
+                                                     float* __restrict__ lg_lds, const float (&x)[DP],
+                                                     float (&score)[DP]) {
+  constexpr int NQ = (DP + 3) / 4;
+  const float* __restrict__ pc = lds + L.gmm_c;
+  const float* __restrict__ vec = lds + L.gmm_sc + ((K + 1) & ~1) * (NQ * 4);  // [2][NQ*4]
+  const int K2 = (K + 1) & ~1;
+  float y[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) y[d] = x[d] * vec[d];
+  float m = -INFINITY, acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  stream_rows<NQ>(reinterpret_cast<const float4*>(lds + L.gmm_lg), K2, [&](int k, auto J0, const auto& q) {
+    constexpr int j0 = decltype(J0)::value;
+    constexpr int n = j0 == 0 ? (NQ + 1) / 2 : NQ - (NQ + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < n; ++j) {
+      const int dd = 4 * (j0 + j);
+      const float qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (dd + i < DP) {
+          const float t = y[dd + i] - qq[i];
+          acc[i] = fmaf(t, t, acc[i]);
+        }
+    }
+    if (j0 != 0 || NQ == 1) {
+      const float l = pc[k] - ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      lg_lds[k * 256] = l;
+      m = fmaxf(m, l);
+      acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
+    }
+  });
+  float z = 0.0f;
+  if constexpr (SCORE) {
+    float P[DP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) P[d] = 0.0f;
+    float e = 0.0f;
+    stream_rows<NQ>(reinterpret_cast<const float4*>(lds + L.gmm_sc), K2, [&](int k, auto J0, const auto& q) {
+      constexpr int j0 = decltype(J0)::value;
+      constexpr int n = j0 == 0 ? (NQ + 1) / 2 : NQ - (NQ + 1) / 2;
+      if (j0 == 0) {
+        e = __expf(lg_lds[k * 256] - m);
+        z += e;
+      }
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        const int dd = 4 * (j0 + j);
+        const float qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (dd + i < DP) P[dd + i] = fmaf(e, qq[i], P[dd + i]);
+      }
+    });
+    const float iz = 1.0f / z;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) score[d] = fmaf(P[d], iz, -x[d] * vec[NQ * 4 + d]);
+  } else {
+    for (int k = 0; k < K; ++k) z += __expf(lg_lds[k * 256] - m);
+  }
+  return m + __logf(z);
+}
+
+template <int DP, bool SCORE>
+__device__ __forceinline__ float gmm_eval(const float* ws, const float* lds, const WsLayout& L, int gmmv, int K,
+                                          float* __restrict__ lg_lds, const float (&x)[DP], float (&score)[DP]) {
+  if (gmmv == 2) return gmm_eval_lds_shared<DP, SCORE>(lds, L, K, lg_lds, x, score);
+  if (gmmv == 1) return gmm_eval_lds<DP, SCORE>(lds, L, K, lg_lds, x, score);
+  return gmm_eval_smem<DP, SCORE>(ws, L, K, lg_lds, x, score);
 }
 
 // Diagonal Gaussian: table [DP][2] = (mu, 1/sigma^2) followed by the scalar  sum_d(-log sigma_d - 0.5 log 2pi).
@@ -292,11 +473,11 @@ __device__ __forceinline__ void funnel_score(const DensArgs& D, int dreal, const
 
 // target.unnorm_log_prob
 template <int DP>
-__device__ __forceinline__ float target_logp(const DensArgs& D, const float* ws, const WsLayout& L, int dreal,
-                                             float* lg_lds, const float (&x)[DP]) {
+__device__ __forceinline__ float target_logp(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
+                                             int gmmv, int dreal, float* lg_lds, const float (&x)[DP]) {
   float dummy[DP];
   switch (D.kind) {
-    case SDEH_DENS_GMM: return gmm_eval<DP, false>(ws, L, D.n_comp, lg_lds, x, dummy) + D.lnc;
+    case SDEH_DENS_GMM: return gmm_eval<DP, false>(ws, lds, L, gmmv, D.n_comp, lg_lds, x, dummy) + D.lnc;
     case SDEH_DENS_DIAG_GAUSS: return dgauss_logp<DP>(ws + L.dg[0], x) + D.lnc;
     case SDEH_DENS_MULTI_WELL: return mwell_logp<DP>(D, dreal, x);
     case SDEH_DENS_FUNNEL: return funnel_logp<DP>(D, dreal, x);
@@ -305,10 +486,10 @@ __device__ __forceinline__ float target_logp(const DensArgs& D, const float* ws,
 }
 
 template <int DP>
-__device__ __forceinline__ void target_score(const DensArgs& D, const float* ws, const WsLayout& L, int dreal,
-                                             float* lg_lds, const float (&x)[DP], float (&s)[DP]) {
+__device__ __forceinline__ void target_score(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
+                                             int gmmv, int dreal, float* lg_lds, const float (&x)[DP], float (&s)[DP]) {
   switch (D.kind) {
-    case SDEH_DENS_GMM: (void)gmm_eval<DP, true>(ws, L, D.n_comp, lg_lds, x, s); break;
+    case SDEH_DENS_GMM: (void)gmm_eval<DP, true>(ws, lds, L, gmmv, D.n_comp, lg_lds, x, s); break;
     case SDEH_DENS_DIAG_GAUSS: dgauss_score<DP>(ws + L.dg[0], x, s); break;
     case SDEH_DENS_MULTI_WELL: mwell_score<DP>(D, dreal, x, s); break;
     case SDEH_DENS_FUNNEL: funnel_score<DP>(D, dreal, x, s); break;
@@ -349,8 +530,11 @@ __device__ __forceinline__ U4 philox_block(unsigned long long seed, unsigned lon
 
 // ---------------------------------------------------------------------------------------------------------
 // the kernel.  PAD = false: d == DP exactly;  PAD = true: d <= DP, coordinates >= d are held at zero.
+// LOSS / CTRL / TGT / GMMV / ACT >= 0 fix the loss kind, control kind, target density kind, GMM table variant and
+// activation at compile time (the BASELINE configurations get such specialised variants: no dead branches, far
+// fewer live registers); -1 leaves the property a wave-uniform run-time switch (the generic variants).
 // ---------------------------------------------------------------------------------------------------------
-template <int DP, int C, bool PAD>
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT>
 __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                    const float* __restrict__ noise, float* __restrict__ xT,
                                                    float* __restrict__ rnd_out, float* __restrict__ xs,
@@ -393,7 +577,10 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
   }
 
   const int flags = A.flags;
-  const int ctrl_kind = A.ctrl_kind, loss_kind = A.loss_kind;
+  const int ctrl_kind = CTRL >= 0 ? CTRL : A.ctrl_kind, loss_kind = LOSS >= 0 ? LOSS : A.loss_kind;
+  const int gmmv = GMMV >= 0 ? GMMV : L.gmm_lds, act = ACT >= 0 ? ACT : A.act;
+  DensArgs tgt = A.target;
+  if (TGT >= 0) tgt.kind = TGT;
   const bool lv = flags & SDEH_FLAG_CHANGE_SDE_CTRL;
   const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
   const bool refc = (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
@@ -403,40 +590,39 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
     const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
 
-    // ---- generative_ctrl(s, x) -----------------------------------------------------------------------
-    float u[DP];
-    mlp_forward<DP, C>(lds, L, A.act, ws + L.emb + i * C, x, u, lane);
-
-    SDEH_FENCE();
+    // ---- generative_ctrl(s, x): score term first (it only needs x), then the network ----------------------
     float tsc[DP], psc[DP];
-    if (need_t) target_score<DP>(A.target, ws, L, d, lg_lds, x, tsc);
-    if (need_p) dgauss_score<DP>(ws + L.dg[1], x, psc);
-
-    if (ctrl_kind == SDEH_CTRL_CLIPPED) {  // reparam.py:25-36
+    if (need_t) {
+      if constexpr (SDEH_ABL & 2) {
 #pragma unroll
-      for (int j = 0; j < DP; ++j) u[j] = clipf(u[j], A.clip_model);
-    } else {
+        for (int j = 0; j < DP; ++j) tsc[j] = -x[j];
+      } else {
+        target_score<DP>(tgt, ws, lds, L, gmmv, d, lg_lds, x, tsc);
+      }
+    }
+    if (need_p) dgauss_score<DP>(ws + L.dg[1], x, psc);
+    float sterm[DP];  // mult * scale_score * clip(score) * clip(gamma(t))
+    if (ctrl_kind != SDEH_CTRL_CLIPPED) {
       const float w = cf[CF_W];
-      float sc[DP];
       if (ctrl_kind == SDEH_CTRL_SCORE) {  // reparam.py:56-83
 #pragma unroll
-        for (int j = 0; j < DP; ++j) sc[j] = tsc[j];
+        for (int j = 0; j < DP; ++j) sterm[j] = tsc[j];
       } else if (ctrl_kind == SDEH_CTRL_LERP) {  // reparam.py:131-144; torch.lerp's two-sided formula
         if (w < 0.5f) {
 #pragma unroll
-          for (int j = 0; j < DP; ++j) sc[j] = psc[j] + w * (tsc[j] - psc[j]);
+          for (int j = 0; j < DP; ++j) sterm[j] = psc[j] + w * (tsc[j] - psc[j]);
         } else {
           const float w1 = 1.0f - w;
 #pragma unroll
-          for (int j = 0; j < DP; ++j) sc[j] = tsc[j] - (tsc[j] - psc[j]) * w1;
+          for (int j = 0; j < DP; ++j) sterm[j] = tsc[j] - (tsc[j] - psc[j]) * w1;
         }
       } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {  // reparam.py:185-197
 #pragma unroll
-        for (int j = 0; j < DP; ++j) sc[j] = w * tsc[j];
+        for (int j = 0; j < DP; ++j) sterm[j] = w * tsc[j];
       } else {  // SDEH_CTRL_LERP_PRIOR, reparam.py:166-178
         const float w1 = 1.0f - w;
 #pragma unroll
-        for (int j = 0; j < DP; ++j) sc[j] = w1 * psc[j];
+        for (int j = 0; j < DP; ++j) sterm[j] = w1 * psc[j];
       }
       cfp gam = as_const(ws + L.gam + i * L.g);
       // ScoreCtrl: ctrl + score;  Lerp*: ctrl + sde.diff(t) * score   (reparam.py:78-83,149-162)
@@ -444,21 +630,28 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
       const float g0 = gam[0];
       if (L.g == 1) {
 #pragma unroll
-        for (int j = 0; j < DP; ++j) {
-          const float s = (A.scale_score * clipf(sc[j], A.clip_score)) * g0;
-          u[j] = clipf(u[j], A.clip_model) + mult * s;
-        }
+        for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * g0);
       } else {
 #pragma unroll
-        for (int j = 0; j < DP; ++j) {
-          const float s = (A.scale_score * clipf(sc[j], A.clip_score)) * gam[j];
-          u[j] = clipf(u[j], A.clip_model) + mult * s;
-        }
+        for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * gam[j]);
       }
-    }
-    if (PAD) {
+    } else {
 #pragma unroll
-      for (int j = 0; j < DP; ++j) u[j] = j < d ? u[j] : 0.0f;
+      for (int j = 0; j < DP; ++j) sterm[j] = 0.0f;
+    }
+    SDEH_FENCE();
+
+    float u[DP];
+    if constexpr (SDEH_ABL & 1) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) u[j] = 0.01f * x[j];
+    } else {
+      mlp_forward<DP, C>(lds, L, act, ws + L.emb + i * C, x, u, lane);
+    }
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {  // ClippedCtrl (reparam.py:25-36) + score term
+      u[j] = clipf(u[j], A.clip_model) + sterm[j];
+      if (PAD) u[j] = j < d ? u[j] : 0.0f;
     }
 
     SDEH_FENCE();
@@ -517,7 +710,13 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
         for (int q = 0; q < 4; ++q)
           if (4 * jb + q < DP) n[q] = np[PAD ? min(4 * jb + q, d - 1) : 4 * jb + q];
       } else if (!PAD || 4 * jb < d) {
-        box_muller4(philox_block(A.seed, A.offset, grow, i, jb), n);
+        if constexpr (SDEH_ABL & 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            n[q] = __uint_as_float((__float_as_uint(x[(4 * jb + q) % DP]) & 0x007fffffu) | 0x3f800000u) - 1.5f;
+        } else {
+          box_muller4(philox_block(A.seed, A.offset, grow, i, jb), n);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -545,7 +744,7 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
 
   // ---- terminal costs (oc.py:225, 337, 449-450) ----------------------------------------------------------
   if (flags & SDEH_FLAG_TERMINAL_SECOND) rnd += dgauss_logp<DP>(ws + L.dg[2], x);
-  if (flags & SDEH_FLAG_TERMINAL_TARGET) rnd -= clipf(target_logp<DP>(A.target, ws, L, d, lg_lds, x), A.clip_target);
+  if (flags & SDEH_FLAG_TERMINAL_TARGET) rnd -= clipf(target_logp<DP>(tgt, ws, lds, L, gmmv, d, lg_lds, x), A.clip_target);
 
   if (live) {
     rnd_out[row] = rnd;
@@ -555,20 +754,20 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
   }
 }
 
-template <int DP, int C, bool PAD>
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT>
 int launch_traj(const TrajArgs& a, hipStream_t stream) {
   const int k_scratch = a.lay.k_max > 0 ? a.lay.k_max : 0;
   const size_t lds_bytes = ((size_t)a.lay.lds_floats + (size_t)k_scratch * 256) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_kernel<DP, C, PAD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
   const unsigned grid = (unsigned)((a.batch + 255) / 256);
-  hipLaunchKernelGGL((traj_kernel<DP, C, PAD>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
+  hipLaunchKernelGGL((traj_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
                      a.xT, a.rnd, a.xs, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }

@@ -1,8 +1,8 @@
-// One translation unit per compiled state dimension:
-//   hipcc -DSDEH_DP=<n> -DSDEH_PAD=<0|1> [-DSDEH_C=<channels>] -c sdeh_traj_inst.hip
-// The trajectory kernel keeps x[d] in registers, so d is a compile-time constant.  PAD=0 variants require
-// d == DP; PAD=1 variants accept any d <= DP (coordinates >= d are held at zero).  The dispatcher
-// (sdeh_api.hip) picks the exact variant when one was compiled, else the smallest padded one.
+// One translation unit per compiled trajectory-kernel variant:
+//   hipcc -DSDEH_DP=<n> -DSDEH_PAD=<0|1> [-DSDEH_SPEC="loss,ctrl,target,gmm,act" -DSDEH_SPECNAME=<tag>] -c sdeh_traj_inst.hip
+// The kernel keeps x[d] in registers, so d is a compile-time constant.  PAD=0 variants require d == DP; PAD=1
+// variants accept any d <= DP (coordinates >= d are held at zero).  SDEH_SPEC additionally fixes the loss / control /
+// target / GMM-table / activation kinds (see sdeh_variants.inc); without it they stay run-time switches.
 #include "sdeh_traj.hpp"
 
 #ifndef SDEH_DP
@@ -11,15 +11,16 @@
 #ifndef SDEH_PAD
 #define SDEH_PAD 0
 #endif
-#ifndef SDEH_C
-#define SDEH_C 64
+#ifndef SDEH_SPEC
+#define SDEH_SPEC -1, -1, -1, -1, -1
+#define SDEH_SPECNAME g
 #endif
 
 #define SDEH_CAT2(a, b, c, d, e, f) a##b##c##d##e##f
 #define SDEH_CAT(a, b, c, d, e, f) SDEH_CAT2(a, b, c, d, e, f)
 
 namespace sdeh {
-int SDEH_CAT(launch_traj_dp, SDEH_DP, _c, SDEH_C, _p, SDEH_PAD)(const TrajArgs& a, hipStream_t stream) {
-  return launch_traj<SDEH_DP, SDEH_C, (SDEH_PAD != 0)>(a, stream);
+int SDEH_CAT(launch_traj_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const TrajArgs& a, hipStream_t stream) {
+  return launch_traj<SDEH_DP, 64, (SDEH_PAD != 0), SDEH_SPEC>(a, stream);
 }
 }  // namespace sdeh

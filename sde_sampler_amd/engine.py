@@ -122,6 +122,8 @@ def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
         out.loc = keep.ptr(dist.loc, device, what)
         out.scale = keep.ptr(dist.scale, device, what)
         out.mixture_weights = keep.ptr(dist.mixture_weights, device, what)
+        if _shared_scale(dist.scale):
+            out.flags |= L.DENS_FLAG_SHARED_SCALE
     elif "DoubleWell" in names:
         out.kind, out.n_components = L.DENS_MULTI_WELL, 1
         out.p0, out.p1 = float(dist.separation), float(dist.shift)
@@ -136,6 +138,22 @@ def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
     else:
         raise _unsupported(f"{what}: distribution {type(dist).__name__} has no fused log-density/score "
                            "(GMM, Gauss, IsotropicGauss, Delta, DoubleWell, MultiWell, Funnel are built in)")
+
+
+_SHARED_SCALE_CACHE: dict = {}
+
+
+def _shared_scale(scale: torch.Tensor) -> bool:
+    """True when every mixture component has the same per-coordinate scale.  Costs one device sync per
+    (tensor, version): targets are fixed buffers, so this happens once."""
+    key = (scale.data_ptr(), scale._version, tuple(scale.shape), str(scale.device))
+    hit = _SHARED_SCALE_CACHE.get(key)
+    if hit is None:
+        hit = bool((scale == scale[:1]).all().item())
+        if len(_SHARED_SCALE_CACHE) > 64:
+            _SHARED_SCALE_CACHE.clear()
+        _SHARED_SCALE_CACHE[key] = hit
+    return hit
 
 
 def _known_distribution(obj) -> bool:

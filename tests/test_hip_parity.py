@@ -132,3 +132,19 @@ def test_ragged_and_tiny_batches():
     for b in (1, 63, 65, 257):
         part = prob.eval(x0[:b], compute_weights=True, noise=noise[:, :b].contiguous())
         assert torch.equal(part.samples, full.samples[:b]), b
+
+
+def test_generic_variants_also_match(tmp_path):
+    """The BASELINE configurations normally dispatch to compile-time specialised kernels; re-run the golden parity
+    test in a subprocess with SDEH_GENERIC_ONLY=1 so that the generic (run-time switched) variants are checked too."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("SDEH_GENERIC_ONLY"):
+        pytest.skip("already the generic run")
+    env = dict(os.environ, SDEH_GENERIC_ONLY="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
+                          "eval_matches_reference_golden or rnd_rows_match_oracle"],
+                         env=env, capture_output=True, text=True, cwd=str(Path(__file__).parents[1]))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]

@@ -176,8 +176,8 @@ int32_t sdeh_plan_last_kernel_ms(SdehPlan* plan, float* ms);
  *   x0      [batch, d]            initial states (prior.sample), device
  *   noise   [n_steps, batch, d]   standard-normal draws to consume INSTEAD of the in-kernel generator
  *                                 (parity mode: reproduces the reference on identical noise), or NULL:
- *                                 in-kernel Philox4x32-10 + Box-Muller keyed by (seed, offset) and counted by
- *                                 (row_offset + row, step, dim/4)  -> results do not depend on batch sharding.
+ *                                 in-kernel Philox4x32-10 + Box-Muller: counter (global row, dim/4, step, offset),
+ *                                 key (seed)  -> results do not depend on how the batch is sharded.
  *   row_offset                    global index of x0 row 0 (rank * local_batch for sharded runs)
  *   x_T     [batch, d]   out      terminal states ("samples")
  *   rnd     [batch]      out      log Radon-Nikodym derivative per trajectory (reference shape [B,1])

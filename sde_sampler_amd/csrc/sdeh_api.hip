@@ -16,19 +16,22 @@ int launch_prep(const PrepArgs& p, hipStream_t stream);
 int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int nb, float* out, hipStream_t stream);
 int launch_weights(const float* rnd, long long n, const float* mx, float* w, hipStream_t stream);
 
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act) int launch_traj_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc)                                \
+  int launch_ws_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                 \
+  int launch_legacy_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 
 struct Variant {
   int dp;
   bool pad;
-  int loss, ctrl, tgt, gmm, act;  // -1 = run-time switch
-  TrajLauncher fn;
+  int loss, ctrl, tgt, gmm, act, refc;  // -1 = run-time switch
+  TrajLauncher fn;         // wave-specialised kernel (sdeh_traj_ws.hpp)
+  TrajLauncher fn_legacy;  // single-wave kernel (sdeh_traj.hpp); returns SDEH_ERR_UNSUPPORTED when not compiled in
   const char* name;
 };
 static const Variant kVariants[] = {
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act) {dp, pad != 0, loss, ctrl, tgt, gmm, act, &launch_traj_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 };
@@ -42,7 +45,7 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-static bool is_generic(const Variant& v) { return v.loss < 0 && v.ctrl < 0 && v.tgt < 0 && v.gmm < 0 && v.act < 0; }
+static bool is_generic(const Variant& v) { return v.loss < 0 && v.ctrl < 0 && v.tgt < 0 && v.gmm < 0 && v.act < 0 && v.refc < 0; }
 
 // generic variant for dimension d: the exact one when compiled, else the smallest padded one
 static const Variant* pick_variant(int d) {
@@ -56,11 +59,11 @@ static const Variant* pick_variant(int d) {
 }
 
 // specialised variant whose compile-time choices all match the problem, if any
-static const Variant* pick_specialised(int d, int loss, int ctrl, int tgt, int gmm, int act) {
+static const Variant* pick_specialised(int d, int loss, int ctrl, int tgt, int gmm, int act, int refc) {
   for (const Variant& v : kVariants) {
     if (is_generic(v) || v.pad || v.dp != d) continue;
     if ((v.loss < 0 || v.loss == loss) && (v.ctrl < 0 || v.ctrl == ctrl) && (v.tgt < 0 || v.tgt == tgt) &&
-        (v.gmm < 0 || v.gmm == gmm) && (v.act < 0 || v.act == act))
+        (v.gmm < 0 || v.gmm == gmm) && (v.act < 0 || v.act == act) && (v.refc < 0 || v.refc == refc))
       return &v;
   }
   return nullptr;
@@ -69,7 +72,8 @@ static const Variant* pick_specialised(int d, int loss, int ctrl, int tgt, int g
 static int align4(int v) { return (v + 3) & ~3; }
 
 // Workspace layout for one problem geometry.
-static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g, bool shared_scale = false) {
+static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g, bool shared_scale = false,
+                            bool gmm_global = false) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.dp = dp; L.c = c; L.ot = c / 32; L.otd = row_tiles(dp); L.r_in = mregs(dp);
@@ -82,10 +86,12 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   L.b_out = o; o += L.otd * 32;
   o = align4(o);
   L.gmm_row = 2 * ((dp + 1) & ~1);
-  const int k_rows = (k_max + 1) & ~1;  // even number of table rows (padding row: logit -inf)
+  const int k_rows = (k_max + 7) & ~7;  // table rows padded to a multiple of 8 (padding rows: logit -inf)
+  L.gmm_rows = k_rows;
   const int gmm_floats = 2 * k_rows * L.gmm_row + align4(k_rows);
-  // LDS budget: image + [K][256] logit scratch must stay within 160 KiB
-  L.gmm_lds = (k_max > 0 && ((size_t)(o + gmm_floats) + (size_t)k_max * 256) * sizeof(float) <= 160 * 1024) ? 1 : 0;
+  // LDS budget of the wave-specialised kernel: image + four [coordinate][64] exchange buffers within 160 KiB
+  const size_t xbuf_floats = (size_t)4 * (mdim(mregs(dp) - 1, 1) + 1) * 64;
+  L.gmm_lds = (k_max > 0 && !gmm_global && ((size_t)(o + gmm_floats) + xbuf_floats) * sizeof(float) <= 160 * 1024) ? 1 : 0;
   if (L.gmm_lds && shared_scale) {
     // shared-scale tables: one word per (k,d), rows of 4*ceil(dp/4) floats, then the two per-coordinate vectors
     const int rs = 4 * ((dp + 3) / 4);
@@ -149,7 +155,9 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   if (v == nullptr) return fail(SDEH_ERR_UNSUPPORTED, "plan_create: no trajectory kernel compiled for dim=%d", desc->dim);
   const int k_max = desc->max_components > 0 ? desc->max_components : 0;
   WsLayout L = make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp);
-  const size_t lds_bytes = ((size_t)L.lds_floats + (size_t)k_max * 256) * sizeof(float);
+  const size_t lds_bytes = L.gmm_lds || k_max == 0
+                               ? ((size_t)L.lds_floats + (size_t)4 * (mdim(mregs(v->dp) - 1, 1) + 1) * 64) * sizeof(float)
+                               : ((size_t)L.lds_floats + (size_t)k_max * 256) * sizeof(float);
   if (lds_bytes > 160 * 1024)
     return fail(SDEH_ERR_UNSUPPORTED, "plan_create: needs %zu B of LDS (> 160 KiB): hidden=%d K=%d", lds_bytes,
                 desc->max_hidden, k_max);
@@ -243,6 +251,9 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
   if (plan == nullptr || pr == nullptr || ts == nullptr || x0 == nullptr || x_T == nullptr || rnd == nullptr)
     return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
   if (batch < 1 || n_steps < 1) return fail(SDEH_ERR_INVALID, "simulate_fwd: batch=%lld n_steps=%d", (long long)batch, n_steps);
+  if (row_offset < 0 || (unsigned long long)row_offset + (unsigned long long)batch > 0x100000000ull)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd: global row indices must fit 32 bits (row_offset=%lld batch=%lld)",
+                (long long)row_offset, (long long)batch);
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   if (d != plan->desc.dim || net.channels != plan->desc.channels)
@@ -299,7 +310,8 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
 
   const Variant* v = plan->variant;
   const bool shared = pr->target.kind == SDEH_DENS_GMM && (pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE);
-  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared);
+  static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
+  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy);
   if ((size_t)L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd: workspace too small");
 
   hipStream_t st = (hipStream_t)stream;
@@ -326,9 +338,17 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
   A.seed = seed; A.offset = offset;
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   static const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing aid: force the generic variants
-  const Variant* sv = no_spec ? nullptr : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds, net.activation);
+  const Variant* sv = no_spec ? nullptr : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds, net.activation, refc ? 1 : 0);
   if (sv != nullptr && sv->dp == v->dp) v = sv;
-  rc = v->fn(A, st);
+  // The wave-specialised kernel needs GMM tables in LDS; mixtures too large for that use the single-wave kernel
+  // with scalar-load tables (also selectable with SDEH_LEGACY=1 for A/B measurements).
+  const bool legacy = force_legacy || (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0);
+  if (legacy) {
+    rc = v->fn_legacy(A, st);
+    if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);
+  } else {
+    rc = v->fn(A, st);
+  }
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd: trajectory kernel launch failed (dp=%d)", v->dp);
   return SDEH_OK;

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
   if (pr.target.kind == SDEH_DENS_GMM) {
     const SdehDensity& G = pr.target;
     const int K = G.n_components;
-    const int K2 = (K + 1) & ~1;  // the LDS paths consume rows in pairs; the padding row has logit -inf
+    const int K2 = L.gmm_rows;  // K rounded up to a multiple of 8; padding rows have logit -inf
     if (L.gmm_lds == 2) {  // shared-scale tables (SDEH_DENS_FLAG_SHARED_SCALE)
       const int rs = L.gmm_row;
       for (int e = gid; e < K2 * rs; e += stride) {
@@ -190,17 +190,19 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
         ws[L.gmm_sc + K2 * rs + rs + j] = ok ? 1.0f / (sg * sg) : 0.0f;
       }
     } else {
-      const int npair = L.gmm_row / 2;
+      // general tables: per coordinate pair a quad (mu_d, mu_d+1, a_d, a_d+1) / (mu/s^2 at d, d+1, 1/s^2 at d, d+1)
+      const int npair = L.gmm_row / 2;  // coordinates per row (even)
       for (int e = gid; e < K2 * npair; e += stride) {
         const int k = e / npair, j = e % npair;
         const bool ok = j < G.dim && k < K;
         const float mu = ok ? G.loc[(size_t)k * G.dim + j] : 0.0f;
         const float sg = ok ? G.scale[(size_t)k * G.dim + j] : 1.0f;
         const float iv = ok ? 1.0f / (sg * sg) : 0.0f;
-        ws[L.gmm_lg + 2 * e] = mu;
-        ws[L.gmm_lg + 2 * e + 1] = 0.5f * iv;
-        ws[L.gmm_sc + 2 * e] = mu * iv;
-        ws[L.gmm_sc + 2 * e + 1] = iv;
+        const int o = k * L.gmm_row + 4 * (j / 2) + (j & 1);
+        ws[L.gmm_lg + o] = mu;
+        ws[L.gmm_lg + o + 2] = 0.5f * iv;
+        ws[L.gmm_sc + o] = mu * iv;
+        ws[L.gmm_sc + o + 2] = iv;
       }
     }
     for (int k = gid; k < K; k += stride) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
       for (int j = 0; j < G.dim; ++j) c -= logf(G.scale[(size_t)k * G.dim + j]) + 0.91893853320467274178f;
       ws[L.gmm_c + k] = c;
     }
-    if (gid == 0 && K2 > K) ws[L.gmm_c + K] = -INFINITY;
+    for (int k = K + gid; k < K2; k += stride) ws[L.gmm_c + k] = -INFINITY;
   }
   pack_diag_gauss(ws + L.dg[0], pr.target, L.dp, gid, stride);
   pack_diag_gauss(ws + L.dg[1], pr.prior, L.dp, gid, stride);

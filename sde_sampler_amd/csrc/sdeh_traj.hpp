@@ -191,17 +191,17 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ lds, const
 template <int DP, bool SCORE>
 __device__ __forceinline__ float gmm_eval_smem(const float* ws, const WsLayout& L, int K, float* __restrict__ lg_lds,
                                                const float (&x)[DP], float (&score)[DP]) {
-  const int npair = L.gmm_row / 2;
-  cf2p plg = as_const2(ws + L.gmm_lg);
+  // rows of (mu_d, mu_d+1, a_d, a_d+1) quads (the layout the wave-specialised kernel reads as float4)
+  cfp plg = as_const(ws + L.gmm_lg);
   cfp pc = as_const(ws + L.gmm_c);
   float m = -INFINITY;
   for (int k = 0; k < K; ++k) {
-    cf2p p = plg + k * npair;
+    cfp p = plg + k * L.gmm_row;
     float acc = 0.0f;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
-      const float t = x[d] - p[d].x;
-      acc = fmaf(t * t, p[d].y, acc);
+      const float t = x[d] - p[4 * (d / 2) + (d & 1)];
+      acc = fmaf(t * t, p[4 * (d / 2) + 2 + (d & 1)], acc);
     }
     const float l = pc[k] - acc;
     lg_lds[k * 256] = l;
@@ -209,18 +209,18 @@ __device__ __forceinline__ float gmm_eval_smem(const float* ws, const WsLayout& 
   }
   float z = 0.0f;
   if constexpr (SCORE) {
-    cf2p psc = as_const2(ws + L.gmm_sc);
+    cfp psc = as_const(ws + L.gmm_sc);
     float P[DP], Q[DP];
 #pragma unroll
     for (int d = 0; d < DP; ++d) P[d] = Q[d] = 0.0f;
     for (int k = 0; k < K; ++k) {
-      cf2p p = psc + k * npair;
+      cfp p = psc + k * L.gmm_row;
       const float e = __expf(lg_lds[k * 256] - m);
       z += e;
 #pragma unroll
       for (int d = 0; d < DP; ++d) {
-        P[d] = fmaf(e, p[d].x, P[d]);
-        Q[d] = fmaf(e, p[d].y, Q[d]);
+        P[d] = fmaf(e, p[4 * (d / 2) + (d & 1)], P[d]);
+        Q[d] = fmaf(e, p[4 * (d / 2) + 2 + (d & 1)], Q[d]);
       }
     }
     const float iz = 1.0f / z;
@@ -235,171 +235,16 @@ __device__ __forceinline__ float gmm_eval_smem(const float* ws, const WsLayout& 
 // Same computation with the tables resident in LDS: every lane reads the same address (broadcast ds_read_b128,
 // two (k,d) pairs per read), so the loads can be prefetched deep into VGPRs -- scalar loads cannot (SMEM returns
 // out of order, ~100 SGPRs, and with one wave per SIMD nothing hides their L2 latency).
-// ---- LDS-resident tables: every lane reads the same address (broadcast ds_read_b128).  Rows are streamed
-// through two register buffers holding half a row each; the next half-row is in flight while the current one is
-// consumed.  hipcc does not software-pipeline LDS reads by itself (it emits read / s_waitcnt lgkmcnt(0) / use),
-// so the order is pinned with scheduling fences.  Scalar loads cannot be pipelined this deep (SMEM returns out of
-// order, ~100 SGPRs) and with one wave per SIMD nothing else hides their L2 latency.  Tables hold an even
-// number of rows; a padding row carries logit -inf.
 template <int N>
 __device__ __forceinline__ void load_f4(const float4* __restrict__ p, float4 (&q)[N]) {
 #pragma unroll
   for (int j = 0; j < N; ++j) q[j] = p[j];
 }
 
-// Streams `rows` rows of NQ float4 each.  f(row, first_pair_index, buffer) is called for each half row.
-template <int NQ, class F>
-__device__ __forceinline__ void stream_rows(const float4* __restrict__ tab, int rows, F&& f) {
-  constexpr int NA = (NQ + 1) / 2, NB = NQ - NA;
-  float4 qa[NA], qb[NB > 0 ? NB : 1];
-  load_f4<NA>(tab, qa);
-  for (int k = 0; k < rows; ++k) {
-    const float4* __restrict__ row = tab + k * NQ;
-    if constexpr (NB > 0) load_f4<NB>(row + NA, qb);
-    SDEH_FENCE();
-    f(k, std::integral_constant<int, 0>{}, qa);
-    SDEH_FENCE();
-    load_f4<NA>(tab + (k + 1 < rows ? k + 1 : 0) * NQ, qa);
-    SDEH_FENCE();
-    if constexpr (NB > 0) f(k, std::integral_constant<int, NA>{}, qb);
-    SDEH_FENCE();
-  }
-}
-
-// General mixture: rows of (mu, 1/(2 sigma^2)) pairs and (mu/sigma^2, 1/sigma^2) pairs, two pairs per float4.
-template <int DP, bool SCORE>
-__device__ __forceinline__ float gmm_eval_lds(const float* __restrict__ lds, const WsLayout& L, int K,
-                                              float* __restrict__ lg_lds, const float (&x)[DP], float (&score)[DP]) {
-  constexpr int NQ = (DP + 1) / 2;
-  const float* __restrict__ pc = lds + L.gmm_c;
-  const int K2 = (K + 1) & ~1;
-  float m = -INFINITY, acc0 = 0.0f, acc1 = 0.0f;
-  stream_rows<NQ>(reinterpret_cast<const float4*>(lds + L.gmm_lg), K2, [&](int k, auto J0, const auto& q) {
-    constexpr int j0 = decltype(J0)::value;
-    constexpr int n = j0 == 0 ? (NQ + 1) / 2 : NQ - (NQ + 1) / 2;
-#pragma unroll
-    for (int j = 0; j < n; ++j) {
-      const int dd = 2 * (j0 + j);
-      const float t0 = x[dd] - q[j].x;
-      acc0 = fmaf(t0 * t0, q[j].y, acc0);
-      if (dd + 1 < DP) {
-        const float t1 = x[dd + 1] - q[j].z;
-        acc1 = fmaf(t1 * t1, q[j].w, acc1);
-      }
-    }
-    if (j0 != 0 || NQ == 1) {  // row complete
-      const float l = pc[k] - (acc0 + acc1);
-      lg_lds[k * 256] = l;
-      m = fmaxf(m, l);
-      acc0 = acc1 = 0.0f;
-    }
-  });
-  float z = 0.0f;
-  if constexpr (SCORE) {
-    float P[DP], Q[DP];
-#pragma unroll
-    for (int d = 0; d < DP; ++d) P[d] = Q[d] = 0.0f;
-    float e = 0.0f;
-    stream_rows<NQ>(reinterpret_cast<const float4*>(lds + L.gmm_sc), K2, [&](int k, auto J0, const auto& q) {
-      constexpr int j0 = decltype(J0)::value;
-      constexpr int n = j0 == 0 ? (NQ + 1) / 2 : NQ - (NQ + 1) / 2;
-      if (j0 == 0) {
-        e = __expf(lg_lds[k * 256] - m);
-        z += e;
-      }
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        const int dd = 2 * (j0 + j);
-        P[dd] = fmaf(e, q[j].x, P[dd]);
-        Q[dd] = fmaf(e, q[j].y, Q[dd]);
-        if (dd + 1 < DP) {
-          P[dd + 1] = fmaf(e, q[j].z, P[dd + 1]);
-          Q[dd + 1] = fmaf(e, q[j].w, Q[dd + 1]);
-        }
-      }
-    });
-    const float iz = 1.0f / z;
-#pragma unroll
-    for (int d = 0; d < DP; ++d) score[d] = (P[d] - x[d] * Q[d]) * iz;
-  } else {
-    for (int k = 0; k < K; ++k) z += __expf(lg_lds[k * 256] - m);
-  }
-  return m + __logf(z);
-}
-
-// Mixture whose scale does not depend on the component (sigma_kd = sigma_d; every named mixture of the
-// reference, distr/gauss.py:14-63): with y_d = x_d / (sqrt2 sigma_d) the logit is c_k - sum_d (y_d - m_kd)^2 and
-// sum_k r_k / sigma_d^2 = 1 / sigma_d^2, so each (k,d) costs one table word and 2 + 1 VALU ops instead of 4 and 3 + 2.
-// Tables: gmm_lg rows m_kd = mu_kd / (sqrt2 sigma_d); gmm_sc rows mu_kd / sigma_d^2; then 1/(sqrt2 sigma_d), 1/sigma_d^2.
-template <int DP, bool SCORE>
-__device__ __forceinline__ float gmm_eval_lds_shared(const float* __restrict__ lds, const WsLayout& L, int K,
-                                                     float* __restrict__ lg_lds, const float (&x)[DP],
-                                                     float (&score)[DP]) {
-  constexpr int NQ = (DP + 3) / 4;
-  const float* __restrict__ pc = lds + L.gmm_c;
-  const float* __restrict__ vec = lds + L.gmm_sc + ((K + 1) & ~1) * (NQ * 4);  // [2][NQ*4]
-  const int K2 = (K + 1) & ~1;
-  float y[DP];
-#pragma unroll
-  for (int d = 0; d < DP; ++d) y[d] = x[d] * vec[d];
-  float m = -INFINITY, acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  stream_rows<NQ>(reinterpret_cast<const float4*>(lds + L.gmm_lg), K2, [&](int k, auto J0, const auto& q) {
-    constexpr int j0 = decltype(J0)::value;
-    constexpr int n = j0 == 0 ? (NQ + 1) / 2 : NQ - (NQ + 1) / 2;
-#pragma unroll
-    for (int j = 0; j < n; ++j) {
-      const int dd = 4 * (j0 + j);
-      const float qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (dd + i < DP) {
-          const float t = y[dd + i] - qq[i];
-          acc[i] = fmaf(t, t, acc[i]);
-        }
-    }
-    if (j0 != 0 || NQ == 1) {
-      const float l = pc[k] - ((acc[0] + acc[1]) + (acc[2] + acc[3]));
-      lg_lds[k * 256] = l;
-      m = fmaxf(m, l);
-      acc[0] = acc[1] = acc[2] = acc[3] = 0.0f;
-    }
-  });
-  float z = 0.0f;
-  if constexpr (SCORE) {
-    float P[DP];
-#pragma unroll
-    for (int d = 0; d < DP; ++d) P[d] = 0.0f;
-    float e = 0.0f;
-    stream_rows<NQ>(reinterpret_cast<const float4*>(lds + L.gmm_sc), K2, [&](int k, auto J0, const auto& q) {
-      constexpr int j0 = decltype(J0)::value;
-      constexpr int n = j0 == 0 ? (NQ + 1) / 2 : NQ - (NQ + 1) / 2;
-      if (j0 == 0) {
-        e = __expf(lg_lds[k * 256] - m);
-        z += e;
-      }
-#pragma unroll
-      for (int j = 0; j < n; ++j) {
-        const int dd = 4 * (j0 + j);
-        const float qq[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (dd + i < DP) P[dd + i] = fmaf(e, qq[i], P[dd + i]);
-      }
-    });
-    const float iz = 1.0f / z;
-#pragma unroll
-    for (int d = 0; d < DP; ++d) score[d] = fmaf(P[d], iz, -x[d] * vec[NQ * 4 + d]);
-  } else {
-    for (int k = 0; k < K; ++k) z += __expf(lg_lds[k * 256] - m);
-  }
-  return m + __logf(z);
-}
-
 template <int DP, bool SCORE>
 __device__ __forceinline__ float gmm_eval(const float* ws, const float* lds, const WsLayout& L, int gmmv, int K,
                                           float* __restrict__ lg_lds, const float (&x)[DP], float (&score)[DP]) {
-  if (gmmv == 2) return gmm_eval_lds_shared<DP, SCORE>(lds, L, K, lg_lds, x, score);
-  if (gmmv == 1) return gmm_eval_lds<DP, SCORE>(lds, L, K, lg_lds, x, score);
+  (void)lds; (void)gmmv;  // the single-wave kernel only handles tables in global memory (scalar loads)
   return gmm_eval_smem<DP, SCORE>(ws, L, K, lg_lds, x, score);
 }
 
@@ -518,23 +363,28 @@ __device__ __forceinline__ void box_muller4(const U4& r, float (&n)[4]) {
   n[3] = rb * __builtin_amdgcn_sinf(u3);
 }
 
+// Counter = (global row, block, step, offset low word); key = (seed low word, seed high ^ offset high); the global
+// row index must fit 32 bits (checked by sdeh_simulate_fwd).  With this arrangement the per-lane products of the
+// first two rounds depend on the row only (two values hipcc hoists out of the step loop for ALL blocks), the
+// other products of those rounds are wave-uniform (SALU), and the key schedule is uniform -- other arrangements
+// make hipcc hoist one product per block (13 x 2 registers) and spill them.
 __device__ __forceinline__ U4 philox_block(unsigned long long seed, unsigned long long offset,
                                            unsigned long long row, int step, int block) {
   U4 c;
   c.x = (uint32_t)row;
-  c.y = (uint32_t)step;
-  c.z = (uint32_t)block | ((uint32_t)(row >> 32) << 16);
+  c.y = (uint32_t)block;
+  c.z = (uint32_t)step;
   c.w = (uint32_t)offset;
   return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32));
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // the kernel.  PAD = false: d == DP exactly;  PAD = true: d <= DP, coordinates >= d are held at zero.
-// LOSS / CTRL / TGT / GMMV / ACT >= 0 fix the loss kind, control kind, target density kind, GMM table variant and
-// activation at compile time (the BASELINE configurations get such specialised variants: no dead branches, far
+// LOSS / CTRL / TGT / GMMV / ACT / REFC >= 0 fix the loss kind, control kind, target density kind, GMM table variant,
+// activation and presence of a reference control at compile time (the BASELINE configurations get such specialised variants: no dead branches, far
 // fewer live registers); -1 leaves the property a wave-uniform run-time switch (the generic variants).
 // ---------------------------------------------------------------------------------------------------------
-template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT>
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC>
 __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                    const float* __restrict__ noise, float* __restrict__ xT,
                                                    float* __restrict__ rnd_out, float* __restrict__ xs,
@@ -583,7 +433,7 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
   if (TGT >= 0) tgt.kind = TGT;
   const bool lv = flags & SDEH_FLAG_CHANGE_SDE_CTRL;
   const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
-  const bool refc = (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
+  const bool refc = REFC >= 0 ? REFC != 0 : (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
   const bool need_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR || refc;
 
   for (int i = 0; i < A.n_steps; ++i) {
@@ -754,20 +604,20 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
   }
 }
 
-template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT>
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC>
 int launch_traj(const TrajArgs& a, hipStream_t stream) {
   const int k_scratch = a.lay.k_max > 0 ? a.lay.k_max : 0;
   const size_t lds_bytes = ((size_t)a.lay.lds_floats + (size_t)k_scratch * 256) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
   const unsigned grid = (unsigned)((a.batch + 255) / 256);
-  hipLaunchKernelGGL((traj_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
+  hipLaunchKernelGGL((traj_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
                      a.xT, a.rnd, a.xs, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }

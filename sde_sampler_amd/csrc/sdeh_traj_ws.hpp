@@ -1,0 +1,550 @@
+// Wave-specialised persistent trajectory kernel (the default path).
+//
+// A 512-thread workgroup owns 256 trajectories as four groups of 64.  Each group is served by TWO wavefronts
+// that the dispatcher places on the same SIMD (a workgroup's waves are dealt to the four SIMDs cyclically):
+//
+//   V wave (waves 0..3): owns the state.  T layout (lane = trajectory): target/prior score, score term of the
+//                        control, Philox/Box-Muller draws, running cost, EM update, terminal log-densities.
+//                        Pure VALU + broadcast LDS reads.
+//   M wave (waves 4..7): evaluates the FourierMLP for the same 64 trajectories on the matrix pipe
+//                        (v_mfma_f32_32x32x2_f32, M layout) with the activation in between.
+//
+// fp32 MFMA issues at the VALU's FLOP rate but on a separate pipe, so a wave that only does MFMAs and a wave that
+// only does VALU work run concurrently on one SIMD; with a single wave per SIMD (all B = 65 536 allows: 1024 SIMDs x
+// 64 lanes) the two kinds of work would alternate.  Per step the waves exchange x (V -> M) and the network output
+// (M -> V) through one [coordinate][trajectory] LDS buffer per group, which also performs the T <-> M layout change
+// (no cross-lane shuffles), separated by two workgroup barriers:
+//
+//   V: score(x), noise            | barrier B | u = clip(nn) + score term, cost, x <- EM(x,u,xi), publish x | barrier A
+//   M: read x, MLP(x), publish nn | barrier B | (prefetch next step's time embedding)                        | barrier A
+#pragma once
+#include "sdeh_traj.hpp"
+
+namespace sdeh {
+
+constexpr int kWsGroups = 4;  // trajectory groups (of 64) per workgroup
+
+// rows of the exchange buffer: every coordinate an M-layout register can address
+template <int DP>
+constexpr int xrows() { return mdim(mregs(DP) - 1, 1) + 1; }
+
+// ---------------------------------------------------------------------------------------------------------
+// GMM with LDS tables, single pass with an online softmax over chunks of 8 components (no logit scratch).
+// SHARED: tables of the shared-scale form (see gmm_eval_lds_shared).  Table rows are padded to a multiple of
+// 8 components; padding rows carry logit -inf.
+// ---------------------------------------------------------------------------------------------------------
+template <int NQ, int ROWS, class F>
+__device__ __forceinline__ void stream_rows_n(const float4* __restrict__ tab, F&& f) {
+  constexpr int NA = (NQ + 1) / 2, NB = NQ - NA;
+  float4 qa[NA], qb[NB > 0 ? NB : 1];
+  load_f4<NA>(tab, qa);
+#pragma unroll
+  for (int k = 0; k < ROWS; ++k) {
+    const float4* __restrict__ row = tab + k * NQ;
+    if constexpr (NB > 0) load_f4<NB>(row + NA, qb);
+    SDEH_FENCE();
+    f(k, std::integral_constant<int, 0>{}, qa);
+    SDEH_FENCE();
+    if (k + 1 < ROWS) load_f4<NA>(tab + (k + 1) * NQ, qa);
+    SDEH_FENCE();
+    if constexpr (NB > 0) f(k, std::integral_constant<int, NA>{}, qb);
+    SDEH_FENCE();
+  }
+}
+
+// fp32 VALU ops process 16 lanes per cycle on gfx950 (a wave64 v_fma_f32 occupies the SIMD for 4 cycles -- measured:
+// SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 4.1); the 157 TFLOP/s vector peak is only reached with the packed forms
+// (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two fp32 per lane, same 4 cycles).  The mixture loops therefore work
+// on coordinate PAIRS held in 64-bit register pairs.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+
+// Table layouts (rows of NQ float4, prepared by sdeh_prep.hip):
+//   SHARED : logit table  m_kd = mu_kd / (sqrt2 sigma_d), four coordinates per float4; score table mu_kd / sigma_d^2;
+//            followed by the vectors 1/(sqrt2 sigma_d) and 1/sigma_d^2.
+//   general: logit table (mu_d, mu_d+1, a_d, a_d+1) with a = 1/(2 sigma^2), two coordinates per float4;
+//            score table (mu/sigma^2 at d, d+1, 1/sigma^2 at d, d+1).
+template <int DP, bool SHARED, bool SCORE>
+__device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const WsLayout& L, int K,
+                                            const float (&x)[DP], float (&score)[DP]) {
+  constexpr int CH = 8;
+  constexpr int NP = (DP + 1) / 2;                           // coordinate pairs
+  constexpr int NQ = SHARED ? (DP + 3) / 4 : (DP + 1) / 2;  // float4 per table row
+  constexpr int NA = (NQ + 1) / 2;
+  const int KR = L.gmm_rows;  // multiple of CH
+  const float* __restrict__ pc = lds + L.gmm_c;
+  const float4* __restrict__ plg = reinterpret_cast<const float4*>(lds + L.gmm_lg);
+  const float4* __restrict__ psc = reinterpret_cast<const float4*>(lds + L.gmm_sc);
+  const float* __restrict__ vec = lds + L.gmm_sc + KR * (NQ * 4);  // SHARED: 1/(sqrt2 sigma_d), then 1/sigma_d^2
+  f2 y[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float x0 = x[2 * p], x1 = 2 * p + 1 < DP ? x[2 * p + 1] : 0.0f;
+    y[p] = SHARED ? f2{x0 * vec[2 * p], x1 * vec[2 * p + 1]} : f2{x0, x1};
+  }
+  float m = -INFINITY, z = 0.0f;
+  f2 P[NP], Q[SHARED ? 1 : NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { P[p] = splat(0.0f); if (!SHARED) Q[p] = splat(0.0f); }
+  for (int c0 = 0; c0 < KR; c0 += CH) {
+    float l[CH];
+    {  // the chunk's constants first: a read issued inside the stream would drain the prefetch queue (lgkmcnt(0))
+      const float4 c_lo = *reinterpret_cast<const float4*>(pc + c0), c_hi = *reinterpret_cast<const float4*>(pc + c0 + 4);
+      l[0] = c_lo.x; l[1] = c_lo.y; l[2] = c_lo.z; l[3] = c_lo.w;
+      l[4] = c_hi.x; l[5] = c_hi.y; l[6] = c_hi.z; l[7] = c_hi.w;
+    }
+    SDEH_FENCE();
+    f2 acc0 = splat(0.0f), acc1 = splat(0.0f);
+    stream_rows_n<NQ, CH>(plg + c0 * NQ, [&](int k, auto J0, const auto& q) {
+      constexpr int j0 = decltype(J0)::value;
+      constexpr int n = j0 == 0 ? NA : NQ - NA;
+#pragma unroll
+      for (int j = 0; j < n; ++j) {
+        if constexpr (SHARED) {
+          const int p = 2 * (j0 + j);
+          const f2 t0 = y[p] - f2{q[j].x, q[j].y};
+          acc0 = pk_fma(t0, t0, acc0);
+          if (p + 1 < NP) {
+            const f2 t1 = y[p + 1] - f2{q[j].z, q[j].w};
+            acc1 = pk_fma(t1, t1, acc1);
+          }
+        } else {
+          const int p = j0 + j;
+          const f2 t = y[p] - f2{q[j].x, q[j].y};
+          if (j & 1) acc1 = pk_fma(t * t, f2{q[j].z, q[j].w}, acc1);
+          else acc0 = pk_fma(t * t, f2{q[j].z, q[j].w}, acc0);
+        }
+      }
+      if (j0 != 0 || NQ == 1) {  // row complete
+        const f2 a = acc0 + acc1;
+        l[k] -= a.x + a.y;
+        acc0 = acc1 = splat(0.0f);
+      }
+    });
+    float cm = l[0];
+#pragma unroll
+    for (int k = 1; k < CH; ++k) cm = fmaxf(cm, l[k]);
+    const float mn = fmaxf(m, cm);
+    const float resc = __expf(m - mn);  // exp(-inf) = 0 on the first chunk
+    m = mn;
+    float e[CH];
+    z *= resc;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) { e[k] = __expf(l[k] - m); z += e[k]; }
+    if constexpr (SCORE) {
+      const f2 r2 = splat(resc);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { P[p] *= r2; if (!SHARED) Q[p] *= r2; }
+      stream_rows_n<NQ, CH>(psc + c0 * NQ, [&](int k, auto J0, const auto& q) {
+        constexpr int j0 = decltype(J0)::value;
+        constexpr int n = j0 == 0 ? NA : NQ - NA;
+        const f2 e2 = splat(e[k]);
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+          if constexpr (SHARED) {
+            const int p = 2 * (j0 + j);
+            P[p] = pk_fma(e2, f2{q[j].x, q[j].y}, P[p]);
+            if (p + 1 < NP) P[p + 1] = pk_fma(e2, f2{q[j].z, q[j].w}, P[p + 1]);
+          } else {
+            const int p = j0 + j;
+            P[p] = pk_fma(e2, f2{q[j].x, q[j].y}, P[p]);
+            Q[p] = pk_fma(e2, f2{q[j].z, q[j].w}, Q[p]);
+          }
+        }
+      });
+    }
+  }
+  if constexpr (SCORE) {
+    const float iz = 1.0f / z;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      const float Pd = (d & 1) ? P[d / 2].y : P[d / 2].x;
+      if constexpr (SHARED) {
+        score[d] = fmaf(Pd, iz, -x[d] * vec[NQ * 4 + d]);
+      } else {
+        const float Qd = (d & 1) ? Q[d / 2].y : Q[d / 2].x;
+        score[d] = (Pd - x[d] * Qd) * iz;
+      }
+    }
+  }
+  return m + __logf(z);
+}
+
+template <int DP>
+__device__ __forceinline__ float ws_target_logp(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
+                                                int gmmv, int dreal, const float (&x)[DP]) {
+  float dummy[DP];
+  switch (D.kind) {
+    case SDEH_DENS_GMM:
+      return (gmmv == 2 ? gmm_online<DP, true, false>(lds, L, D.n_comp, x, dummy)
+                        : gmm_online<DP, false, false>(lds, L, D.n_comp, x, dummy)) + D.lnc;
+    case SDEH_DENS_DIAG_GAUSS: return dgauss_logp<DP>(ws + L.dg[0], x) + D.lnc;
+    case SDEH_DENS_MULTI_WELL: return mwell_logp<DP>(D, dreal, x);
+    case SDEH_DENS_FUNNEL: return funnel_logp<DP>(D, dreal, x);
+    default: return 0.0f;
+  }
+}
+
+template <int DP>
+__device__ __forceinline__ void ws_target_score(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
+                                                int gmmv, int dreal, const float (&x)[DP], float (&s)[DP]) {
+  switch (D.kind) {
+    case SDEH_DENS_GMM:
+      if (gmmv == 2) (void)gmm_online<DP, true, true>(lds, L, D.n_comp, x, s);
+      else (void)gmm_online<DP, false, true>(lds, L, D.n_comp, x, s);
+      break;
+    case SDEH_DENS_DIAG_GAUSS: dgauss_score<DP>(ws + L.dg[0], x, s); break;
+    case SDEH_DENS_MULTI_WELL: mwell_score<DP>(D, dreal, x, s); break;
+    case SDEH_DENS_FUNNEL: funnel_score<DP>(D, dreal, x, s); break;
+    default:
+#pragma unroll
+      for (int d = 0; d < DP; ++d) s[d] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// M wave: FourierMLP forward, x read from / output written to the group's exchange buffer [coordinate][64].
+//
+// The wave's two 32-trajectory column tiles A and B are software-pipelined against each other: while the MFMAs of
+// one tile occupy the matrix pipe, the activation of the other tile's previous output issues on the VALU in their
+// shadow (one element per k-step, order pinned by scheduling fences):
+//   L0(A) | L0(B) + act(A0) | L1(A) + act(B0) | L1(B) + act(A1) | ... | out(A) + act(B_last) | out(B) + publish(A)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_apply(float v, int act) {
+  return act == SDEH_ACT_GELU_ERF ? act_gelu(v) : (act == SDEH_ACT_SILU ? act_silu(v) : act_relu(v));
+}
+
+// out[OTO] += W[s][ot] * in-operand(s) for NS k-steps, while activating the NE elements of `side` in place.
+// The A operands (packed weights in LDS) are fetched PF k-steps ahead through a rotating register window: the LDS
+// queue is shared with the V waves' mixture-table reads, and an un-prefetched weight read in front of every MFMA
+// pair left the matrix pipe idle for the whole LDS latency (measured: 25 us per step for 15 us of MFMA work).
+template <int NS, int OTO, int NSIDE, class IN>
+__device__ __forceinline__ void mfma_stage(const float* __restrict__ w, IN&& in, f32x16 (&out)[OTO],
+                                           f32x16 (&side)[NSIDE], bool do_side, int act) {
+  constexpr int NE = NSIDE * 16;
+  constexpr int PF = NS < 6 ? NS : 6;
+  float wq[PF][OTO];
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+#pragma unroll
+    for (int ot = 0; ot < OTO; ++ot) wq[s][ot] = w[(s * OTO + ot) * 64];
+  SDEH_FENCE();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    float a[OTO];
+#pragma unroll
+    for (int ot = 0; ot < OTO; ++ot) a[ot] = wq[s % PF][ot];
+    if (s + PF < NS) {
+#pragma unroll
+      for (int ot = 0; ot < OTO; ++ot) wq[s % PF][ot] = w[((s + PF) * OTO + ot) * 64];
+    }
+    const float b = in(s);
+#pragma unroll
+    for (int ot = 0; ot < OTO; ++ot) out[ot] = SDEH_MFMA(a[ot], b, out[ot]);
+    if (do_side) {
+#pragma unroll
+      for (int e = s * NE / NS; e < (s + 1) * NE / NS; ++e) side[e / 16][e % 16] = act_apply(side[e / 16][e % 16], act);
+    }
+    SDEH_FENCE();
+  }
+}
+
+template <int DP, int C>
+__device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
+                                       int act, const f32x16 (&emb)[C / 32], int lane) {
+  constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
+  const int h = lane >> 5, j = lane & 31;
+  f32x16 curA[OT], curB[OT], nxtA[OT], nxtB[OT];
+  {  // input layer: e = input_embed(x) + timestep_embed(t)
+    float xa[R], xb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float* row = xbuf + (h ? mdim(r, 1) : mdim(r, 0)) * 64 + j;
+      xa[r] = row[0];
+      xb[r] = row[32];
+    }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) curA[ot] = curB[ot] = emb[ot];
+    const float* w = lds + L.w_in + lane;
+    mfma_stage<R, OT, OT>(w, [&](int s) { return xa[s]; }, curA, curB, false, act);
+    mfma_stage<R, OT, OT>(w, [&](int s) { return xb[s]; }, curB, curA, true, act);  // + act(A0)
+  }
+  // invariant at the top of each layer: curA activated, curB not yet
+  for (int l = 0; l < L.n_hidden; ++l) {
+    const float* bias = lds + L.b_hid + l * C;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) nxtA[ot] = nxtB[ot] = load16(bias + (ot * 2 + h) * 16);
+    const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
+    mfma_stage<C / 2, OT, OT>(w, [&](int s) { return curA[s / 16][s % 16]; }, nxtA, curB, true, act);  // + act(B)
+    mfma_stage<C / 2, OT, OT>(w, [&](int s) { return curB[s / 16][s % 16]; }, nxtB, nxtA, true, act);  // + act(A')
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) { curA[ot] = nxtA[ot]; curB[ot] = nxtB[ot]; }
+  }
+  {  // out_layer(act(e)); the A tile's result is published while the B tile's MFMAs run
+    f32x16 uA[OTD], uB[OTD];
+#pragma unroll
+    for (int t = 0; t < OTD; ++t) uA[t] = uB[t] = load16(lds + L.b_out + (t * 2 + h) * 16);
+    const float* w = lds + L.w_out + lane;
+    mfma_stage<C / 2, OTD, OT>(w, [&](int s) { return curA[s / 16][s % 16]; }, uA, curB, true, act);  // + act(B)
+    f32x16 none[1];
+    mfma_stage<C / 2, OTD, 1>(w, [&](int s) { return curB[s / 16][s % 16]; }, uB, none, false, act);
+    // accumulator register r of lane (j,h) is coordinate mdim(r,h) of trajectory j (tile A) / 32+j (tile B)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float* row = xbuf + (h ? mdim(r, 1) : mdim(r, 0)) * 64 + j;
+      row[0] = uA[r / 16][r % 16];
+      row[32] = uB[r / 16][r % 16];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------------------------
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC>
+__global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
+                                                      const float* __restrict__ noise, float* __restrict__ xT,
+                                                      float* __restrict__ rnd_out, float* __restrict__ xs,
+                                                      const TrajArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int XR = xrows<DP>();
+  const WsLayout& L = A.lay;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_m = wave >= kWsGroups;
+  const int group = is_m ? wave - kWsGroups : wave;
+
+  {  // stage the LDS image (packed weights + GMM tables) once per workgroup
+    const float4* src = reinterpret_cast<const float4*>(ws);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < L.lds_floats / 4; i += 512) dst[i] = src[i];
+  }
+  float* __restrict__ xbuf = lds + L.lds_floats + group * (XR * 64);
+
+  const int ctrl_kind = CTRL >= 0 ? CTRL : A.ctrl_kind, loss_kind = LOSS >= 0 ? LOSS : A.loss_kind;
+  const int gmmv = GMMV >= 0 ? GMMV : L.gmm_lds, act = ACT >= 0 ? ACT : A.act;
+  const int flags = A.flags;
+  const int d = PAD ? A.d : DP;
+  const int n_steps = A.n_steps;
+
+  if (is_m) {
+    // =================================================================================== M wave
+    constexpr int OT = C / 32;
+    const int h = lane >> 5;
+    __syncthreads();  // LDS image staged
+    f32x16 emb[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (ot * 2 + h) * 16);
+    __syncthreads();  // barrier A: x_0 published
+    for (int i = 0; i < n_steps; ++i) {
+      if constexpr ((SDEH_ABL & 1) == 0) ws_mlp<DP, C>(lds, xbuf, L, act, emb, lane);
+      __syncthreads();  // barrier B: network output published
+      if (i + 1 < n_steps) {
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (i + 1) * C + (ot * 2 + h) * 16);
+      }
+      __syncthreads();  // barrier A: x_{i+1} published
+    }
+    return;
+  }
+
+  // ===================================================================================== V wave
+  const long long row = (long long)blockIdx.x * 256 + group * 64 + lane;
+  const bool live = row < A.batch;
+  const long long lrow = live ? row : A.batch - 1;  // dead lanes shadow the last row and never store
+  DensArgs tgt = A.target;
+  if (TGT >= 0) tgt.kind = TGT;
+
+  float x[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    const float v = x0[lrow * d + (PAD ? min(j, d - 1) : j)];
+    x[j] = (!PAD || j < d) ? v : 0.0f;
+  }
+  // exchange buffer: coordinates >= DP that M-layout registers can address stay zero for the whole launch
+#pragma unroll
+  for (int j = 0; j < XR; ++j) xbuf[j * 64 + lane] = j < DP ? x[j] : 0.0f;
+  __syncthreads();  // LDS image staged
+
+  float rnd = 0.0f;
+  if (flags & SDEH_FLAG_INIT_LOGP) rnd = dgauss_logp<DP>(ws + L.dg[2], x);
+  if (xs != nullptr && live) {
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+      if (!PAD || j < d) xs[lrow * d + j] = x[j];
+  }
+  const bool lv = flags & SDEH_FLAG_CHANGE_SDE_CTRL;
+  const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
+  const bool refc = REFC >= 0 ? REFC != 0 : (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
+  const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+  __syncthreads();  // barrier A: x_0 published
+
+  for (int i = 0; i < n_steps; ++i) {
+    cfp cf = as_const(ws + L.coef + i * kCoefStride);
+    const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
+
+    // ---- score term of the control (needs x only; runs while the M wave evaluates the network) -----------
+    float sterm[DP];
+    if (ctrl_kind != SDEH_CTRL_CLIPPED) {
+      float tsc[DP], psc[DP];
+      if (need_t) {
+        if constexpr (SDEH_ABL & 2) {
+#pragma unroll
+          for (int j = 0; j < DP; ++j) tsc[j] = -x[j];
+        } else {
+          ws_target_score<DP>(tgt, ws, lds, L, gmmv, d, x, tsc);
+        }
+      }
+      if (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR) dgauss_score<DP>(ws + L.dg[1], x, psc);
+      const float w = cf[CF_W];
+      if (ctrl_kind == SDEH_CTRL_SCORE) {  // reparam.py:56-83
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sterm[j] = tsc[j];
+      } else if (ctrl_kind == SDEH_CTRL_LERP) {  // reparam.py:131-144; torch.lerp's two-sided formula
+        if (w < 0.5f) {
+#pragma unroll
+          for (int j = 0; j < DP; ++j) sterm[j] = psc[j] + w * (tsc[j] - psc[j]);
+        } else {
+          const float w1 = 1.0f - w;
+#pragma unroll
+          for (int j = 0; j < DP; ++j) sterm[j] = tsc[j] - (tsc[j] - psc[j]) * w1;
+        }
+      } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {  // reparam.py:185-197
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sterm[j] = w * tsc[j];
+      } else {  // SDEH_CTRL_LERP_PRIOR, reparam.py:166-178
+        const float w1 = 1.0f - w;
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sterm[j] = w1 * psc[j];
+      }
+      cfp gam = as_const(ws + L.gam + i * L.g);
+      const float mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;  // Lerp*: ctrl + sde.diff(t) * score
+      const float g0 = gam[0];
+      if (L.g == 1) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * g0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * gam[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) sterm[j] = 0.0f;
+    }
+    SDEH_FENCE();
+
+    // ---- Gaussian draws (independent of the control) --------------------------------------------------------
+    float xi[DP];
+    if (noise != nullptr) {
+      const float* __restrict__ np = noise + ((long long)i * A.batch + lrow) * d;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) xi[j] = np[PAD ? min(j, d - 1) : j];
+    } else {
+#pragma unroll
+      for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
+        float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!PAD || 4 * jb < d) {
+          if constexpr (SDEH_ABL & 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              n[q] = __uint_as_float((__float_as_uint(x[(4 * jb + q) % DP]) & 0x007fffffu) | 0x3f800000u) - 1.5f;
+          } else {
+            box_muller4(philox_block(A.seed, A.offset, grow, i, jb), n);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * jb + q < DP) xi[4 * jb + q] = n[q];
+        SDEH_FENCE();
+      }
+    }
+
+    // exponential integrator (oc.py:428-443):  x <- x a_k + (b_k^2 s^2) u + (s b_k) xi
+    // Euler-Maruyama (oc.py:213-219, 325-331): x <- x + (f x + sig u) dt + sig (xi sqrt(dt))
+    const bool expo = loss_kind == SDEH_LOSS_EXPONENTIAL;
+    const float c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], dt, 1.0f);
+    const float c_u = expo ? cf[CF_B2S2] : sig * dt;
+    const float c_n = expo ? cf[CF_SBK] : sig * sqdt;
+    const float c_i = expo ? cf[CF_SBK] : sqdt;  // Ito term: sum(g * xi) * c_i
+    float rsub[DP];  // reference_ctrl = sigma(t) * prior.score(x) (solver/oc.py:305-306), evaluated at the step's input
+    if (refc) {
+      dgauss_score<DP>(ws + L.dg[1], x, rsub);
+#pragma unroll
+      for (int j = 0; j < DP; ++j) rsub[j] *= sig;
+    }
+    // the part of the update that does not need the control: x <- c_x x + c_n xi  (the control term is added below)
+#pragma unroll
+    for (int j = 0; j < DP; ++j) x[j] = fmaf(c_n, xi[j], c_x * x[j]);
+    SDEH_FENCE();
+
+    __syncthreads();  // barrier B: the M wave has published the network output
+    // ---- u = clip(nn) + score term; running cost (losses/oc.py:204-211, 319-323, 418-431); publish x_{i+1} ---
+    float cost = 0.0f, itosum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const float nn = (SDEH_ABL & 1) ? 0.01f * xi[j] : xbuf[j * 64 + lane];
+      float u = clipf(nn, A.clip_model) + sterm[j];
+      if (PAD) u = j < d ? u : 0.0f;
+      float g = u;  // the control entering the cost / Ito term (gen_plus_inf / gen_minus_ref)
+      if (refc) {
+        g = u - rsub[j];
+        cost = lv ? fmaf(g, u - 0.5f * (rsub[j] + u), cost) : fmaf(g, g, cost);
+      } else {
+        cost = lv ? fmaf(u, u - 0.5f * u, cost) : fmaf(u, u, cost);
+      }
+      itosum = fmaf(g, xi[j], itosum);
+      x[j] = fmaf(c_u, u, x[j]);
+      if (PAD) x[j] = j < d ? x[j] : 0.0f;
+      xbuf[j * 64 + lane] = x[j];
+    }
+    if (!lv) cost *= 0.5f;
+    if (expo) rnd = fmaf(cf[CF_B2S2], cost, rnd);
+    else rnd = fmaf(cost, dt, rnd);
+    if (loss_kind == SDEH_LOSS_TIME_REVERSAL && !(flags & SDEH_FLAG_TRAIN)) rnd -= cf[CF_DDIV];
+    if (flags & SDEH_FLAG_ITO) rnd = fmaf(itosum, c_i, rnd);
+    __syncthreads();  // barrier A: x_{i+1} published
+
+    if (xs != nullptr && live) {
+      float* __restrict__ xp = xs + ((long long)(i + 1) * A.batch + lrow) * d;
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        if (!PAD || j < d) xp[j] = x[j];
+    }
+  }
+
+  // ---- terminal costs (oc.py:225, 337, 449-450) ----------------------------------------------------------
+  if (flags & SDEH_FLAG_TERMINAL_SECOND) rnd += dgauss_logp<DP>(ws + L.dg[2], x);
+  if (flags & SDEH_FLAG_TERMINAL_TARGET) rnd -= clipf(ws_target_logp<DP>(tgt, ws, lds, L, gmmv, d, x), A.clip_target);
+  if (live) {
+    rnd_out[row] = rnd;
+#pragma unroll
+    for (int j = 0; j < DP; ++j)
+      if (!PAD || j < d) xT[row * d + j] = x[j];
+  }
+}
+
+template <int DP>
+inline size_t ws_lds_bytes(const WsLayout& L) {
+  return ((size_t)L.lds_floats + (size_t)kWsGroups * xrows<DP>() * 64) * sizeof(float);
+}
+
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC>
+int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)((a.batch + 255) / 256);
+  hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC>), dim3(grid), dim3(512), lds_bytes, stream,
+                     a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+}  // namespace sdeh

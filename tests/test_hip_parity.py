@@ -134,16 +134,18 @@ def test_ragged_and_tiny_batches():
         assert torch.equal(part.samples, full.samples[:b]), b
 
 
-def test_generic_variants_also_match(tmp_path):
-    """The BASELINE configurations normally dispatch to compile-time specialised kernels; re-run the golden parity
-    test in a subprocess with SDEH_GENERIC_ONLY=1 so that the generic (run-time switched) variants are checked too."""
+@pytest.mark.parametrize("env_var", ["SDEH_GENERIC_ONLY", "SDEH_LEGACY"])
+def test_alternative_kernels_also_match(env_var):
+    """The BASELINE configurations normally dispatch to compile-time specialised, wave-specialised kernels.  Re-run the
+    golden parity tests in a subprocess with SDEH_GENERIC_ONLY=1 (run-time switched variants) and with SDEH_LEGACY=1
+    (the single-wave kernel with scalar-load mixture tables, the fallback for mixtures too large for LDS)."""
     import os
     import subprocess
     import sys
 
-    if os.environ.get("SDEH_GENERIC_ONLY"):
-        pytest.skip("already the generic run")
-    env = dict(os.environ, SDEH_GENERIC_ONLY="1")
+    if os.environ.get("SDEH_GENERIC_ONLY") or os.environ.get("SDEH_LEGACY"):
+        pytest.skip("already an alternative-kernel run")
+    env = dict(os.environ, **{env_var: "1"})
     out = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
                           "eval_matches_reference_golden or rnd_rows_match_oracle"],
                          env=env, capture_output=True, text=True, cwd=str(Path(__file__).parents[1]))

@@ -15,7 +15,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 CSRC = ROOT / "sde_sampler_amd" / "csrc"
-MASKS = [0, 1, 2, 4, 8, 3, 7, 15]
+MASKS = [0, 1, 2, 4, 8, 3, 6]
 
 CHILD = r"""
 import sys, json, torch

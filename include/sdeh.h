@@ -73,6 +73,13 @@ enum {
  * distr/gauss.py:14-63).  Selects a cheaper evaluation (one table word per (k,d)); results are undefined if the
  * promise is false -- the Python binding checks the tensor once per (tensor, version) before setting it. */
 #define SDEH_DENS_FLAG_SHARED_SCALE 1
+/* GMM with SHARED_SCALE only: the caller additionally promises that coordinates >= n are identical in every component
+ * (loc[k,d] == loc[0,d] for d >= n), as in the reference's own high-dimensional mixtures, which pad a 2-d mixture with
+ * zero means (distr/gauss.py:59-60).  Those coordinates factor out of the mixture as one Gaussian: they cancel in the
+ * responsibilities and contribute (loc_d - x_d)/scale_d^2 to the score.  Encoded in bits 8..23 of `flags` as n + 1
+ * (0 = no promise). */
+#define SDEH_DENS_FLAG_NVARY(n) ((((n) + 1) & 0xFFFF) << 8)
+#define SDEH_DENS_FLAG_GET_NVARY(flags) ((((flags) >> 8) & 0xFFFF) - 1) /* -1 when absent */
 
 typedef struct {
   int32_t kind;         /* SdehDensityKind */

@@ -16,7 +16,7 @@ int launch_prep(const PrepArgs& p, hipStream_t stream);
 int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int nb, float* out, hipStream_t stream);
 int launch_weights(const float* rnd, long long n, const float* mx, float* w, hipStream_t stream);
 
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc)                                \
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv)                           \
   int launch_ws_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                 \
   int launch_legacy_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
 #include "sdeh_variants.inc"
@@ -26,12 +26,13 @@ struct Variant {
   int dp;
   bool pad;
   int loss, ctrl, tgt, gmm, act, refc;  // -1 = run-time switch
+  int gnv;                              // > 0: shared-scale mixture tables cover only the first gnv coordinates
   TrajLauncher fn;         // wave-specialised kernel (sdeh_traj_ws.hpp)
   TrajLauncher fn_legacy;  // single-wave kernel (sdeh_traj.hpp); returns SDEH_ERR_UNSUPPORTED when not compiled in
   const char* name;
 };
 static const Variant kVariants[] = {
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 };
@@ -45,7 +46,7 @@ static int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-static bool is_generic(const Variant& v) { return v.loss < 0 && v.ctrl < 0 && v.tgt < 0 && v.gmm < 0 && v.act < 0 && v.refc < 0; }
+static bool is_generic(const Variant& v) { return v.loss < 0 && v.ctrl < 0 && v.tgt < 0 && v.gmm < 0 && v.act < 0 && v.refc < 0 && v.gnv <= 0; }
 
 // generic variant for dimension d: the exact one when compiled, else the smallest padded one
 static const Variant* pick_variant(int d) {
@@ -59,21 +60,27 @@ static const Variant* pick_variant(int d) {
 }
 
 // specialised variant whose compile-time choices all match the problem, if any
-static const Variant* pick_specialised(int d, int loss, int ctrl, int tgt, int gmm, int act, int refc) {
+// gmm: 0 = no LDS tables possible, 1 = general, 2 = shared scale; nvary: varying-prefix length promised by the caller (-1 none)
+static const Variant* pick_specialised(int d, int loss, int ctrl, int tgt, int gmm, int act, int refc, int nvary) {
+  const Variant* best = nullptr;
   for (const Variant& v : kVariants) {
     if (is_generic(v) || v.pad || v.dp != d) continue;
-    if ((v.loss < 0 || v.loss == loss) && (v.ctrl < 0 || v.ctrl == ctrl) && (v.tgt < 0 || v.tgt == tgt) &&
-        (v.gmm < 0 || v.gmm == gmm) && (v.act < 0 || v.act == act) && (v.refc < 0 || v.refc == refc))
-      return &v;
+    if (!((v.loss < 0 || v.loss == loss) && (v.ctrl < 0 || v.ctrl == ctrl) && (v.tgt < 0 || v.tgt == tgt) &&
+          (v.gmm < 0 || v.gmm == gmm) && (v.act < 0 || v.act == act) && (v.refc < 0 || v.refc == refc)))
+      continue;
+    if (v.gnv > 0 && !(gmm == 2 && nvary >= 0 && nvary <= v.gnv)) continue;
+    // prefer the variant whose mixture tables cover the fewest coordinates
+    if (best == nullptr || (v.gnv > 0 && (best->gnv <= 0 || v.gnv < best->gnv))) best = &v;
   }
-  return nullptr;
+  return best;
 }
 
 static int align4(int v) { return (v + 3) & ~3; }
 
 // Workspace layout for one problem geometry.
+// gmm_nv: number of leading coordinates the shared-scale mixture tables cover (multiple of 4; 0 = all)
 static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g, bool shared_scale = false,
-                            bool gmm_global = false) {
+                            bool gmm_global = false, int gmm_nv = 0) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.dp = dp; L.c = c; L.ot = c / 32; L.otd = row_tiles(dp); L.r_in = mregs(dp);
@@ -94,11 +101,13 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   L.gmm_lds = (k_max > 0 && !gmm_global && ((size_t)(o + gmm_floats) + xbuf_floats) * sizeof(float) <= 160 * 1024) ? 1 : 0;
   if (L.gmm_lds && shared_scale) {
     // shared-scale tables: one word per (k,d), rows of 4*ceil(dp/4) floats, then the two per-coordinate vectors
-    const int rs = 4 * ((dp + 3) / 4);
+    const int rs_full = 4 * ((dp + 3) / 4);
+    const int rs = gmm_nv > 0 ? gmm_nv : rs_full;
     L.gmm_lds = 2;
     L.gmm_row = rs;
     L.gmm_lg = o; o += k_rows * rs;
-    L.gmm_sc = o; o += k_rows * rs + 2 * rs;
+    L.gmm_sc = o; o += k_rows * rs;
+    L.gmm_vec = o; o += 4 * rs_full;
     L.gmm_c = o; o += align4(k_rows);
   } else if (L.gmm_lds) {
     L.gmm_lg = o; o += k_rows * L.gmm_row;
@@ -310,8 +319,18 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
 
   const Variant* v = plan->variant;
   const bool shared = pr->target.kind == SDEH_DENS_GMM && (pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE);
+  const int nvary = shared ? SDEH_DENS_FLAG_GET_NVARY(pr->target.flags) : -1;
   static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
+  static const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing aid: force the generic variants
+  // which GMM table form would the layout give?  (0: tables do not fit LDS, 1: general, 2: shared scale)
   WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy);
+  const Variant* sv = no_spec ? nullptr
+                              : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds,
+                                                 net.activation, refc ? 1 : 0, nvary);
+  if (sv != nullptr && sv->dp == v->dp) {
+    v = sv;
+    if (v->gnv > 0) L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, v->gnv);
+  }
   if ((size_t)L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd: workspace too small");
 
   hipStream_t st = (hipStream_t)stream;
@@ -337,9 +356,6 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
   A.second = {pr->second.kind, pr->second.n_components, pr->second.log_norm_const, pr->second.p0, pr->second.p1};
   A.seed = seed; A.offset = offset;
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
-  static const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing aid: force the generic variants
-  const Variant* sv = no_spec ? nullptr : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds, net.activation, refc ? 1 : 0);
-  if (sv != nullptr && sv->dp == v->dp) v = sv;
   // The wave-specialised kernel needs GMM tables in LDS; mixtures too large for that use the single-wave kernel
   // with scalar-load tables (also selectable with SDEH_LEGACY=1 for A/B measurements).
   const bool legacy = force_legacy || (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0);

@@ -56,6 +56,7 @@ struct WsLayout {
   // inside the LDS image when they fit (gmm_lds = 1: broadcast ds_read_b128, deep VGPR prefetch), else in the
   // global part of the workspace (scalar loads).
   int gmm_lds, gmm_row, gmm_rows;  // gmm_rows: table rows = K rounded up to a multiple of 8 (padding: logit -inf)
+  int gmm_vec;    // shared-scale form: four vectors of 4*ceil(dp/4) floats: 1/(sqrt2 s_d), 1/s_d^2, mu_0d/(sqrt2 s_d), mu_0d/s_d^2
   int gmm_lg;     // [K][gmm_row/2][2]  (mu, 1/(2 sigma^2))
   int gmm_sc;     // [K][gmm_row/2][2]  (mu/sigma^2, 1/sigma^2)
   int gmm_c;      // [K]  log_softmax(log w)_k - sum_d (log sigma_kd + 0.5 log 2pi)

@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
     const SdehDensity& G = pr.target;
     const int K = G.n_components;
     const int K2 = L.gmm_rows;  // K rounded up to a multiple of 8; padding rows have logit -inf
-    if (L.gmm_lds == 2) {  // shared-scale tables (SDEH_DENS_FLAG_SHARED_SCALE)
-      const int rs = L.gmm_row;
+    if (L.gmm_lds == 2) {  // shared-scale tables (SDEH_DENS_FLAG_SHARED_SCALE); rows cover the first gmm_row coordinates
+      const int rs = L.gmm_row, rs_full = 4 * ((L.dp + 3) / 4);
       for (int e = gid; e < K2 * rs; e += stride) {
         const int k = e / rs, j = e % rs;
         const bool ok = j < G.dim && k < K;
@@ -183,11 +183,13 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
         ws[L.gmm_lg + e] = ok ? mu * (0.70710678118654752440f / sg) : 0.0f;
         ws[L.gmm_sc + e] = ok ? mu / (sg * sg) : 0.0f;
       }
-      for (int j = gid; j < rs; j += stride) {
+      for (int j = gid; j < rs_full; j += stride) {  // per-coordinate vectors (component 0 stands for all beyond rs)
         const bool ok = j < G.dim;
-        const float sg = ok ? G.scale[j] : 1.0f;
-        ws[L.gmm_sc + K2 * rs + j] = ok ? 0.70710678118654752440f / sg : 0.0f;
-        ws[L.gmm_sc + K2 * rs + rs + j] = ok ? 1.0f / (sg * sg) : 0.0f;
+        const float sg = ok ? G.scale[j] : 1.0f, mu0 = ok ? G.loc[j] : 0.0f;
+        ws[L.gmm_vec + j] = ok ? 0.70710678118654752440f / sg : 0.0f;
+        ws[L.gmm_vec + rs_full + j] = ok ? 1.0f / (sg * sg) : 0.0f;
+        ws[L.gmm_vec + 2 * rs_full + j] = ok ? mu0 * (0.70710678118654752440f / sg) : 0.0f;
+        ws[L.gmm_vec + 3 * rs_full + j] = ok ? mu0 / (sg * sg) : 0.0f;
       }
     } else {
       // general tables: per coordinate pair a quad (mu_d, mu_d+1, a_d, a_d+1) / (mu/s^2 at d, d+1, 1/s^2 at d, d+1)

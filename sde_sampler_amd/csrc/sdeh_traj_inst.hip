@@ -1,5 +1,5 @@
 // One translation unit per compiled trajectory-kernel variant:
-//   hipcc -DSDEH_DP=<n> -DSDEH_PAD=<0|1> [-DSDEH_SPEC="loss,ctrl,target,gmm,act,refc" -DSDEH_SPECNAME=<tag>] -c sdeh_traj_inst.hip
+//   hipcc -DSDEH_DP=<n> -DSDEH_PAD=<0|1> [-DSDEH_SPEC="loss,ctrl,target,gmm,act,refc" -DSDEH_GNV=<n> -DSDEH_SPECNAME=<tag>] -c sdeh_traj_inst.hip
 // The kernels keep x[d] in registers, so d is a compile-time constant.  PAD=0 variants require d == DP; PAD=1
 // variants accept any d <= DP (coordinates >= d are held at zero).  SDEH_SPEC additionally fixes the loss / control /
 // target / GMM-table / activation kinds (see sdeh_variants.inc); without it they stay run-time switches.
@@ -21,13 +21,16 @@
 #ifndef SDEH_GENERIC
 #define SDEH_GENERIC 0
 #endif
+#ifndef SDEH_GNV
+#define SDEH_GNV -1
+#endif
 
 #define SDEH_CAT2(a, b, c, d, e, f) a##b##c##d##e##f
 #define SDEH_CAT(a, b, c, d, e, f) SDEH_CAT2(a, b, c, d, e, f)
 
 namespace sdeh {
 int SDEH_CAT(launch_ws_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const TrajArgs& a, hipStream_t stream) {
-  return launch_traj_ws<SDEH_DP, 64, (SDEH_PAD != 0), SDEH_SPEC>(a, stream);
+  return launch_traj_ws<SDEH_DP, 64, (SDEH_PAD != 0), SDEH_SPEC, SDEH_GNV>(a, stream);
 }
 int SDEH_CAT(launch_legacy_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const TrajArgs& a, hipStream_t stream) {
 #if SDEH_GENERIC

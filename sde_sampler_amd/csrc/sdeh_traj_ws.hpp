@@ -65,18 +65,23 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 //            followed by the vectors 1/(sqrt2 sigma_d) and 1/sigma_d^2.
 //   general: logit table (mu_d, mu_d+1, a_d, a_d+1) with a = 1/(2 sigma^2), two coordinates per float4;
 //            score table (mu/sigma^2 at d, d+1, 1/sigma^2 at d, d+1).
-template <int DP, bool SHARED, bool SCORE>
+//   SHARED with NV < DP: the tables cover only the first NV coordinates (SDEH_DENS_FLAG_NVARY: the others are identical in
+//            every component); those factor out as one Gaussian -- they cancel in the responsibilities and add
+//            (mu_0d - x_d)/sigma_d^2 to the score and -(x_d - mu_0d)^2/(2 sigma_d^2) to the log-density.
+template <int DP, bool SHARED, bool SCORE, int NV>
 __device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const WsLayout& L, int K,
                                             const float (&x)[DP], float (&score)[DP]) {
+  static_assert(NV == DP || (SHARED && NV % 4 == 0 && NV < DP), "NV: DP, or a multiple of 4 below DP (shared scale)");
   constexpr int CH = 8;
-  constexpr int NP = (DP + 1) / 2;                           // coordinate pairs
-  constexpr int NQ = SHARED ? (DP + 3) / 4 : (DP + 1) / 2;  // float4 per table row
+  constexpr int NP = (NV + 1) / 2;                           // coordinate pairs the tables cover
+  constexpr int NQ = SHARED ? (NV + 3) / 4 : (DP + 1) / 2;  // float4 per table row
+  constexpr int RSF = 4 * ((DP + 3) / 4);                   // stride of the per-coordinate vectors
   constexpr int NA = (NQ + 1) / 2;
   const int KR = L.gmm_rows;  // multiple of CH
   const float* __restrict__ pc = lds + L.gmm_c;
   const float4* __restrict__ plg = reinterpret_cast<const float4*>(lds + L.gmm_lg);
   const float4* __restrict__ psc = reinterpret_cast<const float4*>(lds + L.gmm_sc);
-  const float* __restrict__ vec = lds + L.gmm_sc + KR * (NQ * 4);  // SHARED: 1/(sqrt2 sigma_d), then 1/sigma_d^2
+  const float* __restrict__ vec = lds + L.gmm_vec;  // SHARED: 1/(sqrt2 s_d), 1/s_d^2, mu_0d/(sqrt2 s_d), mu_0d/s_d^2
   f2 y[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
@@ -159,26 +164,36 @@ __device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const
     const float iz = 1.0f / z;
 #pragma unroll
     for (int d = 0; d < DP; ++d) {
-      const float Pd = (d & 1) ? P[d / 2].y : P[d / 2].x;
       if constexpr (SHARED) {
-        score[d] = fmaf(Pd, iz, -x[d] * vec[NQ * 4 + d]);
+        if (d < NV) score[d] = fmaf((d & 1) ? P[d / 2].y : P[d / 2].x, iz, -x[d] * vec[RSF + d]);
+        else score[d] = fmaf(-x[d], vec[RSF + d], vec[3 * RSF + d]);
       } else {
-        const float Qd = (d & 1) ? Q[d / 2].y : Q[d / 2].x;
+        const float Pd = (d & 1) ? P[d / 2].y : P[d / 2].x, Qd = (d & 1) ? Q[d / 2].y : Q[d / 2].x;
         score[d] = (Pd - x[d] * Qd) * iz;
       }
     }
   }
-  return m + __logf(z);
+  float logp = m + __logf(z);
+  if constexpr (SHARED && NV < DP) {
+    float rest = 0.0f;
+#pragma unroll
+    for (int d = NV; d < DP; ++d) {
+      const float t = fmaf(x[d], vec[d], -vec[2 * RSF + d]);
+      rest = fmaf(t, t, rest);
+    }
+    logp -= rest;
+  }
+  return logp;
 }
 
-template <int DP>
+template <int DP, int NV>
 __device__ __forceinline__ float ws_target_logp(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
                                                 int gmmv, int dreal, const float (&x)[DP]) {
   float dummy[DP];
   switch (D.kind) {
     case SDEH_DENS_GMM:
-      return (gmmv == 2 ? gmm_online<DP, true, false>(lds, L, D.n_comp, x, dummy)
-                        : gmm_online<DP, false, false>(lds, L, D.n_comp, x, dummy)) + D.lnc;
+      return (gmmv == 2 ? gmm_online<DP, true, false, NV>(lds, L, D.n_comp, x, dummy)
+                        : gmm_online<DP, false, false, DP>(lds, L, D.n_comp, x, dummy)) + D.lnc;
     case SDEH_DENS_DIAG_GAUSS: return dgauss_logp<DP>(ws + L.dg[0], x) + D.lnc;
     case SDEH_DENS_MULTI_WELL: return mwell_logp<DP>(D, dreal, x);
     case SDEH_DENS_FUNNEL: return funnel_logp<DP>(D, dreal, x);
@@ -186,13 +201,13 @@ __device__ __forceinline__ float ws_target_logp(const DensArgs& D, const float* 
   }
 }
 
-template <int DP>
+template <int DP, int NV>
 __device__ __forceinline__ void ws_target_score(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
                                                 int gmmv, int dreal, const float (&x)[DP], float (&s)[DP]) {
   switch (D.kind) {
     case SDEH_DENS_GMM:
-      if (gmmv == 2) (void)gmm_online<DP, true, true>(lds, L, D.n_comp, x, s);
-      else (void)gmm_online<DP, false, true>(lds, L, D.n_comp, x, s);
+      if (gmmv == 2) (void)gmm_online<DP, true, true, NV>(lds, L, D.n_comp, x, s);
+      else (void)gmm_online<DP, false, true, DP>(lds, L, D.n_comp, x, s);
       break;
     case SDEH_DENS_DIAG_GAUSS: dgauss_score<DP>(ws + L.dg[0], x, s); break;
     case SDEH_DENS_MULTI_WELL: mwell_score<DP>(D, dreal, x, s); break;
@@ -302,7 +317,7 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
 // ---------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------
-template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC>
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV>
 __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                       const float* __restrict__ noise, float* __restrict__ xT,
                                                       float* __restrict__ rnd_out, float* __restrict__ xs,
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #pragma unroll
           for (int j = 0; j < DP; ++j) tsc[j] = -x[j];
         } else {
-          ws_target_score<DP>(tgt, ws, lds, L, gmmv, d, x, tsc);
+          ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, tsc);
         }
       }
       if (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR) dgauss_score<DP>(ws + L.dg[1], x, psc);
@@ -516,7 +531,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 
   // ---- terminal costs (oc.py:225, 337, 449-450) ----------------------------------------------------------
   if (flags & SDEH_FLAG_TERMINAL_SECOND) rnd += dgauss_logp<DP>(ws + L.dg[2], x);
-  if (flags & SDEH_FLAG_TERMINAL_TARGET) rnd -= clipf(ws_target_logp<DP>(tgt, ws, lds, L, gmmv, d, x), A.clip_target);
+  if (flags & SDEH_FLAG_TERMINAL_TARGET) rnd -= clipf(ws_target_logp<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x), A.clip_target);
   if (live) {
     rnd_out[row] = rnd;
 #pragma unroll
@@ -530,19 +545,19 @@ inline size_t ws_lds_bytes(const WsLayout& L) {
   return ((size_t)L.lds_floats + (size_t)kWsGroups * xrows<DP>() * 64) * sizeof(float);
 }
 
-template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC>
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV>
 int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   const size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
   const unsigned grid = (unsigned)((a.batch + 255) / 256);
-  hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC>), dim3(grid), dim3(512), lds_bytes, stream,
+  hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>), dim3(grid), dim3(512), lds_bytes, stream,
                      a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }

@@ -122,8 +122,9 @@ def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
         out.loc = keep.ptr(dist.loc, device, what)
         out.scale = keep.ptr(dist.scale, device, what)
         out.mixture_weights = keep.ptr(dist.mixture_weights, device, what)
-        if _shared_scale(dist.scale):
-            out.flags |= L.DENS_FLAG_SHARED_SCALE
+        shared, n_vary = _mixture_structure(dist.loc, dist.scale)
+        if shared:
+            out.flags |= L.DENS_FLAG_SHARED_SCALE | (((n_vary + 1) & 0xFFFF) << 8)
     elif "DoubleWell" in names:
         out.kind, out.n_components = L.DENS_MULTI_WELL, 1
         out.p0, out.p1 = float(dist.separation), float(dist.shift)
@@ -140,20 +141,27 @@ def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
                            "(GMM, Gauss, IsotropicGauss, Delta, DoubleWell, MultiWell, Funnel are built in)")
 
 
-_SHARED_SCALE_CACHE: dict = {}
-
-
-def _shared_scale(scale: torch.Tensor) -> bool:
-    """True when every mixture component has the same per-coordinate scale.  Costs one device sync per
-    (tensor, version): targets are fixed buffers, so this happens once."""
-    key = (scale.data_ptr(), scale._version, tuple(scale.shape), str(scale.device))
-    hit = _SHARED_SCALE_CACHE.get(key)
-    if hit is None:
-        hit = bool((scale == scale[:1]).all().item())
-        if len(_SHARED_SCALE_CACHE) > 64:
-            _SHARED_SCALE_CACHE.clear()
-        _SHARED_SCALE_CACHE[key] = hit
-    return hit
+def _mixture_structure(loc: torch.Tensor, scale: torch.Tensor) -> tuple[bool, int]:
+    """(shared_scale, n_varying): whether every component has the same per-coordinate scale, and -- if so -- the
+    smallest n such that coordinates >= n have the same mean in every component (the reference's high-dimensional
+    mixtures pad a 2-d mixture with zero means, distr/gauss.py:59-60).  These are the promises behind
+    SDEH_DENS_FLAG_SHARED_SCALE / SDEH_DENS_FLAG_NVARY.  Costs one device sync per (tensor object, version): targets
+    are fixed buffers, so this happens once.  The result is cached ON the tensor object (never by address: a freed
+    tensor's address is reused)."""
+    stamp = (loc._version, id(scale), scale._version, str(loc.device))
+    cached = getattr(loc, "_sdeh_structure", None)
+    if cached is not None and cached[0] == stamp:
+        return cached[1]
+    shared = bool((scale == scale[:1]).all().item())
+    n_vary = loc.shape[1]
+    if shared:
+        varying = (loc != loc[:1]).any(dim=0).nonzero()
+        n_vary = int(varying.max().item()) + 1 if varying.numel() else 0
+    try:
+        loc._sdeh_structure = (stamp, (shared, n_vary))
+    except AttributeError:  # exotic tensor subclasses without a __dict__: just recompute next time
+        pass
+    return shared, n_vary
 
 
 def _known_distribution(obj) -> bool:

@@ -30,6 +30,17 @@ WORKLOAD = "gmm50_pis_headline"
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA (= fp32 vector) dense peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_hbm_traffic():
+    """HBM bytes per trajectory-kernel launch from the committed rocprofv3 PMC passes (tools/pmc_profile.sh):
+    2 x FETCH_SIZE (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes."""
+    path = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        rec = json.loads(path.read_text())
+        return (2.0 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024.0
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def flops_per_traj_step(d: int, c: int, lh: int, k: int) -> float:
     """F(d,C,Lh,K) = 4dC + 2 Lh C^2 (MLP, time embedding hoisted) + 6dK + 4K (GMM score) + 20d."""
     return 4 * d * c + 2 * lh * c * c + 6 * d * k + 4 * k + 20 * d
@@ -162,9 +173,12 @@ def main():
                    "batch_per_gpu": B, "global_batch": world * B, "em_steps": T, "dim": d, "gmm_components": 40,
                    "noise": "in-kernel Philox4x32-10 + Box-Muller", "parallelism": f"batch-sharded x{world}"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
-                     "kernel": "sdeh::traj_kernel<50,64,false>", "kernel_ms": k_ms,
-                     "flops_per_traj_step": flops},
+                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_hbm_traffic(),
+                     "algorithmic_hbm_bytes": B * (8 * d + 4),
+                     "kernel": "sdeh::traj_ws_kernel<50,64,...> (wave-specialised; pis_gmm4 variant)", "kernel_ms": k_ms,
+                     "flops_per_traj_step": flops,
+                     "note": "fp32 MFMA and fp32 VALU share one datapath on gfx950 (profiles/r01_ubench_coexec.txt): "
+                             "157.3 TFLOP/s is the budget for both; F counts SURVEY 8d's algorithmic FLOPs"},
         "log_z": {"log_norm_const_is": full.log_norm_const_preds["log_norm_const_is"],
                   "log_norm_const_lb_ito": full.log_norm_const_preds["log_norm_const_lb_ito"],
                   "log_norm_const_lb": res.log_norm_const_preds["log_norm_const_lb"],

@@ -230,6 +230,25 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return act == SDEH_ACT_GELU_ERF ? act_gelu(v) : (act == SDEH_ACT_SILU ? act_silu(v) : act_relu(v));
 }
 
+// Two activations at once: the polynomial of the branch-free GELU runs on v_pk_fma_f32 (one 64-bit register pair).
+__device__ __forceinline__ f2 act_gelu2(f2 v) {
+  const f2 z = {fminf(fabsf(v.x) * 0.70710678118654752440f, 6.0f), fminf(fabsf(v.y) * 0.70710678118654752440f, 6.0f)};
+  f2 p = splat(6.603050149e-07f);
+  p = pk_fma(p, z, splat(-1.530170759e-05f));
+  p = pk_fma(p, z, splat(1.480139295e-04f));
+  p = pk_fma(p, z, splat(-7.626767611e-04f));
+  p = pk_fma(p, z, splat(2.001933838e-03f));
+  p = pk_fma(p, z, splat(3.411742314e-04f));
+  p = pk_fma(p, z, splat(-2.809073479e-02f));
+  p = pk_fma(p, z, splat(1.484803495e-01f));
+  p = pk_fma(p, z, splat(9.184024644e-01f));
+  p = pk_fma(p, z, splat(1.627910815e+00f));
+  const f2 a = pk_fma(-p, z, splat(-1.0f));
+  const float e0 = __builtin_amdgcn_exp2f(a.x), e1 = __builtin_amdgcn_exp2f(a.y);  // 0.5 erfc(z)
+  const f2 phi = {v.x < 0.0f ? e0 : 1.0f - e0, v.y < 0.0f ? e1 : 1.0f - e1};
+  return v * phi;
+}
+
 // out[OTO] += W[s][ot] * in-operand(s) for NS k-steps, while activating the NE elements of `side` in place.
 // The A operands (packed weights in LDS) are fetched PF k-steps ahead through a rotating register window: the LDS
 // queue is shared with the V waves' mixture-table reads, and an un-prefetched weight read in front of every MFMA
@@ -258,8 +277,19 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ w, IN&& in,
 #pragma unroll
     for (int ot = 0; ot < OTO; ++ot) out[ot] = SDEH_MFMA(a[ot], b, out[ot]);
     if (do_side) {
+      // the NE/2 element pairs (2i, 2i+1) are spread evenly over the NS k-steps
 #pragma unroll
-      for (int e = s * NE / NS; e < (s + 1) * NE / NS; ++e) side[e / 16][e % 16] = act_apply(side[e / 16][e % 16], act);
+      for (int i = s * (NE / 2) / NS; i < (s + 1) * (NE / 2) / NS; ++i) {
+        const int e = 2 * i;
+        if (act == SDEH_ACT_GELU_ERF) {
+          const f2 r = act_gelu2(f2{side[e / 16][e % 16], side[(e + 1) / 16][(e + 1) % 16]});
+          side[e / 16][e % 16] = r.x;
+          side[(e + 1) / 16][(e + 1) % 16] = r.y;
+        } else {
+          side[e / 16][e % 16] = act_apply(side[e / 16][e % 16], act);
+          side[(e + 1) / 16][(e + 1) % 16] = act_apply(side[(e + 1) / 16][(e + 1) % 16], act);
+        }
+      }
     }
     SDEH_FENCE();
   }

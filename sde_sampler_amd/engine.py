@@ -31,8 +31,33 @@ _CTRL_UNSUPPORTED = {"CancelDriftCtrl", "PotentialCtrl"}
 _GAUSS_NAMES = {"IsotropicGauss", "Gauss", "Delta"}
 
 
-def _mro_names(obj) -> list[str]:
-    return [c.__name__ for c in type(obj).__mro__]
+_MRO_CACHE: dict = {}
+
+
+def _mro_names(obj) -> tuple:
+    cls = type(obj)
+    names = _MRO_CACHE.get(cls)
+    if names is None:
+        names = _MRO_CACHE[cls] = tuple(c.__name__ for c in cls.__mro__)
+    return names
+
+
+def _scalar(t) -> float:
+    """float(t) for the 0-dim buffers of SDE / distribution objects without a device sync per call: the value is
+    cached on the tensor object and refreshed when the tensor's version counter moves."""
+    if not isinstance(t, torch.Tensor):
+        return float(t)
+    if not t.is_cuda:
+        return float(t)
+    cached = getattr(t, "_sdeh_scalar", None)
+    if cached is not None and cached[0] == t._version:
+        return cached[1]
+    value = float(t)
+    try:
+        t._sdeh_scalar = (t._version, value)
+    except AttributeError:
+        pass
+    return value
 
 
 def _unsupported(msg: str):
@@ -127,11 +152,11 @@ def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
             out.flags |= L.DENS_FLAG_SHARED_SCALE | (((n_vary + 1) & 0xFFFF) << 8)
     elif "DoubleWell" in names:
         out.kind, out.n_components = L.DENS_MULTI_WELL, 1
-        out.p0, out.p1 = float(dist.separation), float(dist.shift)
+        out.p0, out.p1 = _scalar(dist.separation), _scalar(dist.shift)
         out.log_norm_const = 0.0  # DoubleWell.unnorm_log_prob carries no constant
     elif "MultiWell" in names:
         out.kind, out.n_components = L.DENS_MULTI_WELL, dist.n_double_wells
-        out.p0, out.p1 = float(dist.separation), float(dist.double_well.shift)
+        out.p0, out.p1 = _scalar(dist.separation), _scalar(dist.double_well.shift)
         out.log_norm_const = 0.0
     elif "Funnel" in names:
         out.kind = L.DENS_FUNNEL
@@ -288,14 +313,14 @@ class TrajectoryEngine:
             snames = _mro_names(sde)
             if not getattr(sde, "generative", True):
                 raise _unsupported("the engine integrates the generative SDE (generative=True)")
-            pr.terminal_t = float(sde.terminal_t)
+            pr.terminal_t = _scalar(sde.terminal_t)
             if "VP" in snames:
                 pr.sde_kind = L.SDE_VP
-                pr.vp_beta_min, pr.vp_beta_max = float(sde.diff_coeff_sq_min), float(sde.diff_coeff_sq_max)
-                pr.vp_scale = float(sde.scale_diff_coeff)
+                pr.vp_beta_min, pr.vp_beta_max = _scalar(sde.diff_coeff_sq_min), _scalar(sde.diff_coeff_sq_max)
+                pr.vp_scale = _scalar(sde.scale_diff_coeff)
             elif "ConstOU" in snames:
                 pr.sde_kind = L.SDE_CONST_OU
-                pr.ou_drift, pr.ou_diff = float(sde.drift_coeff), float(sde.diff_coeff)
+                pr.ou_drift, pr.ou_diff = _scalar(sde.drift_coeff), _scalar(sde.diff_coeff)
             else:
                 raise _unsupported(f"sde {type(sde).__name__}: VP, ConstOU and ScaledBM are built in")
         pr.exp_alpha, pr.exp_sigma = float(alpha), float(sigma)
@@ -343,13 +368,19 @@ class TrajectoryEngine:
 
     # ------------------------------------------------------------------------------------------------------
 
+_SCRATCH: dict = {}
+
+
 def estimator_stats(rnd: torch.Tensor, max_rnd: float = math.nan) -> torch.Tensor:
     """8 mergeable partial statistics of `rnd` (include/sdeh.h: sdeh_reduce_estimators), on device."""
-    out = torch.empty(8, device=rnd.device, dtype=torch.float32)
-    scratch = torch.empty(L.SDEH_REDUCE_SCRATCH, device=rnd.device, dtype=torch.float32)
+    dev = rnd.device
+    scratch = _SCRATCH.get(dev)
+    if scratch is None:  # stream-ordered reuse: consecutive reductions on one device are serialised by the stream
+        scratch = _SCRATCH[dev] = torch.empty(L.SDEH_REDUCE_SCRATCH, device=dev, dtype=torch.float32)
+    out = torch.empty(8, device=dev, dtype=torch.float32)
     rnd = rnd.contiguous()
-    stream = torch.cuda.current_stream(rnd.device).cuda_stream
-    with torch.cuda.device(rnd.device):
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
         L.check(L.load().sdeh_reduce_estimators(rnd.data_ptr(), rnd.numel(), max_rnd, scratch.data_ptr(),
                                                 out.data_ptr(), stream))
     return out
@@ -371,18 +402,20 @@ def importance_weights(rnd: torch.Tensor, log_weight_max: torch.Tensor) -> torch
 # ----------------------------------------------------------------------------------------------------------
 def merge_stats(stats: torch.Tensor) -> torch.Tensor:
     """Combines per-rank statistics [R, 8] into one [8] vector (Chan's parallel variance + rescaled exp-sums).
-    Runs on the host in float64: the payload is 8 numbers per rank."""
-    stats = stats.detach().to("cpu", torch.float64).reshape(-1, 8)
-    n, s, m2, mx, e1, e2, nf = (stats[:, i] for i in range(7))
-    N = n.sum()
-    valid = n > 0
-    mean_r = torch.where(valid, -s / n.clamp(min=1), torch.zeros_like(s))  # per-rank mean of rnd
-    mean = (mean_r * n).sum() / N.clamp(min=1)
-    M2 = (m2 + n * (mean_r - mean) ** 2).sum()
-    m = torch.where(valid, mx, torch.full_like(mx, -math.inf)).max()
-    scale = torch.where(valid, (mx - m).exp(), torch.zeros_like(mx))
-    return torch.stack([N, s.sum(), M2, m, (e1 * scale).sum(), (e2 * scale * scale).sum(), nf.sum(),
-                        torch.zeros((), dtype=torch.float64)])
+    Runs on the host in double precision: the payload is 8 numbers per rank (one device->host copy)."""
+    rows = stats.detach().reshape(-1, 8).cpu().tolist()
+    N = sum(r[0] for r in rows)
+    S = sum(r[1] for r in rows)
+    NF = sum(r[6] for r in rows)
+    valid = [r for r in rows if r[0] > 0]
+    if not valid:
+        return torch.tensor([0.0, 0.0, 0.0, -math.inf, 0.0, 0.0, NF, 0.0], dtype=torch.float64)
+    mean = -S / N  # mean of rnd over all kept rows
+    M2 = sum(r[2] + r[0] * (-r[1] / r[0] - mean) ** 2 for r in valid)
+    m = max(r[3] for r in valid)
+    e1 = sum(r[4] * math.exp(r[3] - m) for r in valid)
+    e2 = sum(r[5] * math.exp(2.0 * (r[3] - m)) for r in valid)
+    return torch.tensor([N, S, M2, m, e1, e2, NF, 0.0], dtype=torch.float64)
 
 
 def all_gather_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
@@ -393,6 +426,8 @@ def all_gather_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return merge_stats(stats)
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":  # CPU collectives (tests): move the 8 floats to the host first
+        stats = stats.detach().cpu()
     bucket = torch.empty(world * 8, dtype=stats.dtype, device=stats.device)
     dist.all_gather_into_tensor(bucket, stats.contiguous().reshape(8), group=group)
     return merge_stats(bucket)

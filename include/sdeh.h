@@ -195,6 +195,24 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* problem, const floa
                           int64_t row_offset, float* x_T, float* rnd, float* xs, void* stream);
 
 /*
+ * Backward of the control network for the log-variance losses (method "lv" / "lv_traj"; replaces what
+ * `loss.backward()` does through losses/oc.py:60-70,204-219,319-331,418-443 in solver/base.py:399-407).  There the SDE is
+ * driven by the DETACHED control, so x_t is constant in the graph and d rnd_i / d u_{i,t} = dB_{i,t}.  For every row
+ * n = t*B + i the kernel re-evaluates the FourierMLP at the stored x_t = xs[t,i], forms w_i dB (noise replayed from the
+ * same (seed, offset, row_offset) as the forward call, or read from `noise`) and back-propagates through clip,
+ * out_layer, activations and hidden layers.  It writes, coordinate-major (N = n_steps*batch):
+ *   zt   [(Lh+1), C, N]  pre-activation of layer k          dt   [(Lh+1), C, N]  d loss / d zt
+ *   dout [d, N]          d loss / d (out_layer output)      dgam [g, N]          per-row d loss / d gamma(t), g = 1 or d
+ * from which the weight gradients are plain GEMMs over N (dW_k = dt[k] . act(zt[k-1])^T, ...): see
+ * sde_sampler_amd/losses/_autograd.py.  grad_rnd [batch] = d loss / d rnd.  problem->flags must be those of the
+ * forward call (SDEH_FLAG_CHANGE_SDE_CTRL set).  kl / kl_ito (back-propagation through time) -> SDEH_ERR_UNSUPPORTED.
+ */
+int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
+                           const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                           int64_t row_offset, const float* grad_rnd, float* zt, float* dt, float* dout, float* dgam,
+                           void* stream);
+
+/*
  * Batch reductions of BaseOCLoss.compute_results / compute_loss (losses/oc.py:72-123), as mergeable partial
  * statistics so that ranks can combine them with one tiny collective.
  *   out[0] = n (rows with rnd < max_rnd, or finite rnd when max_rnd = +INF)   out[1] = sum(-rnd)

@@ -102,6 +102,8 @@ PROTOTYPES = {
     "sdeh_plan_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
     "sdeh_simulate_fwd": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
                                       C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, C.c_void_p]),
+    "sdeh_ctrl_backward": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64,
+                                       C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_reduce_estimators": (C.c_int32, [fp, C.c_int64, C.c_float, fp, fp, C.c_void_p]),
     "sdeh_importance_weights": (C.c_int32, [fp, C.c_int64, fp, fp, C.c_void_p]),
     "sdeh_debug_philox": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, fp, C.c_void_p]),

@@ -18,7 +18,8 @@ int launch_weights(const float* rnd, long long n, const float* mx, float* w, hip
 
 #define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv)                           \
   int launch_ws_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                 \
-  int launch_legacy_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
+  int launch_legacy_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);             \
+  int launch_bwd_dp##dp##_p##pad##_##tag(const BwdArgs& a, hipStream_t stream);
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 
@@ -29,10 +30,11 @@ struct Variant {
   int gnv;                              // > 0: shared-scale mixture tables cover only the first gnv coordinates
   TrajLauncher fn;         // wave-specialised kernel (sdeh_traj_ws.hpp)
   TrajLauncher fn_legacy;  // single-wave kernel (sdeh_traj.hpp); returns SDEH_ERR_UNSUPPORTED when not compiled in
+  int (*fn_bwd)(const BwdArgs&, hipStream_t);  // control-network backward (sdeh_bwd.hpp), generic variants only
   const char* name;
 };
 static const Variant kVariants[] = {
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 };
@@ -79,8 +81,9 @@ static int align4(int v) { return (v + 3) & ~3; }
 
 // Workspace layout for one problem geometry.
 // gmm_nv: number of leading coordinates the shared-scale mixture tables cover (multiple of 4; 0 = all)
+// with_bwd: also pack the transposed weights the backward kernel needs (they join the LDS image)
 static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g, bool shared_scale = false,
-                            bool gmm_global = false, int gmm_nv = 0) {
+                            bool gmm_global = false, int gmm_nv = 0, bool with_bwd = false) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.dp = dp; L.c = c; L.ot = c / 32; L.otd = row_tiles(dp); L.r_in = mregs(dp);
@@ -92,12 +95,17 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   L.b_hid = o; o += n_hidden * c;
   L.b_out = o; o += L.otd * 32;
   o = align4(o);
+  L.wt_out = L.wt_hid = -1;
+  if (with_bwd) {
+    L.wt_out = o; o += L.r_in * L.ot * 64;
+    L.wt_hid = o; o += n_hidden * L.w_hid_stride;
+  }
   L.gmm_row = 2 * ((dp + 1) & ~1);
   const int k_rows = (k_max + 7) & ~7;  // table rows padded to a multiple of 8 (padding rows: logit -inf)
   L.gmm_rows = k_rows;
   const int gmm_floats = 2 * k_rows * L.gmm_row + align4(k_rows);
   // LDS budget of the wave-specialised kernel: image + four [coordinate][64] exchange buffers within 160 KiB
-  const size_t xbuf_floats = (size_t)4 * (mdim(mregs(dp) - 1, 1) + 1) * 64;
+  const size_t xbuf_floats = with_bwd ? 0 : (size_t)4 * (mdim(mregs(dp) - 1, 1) + 1) * 64;
   L.gmm_lds = (k_max > 0 && !gmm_global && ((size_t)(o + gmm_floats) + xbuf_floats) * sizeof(float) <= 160 * 1024) ? 1 : 0;
   if (L.gmm_lds && shared_scale) {
     // shared-scale tables: one word per (k,d), rows of 4*ceil(dp/4) floats, then the two per-coordinate vectors
@@ -254,11 +262,15 @@ static int check_density(const SdehDensity& D, int d, const char* what, bool all
   return SDEH_OK;
 }
 
-int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
-                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                          float* x_T, float* rnd, float* xs, void* stream) {
-  if (plan == nullptr || pr == nullptr || ts == nullptr || x0 == nullptr || x_T == nullptr || rnd == nullptr)
-    return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
+// Validation shared by the forward and backward entry points; on success fills the layout and the chosen variant.
+struct Checked {
+  WsLayout L;
+  const Variant* v;
+  bool refc;
+};
+static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, int64_t batch,
+                         int64_t row_offset, bool backward, Checked* out) {
+  if (plan == nullptr || pr == nullptr || ts == nullptr) return fail(SDEH_ERR_INVALID, "null argument");
   if (batch < 1 || n_steps < 1) return fail(SDEH_ERR_INVALID, "simulate_fwd: batch=%lld n_steps=%d", (long long)batch, n_steps);
   if (row_offset < 0 || (unsigned long long)row_offset + (unsigned long long)batch > 0x100000000ull)
     return fail(SDEH_ERR_INVALID, "simulate_fwd: global row indices must fit 32 bits (row_offset=%lld batch=%lld)",
@@ -323,8 +335,8 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
   static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
   static const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing aid: force the generic variants
   // which GMM table form would the layout give?  (0: tables do not fit LDS, 1: general, 2: shared scale)
-  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy);
-  const Variant* sv = no_spec ? nullptr
+  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, 0, backward);
+  const Variant* sv = (no_spec || backward) ? nullptr
                               : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds,
                                                  net.activation, refc ? 1 : 0, nvary);
   if (sv != nullptr && sv->dp == v->dp) {
@@ -332,6 +344,24 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
     if (v->gnv > 0) L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, v->gnv);
   }
   if ((size_t)L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd: workspace too small");
+  out->L = L;
+  out->v = v;
+  out->refc = refc;
+  return SDEH_OK;
+}
+
+int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                          float* x_T, float* rnd, float* xs, void* stream) {
+  if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
+  Checked ck;
+  int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, false, &ck);
+  if (rc != SDEH_OK) return rc;
+  const SdehFourierMLP& net = pr->base_model;
+  const int d = net.dim;
+  const WsLayout& L = ck.L;
+  const Variant* v = ck.v;
+  static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;
 
   hipStream_t st = (hipStream_t)stream;
   PrepArgs P;
@@ -368,6 +398,41 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd: trajectory kernel launch failed (dp=%d)", v->dp);
   return SDEH_OK;
+}
+
+int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                           int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                           const float* grad_rnd, float* zt, float* dt, float* dout, float* dgam, void* stream) {
+  if (xs == nullptr || grad_rnd == nullptr || zt == nullptr || dt == nullptr || dout == nullptr)
+    return fail(SDEH_ERR_INVALID, "ctrl_backward: null argument");
+  Checked ck;
+  int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, true, &ck);
+  if (rc != SDEH_OK) return rc;
+  if (!(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL))
+    return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: only the log-variance losses (detached SDE control) are built in; "
+                                      "kl / kl_ito need back-propagation through time (SURVEY.md 8f)");
+  if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && dgam == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward: dgam is null");
+  const WsLayout& L = ck.L;
+  if (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0 && pr->ctrl_kind != SDEH_CTRL_CLIPPED &&
+      pr->ctrl_kind != SDEH_CTRL_LERP_PRIOR)
+    return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: mixture tables do not fit in LDS next to the transposed weights");
+  if (ck.v->fn_bwd == nullptr) return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: no backward kernel for this variant");
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "ctrl_backward: prep kernel launch failed");
+  BwdArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = L; A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd;
+  A.zt = zt; A.dt = dt; A.dout = dout; A.dgam = dgam;
+  A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = pr->base_model.dim;
+  A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = pr->base_model.activation;
+  A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
+  A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
+  A.seed = seed; A.offset = offset;
+  rc = ck.v->fn_bwd(A, st);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward: kernel launch failed");
 }
 
 int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, float* scratch, float* out, void* stream) {

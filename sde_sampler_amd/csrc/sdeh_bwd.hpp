@@ -1,0 +1,329 @@
+// Backward pass of the control network for the log-variance losses.
+//
+// With method = "lv" / "lv_traj" the reference detaches the control that drives the SDE (losses/oc.py:60-70), so the
+// trajectory x_t is a constant of the autograd graph and
+//     d rnd_i / d u_{i,t}  =  dB_{i,t}                 (the (u_sde - u) dt terms vanish identically)
+// for all three losses (TimeReversal 204-219, ReferenceSDE 319-331, ExponentialIntegrator 418-443), with
+// dB = xi sqrt(dt) (Euler-Maruyama) or sigma beta_k xi (exponential integrator).  The parameter gradient is therefore a
+// sum over independent (step, trajectory) rows of  J_theta u(t, x)^T (w_i dB),  w_i = dLoss/drnd_i coming from autograd.
+//
+// This kernel does the per-row part on the matrix pipe for 64 rows (one step, 64 consecutive trajectories) per wave:
+// it re-evaluates the FourierMLP at the stored x_t, forms G = w_i dB (the Gaussian draws are REPLAYED from the Philox
+// counters, or read from the given noise), back-propagates through clip / out_layer / activations / hidden layers
+// with the transposed packed weights, and writes -- coordinate-major, i.e. coalesced --
+//     Zt[k][C][N]  pre-activations of layer k = 0..Lh      Dt[k][C][N]  d loss / d Z_k
+//     Dout[d][N]   d loss / d (network output)              Dgam[g][N]   d loss / d gamma(t) contributions per row
+// with N = T * B.  The weight gradients are then plain GEMMs over N (Dt[k] . act(Zt[k-1])^T etc.), done by the host
+// with library GEMMs, and the time-only sub-networks are differentiated on their [T, .] tables.
+#pragma once
+#include "sdeh_traj_ws.hpp"
+
+namespace sdeh {
+
+__device__ __forceinline__ float act_grad(float v, int act) {
+  if (act == SDEH_ACT_GELU_ERF) {  // Phi(v) + v phi(v)
+    const float z = fminf(fabsf(v) * 0.70710678118654752440f, 6.0f);
+    float p = 6.603050149e-07f;
+    p = fmaf(p, z, -1.530170759e-05f); p = fmaf(p, z, 1.480139295e-04f); p = fmaf(p, z, -7.626767611e-04f);
+    p = fmaf(p, z, 2.001933838e-03f); p = fmaf(p, z, 3.411742314e-04f); p = fmaf(p, z, -2.809073479e-02f);
+    p = fmaf(p, z, 1.484803495e-01f); p = fmaf(p, z, 9.184024644e-01f); p = fmaf(p, z, 1.627910815e+00f);
+    const float e = __builtin_amdgcn_exp2f(fmaf(-p, z, -1.0f));
+    const float Phi = v < 0.0f ? e : 1.0f - e;
+    const float phi = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * v * v);
+    return fmaf(v, phi, Phi);
+  }
+  if (act == SDEH_ACT_SILU) {
+    const float s = 1.0f / (1.0f + __expf(-v));
+    return s * fmaf(v, 1.0f - s, 1.0f);
+  }
+  return v > 0.0f ? 1.0f : 0.0f;
+}
+
+// store / load one [C][N] plane in the M layout: register q of lane (j,h), row tile ot, column tile A/B is
+// channel 32 ot + rho(q,h) of row n0 + j (+32)
+template <int OT>
+__device__ __forceinline__ void store_plane(float* __restrict__ plane, long long N, long long n0, int nrows, int lane,
+                                            const f32x16 (&a)[OT], const f32x16 (&b)[OT]) {
+  const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float* row = plane + (long long)(32 * ot + rho(q, h)) * N + n0 + j;
+      if (j < nrows) row[0] = a[ot][q];
+      if (j + 32 < nrows) row[32] = b[ot][q];
+    }
+}
+template <int OT>
+__device__ __forceinline__ void load_plane(const float* __restrict__ plane, long long N, long long n0, int nrows, int lane,
+                                           f32x16 (&a)[OT], f32x16 (&b)[OT]) {
+  const int h = lane >> 5, j = lane & 31;
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float* row = plane + (long long)(32 * ot + rho(q, h)) * N + n0 + j;
+      a[ot][q] = j < nrows ? row[0] : 0.0f;
+      b[ot][q] = j + 32 < nrows ? row[32] : 0.0f;
+    }
+}
+
+template <int DP, int C, bool PAD>
+__global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
+  const WsLayout& L = A.lay;
+  const float* __restrict__ ws = A.ws;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5;
+  {
+    const float4* src = reinterpret_cast<const float4*>(ws);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < L.lds_floats / 4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  const long long B = A.batch;
+  const long long tiles_per_t = (B + 63) / 64;
+  const long long tile = (long long)blockIdx.x * 4 + wave;
+  if (tile >= tiles_per_t * A.n_steps) return;
+  const int t = (int)(tile / tiles_per_t);
+  const long long i0 = (tile % tiles_per_t) * 64;
+  const int nrows = (int)(B - i0 < 64 ? B - i0 : 64);
+  const long long N = B * A.n_steps;
+  const long long n0 = (long long)t * B + i0;
+  const bool live = lane < nrows;
+  const long long irow = live ? i0 + lane : B - 1;
+  const int d = PAD ? A.d : DP;
+  const int act = A.act, ctrl_kind = A.ctrl_kind;
+
+  float x[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    const float v = A.xs[((long long)t * B + irow) * d + (PAD ? min(j, d - 1) : j)];
+    x[j] = (!PAD || j < d) ? v : 0.0f;
+  }
+  cfp cf = as_const(ws + L.coef + t * kCoefStride);
+
+  // ---- forward, storing the pre-activations ------------------------------------------------------------------
+  f32x16 accA[OT], accB[OT];
+  {
+    const float* emb = ws + L.emb + t * C;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) accA[ot] = accB[ot] = load16(emb + (ot * 2 + h) * 16);
+    float xa[R], xb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float v0 = x[mdim(r, 0)];
+      float v1 = mdim(r, 1) < DP ? x[mdim(r, 1)] : 0.0f;
+      swap32(v0, v1);
+      xa[r] = v0;
+      xb[r] = v1;
+    }
+    const float* w = lds + L.w_in + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const float a = w[(r * OT + ot) * 64];
+        accA[ot] = SDEH_MFMA(a, xa[r], accA[ot]);
+        accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
+        if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
+      }
+  }
+  store_plane<OT>(A.zt, N, n0, nrows, lane, accA, accB);
+  for (int l = 0; l < L.n_hidden; ++l) {
+    activate<OT>(accA, accB, act);
+    f32x16 nA[OT], nB[OT];
+    const float* bias = lds + L.b_hid + l * C;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) nA[ot] = nB[ot] = load16(bias + (ot * 2 + h) * 16);
+    const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const float a = w[((it * 16 + q) * OT + ot) * 64];
+          nA[ot] = SDEH_MFMA(a, accA[it][q], nA[ot]);
+          nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
+          if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+        }
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) { accA[ot] = nA[ot]; accB[ot] = nB[ot]; }
+    store_plane<OT>(A.zt + (long long)(l + 1) * C * N, N, n0, nrows, lane, accA, accB);
+  }
+  float nn[DP];
+  {
+    activate<OT>(accA, accB, act);
+    f32x16 uA[OTD], uB[OTD];
+#pragma unroll
+    for (int tt = 0; tt < OTD; ++tt) uA[tt] = uB[tt] = load16(lds + L.b_out + (tt * 2 + h) * 16);
+    const float* w = lds + L.w_out + lane;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int tt = 0; tt < OTD; ++tt) {
+          const float a = w[((it * 16 + q) * OTD + tt) * 64];
+          uA[tt] = SDEH_MFMA(a, accA[it][q], uA[tt]);
+          uB[tt] = SDEH_MFMA(a, accB[it][q], uB[tt]);
+          if (tt == OTD - 1 && (q & 1)) SDEH_FENCE();
+        }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float v0 = uA[r / 16][r % 16];
+      float v1 = uB[r / 16][r % 16];
+      swap32(v0, v1);
+      nn[mdim(r, 0)] = v0;
+      if (mdim(r, 1) < DP) nn[mdim(r, 1)] = v1;
+    }
+  }
+  SDEH_FENCE();
+
+  // ---- upstream gradient G = w_i dB (T layout) -----------------------------------------------------------------
+  const bool expo = A.loss_kind == SDEH_LOSS_EXPONENTIAL;
+  const float c_i = (expo ? cf[CF_SBK] : cf[CF_SQDT]) * A.grad_rnd[irow];
+  float G[DP];
+  if (A.noise != nullptr) {
+    const float* __restrict__ np = A.noise + ((long long)t * B + irow) * d;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) G[j] = c_i * np[PAD ? min(j, d - 1) : j];
+  } else {
+    const unsigned long long grow = (unsigned long long)(A.row_offset + irow);
+#pragma unroll
+    for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
+      float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (!PAD || 4 * jb < d) box_muller4(philox_block(A.seed, A.offset, grow, t, jb), n);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * jb + q < DP) G[4 * jb + q] = c_i * n[q];
+    }
+  }
+  if (PAD) {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) G[j] = j < d ? G[j] : 0.0f;
+  }
+
+  // ---- d loss / d gamma(t): u = clip(nn) + mult * (scale_score * clip(score)) * gamma ------------------------------
+  if (ctrl_kind != SDEH_CTRL_CLIPPED) {
+    float sc[DP];
+    const float w = cf[CF_W], sig = cf[CF_SIGMA];
+    const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
+    if (need_t) ws_target_score<DP, DP>(A.target, ws, lds, L, L.gmm_lds, d, x, sc);
+    if (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR) {
+      float psc[DP];
+      dgauss_score<DP>(ws + L.dg[1], x, psc);
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        if (ctrl_kind == SDEH_CTRL_LERP_PRIOR) sc[j] = (1.0f - w) * psc[j];
+        else sc[j] = w < 0.5f ? psc[j] + w * (sc[j] - psc[j]) : sc[j] - (sc[j] - psc[j]) * (1.0f - w);
+      }
+    } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) sc[j] = w * sc[j];
+    }
+    const float mult = (ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig) * A.scale_score;
+    if (L.g == 1) {
+      float s = 0.0f;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) s = fmaf(G[j], mult * clipf(sc[j], A.clip_score), s);
+      if (live) A.dgam[n0 + lane] = s;
+    } else {
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        if ((!PAD || j < d) && live) A.dgam[(long long)j * N + n0 + lane] = G[j] * mult * clipf(sc[j], A.clip_score);
+    }
+  }
+
+  // ---- d loss / d nn through the clip; to the M layout ------------------------------------------------------------
+  f32x16 dA[OT], dB[OT];
+  {
+    float ga[R], gb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j0 = mdim(r, 0), j1 = mdim(r, 1);
+      float v0 = fabsf(nn[j0]) <= A.clip_model ? G[j0] : 0.0f;
+      float v1 = j1 < DP ? (fabsf(nn[j1]) <= A.clip_model ? G[j1] : 0.0f) : 0.0f;
+      swap32(v0, v1);
+      ga[r] = v0;
+      gb[r] = v1;
+      // Dout[d][N]: lane (j,h) holds coordinate mdim(r,h) of rows n0 + j (tile A) and n0 + 32 + j (tile B)
+      const int dim = h ? j1 : j0;
+      if (dim < d) {
+        float* row = A.dout + (long long)dim * N + n0 + (lane & 31);
+        if ((lane & 31) < nrows) row[0] = v0;
+        if ((lane & 31) + 32 < nrows) row[32] = v1;
+      }
+    }
+    // d a_last = W_out^T d out
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dA[ot][q] = dB[ot][q] = 0.0f;
+    const float* w = lds + L.wt_out + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        const float a = w[(r * OT + ot) * 64];
+        dA[ot] = SDEH_MFMA(a, ga[r], dA[ot]);
+        dB[ot] = SDEH_MFMA(a, gb[r], dB[ot]);
+        if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
+      }
+  }
+  // ---- back through the layers: dZ_k = dA_k * act'(Z_k);  dA_{k-1} = W_{k-1}^T dZ_k ------------------------------------
+  for (int k = L.n_hidden; k >= 0; --k) {
+    f32x16 zA[OT], zB[OT];
+    load_plane<OT>(A.zt + (long long)k * C * N, N, n0, nrows, lane, zA, zB);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        dA[ot][q] *= act_grad(zA[ot][q], act);
+        dB[ot][q] *= act_grad(zB[ot][q], act);
+      }
+    store_plane<OT>(A.dt + (long long)k * C * N, N, n0, nrows, lane, dA, dB);
+    if (k > 0) {
+      f32x16 pA[OT], pB[OT];
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) pA[ot][q] = pB[ot][q] = 0.0f;
+      const float* w = lds + L.wt_hid + (k - 1) * L.w_hid_stride + lane;
+#pragma unroll
+      for (int it = 0; it < OT; ++it)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int ot = 0; ot < OT; ++ot) {
+            const float a = w[((it * 16 + q) * OT + ot) * 64];
+            pA[ot] = SDEH_MFMA(a, dA[it][q], pA[ot]);
+            pB[ot] = SDEH_MFMA(a, dB[it][q], pB[ot]);
+            if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+          }
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) { dA[ot] = pA[ot]; dB[ot] = pB[ot]; }
+    }
+  }
+}
+
+template <int DP, int C, bool PAD>
+int launch_ctrl_bwd(const BwdArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = (size_t)a.lay.lds_floats * sizeof(float);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  const long long tiles = ((a.batch + 63) / 64) * a.n_steps;
+  hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+}  // namespace sdeh

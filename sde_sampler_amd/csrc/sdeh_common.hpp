@@ -48,6 +48,8 @@ struct WsLayout {
   int w_out;      // [c/2][otd][64]
   int b_hid;      // n_hidden x [c]   (M order)
   int b_out;      // [otd*32]         (M order)
+  int wt_out;     // backward only: transposed out_layer  [r_in][ot][64];  -1 when not packed
+  int wt_hid;     // backward only: transposed hidden layers, n_hidden x [c/2][ot][64]
   // global tables
   int coef;       // [T][16]
   int emb;        // [T][c]  (M order; FourierMLP.timestep_embed(t) + input_embed.bias)
@@ -84,6 +86,24 @@ struct TrajArgs {
   float clip_model, clip_score, scale_score, clip_target;
   float exp_sigma;
   DensArgs target, prior, second;
+  unsigned long long seed, offset;
+};
+
+struct BwdArgs {
+  const float* ws;
+  WsLayout lay;
+  const float* xs;        // [T+1, B, d]
+  const float* noise;     // [T, B, d] or null (Philox replay)
+  const float* grad_rnd;  // [B]
+  float* zt;              // [(Lh+1), C, N]
+  float* dt;              // [(Lh+1), C, N]
+  float* dout;            // [d, N]
+  float* dgam;            // [g, N]
+  long long batch, row_offset;
+  int n_steps, d;
+  int loss_kind, ctrl_kind, flags, act;
+  float clip_model, clip_score, scale_score;
+  DensArgs target;
   unsigned long long seed, offset;
 };
 

@@ -167,6 +167,19 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
     ws[L.w_out + e] = row < d ? net.out_w[(size_t)row * C + chan] : 0.0f;
   }
   for (int c = gid; c < OTD * 32; c += stride) ws[L.b_out + morder(c)] = c < d ? net.out_b[c] : 0.0f;
+  if (L.wt_out >= 0) {  // transposed images for the backward kernel: A operand rows = INPUT channel of the layer
+    for (int e = gid; e < L.r_in * OT * 64; e += stride) {  // out_layer^T: k runs over the coordinates
+      const int lane = e & 63, ot = (e >> 6) % OT, r = (e >> 6) / OT;
+      const int dimidx = mdim(r, lane >> 5);
+      ws[L.wt_out + e] = dimidx < d ? net.out_w[(size_t)dimidx * C + 32 * ot + (lane & 31)] : 0.0f;
+    }
+    for (int l = 0; l < L.n_hidden; ++l)
+      for (int e = gid; e < (C / 2) * OT * 64; e += stride) {  // hidden_layer[l]^T: k runs over the OUTPUT channels
+        const int lane = e & 63, ot = (e >> 6) % OT, sidx = (e >> 6) / OT;
+        const int cout = mdim(sidx, lane >> 5);
+        ws[L.wt_hid + l * L.w_hid_stride + e] = net.hidden_w[l][(size_t)cout * C + 32 * ot + (lane & 31)];
+      }
+  }
 
   // GMM tables (distr/gauss.py:123-135 via torch.distributions.MixtureSameFamily)
   if (pr.target.kind == SDEH_DENS_GMM) {

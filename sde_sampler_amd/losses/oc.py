@@ -12,8 +12,10 @@ ReferenceSDELoss 281-391, ExponentialIntegratorSDELoss 394-505), selected by poi
 * the batch reductions of `compute_results` run on device and, under `torch.distributed`, merge across ranks
   with one 8-float all-gather.
 
-Not built in (raises `SdehUnsupported`, never falls back): the Bridge inference control / divergence term,
-`sde_ctrl_noise` / `sde_ctrl_dropout`, and training (`loss(...)` with autograd) -- SURVEY.md 8f rows f1/f2.
+Training: `loss(...)` with method "lv" / "lv_traj" back-propagates through the fused kernel (losses/_autograd.py +
+`sdeh_ctrl_backward`).  Not built in (raises `SdehUnsupported`, never falls back): back-propagation through time for
+method "kl" / "kl_ito" (their loss VALUE is available under `torch.no_grad()`), the Bridge inference control /
+divergence term, `sde_ctrl_noise` / `sde_ctrl_dropout` -- SURVEY.md 8f rows f1/f2.
 """
 from __future__ import annotations
 
@@ -146,7 +148,6 @@ class BaseOCLoss:
                 second_at_start: bool, second_at_end: bool, return_traj: bool, noise, reference_prior=None,
                 alpha: float = 0.0, sigma: float = 0.0):
         """Common body of the three simulate() methods: fuse what can be fused, call back what cannot."""
-        keep = E._Keep()
         target, clip_target = _resolve_terminal(terminal_unnorm_log_prob)
         second = _resolve_gaussian_log_prob(second_log_prob)
         if target is not None:
@@ -156,32 +157,49 @@ class BaseOCLoss:
                 flags |= L.FLAG_INIT_LOGP
             if second_at_end:
                 flags |= L.FLAG_TERMINAL_SECOND
-        pr = self.engine.build_problem(loss_kind=self._LOSS_KIND, generative_ctrl=self.generative_ctrl, sde=self.sde,
-                                       flags=flags, device=x.device, keep=keep, terminal_target=target,
-                                       clip_target=clip_target, second=second, reference_prior=reference_prior,
-                                       alpha=alpha, sigma=sigma)
-        x_T, rnd, xs = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
-                                       row_offset=self.row_offset)
-        # user-supplied callables the engine does not recognise are evaluated as given (device tensors in/out)
-        if second is None and second_log_prob is not None:
-            if second_at_start:
-                rnd = rnd + second_log_prob(x)
-            if second_at_end:
-                rnd = rnd + second_log_prob(x_T)
-        if target is None:
-            rnd = rnd - terminal_unnorm_log_prob(x_T)
-        assert rnd.shape == (x.shape[0], 1)
-        return x_T, rnd, xs
+        problem_kwargs = dict(loss_kind=self._LOSS_KIND, generative_ctrl=self.generative_ctrl, sde=self.sde, flags=flags,
+                              terminal_target=target, clip_target=clip_target, second=second,
+                              reference_prior=reference_prior, alpha=alpha, sigma=sigma)
+
+        def run(return_traj: bool, want_state: bool = False):
+            keep = E._Keep()
+            pr = self.engine.build_problem(device=x.device, keep=keep, **problem_kwargs)
+            offset = self.engine.calls
+            seed = torch.initial_seed()
+            x_T, rnd, xs = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
+                                           row_offset=self.row_offset, seed=seed)
+            # user-supplied callables the engine does not recognise are evaluated as given (device tensors in/out)
+            if second is None and second_log_prob is not None:
+                if second_at_start:
+                    rnd = rnd + second_log_prob(x)
+                if second_at_end:
+                    rnd = rnd + second_log_prob(x_T)
+            if target is None:
+                rnd = rnd - terminal_unnorm_log_prob(x_T)
+            assert rnd.shape == (x.shape[0], 1)
+            if want_state:
+                state = dict(problem_kwargs=problem_kwargs, noise=noise, seed=seed & 0xFFFFFFFFFFFFFFFF, offset=offset,
+                             row_offset=self.row_offset)
+                return x_T, rnd, xs, state
+            return x_T, rnd, xs
+
+        needs_graph = torch.is_grad_enabled() and any(
+            p.requires_grad for p in getattr(self.generative_ctrl, "parameters", lambda: [])())
+        if needs_graph:
+            if not (flags & L.FLAG_CHANGE_SDE_CTRL):
+                raise L.SdehUnsupported(
+                    -2, "training with method='kl'/'kl_ito' needs back-propagation through time, which is not built yet "
+                        "(SURVEY.md 8f row f1); method='lv'/'lv_traj' trains through the fused kernel, and any method "
+                        "works under torch.no_grad() for the loss value")
+            from sde_sampler_amd.losses._autograd import simulate_with_grad
+
+            x_T, rnd, _ = simulate_with_grad(self, run, ts, x)
+            return x_T, rnd, None
+        return run(return_traj)
 
     def _train_call(self, ts, x, simulate_kwargs: dict):
         if self.traj_per_sample != 1:
             x = x.repeat(self.traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
-        needs_graph = torch.is_grad_enabled() and any(
-            p.requires_grad for p in getattr(self.generative_ctrl, "parameters", lambda: [])())
-        if needs_graph:
-            raise L.SdehUnsupported(
-                -2, "training through the fused trajectory kernel (backward pass) is not built yet "
-                    "(SURVEY.md 8f row f1); call under torch.no_grad() for the loss value only")
         samples, rnd, _ = self.simulate(ts, x, compute_ito_int=self.method != "kl",
                                         change_sde_ctrl=self.method in ["lv", "lv_traj"], return_traj=False,
                                         **simulate_kwargs)

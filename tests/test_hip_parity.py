@@ -94,14 +94,73 @@ def test_rnd_rows_match_oracle(path):
             assert met["train/n_filtered_cumulative"] >= int(fx[f"train_{method}/n_filtered"])
 
 
-def test_training_with_autograd_fails_loudly():
+def test_kl_training_with_autograd_fails_loudly():
+    """method='kl' needs back-propagation through time, which is not built: the loss must say so, not fall back."""
     from sde_sampler_amd._lib import SdehUnsupported
 
     fx, meta, params, tt = load_fixture(GOLDEN[0])
     prob = hip_problem(meta, params, tt)
+    prob.loss.method = "kl"
     x0 = torch.from_numpy(fx["x0"]).cuda()
-    with pytest.raises(SdehUnsupported):
+    with pytest.raises(SdehUnsupported, match="back-propagation through time"):
         prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_lv_training_gradients_match_reference(path):
+    """loss(...).backward() with method='lv' through the fused kernels (forward: trajectory kernel; backward:
+    sdeh_ctrl_backward + library GEMMs) against the parameter gradients the reference's autograd produced on the same
+    noise (tests/golden: train_lv/grad/*)."""
+    fx, meta, params, tt = load_fixture(path)
+    prob = hip_problem(meta, params, tt)
+    prob.loss.method = "lv"
+    x0 = torch.from_numpy(fx["x0"]).cuda()
+    noise = torch.from_numpy(fx["noise"]).cuda()
+    prob.ctrl.zero_grad()
+    val, met = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
+    ref_val = float(fx["train_lv/loss"])
+    assert abs(val.item() - ref_val) <= 2e-3 * max(1.0, abs(ref_val))
+    val.backward()
+    checked = 0
+    for name, p in prob.ctrl.named_parameters():
+        ref = fx[f"train_lv/grad/{name}"]
+        got = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        scale = max(np.abs(ref).max(), 1e-6)
+        err = np.abs(got - ref).max()
+        assert err <= 5e-3 * scale + 1e-6, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+        checked += 1
+    assert checked >= 10
+
+
+def test_lv_training_replays_kernel_noise():
+    """Without an explicit noise tensor the backward pass replays the forward pass's Philox stream: the gradient must
+    equal the one obtained when the same draws are passed explicitly (sdeh_debug_normals exposes them)."""
+    import ctypes as C
+
+    from sde_sampler_amd import _lib as L
+
+    fx, meta, params, tt = load_fixture([p for p in GOLDEN if "cfg4" in p][0])
+    prob = hip_problem(meta, params, tt)
+    prob.loss.method = "lv"
+    x0 = torch.from_numpy(fx["x0"]).cuda()
+    T, B, d = fx["noise"].shape
+    torch.manual_seed(1234)
+    prob.loss.engine.calls = 5
+    prob.ctrl.zero_grad()
+    val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+    val.backward()
+    g_replay = {n: p.grad.clone() for n, p in prob.ctrl.named_parameters()}
+    noise = torch.empty(T, B, d, device="cuda")
+    lib = L.load()
+    for t in range(T):
+        assert lib.sdeh_debug_normals(torch.initial_seed(), 5, 0, t, d, B, noise[t].data_ptr(), None) == 0
+    prob.ctrl.zero_grad()
+    val2, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
+    val2.backward()
+    assert abs(val.item() - val2.item()) <= 1e-5 * max(1.0, abs(val.item()))
+    for n, p in prob.ctrl.named_parameters():
+        scale = max(g_replay[n].abs().max().item(), 1e-6)
+        assert (p.grad - g_replay[n]).abs().max().item() <= 1e-4 * scale, n
 
 
 def test_unrecognised_callables_are_called_back():

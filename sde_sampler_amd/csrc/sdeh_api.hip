@@ -95,10 +95,11 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   L.b_hid = o; o += n_hidden * c;
   L.b_out = o; o += L.otd * 32;
   o = align4(o);
-  L.wt_out = L.wt_hid = -1;
+  L.wt_out = L.wt_hid = L.wt_in = -1;
   if (with_bwd) {
     L.wt_out = o; o += L.r_in * L.ot * 64;
     L.wt_hid = o; o += n_hidden * L.w_hid_stride;
+    L.wt_in = o; o += (c / 2) * L.otd * 64;
   }
   L.gmm_row = 2 * ((dp + 1) & ~1);
   const int k_rows = (k_max + 7) & ~7;  // table rows padded to a multiple of 8 (padding rows: logit -inf)
@@ -408,9 +409,10 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
   Checked ck;
   int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, true, &ck);
   if (rc != SDEH_OK) return rc;
-  if (!(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL))
-    return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: only the log-variance losses (detached SDE control) are built in; "
-                                      "kl / kl_ito need back-propagation through time (SURVEY.md 8f)");
+  const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  if (bptt && (pr->flags & SDEH_FLAG_INIT_LOGP))
+    return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: an initial log-density term with an attached control is not a "
+                                      "configuration the reference produces");
   if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && dgam == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward: dgam is null");
   const WsLayout& L = ck.L;
   if (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0 && pr->ctrl_kind != SDEH_CTRL_CLIPPED &&
@@ -429,6 +431,7 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
   A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = pr->base_model.dim;
   A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = pr->base_model.activation;
   A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
+  A.clip_target = pr->clip_target;
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
   A.seed = seed; A.offset = offset;
   rc = ck.v->fn_bwd(A, st);

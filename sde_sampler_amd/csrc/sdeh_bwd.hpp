@@ -1,4 +1,5 @@
-// Backward pass of the control network for the log-variance losses.
+// Backward pass of the control network: log-variance losses (row-parallel) and KL losses
+// (back-propagation through time).
 //
 // With method = "lv" / "lv_traj" the reference detaches the control that drives the SDE (losses/oc.py:60-70), so the
 // trajectory x_t is a constant of the autograd graph and
@@ -15,6 +16,15 @@
 //     Dout[d][N]   d loss / d (network output)              Dgam[g][N]   d loss / d gamma(t) contributions per row
 // with N = T * B.  The weight gradients are then plain GEMMs over N (Dt[k] . act(Zt[k-1])^T etc.), done by the host
 // with library GEMMs, and the time-only sub-networks are differentiated on their [T, .] tables.
+//
+// BPTT = true (method "kl" / "kl_ito": the SDE is driven by the attached control): a wave keeps its 64 trajectories and
+// walks the stored trajectory backwards, carrying the adjoint lambda_t = dLoss/dx_t in registers:
+//     G_t       = w_i d cost_t / d u + c_u lambda_{t+1}                       (upstream of the control at step t)
+//     lambda_t  = c_x lambda_{t+1} + (du_t/dx_t)^T G_t + w_i d cost_t/dx_t    (du/dx: MLP input gradient through the clip
+//                                                                              + the score term's Jacobian)
+// with the reference's autograd semantics: the mixture score is obtained with create_graph=False (distr/base.py:130-137,
+// models/reparam.py:58-60), i.e. it is a CONSTANT of the graph, whereas the closed-form scores (Gaussian prior/target,
+// double wells, funnel) are differentiated through x.  lambda_T = w_i d(terminal costs)/dx_T.
 #pragma once
 #include "sdeh_traj_ws.hpp"
 
@@ -68,34 +78,58 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, long
     }
 }
 
-template <int DP, int C, bool PAD>
-__global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// v = J^T c for the closed-form scores (the reference differentiates these through x; the mixture's autograd score is a
+// constant of the graph and contributes nothing)
+template <int DP>
+__device__ __forceinline__ void target_score_jt(const DensArgs& D, const float* ws, const WsLayout& L, int dreal,
+                                                const float (&x)[DP], const float (&c)[DP], float (&v)[DP]) {
+  switch (D.kind) {
+    case SDEH_DENS_DIAG_GAUSS: {
+      cf2p p = as_const2(ws + L.dg[0]);
+#pragma unroll
+      for (int j = 0; j < DP; ++j) v[j] = -p[j].y * c[j];
+      break;
+    }
+    case SDEH_DENS_MULTI_WELL:
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const float y = x[j] - D.p1;
+        const float jac = j < D.n_comp ? -4.0f * (3.0f * y * y - D.p0) : -1.0f;
+        v[j] = j < dreal ? jac * c[j] : 0.0f;
+      }
+      break;
+    case SDEH_DENS_FUNNEL: {  // s_0 = -x0/var - (d-1)/2 + e^{-x0} sum x_j^2 / 2,  s_j = -x_j e^{-x0}
+      const float iv = __expf(-x[0]);
+      float sq = 0.0f, cx = 0.0f;
+#pragma unroll
+      for (int j = 1; j < DP; ++j) { sq = fmaf(x[j], x[j], sq); cx = fmaf(c[j], x[j], cx); }
+      v[0] = c[0] * (-1.0f / D.p0 - 0.5f * iv * sq) + iv * cx;
+#pragma unroll
+      for (int j = 1; j < DP; ++j) v[j] = iv * (c[0] * x[j] - c[j]);
+      break;
+    }
+    default:  // SDEH_DENS_GMM (constant by the reference's semantics), none
+#pragma unroll
+      for (int j = 0; j < DP; ++j) v[j] = 0.0f;
+  }
+}
+
+// One 64-row tile (step t, trajectories i0..i0+63).  BPTT: `lam` holds dLoss/dx_{t+1} on entry and dLoss/dx_t on exit.
+template <int DP, int C, bool PAD, bool BPTT>
+__device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restrict__ lds, int t, long long i0, int nrows,
+                                         int lane, float (&lam)[DP]) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const WsLayout& L = A.lay;
   const float* __restrict__ ws = A.ws;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5;
-  {
-    const float4* src = reinterpret_cast<const float4*>(ws);
-    float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < L.lds_floats / 4; i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
-
   const long long B = A.batch;
-  const long long tiles_per_t = (B + 63) / 64;
-  const long long tile = (long long)blockIdx.x * 4 + wave;
-  if (tile >= tiles_per_t * A.n_steps) return;
-  const int t = (int)(tile / tiles_per_t);
-  const long long i0 = (tile % tiles_per_t) * 64;
-  const int nrows = (int)(B - i0 < 64 ? B - i0 : 64);
   const long long N = B * A.n_steps;
   const long long n0 = (long long)t * B + i0;
   const bool live = lane < nrows;
   const long long irow = live ? i0 + lane : B - 1;
   const int d = PAD ? A.d : DP;
   const int act = A.act, ctrl_kind = A.ctrl_kind;
+  const bool refc = (A.flags & SDEH_FLAG_REFERENCE_CTRL) && A.loss_kind == SDEH_LOSS_REFERENCE_SDE;
 
   float x[DP];
 #pragma unroll
@@ -183,48 +217,87 @@ __global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
   }
   SDEH_FENCE();
 
-  // ---- upstream gradient G = w_i dB (T layout) -----------------------------------------------------------------
-  const bool expo = A.loss_kind == SDEH_LOSS_EXPONENTIAL;
-  const float c_i = (expo ? cf[CF_SBK] : cf[CF_SQDT]) * A.grad_rnd[irow];
-  float G[DP];
-  if (A.noise != nullptr) {
-    const float* __restrict__ np = A.noise + ((long long)t * B + irow) * d;
-#pragma unroll
-    for (int j = 0; j < DP; ++j) G[j] = c_i * np[PAD ? min(j, d - 1) : j];
-  } else {
-    const unsigned long long grow = (unsigned long long)(A.row_offset + irow);
-#pragma unroll
-    for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
-      float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (!PAD || 4 * jb < d) box_muller4(philox_block(A.seed, A.offset, grow, t, jb), n);
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (4 * jb + q < DP) G[4 * jb + q] = c_i * n[q];
-    }
-  }
-  if (PAD) {
-#pragma unroll
-    for (int j = 0; j < DP; ++j) G[j] = j < d ? G[j] : 0.0f;
-  }
-
-  // ---- d loss / d gamma(t): u = clip(nn) + mult * (scale_score * clip(score)) * gamma ------------------------------
+  // ---- score term: sc = (1-w') prior_score + w' target_score (per control kind), S = mult * clip(sc) * gamma ---------
+  const float sig = cf[CF_SIGMA], wl = cf[CF_W];
+  float sc[DP], mfac[DP];  // mfac_j = mult * scale_score * gamma_j  (d S_j / d clip(sc_j))
+  float coef_t = 0.0f, coef_p = 0.0f;
   if (ctrl_kind != SDEH_CTRL_CLIPPED) {
-    float sc[DP];
-    const float w = cf[CF_W], sig = cf[CF_SIGMA];
-    const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
-    if (need_t) ws_target_score<DP, DP>(A.target, ws, lds, L, L.gmm_lds, d, x, sc);
+    coef_t = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET ? wl : 0.0f);
+    coef_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR ? 1.0f - wl : 0.0f;
+    float tsc[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) tsc[j] = 0.0f;
+    if (ctrl_kind != SDEH_CTRL_LERP_PRIOR) ws_target_score<DP, DP>(A.target, ws, lds, L, L.gmm_lds, d, x, tsc);
     if (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR) {
       float psc[DP];
       dgauss_score<DP>(ws + L.dg[1], x, psc);
 #pragma unroll
       for (int j = 0; j < DP; ++j) {
-        if (ctrl_kind == SDEH_CTRL_LERP_PRIOR) sc[j] = (1.0f - w) * psc[j];
-        else sc[j] = w < 0.5f ? psc[j] + w * (sc[j] - psc[j]) : sc[j] - (sc[j] - psc[j]) * (1.0f - w);
+        if (ctrl_kind == SDEH_CTRL_LERP_PRIOR) sc[j] = (1.0f - wl) * psc[j];
+        else sc[j] = wl < 0.5f ? psc[j] + wl * (tsc[j] - psc[j]) : tsc[j] - (tsc[j] - psc[j]) * (1.0f - wl);
       }
-    } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {
+    } else {
 #pragma unroll
-      for (int j = 0; j < DP; ++j) sc[j] = w * sc[j];
+      for (int j = 0; j < DP; ++j) sc[j] = coef_t * tsc[j];
     }
+    cfp gam = as_const(ws + L.gam + t * L.g);
+    const float mult = (ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig) * A.scale_score;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) mfac[j] = mult * (L.g == 1 ? gam[0] : gam[j]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) { sc[j] = 0.0f; mfac[j] = 0.0f; }
+  }
+
+  // ---- Gaussian draws of this step (replayed) ---------------------------------------------------------------------
+  float xi[DP];
+  const bool need_xi = !BPTT || (A.flags & SDEH_FLAG_ITO);
+  if (need_xi) {
+    if (A.noise != nullptr) {
+      const float* __restrict__ np = A.noise + ((long long)t * B + irow) * d;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) xi[j] = np[PAD ? min(j, d - 1) : j];
+    } else {
+      const unsigned long long grow = (unsigned long long)(A.row_offset + irow);
+#pragma unroll
+      for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
+        float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (!PAD || 4 * jb < d) box_muller4(philox_block(A.seed, A.offset, grow, t, jb), n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * jb + q < DP) xi[4 * jb + q] = n[q];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) xi[j] = 0.0f;
+  }
+
+  // ---- upstream gradient of the control ------------------------------------------------------------------------------
+  const bool expo = A.loss_kind == SDEH_LOSS_EXPONENTIAL;
+  const float wi = A.grad_rnd[irow];
+  const float c_i = expo ? cf[CF_SBK] : cf[CF_SQDT];              // dB = c_i xi
+  const float cdt = expo ? cf[CF_B2S2] : cf[CF_DT];               // running cost = cdt * (...)
+  const float c_u = expo ? cf[CF_B2S2] : sig * cf[CF_DT];         // x_{t+1} = c_x x_t + c_u u_t + c_n xi_t
+  const float c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], cf[CF_DT], 1.0f);
+  float G[DP], Gc[DP];  // Gc: the running-cost part  w_i d cost_t / d g  (g = u, or u - reference control)
+  cf2p ptab = as_const2(ws + L.dg[1]);
+#pragma unroll
+  for (int j = 0; j < DP; ++j) {
+    if (!BPTT) {  // log-variance: d rnd / d u = dB exactly
+      Gc[j] = wi * c_i * xi[j];
+      G[j] = Gc[j];
+    } else {
+      const float u = clipf(nn[j], A.clip_model) + mfac[j] * clipf(sc[j], A.clip_score);
+      const float r = refc ? sig * (ptab[j].x - x[j]) * ptab[j].y : 0.0f;
+      Gc[j] = wi * fmaf(u - r, cdt, (A.flags & SDEH_FLAG_ITO) ? c_i * xi[j] : 0.0f);
+      G[j] = fmaf(c_u, lam[j], Gc[j]);
+    }
+    if (PAD) { G[j] = j < d ? G[j] : 0.0f; Gc[j] = j < d ? Gc[j] : 0.0f; }
+  }
+
+  // ---- d loss / d gamma(t) -----------------------------------------------------------------------------------------------
+  if (ctrl_kind != SDEH_CTRL_CLIPPED) {
     const float mult = (ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig) * A.scale_score;
     if (L.g == 1) {
       float s = 0.0f;
@@ -308,21 +381,134 @@ __global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
       for (int ot = 0; ot < OT; ++ot) { dA[ot] = pA[ot]; dB[ot] = pB[ot]; }
     }
   }
+
+  if constexpr (BPTT) {
+    // ---- adjoint update: lambda_t = c_x lambda_{t+1} + W_in^T dZ_0 + (dS/dx)^T G + direct cost terms -----------------------
+    float dx[DP];
+    {
+      f32x16 xA[OTD], xB[OTD];
+#pragma unroll
+      for (int tt = 0; tt < OTD; ++tt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xA[tt][q] = xB[tt][q] = 0.0f;
+      const float* w = lds + L.wt_in + lane;
+#pragma unroll
+      for (int it = 0; it < OT; ++it)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+#pragma unroll
+          for (int tt = 0; tt < OTD; ++tt) {
+            const float a = w[((it * 16 + q) * OTD + tt) * 64];
+            xA[tt] = SDEH_MFMA(a, dA[it][q], xA[tt]);
+            xB[tt] = SDEH_MFMA(a, dB[it][q], xB[tt]);
+            if (tt == OTD - 1 && (q & 1)) SDEH_FENCE();
+          }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float v0 = xA[r / 16][r % 16];
+        float v1 = xB[r / 16][r % 16];
+        swap32(v0, v1);
+        dx[mdim(r, 0)] = v0;
+        if (mdim(r, 1) < DP) dx[mdim(r, 1)] = v1;
+      }
+    }
+    float cvec[DP], vt[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) cvec[j] = fabsf(sc[j]) <= A.clip_score ? mfac[j] * G[j] : 0.0f;
+    if (coef_t != 0.0f) target_score_jt<DP>(A.target, ws, L, d, x, cvec, vt);
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      float v = fmaf(c_x, lam[j], dx[j]);
+      if (coef_t != 0.0f) v = fmaf(coef_t, vt[j], v);
+      if (coef_p != 0.0f) v = fmaf(-coef_p * ptab[j].y, cvec[j], v);   // Gaussian prior: J = -1/sigma^2
+      if (refc) v = fmaf(sig * ptab[j].y, Gc[j], v);                   // cost depends on x through sigma * prior.score(x)
+      lam[j] = (!PAD || j < d) ? v : 0.0f;
+    }
+  }
+}
+
+template <int DP, int C, bool PAD, bool BPTT>
+__global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const WsLayout& L = A.lay;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const float4* src = reinterpret_cast<const float4*>(A.ws);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < L.lds_floats / 4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const long long B = A.batch;
+  const long long tiles_per_t = (B + 63) / 64;
+  const long long tile = (long long)blockIdx.x * 4 + wave;
+  float lam[DP];
+  if constexpr (!BPTT) {
+    if (tile >= tiles_per_t * A.n_steps) return;
+    const int t = (int)(tile / tiles_per_t);
+    const long long i0 = (tile % tiles_per_t) * 64;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) lam[j] = 0.0f;
+    bwd_tile<DP, C, PAD, false>(A, lds, t, i0, (int)(B - i0 < 64 ? B - i0 : 64), lane, lam);
+  } else {
+    if (tile >= tiles_per_t) return;
+    const long long i0 = tile * 64;
+    const int nrows = (int)(B - i0 < 64 ? B - i0 : 64);
+    const long long irow = lane < nrows ? i0 + lane : B - 1;
+    const int d = PAD ? A.d : DP;
+    // lambda_T = w_i d(terminal costs)/dx_T  (losses/oc.py:225,337,449-450)
+    float x[DP];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const float v = A.xs[((long long)A.n_steps * B + irow) * d + (PAD ? min(j, d - 1) : j)];
+      x[j] = (!PAD || j < d) ? v : 0.0f;
+    }
+    const float wi = A.grad_rnd[irow];
+#pragma unroll
+    for (int j = 0; j < DP; ++j) lam[j] = 0.0f;
+    if (A.flags & SDEH_FLAG_TERMINAL_SECOND) {
+      float s2[DP];
+      dgauss_score<DP>(A.ws + L.dg[2], x, s2);
+#pragma unroll
+      for (int j = 0; j < DP; ++j) lam[j] = wi * s2[j];
+    }
+    if (A.flags & SDEH_FLAG_TERMINAL_TARGET) {
+      float st[DP];
+      ws_target_score<DP, DP>(A.target, A.ws, lds, L, L.gmm_lds, d, x, st);
+      float keep = 1.0f;
+      if (A.clip_target < 3.0e38f) {
+        const float lp = ws_target_logp<DP, DP>(A.target, A.ws, lds, L, L.gmm_lds, d, x);
+        keep = fabsf(lp) <= A.clip_target ? 1.0f : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < DP; ++j) lam[j] = fmaf(-wi * keep, st[j], lam[j]);
+    }
+    if (PAD) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) lam[j] = j < d ? lam[j] : 0.0f;
+    }
+    for (int t = A.n_steps - 1; t >= 0; --t) bwd_tile<DP, C, PAD, true>(A, lds, t, i0, nrows, lane, lam);
+  }
 }
 
 template <int DP, int C, bool PAD>
 int launch_ctrl_bwd(const BwdArgs& a, hipStream_t stream) {
   const size_t lds_bytes = (size_t)a.lay.lds_floats * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  const bool bptt = !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
-  const long long tiles = ((a.batch + 63) / 64) * a.n_steps;
-  hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), lds_bytes, stream, a);
+  const long long tiles = ((a.batch + 63) / 64) * (bptt ? 1 : a.n_steps);
+  const dim3 grid((unsigned)((tiles + 3) / 4));
+  if (bptt) hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, true>), grid, dim3(256), lds_bytes, stream, a);
+  else hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, false>), grid, dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

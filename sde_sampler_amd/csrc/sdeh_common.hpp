@@ -50,6 +50,7 @@ struct WsLayout {
   int b_out;      // [otd*32]         (M order)
   int wt_out;     // backward only: transposed out_layer  [r_in][ot][64];  -1 when not packed
   int wt_hid;     // backward only: transposed hidden layers, n_hidden x [c/2][ot][64]
+  int wt_in;      // backward only (BPTT): transposed input_embed  [c/2][otd][64]
   // global tables
   int coef;       // [T][16]
   int emb;        // [T][c]  (M order; FourierMLP.timestep_embed(t) + input_embed.bias)
@@ -102,7 +103,7 @@ struct BwdArgs {
   long long batch, row_offset;
   int n_steps, d;
   int loss_kind, ctrl_kind, flags, act;
-  float clip_model, clip_score, scale_score;
+  float clip_model, clip_score, scale_score, clip_target;
   DensArgs target;
   unsigned long long seed, offset;
 };

@@ -173,6 +173,11 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
       const int dimidx = mdim(r, lane >> 5);
       ws[L.wt_out + e] = dimidx < d ? net.out_w[(size_t)dimidx * C + 32 * ot + (lane & 31)] : 0.0f;
     }
+    for (int e = gid; e < (C / 2) * OTD * 64; e += stride) {  // input_embed^T: rows = coordinates, k over channels
+      const int lane = e & 63, t = (e >> 6) % OTD, sidx = (e >> 6) / OTD;
+      const int row = 32 * t + (lane & 31);
+      ws[L.wt_in + e] = row < d ? net.input_w[(size_t)mdim(sidx, lane >> 5) * d + row] : 0.0f;
+    }
     for (int l = 0; l < L.n_hidden; ++l)
       for (int e = gid; e < (C / 2) * OT * 64; e += stride) {  // hidden_layer[l]^T: k runs over the OUTPUT channels
         const int lane = e & 63, ot = (e >> 6) % OT, sidx = (e >> 6) / OT;

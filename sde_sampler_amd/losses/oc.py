@@ -12,10 +12,10 @@ ReferenceSDELoss 281-391, ExponentialIntegratorSDELoss 394-505), selected by poi
 * the batch reductions of `compute_results` run on device and, under `torch.distributed`, merge across ranks
   with one 8-float all-gather.
 
-Training: `loss(...)` with method "lv" / "lv_traj" back-propagates through the fused kernel (losses/_autograd.py +
-`sdeh_ctrl_backward`).  Not built in (raises `SdehUnsupported`, never falls back): back-propagation through time for
-method "kl" / "kl_ito" (their loss VALUE is available under `torch.no_grad()`), the Bridge inference control /
-divergence term, `sde_ctrl_noise` / `sde_ctrl_dropout` -- SURVEY.md 8f rows f1/f2.
+Training: `loss(...)` back-propagates through the fused kernels for every method (losses/_autograd.py +
+`sdeh_ctrl_backward`): row-parallel for "lv" / "lv_traj" (detached SDE control), back-propagation through time with the
+adjoint kept in registers for "kl" / "kl_ito".  Not built in (raises `SdehUnsupported`, never falls back): the Bridge
+inference control / divergence term and `sde_ctrl_noise` / `sde_ctrl_dropout` -- SURVEY.md 8f row f2.
 """
 from __future__ import annotations
 
@@ -186,11 +186,12 @@ class BaseOCLoss:
         needs_graph = torch.is_grad_enabled() and any(
             p.requires_grad for p in getattr(self.generative_ctrl, "parameters", lambda: [])())
         if needs_graph:
-            if not (flags & L.FLAG_CHANGE_SDE_CTRL):
+            if not (flags & L.FLAG_CHANGE_SDE_CTRL) and (target is None or (second is None and second_log_prob is not None)):
                 raise L.SdehUnsupported(
-                    -2, "training with method='kl'/'kl_ito' needs back-propagation through time, which is not built yet "
-                        "(SURVEY.md 8f row f1); method='lv'/'lv_traj' trains through the fused kernel, and any method "
-                        "works under torch.no_grad() for the loss value")
+                    -2, "training with method='kl'/'kl_ito' back-propagates through the terminal log-densities inside "
+                        "the kernel: terminal_unnorm_log_prob / reference_log_prob must be the methods of built-in "
+                        "distributions (callables the engine cannot fuse are only supported for method='lv'/'lv_traj' "
+                        "or under torch.no_grad())")
             from sde_sampler_amd.losses._autograd import simulate_with_grad
 
             x_T, rnd, _ = simulate_with_grad(self, run, ts, x)

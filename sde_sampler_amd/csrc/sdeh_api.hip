@@ -173,12 +173,14 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   if (v == nullptr) return fail(SDEH_ERR_UNSUPPORTED, "plan_create: no trajectory kernel compiled for dim=%d", desc->dim);
   const int k_max = desc->max_components > 0 ? desc->max_components : 0;
   WsLayout L = make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp);
-  const size_t lds_bytes = L.gmm_lds || k_max == 0
-                               ? ((size_t)L.lds_floats + (size_t)4 * (mdim(mregs(v->dp) - 1, 1) + 1) * 64) * sizeof(float)
-                               : ((size_t)L.lds_floats + (size_t)k_max * 256) * sizeof(float);
-  if (lds_bytes > 160 * 1024)
-    return fail(SDEH_ERR_UNSUPPORTED, "plan_create: needs %zu B of LDS (> 160 KiB): hidden=%d K=%d", lds_bytes,
-                desc->max_hidden, k_max);
+  // LDS: the wave-specialised kernel needs image + exchange buffers, the single-wave kernel image + logit scratch;
+  // a plan is usable when either fits (deep networks fall back to the single-wave kernel at launch time)
+  const size_t img = (size_t)L.lds_floats * sizeof(float);
+  const size_t lds_ws = img + (size_t)4 * (mdim(mregs(v->dp) - 1, 1) + 1) * 64 * sizeof(float);
+  const size_t lds_legacy = img + (size_t)k_max * 256 * sizeof(float);
+  if ((lds_ws < lds_legacy ? lds_ws : lds_legacy) > 160 * 1024)
+    return fail(SDEH_ERR_UNSUPPORTED, "plan_create: needs %zu B of LDS (> 160 KiB): hidden=%d K=%d",
+                lds_ws < lds_legacy ? lds_ws : lds_legacy, desc->max_hidden, k_max);
   SdehPlan* p = new (std::nothrow) SdehPlan();
   if (p == nullptr) return fail(SDEH_ERR_INVALID, "plan_create: out of host memory");
   p->desc = *desc;
@@ -395,6 +397,8 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
     if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);
   } else {
     rc = v->fn(A, st);
+    // image + exchange buffers beyond 160 KiB (deep networks): the single-wave kernel needs less LDS
+    if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) rc = plan->variant->fn_legacy(A, st);
   }
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd: trajectory kernel launch failed (dp=%d)", v->dp);

@@ -196,6 +196,9 @@ CASES = {
 }
 
 
+EXTRA_METHODS = {"cfg1_dw_dis_lv", "cfg4_funnel_dds_lv", "eulerdds_funnel_kl"}
+
+
 def random_gmm(dim: int, k: int, seed: int):
     gen = torch.Generator()
     gen.manual_seed(seed)
@@ -376,6 +379,30 @@ def run_case(name, case):
             out[f"train_{method}/grad/{k}"] = (p.grad.detach().numpy().copy() if p.grad is not None
                                                else np.zeros(tuple(p.shape), np.float32))
     loss.method = case["loss"]["method"]
+
+    # --- the remaining loss methods (kl_ito, lv_traj with two trajectories per sample) on a few configurations ---
+    if name in EXTRA_METHODS:
+        loss.method, loss.n_filtered = "kl_ito", 0
+        ctrl.zero_grad()
+        torch.set_rng_state(state)
+        val, metrics = loss(ts, x0, terminal, second)
+        val.backward()
+        out["train_kl_ito/loss"] = np.float64(val.item())
+        for k, p in ctrl.named_parameters():
+            out[f"train_kl_ito/grad/{k}"] = p.grad.detach().numpy().copy()
+        loss.method, loss.traj_per_sample, loss.n_filtered = "lv_traj", 2, 0
+        ctrl.zero_grad()
+        torch.manual_seed(case["seed"] + 100)
+        x_rep = x0.repeat(2, 1, 1).reshape(-1, x0.shape[-1])
+        state2 = torch.get_rng_state()
+        out["noise_traj2"] = torch.stack([torch.randn_like(x_rep) for _ in range(len(ts) - 1)]).numpy()
+        torch.set_rng_state(state2)
+        val, metrics = loss(ts, x0, terminal, second)
+        val.backward()
+        out["train_lv_traj/loss"] = np.float64(val.item())
+        for k, p in ctrl.named_parameters():
+            out[f"train_lv_traj/grad/{k}"] = p.grad.detach().numpy().copy()
+        loss.method, loss.traj_per_sample = case["loss"]["method"], 1
 
     # distribution known-answer vectors (reference tests/distr_eval.py:45-55 pins analytic == autograd score)
     torch.manual_seed(99)

@@ -246,3 +246,50 @@ def test_mixture_table_variants_vs_oracle(case):
     _row_check("x_T", out.samples.cpu().numpy(), ref["samples"].numpy())
     _est_check("lb_ito", out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"])
     _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
+
+
+def test_deep_network_falls_back_to_single_wave_kernel():
+    """num_layers = 8 (six hidden layers): packed weights + exchange buffers exceed 160 KiB of LDS, so the launch falls
+    back to the single-wave kernel.  Checked against the oracle."""
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec("cfg4_funnel_dds_lv")
+    spec["net"]["num_layers"] = 8
+    spec["grid"]["steps"] = 20
+    prob = problems.build(spec)
+    params = {n: v.detach().clone() for n, v in prob.ctrl.state_dict().items()}
+    B, d = 80, 10
+    torch.manual_seed(4)
+    x0 = torch.randn(B, d)
+    ts = prob.ts.clone()
+    noise = torch.randn(ts.numel() - 1, B, d)
+    ref = eo.Problem(spec, params, None).eval(ts, x0.clone(), noise, compute_weights=True)
+    prob.to("cuda:0")
+    out = prob.eval(x0.cuda(), compute_weights=True, noise=noise.cuda())
+    _row_check("x_T", out.samples.cpu().numpy(), ref["samples"].numpy())
+    _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
+
+
+EXTRA_METHODS = [p for p in GOLDEN if "train_kl_ito/loss" in np.load(p).files]
+
+
+@pytest.mark.parametrize("path", EXTRA_METHODS, ids=lambda p: Path(p).stem)
+def test_kl_ito_and_lv_traj_training_match_reference(path):
+    """The two remaining loss methods: kl_ito (BPTT with the Ito term) and lv_traj (variance over traj_per_sample = 2
+    trajectories started from the same x0), losses and parameter gradients vs the reference."""
+    fx, meta, params, tt = load_fixture(path)
+    x0 = torch.from_numpy(fx["x0"]).cuda()
+    for method, noise, tps in (("kl_ito", fx["noise"], 1), ("lv_traj", fx["noise_traj2"], 2)):
+        prob = hip_problem(meta, params, tt)
+        prob.loss.method, prob.loss.traj_per_sample = method, tps
+        val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob,
+                           noise=torch.from_numpy(noise).cuda())
+        ref_val = float(fx[f"train_{method}/loss"])
+        assert abs(val.item() - ref_val) <= 2e-3 * max(1.0, abs(ref_val)), (method, val.item(), ref_val)
+        val.backward()
+        for name, p in prob.ctrl.named_parameters():
+            ref = fx[f"train_{method}/grad/{name}"]
+            scale = max(np.abs(ref).max(), 1e-6)
+            err = np.abs(p.grad.cpu().numpy() - ref).max()
+            assert err <= 2e-4 * scale + 1e-7, f"{method} {name}: max err {err:.3e} vs scale {scale:.3e}"

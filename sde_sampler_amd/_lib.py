@@ -16,12 +16,13 @@ SDEH_REDUCE_SCRATCH = 8192
 
 # enums (include/sdeh.h)
 LOSS_TIME_REVERSAL, LOSS_REFERENCE_SDE, LOSS_EXPONENTIAL = 0, 1, 2
-CTRL_CLIPPED, CTRL_SCORE, CTRL_LERP, CTRL_LERP_TARGET, CTRL_LERP_PRIOR = 0, 1, 2, 3, 4
+CTRL_CLIPPED, CTRL_SCORE, CTRL_LERP, CTRL_LERP_TARGET, CTRL_LERP_PRIOR, CTRL_NONE = 0, 1, 2, 3, 4, 5
 SDE_NONE, SDE_VP, SDE_CONST_OU = 0, 1, 2
 DENS_NONE, DENS_GMM, DENS_DIAG_GAUSS, DENS_MULTI_WELL, DENS_FUNNEL = 0, 1, 2, 3, 4
 ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2
 FLAG_TRAIN, FLAG_ITO, FLAG_CHANGE_SDE_CTRL, FLAG_INIT_LOGP = 1, 2, 4, 8
-FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL = 16, 32, 64
+FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL, FLAG_INFERENCE_SDE = 16, 32, 64, 128
+INT_LANGEVIN, INT_CONTROLLED = 0, 1
 DENS_FLAG_SHARED_SCALE = 1
 
 STATUS = {0: "SDEH_OK", -1: "SDEH_ERR_INVALID", -2: "SDEH_ERR_UNSUPPORTED", -3: "SDEH_ERR_HIP", -4: "SDEH_ERR_CAPACITY"}
@@ -104,6 +105,8 @@ PROTOTYPES = {
                                       C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, C.c_void_p]),
     "sdeh_ctrl_backward": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64,
                                        C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_integrate": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), C.c_int32, fp, C.c_int32, fp, C.c_int32, C.c_float,
+                                   fp, C.c_int64, fp, C.c_uint64, C.c_uint64, C.c_int64, fp, C.c_void_p]),
     "sdeh_reduce_estimators": (C.c_int32, [fp, C.c_int64, C.c_float, fp, fp, C.c_void_p]),
     "sdeh_importance_weights": (C.c_int32, [fp, C.c_int64, fp, fp, C.c_void_p]),
     "sdeh_debug_philox": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, fp, C.c_void_p]),

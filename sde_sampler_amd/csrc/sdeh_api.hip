@@ -19,7 +19,8 @@ int launch_weights(const float* rnd, long long n, const float* mx, float* w, hip
 #define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv)                           \
   int launch_ws_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                 \
   int launch_legacy_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);             \
-  int launch_bwd_dp##dp##_p##pad##_##tag(const BwdArgs& a, hipStream_t stream);
+  int launch_bwd_dp##dp##_p##pad##_##tag(const BwdArgs& a, hipStream_t stream);                  \
+  int launch_int_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 
@@ -31,10 +32,11 @@ struct Variant {
   TrajLauncher fn;         // wave-specialised kernel (sdeh_traj_ws.hpp)
   TrajLauncher fn_legacy;  // single-wave kernel (sdeh_traj.hpp); returns SDEH_ERR_UNSUPPORTED when not compiled in
   int (*fn_bwd)(const BwdArgs&, hipStream_t);  // control-network backward (sdeh_bwd.hpp), generic variants only
+  TrajLauncher fn_int;     // plain Euler integrator (sdeh_integrate.hpp), generic variants only
   const char* name;
 };
 static const Variant kVariants[] = {
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, &launch_int_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 };
@@ -128,6 +130,7 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   L.coef = o; o += t_max * kCoefStride;
   L.emb = o; o += t_max * c;
   L.gam = o; o += align4(t_max * g);
+  L.out_cnt = o; o += align4(t_max + 1);
   if (!L.gmm_lds) {
     L.gmm_lg = o; o += k_rows * L.gmm_row;
     L.gmm_sc = o; o += k_rows * L.gmm_row;
@@ -272,7 +275,7 @@ struct Checked {
   bool refc;
 };
 static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, int64_t batch,
-                         int64_t row_offset, bool backward, Checked* out) {
+                         int64_t row_offset, bool backward, Checked* out, bool integrate = false) {
   if (plan == nullptr || pr == nullptr || ts == nullptr) return fail(SDEH_ERR_INVALID, "null argument");
   if (batch < 1 || n_steps < 1) return fail(SDEH_ERR_INVALID, "simulate_fwd: batch=%lld n_steps=%d", (long long)batch, n_steps);
   if (row_offset < 0 || (unsigned long long)row_offset + (unsigned long long)batch > 0x100000000ull)
@@ -300,6 +303,8 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     return fail(SDEH_ERR_INVALID, "simulate_fwd: loss_kind %d", pr->loss_kind);
   if (pr->ctrl_kind < SDEH_CTRL_CLIPPED || pr->ctrl_kind > SDEH_CTRL_LERP_PRIOR)
     return fail(SDEH_ERR_INVALID, "simulate_fwd: ctrl_kind %d", pr->ctrl_kind);
+  if ((pr->flags & SDEH_FLAG_INFERENCE_SDE) && !integrate)
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd: the losses integrate the generative SDE (SDEH_FLAG_INFERENCE_SDE is for sdeh_integrate)");
   if (pr->loss_kind != SDEH_LOSS_EXPONENTIAL && pr->sde_kind == SDEH_SDE_NONE)
     return fail(SDEH_ERR_INVALID, "simulate_fwd: loss kind %d needs an sde", pr->loss_kind);
   const bool lerp_family = pr->ctrl_kind >= SDEH_CTRL_LERP;
@@ -338,8 +343,10 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
   static const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing aid: force the generic variants
   // which GMM table form would the layout give?  (0: tables do not fit LDS, 1: general, 2: shared scale)
-  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, 0, backward);
-  const Variant* sv = (no_spec || backward) ? nullptr
+  // the integrator runs on the single-wave code path: generic variant, mixture tables in global memory
+  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared && !integrate, force_legacy || integrate,
+                           0, backward);
+  const Variant* sv = (no_spec || backward || integrate) ? nullptr
                               : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds,
                                                  net.activation, refc ? 1 : 0, nvary);
   if (sv != nullptr && sv->dp == v->dp) {
@@ -373,6 +380,7 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
   P.prob = *pr;
   P.ts = ts;
   P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
   rc = launch_prep(P, st);
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd: prep kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
 
@@ -426,6 +434,7 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
   hipStream_t st = (hipStream_t)stream;
   PrepArgs P;
   P.ws = plan->ws; P.lay = L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
   rc = launch_prep(P, st);
   if (rc != SDEH_OK) return fail(rc, "ctrl_backward: prep kernel launch failed");
   BwdArgs A;
@@ -440,6 +449,66 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
   A.seed = seed; A.offset = offset;
   rc = ck.v->fn_bwd(A, st);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward: kernel launch failed");
+}
+
+int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, const float* timesteps, int32_t n_steps,
+                       const float* ts_out, int32_t n_out, float eps, const float* x_init, int64_t batch,
+                       const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, float* xs_out,
+                       void* stream) {
+  if (plan == nullptr || pr == nullptr || timesteps == nullptr || ts_out == nullptr || x_init == nullptr || xs_out == nullptr)
+    return fail(SDEH_ERR_INVALID, "integrate: null argument");
+  if (kind != SDEH_INT_LANGEVIN && kind != SDEH_INT_CONTROLLED) return fail(SDEH_ERR_INVALID, "integrate: kind %d", kind);
+  if (n_out < 1 || n_out > plan->desc.max_steps + 1)
+    return fail(SDEH_ERR_CAPACITY, "integrate: %d output times (plan allows %d)", n_out, plan->desc.max_steps + 1);
+  if (pr->sde_kind == SDEH_SDE_NONE) return fail(SDEH_ERR_INVALID, "integrate: needs an sde");
+  if (kind == SDEH_INT_LANGEVIN && pr->ctrl_kind != SDEH_CTRL_NONE)
+    return fail(SDEH_ERR_INVALID, "integrate: LangevinSDE has no control (ctrl_kind must be SDEH_CTRL_NONE)");
+  const int d = pr->base_model.dim;
+  Checked ck;
+  int rc;
+  if (pr->ctrl_kind == SDEH_CTRL_NONE) {
+    if (batch < 1 || n_steps < 1) return fail(SDEH_ERR_INVALID, "integrate: batch=%lld n_steps=%d", (long long)batch, n_steps);
+    if (row_offset < 0 || (unsigned long long)row_offset + (unsigned long long)batch > 0x100000000ull)
+      return fail(SDEH_ERR_INVALID, "integrate: global row indices must fit 32 bits");
+    if (d != plan->desc.dim) return fail(SDEH_ERR_CAPACITY, "integrate: dim %d differs from the plan's %d", d, plan->desc.dim);
+    if (n_steps > plan->desc.max_steps) return fail(SDEH_ERR_CAPACITY, "integrate: %d steps > plan max %d", n_steps, plan->desc.max_steps);
+    rc = check_density(pr->target, d, "target", kind != SDEH_INT_LANGEVIN);
+    if (rc != SDEH_OK) return rc;
+    const int k = pr->target.kind == SDEH_DENS_GMM ? pr->target.n_components : 0;
+    if (k > plan->desc.max_components) return fail(SDEH_ERR_CAPACITY, "integrate: GMM with %d components > plan max %d", k, plan->desc.max_components);
+    ck.v = plan->variant;
+    ck.refc = false;
+    ck.L = make_layout(ck.v->dp, plan->desc.channels, 0, n_steps, k, 1, false, true);
+    if ((size_t)ck.L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "integrate: workspace too small");
+  } else {
+    SdehProblem q = *pr;  // the loss-specific fields are not used by the integrator
+    q.loss_kind = SDEH_LOSS_TIME_REVERSAL;
+    q.flags &= SDEH_FLAG_INFERENCE_SDE;
+    rc = check_problem(plan, &q, timesteps, n_steps, batch, row_offset, false, &ck, true);
+    if (rc != SDEH_OK) return rc;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = ck.L; P.prob = *pr; P.ts = timesteps; P.n_steps = n_steps;
+  P.prob.flags &= SDEH_FLAG_INFERENCE_SDE;
+  P.ts_out = ts_out; P.n_out = n_out; P.eps = eps;
+  rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "integrate: prep kernel launch failed");
+  TrajArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = ck.L;
+  A.x0 = x_init; A.noise = noise; A.xs = xs_out;
+  A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d;
+  A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags & SDEH_FLAG_INFERENCE_SDE; A.act = pr->base_model.activation;
+  A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
+  A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
+  A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
+  A.seed = seed; A.offset = offset;
+  A.int_kind = kind; A.n_out = n_out; A.ts_out = ts_out;
+  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  rc = plan->variant->fn_int(A, st);
+  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "integrate: kernel launch failed (dp=%d)", plan->variant->dp);
 }
 
 int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, float* scratch, float* out, void* stream) {

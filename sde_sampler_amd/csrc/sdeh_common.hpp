@@ -55,6 +55,7 @@ struct WsLayout {
   int coef;       // [T][16]
   int emb;        // [T][c]  (M order; FourierMLP.timestep_embed(t) + input_embed.bias)
   int gam;        // [T][g]  clip(score_model(t), clip_model)
+  int out_cnt;    // sdeh_integrate: [T+1] ints, out_cnt[i] = number of output times emitted by steps < i
   // GMM tables: rows of `gmm_row` floats (dp rounded up to even pairs, so rows are float4-aligned).  They live
   // inside the LDS image when they fit (gmm_lds = 1: broadcast ds_read_b128, deep VGPR prefetch), else in the
   // global part of the workspace (scalar loads).
@@ -88,6 +89,9 @@ struct TrajArgs {
   float exp_sigma;
   DensArgs target, prior, second;
   unsigned long long seed, offset;
+  // sdeh_integrate only
+  int int_kind, n_out;
+  const float* ts_out;
 };
 
 struct BwdArgs {
@@ -114,6 +118,9 @@ struct PrepArgs {
   SdehProblem prob;  // by value: holds the device pointers of all parameters
   const float* ts;
   int n_steps;
+  const float* ts_out;  // sdeh_integrate: output times (null otherwise)
+  int n_out;
+  float eps;
 };
 
 // ---------------------------------------------------------------------------------------------------------

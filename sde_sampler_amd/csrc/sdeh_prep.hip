@@ -99,18 +99,23 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
       float* cf = ws + L.coef + i * kCoefStride;
       const float dt = t - s;
       float sigma = 0.0f, drift = 0.0f, ddiv = 0.0f, w = 0.0f;
+      // generative=False (SDEH_FLAG_INFERENCE_SDE, sdeh_integrate only): sign -1, VP schedule runs min -> max
+      const bool inf = pr.flags & SDEH_FLAG_INFERENCE_SDE;
+      const float sgn = inf ? -1.0f : 1.0f;
       if (pr.sde_kind == SDEH_SDE_VP) {  // eq/sdes.py:222-245 (generative: lerp(max, min, t/T), sign +1)
-        const float bs = lerpf(pr.vp_beta_max, pr.vp_beta_min, s / pr.terminal_t);
-        const float bt = lerpf(pr.vp_beta_max, pr.vp_beta_min, t / pr.terminal_t);
+        const float b0 = inf ? pr.vp_beta_min : pr.vp_beta_max, b1 = inf ? pr.vp_beta_max : pr.vp_beta_min;
+        const float bs = lerpf(b0, b1, s / pr.terminal_t);
+        const float bt = lerpf(b0, b1, t / pr.terminal_t);
         sigma = pr.vp_scale * sqrtf(bs);
-        drift = 0.5f * bs;
-        ddiv = 0.25f * (bt + bs) * dt * (float)pr.base_model.dim;
+        drift = sgn * 0.5f * bs;
+        ddiv = sgn * 0.25f * (bt + bs) * dt * (float)pr.base_model.dim;
       } else if (pr.sde_kind == SDEH_SDE_CONST_OU) {  // eq/sdes.py:141-155
         sigma = pr.ou_diff;
-        drift = pr.ou_drift;
-        ddiv = pr.ou_drift * dt * (float)pr.base_model.dim;
+        drift = sgn * pr.ou_drift;
+        ddiv = sgn * pr.ou_drift * dt * (float)pr.base_model.dim;
       }
-      if (pr.sde_kind != SDEH_SDE_NONE) w = s / pr.terminal_t;
+      // the control's clock: ControlledSDE hands terminal_t - t to its ctrl when the sde is not generative (sdes.py:301-303)
+      if (pr.sde_kind != SDEH_SDE_NONE) w = (inf ? pr.terminal_t - s : s) / pr.terminal_t;
       const float bk = fminf(fmaxf(pr.exp_alpha * sqrtf(dt), 0.0f), 1.0f);  // losses/oc.py:429-430
       cf[CF_S] = s; cf[CF_T] = t; cf[CF_DT] = dt; cf[CF_SQDT] = sqrtf(dt);
       cf[CF_SIGMA] = sigma; cf[CF_DRIFT] = drift; cf[CF_DDIV] = ddiv; cf[CF_W] = w;
@@ -118,17 +123,32 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
       cf[CF_B2S2] = bk * bk * (pr.exp_sigma * pr.exp_sigma);
       cf[CF_SBK] = pr.exp_sigma * bk;
       for (int k = 12; k < kCoefStride; ++k) cf[k] = 0.0f;
+      if (P.ts_out != nullptr) {
+        // output schedule of EulerIntegrator.integrate (eq/integrator.py:120-122): step i emits the output times in
+        // (.., t_i+1 + eps] not emitted earlier; out_cnt[i] = #{ts_out <= timesteps[i] + eps} (0 for i = 0)
+        int* cnt = reinterpret_cast<int*>(ws + L.out_cnt);
+        const float lim = t + P.eps;
+        int lo = 0, hi = P.n_out;  // first index with ts_out > lim
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (P.ts_out[mid] <= lim) lo = mid + 1; else hi = mid;
+        }
+        cnt[i + 1] = lo;
+        if (i == 0) cnt[0] = 0;
+      }
     }
+    if (pr.ctrl_kind == SDEH_CTRL_NONE) return;  // no network, no gamma
     const int act = pr.base_model.activation;
+    const float s_ctrl = (pr.flags & SDEH_FLAG_INFERENCE_SDE) ? pr.terminal_t - s : s;
     // FourierMLP.timestep_embed(s) + input_embed.bias, stored in M order
-    time_embed_block(pr.base_model.timestep_embed, act, s, sh_in, sh_a, sh_b, sh_res);
+    time_embed_block(pr.base_model.timestep_embed, act, s_ctrl, sh_in, sh_a, sh_b, sh_res);
     for (int c = tid; c < L.c; c += blockDim.x)
       ws[L.emb + i * L.c + morder(c)] = sh_res[c] + pr.base_model.input_b[c];
     __syncthreads();
     // gamma(s)
     if (pr.ctrl_kind != SDEH_CTRL_CLIPPED) {
       if (pr.score_model.n_hidden > 0) {
-        time_embed_block(pr.score_model, act, s, sh_in, sh_a, sh_b, sh_res);
+        time_embed_block(pr.score_model, act, s_ctrl, sh_in, sh_a, sh_b, sh_res);
         for (int o = tid; o < L.g; o += blockDim.x) {
           float v = o < pr.score_model.dim_out ? sh_res[o] : 0.0f;
           v = fminf(fmaxf(v, -pr.clip_model), pr.clip_model);
@@ -147,6 +167,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
   const SdehFourierMLP& net = pr.base_model;
   const int d = net.dim, C = L.c, OT = L.ot, OTD = L.otd;
 
+  if (pr.ctrl_kind != SDEH_CTRL_NONE) {
   for (int e = gid; e < L.r_in * OT * 64; e += stride) {  // input_embed.weight [C, d]
     const int lane = e & 63, ot = (e >> 6) % OT, r = (e >> 6) / OT;
     const int dimidx = mdim(r, lane >> 5);
@@ -185,6 +206,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
         ws[L.wt_hid + l * L.w_hid_stride + e] = net.hidden_w[l][(size_t)cout * C + 32 * ot + (lane & 31)];
       }
   }
+
+  }  // ctrl_kind != NONE
 
   // GMM tables (distr/gauss.py:123-135 via torch.distributions.MixtureSameFamily)
   if (pr.target.kind == SDEH_DENS_GMM) {

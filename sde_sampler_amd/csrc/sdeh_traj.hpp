@@ -379,6 +379,53 @@ __device__ __forceinline__ U4 philox_block(unsigned long long seed, unsigned lon
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// score part of the control:  mult * scale_score * clip(score mix, clip_score) * clip(gamma(t), clip_model)
+// (reparam.py:56-83 ScoreCtrl, 131-162 LerpCtrl, 166-178 LerpPriorCtrl, 185-197 LerpTargetCtrl); zeros for ClippedCtrl
+// ---------------------------------------------------------------------------------------------------------
+template <int DP>
+__device__ __forceinline__ void ctrl_score_term(int ctrl_kind, const TrajArgs& A, const WsLayout& L, const float* ws,
+                                                int i, cfp cf, float sig, const float (&tsc)[DP],
+                                                const float (&psc)[DP], float (&sterm)[DP]) {
+  if (ctrl_kind != SDEH_CTRL_CLIPPED) {
+    const float w = cf[CF_W];
+    if (ctrl_kind == SDEH_CTRL_SCORE) {  // reparam.py:56-83
+#pragma unroll
+      for (int j = 0; j < DP; ++j) sterm[j] = tsc[j];
+    } else if (ctrl_kind == SDEH_CTRL_LERP) {  // reparam.py:131-144; torch.lerp's two-sided formula
+      if (w < 0.5f) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sterm[j] = psc[j] + w * (tsc[j] - psc[j]);
+      } else {
+        const float w1 = 1.0f - w;
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sterm[j] = tsc[j] - (tsc[j] - psc[j]) * w1;
+      }
+    } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {  // reparam.py:185-197
+#pragma unroll
+      for (int j = 0; j < DP; ++j) sterm[j] = w * tsc[j];
+    } else {  // SDEH_CTRL_LERP_PRIOR, reparam.py:166-178
+      const float w1 = 1.0f - w;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) sterm[j] = w1 * psc[j];
+    }
+    cfp gam = as_const(ws + L.gam + i * L.g);
+    // ScoreCtrl: ctrl + score;  Lerp*: ctrl + sde.diff(t) * score   (reparam.py:78-83,149-162)
+    const float mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;
+    const float g0 = gam[0];
+    if (L.g == 1) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * g0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * gam[j]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < DP; ++j) sterm[j] = 0.0f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // the kernel.  PAD = false: d == DP exactly;  PAD = true: d <= DP, coordinates >= d are held at zero.
 // LOSS / CTRL / TGT / GMMV / ACT / REFC >= 0 fix the loss kind, control kind, target density kind, GMM table variant,
 // activation and presence of a reference control at compile time (the BASELINE configurations get such specialised variants: no dead branches, far
@@ -452,43 +499,7 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
     }
     if (need_p) dgauss_score<DP>(ws + L.dg[1], x, psc);
     float sterm[DP];  // mult * scale_score * clip(score) * clip(gamma(t))
-    if (ctrl_kind != SDEH_CTRL_CLIPPED) {
-      const float w = cf[CF_W];
-      if (ctrl_kind == SDEH_CTRL_SCORE) {  // reparam.py:56-83
-#pragma unroll
-        for (int j = 0; j < DP; ++j) sterm[j] = tsc[j];
-      } else if (ctrl_kind == SDEH_CTRL_LERP) {  // reparam.py:131-144; torch.lerp's two-sided formula
-        if (w < 0.5f) {
-#pragma unroll
-          for (int j = 0; j < DP; ++j) sterm[j] = psc[j] + w * (tsc[j] - psc[j]);
-        } else {
-          const float w1 = 1.0f - w;
-#pragma unroll
-          for (int j = 0; j < DP; ++j) sterm[j] = tsc[j] - (tsc[j] - psc[j]) * w1;
-        }
-      } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {  // reparam.py:185-197
-#pragma unroll
-        for (int j = 0; j < DP; ++j) sterm[j] = w * tsc[j];
-      } else {  // SDEH_CTRL_LERP_PRIOR, reparam.py:166-178
-        const float w1 = 1.0f - w;
-#pragma unroll
-        for (int j = 0; j < DP; ++j) sterm[j] = w1 * psc[j];
-      }
-      cfp gam = as_const(ws + L.gam + i * L.g);
-      // ScoreCtrl: ctrl + score;  Lerp*: ctrl + sde.diff(t) * score   (reparam.py:78-83,149-162)
-      const float mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;
-      const float g0 = gam[0];
-      if (L.g == 1) {
-#pragma unroll
-        for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * g0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * gam[j]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < DP; ++j) sterm[j] = 0.0f;
-    }
+    ctrl_score_term<DP>(ctrl_kind, A, L, ws, i, cf, sig, tsc, psc, sterm);
     SDEH_FENCE();
 
     float u[DP];

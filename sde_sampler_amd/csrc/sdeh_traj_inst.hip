@@ -6,6 +6,7 @@
 // Every variant gets the wave-specialised kernel; the generic ones also carry the single-wave ("legacy") kernel,
 // which is the fallback for mixtures whose tables do not fit in LDS.
 #include "sdeh_bwd.hpp"
+#include "sdeh_integrate.hpp"
 
 #ifndef SDEH_DP
 #error "compile with -DSDEH_DP=<state dimension>"
@@ -43,6 +44,14 @@ int SDEH_CAT(launch_legacy_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const Tr
 int SDEH_CAT(launch_bwd_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const BwdArgs& a, hipStream_t stream) {
 #if SDEH_GENERIC
   return launch_ctrl_bwd<SDEH_DP, 64, (SDEH_PAD != 0)>(a, stream);
+#else
+  (void)a; (void)stream;
+  return SDEH_ERR_UNSUPPORTED;
+#endif
+}
+int SDEH_CAT(launch_int_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const TrajArgs& a, hipStream_t stream) {
+#if SDEH_GENERIC
+  return launch_integrate<SDEH_DP, 64, (SDEH_PAD != 0)>(a, stream);
 #else
   (void)a; (void)stream;
   return SDEH_ERR_UNSUPPORTED;

@@ -200,6 +200,15 @@ def _bound_owner(fn, method: str):
     return owner if owner is not None and getattr(fn, "__name__", None) == method else None
 
 
+def _same_coefficients(a, b) -> bool:
+    """True when two OU objects describe the same process up to the `generative` flag (the solver builds the
+    inference SDE as `instantiate(cfg.sde, generative=False)`, solver/oc.py:130-133)."""
+    if type(a) is not type(b):
+        return False
+    names = ("terminal_t", "diff_coeff_sq_min", "diff_coeff_sq_max", "scale_diff_coeff", "drift_coeff", "diff_coeff")
+    return all(_scalar(getattr(a, n)) == _scalar(getattr(b, n)) for n in names if hasattr(a, n))
+
+
 class _Plan:
     def __init__(self, lib, desc: L.SdehPlanDesc):
         self.lib, self.handle = lib, C.c_void_p()
@@ -248,9 +257,23 @@ class TrajectoryEngine:
     # ------------------------------------------------------------------------------------------------------
     def build_problem(self, *, loss_kind: int, generative_ctrl, sde, flags: int, device, keep: _Keep,
                       terminal_target=None, clip_target=None, second=None, reference_prior=None,
-                      alpha: float = 0.0, sigma: float = 0.0) -> L.SdehProblem:
+                      alpha: float = 0.0, sigma: float = 0.0, allow_inference_sde: bool = False,
+                      dim: int | None = None) -> L.SdehProblem:
         pr = L.SdehProblem()
         pr.loss_kind, pr.flags = loss_kind, flags
+        if generative_ctrl is None:  # sdeh_integrate only: LangevinSDE / bare OU / ControlledSDE(ctrl=None)
+            if not allow_inference_sde:
+                raise ValueError("generative_ctrl is None")
+            pr.ctrl_kind = L.CTRL_NONE
+            pr.clip_model = pr.clip_score = pr.clip_target = _INF
+            pr.scale_score = 1.0
+            pr.base_model.dim, pr.base_model.channels = int(dim), 64
+            if terminal_target is not None:
+                _fill_density(terminal_target, pr.target, keep, device, "target")
+                if pr.target.dim != dim:
+                    raise ValueError(f"target dim {pr.target.dim} != state dim {dim}")
+            self._fill_sde(pr, sde, allow_inference_sde)
+            return pr
         # ---- control --------------------------------------------------------------------------------------
         names = _mro_names(generative_ctrl)
         bad = [n for n in names if n in _CTRL_UNSUPPORTED]
@@ -292,7 +315,7 @@ class TrajectoryEngine:
                     raise _unsupported("prior_score and reference_ctrl use different priors")
                 reference_prior = owner
             ctrl_sde = getattr(generative_ctrl, "sde", None)
-            if kind >= L.CTRL_LERP and ctrl_sde is not None and ctrl_sde is not sde:
+            if kind >= L.CTRL_LERP and ctrl_sde is not None and ctrl_sde is not sde and not _same_coefficients(ctrl_sde, sde):
                 raise _unsupported("generative_ctrl.sde differs from the loss's sde")
         if target_obj is not None:
             _fill_density(target_obj, pr.target, keep, device, "target")
@@ -306,25 +329,73 @@ class TrajectoryEngine:
             _fill_density(second, pr.second, keep, device, "initial/reference density")
             if pr.second.kind != L.DENS_DIAG_GAUSS:
                 raise _unsupported("only Gaussian initial/reference densities are fused")
-        # ---- sde ------------------------------------------------------------------------------------------
-        if sde is None:
-            pr.sde_kind = L.SDE_NONE
-        else:
-            snames = _mro_names(sde)
-            if not getattr(sde, "generative", True):
-                raise _unsupported("the engine integrates the generative SDE (generative=True)")
-            pr.terminal_t = _scalar(sde.terminal_t)
-            if "VP" in snames:
-                pr.sde_kind = L.SDE_VP
-                pr.vp_beta_min, pr.vp_beta_max = _scalar(sde.diff_coeff_sq_min), _scalar(sde.diff_coeff_sq_max)
-                pr.vp_scale = _scalar(sde.scale_diff_coeff)
-            elif "ConstOU" in snames:
-                pr.sde_kind = L.SDE_CONST_OU
-                pr.ou_drift, pr.ou_diff = _scalar(sde.drift_coeff), _scalar(sde.diff_coeff)
-            else:
-                raise _unsupported(f"sde {type(sde).__name__}: VP, ConstOU and ScaledBM are built in")
+        self._fill_sde(pr, sde, allow_inference_sde)
         pr.exp_alpha, pr.exp_sigma = float(alpha), float(sigma)
         return pr
+
+    @staticmethod
+    def _fill_sde(pr: L.SdehProblem, sde, allow_inference_sde: bool = False):
+        if sde is None:
+            pr.sde_kind = L.SDE_NONE
+            return
+        snames = _mro_names(sde)
+        if not getattr(sde, "generative", True):
+            if not allow_inference_sde:
+                raise _unsupported("the engine integrates the generative SDE (generative=True)")
+            pr.flags |= L.FLAG_INFERENCE_SDE
+        pr.terminal_t = _scalar(sde.terminal_t)
+        if "VP" in snames:
+            pr.sde_kind = L.SDE_VP
+            pr.vp_beta_min, pr.vp_beta_max = _scalar(sde.diff_coeff_sq_min), _scalar(sde.diff_coeff_sq_max)
+            pr.vp_scale = _scalar(sde.scale_diff_coeff)
+        elif "ConstOU" in snames:
+            pr.sde_kind = L.SDE_CONST_OU
+            pr.ou_drift, pr.ou_diff = _scalar(sde.drift_coeff), _scalar(sde.diff_coeff)
+        elif "LangevinSDE" in snames:  # constant diffusion, the drift is the (clipped) target score
+            pr.sde_kind = L.SDE_CONST_OU
+            pr.ou_drift, pr.ou_diff = 0.0, _scalar(sde.diff_coeff)
+        else:
+            raise _unsupported(f"sde {type(sde).__name__}: VP, ConstOU and ScaledBM are built in")
+
+    # ------------------------------------------------------------------------------------------------------
+    def integrate(self, pr: L.SdehProblem, kind: int, timesteps: torch.Tensor, ts: torch.Tensor, x: torch.Tensor, *,
+                  noise: torch.Tensor | None, eps: float, keep: _Keep, row_offset: int = 0,
+                  seed: int | None = None) -> torch.Tensor:
+        """Launches prep + the Euler integrator kernel (sdeh_integrate).  Returns xs [len(ts), B, d]."""
+        if not x.is_cuda:
+            raise RuntimeError("the HIP trajectory engine needs CUDA/HIP tensors (got a CPU tensor); "
+                               "there is no CPU path in this package")
+        device = x.device
+        lib = L.load()
+        if x.dim() != 2:
+            raise ValueError(f"x_init must be [batch, dim], got {tuple(x.shape)}")
+        batch, dim = x.shape
+        if dim != pr.base_model.dim:
+            raise ValueError(f"x_init has dim {dim}, the problem expects {pr.base_model.dim}")
+        n_steps, n_out = timesteps.numel() - 1, ts.numel()
+        if n_steps < 1 or n_out < 1:
+            raise ValueError("need at least two integration time points and one output time")
+        steps_p = keep.ptr(timesteps.reshape(-1), device, "timesteps")
+        ts_p = keep.ptr(ts.reshape(-1), device, "ts")
+        x_p = keep.ptr(x, device, "x_init")
+        noise_p = None
+        if noise is not None:
+            if tuple(noise.shape) != (n_steps, batch, dim):
+                raise ValueError(f"noise must be [{n_steps}, {batch}, {dim}], got {tuple(noise.shape)}")
+            noise_p = keep.ptr(noise, device, "noise")
+        xs = torch.empty((n_out, batch, dim), device=device, dtype=torch.float32)
+        k = pr.target.n_components if pr.target.kind == L.DENS_GMM else 0
+        plan = self._plan(device, dim, 64, pr.base_model.n_hidden, max(n_steps, n_out), k)
+        if seed is None:
+            seed = torch.initial_seed()
+        offset = self.calls
+        self.calls += 1
+        stream = torch.cuda.current_stream(device).cuda_stream
+        with torch.cuda.device(device):
+            L.check(lib.sdeh_integrate(plan.handle, C.byref(pr), kind, steps_p, n_steps, ts_p, n_out, float(eps), x_p,
+                                       batch, noise_p, seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, xs.data_ptr(),
+                                       stream))
+        return xs
 
     # ------------------------------------------------------------------------------------------------------
     def run(self, pr: L.SdehProblem, ts: torch.Tensor, x: torch.Tensor, *, noise: torch.Tensor | None,

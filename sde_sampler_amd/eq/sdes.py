@@ -146,3 +146,29 @@ class VP(OU):
         if var_init is not None:
             var = var + growth**2 * var_init
         return growth * x_init, var
+
+
+class LangevinSDE(TorchSDE):
+    """Overdamped Langevin dynamics dX = clip(target_score(X) * diff_coeff^2 / 2) dt + diff_coeff dW
+    (reference eq/sdes.py:38-65; used by solver/langevin.py:45-46)."""
+
+    def __init__(self, target_score, diff_coeff: float = 1.0, clip_score: float | None = None, **kwargs):
+        super().__init__(**kwargs)
+        self.target_score = target_score
+        _buf(self, "diff_coeff", diff_coeff)
+        self.clip_score = clip_score
+
+
+class ControlledSDE(TorchSDE):
+    """An OU process whose drift is shifted by diff * ctrl(t', x); t' = terminal_t - t when the OU process is the
+    inference one (reference eq/sdes.py:272-305)."""
+
+    def __init__(self, sde: OU, ctrl=None, **kwargs):
+        super().__init__(terminal_t=sde.terminal_t.item(), **kwargs)
+        self.sde = sde
+        self.sde_type = sde.sde_type
+        self.noise_type = sde.noise_type
+        self.ctrl = ctrl
+
+    def diff(self, t, x):
+        return self.sde.diff(t, x)

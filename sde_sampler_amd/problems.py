@@ -84,15 +84,47 @@ def build_prior(spec: dict):
 def build_sde(spec: dict | None):
     if spec is None:
         return None
-    kind = spec["kind"]
+    kind, gen = spec["kind"], spec.get("generative", True)
     if kind == "vp":
         return VP(diff_coeff_sq_min=spec["beta_min"], diff_coeff_sq_max=spec["beta_max"],
-                  scale_diff_coeff=spec.get("scale", 1.0), terminal_t=spec["terminal_t"])
+                  scale_diff_coeff=spec.get("scale", 1.0), terminal_t=spec["terminal_t"], generative=gen)
     if kind == "const_ou":
-        return ConstOU(drift_coeff=spec["drift_coeff"], diff_coeff=spec["diff_coeff"], terminal_t=spec["terminal_t"])
+        return ConstOU(drift_coeff=spec["drift_coeff"], diff_coeff=spec["diff_coeff"], terminal_t=spec["terminal_t"],
+                       generative=gen)
     if kind == "scaled_bm":
-        return ScaledBM(diff_coeff=spec["diff_coeff"], terminal_t=spec["terminal_t"])
+        return ScaledBM(diff_coeff=spec["diff_coeff"], terminal_t=spec["terminal_t"], generative=gen)
     raise ValueError(f"unknown sde kind {kind}")
+
+
+def build_integration(spec: dict, params: dict | None = None, target_tensors: dict | None = None, device=None):
+    """The SDE object handed to `EulerIntegrator.integrate` for an `integrate` spec (the `int_*` golden fixtures):
+    kind "langevin" -> LangevinSDE(target.score, diff_coeff, clip_score)              (solver/langevin.py:20-24)
+    kind "controlled" -> a bare OU process, or ControlledSDE(OU, ctrl) with the control built on the generative twin of
+    the OU process                                                                        (solver/oc.py:130-143).
+    Returns (sde, target, prior, ctrl | None)."""
+    from sde_sampler_amd.eq.sdes import ControlledSDE, LangevinSDE
+
+    target = build_target(spec["target"], target_tensors)
+    prior = build_prior(spec["prior"])
+    ispec, ctrl = spec["integrate"], None
+    if ispec["kind"] == "langevin":
+        sde = LangevinSDE(target_score=target.score, diff_coeff=ispec["diff_coeff"], clip_score=ispec.get("clip_score"),
+                          terminal_t=spec["grid"]["end"])
+    else:
+        sde = build_sde(spec["sde"])
+        if spec.get("ctrl"):
+            ctrl = build_ctrl(spec["ctrl"], spec["net"], spec["target"]["dim"], build_sde(dict(spec["sde"], generative=True)),
+                              prior, target)
+            if params is not None:
+                ctrl.load_state_dict(params)
+            sde = ControlledSDE(sde=sde, ctrl=ctrl)
+        elif spec.get("wrap"):
+            sde = ControlledSDE(sde=sde, ctrl=None)
+    if device is not None:
+        for mod in (target, prior, sde, ctrl):
+            if mod is not None:
+                mod.to(device)
+    return sde, target, prior, ctrl
 
 
 def build_ctrl(spec: dict, net: dict, dim: int, sde, prior, target, live_last_layers: bool = True):

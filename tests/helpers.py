@@ -7,7 +7,9 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = Path(__file__).parent / "golden"
-GOLDEN = sorted(glob.glob(str(GOLDEN_DIR / "*.npz")))
+_ALL = sorted(glob.glob(str(GOLDEN_DIR / "*.npz")))
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith("int_")]      # loss-loop fixtures (make_golden.py)
+GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]      # Euler-integrator fixtures (make_golden_integrator.py)
 
 
 def load_fixture(path):

@@ -216,3 +216,16 @@ def test_merge_stats_matches_direct_computation():
     assert est["var_rnd"] == pytest.approx(rnd.var().item(), rel=1e-10)
     assert est["log_norm_const_is"] == pytest.approx((w.mean().log() + m).item(), abs=1e-10)
     assert est["ess"] == pytest.approx((w.sum() ** 2 / (w**2).sum()).item(), rel=1e-10)
+
+
+def test_euler_integrator_has_no_cpu_path():
+    """EulerIntegrator mirrors the reference's constructor / integrate signature; CPU tensors are refused (no fallback)."""
+    from sde_sampler_amd.eq.integrator import EulerIntegrator
+    from sde_sampler_amd.eq.sdes import VP, ControlledSDE
+
+    integ = EulerIntegrator(dt=0.1)
+    assert (integ.dt, integ.steps, integ.rescale_t, integ.eps) == (0.1, None, None, 1e-8)
+    sde = ControlledSDE(sde=VP(generative=False), ctrl=None)
+    assert sde.terminal_t.item() == 1.0 and sde.noise_type == "diagonal"
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        integ.integrate(sde, ts=torch.linspace(0, 1, 3), x_init=torch.zeros(4, 2))

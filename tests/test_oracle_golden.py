@@ -10,7 +10,9 @@ import torch
 
 from oracle import em_oracle as eo
 
-GOLDEN = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
+_ALL = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith("int_")]
+GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]
 assert GOLDEN, "golden fixtures missing"
 
 
@@ -116,3 +118,22 @@ def test_remaining_methods_bit_exact(path):
         assert loss.item() == float(fx[f"train_{method}/loss"])
         for k in names:
             assert np.array_equal(params[k].grad.numpy(), fx[f"train_{method}/grad/{k}"]), (method, k)
+
+
+@pytest.mark.parametrize("path", GOLDEN_INT, ids=lambda p: Path(p).stem)
+def test_euler_integrator_bit_exact(path):
+    """oracle.euler_integrate / integration_case vs the reference's EulerIntegrator.integrate on LangevinSDE, bare OU
+    processes and ControlledSDE (tests/golden/make_golden_integrator.py), same noise: bit-exact."""
+    import json
+
+    fx = np.load(path)
+    meta = json.loads(bytes(fx["meta"]).decode())
+    params = {k[len("param/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("param/")}
+    tt = None
+    if meta["target"]["kind"] == "gmm":
+        tt = {k: torch.from_numpy(fx["target/" + k].copy()) for k in ("loc", "scale", "mixture_weights")}
+    drift, diff = eo.integration_case(meta, params, tt)
+    xs = eo.euler_integrate(drift, diff, torch.from_numpy(fx["ts"]), torch.from_numpy(fx["x_init"]),
+                            torch.from_numpy(fx["timesteps"]), noise=torch.from_numpy(fx["noise"]))
+    assert xs.shape == fx["xs"].shape
+    assert np.array_equal(xs.detach().numpy(), fx["xs"])

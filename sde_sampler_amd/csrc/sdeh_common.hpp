@@ -138,8 +138,8 @@ __host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
     const uint64_t p1 = (uint64_t)M1 * c.z;
     U4 n;
     n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
-    n.y = (uint32_t)p1;
     n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+    n.y = (uint32_t)p1;
     n.w = (uint32_t)p0;
     c = n;
     k0 += W0;

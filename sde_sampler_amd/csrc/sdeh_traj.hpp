@@ -38,25 +38,28 @@ __device__ __forceinline__ void swap32(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ float clipf(float v, float m) { return fminf(fmaxf(v, -m), m); }
+// clamp(v, -m, m) as one v_med3_f32 (m = +inf: identity; NaN -> -m, as fminf(fmaxf(v, -m), m) gives)
+__device__ __forceinline__ float clipf(float v, float m) { return __builtin_amdgcn_fmed3f(v, -m, m); }
 
-// GELU(v) = v * Phi(v) with Phi(v) = 0.5 erfc(-v/sqrt2).  Branch-free: erfc(z) = 2^-q(z) for z >= 0 with q a
-// degree-10 polynomial fit of -log2 erfc on [0, 6] (max |error| of GELU vs the exact erf form ~1e-7 |v|, i.e.
-// fp32 rounding level; checked by tests/test_hip_parity.py::test_gelu_accuracy).
+// GELU(v) = v Phi(v) = max(v, 0) - |v| Phi(-|v|).  Branch-free: Phi(-t) = 2^q(t) for t = min(|v|, 6) with q a degree-7
+// polynomial, the weighted minimax fit of log2 Phi(-t) on [0, 6] (weight = d GELU / d q = t Phi(-t) ln 2, so the fit
+// error is an ABSOLUTE error of GELU: 2.7e-8, below the fp32 rounding of the evaluation itself).  Measured against the
+// exact erf form in fp64: max |error| 8e-8 max(1, |v|) -- torch's own fp32 erf GELU has 3.5e-7 (tools/gelu_fit.py;
+// tests/test_hip_rng_and_stats.py::test_gelu_accuracy).  11 VALU instructions: v_med3(|v|), 7 v_fma, v_exp, v_med3, v_fma.
 __device__ __forceinline__ float act_gelu(float v) {
-  const float z = fminf(fabsf(v) * 0.70710678118654752440f, 6.0f);
-  float p = 6.603050149e-07f;
-  p = fmaf(p, z, -1.530170759e-05f);
-  p = fmaf(p, z, 1.480139295e-04f);
-  p = fmaf(p, z, -7.626767611e-04f);
-  p = fmaf(p, z, 2.001933838e-03f);
-  p = fmaf(p, z, 3.411742314e-04f);
-  p = fmaf(p, z, -2.809073479e-02f);
-  p = fmaf(p, z, 1.484803495e-01f);
-  p = fmaf(p, z, 9.184024644e-01f);
-  p = fmaf(p, z, 1.627910815e+00f);
-  const float e = __builtin_amdgcn_exp2f(fmaf(-p, z, -1.0f));  // 0.5 erfc(z)
-  return v * (v < 0.0f ? e : 1.0f - e);
+  // v_med3_f32: fminf would add a canonicalising v_max_f32 in front
+  const float t = __builtin_amdgcn_fmed3f(fabsf(v), 0.0f, 6.0f);
+  float q = 3.1519810942e-06f;
+  q = fmaf(q, t, 2.9382445567e-07f);
+  q = fmaf(q, t, -6.3593041018e-04f);
+  q = fmaf(q, t, 7.8107097075e-03f);
+  q = fmaf(q, t, -5.3123810262e-02f);
+  q = fmaf(q, t, -4.5892834822e-01f);
+  q = fmaf(q, t, -1.1511629160e+00f);
+  q = fmaf(q, t, -9.9999612579e-01f);
+  float relu;  // one v_max_f32: written in C (fmaxf, or med3 with +inf) hipcc adds a canonicalising v_max_f32 v, v, v in front
+  asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(v));
+  return fmaf(-t, __builtin_amdgcn_exp2f(q), relu);
 }
 __device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }
 __device__ __forceinline__ float act_relu(float v) { return fmaxf(v, 0.0f); }
@@ -354,8 +357,8 @@ __device__ __forceinline__ void box_muller4(const U4& r, float (&n)[4]) {
   const float u2 = ((float)(r.z >> 8) + 0.5f) * S;
   const float u3 = ((float)(r.w >> 8) + 0.5f) * S;
   // v_log_f32 is log2:  -2 ln u = -2 ln2 log2 u
-  const float ra = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));
-  const float rb = __builtin_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
+  const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));  // v_sqrt_f32 (1 ulp; the argument is never denormal)
+  const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));
   // v_sin_f32 / v_cos_f32 take the angle in revolutions
   n[0] = ra * __builtin_amdgcn_cosf(u1);
   n[1] = ra * __builtin_amdgcn_sinf(u1);
@@ -412,7 +415,11 @@ __device__ __forceinline__ void ctrl_score_term(int ctrl_kind, const TrajArgs& A
     // ScoreCtrl: ctrl + score;  Lerp*: ctrl + sde.diff(t) * score   (reparam.py:78-83,149-162)
     const float mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;
     const float g0 = gam[0];
-    if (L.g == 1) {
+    if (L.g == 1 && A.scale_score == 1.0f && ctrl_kind == SDEH_CTRL_SCORE) {
+      // the shipped ScoreCtrl configurations: 1.0 * ((1.0 * clip) * g0) is one multiply, bit-identical
+#pragma unroll
+      for (int j = 0; j < DP; ++j) sterm[j] = clipf(sterm[j], A.clip_score) * g0;
+    } else if (L.g == 1) {
 #pragma unroll
       for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * g0);
     } else {

@@ -20,6 +20,13 @@
 #pragma once
 #include "sdeh_traj.hpp"
 
+#ifndef SDEH_MPRIO
+#define SDEH_MPRIO 3
+#endif
+#ifndef SDEH_VPRIO
+#define SDEH_VPRIO 0
+#endif
+
 namespace sdeh {
 
 constexpr int kWsGroups = 4;  // trajectory groups (of 64) per workgroup
@@ -230,24 +237,10 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return act == SDEH_ACT_GELU_ERF ? act_gelu(v) : (act == SDEH_ACT_SILU ? act_silu(v) : act_relu(v));
 }
 
-// Two activations at once: the polynomial of the branch-free GELU runs on v_pk_fma_f32 (one 64-bit register pair).
-__device__ __forceinline__ f2 act_gelu2(f2 v) {
-  const f2 z = {fminf(fabsf(v.x) * 0.70710678118654752440f, 6.0f), fminf(fabsf(v.y) * 0.70710678118654752440f, 6.0f)};
-  f2 p = splat(6.603050149e-07f);
-  p = pk_fma(p, z, splat(-1.530170759e-05f));
-  p = pk_fma(p, z, splat(1.480139295e-04f));
-  p = pk_fma(p, z, splat(-7.626767611e-04f));
-  p = pk_fma(p, z, splat(2.001933838e-03f));
-  p = pk_fma(p, z, splat(3.411742314e-04f));
-  p = pk_fma(p, z, splat(-2.809073479e-02f));
-  p = pk_fma(p, z, splat(1.484803495e-01f));
-  p = pk_fma(p, z, splat(9.184024644e-01f));
-  p = pk_fma(p, z, splat(1.627910815e+00f));
-  const f2 a = pk_fma(-p, z, splat(-1.0f));
-  const float e0 = __builtin_amdgcn_exp2f(a.x), e1 = __builtin_amdgcn_exp2f(a.y);  // 0.5 erfc(z)
-  const f2 phi = {v.x < 0.0f ? e0 : 1.0f - e0, v.y < 0.0f ? e1 : 1.0f - e1};
-  return v * phi;
-}
+// Two activations at once.  (A v_pk_fma_f32 formulation of the polynomial does not survive: hipcc unpacks packed fp32
+// ops whose second operand is a splat SGPR constant back into two v_fma_f32 -- and a packed op costs ~5.3 cycles against
+// 2 x 4, so little is lost.)
+__device__ __forceinline__ f2 act_gelu2(f2 v) { return f2{act_gelu(v.x), act_gelu(v.y)}; }
 
 // out[OTO] += W[s][ot] * in-operand(s) for NS k-steps, while activating the NE elements of `side` in place.
 // The A operands (packed weights in LDS) are fetched PF k-steps ahead through a rotating register window: the LDS
@@ -276,7 +269,7 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ w, IN&& in,
     const float b = in(s);
 #pragma unroll
     for (int ot = 0; ot < OTO; ++ot) out[ot] = SDEH_MFMA(a[ot], b, out[ot]);
-    if (do_side) {
+    if (do_side && !(SDEH_ABL & 8)) {
       // the NE/2 element pairs (2i, 2i+1) are spread evenly over the NS k-steps
 #pragma unroll
       for (int i = s * (NE / 2) / NS; i < (s + 1) * (NE / 2) / NS; ++i) {
@@ -378,6 +371,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     // =================================================================================== M wave
     constexpr int OT = C / 32;
     const int h = lane >> 5;
+#if SDEH_MPRIO > 0
+    __builtin_amdgcn_s_setprio(SDEH_MPRIO);
+#endif
     __syncthreads();  // LDS image staged
     f32x16 emb[OT];
 #pragma unroll
@@ -396,6 +392,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   }
 
   // ===================================================================================== V wave
+#if SDEH_VPRIO > 0
+  __builtin_amdgcn_s_setprio(SDEH_VPRIO);
+#endif
   const long long row = (long long)blockIdx.x * 256 + group * 64 + lane;
   const bool live = row < A.batch;
   const long long lrow = live ? row : A.batch - 1;  // dead lanes shadow the last row and never store
@@ -467,7 +466,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       cfp gam = as_const(ws + L.gam + i * L.g);
       const float mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;  // Lerp*: ctrl + sde.diff(t) * score
       const float g0 = gam[0];
-      if (L.g == 1) {
+      if (L.g == 1 && A.scale_score == 1.0f && ctrl_kind == SDEH_CTRL_SCORE) {
+        // the shipped ScoreCtrl configurations: 1.0 * ((1.0 * clip) * g0) is one multiply, bit-identical
+#pragma unroll
+        for (int j = 0; j < DP; ++j) sterm[j] = clipf(sterm[j], A.clip_score) * g0;
+      } else if (L.g == 1) {
 #pragma unroll
         for (int j = 0; j < DP; ++j) sterm[j] = mult * ((A.scale_score * clipf(sterm[j], A.clip_score)) * g0);
       } else {
@@ -525,31 +528,48 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     SDEH_FENCE();
 
     __syncthreads();  // barrier B: the M wave has published the network output
-    // ---- u = clip(nn) + score term; running cost (losses/oc.py:204-211, 319-323, 418-431); publish x_{i+1} ---
-    float cost = 0.0f, itosum = 0.0f;
+    // ---- u = clip(nn) + score term; publish x_{i+1} first: the M wave is idle until barrier A ------------------------
+    float u[DP];
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
       const float nn = (SDEH_ABL & 1) ? 0.01f * xi[j] : xbuf[j * 64 + lane];
-      float u = clipf(nn, A.clip_model) + sterm[j];
-      if (PAD) u = j < d ? u : 0.0f;
-      float g = u;  // the control entering the cost / Ito term (gen_plus_inf / gen_minus_ref)
-      if (refc) {
-        g = u - rsub[j];
-        cost = lv ? fmaf(g, u - 0.5f * (rsub[j] + u), cost) : fmaf(g, g, cost);
-      } else {
-        cost = lv ? fmaf(u, u - 0.5f * u, cost) : fmaf(u, u, cost);
-      }
-      itosum = fmaf(g, xi[j], itosum);
-      x[j] = fmaf(c_u, u, x[j]);
+      u[j] = clipf(nn, A.clip_model) + sterm[j];
+      if (PAD) u[j] = j < d ? u[j] : 0.0f;
+      x[j] = fmaf(c_u, u[j], x[j]);
       if (PAD) x[j] = j < d ? x[j] : 0.0f;
       xbuf[j * 64 + lane] = x[j];
     }
-    if (!lv) cost *= 0.5f;
+    __syncthreads();  // barrier A: x_{i+1} published
+    // ---- running cost (losses/oc.py:204-211, 319-323, 418-431) and Ito term, in the shadow of the next network pass -----
+    float cost = 0.0f;
+    if (!refc) {
+      // u (u - 0.5 u) accumulates to exactly half of what u u does (scaling by 0.5 commutes with every rounding), so the
+      // log-variance and the KL form of the cost are the same sum
+#pragma unroll
+      for (int j = 0; j < DP; ++j) cost = fmaf(u[j], u[j], cost);
+      cost *= 0.5f;
+    } else if (lv) {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) cost = fmaf(u[j] - rsub[j], u[j] - 0.5f * (rsub[j] + u[j]), cost);
+    } else {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) { const float g = u[j] - rsub[j]; cost = fmaf(g, g, cost); }
+      cost *= 0.5f;
+    }
     if (expo) rnd = fmaf(cf[CF_B2S2], cost, rnd);
     else rnd = fmaf(cost, dt, rnd);
     if (loss_kind == SDEH_LOSS_TIME_REVERSAL && !(flags & SDEH_FLAG_TRAIN)) rnd -= cf[CF_DDIV];
-    if (flags & SDEH_FLAG_ITO) rnd = fmaf(itosum, c_i, rnd);
-    __syncthreads();  // barrier A: x_{i+1} published
+    if (flags & SDEH_FLAG_ITO) {  // the control entering the Ito term: gen_plus_inf / gen_minus_ref
+      float itosum = 0.0f;
+      if (refc) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) itosum = fmaf(u[j] - rsub[j], xi[j], itosum);
+      } else {
+#pragma unroll
+        for (int j = 0; j < DP; ++j) itosum = fmaf(u[j], xi[j], itosum);
+      }
+      rnd = fmaf(itosum, c_i, rnd);
+    }
 
     if (xs != nullptr && live) {
       float* __restrict__ xp = xs + ((long long)(i + 1) * A.batch + lrow) * d;

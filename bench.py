@@ -90,7 +90,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps (the first ~8 launches after idle run while the GPU clock is still ramping up)")
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the workload's 65 536)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
@@ -184,6 +185,7 @@ def main():
                      "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_hbm_traffic(),
                      "algorithmic_hbm_bytes": B * (8 * d + 4),
                      "kernel": "sdeh::traj_ws_kernel<50,64,...> (wave-specialised; pis_gmm4 variant)", "kernel_ms": k_ms,
+                     "kernel_ms_min": min(kernel_ms),
                      "flops_per_traj_step": flops,
                      "note": "fp32 MFMA and fp32 VALU share one datapath on gfx950 (profiles/r01_ubench_coexec.txt): "
                              "157.3 TFLOP/s is the budget for both; F counts SURVEY 8d's algorithmic FLOPs"},

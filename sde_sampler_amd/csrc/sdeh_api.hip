@@ -343,9 +343,8 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
   static const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing aid: force the generic variants
   // which GMM table form would the layout give?  (0: tables do not fit LDS, 1: general, 2: shared scale)
-  // the integrator runs on the single-wave code path: generic variant, mixture tables in global memory
-  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared && !integrate, force_legacy || integrate,
-                           0, backward);
+  // the integrator runs on the single-wave code path of the generic variant (mixture tables in LDS when they fit)
+  WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, 0, backward);
   const Variant* sv = (no_spec || backward || integrate) ? nullptr
                               : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds,
                                                  net.activation, refc ? 1 : 0, nvary);
@@ -478,7 +477,8 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, cons
     if (k > plan->desc.max_components) return fail(SDEH_ERR_CAPACITY, "integrate: GMM with %d components > plan max %d", k, plan->desc.max_components);
     ck.v = plan->variant;
     ck.refc = false;
-    ck.L = make_layout(ck.v->dp, plan->desc.channels, 0, n_steps, k, 1, false, true);
+    ck.L = make_layout(ck.v->dp, plan->desc.channels, 0, n_steps, k, 1,
+                       k > 0 && (pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE), false);
     if ((size_t)ck.L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "integrate: workspace too small");
   } else {
     SdehProblem q = *pr;  // the loss-specific fields are not used by the integrator

@@ -7,7 +7,7 @@
 // reference writes (and torch.cat's) one [B,d] tensor per step and interpolates afterwards; here only the requested
 // output times are ever written.
 #pragma once
-#include "sdeh_traj.hpp"
+#include "sdeh_traj_ws.hpp"
 
 namespace sdeh {
 
@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void integrate_kernel(const float* __restrict_
   const bool langevin = A.int_kind == SDEH_INT_LANGEVIN;
   const bool net = ctrl_kind != SDEH_CTRL_NONE;
 
-  if (net) {  // packed weights (LDS image)
+  const int gmmv = L.gmm_lds;  // 1 / 2: mixture tables inside the LDS image (general / shared-scale form); 0: global memory
+  if (net || gmmv != 0) {  // packed weights + mixture tables (LDS image)
     const float4* src = reinterpret_cast<const float4*>(ws);
     float4* dst = reinterpret_cast<float4*>(lds);
     for (int i = tid; i < L.lds_floats / 4; i += 256) dst[i] = src[i];
@@ -64,7 +65,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(const float* __restrict_
     // ---- drift --------------------------------------------------------------------------------------------
     float dr[DP];
     float tsc[DP], psc[DP];
-    if (need_t) target_score<DP>(tgt, ws, lds, L, 0, d, lg_lds, x, tsc);
+    if (need_t) {
+      // mixtures: streamed from LDS with an online softmax when the tables fit, else two passes over scalar loads
+      if (tgt.kind == SDEH_DENS_GMM && gmmv != 0) ws_target_score<DP, DP>(tgt, ws, lds, L, gmmv, d, x, tsc);
+      else target_score<DP>(tgt, ws, lds, L, 0, d, lg_lds, x, tsc);
+    }
     if (need_p) dgauss_score<DP>(ws + L.dg[1], x, psc);
     if (langevin) {  // eq/sdes.py:53-61: clip(target_score(x) * diff_coeff**2 / 2.0, clip_score)
       const float s2 = sig * sig;
@@ -117,7 +122,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(const float* __restrict_
 
 template <int DP, int C, bool PAD>
 int launch_integrate(const TrajArgs& a, hipStream_t stream) {
-  const int k_scratch = a.lay.k_max > 0 ? a.lay.k_max : 0;
+  const int k_scratch = (a.lay.k_max > 0 && a.lay.gmm_lds == 0) ? a.lay.k_max : 0;
   const size_t lds_bytes = ((size_t)a.lay.lds_floats + (size_t)k_scratch * 256) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_set = false;

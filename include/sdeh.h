@@ -257,6 +257,36 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* problem, int32_t kind,
                        int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                        float* xs_out, void* stream);
 
+/*
+ * Entropy-regularised optimal-transport cost between two point clouds.  Replaces Sinkhorn.compute (eval/sinkhorn.py:
+ * 63-178), whose [n, m] reductions the reference delegates to pykeops (pinned `pykeops` in its requirements; absent here):
+ *   M_ij = ||x_i - y_j||_p (p = 1 or 2);  u = 0, v = eps log w_y;  repeat (at most max_iters times)
+ *     u_i = eps (log w_x_i - logsumexp_j((v_j - M_ij)/eps));   v_j = eps (log w_y_j - logsumexp_i((u_i - M_ij)/eps))
+ *   until max|du| < stop_thresh and max|dv| < stop_thresh;   distance = sum_ij exp((u_i + v_j - M_ij)/eps) M_ij.
+ * w_x / w_y NULL = the reference's uniform weights (ones(n)/n and ones(m)/m * n/m).  The convergence test runs on the
+ * device (no host synchronisation; converged iterations' kernels return immediately).
+ *   out[0] = distance   out[1] = iterations run   out[2], out[3] = last max|du|, max|dv|
+ *   corr_x_to_y [n] / corr_y_to_x [m]: optional argmax of the transport plan per row / column (NULL to skip)
+ *   workspace: sdeh_sinkhorn_workspace_floats(n, m) floats, caller-owned
+ */
+int64_t sdeh_sinkhorn_workspace_floats(int64_t n, int64_t m);
+int32_t sdeh_sinkhorn(const float* x, int64_t n, const float* y, int64_t m, int32_t d, const float* w_x, const float* w_y,
+                      int32_t p, float eps, int32_t max_iters, float stop_thresh, float* workspace, float* out,
+                      int64_t* corr_x_to_y, int64_t* corr_y_to_x, void* stream);
+
+/*
+ * One pass over samples[batch, d] (+ optional importance weights[batch], optional box domain[d, 2]) producing everything
+ * get_metrics (eval/metrics.py:70-184) reduces over the batch, as sums that can be merged across ranks:
+ *   out[0] = batch   out[1] = sum w   out[2] = sum w^2   out[3] = rows inside the domain (-1 without a domain)
+ *   out[4..8)  = sum_i f_k(x_i),  f = square, abs, sum, square_minus_sum (distr/base.py:12-17; each sums over coordinates)
+ *   out[8..12) = sum_i w_i f_k(x_i)
+ *   out[12 .. 12+d) = per-coordinate mean      out[12+d .. 12+2d) = per-coordinate M2 = sum_i (x_id - mean_d)^2
+ * d <= 256.  scratch: sdeh_sample_stats_scratch_floats(d) floats.
+ */
+int64_t sdeh_sample_stats_scratch_floats(int32_t d);
+int32_t sdeh_sample_stats(const float* samples, int64_t batch, int32_t d, const float* weights, const float* domain,
+                          float* scratch, float* out, void* stream);
+
 /* Philox4x32-10 known-answer hook used by the tests: fills out[4*n] with the generator's raw words for
  * counters (row_offset+i, step, block, offset) and the (seed) key -- the exact stream sdeh_simulate_fwd consumes. */
 int32_t sdeh_debug_philox(uint64_t seed, uint64_t offset, int64_t row_offset, int32_t step, int32_t block,

@@ -107,6 +107,11 @@ PROTOTYPES = {
                                        C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_integrate": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), C.c_int32, fp, C.c_int32, fp, C.c_int32, C.c_float,
                                    fp, C.c_int64, fp, C.c_uint64, C.c_uint64, C.c_int64, fp, C.c_void_p]),
+    "sdeh_sinkhorn_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64]),
+    "sdeh_sinkhorn": (C.c_int32, [fp, C.c_int64, fp, C.c_int64, C.c_int32, fp, fp, C.c_int32, C.c_float, C.c_int32, C.c_float,
+                                  fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_sample_stats_scratch_floats": (C.c_int64, [C.c_int32]),
+    "sdeh_sample_stats": (C.c_int32, [fp, C.c_int64, C.c_int32, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_reduce_estimators": (C.c_int32, [fp, C.c_int64, C.c_float, fp, fp, C.c_void_p]),
     "sdeh_importance_weights": (C.c_int32, [fp, C.c_int64, fp, fp, C.c_void_p]),
     "sdeh_debug_philox": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, fp, C.c_void_p]),

@@ -15,12 +15,21 @@ namespace sdeh {
 int launch_prep(const PrepArgs& p, hipStream_t stream);
 int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int nb, float* out, hipStream_t stream);
 int launch_weights(const float* rnd, long long n, const float* mx, float* w, hipStream_t stream);
+int launch_sink_init(float* u, float* v, float* log_a, float* log_b, const float* w_x, const float* w_y, long long n,
+                     long long m, float eps, int* flags, hipStream_t st);
+int launch_sink_finalize(const float* pm, const float* ps, int splits, long long np, const float* log_w, float eps, float* pot,
+                         int* err_bits, const int* done, hipStream_t st);
+int launch_sink_check(int* flags, float thresh, hipStream_t st);
+int launch_sink_dist_final(const float* part, int nb, const int* flags, float* out, hipStream_t st);
+int launch_sample_stats(const float* x, const float* w, const float* domain, long long B, int d, float* scratch, int nb,
+                        float* out, hipStream_t st);
 
 #define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv)                           \
   int launch_ws_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                 \
   int launch_legacy_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);             \
   int launch_bwd_dp##dp##_p##pad##_##tag(const BwdArgs& a, hipStream_t stream);                  \
-  int launch_int_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
+  int launch_int_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                  \
+  int launch_sink_dp##dp##_p##pad##_##tag(const SinkArgs& a, int mode, int splits, hipStream_t stream);
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 
@@ -33,10 +42,11 @@ struct Variant {
   TrajLauncher fn_legacy;  // single-wave kernel (sdeh_traj.hpp); returns SDEH_ERR_UNSUPPORTED when not compiled in
   int (*fn_bwd)(const BwdArgs&, hipStream_t);  // control-network backward (sdeh_bwd.hpp), generic variants only
   TrajLauncher fn_int;     // plain Euler integrator (sdeh_integrate.hpp), generic variants only
+  SinkLauncher fn_sink;    // Sinkhorn sweeps (sdeh_sinkhorn.hpp), generic variants only
   const char* name;
 };
 static const Variant kVariants[] = {
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, &launch_int_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, &launch_int_dp##dp##_p##pad##_##tag, &launch_sink_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 };
@@ -509,6 +519,88 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, cons
   rc = plan->variant->fn_int(A, st);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "integrate: kernel launch failed (dp=%d)", plan->variant->dp);
+}
+
+static constexpr int kSinkMaxSplits = 64;
+static constexpr int kStatBlocks = 256;
+
+int64_t sdeh_sinkhorn_workspace_floats(int64_t n, int64_t m) {
+  if (n < 1 || m < 1) return 0;
+  const int64_t mx = n > m ? n : m;
+  return 2 * (n + m) + 2 * (int64_t)kSinkMaxSplits * mx + (mx + 63) / 64 + 16;
+}
+
+int32_t sdeh_sinkhorn(const float* x, int64_t n, const float* y, int64_t m, int32_t d, const float* w_x, const float* w_y,
+                      int32_t p, float eps, int32_t max_iters, float stop_thresh, float* workspace, float* out,
+                      int64_t* corr_x_to_y, int64_t* corr_y_to_x, void* stream) {
+  if (x == nullptr || y == nullptr || workspace == nullptr || out == nullptr) return fail(SDEH_ERR_INVALID, "sinkhorn: null argument");
+  if (n < 1 || m < 1 || d < 1) return fail(SDEH_ERR_INVALID, "sinkhorn: n=%lld m=%lld d=%d", (long long)n, (long long)m, d);
+  if (p != 1 && p != 2) return fail(SDEH_ERR_UNSUPPORTED, "sinkhorn: p=%d (1 and 2 are built in)", p);
+  if (!(eps > 0.0f) || max_iters < 1) return fail(SDEH_ERR_INVALID, "sinkhorn: eps=%g max_iters=%d", eps, max_iters);
+  if ((w_x == nullptr) != (w_y == nullptr)) return fail(SDEH_ERR_INVALID, "sinkhorn: give both weight vectors or neither");
+  const Variant* v = pick_variant(d);
+  if (v == nullptr) return fail(SDEH_ERR_UNSUPPORTED, "sinkhorn: no kernel compiled for dim=%d", d);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t mx = n > m ? n : m;
+  float* u = workspace;
+  float* vv = u + n;
+  float* log_a = vv + m;
+  float* log_b = log_a + n;
+  float* part_m = log_b + m;
+  float* part_s = part_m + (int64_t)kSinkMaxSplits * mx;
+  float* dpart = part_s + (int64_t)kSinkMaxSplits * mx;
+  int* flags = reinterpret_cast<int*>(dpart + (mx + 63) / 64);
+  int rc = launch_sink_init(u, vv, log_a, log_b, w_x, w_y, n, m, eps, flags, st);
+  if (rc != SDEH_OK) return fail(rc, "sinkhorn: init launch failed");
+  SinkArgs A;
+  memset(&A, 0, sizeof(A));
+  A.d = d; A.pnorm = p; A.inv_eps = (float)(1.0 / (double)eps); A.done = flags;
+  A.part_m = part_m; A.part_s = part_s;
+  auto splits_for = [](int64_t np, int64_t nq) {
+    const int64_t rb = (np + 63) / 64, tiles = (nq + 255) / 256;
+    int64_t s = (1024 + rb - 1) / rb;  // aim at >= 1024 workgroups
+    if (s > tiles) s = tiles;
+    if (s > kSinkMaxSplits) s = kSinkMaxSplits;
+    return (int)(s < 1 ? 1 : s);
+  };
+  const int su = splits_for(n, m), sv = splits_for(m, n);
+  for (int it = 0; it < max_iters; ++it) {
+    // u_i = eps (log a_i - LSE_j((v_j - M_ij)/eps))          eval/sinkhorn.py:153-155
+    A.P = x; A.np = n; A.Q = y; A.nq = m; A.pot_q = vv;
+    rc = v->fn_sink(A, 0, su, st);
+    if (rc == SDEH_OK) rc = launch_sink_finalize(part_m, part_s, su, n, log_a, eps, u, flags + 2, flags, st);
+    // v_j = eps (log b_j - LSE_i((u_i - M_ij)/eps))          eval/sinkhorn.py:157-159
+    A.P = y; A.np = m; A.Q = x; A.nq = n; A.pot_q = u;
+    if (rc == SDEH_OK) rc = v->fn_sink(A, 0, sv, st);
+    if (rc == SDEH_OK) rc = launch_sink_finalize(part_m, part_s, sv, m, log_b, eps, vv, flags + 3, flags, st);
+    if (rc == SDEH_OK) rc = launch_sink_check(flags, stop_thresh, st);
+    if (rc != SDEH_OK) return fail(rc, "sinkhorn: iteration %d launch failed", it);
+  }
+  // distance = sum_ij P_ij M_ij (+ argmax of the plan)            eval/sinkhorn.py:169-178
+  A.done = nullptr; A.part_m = nullptr;
+  A.P = x; A.np = n; A.Q = y; A.nq = m; A.pot_q = vv; A.pot_p = u; A.part_s = dpart;
+  A.corr = reinterpret_cast<long long*>(corr_x_to_y);
+  rc = v->fn_sink(A, 1, 1, st);
+  if (rc == SDEH_OK) rc = launch_sink_dist_final(dpart, (int)((n + 63) / 64), flags, out, st);
+  if (rc == SDEH_OK && corr_y_to_x != nullptr) {
+    A.P = y; A.np = m; A.Q = x; A.nq = n; A.pot_q = u; A.pot_p = vv; A.part_s = nullptr;
+    A.corr = reinterpret_cast<long long*>(corr_y_to_x);
+    rc = v->fn_sink(A, 1, 1, st);
+  }
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "sinkhorn: distance launch failed");
+}
+
+int64_t sdeh_sample_stats_scratch_floats(int32_t d) { return d < 1 ? 0 : (int64_t)kStatBlocks * (12 + 3 * (int64_t)d); }
+
+int32_t sdeh_sample_stats(const float* samples, int64_t batch, int32_t d, const float* weights, const float* domain,
+                          float* scratch, float* out, void* stream) {
+  if (samples == nullptr || scratch == nullptr || out == nullptr || batch < 1 || d < 1)
+    return fail(SDEH_ERR_INVALID, "sample_stats: bad argument");
+  if (d > 256) return fail(SDEH_ERR_UNSUPPORTED, "sample_stats: d=%d > 256", d);
+  int64_t nb = (batch + 255) / 256;
+  if (nb > kStatBlocks) nb = kStatBlocks;
+  const int rc = launch_sample_stats(samples, weights, domain, batch, d, scratch, (int)nb, out, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "sample_stats: launch failed");
 }
 
 int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, float* scratch, float* out, void* stream) {

@@ -148,7 +148,23 @@ __host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
   return c;
 }
 
+// sdeh_sinkhorn sweeps (sdeh_sinkhorn.hpp): rows P[np,d] against the cloud Q[nq,d]
+struct SinkArgs {
+  const float* P;
+  const float* Q;
+  const float* pot_q;  // [nq]
+  const float* pot_p;  // [np]  (distance sweep only)
+  float* part_m;       // [splits][np]
+  float* part_s;       // [splits][np];  distance sweep: [row blocks]
+  long long* corr;     // [np] or null
+  const int* done;     // device flag: non-zero = converged, sweeps become no-ops
+  long long np, nq;
+  int d, pnorm;
+  float inv_eps;
+};
+
 // launchers implemented in the per-DP translation units (sdeh_traj_inst.hip)
 typedef int (*TrajLauncher)(const TrajArgs& a, hipStream_t stream);
+typedef int (*SinkLauncher)(const SinkArgs& a, int mode, int splits, hipStream_t stream);
 
 }  // namespace sdeh

@@ -7,6 +7,7 @@
 // which is the fallback for mixtures whose tables do not fit in LDS.
 #include "sdeh_bwd.hpp"
 #include "sdeh_integrate.hpp"
+#include "sdeh_sinkhorn.hpp"
 
 #ifndef SDEH_DP
 #error "compile with -DSDEH_DP=<state dimension>"
@@ -54,6 +55,14 @@ int SDEH_CAT(launch_int_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const TrajA
   return launch_integrate<SDEH_DP, 64, (SDEH_PAD != 0)>(a, stream);
 #else
   (void)a; (void)stream;
+  return SDEH_ERR_UNSUPPORTED;
+#endif
+}
+int SDEH_CAT(launch_sink_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const SinkArgs& a, int mode, int splits, hipStream_t stream) {
+#if SDEH_GENERIC
+  return launch_sink<SDEH_DP, (SDEH_PAD != 0)>(a, mode, splits, stream);
+#else
+  (void)a; (void)mode; (void)splits; (void)stream;
   return SDEH_ERR_UNSUPPORTED;
 #endif
 }

@@ -8,8 +8,16 @@ import torch
 
 GOLDEN_DIR = Path(__file__).parent / "golden"
 _ALL = sorted(glob.glob(str(GOLDEN_DIR / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith("int_")]      # loss-loop fixtures (make_golden.py)
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_"))]  # loss-loop fixtures (make_golden.py)
 GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]      # Euler-integrator fixtures (make_golden_integrator.py)
+GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]  # get_metrics fixtures (make_golden_metrics.py)
+
+
+def load_metrics_fixture(path):
+    fx = np.load(path)
+    meta = json.loads(bytes(fx["meta"]).decode())
+    expected = {tag: json.loads(bytes(fx[f"metrics_{tag}"]).decode()) for tag in ("w", "nw")}
+    return fx, meta, expected
 
 
 def load_fixture(path):

@@ -229,3 +229,30 @@ def test_euler_integrator_has_no_cpu_path():
     assert sde.terminal_t.item() == 1.0 and sde.noise_type == "diagonal"
     with pytest.raises(RuntimeError, match="no CPU path"):
         integ.integrate(sde, ts=torch.linspace(0, 1, 3), x_init=torch.zeros(4, 2))
+
+
+def test_sinkhorn_argument_checks_mirror_the_reference():
+    """Constructor / argument validation of eval/sinkhorn.py:34-60,71-110 (no GPU involved) and the loud CPU refusal."""
+    from sde_sampler_amd.eval.sinkhorn import Sinkhorn
+
+    with pytest.raises(TypeError):
+        Sinkhorn(p=2.0)
+    with pytest.raises(ValueError):
+        Sinkhorn(p=0)
+    with pytest.raises(ValueError):
+        Sinkhorn(eps=0.0)
+    with pytest.raises(TypeError):
+        Sinkhorn(max_iters=0)
+    with pytest.raises(TypeError):
+        Sinkhorn(stop_thresh=1)
+    sk = Sinkhorn()
+    assert (sk.p, sk.eps, sk.max_iters, sk.stop_thresh, sk.n_max) == (2, 1e-3, 100, 1e-5, None)
+    x, y = torch.zeros(4, 2), torch.zeros(5, 3)
+    with pytest.raises(ValueError):
+        sk.compute(x[0], y)
+    with pytest.raises(ValueError):
+        sk.compute(x, y)  # dimension mismatch
+    with pytest.raises(ValueError):
+        sk.compute(x, torch.zeros(5, 2), w_x=torch.ones(4) / 4)  # only one weight vector
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        sk.compute(x, torch.zeros(5, 2))

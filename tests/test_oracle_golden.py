@@ -11,7 +11,8 @@ import torch
 from oracle import em_oracle as eo
 
 _ALL = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith("int_")]
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_"))]
+GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]
 GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]
 assert GOLDEN, "golden fixtures missing"
 
@@ -137,3 +138,23 @@ def test_euler_integrator_bit_exact(path):
                             torch.from_numpy(fx["timesteps"]), noise=torch.from_numpy(fx["noise"]))
     assert xs.shape == fx["xs"].shape
     assert np.array_equal(xs.detach().numpy(), fx["xs"])
+
+
+@pytest.mark.parametrize("path", GOLDEN_METRICS, ids=lambda p: Path(p).stem)
+def test_metrics_oracle_matches_reference(path):
+    """oracle.eval_oracle.metrics_reference_keys vs the reference's get_metrics output (make_golden_metrics.py)."""
+    from oracle import eval_oracle as ev
+    from tests.helpers import load_metrics_fixture
+
+    fx, meta, expected = load_metrics_fixture(path)
+    st = meta["stats"]
+    samples, weights = torch.from_numpy(fx["samples"]), torch.from_numpy(fx["weights"])
+    kw = dict(expectations=st["expectations"], log_norm_const=st["log_norm_const"],
+              stddevs=torch.from_numpy(fx["stddevs"]) if st["has_stddevs"] else None,
+              domain=torch.from_numpy(fx["domain"]) if st["has_domain"] else None, log_norm_const_preds=st["preds"],
+              marginal_dims=[m for m in meta["marginal_dims"] if m < meta["target"]["dim"]])
+    for tag, w in (("w", weights), ("nw", None)):
+        got = ev.metrics_reference_keys(samples, w, **kw)
+        assert set(got) == set(expected[tag]), set(got) ^ set(expected[tag])
+        for k, v in expected[tag].items():
+            assert got[k] == pytest.approx(v, rel=1e-6, abs=1e-9), k

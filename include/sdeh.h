@@ -68,8 +68,10 @@ enum {
   SDEH_FLAG_TERMINAL_TARGET = 16,/* subtract clip(target.unnorm_log_prob(x_T), clip_target) in-kernel (oc.py:225) */
   SDEH_FLAG_TERMINAL_SECOND = 32,/* add second.log_prob(x_T) in-kernel (oc.py:337,449-450) */
   SDEH_FLAG_REFERENCE_CTRL = 64, /* ReferenceSDELoss.reference_ctrl = sigma(t) * prior.score(x) (solver/oc.py:305-306) */
-  SDEH_FLAG_INFERENCE_SDE = 128  /* sdeh_integrate only: the sde was built with generative=False (eq/sdes.py:76-77: sign -1,
+  SDEH_FLAG_INFERENCE_SDE = 128, /* sdeh_integrate only: the sde was built with generative=False (eq/sdes.py:76-77: sign -1,
                                     VP schedule min->max) and ControlledSDE evaluates its ctrl at terminal_t - t (sdes.py:301-303) */
+  SDEH_FLAG_INFERENCE_CTRL = 256 /* TimeReversalLoss.inference_ctrl is set (Bridge, losses/oc.py:189-202): SdehProblem.inference
+                                    describes it; rnd += sigma div_x(v) dt with the EXACT divergence, costs on u + v / u - v */
 };
 
 /* GMM only: scale[k,d] == scale[0,d] for every component k (true for every named mixture of the reference,
@@ -127,6 +129,15 @@ typedef struct {
   SdehTimeEmbed timestep_embed; /* FourierMLP.timestep_embed (num_layers=2, dim_out=C) */
 } SdehFourierMLP;
 
+/* TimeReversalLoss.inference_ctrl (Bridge): ClippedCtrl or LerpPriorCtrl over its own FourierMLP / TimeEmbed
+ * (conf/solver/bridge.yaml, basic_bridge.yaml; built on the solver's generative sde and prior, solver/oc.py:134-140). */
+typedef struct {
+  int32_t ctrl_kind; /* SDEH_CTRL_CLIPPED or SDEH_CTRL_LERP_PRIOR */
+  float clip_model, clip_score, scale_score;
+  SdehFourierMLP base_model;
+  SdehTimeEmbed score_model;
+} SdehInferenceCtrl;
+
 /* One evaluation problem == what the reference loss object + its collaborators hold. */
 typedef struct {
   int32_t loss_kind; /* SdehLossKind */
@@ -146,6 +157,7 @@ typedef struct {
   SdehDensity target;                       /* target (score + terminal log-density) */
   SdehDensity prior;                        /* prior_score of Lerp*Ctrl / reference_ctrl */
   SdehDensity second;                       /* initial_log_prob (DIS) or reference_log_prob (PIS/DDS) density */
+  SdehInferenceCtrl inference;              /* read only with SDEH_FLAG_INFERENCE_CTRL */
 } SdehProblem;
 
 typedef struct {

@@ -24,7 +24,7 @@ Reference lines restated (all relative to /root/reference/sde_sampler):
   distr/gauss.py:123-140,215-223, distr/double_well.py:39-45,165-179, distr/funnel.py:54-80,
   distr/base.py:130-137     -> class Density
   losses/oc.py:50-58,72-123 -> filter_mask(), compute_loss(), compute_results()
-  losses/oc.py:156-230      -> simulate() kind="time_reversal"
+  losses/oc.py:156-230      -> simulate() kind="time_reversal" (incl. the Bridge branch 189-202 with utils/autograd.py:81-105)
   losses/oc.py:286-343      -> simulate() kind="reference_sde"
   losses/oc.py:400-457      -> simulate() kind="exponential"
   solver/oc.py:189-191,243,288-306 -> Problem.second_log_prob / reference_ctrl wiring
@@ -353,6 +353,25 @@ class Ctrl:
 
 
 # ------------------------------------------------------------------------------------------------
+# exact divergence of a control by automatic differentiation (utils/autograd.py:14-22,81-105)
+# ------------------------------------------------------------------------------------------------
+def compute_divx(fn, t: Tensor, x: Tensor, create_graph: bool = True, noise_type=None):
+    if noise_type is not None:
+        raise NotImplementedError("Hutchinson divergence estimators draw their own noise: not restated")
+    requires_grad = x.requires_grad
+    with torch.set_grad_enabled(True):
+        x.requires_grad_(True)
+        outputs = fn(t, x)
+        div = 0.0
+        for i in range(outputs.shape[-1]):
+            div = div + torch.autograd.grad(outputs[:, i].sum(), x, create_graph=create_graph, retain_graph=True)[0][:, i:i + 1]
+    x.requires_grad_(requires_grad)
+    if not torch.is_grad_enabled():
+        outputs = outputs.detach()
+    return div, outputs
+
+
+# ------------------------------------------------------------------------------------------------
 # estimators (losses/oc.py:50-123)
 # ------------------------------------------------------------------------------------------------
 def filter_mask(rnd: Tensor, max_rnd=None) -> Tensor:
@@ -388,7 +407,7 @@ def compute_results(rnd: Tensor, compute_weights: bool) -> dict:
 # the problem = plain-data spec (the JSON stored in each golden fixture) + parameter dict
 # ------------------------------------------------------------------------------------------------
 class Problem:
-    def __init__(self, meta: dict, params: dict, target_tensors: dict | None = None):
+    def __init__(self, meta: dict, params: dict, target_tensors: dict | None = None, params_inf: dict | None = None):
         self.meta = meta
         tspec, pspec = dict(meta["target"]), dict(meta["prior"])
         self.dim = tspec["dim"]
@@ -401,6 +420,11 @@ class Problem:
         self.alpha, self.sigma = lspec.get("alpha"), lspec.get("sigma")
         self.clip_target = meta.get("clip_target")
         self.reference_ctrl = None
+        # Bridge: a second control network whose divergence enters the cost (losses/oc.py:189-202, solver/oc.py:127-143)
+        self.inference_ctrl, self.div_estimator = None, lspec.get("div_estimator")
+        if meta.get("inference_ctrl"):
+            self.inference_ctrl = Ctrl(meta["inference_ctrl"], meta.get("inference_net", meta["net"]), params_inf or {},
+                                       self.sde, self.prior, self.target)
         if self.kind == "time_reversal":
             self.second = self.prior  # initial_log_prob = prior.log_prob
         elif self.kind == "reference_sde":
@@ -454,6 +478,11 @@ class Problem:
                 if kind == "reference_sde" and self.reference_ctrl is not None:  # losses/oc.py:311-317
                     r = self.reference_ctrl(s, x)
                     g_minus, g_plus = u - r, r + u
+                elif kind == "time_reversal" and self.inference_ctrl is not None:  # losses/oc.py:189-202
+                    div, v = compute_divx(self.inference_ctrl, s, x, create_graph=train,
+                                          noise_type=self.div_estimator if train else None)
+                    rnd = rnd + sig * div * dt
+                    g_plus, g_minus = u + v, u - v
                 else:
                     g_minus = g_plus = u
                 if kind == "time_reversal":  # losses/oc.py:204-211
@@ -509,10 +538,11 @@ def problem_from_fixture(fx) -> tuple["Problem", dict]:
 
     meta = json.loads(bytes(fx["meta"]).decode())
     params = {k[len("param/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("param/")}
+    params_inf = {k[len("param_inf/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("param_inf/")}
     tt = None
     if meta["target"]["kind"] == "gmm":
         tt = {k: torch.from_numpy(fx["target/" + k].copy()) for k in ("loc", "scale", "mixture_weights")}
-    return Problem(meta, params, tt), params
+    return Problem(meta, params, tt, params_inf or None), params
 
 
 # ------------------------------------------------------------------------------------------------

@@ -21,7 +21,8 @@ SDE_NONE, SDE_VP, SDE_CONST_OU = 0, 1, 2
 DENS_NONE, DENS_GMM, DENS_DIAG_GAUSS, DENS_MULTI_WELL, DENS_FUNNEL = 0, 1, 2, 3, 4
 ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2
 FLAG_TRAIN, FLAG_ITO, FLAG_CHANGE_SDE_CTRL, FLAG_INIT_LOGP = 1, 2, 4, 8
-FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL, FLAG_INFERENCE_SDE = 16, 32, 64, 128
+FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL = 16, 32, 64
+FLAG_INFERENCE_SDE, FLAG_INFERENCE_CTRL = 128, 256
 INT_LANGEVIN, INT_CONTROLLED = 0, 1
 DENS_FLAG_SHARED_SCALE = 1
 
@@ -57,6 +58,13 @@ class SdehFourierMLP(C.Structure):
     ]
 
 
+class SdehInferenceCtrl(C.Structure):
+    _fields_ = [
+        ("ctrl_kind", C.c_int32), ("clip_model", C.c_float), ("clip_score", C.c_float), ("scale_score", C.c_float),
+        ("base_model", SdehFourierMLP), ("score_model", SdehTimeEmbed),
+    ]
+
+
 class SdehProblem(C.Structure):
     _fields_ = [
         ("loss_kind", C.c_int32), ("ctrl_kind", C.c_int32), ("sde_kind", C.c_int32), ("flags", C.c_int32),
@@ -67,6 +75,7 @@ class SdehProblem(C.Structure):
         ("exp_alpha", C.c_float), ("exp_sigma", C.c_float),
         ("base_model", SdehFourierMLP), ("score_model", SdehTimeEmbed),
         ("target", SdehDensity), ("prior", SdehDensity), ("second", SdehDensity),
+        ("inference", SdehInferenceCtrl),
     ]
 
 

@@ -29,7 +29,8 @@ int launch_sample_stats(const float* x, const float* w, const float* domain, lon
   int launch_legacy_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);             \
   int launch_bwd_dp##dp##_p##pad##_##tag(const BwdArgs& a, hipStream_t stream);                  \
   int launch_int_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                  \
-  int launch_sink_dp##dp##_p##pad##_##tag(const SinkArgs& a, int mode, int splits, hipStream_t stream);
+  int launch_sink_dp##dp##_p##pad##_##tag(const SinkArgs& a, int mode, int splits, hipStream_t stream); \
+  int launch_bridge_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 
@@ -43,10 +44,11 @@ struct Variant {
   int (*fn_bwd)(const BwdArgs&, hipStream_t);  // control-network backward (sdeh_bwd.hpp), generic variants only
   TrajLauncher fn_int;     // plain Euler integrator (sdeh_integrate.hpp), generic variants only
   SinkLauncher fn_sink;    // Sinkhorn sweeps (sdeh_sinkhorn.hpp), generic variants only
+  TrajLauncher fn_bridge;  // TimeReversalLoss with an inference control (sdeh_bridge.hpp), generic variants only
   const char* name;
 };
 static const Variant kVariants[] = {
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, &launch_int_dp##dp##_p##pad##_##tag, &launch_sink_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, &launch_int_dp##dp##_p##pad##_##tag, &launch_sink_dp##dp##_p##pad##_##tag, &launch_bridge_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 };
@@ -95,7 +97,7 @@ static int align4(int v) { return (v + 3) & ~3; }
 // gmm_nv: number of leading coordinates the shared-scale mixture tables cover (multiple of 4; 0 = all)
 // with_bwd: also pack the transposed weights the backward kernel needs (they join the LDS image)
 static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g, bool shared_scale = false,
-                            bool gmm_global = false, int gmm_nv = 0, bool with_bwd = false) {
+                            bool gmm_global = false, int gmm_nv = 0, bool with_bwd = false, bool with_tan = false) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.dp = dp; L.c = c; L.ot = c / 32; L.otd = row_tiles(dp); L.r_in = mregs(dp);
@@ -141,6 +143,11 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   L.emb = o; o += t_max * c;
   L.gam = o; o += align4(t_max * g);
   L.out_cnt = o; o += align4(t_max + 1);
+  L.tan_in = L.tan_out = -1;
+  if (with_tan) {
+    L.tan_in = o; o += dp * c;
+    L.tan_out = o; o += dp * c;
+  }
   if (!L.gmm_lds) {
     L.gmm_lg = o; o += k_rows * L.gmm_row;
     L.gmm_sc = o; o += k_rows * L.gmm_row;
@@ -199,7 +206,8 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   p->desc = *desc;
   p->device = desc->device;
   p->variant = v;
-  p->ws_floats = (size_t)L.total;
+  // twice: the Bridge path packs a second (inference) network + its tangent tables into a second region
+  p->ws_floats = 2 * (size_t)L.total + 2 * (size_t)v->dp * desc->channels + 64;
   p->timing = p->timed = false;
   p->ev0 = p->ev1 = nullptr;
   int prev = 0;
@@ -283,6 +291,7 @@ struct Checked {
   WsLayout L;
   const Variant* v;
   bool refc;
+  int g, k;
 };
 static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, int64_t batch,
                          int64_t row_offset, bool backward, Checked* out, bool integrate = false) {
@@ -313,6 +322,8 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     return fail(SDEH_ERR_INVALID, "simulate_fwd: loss_kind %d", pr->loss_kind);
   if (pr->ctrl_kind < SDEH_CTRL_CLIPPED || pr->ctrl_kind > SDEH_CTRL_LERP_PRIOR)
     return fail(SDEH_ERR_INVALID, "simulate_fwd: ctrl_kind %d", pr->ctrl_kind);
+  if ((pr->flags & SDEH_FLAG_INFERENCE_CTRL) && (backward || integrate || pr->loss_kind != SDEH_LOSS_TIME_REVERSAL))
+    return fail(SDEH_ERR_UNSUPPORTED, "an inference control is only evaluated forward, inside TimeReversalLoss (Bridge)");
   if ((pr->flags & SDEH_FLAG_INFERENCE_SDE) && !integrate)
     return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd: the losses integrate the generative SDE (SDEH_FLAG_INFERENCE_SDE is for sdeh_integrate)");
   if (pr->loss_kind != SDEH_LOSS_EXPONENTIAL && pr->sde_kind == SDEH_SDE_NONE)
@@ -366,7 +377,83 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   out->L = L;
   out->v = v;
   out->refc = refc;
+  out->g = g;
+  out->k = k;
   return SDEH_OK;
+}
+
+// TimeReversalLoss with an inference control (Bridge): two networks, exact divergence by forward-mode tangents
+static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                           int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                           float* x_T, float* rnd, float* xs, void* stream, const Checked& ck) {
+  const SdehInferenceCtrl& inf = pr->inference;
+  const SdehFourierMLP& net = pr->base_model;
+  const SdehFourierMLP& net2 = inf.base_model;
+  const int d = net.dim;
+  if (inf.ctrl_kind != SDEH_CTRL_CLIPPED && inf.ctrl_kind != SDEH_CTRL_LERP_PRIOR)
+    return fail(SDEH_ERR_UNSUPPORTED, "inference control kind %d: ClippedCtrl and LerpPriorCtrl have a built-in divergence", inf.ctrl_kind);
+  if (net2.dim != d || net2.channels != net.channels)
+    return fail(SDEH_ERR_INVALID, "inference control: dim/channels (%d,%d) differ from the generative control's (%d,%d)", net2.dim,
+                net2.channels, d, net.channels);
+  if (net2.n_hidden < 0 || net2.n_hidden > plan->desc.max_hidden)
+    return fail(SDEH_ERR_CAPACITY, "inference control: %d hidden layers > plan max %d", net2.n_hidden, plan->desc.max_hidden);
+  if (net2.activation < SDEH_ACT_GELU_ERF || net2.activation > SDEH_ACT_RELU) return fail(SDEH_ERR_UNSUPPORTED, "inference control: activation %d", net2.activation);
+  if (net2.input_w == nullptr || net2.input_b == nullptr || net2.out_w == nullptr || net2.out_b == nullptr)
+    return fail(SDEH_ERR_INVALID, "inference control: null base_model parameter");
+  for (int i = 0; i < net2.n_hidden; ++i)
+    if (net2.hidden_w[i] == nullptr || net2.hidden_b[i] == nullptr) return fail(SDEH_ERR_INVALID, "inference control: null hidden layer %d", i);
+  int rc = check_time_embed(net2.timestep_embed, net2.channels, "inference base_model.timestep_embed");
+  if (rc != SDEH_OK) return rc;
+  int g2 = 1;
+  if (inf.ctrl_kind == SDEH_CTRL_LERP_PRIOR) {
+    if (pr->prior.kind != SDEH_DENS_DIAG_GAUSS) return fail(SDEH_ERR_UNSUPPORTED, "LerpPriorCtrl inference control needs a Gaussian prior");
+    if (pr->sde_kind == SDEH_SDE_NONE) return fail(SDEH_ERR_INVALID, "Lerp controls need an sde");
+    if (inf.score_model.n_hidden > 0) {
+      rc = check_time_embed(inf.score_model, net2.channels, "inference score_model");
+      if (rc != SDEH_OK) return rc;
+      if (inf.score_model.dim_out != 1 && inf.score_model.dim_out != d)
+        return fail(SDEH_ERR_UNSUPPORTED, "inference score_model.dim_out=%d (1 or dim supported)", inf.score_model.dim_out);
+      g2 = inf.score_model.dim_out == 1 ? 1 : plan->variant->dp;
+    }
+  }
+  const Variant* v = plan->variant;
+  const int dp = v->dp;
+  // single-wave code path: mixture tables in global memory, both packed networks in LDS
+  const WsLayout L1 = make_layout(dp, net.channels, net.n_hidden, n_steps, ck.k, ck.g, false, true);
+  const WsLayout L2 = make_layout(dp, net.channels, net2.n_hidden, n_steps, 0, g2, false, true, 0, false, true);
+  if ((size_t)L1.total + (size_t)L2.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd (bridge): workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = L1; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
+  rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "simulate_fwd (bridge): prep kernel launch failed");
+  PrepArgs P2 = P;  // second region: the inference control's network, time embeddings and gamma table
+  P2.ws = plan->ws + L1.total; P2.lay = L2;
+  P2.prob.ctrl_kind = inf.ctrl_kind; P2.prob.clip_model = inf.clip_model; P2.prob.clip_score = inf.clip_score;
+  P2.prob.scale_score = inf.scale_score; P2.prob.base_model = inf.base_model; P2.prob.score_model = inf.score_model;
+  P2.prob.target.kind = P2.prob.prior.kind = P2.prob.second.kind = SDEH_DENS_NONE;  // the density tables live in region 1
+  rc = launch_prep(P2, st);
+  if (rc != SDEH_OK) return fail(rc, "simulate_fwd (bridge): second prep kernel launch failed");
+  TrajArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = L1; A.ws2 = plan->ws + L1.total; A.lay2 = L2;
+  A.x0 = x0; A.noise = noise; A.xT = x_T; A.rnd = rnd; A.xs = xs;
+  A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d;
+  A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = net.activation;
+  A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score; A.clip_target = pr->clip_target;
+  A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
+  A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
+  A.second = {pr->second.kind, pr->second.n_components, pr->second.log_norm_const, pr->second.p0, pr->second.p1};
+  A.seed = seed; A.offset = offset;
+  A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
+  A.inf_clip_model = inf.clip_model; A.inf_clip_score = inf.clip_score; A.inf_scale_score = inf.scale_score;
+  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  rc = v->fn_bridge(A, st);
+  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  if (rc == SDEH_ERR_UNSUPPORTED)
+    return fail(rc, "simulate_fwd (bridge): two packed networks (+ mixture scratch) exceed 160 KiB of LDS at dim=%d", d);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "simulate_fwd (bridge): kernel launch failed");
 }
 
 int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
@@ -378,6 +465,8 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
   if (rc != SDEH_OK) return rc;
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
+  if (pr->flags & SDEH_FLAG_INFERENCE_CTRL)
+    return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck);
   const WsLayout& L = ck.L;
   const Variant* v = ck.v;
   static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;

@@ -56,6 +56,9 @@ struct WsLayout {
   int emb;        // [T][c]  (M order; FourierMLP.timestep_embed(t) + input_embed.bias)
   int gam;        // [T][g]  clip(score_model(t), clip_model)
   int out_cnt;    // sdeh_integrate: [T+1] ints, out_cnt[i] = number of output times emitted by steps < i
+  // Bridge (forward-mode tangents of the inference network): column j of input_embed.weight and row j of out_layer.weight,
+  // [dp][C] each in accumulator (M) order; -1 when not packed
+  int tan_in, tan_out;
   // GMM tables: rows of `gmm_row` floats (dp rounded up to even pairs, so rows are float4-aligned).  They live
   // inside the LDS image when they fit (gmm_lds = 1: broadcast ds_read_b128, deep VGPR prefetch), else in the
   // global part of the workspace (scalar loads).
@@ -92,6 +95,11 @@ struct TrajArgs {
   // sdeh_integrate only
   int int_kind, n_out;
   const float* ts_out;
+  // Bridge only: the inference control's workspace region (own layout) and attributes
+  const float* ws2;
+  WsLayout lay2;
+  int inf_kind, inf_act;
+  float inf_clip_model, inf_clip_score, inf_scale_score;
 };
 
 struct BwdArgs {

@@ -188,6 +188,13 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
     ws[L.w_out + e] = row < d ? net.out_w[(size_t)row * C + chan] : 0.0f;
   }
   for (int c = gid; c < OTD * 32; c += stride) ws[L.b_out + morder(c)] = c < d ? net.out_b[c] : 0.0f;
+  if (L.tan_in >= 0) {  // forward-mode tangent seeds / read-outs of the Bridge divergence (sdeh_bridge.hpp)
+    for (int e = gid; e < L.dp * C; e += stride) {
+      const int jt = e / C, c = e % C;
+      ws[L.tan_in + jt * C + morder(c)] = jt < d ? net.input_w[(size_t)c * d + jt] : 0.0f;
+      ws[L.tan_out + jt * C + morder(c)] = jt < d ? net.out_w[(size_t)jt * C + c] : 0.0f;
+    }
+  }
   if (L.wt_out >= 0) {  // transposed images for the backward kernel: A operand rows = INPUT channel of the layer
     for (int e = gid; e < L.r_in * OT * 64; e += stride) {  // out_layer^T: k runs over the coordinates
       const int lane = e & 63, ot = (e >> 6) % OT, r = (e >> 6) / OT;

@@ -8,6 +8,7 @@
 #include "sdeh_bwd.hpp"
 #include "sdeh_integrate.hpp"
 #include "sdeh_sinkhorn.hpp"
+#include "sdeh_bridge.hpp"
 
 #ifndef SDEH_DP
 #error "compile with -DSDEH_DP=<state dimension>"
@@ -53,6 +54,14 @@ int SDEH_CAT(launch_bwd_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const BwdAr
 int SDEH_CAT(launch_int_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const TrajArgs& a, hipStream_t stream) {
 #if SDEH_GENERIC
   return launch_integrate<SDEH_DP, 64, (SDEH_PAD != 0)>(a, stream);
+#else
+  (void)a; (void)stream;
+  return SDEH_ERR_UNSUPPORTED;
+#endif
+}
+int SDEH_CAT(launch_bridge_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const TrajArgs& a, hipStream_t stream) {
+#if SDEH_GENERIC
+  return launch_bridge<SDEH_DP, 64, (SDEH_PAD != 0)>(a, stream);
 #else
   (void)a; (void)stream;
   return SDEH_ERR_UNSUPPORTED;

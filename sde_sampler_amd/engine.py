@@ -258,7 +258,7 @@ class TrajectoryEngine:
     def build_problem(self, *, loss_kind: int, generative_ctrl, sde, flags: int, device, keep: _Keep,
                       terminal_target=None, clip_target=None, second=None, reference_prior=None,
                       alpha: float = 0.0, sigma: float = 0.0, allow_inference_sde: bool = False,
-                      dim: int | None = None) -> L.SdehProblem:
+                      dim: int | None = None, inference_ctrl=None) -> L.SdehProblem:
         pr = L.SdehProblem()
         pr.loss_kind, pr.flags = loss_kind, flags
         if generative_ctrl is None:  # sdeh_integrate only: LangevinSDE / bare OU / ControlledSDE(ctrl=None)
@@ -329,6 +329,42 @@ class TrajectoryEngine:
             _fill_density(second, pr.second, keep, device, "initial/reference density")
             if pr.second.kind != L.DENS_DIAG_GAUSS:
                 raise _unsupported("only Gaussian initial/reference densities are fused")
+        if inference_ctrl is not None:  # Bridge: TimeReversalLoss.inference_ctrl (losses/oc.py:189-202)
+            inames = _mro_names(inference_ctrl)
+            ikind = next((_CTRL_KINDS[n] for n in inames if n in _CTRL_KINDS), None)
+            if ikind not in (L.CTRL_CLIPPED, L.CTRL_LERP_PRIOR):
+                raise _unsupported(f"inference_ctrl {type(inference_ctrl).__name__}: the divergence is built in for ClippedCtrl "
+                                   "and LerpPriorCtrl (the reference's Bridge configurations)")
+            if getattr(inference_ctrl, "hard_constrain", False):
+                raise _unsupported("hard_constrain=True (dead code in the reference) is not supported")
+            if getattr(inference_ctrl, "detach_score", False) and ikind == L.CTRL_LERP_PRIOR:
+                raise _unsupported("inference_ctrl.detach_score=True removes the score term from the divergence; "
+                                   "the built-in divergence assumes detach_score=False (conf/solver/bridge.yaml)")
+            inf = pr.inference
+            inf.ctrl_kind = ikind
+            icm, ics = getattr(inference_ctrl, "clip_model", None), getattr(inference_ctrl, "clip_score", None)
+            inf.clip_model = _INF if icm is None else float(icm)
+            inf.clip_score = _INF if ics is None else float(ics)
+            inf.scale_score = float(getattr(inference_ctrl, "scale_score", 1.0))
+            _fill_fourier_mlp(inference_ctrl.base_model, inf.base_model, keep, device)
+            if inf.base_model.dim != dim:
+                raise ValueError(f"inference_ctrl dim {inf.base_model.dim} != generative_ctrl dim {dim}")
+            if ikind == L.CTRL_LERP_PRIOR:
+                ism = getattr(inference_ctrl, "score_model", None)
+                if ism is not None:
+                    _fill_time_embed(ism, inf.score_model, keep, device, "inference score_model")
+                owner = _bound_owner(inference_ctrl.prior_score, "score")
+                if owner is None or not _known_distribution(owner):
+                    raise _unsupported("inference_ctrl.prior_score must be the `.score` of a Gaussian prior")
+                if pr.prior.kind != L.DENS_NONE and owner is not reference_prior:
+                    raise _unsupported("inference_ctrl.prior_score and the generative control use different priors")
+                _fill_density(owner, pr.prior, keep, device, "prior")
+                if pr.prior.kind != L.DENS_DIAG_GAUSS:
+                    raise _unsupported("only Gaussian priors have a fused score")
+                isde = getattr(inference_ctrl, "sde", None)
+                if isde is not None and isde is not sde and not _same_coefficients(isde, sde):
+                    raise _unsupported("inference_ctrl.sde differs from the loss's sde")
+            pr.flags |= L.FLAG_INFERENCE_CTRL
         self._fill_sde(pr, sde, allow_inference_sde)
         pr.exp_alpha, pr.exp_sigma = float(alpha), float(sigma)
         return pr

@@ -146,7 +146,7 @@ class BaseOCLoss:
 
     def _launch(self, ts, x, *, flags: int, terminal_unnorm_log_prob: Callable, second_log_prob: Callable | None,
                 second_at_start: bool, second_at_end: bool, return_traj: bool, noise, reference_prior=None,
-                alpha: float = 0.0, sigma: float = 0.0):
+                alpha: float = 0.0, sigma: float = 0.0, inference_ctrl=None):
         """Common body of the three simulate() methods: fuse what can be fused, call back what cannot."""
         target, clip_target = _resolve_terminal(terminal_unnorm_log_prob)
         second = _resolve_gaussian_log_prob(second_log_prob)
@@ -159,7 +159,7 @@ class BaseOCLoss:
                 flags |= L.FLAG_TERMINAL_SECOND
         problem_kwargs = dict(loss_kind=self._LOSS_KIND, generative_ctrl=self.generative_ctrl, sde=self.sde, flags=flags,
                               terminal_target=target, clip_target=clip_target, second=second,
-                              reference_prior=reference_prior, alpha=alpha, sigma=sigma)
+                              reference_prior=reference_prior, alpha=alpha, sigma=sigma, inference_ctrl=inference_ctrl)
 
         def run(return_traj: bool, want_state: bool = False):
             keep = E._Keep()
@@ -184,7 +184,13 @@ class BaseOCLoss:
             return x_T, rnd, xs
 
         needs_graph = torch.is_grad_enabled() and any(
-            p.requires_grad for p in getattr(self.generative_ctrl, "parameters", lambda: [])())
+            p.requires_grad for mod in (self.generative_ctrl, inference_ctrl)
+            for p in getattr(mod, "parameters", lambda: [])())
+        if needs_graph and inference_ctrl is not None:
+            raise L.SdehUnsupported(
+                -2, "training a Bridge (TimeReversalLoss with an inference control) differentiates the exact divergence "
+                    "(second-order derivatives of the inference network): only the forward / evaluation pass is built "
+                    "(call under torch.no_grad(), or loss.eval)")
         if needs_graph:
             if not (flags & L.FLAG_CHANGE_SDE_CTRL) and (target is None or (second is None and second_log_prob is not None)):
                 raise L.SdehUnsupported(
@@ -208,7 +214,9 @@ class BaseOCLoss:
 
 
 class TimeReversalLoss(BaseOCLoss):
-    """DIS (and, once the divergence term exists, Bridge): reference losses/oc.py:140-278."""
+    """DIS, and Bridge when `inference_ctrl` is given (forward / evaluation: the exact divergence of the inference control per
+    step, losses/oc.py:189-202; `div_estimator` only matters in training, which is not built for Bridge): reference
+    losses/oc.py:140-278."""
 
     _LOSS_KIND = L.LOSS_TIME_REVERSAL
 
@@ -222,16 +230,13 @@ class TimeReversalLoss(BaseOCLoss):
     def simulate(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None = None,
                  train: bool = True, compute_ito_int: bool = False, change_sde_ctrl: bool = False,
                  return_traj: bool = False, *, noise: torch.Tensor | None = None):
-        if self.inference_ctrl is not None:
-            raise L.SdehUnsupported(-2, "TimeReversalLoss with an inference control (Bridge: divergence of the "
-                                        "inference ctrl per step) is not built yet (SURVEY.md 8f row f2)")
         self._check_common(change_sde_ctrl)
         flags = (L.FLAG_TRAIN if train else 0) | (L.FLAG_ITO if compute_ito_int else 0) | \
                 (L.FLAG_CHANGE_SDE_CTRL if change_sde_ctrl else 0)
         with_initial = not (train and self.method in ["kl", "kl_ito"])  # reference 168-172
         return self._launch(ts, x, flags=flags, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
                             second_log_prob=initial_log_prob if with_initial else None, second_at_start=True,
-                            second_at_end=False, return_traj=return_traj, noise=noise)
+                            second_at_end=False, return_traj=return_traj, noise=noise, inference_ctrl=self.inference_ctrl)
 
     def __call__(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None, *, noise=None):
         return self._train_call(ts, x, dict(terminal_unnorm_log_prob=terminal_unnorm_log_prob,

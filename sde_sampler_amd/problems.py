@@ -182,7 +182,8 @@ class Problem:
     ts: torch.Tensor
 
     def to(self, device):
-        for mod in (self.target, self.prior, self.sde, self.ctrl, self.reference_distr):
+        for mod in (self.target, self.prior, self.sde, self.ctrl, self.reference_distr,
+                    getattr(self.loss, "inference_ctrl", None)):
             if isinstance(mod, nn.Module):
                 mod.to(device)
         self.ts = self.ts.to(device)
@@ -195,7 +196,8 @@ class Problem:
                                   compute_weights=compute_weights, return_traj=return_traj, noise=noise)
 
 
-def build(spec: dict, params: dict | None = None, target_tensors: dict | None = None, device=None) -> Problem:
+def build(spec: dict, params: dict | None = None, target_tensors: dict | None = None, device=None,
+          params_inf: dict | None = None) -> Problem:
     spec = copy.deepcopy(spec)
     torch.manual_seed(spec.get("init_seed", 1))  # conf/base.yaml:8
     target = build_target(spec["target"], target_tensors)
@@ -211,7 +213,13 @@ def build(spec: dict, params: dict | None = None, target_tensors: dict | None = 
                   filter_samples=getattr(target, "filter", None))
     reference = None
     if ls["kind"] == "time_reversal":
-        loss = TimeReversalLoss(**common)
+        inference = None
+        if spec.get("inference_ctrl"):  # Bridge (solver/oc.py:127-153): a second control over the same sde / prior / target
+            inference = build_ctrl(spec["inference_ctrl"], spec.get("inference_net", spec["net"]), dim, sde, prior, target)
+            if params_inf is not None:
+                missing, unexpected = inference.load_state_dict(params_inf, strict=False)
+                assert not unexpected and all("timestep_coeff" in m for m in missing), (missing, unexpected)
+        loss = TimeReversalLoss(**common, inference_ctrl=inference, div_estimator=ls.get("div_estimator"))
         second = prior.log_prob
     elif ls["kind"] == "reference_sde":
         if ls.get("reference_ctrl") == "prior_score":

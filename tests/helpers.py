@@ -8,8 +8,9 @@ import torch
 
 GOLDEN_DIR = Path(__file__).parent / "golden"
 _ALL = sorted(glob.glob(str(GOLDEN_DIR / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_"))]  # loss-loop fixtures (make_golden.py)
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_"))]  # loss-loop fixtures (make_golden.py)
 GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]      # Euler-integrator fixtures (make_golden_integrator.py)
+GOLDEN_BRIDGE = [p for p in _ALL if Path(p).name.startswith("bridge_")]    # Bridge fixtures (make_golden_bridge.py)
 GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]  # get_metrics fixtures (make_golden_metrics.py)
 
 
@@ -28,6 +29,10 @@ def load_fixture(path):
     if meta["target"]["kind"] == "gmm":
         tt = {k: torch.from_numpy(fx["target/" + k].copy()) for k in ("loc", "scale", "mixture_weights")}
     return fx, meta, params, tt
+
+
+def inference_params(fx):
+    return {k[len("param_inf/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("param_inf/")}
 
 
 def hip_problem(meta, params, tt, device="cuda:0"):

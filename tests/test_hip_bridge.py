@@ -1,0 +1,58 @@
+"""GPU parity tests of the Bridge branch (TimeReversalLoss with an inference control, reference losses/oc.py:189-202):
+evaluation against the reference's golden vectors on identical noise; training refuses loudly."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN_BRIDGE, inference_params, load_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(path):
+    from sde_sampler_amd import problems
+
+    fx, meta, params, tt = load_fixture(path)
+    prob = problems.build(meta, params, tt, device=DEV, params_inf=inference_params(fx))
+    return fx, meta, prob
+
+
+@pytest.mark.parametrize("path", GOLDEN_BRIDGE, ids=lambda p: Path(p).stem)
+def test_bridge_eval_matches_reference_golden(path):
+    fx, meta, prob = _build(path)
+    x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
+    r1 = prob.eval(x0, compute_weights=True, noise=noise)
+    # the divergence sums d (or 2d) Jacobian entries of magnitude O(1) per step, accumulated over T steps into rnd
+    scale = np.maximum(1.0, np.abs(fx["eval1/rnd"]))
+    assert np.abs(r1.samples.cpu().numpy() - fx["eval1/x_T"]).max() < 2e-3
+    err = np.abs(r1.weights.cpu().numpy() - fx["eval1/weights"])
+    assert (err <= 2e-3 * np.maximum(fx["eval1/weights"], 1e-3)).all(), err.max()
+    assert abs(r1.log_norm_const_preds["log_norm_const_is"] - float(fx["eval1/log_norm_const_is"])) < 1e-3
+    assert abs(r1.log_norm_const_preds["log_norm_const_lb_ito"] - float(fx["eval1/log_norm_const_lb_ito"])) < 1e-3 * scale.max()
+    r2 = prob.eval(x0, compute_weights=False, noise=noise)
+    assert abs(r2.log_norm_const_preds["log_norm_const_lb"] - float(fx["eval2/log_norm_const_lb"])) < 1e-3 * scale.max()
+    # per-row rnd through simulate (train=False, no Ito term)
+    with torch.no_grad():
+        _, rnd, xs = prob.loss.simulate(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, train=False,
+                                        compute_ito_int=False, return_traj=True, noise=noise)
+    assert xs.shape == (prob.ts.numel(), *x0.shape)
+    err = np.abs(rnd.cpu().numpy() - fx["eval2/rnd"])
+    assert (err <= 1e-4 * scale + 1e-3).all(), (err / scale).max()
+
+
+def test_bridge_in_kernel_noise_and_training_refusal():
+    from sde_sampler_amd import SdehUnsupported
+
+    fx, meta, prob = _build([p for p in GOLDEN_BRIDGE if "gmm2" in p][0])
+    torch.manual_seed(0)
+    x0 = prob.prior.sample((4096,))
+    a = prob.eval(x0, compute_weights=True)
+    prob.loss.engine.calls -= 1  # same Philox stream
+    b = prob.eval(x0, compute_weights=True)
+    assert torch.equal(a.samples, b.samples) and torch.equal(a.weights, b.weights)
+    assert torch.isfinite(a.samples).all() and np.isfinite(a.log_norm_const_preds["log_norm_const_is"])
+    with pytest.raises(SdehUnsupported, match="second-order"):
+        prob.loss(prob.ts, x0[:64], prob.target.unnorm_log_prob, prob.second_log_prob)

@@ -11,7 +11,8 @@ import torch
 from oracle import em_oracle as eo
 
 _ALL = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_"))]
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_"))]
+GOLDEN_BRIDGE = [p for p in _ALL if Path(p).name.startswith("bridge_")]
 GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]
 GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]
 assert GOLDEN, "golden fixtures missing"
@@ -158,3 +159,35 @@ def test_metrics_oracle_matches_reference(path):
         assert set(got) == set(expected[tag]), set(got) ^ set(expected[tag])
         for k, v in expected[tag].items():
             assert got[k] == pytest.approx(v, rel=1e-6, abs=1e-9), k
+
+
+@pytest.mark.parametrize("path", GOLDEN_BRIDGE, ids=lambda p: Path(p).stem)
+def test_bridge_branch_bit_exact(path):
+    """TimeReversalLoss with an inference control (losses/oc.py:189-202): evaluation passes, train losses and the parameter
+    gradients of BOTH networks (exact divergence, create_graph=True) against the reference run."""
+    fx, prob, params, ts, x0, noise = load(path)
+    assert prob.inference_ctrl is not None
+    r1 = prob.eval(ts, x0, noise, compute_weights=True)
+    assert np.array_equal(r1["samples"].numpy(), fx["eval1/x_T"])
+    assert np.array_equal(r1["rnd"].numpy(), fx["eval1/rnd"])
+    assert np.array_equal(r1["weights"].numpy(), fx["eval1/weights"])
+    assert r1["log_norm_const_is"] == float(fx["eval1/log_norm_const_is"])
+    assert r1["log_norm_const_lb_ito"] == float(fx["eval1/log_norm_const_lb_ito"])
+    r2 = prob.eval(ts, x0, noise, compute_weights=False)
+    assert np.array_equal(r2["rnd"].numpy(), fx["eval2/rnd"])
+    assert r2["log_norm_const_lb"] == float(fx["eval2/log_norm_const_lb"])
+    pinf = prob.inference_ctrl.p
+    for method in ("kl", "lv"):
+        leaves = [p.requires_grad_(True) for p in list(params.values()) + list(pinf.values())]
+        for p in leaves:
+            p.grad = None
+        loss, _, _, _ = prob.train_loss(ts, x0, noise, method=method)
+        loss.backward()
+        assert loss.item() == float(fx[f"train_{method}/loss"])
+        for prefix, pd in (("grad", params), ("grad_inf", pinf)):
+            for k, p in pd.items():
+                key = f"train_{method}/{prefix}/{k}"
+                if key not in fx.files:
+                    continue
+                g = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+                assert np.array_equal(g, fx[key]), key

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Times the Bridge evaluation kernel (two networks + d forward-mode tangent passes per step) at eval-batch size."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sde_sampler_amd import problems
+
+NET = dict(channels=64, num_layers=4, activation="gelu")
+for name, tspec, B, T in [("basic_bridge gmm-fab d=2", dict(kind="gmm", dim=2, name="fab"), 65536, 100),
+                          ("bridge funnel d=10", dict(kind="funnel", dim=10), 32768, 100)]:
+    d = tspec["dim"]
+    spec = dict(batch=B, target=tspec, prior=dict(kind="iso_gauss", dim=d),
+                sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+                ctrl=dict(kind="lerp_target", clip_model=1e4, clip_score=1e4, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                inference_ctrl=dict(kind="lerp_prior", clip_model=1e4, clip_score=1e4, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                net=NET, loss=dict(kind="time_reversal", method="kl"), grid=dict(start=0.0, end=1.0, steps=T))
+    prob = problems.build(spec, device="cuda:0")
+    x0 = prob.prior.sample((B,))
+    prob.loss.engine.timing = True
+    ms = []
+    for i in range(12):
+        r = prob.eval(x0, compute_weights=False)
+        ms.append(prob.loss.engine.last_kernel_ms())
+    best = min(ms[4:])
+    passes = 1 + 2 * d  # generative MLP + (base + tangent) per coordinate
+    print(f"{name:28s} B={B} T={T} d={d}: kernel {best:8.3f} ms  {B * T / best / 1e6:6.3f} G traj-steps/s  "
+          f"({passes} MLP-widths of MFMA work per step)  lb={r.log_norm_const_preds['log_norm_const_lb']:+.4f}", flush=True)

@@ -2,8 +2,10 @@
 """Times the Bridge evaluation kernel (two networks + d forward-mode tangent passes per step) at eval-batch size."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import time
 import torch
 from sde_sampler_amd import problems
+from oracle import em_oracle as eo
 
 NET = dict(channels=64, num_layers=4, activation="gelu")
 for name, tspec, B, T in [("basic_bridge gmm-fab d=2", dict(kind="gmm", dim=2, name="fab"), 65536, 100),
@@ -23,5 +25,18 @@ for name, tspec, B, T in [("basic_bridge gmm-fab d=2", dict(kind="gmm", dim=2, n
         ms.append(prob.loss.engine.last_kernel_ms())
     best = min(ms[4:])
     passes = 1 + 2 * d  # generative MLP + (base + tangent) per coordinate
+    # CPU oracle (the reference loop restated: d autograd backward passes per step for the divergence), bounded sample
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    tt = None
+    if tspec["kind"] == "gmm":
+        tt = dict(loc=prob.target.loc.cpu(), scale=prob.target.scale.cpu(), mixture_weights=prob.target.mixture_weights.cpu())
+    cpu_params = {k: v.detach().cpu() for k, v in prob.ctrl.state_dict().items()}
+    cpu_inf = {k: v.detach().cpu() for k, v in prob.loss.inference_ctrl.state_dict().items()}
+    oracle = eo.Problem(spec, cpu_params, tt, cpu_inf)
+    nb, ns = 2048, 10
+    t0 = time.perf_counter()
+    oracle.eval(prob.ts[: ns + 1].cpu(), x0[:nb].cpu(), None, compute_weights=False)
+    cpu = nb * ns / (time.perf_counter() - t0)
     print(f"{name:28s} B={B} T={T} d={d}: kernel {best:8.3f} ms  {B * T / best / 1e6:6.3f} G traj-steps/s  "
-          f"({passes} MLP-widths of MFMA work per step)  lb={r.log_norm_const_preds['log_norm_const_lb']:+.4f}", flush=True)
+          f"({passes} MLP-widths of MFMA work per step)  lb={r.log_norm_const_preds['log_norm_const_lb']:+.4f}  | CPU oracle "
+          f"{cpu / 1e3:7.1f} k traj-steps/s ({nb} x {ns} steps, 32 threads) -> x{B * T / best * 1e3 / cpu:,.0f}", flush=True)

@@ -30,7 +30,8 @@ int launch_sample_stats(const float* x, const float* w, const float* domain, lon
   int launch_bwd_dp##dp##_p##pad##_##tag(const BwdArgs& a, hipStream_t stream);                  \
   int launch_int_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                  \
   int launch_sink_dp##dp##_p##pad##_##tag(const SinkArgs& a, int mode, int splits, hipStream_t stream); \
-  int launch_bridge_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);
+  int launch_bridge_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);              \
+  int launch_bridge_bwd_dp##dp##_p##pad##_##tag(const BridgeBwdArgs& a, hipStream_t stream);
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 
@@ -45,10 +46,11 @@ struct Variant {
   TrajLauncher fn_int;     // plain Euler integrator (sdeh_integrate.hpp), generic variants only
   SinkLauncher fn_sink;    // Sinkhorn sweeps (sdeh_sinkhorn.hpp), generic variants only
   TrajLauncher fn_bridge;  // TimeReversalLoss with an inference control (sdeh_bridge.hpp), generic variants only
+  int (*fn_bridge_bwd)(const BridgeBwdArgs&, hipStream_t);  // gradient of the divergence term (sdeh_bridge.hpp)
   const char* name;
 };
 static const Variant kVariants[] = {
-#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, &launch_int_dp##dp##_p##pad##_##tag, &launch_sink_dp##dp##_p##pad##_##tag, &launch_bridge_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
+#define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv) {dp, pad != 0, loss, ctrl, tgt, gmm, act, refc, gnv, &launch_ws_dp##dp##_p##pad##_##tag, &launch_legacy_dp##dp##_p##pad##_##tag, &launch_bwd_dp##dp##_p##pad##_##tag, &launch_int_dp##dp##_p##pad##_##tag, &launch_sink_dp##dp##_p##pad##_##tag, &launch_bridge_dp##dp##_p##pad##_##tag, &launch_bridge_bwd_dp##dp##_p##pad##_##tag, #dp "_" #pad "_" #tag},
 #include "sdeh_variants.inc"
 #undef SDEH_DECL
 };
@@ -206,8 +208,10 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   p->desc = *desc;
   p->device = desc->device;
   p->variant = v;
-  // twice: the Bridge path packs a second (inference) network + its tangent tables into a second region
-  p->ws_floats = 2 * (size_t)L.total + 2 * (size_t)v->dp * desc->channels + 64;
+  // region 1: the largest layout of any call (backward packs transposed weights too); region 2: the Bridge paths pack a
+  // second (inference) network with transposed weights and tangent tables
+  p->ws_floats = (size_t)make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp, false, false, 0, true).total +
+                 (size_t)make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, 0, v->dp, false, true, 0, true, true).total + 64;
   p->timing = p->timed = false;
   p->ev0 = p->ev1 = nullptr;
   int prev = 0;
@@ -385,7 +389,7 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
 // TimeReversalLoss with an inference control (Bridge): two networks, exact divergence by forward-mode tangents
 static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                            int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                           float* x_T, float* rnd, float* xs, void* stream, const Checked& ck) {
+                           float* x_T, float* rnd, float* xs, void* stream, const Checked& ck, float* gp) {
   const SdehInferenceCtrl& inf = pr->inference;
   const SdehFourierMLP& net = pr->base_model;
   const SdehFourierMLP& net2 = inf.base_model;
@@ -448,6 +452,7 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
   A.seed = seed; A.offset = offset;
   A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
   A.inf_clip_model = inf.clip_model; A.inf_clip_score = inf.clip_score; A.inf_scale_score = inf.scale_score;
+  A.gp = gp;
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   rc = v->fn_bridge(A, st);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
@@ -459,14 +464,22 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
 int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                           int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                           float* x_T, float* rnd, float* xs, void* stream) {
+  return sdeh_simulate_fwd_aux(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, nullptr, stream);
+}
+
+int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                              int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                              float* x_T, float* rnd, float* xs, float* gp, void* stream) {
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
+  if (gp != nullptr && (pr == nullptr || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)))
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_aux: the u + v plane only exists for problems with an inference control");
   Checked ck;
   int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, false, &ck);
   if (rc != SDEH_OK) return rc;
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   if (pr->flags & SDEH_FLAG_INFERENCE_CTRL)
-    return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck);
+    return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp);
   const WsLayout& L = ck.L;
   const Variant* v = ck.v;
   static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;
@@ -514,12 +527,71 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
 int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                            int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                            const float* grad_rnd, float* zt, float* dt, float* dout, float* dgam, void* stream) {
+  return sdeh_ctrl_backward_ex(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, nullptr, zt, dt, dout,
+                               dgam, stream);
+}
+
+int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                 int64_t batch, const float* grad_rnd, const float* zt, float* tz, float* ta, float* td,
+                                 float* d2, float* cj, float* dgam, void* stream) {
+  if (plan == nullptr || pr == nullptr || ts == nullptr || xs == nullptr || grad_rnd == nullptr || zt == nullptr || tz == nullptr ||
+      ta == nullptr || td == nullptr || d2 == nullptr || cj == nullptr)
+    return fail(SDEH_ERR_INVALID, "bridge_div_backward: null argument");
+  if (!(pr->flags & SDEH_FLAG_INFERENCE_CTRL)) return fail(SDEH_ERR_INVALID, "bridge_div_backward: the problem has no inference control");
+  if (batch < 1 || n_steps < 1 || n_steps > plan->desc.max_steps) return fail(SDEH_ERR_INVALID, "bridge_div_backward: batch=%lld n_steps=%d", (long long)batch, n_steps);
+  const SdehInferenceCtrl& inf = pr->inference;
+  const SdehFourierMLP& net2 = inf.base_model;
+  const int d = net2.dim;
+  if (d != plan->desc.dim || net2.channels != plan->desc.channels || net2.n_hidden > plan->desc.max_hidden)
+    return fail(SDEH_ERR_CAPACITY, "bridge_div_backward: network geometry differs from the plan's");
+  if (inf.ctrl_kind != SDEH_CTRL_CLIPPED && inf.ctrl_kind != SDEH_CTRL_LERP_PRIOR)
+    return fail(SDEH_ERR_UNSUPPORTED, "bridge_div_backward: inference control kind %d", inf.ctrl_kind);
+  if (inf.ctrl_kind == SDEH_CTRL_LERP_PRIOR && (pr->prior.kind != SDEH_DENS_DIAG_GAUSS || dgam == nullptr))
+    return fail(SDEH_ERR_INVALID, "bridge_div_backward: LerpPriorCtrl needs the Gaussian prior and dgam");
+  int g2 = 1;
+  if (inf.ctrl_kind == SDEH_CTRL_LERP_PRIOR && inf.score_model.n_hidden > 0) g2 = inf.score_model.dim_out == 1 ? 1 : plan->variant->dp;
+  const Variant* v = plan->variant;
+  // region 1: only the per-step coefficients and the prior table are read (no network: ctrl NONE); region 2: the inference network
+  const WsLayout L1 = make_layout(v->dp, net2.channels, 0, n_steps, 0, 1, false, true);
+  const WsLayout L2 = make_layout(v->dp, net2.channels, net2.n_hidden, n_steps, 0, g2, false, true, 0, true, true);
+  if ((size_t)L1.total + (size_t)L2.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "bridge_div_backward: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = L1; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
+  P.prob.ctrl_kind = SDEH_CTRL_NONE; P.prob.target.kind = SDEH_DENS_NONE; P.prob.second.kind = SDEH_DENS_NONE;
+  P.prob.flags &= ~SDEH_FLAG_INFERENCE_SDE;
+  int rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "bridge_div_backward: prep kernel launch failed");
+  PrepArgs P2 = P;
+  P2.prob = *pr;
+  P2.ws = plan->ws + L1.total; P2.lay = L2;
+  P2.prob.ctrl_kind = inf.ctrl_kind; P2.prob.clip_model = inf.clip_model; P2.prob.clip_score = inf.clip_score;
+  P2.prob.scale_score = inf.scale_score; P2.prob.base_model = inf.base_model; P2.prob.score_model = inf.score_model;
+  P2.prob.target.kind = P2.prob.prior.kind = P2.prob.second.kind = SDEH_DENS_NONE;
+  rc = launch_prep(P2, st);
+  if (rc != SDEH_OK) return fail(rc, "bridge_div_backward: second prep kernel launch failed");
+  BridgeBwdArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = L1; A.ws2 = plan->ws + L1.total; A.lay2 = L2;
+  A.xs = xs; A.grad_rnd = grad_rnd; A.zt = zt; A.tz = tz; A.ta = ta; A.td = td; A.d2 = d2; A.cj = cj; A.dgam = dgam;
+  A.batch = batch; A.n_steps = n_steps; A.d = d; A.inf_kind = inf.ctrl_kind; A.act = net2.activation;
+  A.clip_model = inf.clip_model; A.clip_score = inf.clip_score; A.scale_score = inf.scale_score;
+  rc = v->fn_bridge_bwd(A, st);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "bridge_div_backward: kernel launch failed");
+}
+
+int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                              int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                              const float* grad_rnd, const float* gextra, float* zt, float* dt, float* dout, float* dgam,
+                              void* stream) {
   if (xs == nullptr || grad_rnd == nullptr || zt == nullptr || dt == nullptr || dout == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward: null argument");
   Checked ck;
   int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, true, &ck);
   if (rc != SDEH_OK) return rc;
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  if (bptt && gextra != nullptr) return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward_ex: gextra is a row-parallel (lv) input");
   if (bptt && (pr->flags & SDEH_FLAG_INIT_LOGP))
     return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: an initial log-density term with an attached control is not a "
                                       "configuration the reference produces");
@@ -537,7 +609,7 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
   if (rc != SDEH_OK) return fail(rc, "ctrl_backward: prep kernel launch failed");
   BwdArgs A;
   memset(&A, 0, sizeof(A));
-  A.ws = plan->ws; A.lay = L; A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd;
+  A.ws = plan->ws; A.lay = L; A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.gextra = gextra;
   A.zt = zt; A.dt = dt; A.dout = dout; A.dgam = dgam;
   A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = pr->base_model.dim;
   A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = pr->base_model.activation;

@@ -251,6 +251,12 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
     }
     rnd = fmaf(cost, dt, rnd);
     if (!(flags & SDEH_FLAG_TRAIN)) rnd -= cf[CF_DDIV];
+    if (A.gp != nullptr && live) {
+      float* __restrict__ gpp = A.gp + ((long long)i * A.batch + lrow) * d;
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        if (!PAD || j < d) gpp[j] = gp[j];
+    }
 
     // ---- Gaussian draw, Euler-Maruyama step driven by u, Ito term on u + v (losses/oc.py:213-219) --------------------------
     SDEH_FENCE();
@@ -298,6 +304,245 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
     for (int j = 0; j < DP; ++j)
       if (!PAD || j < d) xT[row * d + j] = x[j];
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Gradient of the divergence term w.r.t. the inference network (method "lv": the trajectory is constant in the graph).
+// loss contribution of row n = (t, i):   sum_j c_j J_jj(x_n),   c_j = w_i sigma_t dt_t 1[|v_nn,j| <= clip_model],
+// J_jj = w_out[j] . da_L^j,  da_l^j = act'(z_l) dz_l^j,  dz_{l+1}^j = W_{l+1} da_l^j,  dz_0^j = W_in[:, j].
+// Reverse mode over that forward-mode computation, one tangent at a time:
+//   adj(da_L^j) = c_j w_out[j];   adj(dz_l^j) = act'(z_l) adj(da_l^j);   adj(da_{l-1}^j) = W_l^T adj(dz_l^j)
+//   S_l += act''(z_l) dz_l^j adj(da_l^j)        (how the base pre-activations enter: through act')
+// then ONE base chain  adj(z_L) = S_L,  adj(z_{l-1}) = S_{l-1} + act'(z_{l-1}) W_l^T adj(z_l).
+// All layer quantities go to coordinate-major planes; the weight gradients are GEMMs over N (losses/_autograd.py).
+// ---------------------------------------------------------------------------------------------------------
+template <int DP, int C, bool PAD>
+__global__ __launch_bounds__(256) void bridge_div_bwd_kernel(const BridgeBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
+  const WsLayout& L = A.lay;
+  const WsLayout& L2 = A.lay2;
+  const float* __restrict__ ws = A.ws;
+  const float* __restrict__ ws2 = A.ws2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  {
+    const float4* src = reinterpret_cast<const float4*>(ws2);
+    float4* dst = reinterpret_cast<float4*>(lds);
+    for (int i = tid; i < L2.lds_floats / 4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const long long B = A.batch;
+  const long long tiles_per_t = (B + 63) / 64;
+  const long long tile = (long long)blockIdx.x * 4 + wave;
+  if (tile >= tiles_per_t * A.n_steps) return;
+  const int t = (int)(tile / tiles_per_t);
+  const long long i0 = (tile % tiles_per_t) * 64;
+  const int nrows = (int)(B - i0 < 64 ? B - i0 : 64);
+  const long long N = B * A.n_steps, n0 = (long long)t * B + i0;
+  const bool live = lane < nrows;
+  const long long irow = live ? i0 + lane : B - 1;
+  const int d = PAD ? A.d : DP, act = A.act, Lh = L2.n_hidden;
+  const long long plane = (long long)C * N, pset = (long long)(Lh + 1) * plane;
+  cfp cf = as_const(ws + L.coef + t * kCoefStride);
+  const float sig = cf[CF_SIGMA], dt = cf[CF_DT];
+  const float c0 = live ? A.grad_rnd[irow] * sig * dt : 0.0f;
+
+  // ---- v_nn = out_layer(act(z_L)) for the clamp mask; x for the score part ------------------------------------------
+  float vnn[DP];
+  {
+    f32x16 aA[OT], aB[OT];
+    load_plane<OT>(A.zt + (long long)Lh * plane, N, n0, nrows, lane, aA, aB);
+    activate<OT>(aA, aB, act);
+    f32x16 uA[OTD], uB[OTD];
+#pragma unroll
+    for (int tt = 0; tt < OTD; ++tt) uA[tt] = uB[tt] = load16(lds + L2.b_out + (tt * 2 + h) * 16);
+    const float* w = lds + L2.w_out + lane;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int tt = 0; tt < OTD; ++tt) {
+          const float a = w[((it * 16 + q) * OTD + tt) * 64];
+          uA[tt] = SDEH_MFMA(a, aA[it][q], uA[tt]);
+          uB[tt] = SDEH_MFMA(a, aB[it][q], uB[tt]);
+          if (tt == OTD - 1 && (q & 1)) SDEH_FENCE();
+        }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float v0 = uA[r / 16][r % 16];
+      float v1 = uB[r / 16][r % 16];
+      swap32(v0, v1);
+      vnn[mdim(r, 0)] = v0;
+      if (mdim(r, 1) < DP) vnn[mdim(r, 1)] = v1;
+    }
+  }
+  // ---- score part of the divergence: only gamma(t) carries parameters ----------------------------------------------------
+  if (A.inf_kind == SDEH_CTRL_LERP_PRIOR) {
+    const float w1 = 1.0f - cf[CF_W];
+    cf2p ptab = as_const2(ws + L.dg[1]);
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const float xj = (!PAD || j < d) ? A.xs[((long long)t * B + irow) * d + (PAD ? min(j, d - 1) : j)] : 0.0f;
+      const float sc = w1 * (ptab[j].x - xj) * ptab[j].y;
+      const bool inside = sc >= -A.clip_score && sc <= A.clip_score;
+      const float dsc = (inside && (!PAD || j < d)) ? -(w1 * ptab[j].y) : 0.0f;
+      const float gj = c0 * sig * A.scale_score * dsc;  // d (w_i sigma dt div) / d gamma_j
+      if (L2.g == 1) s += gj;
+      else if ((!PAD || j < d) && live) A.dgam[(long long)j * N + n0 + lane] = gj;
+    }
+    if (L2.g == 1 && live) A.dgam[n0 + lane] = s;
+  }
+
+  // ---- one tangent at a time ---------------------------------------------------------------------------------------
+  for (int jt = 0; jt < d; ++jt) {
+    float vj = 0.0f;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) vj = k == jt ? vnn[k] : vj;
+    const float c = (vj >= -A.clip_model && vj <= A.clip_model) ? c0 : 0.0f;
+    if (live) A.cj[(long long)jt * N + n0 + lane] = c;
+    const float cA = __shfl(c, lane & 31), cB = __shfl(c, 32 + (lane & 31));
+    float* tzj = A.tz + (long long)jt * pset;
+    float* taj = A.ta + (long long)jt * pset;
+    float* tdj = A.td + (long long)jt * pset;
+    // forward: dz_0 = W_in[:, jt];  da_l = act'(z_l) dz_l;  dz_{l+1} = W_{l+1} da_l
+    f32x16 tA[OT], tB[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) tA[ot] = tB[ot] = load16(ws2 + L2.tan_in + jt * C + (ot * 2 + h) * 16);
+    for (int l = 0; l <= Lh; ++l) {
+      f32x16 zA[OT], zB[OT];
+      load_plane<OT>(A.zt + (long long)l * plane, N, n0, nrows, lane, zA, zB);
+      store_plane<OT>(tzj + (long long)l * plane, N, n0, nrows, lane, tA, tB);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          tA[ot][q] *= act_grad(zA[ot][q], act);
+          tB[ot][q] *= act_grad(zB[ot][q], act);
+        }
+      store_plane<OT>(taj + (long long)l * plane, N, n0, nrows, lane, tA, tB);
+      if (l < Lh) {
+        f32x16 nA[OT], nB[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) nA[ot][q] = nB[ot][q] = 0.0f;
+        const float* w = lds + L2.w_hid + l * L2.w_hid_stride + lane;
+#pragma unroll
+        for (int it = 0; it < OT; ++it)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+              const float a = w[((it * 16 + q) * OT + ot) * 64];
+              nA[ot] = SDEH_MFMA(a, tA[it][q], nA[ot]);
+              nB[ot] = SDEH_MFMA(a, tB[it][q], nB[ot]);
+              if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+            }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) { tA[ot] = nA[ot]; tB[ot] = nB[ot]; }
+      }
+    }
+    // reverse: adj(da_L) = c w_out[jt]
+    f32x16 gA[OT], gB[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+      const f32x16 wr = load16(ws2 + L2.tan_out + jt * C + (ot * 2 + h) * 16);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { gA[ot][q] = cA * wr[q]; gB[ot][q] = cB * wr[q]; }
+    }
+    for (int l = Lh; l >= 0; --l) {
+      f32x16 zA[OT], zB[OT], dzA[OT], dzB[OT], sA[OT], sB[OT];
+      load_plane<OT>(A.zt + (long long)l * plane, N, n0, nrows, lane, zA, zB);
+      load_plane<OT>(tzj + (long long)l * plane, N, n0, nrows, lane, dzA, dzB);
+      if (jt > 0) load_plane<OT>(A.d2 + (long long)l * plane, N, n0, nrows, lane, sA, sB);
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float s0 = act_grad2(zA[ot][q], act) * dzA[ot][q] * gA[ot][q];
+          const float s1 = act_grad2(zB[ot][q], act) * dzB[ot][q] * gB[ot][q];
+          sA[ot][q] = jt > 0 ? sA[ot][q] + s0 : s0;
+          sB[ot][q] = jt > 0 ? sB[ot][q] + s1 : s1;
+          gA[ot][q] *= act_grad(zA[ot][q], act);
+          gB[ot][q] *= act_grad(zB[ot][q], act);
+        }
+      store_plane<OT>(A.d2 + (long long)l * plane, N, n0, nrows, lane, sA, sB);
+      store_plane<OT>(tdj + (long long)l * plane, N, n0, nrows, lane, gA, gB);
+      if (l > 0) {
+        f32x16 pA[OT], pB[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) pA[ot][q] = pB[ot][q] = 0.0f;
+        const float* w = lds + L2.wt_hid + (l - 1) * L2.w_hid_stride + lane;
+#pragma unroll
+        for (int it = 0; it < OT; ++it)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+              const float a = w[((it * 16 + q) * OT + ot) * 64];
+              pA[ot] = SDEH_MFMA(a, gA[it][q], pA[ot]);
+              pB[ot] = SDEH_MFMA(a, gB[it][q], pB[ot]);
+              if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+            }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) { gA[ot] = pA[ot]; gB[ot] = pB[ot]; }
+      }
+    }
+  }
+
+  // ---- the base chain: adj(z_{l-1}) = S_{l-1} + act'(z_{l-1}) W_l^T adj(z_l) ------------------------------------------------
+  f32x16 bA[OT], bB[OT];
+  load_plane<OT>(A.d2 + (long long)Lh * plane, N, n0, nrows, lane, bA, bB);
+  for (int l = Lh; l >= 1; --l) {
+    f32x16 pA[OT], pB[OT];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pA[ot][q] = pB[ot][q] = 0.0f;
+    const float* w = lds + L2.wt_hid + (l - 1) * L2.w_hid_stride + lane;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const float a = w[((it * 16 + q) * OT + ot) * 64];
+          pA[ot] = SDEH_MFMA(a, bA[it][q], pA[ot]);
+          pB[ot] = SDEH_MFMA(a, bB[it][q], pB[ot]);
+          if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+        }
+    f32x16 zA[OT], zB[OT];
+    load_plane<OT>(A.zt + (long long)(l - 1) * plane, N, n0, nrows, lane, zA, zB);
+    load_plane<OT>(A.d2 + (long long)(l - 1) * plane, N, n0, nrows, lane, bA, bB);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        bA[ot][q] = fmaf(act_grad(zA[ot][q], act), pA[ot][q], bA[ot][q]);
+        bB[ot][q] = fmaf(act_grad(zB[ot][q], act), pB[ot][q], bB[ot][q]);
+      }
+    store_plane<OT>(A.d2 + (long long)(l - 1) * plane, N, n0, nrows, lane, bA, bB);
+  }
+}
+
+template <int DP, int C, bool PAD>
+int launch_bridge_div_bwd(const BridgeBwdArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = (size_t)a.lay2.lds_floats * sizeof(float);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_div_bwd_kernel<DP, C, PAD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  const long long tiles = ((a.batch + 63) / 64) * a.n_steps;
+  hipLaunchKernelGGL((bridge_div_bwd_kernel<DP, C, PAD>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
 template <int DP, int C, bool PAD>

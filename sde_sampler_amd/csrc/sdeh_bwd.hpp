@@ -49,6 +49,17 @@ __device__ __forceinline__ float act_grad(float v, int act) {
   return v > 0.0f ? 1.0f : 0.0f;
 }
 
+// second derivative of the activation (Bridge: the divergence's dependence on the base pre-activations)
+__device__ __forceinline__ float act_grad2(float v, int act) {
+  if (act == SDEH_ACT_GELU_ERF)  // (Phi + v phi)' = phi (2 - v^2)
+    return 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * v * v) * (2.0f - v * v);
+  if (act == SDEH_ACT_SILU) {  // s' (2 + v (1 - 2 s)),  s = sigmoid(v)
+    const float s = 1.0f / (1.0f + __expf(-v));
+    return s * (1.0f - s) * fmaf(v, 1.0f - 2.0f * s, 2.0f);
+  }
+  return 0.0f;
+}
+
 // store / load one [C][N] plane in the M layout: register q of lane (j,h), row tile ot, column tile A/B is
 // channel 32 ot + rho(q,h) of row n0 + j (+32)
 template <int OT>
@@ -284,8 +295,9 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
   cf2p ptab = as_const2(ws + L.dg[1]);
 #pragma unroll
   for (int j = 0; j < DP; ++j) {
-    if (!BPTT) {  // log-variance: d rnd / d u = dB exactly
+    if (!BPTT) {  // log-variance: d rnd / d u = dB exactly (+ the Bridge cost's u + v for the inference network)
       Gc[j] = wi * c_i * xi[j];
+      if (A.gextra != nullptr) Gc[j] = fmaf(wi * cdt, A.gextra[((long long)t * B + irow) * d + (PAD ? min(j, d - 1) : j)], Gc[j]);
       G[j] = Gc[j];
     } else {
       const float u = clipf(nn[j], A.clip_model) + mfac[j] * clipf(sc[j], A.clip_score);

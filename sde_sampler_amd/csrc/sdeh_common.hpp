@@ -100,6 +100,27 @@ struct TrajArgs {
   WsLayout lay2;
   int inf_kind, inf_act;
   float inf_clip_model, inf_clip_score, inf_scale_score;
+  float* gp;  // [T, B, d] or null: u + v per step (needed by the backward pass of the inference network)
+};
+
+// sdeh_bridge_div_backward (sdeh_bridge.hpp): gradient of  sum_n w_i sigma dt div_x v(x_n)  w.r.t. the inference network
+struct BridgeBwdArgs {
+  const float* ws;   // region 1: per-step coefficients, prior table
+  WsLayout lay;
+  const float* ws2;  // region 2: the inference network (packed + transposed weights, tangent tables, gamma)
+  WsLayout lay2;
+  const float* xs;        // [T+1, B, d]
+  const float* grad_rnd;  // [B]
+  const float* zt;        // [(Lh+1), C, N]  pre-activations of the inference network (from sdeh_ctrl_backward)
+  float* tz;              // [d][(Lh+1), C, N]  tangent pre-activations      d z_l / d x_j
+  float* ta;              // [d][(Lh+1), C, N]  tangent activations          act'(z_l) d z_l / d x_j
+  float* td;              // [d][(Lh+1), C, N]  adjoints of the tangent pre-activations
+  float* d2;              // [(Lh+1), C, N]     adjoints of the base pre-activations (second-order path)
+  float* cj;              // [d, N]             c_j = w_i sigma dt 1[|v_nn,j| <= clip_model]
+  float* dgam;            // [g, N]             d / d gamma(t) of the score part of the divergence
+  long long batch;
+  int n_steps, d, inf_kind, act;
+  float clip_model, clip_score, scale_score;
 };
 
 struct BwdArgs {
@@ -108,6 +129,7 @@ struct BwdArgs {
   const float* xs;        // [T+1, B, d]
   const float* noise;     // [T, B, d] or null (Philox replay)
   const float* grad_rnd;  // [B]
+  const float* gextra;    // [T, B, d] or null: additional d rnd_i / d u_{i,t} = cdt * gextra (Bridge: u + v for the inference net)
   float* zt;              // [(Lh+1), C, N]
   float* dt;              // [(Lh+1), C, N]
   float* dout;            // [d, N]

@@ -67,6 +67,14 @@ int SDEH_CAT(launch_bridge_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const Tr
   return SDEH_ERR_UNSUPPORTED;
 #endif
 }
+int SDEH_CAT(launch_bridge_bwd_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const BridgeBwdArgs& a, hipStream_t stream) {
+#if SDEH_GENERIC
+  return launch_bridge_div_bwd<SDEH_DP, 64, (SDEH_PAD != 0)>(a, stream);
+#else
+  (void)a; (void)stream;
+  return SDEH_ERR_UNSUPPORTED;
+#endif
+}
 int SDEH_CAT(launch_sink_dp, SDEH_DP, _p, SDEH_PAD, _, SDEH_SPECNAME)(const SinkArgs& a, int mode, int splits, hipStream_t stream) {
 #if SDEH_GENERIC
   return launch_sink<SDEH_DP, (SDEH_PAD != 0)>(a, mode, splits, stream);

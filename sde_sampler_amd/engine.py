@@ -435,8 +435,9 @@ class TrajectoryEngine:
 
     # ------------------------------------------------------------------------------------------------------
     def run(self, pr: L.SdehProblem, ts: torch.Tensor, x: torch.Tensor, *, noise: torch.Tensor | None,
-            return_traj: bool, keep: _Keep, row_offset: int = 0, seed: int | None = None):
-        """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None)."""
+            return_traj: bool, keep: _Keep, row_offset: int = 0, seed: int | None = None, want_gp: bool = False):
+        """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None); with `want_gp`
+        (Bridge training) additionally the plane u + v [T,B,d] as a fourth element."""
         if not x.is_cuda:
             raise RuntimeError("the HIP trajectory engine needs CUDA/HIP tensors (got a CPU tensor); "
                                "there is no CPU path in this package")
@@ -461,16 +462,23 @@ class TrajectoryEngine:
         rnd = torch.empty((batch, 1), device=device, dtype=torch.float32)
         xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32) if return_traj else None
         k = pr.target.n_components if pr.target.kind == L.DENS_GMM else 0
-        plan = self._plan(device, dim, pr.base_model.channels, pr.base_model.n_hidden, n_steps, k)
+        n_hidden = pr.base_model.n_hidden
+        if pr.flags & L.FLAG_INFERENCE_CTRL:
+            n_hidden = max(n_hidden, pr.inference.base_model.n_hidden)
+        plan = self._plan(device, dim, pr.base_model.channels, n_hidden, n_steps, k)
         if seed is None:
             seed = torch.initial_seed()
         offset = self.calls
         self.calls += 1
         stream = torch.cuda.current_stream(device).cuda_stream
+        gp = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32) if want_gp else None
         with torch.cuda.device(device):
-            L.check(lib.sdeh_simulate_fwd(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
-                                          seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
-                                          rnd.data_ptr(), None if xs is None else xs.data_ptr(), stream))
+            L.check(lib.sdeh_simulate_fwd_aux(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
+                                              seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
+                                              rnd.data_ptr(), None if xs is None else xs.data_ptr(),
+                                              None if gp is None else gp.data_ptr(), stream))
+        if want_gp:
+            return x_T, rnd, xs, gp
         return x_T, rnd, xs
 
     # ------------------------------------------------------------------------------------------------------

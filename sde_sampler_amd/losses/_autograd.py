@@ -1,11 +1,15 @@
-"""Autograd bridge for training through the fused trajectory kernel (log-variance losses).
+"""Autograd bridge for training through the fused trajectory kernels.
 
 `simulate_with_grad(...)` returns `(x_T, rnd, None)` like `simulate()`, with `rnd` attached to the autograd graph of the
 control network's parameters.  Forward = the HIP trajectory kernel (keeping the trajectory `xs`); backward =
 `sdeh_ctrl_backward` (HIP: per-row re-evaluation + back-propagation on the matrix pipe, noise replayed from the
-Philox counters) followed by plain library GEMMs over the N = T*B rows for the weight gradients and by autograd on the
-two time-only sub-networks' [T, .] tables.  See include/sdeh.h for why this is exact for method = "lv" / "lv_traj"
-(the reference detaches the control that drives the SDE, losses/oc.py:60-70).
+Philox counters; back-propagation through time for method "kl" / "kl_ito") followed by plain library GEMMs over the
+N = T*B rows for the weight gradients and by autograd on the two time-only sub-networks' [T, .] tables.
+
+`simulate_bridge_with_grad(...)` does the same for a Bridge (TimeReversalLoss with an inference control) and the
+log-variance methods: the generative network as above, the inference network through `sdeh_ctrl_backward_ex` (upstream
+gradient (u + v) dt + dB) plus `sdeh_bridge_div_backward` (the divergence term: reverse mode over the forward-mode
+tangents, see include/sdeh.h).
 """
 from __future__ import annotations
 
@@ -19,6 +23,83 @@ from sde_sampler_amd import engine as E
 
 def _ctrl_parameters(ctrl) -> list[torch.nn.Parameter]:
     return [p for p in ctrl.parameters() if p.requires_grad]
+
+
+def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None):
+    """Runs sdeh_ctrl_backward(_ex) for the control in the problem's generative slots; returns the planes."""
+    dev = xs.device
+    T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+    N, Cn, Lh = T * B, pr.base_model.channels, pr.base_model.n_hidden
+    g = 0 if pr.ctrl_kind == L.CTRL_CLIPPED else (pr.score_model.dim_out if pr.score_model.n_hidden > 0 else 1)
+    zt = torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
+    dt = torch.empty_like(zt)
+    dout = torch.empty((d, N), device=dev, dtype=torch.float32)
+    dgam = torch.zeros((max(g, 1), N), device=dev, dtype=torch.float32)
+    plan = engine._plan(dev, d, Cn, Lh, T, pr.target.n_components if pr.target.kind == L.DENS_GMM else 0)
+    noise = st["noise"]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        L.check(L.load().sdeh_ctrl_backward_ex(
+            plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
+            None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
+            w.data_ptr(), None if gextra is None else gextra.data_ptr(), zt.data_ptr(), dt.data_ptr(), dout.data_ptr(),
+            dgam.data_ptr(), stream))
+    return zt, dt, dout, dgam
+
+
+def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, torch.Tensor]:
+    """Parameter gradients of one control from the coordinate-major planes (GEMMs over N; autograd on the [T, .] tables of
+    the two time-only sub-networks).  `extra`: additive second-order contributions of the Bridge divergence term."""
+    base = ctrl.base_model
+    T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+    N, Cn, Lh = T * B, base.channels, len(base.hidden_layer)
+    score_model = getattr(ctrl, "score_model", None)
+    g = 0 if score_model is None else score_model.out_layer.out_features
+    act = base.activation
+    grads: dict[int, torch.Tensor] = {}
+    extra = extra or {}
+    with torch.no_grad():
+        X = xs[:T].reshape(N, d)
+        d0 = dt[0] + extra["d2"][0] if "d2" in extra else dt[0]
+        grads[id(base.input_embed.weight)] = d0 @ X
+        d_emb = d0.reshape(Cn, T, B).sum(dim=2).t().contiguous()  # [T, C]: gradient of the time embedding table
+        grads[id(base.input_embed.bias)] = d_emb.sum(dim=0)
+        for k in range(Lh + 1):
+            a_k = act(zt[k])
+            if k < Lh:
+                lin = base.hidden_layer[k]
+                dk = dt[k + 1] + extra["d2"][k + 1] if "d2" in extra else dt[k + 1]
+                grads[id(lin.weight)] = dk @ a_k.t()
+                grads[id(lin.bias)] = dk.sum(dim=1)
+            else:
+                grads[id(base.out_layer.weight)] = dout @ a_k.t()
+                grads[id(base.out_layer.bias)] = dout.sum(dim=1)
+        if "td" in extra:  # tangent streams of the divergence term, one per coordinate j
+            td, ta, cj = extra["td"], extra["ta"], extra["cj"]
+            for j in range(d):
+                grads[id(base.input_embed.weight)][:, j] += td[j, 0].sum(dim=1)
+                for k in range(Lh):
+                    grads[id(base.hidden_layer[k].weight)] += td[j, k + 1] @ ta[j, k].t()
+                grads[id(base.out_layer.weight)][j] += (ta[j, Lh] * cj[j][None, :]).sum(dim=1)
+    # the two time-only sub-networks: differentiate their [T, .] tables
+    with torch.enable_grad():
+        te_params = [p for p in base.timestep_embed.parameters() if p.requires_grad]
+        if te_params:
+            emb = base.timestep_embed(ts[:-1])
+            for p, gp in zip(te_params, torch.autograd.grad(emb, te_params, d_emb, allow_unused=True)):
+                grads[id(p)] = gp
+        if score_model is not None:
+            sm_params = [p for p in score_model.parameters() if p.requires_grad]
+            if sm_params:
+                gam = score_model(ts[:-1])
+                clip_model = getattr(ctrl, "clip_model", None)
+                if clip_model is not None:
+                    gam = gam.clip(min=-clip_model, max=clip_model)
+                dg = dgam[:g] + extra["dgam"][:g] if "dgam" in extra else dgam[:g]
+                d_gam = dg.reshape(g, T, B).sum(dim=2).t().contiguous()  # [T, g]
+                for p, gp in zip(sm_params, torch.autograd.grad(gam, sm_params, d_gam, allow_unused=True)):
+                    grads[id(p)] = gp
+    return grads
 
 
 class _TrajectoryFn(torch.autograd.Function):
@@ -35,76 +116,87 @@ class _TrajectoryFn(torch.autograd.Function):
     def backward(ctx, _grad_xT, grad_rnd):
         ts, xs = ctx.saved_tensors
         loss, st = ctx.loss, ctx.state
-        ctrl = loss.generative_ctrl
-        base = ctrl.base_model
-        dev = xs.device
-        T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
-        N, Cn, Lh = T * B, base.channels, len(base.hidden_layer)
-        score_model = getattr(ctrl, "score_model", None)
-        g = 0 if score_model is None else score_model.out_layer.out_features
-        zt = torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
-        dt = torch.empty_like(zt)
-        dout = torch.empty((d, N), device=dev, dtype=torch.float32)
-        dgam = torch.empty((max(g, 1), N), device=dev, dtype=torch.float32)
         w = grad_rnd.reshape(-1).contiguous().float()
         keep = E._Keep()
-        pr = loss.engine.build_problem(device=dev, keep=keep, **st["problem_kwargs"])
-        plan = loss.engine._plan(dev, d, Cn, Lh, T, pr.target.n_components if pr.target.kind == L.DENS_GMM else 0)
-        noise = st["noise"]
-        stream = torch.cuda.current_stream(dev).cuda_stream
+        pr = loss.engine.build_problem(device=xs.device, keep=keep, **st["problem_kwargs"])
+        planes = _ctrl_backward(loss.engine, pr, keep, ts, xs, w, st)
+        grads = _weight_grads(loss.generative_ctrl, ts, xs, *planes)
+        return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
+
+
+class _BridgeFn(torch.autograd.Function):
+    """Bridge, log-variance methods: parameters = generative network's, then inference network's."""
+
+    @staticmethod
+    def forward(ctx, loss, launch, ts, x, *params):
+        x_T, rnd, xs, gp, state = launch(return_traj=True, want_state=True, want_gp=True)
+        ctx.loss, ctx.state = loss, state
+        ctx.save_for_backward(ts, xs, gp)
+        ctx.mark_non_differentiable(x_T)
+        return x_T, rnd
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, _grad_xT, grad_rnd):
+        ts, xs, gp = ctx.saved_tensors
+        loss, st = ctx.loss, ctx.state
+        dev = xs.device
+        T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+        N = T * B
+        w = grad_rnd.reshape(-1).contiguous().float()
+        kw = dict(st["problem_kwargs"])
+        inf = kw.pop("inference_ctrl")
+        # generative network: d rnd / d u = dB (the cost's u-derivative vanishes identically for the log-variance form)
+        keep = E._Keep()
+        pr_u = loss.engine.build_problem(device=dev, keep=keep, **kw)
+        grads = _weight_grads(loss.generative_ctrl, ts, xs, *_ctrl_backward(loss.engine, pr_u, keep, ts, xs, w, st))
+        # inference network, first order: d rnd / d v = (u + v) dt + dB
+        keep_v = E._Keep()
+        kw_v = dict(kw, generative_ctrl=inf, terminal_target=None, second=None, clip_target=None,
+                    flags=kw["flags"] & ~(L.FLAG_TERMINAL_TARGET | L.FLAG_INIT_LOGP | L.FLAG_TERMINAL_SECOND))
+        pr_v = loss.engine.build_problem(device=dev, keep=keep_v, **kw_v)
+        zt, dt, dout, dgam = _ctrl_backward(loss.engine, pr_v, keep_v, ts, xs, w, st, gextra=gp)
+        # inference network, divergence term
+        keep_b = E._Keep()
+        pr_b = loss.engine.build_problem(device=dev, keep=keep_b, **st["problem_kwargs"])
+        Cn, Lh = pr_b.inference.base_model.channels, pr_b.inference.base_model.n_hidden
+        g = dgam.shape[0]
+        tz = torch.empty((d, Lh + 1, Cn, N), device=dev, dtype=torch.float32)
+        ta, td = torch.empty_like(tz), torch.empty_like(tz)
+        d2 = torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
+        cj = torch.empty((d, N), device=dev, dtype=torch.float32)
+        dgam2 = torch.zeros((g, N), device=dev, dtype=torch.float32)
+        plan = loss.engine._plan(dev, d, Cn, max(Lh, pr_b.base_model.n_hidden), T, 0)
         with torch.cuda.device(dev):
-            L.check(L.load().sdeh_ctrl_backward(
-                plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
-                None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
-                w.data_ptr(), zt.data_ptr(), dt.data_ptr(), dout.data_ptr(), dgam.data_ptr(), stream))
-        act = base.activation
-        grads: dict[int, torch.Tensor] = {}
-        with torch.no_grad():
-            a_prev = None
-            X = xs[:T].reshape(N, d)
-            grads[id(base.input_embed.weight)] = dt[0] @ X
-            d_emb = dt[0].reshape(Cn, T, B).sum(dim=2).t().contiguous()  # [T, C]: gradient of the time embedding table
-            grads[id(base.input_embed.bias)] = d_emb.sum(dim=0)
-            for k in range(Lh + 1):
-                a_k = act(zt[k])
-                if k < Lh:
-                    lin = base.hidden_layer[k]
-                    grads[id(lin.weight)] = dt[k + 1] @ a_k.t()
-                    grads[id(lin.bias)] = dt[k + 1].sum(dim=1)
-                else:
-                    grads[id(base.out_layer.weight)] = dout @ a_k.t()
-                    grads[id(base.out_layer.bias)] = dout.sum(dim=1)
-        # the two time-only sub-networks: differentiate their [T, .] tables
-        with torch.enable_grad():
-            te_params = [p for p in base.timestep_embed.parameters() if p.requires_grad]
-            if te_params:
-                emb = base.timestep_embed(ts[:-1])
-                for p, gp in zip(te_params, torch.autograd.grad(emb, te_params, d_emb, allow_unused=True)):
-                    grads[id(p)] = gp
-            if score_model is not None:
-                sm_params = [p for p in score_model.parameters() if p.requires_grad]
-                if sm_params:
-                    gam = score_model(ts[:-1])
-                    clip_model = getattr(ctrl, "clip_model", None)
-                    if clip_model is not None:
-                        gam = gam.clip(min=-clip_model, max=clip_model)
-                    d_gam = dgam[:g].reshape(g, T, B).sum(dim=2).t().contiguous()  # [T, g]
-                    for p, gp in zip(sm_params, torch.autograd.grad(gam, sm_params, d_gam, allow_unused=True)):
-                        grads[id(p)] = gp
-        out = tuple(grads.get(id(p)) for p in st["params"])
-        return (None, None, None, None) + out
+            L.check(L.load().sdeh_bridge_div_backward(
+                plan.handle, C.byref(pr_b), keep_b.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B, w.data_ptr(),
+                zt.data_ptr(), tz.data_ptr(), ta.data_ptr(), td.data_ptr(), d2.data_ptr(), cj.data_ptr(), dgam2.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream))
+        grads.update(_weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, td=td, ta=ta, cj=cj, dgam=dgam2)))
+        return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
 
 def simulate_with_grad(loss, launch, ts, x):
     """`launch(return_traj, want_state)` runs the HIP forward; returns (x_T, rnd attached to the parameters, None)."""
     params = _ctrl_parameters(loss.generative_ctrl)
-    holder = {}
 
     def wrapped(return_traj, want_state):
         x_T, rnd, xs, state = launch(return_traj=return_traj, want_state=want_state)
         state["params"] = params
-        holder["state"] = state
         return x_T, rnd, xs, state
 
     x_T, rnd = _TrajectoryFn.apply(loss, wrapped, ts, x, *params)
+    return x_T, rnd, None
+
+
+def simulate_bridge_with_grad(loss, launch, ts, x, inference_ctrl):
+    """Bridge counterpart (methods "lv" / "lv_traj"): `rnd` is attached to the parameters of both networks."""
+    params = _ctrl_parameters(loss.generative_ctrl) + _ctrl_parameters(inference_ctrl)
+
+    def wrapped(return_traj, want_state, want_gp):
+        x_T, rnd, xs, gp, state = launch(return_traj=return_traj, want_state=want_state, want_gp=want_gp)
+        state["params"] = params
+        return x_T, rnd, xs, gp, state
+
+    x_T, rnd = _BridgeFn.apply(loss, wrapped, ts, x, *params)
     return x_T, rnd, None

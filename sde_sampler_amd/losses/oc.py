@@ -161,13 +161,14 @@ class BaseOCLoss:
                               terminal_target=target, clip_target=clip_target, second=second,
                               reference_prior=reference_prior, alpha=alpha, sigma=sigma, inference_ctrl=inference_ctrl)
 
-        def run(return_traj: bool, want_state: bool = False):
+        def run(return_traj: bool, want_state: bool = False, want_gp: bool = False):
             keep = E._Keep()
             pr = self.engine.build_problem(device=x.device, keep=keep, **problem_kwargs)
             offset = self.engine.calls
             seed = torch.initial_seed()
-            x_T, rnd, xs = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
-                                           row_offset=self.row_offset, seed=seed)
+            out = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
+                                  row_offset=self.row_offset, seed=seed, want_gp=want_gp)
+            x_T, rnd, xs = out[:3]
             # user-supplied callables the engine does not recognise are evaluated as given (device tensors in/out)
             if second is None and second_log_prob is not None:
                 if second_at_start:
@@ -180,17 +181,24 @@ class BaseOCLoss:
             if want_state:
                 state = dict(problem_kwargs=problem_kwargs, noise=noise, seed=seed & 0xFFFFFFFFFFFFFFFF, offset=offset,
                              row_offset=self.row_offset)
-                return x_T, rnd, xs, state
+                return (x_T, rnd, xs, out[3], state) if want_gp else (x_T, rnd, xs, state)
             return x_T, rnd, xs
 
         needs_graph = torch.is_grad_enabled() and any(
             p.requires_grad for mod in (self.generative_ctrl, inference_ctrl)
             for p in getattr(mod, "parameters", lambda: [])())
         if needs_graph and inference_ctrl is not None:
-            raise L.SdehUnsupported(
-                -2, "training a Bridge (TimeReversalLoss with an inference control) differentiates the exact divergence "
-                    "(second-order derivatives of the inference network): only the forward / evaluation pass is built "
-                    "(call under torch.no_grad(), or loss.eval)")
+            if not (flags & L.FLAG_CHANGE_SDE_CTRL):
+                raise L.SdehUnsupported(
+                    -2, "training a Bridge with method='kl'/'kl_ito' back-propagates through time through the exact "
+                        "divergence (second-order derivatives w.r.t. the state): built for method='lv'/'lv_traj' only "
+                        "(conf/solver/bridge.yaml); evaluation works under torch.no_grad()")
+            if getattr(self, "div_estimator", None) is not None:
+                raise L.SdehUnsupported(-2, "div_estimator (Hutchinson) is not built: the exact divergence is")
+            from sde_sampler_amd.losses._autograd import simulate_bridge_with_grad
+
+            x_T, rnd, _ = simulate_bridge_with_grad(self, run, ts, x, inference_ctrl)
+            return x_T, rnd, None
         if needs_graph:
             if not (flags & L.FLAG_CHANGE_SDE_CTRL) and (target is None or (second is None and second_log_prob is not None)):
                 raise L.SdehUnsupported(

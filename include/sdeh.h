@@ -231,7 +231,7 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* problem, const flo
                            void* stream);
 
 /*
- * Training a Bridge with method "lv" / "lv_traj" (TimeReversalLoss with an inference control, losses/oc.py:189-206): the
+ * Training a Bridge (TimeReversalLoss with an inference control, losses/oc.py:189-206).  Method "lv" / "lv_traj": the
  * SDE is driven by the detached generative control, so x_t is constant in the graph and, per row n = (t, i),
  *   d rnd / d u = dB                      -> generative network:  sdeh_ctrl_backward on the problem WITHOUT the inference control
  *   d rnd / d v = (u + v) dt + dB         -> inference network:   sdeh_ctrl_backward_ex on a problem whose generative slots
@@ -244,17 +244,27 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* problem, const flo
  *   d2 [(Lh+1), C, N]  adjoint of z_l through the divergence       cj [d, N]  w_i sigma dt 1[|v_nn,j| <= clip_model]
  *   dgam [g, N]        d / d gamma(t) of the score part of the divergence
  * from which the parameter gradients are GEMMs over N (sde_sampler_amd/losses/_autograd.py).
+ *
+ * Method "kl" / "kl_ito" (the generative control drives the SDE: back-propagation through time): the inference network's
+ * gradient does not depend on d loss / d x (v does not drive the SDE), so it is computed row-parallel first -- force the
+ * row-parallel mode by setting SDEH_FLAG_CHANGE_SDE_CTRL in that problem's flags -- together with its own contribution to
+ * d loss / d x_t (dx_out; sdeh_bridge_div_backward ADDS the divergence term's to the same plane); the generative network's
+ * back-propagation through time then takes that plane as lam_extra and the (u + v) plane as cost_ctrl.
+ *   gextra    [T,B,d] or NULL (row-parallel): extra upstream gradient  w_i cdt gextra
+ *   cost_ctrl [T,B,d] or NULL (BPTT): the control entering the running cost instead of u
+ *   lam_extra [T,B,d] or NULL (BPTT): added to d loss / d x_t          dx_out [T,B,d] or NULL (row-parallel): written
  */
 int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                               const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, float* x_T, float* rnd, float* xs, float* gp, void* stream);
 int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                               const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
-                              int64_t row_offset, const float* grad_rnd, const float* gextra, float* zt, float* dt,
-                              float* dout, float* dgam, void* stream);
+                              int64_t row_offset, const float* grad_rnd, const float* gextra, const float* cost_ctrl,
+                              const float* lam_extra, float* dx_out, float* zt, float* dt, float* dout, float* dgam,
+                              void* stream);
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                                  const float* xs, int64_t batch, const float* grad_rnd, const float* zt, float* tz,
-                                 float* ta, float* td, float* d2, float* cj, float* dgam, void* stream);
+                                 float* ta, float* td, float* d2, float* cj, float* dgam, float* dx_accum, void* stream);
 
 /*
  * Batch reductions of BaseOCLoss.compute_results / compute_loss (losses/oc.py:72-123), as mergeable partial

@@ -527,13 +527,13 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float
 int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                            int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                            const float* grad_rnd, float* zt, float* dt, float* dout, float* dgam, void* stream) {
-  return sdeh_ctrl_backward_ex(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, nullptr, zt, dt, dout,
-                               dgam, stream);
+  return sdeh_ctrl_backward_ex(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, nullptr, nullptr,
+                               nullptr, nullptr, zt, dt, dout, dgam, stream);
 }
 
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                                  int64_t batch, const float* grad_rnd, const float* zt, float* tz, float* ta, float* td,
-                                 float* d2, float* cj, float* dgam, void* stream) {
+                                 float* d2, float* cj, float* dgam, float* dx_accum, void* stream) {
   if (plan == nullptr || pr == nullptr || ts == nullptr || xs == nullptr || grad_rnd == nullptr || zt == nullptr || tz == nullptr ||
       ta == nullptr || td == nullptr || d2 == nullptr || cj == nullptr)
     return fail(SDEH_ERR_INVALID, "bridge_div_backward: null argument");
@@ -574,7 +574,7 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const fl
   BridgeBwdArgs A;
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = L1; A.ws2 = plan->ws + L1.total; A.lay2 = L2;
-  A.xs = xs; A.grad_rnd = grad_rnd; A.zt = zt; A.tz = tz; A.ta = ta; A.td = td; A.d2 = d2; A.cj = cj; A.dgam = dgam;
+  A.xs = xs; A.grad_rnd = grad_rnd; A.zt = zt; A.tz = tz; A.ta = ta; A.td = td; A.d2 = d2; A.cj = cj; A.dgam = dgam; A.dx = dx_accum;
   A.batch = batch; A.n_steps = n_steps; A.d = d; A.inf_kind = inf.ctrl_kind; A.act = net2.activation;
   A.clip_model = inf.clip_model; A.clip_score = inf.clip_score; A.scale_score = inf.scale_score;
   rc = v->fn_bridge_bwd(A, st);
@@ -583,15 +583,18 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const fl
 
 int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                               int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                              const float* grad_rnd, const float* gextra, float* zt, float* dt, float* dout, float* dgam,
-                              void* stream) {
+                              const float* grad_rnd, const float* gextra, const float* cost_ctrl, const float* lam_extra,
+                              float* dx_out, float* zt, float* dt, float* dout, float* dgam, void* stream) {
   if (xs == nullptr || grad_rnd == nullptr || zt == nullptr || dt == nullptr || dout == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward: null argument");
   Checked ck;
   int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, true, &ck);
   if (rc != SDEH_OK) return rc;
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
-  if (bptt && gextra != nullptr) return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward_ex: gextra is a row-parallel (lv) input");
+  if (bptt && (gextra != nullptr || dx_out != nullptr))
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_ex: gextra / dx_out belong to the row-parallel mode (SDEH_FLAG_CHANGE_SDE_CTRL)");
+  if (!bptt && (cost_ctrl != nullptr || lam_extra != nullptr))
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_ex: cost_ctrl / lam_extra belong to back-propagation through time");
   if (bptt && (pr->flags & SDEH_FLAG_INIT_LOGP))
     return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: an initial log-density term with an attached control is not a "
                                       "configuration the reference produces");
@@ -610,6 +613,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
   BwdArgs A;
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = L; A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.gextra = gextra;
+  A.cost_ctrl = cost_ctrl; A.lam_extra = lam_extra; A.dx = dx_out;
   A.zt = zt; A.dt = dt; A.dout = dout; A.dgam = dgam;
   A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = pr->base_model.dim;
   A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = pr->base_model.activation;

@@ -527,6 +527,41 @@ __global__ __launch_bounds__(256) void bridge_div_bwd_kernel(const BridgeBwdArgs
       }
     store_plane<OT>(A.d2 + (long long)(l - 1) * plane, N, n0, nrows, lane, bA, bB);
   }
+  // ---- d / d x_t of the divergence term: W_in^T adj(z_0)  (kl: joins the back-propagation through time) ----------------------
+  if (A.dx != nullptr) {
+    f32x16 xA[OTD], xB[OTD];
+#pragma unroll
+    for (int tt = 0; tt < OTD; ++tt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xA[tt][q] = xB[tt][q] = 0.0f;
+    const float* w = lds + L2.wt_in + lane;
+#pragma unroll
+    for (int it = 0; it < OT; ++it)
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int tt = 0; tt < OTD; ++tt) {
+          const float a = w[((it * 16 + q) * OTD + tt) * 64];
+          xA[tt] = SDEH_MFMA(a, bA[it][q], xA[tt]);
+          xB[tt] = SDEH_MFMA(a, bB[it][q], xB[tt]);
+          if (tt == OTD - 1 && (q & 1)) SDEH_FENCE();
+        }
+    float dxv[DP];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float v0 = xA[r / 16][r % 16];
+      float v1 = xB[r / 16][r % 16];
+      swap32(v0, v1);
+      dxv[mdim(r, 0)] = v0;
+      if (mdim(r, 1) < DP) dxv[mdim(r, 1)] = v1;
+    }
+    if (live) {
+      float* __restrict__ row = A.dx + ((long long)t * B + irow) * d;
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        if (!PAD || j < d) row[j] += dxv[j];
+    }
+  }
 }
 
 template <int DP, int C, bool PAD>

@@ -262,7 +262,7 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
 
   // ---- Gaussian draws of this step (replayed) ---------------------------------------------------------------------
   float xi[DP];
-  const bool need_xi = !BPTT || (A.flags & SDEH_FLAG_ITO);
+  const bool need_xi = (A.flags & SDEH_FLAG_ITO) != 0;  // the log-variance methods always carry the Ito term
   if (need_xi) {
     if (A.noise != nullptr) {
       const float* __restrict__ np = A.noise + ((long long)t * B + irow) * d;
@@ -296,13 +296,14 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
 #pragma unroll
   for (int j = 0; j < DP; ++j) {
     if (!BPTT) {  // log-variance: d rnd / d u = dB exactly (+ the Bridge cost's u + v for the inference network)
-      Gc[j] = wi * c_i * xi[j];
+      Gc[j] = (A.flags & SDEH_FLAG_ITO) ? wi * c_i * xi[j] : 0.0f;
       if (A.gextra != nullptr) Gc[j] = fmaf(wi * cdt, A.gextra[((long long)t * B + irow) * d + (PAD ? min(j, d - 1) : j)], Gc[j]);
       G[j] = Gc[j];
     } else {
       const float u = clipf(nn[j], A.clip_model) + mfac[j] * clipf(sc[j], A.clip_score);
       const float r = refc ? sig * (ptab[j].x - x[j]) * ptab[j].y : 0.0f;
-      Gc[j] = wi * fmaf(u - r, cdt, (A.flags & SDEH_FLAG_ITO) ? c_i * xi[j] : 0.0f);
+      const float uc = A.cost_ctrl != nullptr ? A.cost_ctrl[((long long)t * B + irow) * d + (PAD ? min(j, d - 1) : j)] : u - r;
+      Gc[j] = wi * fmaf(uc, cdt, (A.flags & SDEH_FLAG_ITO) ? c_i * xi[j] : 0.0f);
       G[j] = fmaf(c_u, lam[j], Gc[j]);
     }
     if (PAD) { G[j] = j < d ? G[j] : 0.0f; Gc[j] = j < d ? Gc[j] : 0.0f; }
@@ -394,8 +395,9 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
     }
   }
 
-  if constexpr (BPTT) {
+  if (BPTT || A.dx != nullptr) {
     // ---- adjoint update: lambda_t = c_x lambda_{t+1} + W_in^T dZ_0 + (dS/dx)^T G + direct cost terms -----------------------
+    // (row-parallel mode with A.dx: the same quantity without the recursion, written to the plane)
     float dx[DP];
     {
       f32x16 xA[OTD], xB[OTD];
@@ -430,11 +432,16 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
     if (coef_t != 0.0f) target_score_jt<DP>(A.target, ws, L, d, x, cvec, vt);
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
-      float v = fmaf(c_x, lam[j], dx[j]);
+      float v = BPTT ? fmaf(c_x, lam[j], dx[j]) : dx[j];
       if (coef_t != 0.0f) v = fmaf(coef_t, vt[j], v);
       if (coef_p != 0.0f) v = fmaf(-coef_p * ptab[j].y, cvec[j], v);   // Gaussian prior: J = -1/sigma^2
       if (refc) v = fmaf(sig * ptab[j].y, Gc[j], v);                   // cost depends on x through sigma * prior.score(x)
-      lam[j] = (!PAD || j < d) ? v : 0.0f;
+      if (BPTT) {
+        if (A.lam_extra != nullptr) v += A.lam_extra[((long long)t * B + irow) * d + (PAD ? min(j, d - 1) : j)];
+        lam[j] = (!PAD || j < d) ? v : 0.0f;
+      } else if (live && (!PAD || j < d)) {
+        A.dx[((long long)t * B + irow) * d + j] = v;
+      }
     }
   }
 }

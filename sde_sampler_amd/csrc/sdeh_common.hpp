@@ -118,6 +118,7 @@ struct BridgeBwdArgs {
   float* d2;              // [(Lh+1), C, N]     adjoints of the base pre-activations (second-order path)
   float* cj;              // [d, N]             c_j = w_i sigma dt 1[|v_nn,j| <= clip_model]
   float* dgam;            // [g, N]             d / d gamma(t) of the score part of the divergence
+  float* dx;              // [T, B, d] or null: d / d x_t of the divergence term is ADDED to this plane
   long long batch;
   int n_steps, d, inf_kind, act;
   float clip_model, clip_score, scale_score;
@@ -130,6 +131,9 @@ struct BwdArgs {
   const float* noise;     // [T, B, d] or null (Philox replay)
   const float* grad_rnd;  // [B]
   const float* gextra;    // [T, B, d] or null: additional d rnd_i / d u_{i,t} = cdt * gextra (Bridge: u + v for the inference net)
+  const float* cost_ctrl; // [T, B, d] or null (BPTT): the control entering the running cost instead of u (Bridge: u + v)
+  const float* lam_extra; // [T, B, d] or null (BPTT): added to d loss / d x_t (Bridge: the inference network's share)
+  float* dx;              // [T, B, d] or null (row-parallel): d loss / d x_t through this control, written per row
   float* zt;              // [(Lh+1), C, N]
   float* dt;              // [(Lh+1), C, N]
   float* dout;            // [d, N]

@@ -25,8 +25,8 @@ def _ctrl_parameters(ctrl) -> list[torch.nn.Parameter]:
     return [p for p in ctrl.parameters() if p.requires_grad]
 
 
-def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None):
-    """Runs sdeh_ctrl_backward(_ex) for the control in the problem's generative slots; returns the planes."""
+def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None, lam_extra=None, dx_out=None):
+    """Runs sdeh_ctrl_backward_ex for the control in the problem's generative slots; returns the planes."""
     dev = xs.device
     T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
     N, Cn, Lh = T * B, pr.base_model.channels, pr.base_model.n_hidden
@@ -38,12 +38,13 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None):
     plan = engine._plan(dev, d, Cn, Lh, T, pr.target.n_components if pr.target.kind == L.DENS_GMM else 0)
     noise = st["noise"]
     stream = torch.cuda.current_stream(dev).cuda_stream
+    ptr = lambda t: None if t is None else t.data_ptr()
     with torch.cuda.device(dev):
         L.check(L.load().sdeh_ctrl_backward_ex(
             plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
             None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
-            w.data_ptr(), None if gextra is None else gextra.data_ptr(), zt.data_ptr(), dt.data_ptr(), dout.data_ptr(),
-            dgam.data_ptr(), stream))
+            w.data_ptr(), ptr(gextra), ptr(cost_ctrl), ptr(lam_extra), ptr(dx_out), zt.data_ptr(), dt.data_ptr(),
+            dout.data_ptr(), dgam.data_ptr(), stream))
     return zt, dt, dout, dgam
 
 
@@ -125,7 +126,7 @@ class _TrajectoryFn(torch.autograd.Function):
 
 
 class _BridgeFn(torch.autograd.Function):
-    """Bridge, log-variance methods: parameters = generative network's, then inference network's."""
+    """Bridge: parameters = the generative network's, then the inference network's."""
 
     @staticmethod
     def forward(ctx, loss, launch, ts, x, *params):
@@ -146,19 +147,26 @@ class _BridgeFn(torch.autograd.Function):
         w = grad_rnd.reshape(-1).contiguous().float()
         kw = dict(st["problem_kwargs"])
         inf = kw.pop("inference_ctrl")
-        # generative network: d rnd / d u = dB (the cost's u-derivative vanishes identically for the log-variance form)
-        keep = E._Keep()
-        pr_u = loss.engine.build_problem(device=dev, keep=keep, **kw)
-        grads = _weight_grads(loss.generative_ctrl, ts, xs, *_ctrl_backward(loss.engine, pr_u, keep, ts, xs, w, st))
-        # inference network, first order: d rnd / d v = (u + v) dt + dB
+        lv = bool(kw["flags"] & L.FLAG_CHANGE_SDE_CTRL)
+        eng = loss.engine
+
+        def generative(**extra):  # lv: d rnd / d u = dB (the cost's u-derivative vanishes identically); kl: BPTT
+            keep = E._Keep()
+            pr_u = eng.build_problem(device=dev, keep=keep, **kw)
+            return _weight_grads(loss.generative_ctrl, ts, xs, *_ctrl_backward(eng, pr_u, keep, ts, xs, w, st, **extra))
+
+        grads = generative() if lv else None
+        # inference network, first order: d rnd / d v = (u + v) dt (+ dB with the Ito term); v does not drive the SDE, so this is
+        # row-parallel for every method.  kl: its share of d loss / d x_t is collected in `dx` for the generative network's BPTT
+        dx = None if lv else torch.empty((T, B, d), device=dev, dtype=torch.float32)
         keep_v = E._Keep()
-        kw_v = dict(kw, generative_ctrl=inf, terminal_target=None, second=None, clip_target=None,
-                    flags=kw["flags"] & ~(L.FLAG_TERMINAL_TARGET | L.FLAG_INIT_LOGP | L.FLAG_TERMINAL_SECOND))
-        pr_v = loss.engine.build_problem(device=dev, keep=keep_v, **kw_v)
-        zt, dt, dout, dgam = _ctrl_backward(loss.engine, pr_v, keep_v, ts, xs, w, st, gextra=gp)
+        v_flags = (kw["flags"] | L.FLAG_CHANGE_SDE_CTRL) & ~(L.FLAG_TERMINAL_TARGET | L.FLAG_INIT_LOGP | L.FLAG_TERMINAL_SECOND)
+        kw_v = dict(kw, generative_ctrl=inf, terminal_target=None, second=None, clip_target=None, flags=v_flags)
+        pr_v = eng.build_problem(device=dev, keep=keep_v, **kw_v)
+        zt, dt, dout, dgam = _ctrl_backward(eng, pr_v, keep_v, ts, xs, w, st, gextra=gp, dx_out=dx)
         # inference network, divergence term
         keep_b = E._Keep()
-        pr_b = loss.engine.build_problem(device=dev, keep=keep_b, **st["problem_kwargs"])
+        pr_b = eng.build_problem(device=dev, keep=keep_b, **st["problem_kwargs"])
         Cn, Lh = pr_b.inference.base_model.channels, pr_b.inference.base_model.n_hidden
         g = dgam.shape[0]
         tz = torch.empty((d, Lh + 1, Cn, N), device=dev, dtype=torch.float32)
@@ -166,12 +174,14 @@ class _BridgeFn(torch.autograd.Function):
         d2 = torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
         cj = torch.empty((d, N), device=dev, dtype=torch.float32)
         dgam2 = torch.zeros((g, N), device=dev, dtype=torch.float32)
-        plan = loss.engine._plan(dev, d, Cn, max(Lh, pr_b.base_model.n_hidden), T, 0)
+        plan = eng._plan(dev, d, Cn, max(Lh, pr_b.base_model.n_hidden), T, 0)
         with torch.cuda.device(dev):
             L.check(L.load().sdeh_bridge_div_backward(
                 plan.handle, C.byref(pr_b), keep_b.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B, w.data_ptr(),
                 zt.data_ptr(), tz.data_ptr(), ta.data_ptr(), td.data_ptr(), d2.data_ptr(), cj.data_ptr(), dgam2.data_ptr(),
-                torch.cuda.current_stream(dev).cuda_stream))
+                None if dx is None else dx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        if not lv:  # generative network: back-propagation through time with the cost on u + v and the extra d loss / d x_t
+            grads = generative(cost_ctrl=gp, lam_extra=dx)
         grads.update(_weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, td=td, ta=ta, cj=cj, dgam=dgam2)))
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
@@ -190,7 +200,7 @@ def simulate_with_grad(loss, launch, ts, x):
 
 
 def simulate_bridge_with_grad(loss, launch, ts, x, inference_ctrl):
-    """Bridge counterpart (methods "lv" / "lv_traj"): `rnd` is attached to the parameters of both networks."""
+    """Bridge counterpart: `rnd` is attached to the parameters of both networks."""
     params = _ctrl_parameters(loss.generative_ctrl) + _ctrl_parameters(inference_ctrl)
 
     def wrapped(return_traj, want_state, want_gp):

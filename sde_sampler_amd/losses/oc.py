@@ -187,12 +187,11 @@ class BaseOCLoss:
         needs_graph = torch.is_grad_enabled() and any(
             p.requires_grad for mod in (self.generative_ctrl, inference_ctrl)
             for p in getattr(mod, "parameters", lambda: [])())
+        kl_unfused = not (flags & L.FLAG_CHANGE_SDE_CTRL) and (target is None or (second is None and second_log_prob is not None))
         if needs_graph and inference_ctrl is not None:
-            if not (flags & L.FLAG_CHANGE_SDE_CTRL):
-                raise L.SdehUnsupported(
-                    -2, "training a Bridge with method='kl'/'kl_ito' back-propagates through time through the exact "
-                        "divergence (second-order derivatives w.r.t. the state): built for method='lv'/'lv_traj' only "
-                        "(conf/solver/bridge.yaml); evaluation works under torch.no_grad()")
+            if kl_unfused:
+                raise L.SdehUnsupported(-2, "Bridge training with method='kl'/'kl_ito' needs terminal / initial log-densities "
+                                            "of built-in distributions (they are differentiated inside the kernel)")
             if getattr(self, "div_estimator", None) is not None:
                 raise L.SdehUnsupported(-2, "div_estimator (Hutchinson) is not built: the exact divergence is")
             from sde_sampler_amd.losses._autograd import simulate_bridge_with_grad

@@ -54,8 +54,8 @@ def test_bridge_in_kernel_noise_and_training_refusal():
     b = prob.eval(x0, compute_weights=True)
     assert torch.equal(a.samples, b.samples) and torch.equal(a.weights, b.weights)
     assert torch.isfinite(a.samples).all() and np.isfinite(a.log_norm_const_preds["log_norm_const_is"])
-    assert prob.loss.method == "kl"
-    with pytest.raises(SdehUnsupported, match="second-order"):  # kl needs BPTT through the divergence
+    prob.loss.div_estimator = "rademacher"  # Hutchinson estimators only act in training and are not built
+    with pytest.raises(SdehUnsupported, match="div_estimator"):
         prob.loss(prob.ts, x0[:64], prob.target.unnorm_log_prob, prob.second_log_prob)
 
 
@@ -63,25 +63,27 @@ def _rel(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
 
 
+@pytest.mark.parametrize("method", ["lv", "kl"])
 @pytest.mark.parametrize("path", GOLDEN_BRIDGE, ids=lambda p: Path(p).stem)
-def test_bridge_lv_training_gradients_match_reference(path):
-    """loss(...).backward() with method lv: loss value and the parameter gradients of BOTH networks against the reference's
-    autograd (exact divergence with create_graph=True) on identical noise."""
+def test_bridge_training_gradients_match_reference(path, method):
+    """loss(...).backward(): loss value and the parameter gradients of BOTH networks against the reference's autograd (exact
+    divergence with create_graph=True) on identical noise -- lv (row-parallel) and kl (back-propagation through time through
+    both controls and the divergence)."""
     fx, meta, prob = _build(path)
     x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
     loss = prob.loss
-    loss.method, loss.max_rnd = "lv", 1e8
+    loss.method, loss.max_rnd = method, (1e8 if method == "lv" else None)
     ctrl, inf = prob.ctrl, loss.inference_ctrl
     for p in list(ctrl.parameters()) + list(inf.parameters()):
         p.grad = None
     val, _ = loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
     val.backward()
-    ref = float(fx["train_lv/loss"])
+    ref = float(fx[f"train_{method}/loss"])
     assert abs(val.item() - ref) <= 2e-3 * max(1.0, abs(ref)), (val.item(), ref)
     worst = {}
     for prefix, mod in (("grad", ctrl), ("grad_inf", inf)):
         for k, p in mod.named_parameters():
-            key = f"train_lv/{prefix}/{k}"
+            key = f"train_{method}/{prefix}/{k}"
             if key not in fx.files:
                 continue
             g_ref = torch.from_numpy(fx[key])
@@ -90,5 +92,7 @@ def test_bridge_lv_training_gradients_match_reference(path):
                 assert g.abs().max() <= 1e-6, key
                 continue
             worst[key] = _rel(g, g_ref)
-    bad = {k: v for k, v in worst.items() if v > 2e-4}  # measured: <= 5e-6 (profiles/r01_bridge_gradient_parity.txt)
+    # measured: <= 5e-6, except mw5 / kl (active clamps under back-propagation through time): 1.4e-4 (profiles/r01_bridge_gradient_parity.txt)
+    tol = 2e-4 if method == "lv" else 1e-3
+    bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, bad

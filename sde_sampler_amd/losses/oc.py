@@ -221,9 +221,9 @@ class BaseOCLoss:
 
 
 class TimeReversalLoss(BaseOCLoss):
-    """DIS, and Bridge when `inference_ctrl` is given (forward / evaluation: the exact divergence of the inference control per
-    step, losses/oc.py:189-202; `div_estimator` only matters in training, which is not built for Bridge): reference
-    losses/oc.py:140-278."""
+    """DIS, and Bridge when `inference_ctrl` is given (the exact divergence of the inference control per step,
+    losses/oc.py:189-202; evaluation and training with every loss method; the Hutchinson `div_estimator`s, which only act
+    in training, are not built): reference losses/oc.py:140-278."""
 
     _LOSS_KIND = L.LOSS_TIME_REVERSAL
 

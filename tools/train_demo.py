@@ -21,7 +21,15 @@ def main():
     ap.add_argument("--method", default=None)
     ap.add_argument("--lr", type=float, default=5e-3)
     args = ap.parse_args()
-    spec = problems.baseline_spec(args.name)
+    if args.name == "bridge_dw":  # a Bridge (conf/solver/bridge.yaml style) on the shifted double well
+        lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)  # conf/solver/bridge.yaml
+        spec = dict(batch=args.batch, target=dict(kind="double_well", dim=1, separation=2.0, shift=1.5),
+                    prior=dict(kind="iso_gauss", dim=1), sde=dict(kind="scaled_bm", diff_coeff=2.0, terminal_t=1.0),
+                    ctrl=dict(kind="lerp_target", **lerp), inference_ctrl=dict(kind="lerp_prior", **lerp),
+                    net=dict(channels=64, num_layers=4, activation="gelu"),
+                    loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=100))
+    else:
+        spec = problems.baseline_spec(args.name)
     if args.method:
         spec["loss"]["method"] = args.method
     prob = problems.build(spec, device="cuda:0")
@@ -29,7 +37,13 @@ def main():
     if hasattr(prob.target, "compute_stats"):
         prob.target.compute_stats()
     true_logz = prob.target.log_norm_const
-    opt = torch.optim.Adam(prob.ctrl.parameters(), lr=args.lr)
+    train_params = list(prob.ctrl.parameters())
+    groups = [dict(params=train_params, lr=args.lr)]
+    if getattr(prob.loss, "inference_ctrl", None) is not None:  # conf/solver/bridge.yaml: inference_ctrl lr = 0.02 x lr
+        inf_params = list(prob.loss.inference_ctrl.parameters())
+        groups.append(dict(params=inf_params, lr=0.02 * args.lr))
+        train_params = train_params + inf_params
+    opt = torch.optim.Adam(groups)
 
     def evaluate(tag):
         x = prob.prior.sample((16384,))
@@ -48,7 +62,7 @@ def main():
         loss, _ = prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)
         opt.zero_grad(set_to_none=True)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(prob.ctrl.parameters(), 1.0)
+        torch.nn.utils.clip_grad_norm_(train_params, 1.0)
         opt.step()
         if (step + 1) % 100 == 0:
             torch.cuda.synchronize()

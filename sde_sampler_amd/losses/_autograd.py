@@ -48,6 +48,22 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
     return zt, dt, dout, dgam
 
 
+def _nt(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
+    """a [P, N] @ b[Q, N]^T with the long contraction split into chunks (a strided batched GEMM + a sum over the chunks):
+    rocBLAS runs a 64 x 64 x 2e5 product 5-20x faster this way, and a [64, N] @ [N, 1] product 25x
+    (tools/ubench/splitk_gemm.py)."""
+    P, N = a.shape
+    Q = b.shape[0]
+    S = N // chunk
+    if S < 2:
+        return a @ b.t()
+    main = S * chunk
+    out = torch.bmm(a[:, :main].view(P, S, chunk).transpose(0, 1), b[:, :main].view(Q, S, chunk).permute(1, 2, 0)).sum(dim=0)
+    if main < N:
+        out += a[:, main:] @ b[:, main:].t()
+    return out
+
+
 def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, torch.Tensor]:
     """Parameter gradients of one control from the coordinate-major planes (GEMMs over N; autograd on the [T, .] tables of
     the two time-only sub-networks).  `extra`: additive second-order contributions of the Bridge divergence term."""
@@ -60,9 +76,9 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, tor
     grads: dict[int, torch.Tensor] = {}
     extra = extra or {}
     with torch.no_grad():
-        X = xs[:T].reshape(N, d)
+        Xt = xs[:T].reshape(N, d).t().contiguous()  # [d, N]
         d0 = dt[0] + extra["d2"][0] if "d2" in extra else dt[0]
-        grads[id(base.input_embed.weight)] = d0 @ X
+        grads[id(base.input_embed.weight)] = _nt(d0, Xt)
         d_emb = d0.reshape(Cn, T, B).sum(dim=2).t().contiguous()  # [T, C]: gradient of the time embedding table
         grads[id(base.input_embed.bias)] = d_emb.sum(dim=0)
         for k in range(Lh + 1):
@@ -70,17 +86,17 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, tor
             if k < Lh:
                 lin = base.hidden_layer[k]
                 dk = dt[k + 1] + extra["d2"][k + 1] if "d2" in extra else dt[k + 1]
-                grads[id(lin.weight)] = dk @ a_k.t()
+                grads[id(lin.weight)] = _nt(dk, a_k)
                 grads[id(lin.bias)] = dk.sum(dim=1)
             else:
-                grads[id(base.out_layer.weight)] = dout @ a_k.t()
+                grads[id(base.out_layer.weight)] = _nt(dout, a_k)
                 grads[id(base.out_layer.bias)] = dout.sum(dim=1)
         if "td" in extra:  # tangent streams of the divergence term, one per coordinate j
             td, ta, cj = extra["td"], extra["ta"], extra["cj"]
             for j in range(d):
                 grads[id(base.input_embed.weight)][:, j] += td[j, 0].sum(dim=1)
                 for k in range(Lh):
-                    grads[id(base.hidden_layer[k].weight)] += td[j, k + 1] @ ta[j, k].t()
+                    grads[id(base.hidden_layer[k].weight)] += _nt(td[j, k + 1], ta[j, k])
                 grads[id(base.out_layer.weight)][j] += (ta[j, Lh] * cj[j][None, :]).sum(dim=1)
     # the two time-only sub-networks: differentiate their [T, .] tables
     with torch.enable_grad():

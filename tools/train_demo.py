@@ -56,7 +56,7 @@ def main():
         return err
 
     e0 = evaluate("init")
-    t0 = time.perf_counter()
+    t0 = t_last = time.perf_counter()
     for step in range(args.steps):
         x = prob.prior.sample((args.batch,))
         loss, _ = prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)
@@ -66,7 +66,10 @@ def main():
         opt.step()
         if (step + 1) % 100 == 0:
             torch.cuda.synchronize()
-            print(f"step {step + 1}: loss {loss.item():.4f}  ({1e3 * (time.perf_counter() - t0) / (step + 1):.2f} ms/step)", flush=True)
+            now = time.perf_counter()
+            print(f"step {step + 1}: loss {loss.item():.4f}  ({1e3 * (now - t_last) / 100:.2f} ms/step over the last 100 steps, "
+                  f"{1e3 * (now - t0) / (step + 1):.2f} since the start)", flush=True)
+            t_last = now
     e1 = evaluate("trained")
     print(f"RESULT method={spec['loss']['method']} steps={args.steps} err_init={e0:.4f} err_trained={e1:.4f}")
 

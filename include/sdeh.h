@@ -245,6 +245,11 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* problem, const flo
  *   dgam [g, N]        d / d gamma(t) of the score part of the divergence
  * from which the parameter gradients are GEMMs over N (sde_sampler_amd/losses/_autograd.py).
  *
+ * div_noise [n_steps, batch, d] (both entry points; NULL = exact divergence): probe vectors of the Hutchinson estimator
+ * eps^T J eps (TimeReversalLoss.div_estimator = "rademacher" / "gauss", utils/autograd.py:25-42; training only, n_samples = 1;
+ * the caller draws them).  With probes the backward works on ONE tangent (tz, ta, td are [1][(Lh+1), C, N]) and
+ * cj [d, N] = w_i sigma dt eps_j 1[|v_nn,j| <= clip_model].
+ *
  * Method "kl" / "kl_ito" (the generative control drives the SDE: back-propagation through time): the inference network's
  * gradient does not depend on d loss / d x (v does not drive the SDE), so it is computed row-parallel first -- force the
  * row-parallel mode by setting SDEH_FLAG_CHANGE_SDE_CTRL in that problem's flags -- together with its own contribution to
@@ -256,7 +261,8 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* problem, const flo
  */
 int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                               const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
-                              int64_t row_offset, float* x_T, float* rnd, float* xs, float* gp, void* stream);
+                              int64_t row_offset, float* x_T, float* rnd, float* xs, float* gp, const float* div_noise,
+                              void* stream);
 int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                               const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, const float* grad_rnd, const float* gextra, const float* cost_ctrl,
@@ -264,7 +270,8 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* problem, const 
                               void* stream);
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                                  const float* xs, int64_t batch, const float* grad_rnd, const float* zt, float* tz,
-                                 float* ta, float* td, float* d2, float* cj, float* dgam, float* dx_accum, void* stream);
+                                 float* ta, float* td, float* d2, float* cj, float* dgam, float* dx_accum,
+                                 const float* div_noise, void* stream);
 
 /*
  * Batch reductions of BaseOCLoss.compute_results / compute_loss (losses/oc.py:72-123), as mergeable partial

@@ -355,16 +355,28 @@ class Ctrl:
 # ------------------------------------------------------------------------------------------------
 # exact divergence of a control by automatic differentiation (utils/autograd.py:14-22,81-105)
 # ------------------------------------------------------------------------------------------------
-def compute_divx(fn, t: Tensor, x: Tensor, create_graph: bool = True, noise_type=None):
-    if noise_type is not None:
-        raise NotImplementedError("Hutchinson divergence estimators draw their own noise: not restated")
+def compute_divx(fn, t: Tensor, x: Tensor, create_graph: bool = True, noise_type=None, probe: Tensor | None = None):
+    """utils/autograd.py:81-105 (+ _compute_autodiv 14-22, _estimate_autodiv 25-42 with n_samples = 1).  `probe` replaces the
+    estimator's own draw (randint_like * 2 - 1 for "rademacher", randn_like for "gauss")."""
     requires_grad = x.requires_grad
     with torch.set_grad_enabled(True):
         x.requires_grad_(True)
         outputs = fn(t, x)
-        div = 0.0
-        for i in range(outputs.shape[-1]):
-            div = div + torch.autograd.grad(outputs[:, i].sum(), x, create_graph=create_graph, retain_graph=True)[0][:, i:i + 1]
+        if noise_type is None:
+            div = 0.0
+            for i in range(outputs.shape[-1]):
+                div = div + torch.autograd.grad(outputs[:, i].sum(), x, create_graph=create_graph, retain_graph=True)[0][:, i:i + 1]
+        else:
+            if probe is not None:
+                noise = probe
+            elif noise_type == "rademacher":
+                noise = torch.randint_like(outputs, low=0, high=2).float() * 2 - 1.0
+            elif noise_type == "gauss":
+                noise = torch.randn_like(outputs)
+            else:
+                raise NotImplementedError(f"Undefined noise type {noise_type}.")
+            grad = torch.autograd.grad(outputs, x, grad_outputs=noise, create_graph=create_graph)[0]
+            div = 0.0 + (grad * noise).sum(dim=-1, keepdims=True)
     x.requires_grad_(requires_grad)
     if not torch.is_grad_enabled():
         outputs = outputs.detach()
@@ -447,7 +459,7 @@ class Problem:
     # -- the three loops ------------------------------------------------------------------------
     def simulate(self, ts: Tensor, x: Tensor, noise: Tensor | None = None, *, train: bool = False,
                  compute_ito_int: bool = False, change_sde_ctrl: bool = False, return_traj: bool = False,
-                 method: str | None = None):
+                 method: str | None = None, div_noise: Tensor | None = None):
         """Returns (x_T, rnd, xs|None).  `noise[i]` replaces the i-th `randn_like(x)` draw when given."""
         kind, sde, ctrl = self.kind, self.sde, self.ctrl
         method = method or self.method
@@ -480,7 +492,8 @@ class Problem:
                     g_minus, g_plus = u - r, r + u
                 elif kind == "time_reversal" and self.inference_ctrl is not None:  # losses/oc.py:189-202
                     div, v = compute_divx(self.inference_ctrl, s, x, create_graph=train,
-                                          noise_type=self.div_estimator if train else None)
+                                          noise_type=self.div_estimator if train else None,
+                                          probe=None if div_noise is None else div_noise[i])
                     rnd = rnd + sig * div * dt
                     g_plus, g_minus = u + v, u - v
                 else:
@@ -522,12 +535,12 @@ class Problem:
         return out
 
     # -- loss(...) (losses/oc.py:232-256, 345-369, 459-483) ---------------------------------------
-    def train_loss(self, ts, x, noise=None, method=None, traj_per_sample: int = 1):
+    def train_loss(self, ts, x, noise=None, method=None, traj_per_sample: int = 1, div_noise=None):
         method = method or self.method
         if traj_per_sample != 1:
             x = x.repeat(traj_per_sample, 1, 1).reshape(-1, x.shape[-1])
         xT, rnd, _ = self.simulate(ts, x, noise, train=True, compute_ito_int=method != "kl",
-                                   change_sde_ctrl=method in ("lv", "lv_traj"), method=method)
+                                   change_sde_ctrl=method in ("lv", "lv_traj"), method=method, div_noise=div_noise)
         loss, n_filtered = compute_loss(rnd, method, self.max_rnd, traj_per_sample)
         return loss, n_filtered, rnd, xT
 

@@ -389,7 +389,8 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
 // TimeReversalLoss with an inference control (Bridge): two networks, exact divergence by forward-mode tangents
 static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                            int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                           float* x_T, float* rnd, float* xs, void* stream, const Checked& ck, float* gp) {
+                           float* x_T, float* rnd, float* xs, void* stream, const Checked& ck, float* gp,
+                           const float* div_noise) {
   const SdehInferenceCtrl& inf = pr->inference;
   const SdehFourierMLP& net = pr->base_model;
   const SdehFourierMLP& net2 = inf.base_model;
@@ -452,7 +453,7 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
   A.seed = seed; A.offset = offset;
   A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
   A.inf_clip_model = inf.clip_model; A.inf_clip_score = inf.clip_score; A.inf_scale_score = inf.scale_score;
-  A.gp = gp;
+  A.gp = gp; A.div_noise = div_noise;
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   rc = v->fn_bridge(A, st);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
@@ -464,22 +465,23 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
 int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                           int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                           float* x_T, float* rnd, float* xs, void* stream) {
-  return sdeh_simulate_fwd_aux(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, nullptr, stream);
+  return sdeh_simulate_fwd_aux(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, nullptr, nullptr,
+                               stream);
 }
 
 int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                               int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                              float* x_T, float* rnd, float* xs, float* gp, void* stream) {
+                              float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, void* stream) {
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
-  if (gp != nullptr && (pr == nullptr || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)))
-    return fail(SDEH_ERR_INVALID, "simulate_fwd_aux: the u + v plane only exists for problems with an inference control");
+  if ((gp != nullptr || div_noise != nullptr) && (pr == nullptr || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)))
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_aux: gp / div_noise only exist for problems with an inference control");
   Checked ck;
   int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, false, &ck);
   if (rc != SDEH_OK) return rc;
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   if (pr->flags & SDEH_FLAG_INFERENCE_CTRL)
-    return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp);
+    return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise);
   const WsLayout& L = ck.L;
   const Variant* v = ck.v;
   static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;
@@ -533,7 +535,7 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
 
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                                  int64_t batch, const float* grad_rnd, const float* zt, float* tz, float* ta, float* td,
-                                 float* d2, float* cj, float* dgam, float* dx_accum, void* stream) {
+                                 float* d2, float* cj, float* dgam, float* dx_accum, const float* div_noise, void* stream) {
   if (plan == nullptr || pr == nullptr || ts == nullptr || xs == nullptr || grad_rnd == nullptr || zt == nullptr || tz == nullptr ||
       ta == nullptr || td == nullptr || d2 == nullptr || cj == nullptr)
     return fail(SDEH_ERR_INVALID, "bridge_div_backward: null argument");
@@ -574,7 +576,7 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const fl
   BridgeBwdArgs A;
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = L1; A.ws2 = plan->ws + L1.total; A.lay2 = L2;
-  A.xs = xs; A.grad_rnd = grad_rnd; A.zt = zt; A.tz = tz; A.ta = ta; A.td = td; A.d2 = d2; A.cj = cj; A.dgam = dgam; A.dx = dx_accum;
+  A.xs = xs; A.grad_rnd = grad_rnd; A.zt = zt; A.tz = tz; A.ta = ta; A.td = td; A.d2 = d2; A.cj = cj; A.dgam = dgam; A.dx = dx_accum; A.eps = div_noise;
   A.batch = batch; A.n_steps = n_steps; A.d = d; A.inf_kind = inf.ctrl_kind; A.act = net2.activation;
   A.clip_model = inf.clip_model; A.clip_score = inf.clip_score; A.scale_score = inf.scale_score;
   rc = v->fn_bridge_bwd(A, st);

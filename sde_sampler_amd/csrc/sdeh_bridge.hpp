@@ -15,21 +15,29 @@ namespace sdeh {
 
 // FourierMLP value and the tangent of input direction e_jt: out = NN(t, x) (T layout), djj = d NN_jt / d x_jt.
 // tin / tout: column jt of input_embed.weight / row jt of out_layer.weight in accumulator order (WsLayout::tan_in/out).
-template <int DP, int C>
+// VEC (Hutchinson probe, utils/autograd.py:25-42): the tangent direction is the per-trajectory vector `eps` instead of e_jt
+// (seed = W_in eps through the input layer's MFMAs) and the read-out is the whole vector tvec = J eps.
+template <int DP, int C, bool VEC = false>
 __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ lds, const WsLayout& L, int act,
                                                     const float* __restrict__ emb_step, const float* __restrict__ tin,
                                                     const float* __restrict__ tout, const float (&x)[DP],
-                                                    float (&out)[DP], float& djj, int lane) {
+                                                    float (&out)[DP], float& djj, int lane, const float* eps = nullptr,
+                                                    float* tvec = nullptr) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5;
   f32x16 accA[OT], accB[OT], tA[OT], tB[OT];
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot) {
     accA[ot] = accB[ot] = load16(emb_step + (ot * 2 + h) * 16);
-    tA[ot] = tB[ot] = load16(tin + (ot * 2 + h) * 16);  // d z_0 / d x_jt = W_in[:, jt] for every trajectory
+    if constexpr (VEC) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tA[ot][q] = tB[ot][q] = 0.0f;
+    } else {
+      tA[ot] = tB[ot] = load16(tin + (ot * 2 + h) * 16);  // d z_0 / d x_jt = W_in[:, jt] for every trajectory
+    }
   }
   {
-    float xa[R], xb[R];
+    float xa[R], xb[R], ea[R], eb[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float v0 = x[mdim(r, 0)];
@@ -37,6 +45,13 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
       swap32(v0, v1);
       xa[r] = v0;
       xb[r] = v1;
+      if constexpr (VEC) {
+        float e0 = eps[mdim(r, 0)];
+        float e1 = mdim(r, 1) < DP ? eps[mdim(r, 1)] : 0.0f;
+        swap32(e0, e1);
+        ea[r] = e0;
+        eb[r] = e1;
+      }
     }
     const float* w = lds + L.w_in + lane;
 #pragma unroll
@@ -46,10 +61,14 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
         const float a = w[(r * OT + ot) * 64];
         accA[ot] = SDEH_MFMA(a, xa[r], accA[ot]);
         accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
+        if constexpr (VEC) {
+          tA[ot] = SDEH_MFMA(a, ea[r], tA[ot]);
+          tB[ot] = SDEH_MFMA(a, eb[r], tB[ot]);
+        }
         if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
       }
   }
-  f32x16 uA[OTD], uB[OTD];
+  f32x16 uA[OTD], uB[OTD], tuA[VEC ? OTD : 1], tuB[VEC ? OTD : 1];
   float sA = 0.0f, sB = 0.0f;
   for (int l = 0; l <= L.n_hidden; ++l) {
     // a_l = act(z_l);  d a_l = act'(z_l) d z_l
@@ -99,16 +118,26 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
             const float a = w[((it * 16 + q) * OTD + t) * 64];
             uA[t] = SDEH_MFMA(a, accA[it][q], uA[t]);
             uB[t] = SDEH_MFMA(a, accB[it][q], uB[t]);
+            if constexpr (VEC) {
+              if (it == 0 && q == 0) {
+#pragma unroll
+                for (int qq = 0; qq < 16; ++qq) tuA[t][qq] = tuB[t][qq] = 0.0f;
+              }
+              tuA[t] = SDEH_MFMA(a, tA[it][q], tuA[t]);
+              tuB[t] = SDEH_MFMA(a, tB[it][q], tuB[t]);
+            }
             if (t == OTD - 1 && (q & 1)) SDEH_FENCE();
           }
-      // read-out of the tangent: row jt of out_layer.weight . d a_last (this lane holds 32 of the 64 channels per tile)
+      if constexpr (!VEC) {
+        // read-out of the tangent: row jt of out_layer.weight . d a_last (this lane holds 32 of the 64 channels per tile)
 #pragma unroll
-      for (int ot = 0; ot < OT; ++ot) {
-        const f32x16 wr = load16(tout + (ot * 2 + h) * 16);
+        for (int ot = 0; ot < OT; ++ot) {
+          const f32x16 wr = load16(tout + (ot * 2 + h) * 16);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          sA = fmaf(wr[q], tA[ot][q], sA);
-          sB = fmaf(wr[q], tB[ot][q], sB);
+          for (int q = 0; q < 16; ++q) {
+            sA = fmaf(wr[q], tA[ot][q], sA);
+            sB = fmaf(wr[q], tB[ot][q], sB);
+          }
         }
       }
     }
@@ -120,11 +149,20 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
     swap32(v0, v1);
     out[mdim(r, 0)] = v0;
     if (mdim(r, 1) < DP) out[mdim(r, 1)] = v1;
+    if constexpr (VEC) {
+      float t0 = tuA[r / 16][r % 16];
+      float t1 = tuB[r / 16][r % 16];
+      swap32(t0, t1);
+      tvec[mdim(r, 0)] = t0;
+      if (mdim(r, 1) < DP) tvec[mdim(r, 1)] = t1;
+    }
   }
-  // the other lane half holds the remaining channels of the same trajectory column
-  sA += __shfl_xor(sA, 32);
-  sB += __shfl_xor(sB, 32);
-  djj = lane < 32 ? sA : sB;  // T layout: lane = trajectory (tile A: 0..31, tile B: 32..63)
+  if constexpr (!VEC) {
+    // the other lane half holds the remaining channels of the same trajectory column
+    sA += __shfl_xor(sA, 32);
+    sB += __shfl_xor(sB, 32);
+    djj = lane < 32 ? sA : sB;  // T layout: lane = trajectory (tile A: 0..31, tile B: 32..63)
+  }
 }
 
 template <int DP, int C, bool PAD>
@@ -202,6 +240,22 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
     // ---- inference control v and its exact divergence ------------------------------------------------------------------
     float v[DP];
     float div = 0.0f;
+    float eps2[DP];  // eps_j^2 (Hutchinson) or 1: weight of the score term's diagonal derivative
+#pragma unroll
+    for (int j = 0; j < DP; ++j) eps2[j] = 1.0f;
+    if (A.div_noise != nullptr) {  // Hutchinson estimate eps^T J eps with the given probe vectors (utils/autograd.py:25-42)
+      float eps[DP], tv[DP], dummy;
+      const float* __restrict__ ep = A.div_noise + ((long long)i * A.batch + lrow) * d;
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        eps[j] = (!PAD || j < d) ? ep[PAD ? min(j, d - 1) : j] : 0.0f;
+        eps2[j] = eps[j] * eps[j];
+      }
+      mlp_forward_tangent<DP, C, true>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, nullptr, nullptr, x, v, dummy, lane, eps, tv);
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        div += (v[j] >= -A.inf_clip_model && v[j] <= A.inf_clip_model) ? eps[j] * tv[j] : 0.0f;
+    } else
     for (int jt = 0; jt < d; ++jt) {  // one forward-mode tangent per coordinate
       float djj;
       mlp_forward_tangent<DP, C>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, ws2 + L2.tan_in + jt * C,
@@ -224,7 +278,7 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
         const bool inside = sc >= -A.inf_clip_score && sc <= A.inf_clip_score;
         v[j] = clipf(v[j], A.inf_clip_model) + sig * ((A.inf_scale_score * clipf(sc, A.inf_clip_score)) * g);
         const float dsc = inside ? -(w1 * ptab[j].y) : 0.0f;
-        if (!PAD || j < d) div = fmaf(sig * A.inf_scale_score * g, dsc, div);
+        if (!PAD || j < d) div = fmaf(sig * A.inf_scale_score * g, dsc * eps2[j], div);
         if (PAD) v[j] = j < d ? v[j] : 0.0f;
       }
     } else {
@@ -377,6 +431,12 @@ __global__ __launch_bounds__(256) void bridge_div_bwd_kernel(const BridgeBwdArgs
       if (mdim(r, 1) < DP) vnn[mdim(r, 1)] = v1;
     }
   }
+  // Hutchinson probe vector of this row (training with div_estimator): ONE tangent in direction eps instead of d unit ones
+  const bool vec = A.eps != nullptr;
+  float eps[DP];
+#pragma unroll
+  for (int j = 0; j < DP; ++j)
+    eps[j] = (vec && (!PAD || j < d)) ? A.eps[((long long)t * B + irow) * d + (PAD ? min(j, d - 1) : j)] : 1.0f;
   // ---- score part of the divergence: only gamma(t) carries parameters ----------------------------------------------------
   if (A.inf_kind == SDEH_CTRL_LERP_PRIOR) {
     const float w1 = 1.0f - cf[CF_W];
@@ -388,28 +448,64 @@ __global__ __launch_bounds__(256) void bridge_div_bwd_kernel(const BridgeBwdArgs
       const float sc = w1 * (ptab[j].x - xj) * ptab[j].y;
       const bool inside = sc >= -A.clip_score && sc <= A.clip_score;
       const float dsc = (inside && (!PAD || j < d)) ? -(w1 * ptab[j].y) : 0.0f;
-      const float gj = c0 * sig * A.scale_score * dsc;  // d (w_i sigma dt div) / d gamma_j
+      const float gj = c0 * sig * A.scale_score * dsc * (vec ? eps[j] * eps[j] : 1.0f);  // d (w_i sigma dt div) / d gamma_j
       if (L2.g == 1) s += gj;
       else if ((!PAD || j < d) && live) A.dgam[(long long)j * N + n0 + lane] = gj;
     }
     if (L2.g == 1 && live) A.dgam[n0 + lane] = s;
   }
 
-  // ---- one tangent at a time ---------------------------------------------------------------------------------------
-  for (int jt = 0; jt < d; ++jt) {
-    float vj = 0.0f;
-#pragma unroll
-    for (int k = 0; k < DP; ++k) vj = k == jt ? vnn[k] : vj;
-    const float c = (vj >= -A.clip_model && vj <= A.clip_model) ? c0 : 0.0f;
-    if (live) A.cj[(long long)jt * N + n0 + lane] = c;
-    const float cA = __shfl(c, lane & 31), cB = __shfl(c, 32 + (lane & 31));
+  // ---- one tangent at a time (exact: d unit directions; Hutchinson: the single direction eps) ---------------------------------
+  const int ntan = vec ? 1 : d;
+  for (int jt = 0; jt < ntan; ++jt) {
     float* tzj = A.tz + (long long)jt * pset;
     float* taj = A.ta + (long long)jt * pset;
     float* tdj = A.td + (long long)jt * pset;
-    // forward: dz_0 = W_in[:, jt];  da_l = act'(z_l) dz_l;  dz_{l+1} = W_{l+1} da_l
     f32x16 tA[OT], tB[OT];
+    float cA = 0.0f, cB = 0.0f;
+    float adj_out[DP];  // Hutchinson: adjoint of the tangent's output vector, c0 eps_j 1[|v_nn,j| <= clip_model]
+    if (!vec) {
+      float vj = 0.0f;
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) tA[ot] = tB[ot] = load16(ws2 + L2.tan_in + jt * C + (ot * 2 + h) * 16);
+      for (int k = 0; k < DP; ++k) vj = k == jt ? vnn[k] : vj;
+      const float c = (vj >= -A.clip_model && vj <= A.clip_model) ? c0 : 0.0f;
+      if (live) A.cj[(long long)jt * N + n0 + lane] = c;
+      cA = __shfl(c, lane & 31);
+      cB = __shfl(c, 32 + (lane & 31));
+      // forward: dz_0 = W_in[:, jt];  da_l = act'(z_l) dz_l;  dz_{l+1} = W_{l+1} da_l
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) tA[ot] = tB[ot] = load16(ws2 + L2.tan_in + jt * C + (ot * 2 + h) * 16);
+    } else {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        adj_out[j] = (vnn[j] >= -A.clip_model && vnn[j] <= A.clip_model && (!PAD || j < d)) ? c0 * eps[j] : 0.0f;
+        if (live && (!PAD || j < d)) A.cj[(long long)j * N + n0 + lane] = adj_out[j];
+      }
+      // forward: dz_0 = W_in eps
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tA[ot][q] = tB[ot][q] = 0.0f;
+      float ea[R], eb[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float e0 = (!PAD || mdim(r, 0) < d) ? eps[mdim(r, 0)] : 0.0f;
+        float e1 = (mdim(r, 1) < DP && (!PAD || mdim(r, 1) < d)) ? eps[mdim(r, 1)] : 0.0f;
+        swap32(e0, e1);
+        ea[r] = e0;
+        eb[r] = e1;
+      }
+      const float* w = lds + L2.w_in + lane;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const float a = w[(r * OT + ot) * 64];
+          tA[ot] = SDEH_MFMA(a, ea[r], tA[ot]);
+          tB[ot] = SDEH_MFMA(a, eb[r], tB[ot]);
+          if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
+        }
+    }
     for (int l = 0; l <= Lh; ++l) {
       f32x16 zA[OT], zB[OT];
       load_plane<OT>(A.zt + (long long)l * plane, N, n0, nrows, lane, zA, zB);
@@ -444,13 +540,39 @@ __global__ __launch_bounds__(256) void bridge_div_bwd_kernel(const BridgeBwdArgs
         for (int ot = 0; ot < OT; ++ot) { tA[ot] = nA[ot]; tB[ot] = nB[ot]; }
       }
     }
-    // reverse: adj(da_L) = c w_out[jt]
+    // reverse: adj(da_L) = c w_out[jt]   (Hutchinson: W_out^T adj_out)
     f32x16 gA[OT], gB[OT];
+    if (!vec) {
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) {
-      const f32x16 wr = load16(ws2 + L2.tan_out + jt * C + (ot * 2 + h) * 16);
+      for (int ot = 0; ot < OT; ++ot) {
+        const f32x16 wr = load16(ws2 + L2.tan_out + jt * C + (ot * 2 + h) * 16);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) { gA[ot][q] = cA * wr[q]; gB[ot][q] = cB * wr[q]; }
+        for (int q = 0; q < 16; ++q) { gA[ot][q] = cA * wr[q]; gB[ot][q] = cB * wr[q]; }
+      }
+    } else {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) gA[ot][q] = gB[ot][q] = 0.0f;
+      float ga[R], gb[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float v0 = adj_out[mdim(r, 0)];
+        float v1 = mdim(r, 1) < DP ? adj_out[mdim(r, 1)] : 0.0f;
+        swap32(v0, v1);
+        ga[r] = v0;
+        gb[r] = v1;
+      }
+      const float* w = lds + L2.wt_out + lane;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const float a = w[(r * OT + ot) * 64];
+          gA[ot] = SDEH_MFMA(a, ga[r], gA[ot]);
+          gB[ot] = SDEH_MFMA(a, gb[r], gB[ot]);
+          if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
+        }
     }
     for (int l = Lh; l >= 0; --l) {
       f32x16 zA[OT], zB[OT], dzA[OT], dzB[OT], sA[OT], sB[OT];

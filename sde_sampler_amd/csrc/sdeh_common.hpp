@@ -101,6 +101,7 @@ struct TrajArgs {
   int inf_kind, inf_act;
   float inf_clip_model, inf_clip_score, inf_scale_score;
   float* gp;  // [T, B, d] or null: u + v per step (needed by the backward pass of the inference network)
+  const float* div_noise;  // [T, B, d] or null: Hutchinson probe vectors (training with div_estimator); null = exact divergence
 };
 
 // sdeh_bridge_div_backward (sdeh_bridge.hpp): gradient of  sum_n w_i sigma dt div_x v(x_n)  w.r.t. the inference network
@@ -119,6 +120,7 @@ struct BridgeBwdArgs {
   float* cj;              // [d, N]             c_j = w_i sigma dt 1[|v_nn,j| <= clip_model]
   float* dgam;            // [g, N]             d / d gamma(t) of the score part of the divergence
   float* dx;              // [T, B, d] or null: d / d x_t of the divergence term is ADDED to this plane
+  const float* eps;       // [T, B, d] or null: Hutchinson probe vectors (then tz/ta/td hold ONE tangent, cj = c0 eps_j m_j)
   long long batch;
   int n_steps, d, inf_kind, act;
   float clip_model, clip_score, scale_score;

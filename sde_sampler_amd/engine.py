@@ -448,7 +448,8 @@ class TrajectoryEngine:
 
     # ------------------------------------------------------------------------------------------------------
     def run(self, pr: L.SdehProblem, ts: torch.Tensor, x: torch.Tensor, *, noise: torch.Tensor | None,
-            return_traj: bool, keep: _Keep, row_offset: int = 0, seed: int | None = None, want_gp: bool = False):
+            return_traj: bool, keep: _Keep, row_offset: int = 0, seed: int | None = None, want_gp: bool = False,
+            div_noise: torch.Tensor | None = None):
         """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None); with `want_gp`
         (Bridge training) additionally the plane u + v [T,B,d] as a fourth element."""
         if not x.is_cuda:
@@ -485,11 +486,16 @@ class TrajectoryEngine:
         self.calls += 1
         stream = torch.cuda.current_stream(device).cuda_stream
         gp = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32) if want_gp else None
+        dn_p = None
+        if div_noise is not None:
+            if tuple(div_noise.shape) != (n_steps, batch, dim):
+                raise ValueError(f"div_noise must be [{n_steps}, {batch}, {dim}], got {tuple(div_noise.shape)}")
+            dn_p = keep.ptr(div_noise, device, "div_noise")
         with torch.cuda.device(device):
             L.check(lib.sdeh_simulate_fwd_aux(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
                                               seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
                                               rnd.data_ptr(), None if xs is None else xs.data_ptr(),
-                                              None if gp is None else gp.data_ptr(), stream))
+                                              None if gp is None else gp.data_ptr(), dn_p, stream))
         if want_gp:
             return x_T, rnd, xs, gp
         return x_T, rnd, xs

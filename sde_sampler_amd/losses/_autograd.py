@@ -91,7 +91,13 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, tor
             else:
                 grads[id(base.out_layer.weight)] = _nt(dout, a_k)
                 grads[id(base.out_layer.bias)] = dout.sum(dim=1)
-        if "td" in extra:  # tangent streams of the divergence term, one per coordinate j
+        if "td" in extra and extra.get("eps") is not None:  # Hutchinson: one tangent stream in direction eps
+            td, ta, cj = extra["td"], extra["ta"], extra["cj"]
+            grads[id(base.input_embed.weight)] += _nt(td[0, 0], extra["eps"].reshape(N, d).t().contiguous())
+            for k in range(Lh):
+                grads[id(base.hidden_layer[k].weight)] += _nt(td[0, k + 1], ta[0, k])
+            grads[id(base.out_layer.weight)] += _nt(cj, ta[0, Lh])
+        elif "td" in extra:  # tangent streams of the divergence term, one per coordinate j
             td, ta, cj = extra["td"], extra["ta"], extra["cj"]
             for j in range(d):
                 grads[id(base.input_embed.weight)][:, j] += td[j, 0].sum(dim=1)
@@ -185,7 +191,10 @@ class _BridgeFn(torch.autograd.Function):
         pr_b = eng.build_problem(device=dev, keep=keep_b, **st["problem_kwargs"])
         Cn, Lh = pr_b.inference.base_model.channels, pr_b.inference.base_model.n_hidden
         g = dgam.shape[0]
-        tz = torch.empty((d, Lh + 1, Cn, N), device=dev, dtype=torch.float32)
+        eps = st.get("div_noise")
+        if eps is not None:
+            eps = eps.detach().to(device=dev, dtype=torch.float32).contiguous()
+        tz = torch.empty((1 if eps is not None else d, Lh + 1, Cn, N), device=dev, dtype=torch.float32)
         ta, td = torch.empty_like(tz), torch.empty_like(tz)
         d2 = torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
         cj = torch.empty((d, N), device=dev, dtype=torch.float32)
@@ -195,10 +204,11 @@ class _BridgeFn(torch.autograd.Function):
             L.check(L.load().sdeh_bridge_div_backward(
                 plan.handle, C.byref(pr_b), keep_b.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B, w.data_ptr(),
                 zt.data_ptr(), tz.data_ptr(), ta.data_ptr(), td.data_ptr(), d2.data_ptr(), cj.data_ptr(), dgam2.data_ptr(),
-                None if dx is None else dx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+                None if dx is None else dx.data_ptr(), None if eps is None else eps.data_ptr(),
+                torch.cuda.current_stream(dev).cuda_stream))
         if not lv:  # generative network: back-propagation through time with the cost on u + v and the extra d loss / d x_t
             grads = generative(cost_ctrl=gp, lam_extra=dx)
-        grads.update(_weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, td=td, ta=ta, cj=cj, dgam=dgam2)))
+        grads.update(_weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, td=td, ta=ta, cj=cj, dgam=dgam2, eps=eps)))
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
 

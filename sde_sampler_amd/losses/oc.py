@@ -146,7 +146,7 @@ class BaseOCLoss:
 
     def _launch(self, ts, x, *, flags: int, terminal_unnorm_log_prob: Callable, second_log_prob: Callable | None,
                 second_at_start: bool, second_at_end: bool, return_traj: bool, noise, reference_prior=None,
-                alpha: float = 0.0, sigma: float = 0.0, inference_ctrl=None):
+                alpha: float = 0.0, sigma: float = 0.0, inference_ctrl=None, div_noise=None):
         """Common body of the three simulate() methods: fuse what can be fused, call back what cannot."""
         target, clip_target = _resolve_terminal(terminal_unnorm_log_prob)
         second = _resolve_gaussian_log_prob(second_log_prob)
@@ -167,7 +167,7 @@ class BaseOCLoss:
             offset = self.engine.calls
             seed = torch.initial_seed()
             out = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
-                                  row_offset=self.row_offset, seed=seed, want_gp=want_gp)
+                                  row_offset=self.row_offset, seed=seed, want_gp=want_gp, div_noise=div_noise)
             x_T, rnd, xs = out[:3]
             # user-supplied callables the engine does not recognise are evaluated as given (device tensors in/out)
             if second is None and second_log_prob is not None:
@@ -180,7 +180,7 @@ class BaseOCLoss:
             assert rnd.shape == (x.shape[0], 1)
             if want_state:
                 state = dict(problem_kwargs=problem_kwargs, noise=noise, seed=seed & 0xFFFFFFFFFFFFFFFF, offset=offset,
-                             row_offset=self.row_offset)
+                             row_offset=self.row_offset, div_noise=div_noise)
                 return (x_T, rnd, xs, out[3], state) if want_gp else (x_T, rnd, xs, state)
             return x_T, rnd, xs
 
@@ -192,8 +192,6 @@ class BaseOCLoss:
             if kl_unfused:
                 raise L.SdehUnsupported(-2, "Bridge training with method='kl'/'kl_ito' needs terminal / initial log-densities "
                                             "of built-in distributions (they are differentiated inside the kernel)")
-            if getattr(self, "div_estimator", None) is not None:
-                raise L.SdehUnsupported(-2, "div_estimator (Hutchinson) is not built: the exact divergence is")
             from sde_sampler_amd.losses._autograd import simulate_bridge_with_grad
 
             x_T, rnd, _ = simulate_bridge_with_grad(self, run, ts, x, inference_ctrl)
@@ -222,8 +220,8 @@ class BaseOCLoss:
 
 class TimeReversalLoss(BaseOCLoss):
     """DIS, and Bridge when `inference_ctrl` is given (the exact divergence of the inference control per step,
-    losses/oc.py:189-202; evaluation and training with every loss method; the Hutchinson `div_estimator`s, which only act
-    in training, are not built): reference losses/oc.py:140-278."""
+    losses/oc.py:189-202, or its Hutchinson estimate in training when `div_estimator` is "rademacher" / "gauss"; evaluation and
+    training with every loss method): reference losses/oc.py:140-278."""
 
     _LOSS_KIND = L.LOSS_TIME_REVERSAL
 
@@ -236,18 +234,33 @@ class TimeReversalLoss(BaseOCLoss):
 
     def simulate(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None = None,
                  train: bool = True, compute_ito_int: bool = False, change_sde_ctrl: bool = False,
-                 return_traj: bool = False, *, noise: torch.Tensor | None = None):
+                 return_traj: bool = False, *, noise: torch.Tensor | None = None, div_noise: torch.Tensor | None = None):
         self._check_common(change_sde_ctrl)
+        if self.inference_ctrl is not None and train and self.div_estimator is not None and div_noise is None:
+            # probe vectors of the Hutchinson estimator (utils/autograd.py:25-42, n_samples = 1), one per trajectory and step
+            shape = (ts.numel() - 1, *x.shape)
+            if self.div_estimator == "rademacher":
+                div_noise = torch.randint(0, 2, shape, device=x.device).float() * 2 - 1.0
+            elif self.div_estimator == "gauss":
+                div_noise = torch.randn(shape, device=x.device)
+            else:
+                raise NotImplementedError(f"Undefined noise type {self.div_estimator}.")
+        if not (self.inference_ctrl is not None and train and self.div_estimator is not None):
+            div_noise = None  # the estimator only acts in training (losses/oc.py:190)
         flags = (L.FLAG_TRAIN if train else 0) | (L.FLAG_ITO if compute_ito_int else 0) | \
                 (L.FLAG_CHANGE_SDE_CTRL if change_sde_ctrl else 0)
         with_initial = not (train and self.method in ["kl", "kl_ito"])  # reference 168-172
         return self._launch(ts, x, flags=flags, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
                             second_log_prob=initial_log_prob if with_initial else None, second_at_start=True,
-                            second_at_end=False, return_traj=return_traj, noise=noise, inference_ctrl=self.inference_ctrl)
+                            second_at_end=False, return_traj=return_traj, noise=noise, inference_ctrl=self.inference_ctrl,
+                            div_noise=div_noise)
 
-    def __call__(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None, *, noise=None):
-        return self._train_call(ts, x, dict(terminal_unnorm_log_prob=terminal_unnorm_log_prob,
-                                            initial_log_prob=initial_log_prob, train=True, noise=noise))
+    def __call__(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None, *, noise=None,
+                 div_noise=None):
+        kw = dict(terminal_unnorm_log_prob=terminal_unnorm_log_prob, initial_log_prob=initial_log_prob, train=True, noise=noise)
+        if div_noise is not None:
+            kw["div_noise"] = div_noise
+        return self._train_call(ts, x, kw)
 
     def eval(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None = None,
              compute_weights: bool = True, return_traj: bool = True, *, noise=None) -> Results:

@@ -99,6 +99,28 @@ def run_case(name, case):
             for k, p in mod.named_parameters():
                 out[f"train_{method}/{prefix}/{k}"] = (p.grad.detach().numpy().copy() if p.grad is not None
                                                        else np.zeros(tuple(p.shape), np.float32))
+    # Hutchinson divergence estimators (TimeReversalLoss.div_estimator; they only act in training): per step the reference
+    # draws the probe (compute_divx) BEFORE the Brownian increment, so both sequences are pre-drawn in that order
+    for est in ("rademacher", "gauss"):
+        loss.div_estimator, loss.method, loss.n_filtered = est, "lv", 0
+        torch.manual_seed(case["seed"] + 7)
+        st = torch.get_rng_state()
+        probes, incs = [], []
+        for _ in range(len(ts) - 1):
+            probes.append(torch.randint_like(x0, low=0, high=2).float() * 2 - 1.0 if est == "rademacher" else torch.randn_like(x0))
+            incs.append(torch.randn_like(x0))
+        out[f"hutch_{est}/probes"], out[f"hutch_{est}/noise"] = torch.stack(probes).numpy(), torch.stack(incs).numpy()
+        ctrl.zero_grad(); inf.zero_grad()
+        torch.set_rng_state(st)
+        val, _ = loss(ts, x0, terminal, second)
+        val.backward()
+        out[f"hutch_{est}/loss"] = np.float64(val.item())
+        for prefix, mod in (("grad", ctrl), ("grad_inf", inf)):
+            for k, p in mod.named_parameters():
+                out[f"hutch_{est}/{prefix}/{k}"] = (p.grad.detach().numpy().copy() if p.grad is not None
+                                                    else np.zeros(tuple(p.shape), np.float32))
+    loss.div_estimator, loss.method = None, lspec["method"]
+
     torch.manual_seed(99)
     xq = x0 + 0.5 * torch.randn_like(x0)
     out["kat/x"] = xq.numpy()

@@ -54,9 +54,16 @@ def test_bridge_in_kernel_noise_and_training_refusal():
     b = prob.eval(x0, compute_weights=True)
     assert torch.equal(a.samples, b.samples) and torch.equal(a.weights, b.weights)
     assert torch.isfinite(a.samples).all() and np.isfinite(a.log_norm_const_preds["log_norm_const_is"])
-    prob.loss.div_estimator = "rademacher"  # Hutchinson estimators only act in training and are not built
-    with pytest.raises(SdehUnsupported, match="div_estimator"):
+    prob.loss.div_estimator = "sobol"  # utils/autograd.py:38-39
+    with pytest.raises(NotImplementedError, match="Undefined noise type"):
         prob.loss(prob.ts, x0[:64], prob.target.unnorm_log_prob, prob.second_log_prob)
+    # an inference control without a built-in divergence
+    from sde_sampler_amd.models.reparam import ScoreCtrl
+
+    bad = ScoreCtrl(base_model=prob.loss.inference_ctrl.base_model, score_model=None, target_score=prob.target.score)
+    prob.loss.inference_ctrl, prob.loss.div_estimator = bad, None
+    with pytest.raises(SdehUnsupported, match="ClippedCtrl"):
+        prob.eval(x0[:64])
 
 
 def _rel(a, b):
@@ -96,3 +103,36 @@ def test_bridge_training_gradients_match_reference(path, method):
     tol = 2e-4 if method == "lv" else 1e-3
     bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("est", ["rademacher", "gauss"])
+@pytest.mark.parametrize("path", GOLDEN_BRIDGE, ids=lambda p: Path(p).stem)
+def test_bridge_hutchinson_training_matches_reference(path, est):
+    """Training with div_estimator: the Hutchinson estimate eps^T J eps in the forward pass and its gradient, with the
+    reference's probe vectors and Brownian increments replayed."""
+    fx, meta, prob = _build(path)
+    x0 = torch.from_numpy(fx["x0"]).to(DEV)
+    noise, probes = torch.from_numpy(fx[f"hutch_{est}/noise"]).to(DEV), torch.from_numpy(fx[f"hutch_{est}/probes"]).to(DEV)
+    loss = prob.loss
+    loss.method, loss.max_rnd, loss.div_estimator = "lv", 1e8, est
+    val, _ = loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise, div_noise=probes)
+    val.backward()
+    ref = float(fx[f"hutch_{est}/loss"])
+    assert abs(val.item() - ref) <= 2e-3 * max(1.0, abs(ref)), (val.item(), ref)
+    worst = {}
+    for prefix, mod in (("grad", prob.ctrl), ("grad_inf", loss.inference_ctrl)):
+        for k, p in mod.named_parameters():
+            key = f"hutch_{est}/{prefix}/{k}"
+            if key not in fx.files:
+                continue
+            g_ref = torch.from_numpy(fx[key])
+            g = p.grad.cpu() if p.grad is not None else torch.zeros_like(g_ref)
+            if g_ref.abs().max() == 0:
+                assert g.abs().max() <= 1e-6, key
+                continue
+            worst[key] = _rel(g, g_ref)
+    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    assert not bad, bad
+    # without given probes the loss draws its own (device RNG) and still trains
+    val2, _ = loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+    assert torch.isfinite(val2)

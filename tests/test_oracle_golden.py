@@ -191,3 +191,24 @@ def test_bridge_branch_bit_exact(path):
                     continue
                 g = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
                 assert np.array_equal(g, fx[key]), key
+
+
+@pytest.mark.parametrize("est", ["rademacher", "gauss"])
+@pytest.mark.parametrize("path", GOLDEN_BRIDGE, ids=lambda p: Path(p).stem)
+def test_bridge_hutchinson_estimators_bit_exact(path, est):
+    """TimeReversalLoss.div_estimator (utils/autograd.py:25-42) in training, probes and Brownian increments replayed."""
+    fx, prob, params, ts, x0, _ = load(path)
+    prob.div_estimator = est
+    pinf = prob.inference_ctrl.p
+    for p in list(params.values()) + list(pinf.values()):
+        p.requires_grad_(True)
+        p.grad = None
+    loss, _, _, _ = prob.train_loss(ts, x0, torch.from_numpy(fx[f"hutch_{est}/noise"]), method="lv",
+                                    div_noise=torch.from_numpy(fx[f"hutch_{est}/probes"]))
+    loss.backward()
+    assert loss.item() == float(fx[f"hutch_{est}/loss"])
+    for prefix, pd in (("grad", params), ("grad_inf", pinf)):
+        for k, p in pd.items():
+            key = f"hutch_{est}/{prefix}/{k}"
+            if key in fx.files and p.grad is not None:
+                assert np.array_equal(p.grad.numpy(), fx[key]), key

@@ -1,22 +1,26 @@
 // Wave-specialised persistent trajectory kernel (the default path).
 //
-// A 512-thread workgroup owns 256 trajectories as four groups of 64.  Each group is served by TWO wavefronts
-// that the dispatcher places on the same SIMD (a workgroup's waves are dealt to the four SIMDs cyclically):
+// A workgroup owns G groups of 64 trajectories (G = 4: 512 threads, 256 trajectories).  Each group is served by TWO
+// wavefronts -- waves g and G + g; a workgroup's waves are dealt to the CU's four SIMDs cyclically, so with G = 4 both
+// land on the same SIMD:
 //
-//   V wave (waves 0..3): owns the state.  T layout (lane = trajectory): target/prior score, score term of the
-//                        control, Philox/Box-Muller draws, running cost, EM update, terminal log-densities.
-//                        Pure VALU + broadcast LDS reads.
-//   M wave (waves 4..7): evaluates the FourierMLP for the same 64 trajectories on the matrix pipe
-//                        (v_mfma_f32_32x32x2_f32, M layout) with the activation in between.
+//   V wave (waves 0..G-1):  owns the state.  T layout (lane = trajectory): target/prior score, score term of the
+//                           control, Philox/Box-Muller draws, running cost, EM update, terminal log-densities.
+//                           Pure VALU + broadcast LDS reads.
+//   M wave (waves G..2G-1): evaluates the FourierMLP for the same 64 trajectories on the matrix pipe
+//                           (v_mfma_f32_32x32x2_f32, M layout) with the activation in between.
 //
-// fp32 MFMA issues at the VALU's FLOP rate but on a separate pipe, so a wave that only does MFMAs and a wave that
-// only does VALU work run concurrently on one SIMD; with a single wave per SIMD (all B = 65 536 allows: 1024 SIMDs x
-// 64 lanes) the two kinds of work would alternate.  Per step the waves exchange x (V -> M) and the network output
+// fp32 MFMA and fp32 VALU instructions share the SIMD's fp32 datapath on gfx950 (profiles/r01_ubench_coexec.txt): two
+// waves on one SIMD do not add throughput, they hide each other's latencies (LDS, MFMA result latency, barriers).
+// B = 65 536 is exactly one group per SIMD (1024 SIMDs x 64 lanes), so there G = 4 and the pair shares a SIMD.  When the
+// batch needs at most half of the SIMDs (B <= 32 768) the launcher uses G = 2 (256-thread workgroups, one wave per SIMD):
+// the V and the M wave of a group then sit on DIFFERENT SIMDs and really run concurrently -- a step costs
+// max(M chain, V work) instead of their sum.  Per step the waves exchange x (V -> M) and the network output
 // (M -> V) through one [coordinate][trajectory] LDS buffer per group, which also performs the T <-> M layout change
 // (no cross-lane shuffles), separated by two workgroup barriers:
 //
-//   V: score(x), noise            | barrier B | u = clip(nn) + score term, cost, x <- EM(x,u,xi), publish x | barrier A
-//   M: read x, MLP(x), publish nn | barrier B | (prefetch next step's time embedding)                        | barrier A
+//   V: score(x), noise            | barrier B | u = clip(nn) + score term, x <- EM(x,u,xi), publish x | barrier A | cost, Ito
+//   M: read x, MLP(x), publish nn | barrier B | (prefetch next step's time embedding)                  | barrier A
 #pragma once
 #include "sdeh_traj.hpp"
 
@@ -29,7 +33,7 @@
 
 namespace sdeh {
 
-constexpr int kWsGroups = 4;  // trajectory groups (of 64) per workgroup
+constexpr int kWsGroups = 4;  // most trajectory groups (of 64) per workgroup; the launcher picks 4 or 2 (blockDim.x = 128 G)
 
 // rows of the exchange buffer: every coordinate an M-layout register can address
 template <int DP>
@@ -351,13 +355,14 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_m = wave >= kWsGroups;
-  const int group = is_m ? wave - kWsGroups : wave;
+  const int n_groups = (int)(blockDim.x >> 7);
+  const bool is_m = wave >= n_groups;
+  const int group = is_m ? wave - n_groups : wave;
 
   {  // stage the LDS image (packed weights + GMM tables) once per workgroup
     const float4* src = reinterpret_cast<const float4*>(ws);
     float4* dst = reinterpret_cast<float4*>(lds);
-    for (int i = tid; i < L.lds_floats / 4; i += 512) dst[i] = src[i];
+    for (int i = tid; i < L.lds_floats / 4; i += (int)blockDim.x) dst[i] = src[i];
   }
   float* __restrict__ xbuf = lds + L.lds_floats + group * (XR * 64);
 
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #if SDEH_VPRIO > 0
   __builtin_amdgcn_s_setprio(SDEH_VPRIO);
 #endif
-  const long long row = (long long)blockIdx.x * 256 + group * 64 + lane;
+  const long long row = (long long)blockIdx.x * (64 * n_groups) + group * 64 + lane;
   const bool live = row < A.batch;
   const long long lrow = live ? row : A.batch - 1;  // dead lanes shadow the last row and never store
   DensArgs tgt = A.target;
@@ -606,8 +611,12 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((a.batch + 255) / 256);
-  hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>), dim3(grid), dim3(512), lds_bytes, stream,
+  // G = 2 as soon as every wave can have a SIMD of its own (one 256-thread workgroup per CU, 256 CUs): see the header
+  static const char* force = getenv("SDEH_WS_GROUPS");
+  int groups = a.batch <= 2 * 64 * 256 ? 2 : kWsGroups;
+  if (force != nullptr && (force[0] == '2' || force[0] == '4')) groups = force[0] - '0';
+  const unsigned grid = (unsigned)((a.batch + 64 * groups - 1) / (64 * groups));
+  hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>), dim3(grid), dim3(128 * groups), lds_bytes, stream,
                      a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }

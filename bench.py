@@ -131,7 +131,9 @@ def main():
                       mixture_weights=prob.target.mixture_weights.clone()))
     prob.to(device)
     B, T, d = spec["batch"], prob.ts.numel() - 1, spec["target"]["dim"]
-    torch.manual_seed(1 + rank)
+    # the same seed on every rank: the in-kernel Philox stream is keyed by (seed, call, GLOBAL row), so the N-rank job draws
+    # exactly the noise a single launch over the N*B rows would (x0 of the Delta prior is zero on every rank)
+    torch.manual_seed(1)
     x0 = prob.prior.sample((B,))
     prob.loss.row_offset = rank * B
     prob.loss.engine.timing = True

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the Bridge evaluation kernel (two networks + d forward-mode tangent passes per step) at eval-batch size."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import time
 import torch
 from sde_sampler_amd import problems

@@ -2,7 +2,7 @@
 """Times the evaluation-side kernels: Sinkhorn() at the reference's settings (eps 1e-3, 100 iterations) on eval-batch-sized
 clouds, get_metrics' statistics pass, and the CPU dense oracle on a bounded sample."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from sde_sampler_amd.eval.sinkhorn import Sinkhorn
 from sde_sampler_amd.eval.metrics import sample_stats

@@ -3,7 +3,7 @@
 (conf/solver/langevin.yaml: B = 6000, dt = 0.01 over [0, 100] = 10 000 steps, 1001 output times) and on a throughput-sized
 batch, and the CPU oracle (reference loop restated) on a bounded number of steps of the same problem."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from sde_sampler_amd import problems
 from sde_sampler_amd.eq.integrator import EulerIntegrator

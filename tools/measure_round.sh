@@ -12,4 +12,4 @@ head -12 gpurun_out/v6/kernel_stats.txt
 bash tools/pmc_profile.sh gpurun_out/v6/pmc > /dev/null 2>&1
 cat gpurun_out/v6/pmc/summary.txt | head -50
 python tools/all_configs_timing.py 2>&1 | tee gpurun_out/v6/all_configs.txt
-python tools/integrator_timing.py 2>&1 | tee gpurun_out/v6/integrator.txt
+python tests/perf/integrator_timing.py 2>&1 | tee gpurun_out/v6/integrator.txt

@@ -12,10 +12,10 @@
 //
 // fp32 MFMA and fp32 VALU instructions share the SIMD's fp32 datapath on gfx950 (profiles/r01_ubench_coexec.txt): two
 // waves on one SIMD do not add throughput, they hide each other's latencies (LDS, MFMA result latency, barriers).
-// B = 65 536 is exactly one group per SIMD (1024 SIMDs x 64 lanes), so there G = 4 and the pair shares a SIMD.  When the
-// batch needs at most half of the SIMDs (B <= 32 768) the launcher uses G = 2 (256-thread workgroups, one wave per SIMD):
-// the V and the M wave of a group then sit on DIFFERENT SIMDs and really run concurrently -- a step costs
-// max(M chain, V work) instead of their sum.  Per step the waves exchange x (V -> M) and the network output
+// B = 65 536 is exactly one group per SIMD (1024 SIMDs x 64 lanes), so there G = 4 and the pair shares a SIMD.  Smaller
+// batches use groups of 32 trajectories (TrajArgs::half: one column tile per M wave, ws_mlp_half) and, when every wave can
+// have a SIMD of its own, G = 2 so that the V and the M wave of a group sit on DIFFERENT SIMDs and really run concurrently
+// (launch_traj_ws has the table).  Per step the waves exchange x (V -> M) and the network output
 // (M -> V) through one [coordinate][trajectory] LDS buffer per group, which also performs the T <-> M layout change
 // (no cross-lane shuffles), separated by two workgroup barriers:
 //
@@ -341,6 +341,47 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
   }
 }
 
+// Single-tile variant for small batches (TrajArgs::half): the group is 32 trajectories = one MFMA column tile, so the chain of
+// dependent layers is half as long (the launch is latency-bound: a handful of wavefronts on 1024 SIMDs).
+template <int DP, int C>
+__device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
+                                            int act, const f32x16 (&emb)[C / 32], int lane) {
+  constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
+  const int h = lane >> 5, j = lane & 31;
+  f32x16 cur[OT], nxt[OT], none[1];
+  auto activate_all = [&]() {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) cur[ot][q] = act_apply(cur[ot][q], act);
+  };
+  {
+    float xa[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) xa[r] = xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j];
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) cur[ot] = emb[ot];
+    mfma_stage<R, OT, 1>(lds + L.w_in + lane, [&](int s) { return xa[s]; }, cur, none, false, act);
+  }
+  for (int l = 0; l < L.n_hidden; ++l) {
+    activate_all();
+    const float* bias = lds + L.b_hid + l * C;
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) nxt[ot] = load16(bias + (ot * 2 + h) * 16);
+    mfma_stage<C / 2, OT, 1>(lds + L.w_hid + l * L.w_hid_stride + lane, [&](int s) { return cur[s / 16][s % 16]; }, nxt, none,
+                             false, act);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) cur[ot] = nxt[ot];
+  }
+  activate_all();
+  f32x16 u[OTD];
+#pragma unroll
+  for (int t = 0; t < OTD; ++t) u[t] = load16(lds + L.b_out + (t * 2 + h) * 16);
+  mfma_stage<C / 2, OTD, 1>(lds + L.w_out + lane, [&](int s) { return cur[s / 16][s % 16]; }, u, none, false, act);
+#pragma unroll
+  for (int r = 0; r < R; ++r) xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j] = u[r / 16][r % 16];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------
@@ -385,7 +426,10 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (ot * 2 + h) * 16);
     __syncthreads();  // barrier A: x_0 published
     for (int i = 0; i < n_steps; ++i) {
-      if constexpr ((SDEH_ABL & 1) == 0) ws_mlp<DP, C>(lds, xbuf, L, act, emb, lane);
+      if constexpr ((SDEH_ABL & 1) == 0) {
+        if (A.half) ws_mlp_half<DP, C>(lds, xbuf, L, act, emb, lane);
+        else ws_mlp<DP, C>(lds, xbuf, L, act, emb, lane);
+      }
       __syncthreads();  // barrier B: network output published
       if (i + 1 < n_steps) {
 #pragma unroll
@@ -400,8 +444,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #if SDEH_VPRIO > 0
   __builtin_amdgcn_s_setprio(SDEH_VPRIO);
 #endif
-  const long long row = (long long)blockIdx.x * (64 * n_groups) + group * 64 + lane;
-  const bool live = row < A.batch;
+  const int rpg = A.half ? 32 : 64;  // trajectories per group
+  const long long row = (long long)blockIdx.x * (rpg * n_groups) + group * rpg + lane;
+  const bool live = lane < rpg && row < A.batch;
   const long long lrow = live ? row : A.batch - 1;  // dead lanes shadow the last row and never store
   DensArgs tgt = A.target;
   if (TGT >= 0) tgt.kind = TGT;
@@ -611,13 +656,21 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
-  // G = 2 as soon as every wave can have a SIMD of its own (one 256-thread workgroup per CU, 256 CUs): see the header
-  static const char* force = getenv("SDEH_WS_GROUPS");
-  int groups = a.batch <= 2 * 64 * 256 ? 2 : kWsGroups;
-  if (force != nullptr && (force[0] == '2' || force[0] == '4')) groups = force[0] - '0';
-  const unsigned grid = (unsigned)((a.batch + 64 * groups - 1) / (64 * groups));
+  // Placement by batch size (256 CUs x 4 SIMDs; the register budget allows two of these waves per SIMD):
+  //   B >  32 768 : groups of 64, G = 4 -- V and M wave of a group share a SIMD (B = 65 536 fills every SIMD exactly)
+  //   B <= 32 768 : groups of 32 (one MFMA column tile per M wave: half the dependent chain per step), G = 4, sharing a SIMD
+  //   B <= 16 384 : groups of 32, G = 2 -- every wave has a SIMD of its own, V and M really run concurrently; the reference's
+  //                 default batch sizes (train 512 / 2048, eval 6000) live here and are latency-bound: 14.5 -> 7.1 us per step
+  static const char* force = getenv("SDEH_WS_GROUPS");  // testing aid: "2" | "4" | "2h" | "4h"
+  int groups = a.batch <= 2 * 32 * 256 ? 2 : kWsGroups;
+  int half = a.batch <= 4 * 32 * 256 ? 1 : 0;
+  if (force != nullptr && (force[0] == '2' || force[0] == '4')) { groups = force[0] - '0'; half = force[1] == 'h' ? 1 : 0; }
+  TrajArgs b = a;
+  b.half = half;
+  const int rows = (half ? 32 : 64) * groups;
+  const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);
   hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>), dim3(grid), dim3(128 * groups), lds_bytes, stream,
-                     a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, a);
+                     a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

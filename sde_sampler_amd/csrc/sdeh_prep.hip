@@ -38,30 +38,35 @@ __device__ void time_embed_block(const SdehTimeEmbed& te, int act, float t, floa
     sh_in[C + c] = cosf(arg);
   }
   __syncthreads();
-  for (int c = tid; c < C; c += nt) {
-    const float* w = te.hidden_w[0] + (size_t)c * 2 * C;
+  // every output is a dot product of length C or 2C: four adjacent lanes share one (k = part, part + 4, ...) and combine
+  // with two shuffles -- all 256 threads work on the 64 outputs of a layer instead of 64 of them (launch latency of the
+  // whole prep kernel: 35 -> ~15 us, which is what an evaluation at the reference's batch sizes waits for)
+  const int part = tid & 3, grp = tid >> 2, ngrp = nt >> 2;
+  auto dot4 = [&](const float* w, const float* v, int n) {
     float acc = 0.0f;
-    for (int k = 0; k < 2 * C; ++k) acc = fmaf(w[k], sh_in[k], acc);
-    sh_a[c] = actf(acc + te.hidden_b[0][c], act);
+    for (int k = part; k < n; k += 4) acc = fmaf(w[k], v[k], acc);
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    return acc;
+  };
+  for (int c = grp; c < C; c += ngrp) {
+    const float acc = dot4(te.hidden_w[0] + (size_t)c * 2 * C, sh_in, 2 * C);
+    if (part == 0) sh_a[c] = actf(acc + te.hidden_b[0][c], act);
   }
   __syncthreads();
   float* cur = sh_a;
   float* nxt = sh_b;
   for (int l = 1; l < te.n_hidden; ++l) {
-    for (int c = tid; c < C; c += nt) {
-      const float* w = te.hidden_w[l] + (size_t)c * C;
-      float acc = 0.0f;
-      for (int k = 0; k < C; ++k) acc = fmaf(w[k], cur[k], acc);
-      nxt[c] = actf(acc + te.hidden_b[l][c], act);
+    for (int c = grp; c < C; c += ngrp) {
+      const float acc = dot4(te.hidden_w[l] + (size_t)c * C, cur, C);
+      if (part == 0) nxt[c] = actf(acc + te.hidden_b[l][c], act);
     }
     __syncthreads();
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
-  for (int o = tid; o < te.dim_out; o += nt) {
-    const float* w = te.out_w + (size_t)o * C;
-    float acc = 0.0f;
-    for (int k = 0; k < C; ++k) acc = fmaf(w[k], cur[k], acc);
-    res[o] = acc + te.out_b[o];
+  for (int o = grp; o < te.dim_out; o += ngrp) {
+    const float acc = dot4(te.out_w + (size_t)o * C, cur, C);
+    if (part == 0) res[o] = acc + te.out_b[o];
   }
   __syncthreads();
 }

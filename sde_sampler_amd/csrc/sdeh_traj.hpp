@@ -350,11 +350,13 @@ __device__ __forceinline__ void target_score(const DensArgs& D, const float* ws,
 // Gaussian draws: Philox4x32-10 words -> Box-Muller.  Block j of a step yields coordinates 4j..4j+3.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void box_muller4(const U4& r, float (&n)[4]) {
-  constexpr float S = 5.9604644775390625e-08f;  // 2^-24
-  const float u0 = ((float)(r.x >> 8) + 0.5f) * S;
-  const float u1 = ((float)(r.y >> 8) + 0.5f) * S;
-  const float u2 = ((float)(r.z >> 8) + 0.5f) * S;
-  const float u3 = ((float)(r.w >> 8) + 0.5f) * S;
+  // uniform in (0, 1]: the whole 32-bit word scaled by 2^-32 (v_cvt_f32_u32 rounds it to 24 significant bits) plus 2^-33 so
+  // that the logarithm never sees 0 -- one conversion and one fma per uniform
+  constexpr float S = 2.3283064365386963e-10f, H = 1.1641532182693481e-10f;
+  const float u0 = fmaf((float)r.x, S, H);
+  const float u1 = fmaf((float)r.y, S, H);
+  const float u2 = fmaf((float)r.z, S, H);
+  const float u3 = fmaf((float)r.w, S, H);
   // v_log_f32 is log2:  -2 ln u = -2 ln2 log2 u
   const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u0));  // v_sqrt_f32 (1 ulp; the argument is never denormal)
   const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u2));

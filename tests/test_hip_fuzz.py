@@ -1,0 +1,155 @@
+"""Randomised parity sweep: seeded random problems (loss x control x SDE x target x network shape x clip activity x batch
+raggedness) through the HIP engine vs the CPU oracle on identical noise.  The golden fixtures pin nine hand-picked
+configurations; this sweeps the combinations in between (and the kernel-variant selection that goes with them)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import em_oracle as eo
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N_CASES = 96
+N_TRAIN = 32
+
+
+def random_spec(rng: np.random.Generator) -> dict:
+    d = int(rng.choice([1, 2, 3, 5, 8, 10, 16, 50]))
+    loss_kind = str(rng.choice(["time_reversal", "reference_sde", "exponential"]))
+    # target
+    tkinds = ["gmm", "iso_gauss", "funnel", "multi_well"] if d >= 2 else ["double_well", "iso_gauss", "multi_well"]
+    tk = str(rng.choice(tkinds))
+    if tk == "gmm":
+        target = dict(kind="gmm", dim=d, name="fab" if d == 2 and rng.random() < 0.5 else ("fab50" if d == 50 else "random7"))
+        if target["name"] == "fab50" and d != 50:
+            target["name"] = "random7"
+    elif tk == "iso_gauss":
+        target = dict(kind="iso_gauss", dim=d, loc=float(rng.uniform(-2, 2)), scale=float(rng.uniform(0.5, 2.0)))
+    elif tk == "funnel":
+        target = dict(kind="funnel", dim=d)
+    elif tk == "double_well":
+        target = dict(kind="double_well", dim=1, separation=float(rng.uniform(1, 3)), shift=float(rng.uniform(-1, 1)))
+    else:
+        target = dict(kind="multi_well", dim=d, n_double_wells=int(rng.integers(1, d + 1)), separation=float(rng.uniform(1, 3)),
+                      shift=float(rng.uniform(-0.5, 0.5)))
+    # sde / prior / control kinds that make sense for the loss (solver/oc.py)
+    if loss_kind == "exponential":
+        sde, prior = None, dict(kind="iso_gauss", dim=d, loc=0.0, scale=1.0)
+        ctrl_kind = str(rng.choice(["score", "clipped"]))
+    else:
+        sk = str(rng.choice(["vp", "const_ou", "scaled_bm"]))
+        if sk == "vp":
+            sde = dict(kind="vp", beta_min=float(rng.uniform(0.05, 0.5)), beta_max=float(rng.uniform(2, 8)), scale=float(rng.uniform(0.7, 1.3)),
+                       terminal_t=float(rng.choice([1.0, 2.0])))
+        elif sk == "const_ou":
+            sde = dict(kind="const_ou", drift_coeff=float(rng.uniform(0.2, 1.5)), diff_coeff=float(rng.uniform(0.5, 1.5)), terminal_t=1.0)
+        else:
+            sde = dict(kind="scaled_bm", diff_coeff=float(rng.uniform(0.4, 1.5)), terminal_t=float(rng.choice([1.0, 5.0])))
+        if loss_kind == "reference_sde" and sk == "vp":
+            sde["scale"] = 1.0  # EulerDDS: the reference Gaussian's variance (1 - e^{2I}) scale^2 + e^{2I} must stay positive
+        if loss_kind == "reference_sde" and sk != "vp" and rng.random() < 0.5:
+            prior, ctrl_kind = dict(kind="delta", dim=d), str(rng.choice(["score", "clipped"]))  # PIS
+        else:
+            prior = dict(kind="iso_gauss", dim=d, loc=0.0, scale=1.0)
+            ctrl_kind = str(rng.choice(["score", "clipped", "lerp", "lerp_target", "lerp_prior"]))
+    clip_active = rng.random() < 0.4
+    ctrl = dict(kind=ctrl_kind, clip_model=float(rng.uniform(0.2, 2.0)) if clip_active else 1e4)
+    if ctrl_kind != "clipped":
+        ctrl.update(clip_score=float(rng.uniform(0.5, 5.0)) if clip_active else 1e4, scale_score=float(rng.choice([1.0, 0.5, 2.0])),
+                    gamma_dim=int(rng.choice([1, d])), gamma_bias=float(rng.choice([1.0, 0.01])))
+    loss = dict(kind=loss_kind, method="kl", max_rnd=None)
+    if loss_kind == "exponential":
+        loss.update(alpha=float(rng.uniform(0.5, 1.5)), sigma=float(rng.uniform(0.7, 1.3)))
+    if loss_kind == "reference_sde" and prior["kind"] != "delta":
+        loss["reference_ctrl"] = "prior_score"  # EulerDDS
+    steps = int(rng.integers(4, 33))
+    end = sde["terminal_t"] if sde else float(rng.uniform(3.0, 12.8))
+    grid = dict(start=0.0, end=end, steps=steps, rescale_t="cosine" if loss_kind == "exponential" and rng.random() < 0.5 else None)
+    net = dict(channels=64, num_layers=int(rng.integers(3, 6)), activation=str(rng.choice(["gelu", "silu", "relu"])))
+    return dict(target=target, prior=prior, sde=sde, ctrl=ctrl, net=net, loss=loss, grid=grid,
+                batch=int(rng.choice([1, 7, 33, 64, 65, 100, 257, 300])), init_seed=int(rng.integers(1, 1000)))
+
+
+@pytest.mark.parametrize("case", range(N_CASES))
+def test_random_problem_matches_oracle(case):
+    from sde_sampler_amd import problems
+
+    rng = np.random.default_rng(1000 + case)
+    spec = random_spec(rng)
+    prob = problems.build(spec)
+    params = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
+    tt = None
+    if spec["target"]["kind"] == "gmm":
+        tt = dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+    oracle = eo.Problem(spec, params, tt)
+    ts = prob.ts.clone()
+    B, d, T = spec["batch"], spec["target"]["dim"], ts.numel() - 1
+    torch.manual_seed(case)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(T, B, d)
+    weights = bool(rng.random() < 0.5)
+    torch.set_num_threads(4)
+    ref = oracle.eval(ts, x0.clone(), noise, compute_weights=weights, return_traj=True)
+    prob.to(DEV)
+    out = prob.eval(x0.to(DEV), compute_weights=weights, return_traj=True, noise=noise.to(DEV))
+    tag = f"case {case}: {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T} {spec['net']}"
+    # Per-row criterion: the dynamics amplify 1-ulp differences -- stiff wells with large steps and active clamps
+    # can take single rows from 2e-6 to 0.2 within 20 steps (tools/fuzz_case_debug.py shows the step-by-step growth of such a
+    # case) -- so the bulk of the rows must agree tightly and only a minority may have drifted.
+    scale = max(1.0, float(ref["xs"].abs().max()))
+    row_err = (out.xs.cpu() - ref["xs"]).abs().amax(dim=(0, 2))
+    assert row_err.median().item() <= 1e-4 * scale, f"{tag}: median row error {row_err.median().item():.3e} (scale {scale:.2f})"
+    drifted = (row_err > 2e-3 * scale).float().mean().item()
+    assert drifted <= 0.25, f"{tag}: {drifted:.0%} of the rows differ by more than {2e-3 * scale:.1e}"
+    assert row_err[:1].item() >= 0.0 and (out.xs[0].cpu() == ref["xs"][0]).all()  # the initial state is passed through
+    key = "log_norm_const_lb_ito" if weights else "log_norm_const_lb"
+    got, want = out.log_norm_const_preds[key], ref[key]
+    assert math.isfinite(got) and abs(got - want) <= 2e-3 * max(1.0, abs(want)), f"{tag}: {key} {got} vs {want}"
+    if weights:
+        got, want = out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"]
+        assert abs(got - want) <= 5e-3 * max(1.0, abs(want)), f"{tag}: log_norm_const_is {got} vs {want}"
+
+
+@pytest.mark.parametrize("case", range(N_TRAIN))
+def test_random_training_gradients_match_oracle(case):
+    """loss(...).backward() through the HIP forward + backward kernels vs the oracle's autograd, methods kl / kl_ito / lv."""
+    from sde_sampler_amd import problems
+
+    rng = np.random.default_rng(5000 + case)
+    spec = random_spec(rng)
+    method = str(rng.choice(["kl", "kl_ito", "lv"]))
+    spec["loss"]["method"] = method
+    spec["loss"]["max_rnd"] = 1e8 if method == "lv" else None
+    spec["batch"] = int(rng.choice([33, 64, 100]))  # at least two rows for the variance
+    prob = problems.build(spec)
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in prob.ctrl.state_dict().items()}
+    tt = None
+    if spec["target"]["kind"] == "gmm":
+        tt = dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+    oracle = eo.Problem(spec, params, tt)
+    ts = prob.ts.clone()
+    B, d, T = spec["batch"], spec["target"]["dim"], ts.numel() - 1
+    torch.manual_seed(case)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(T, B, d)
+    torch.set_num_threads(4)
+    ref_loss, _, _, _ = oracle.train_loss(ts, x0.clone(), noise, method=method)
+    ref_loss.backward()
+    prob.to(DEV)
+    val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
+    val.backward()
+    tag = f"case {case}: {method} {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"
+    assert abs(val.item() - ref_loss.item()) <= 2e-3 * max(1.0, abs(ref_loss.item())), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    gmax = max((p.grad.abs().max().item() for p in params.values() if p.grad is not None), default=0.0)
+    for k, p in prob.ctrl.named_parameters():
+        g_ref = params[k].grad
+        if g_ref is None:
+            continue
+        g = p.grad.cpu() if p.grad is not None else torch.zeros_like(g_ref)
+        # relative to the tensor's own scale, with a floor at 1e-4 of the largest gradient of the network (tiny gradients of
+        # e.g. a clamped gamma carry only rounding noise)
+        denom = max(g_ref.abs().max().item(), 1e-4 * gmax, 1e-12)
+        err = (g - g_ref).abs().max().item() / denom
+        assert err <= 5e-3, f"{tag}: grad {k} rel err {err:.2e}"

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 N_CASES = 96
 N_TRAIN = 32
+N_BRIDGE = 24
 
 
 def random_spec(rng: np.random.Generator) -> dict:
@@ -153,3 +154,74 @@ def test_random_training_gradients_match_oracle(case):
         denom = max(g_ref.abs().max().item(), 1e-4 * gmax, 1e-12)
         err = (g - g_ref).abs().max().item() / denom
         assert err <= 5e-3, f"{tag}: grad {k} rel err {err:.2e}"
+
+
+def random_bridge_spec(rng: np.random.Generator) -> dict:
+    while True:
+        spec = random_spec(rng)
+        if spec["loss"]["kind"] == "time_reversal" and spec["target"]["dim"] <= 10:
+            break
+    d = spec["target"]["dim"]
+    clip_active = rng.random() < 0.4
+    inf = dict(kind=str(rng.choice(["lerp_prior", "clipped"])), clip_model=float(rng.uniform(0.02, 0.5)) if clip_active else 1e4)
+    if inf["kind"] == "lerp_prior":
+        inf.update(clip_score=float(rng.uniform(0.5, 3.0)) if clip_active else 1e4, scale_score=float(rng.choice([1.0, 0.5])),
+                   gamma_dim=int(rng.choice([1, d])), gamma_bias=1.0)
+    spec["inference_ctrl"] = inf
+    spec["inference_net"] = dict(channels=64, num_layers=int(rng.integers(3, 6)), activation=str(rng.choice(["gelu", "silu", "relu"])))
+    spec["grid"]["steps"] = int(rng.integers(4, 17))
+    spec["batch"] = int(rng.choice([33, 64, 100]))
+    return spec
+
+
+@pytest.mark.parametrize("case", range(N_BRIDGE))
+def test_random_bridge_matches_oracle(case):
+    """Bridge (TimeReversalLoss with an inference control): evaluation and training gradients of both networks."""
+    from sde_sampler_amd import problems
+
+    rng = np.random.default_rng(9000 + case)
+    spec = random_bridge_spec(rng)
+    method = str(rng.choice(["kl", "kl_ito", "lv"]))
+    spec["loss"].update(method=method, max_rnd=1e8 if method == "lv" else None)
+    prob = problems.build(spec)
+    inf = prob.loss.inference_ctrl
+    leaf = lambda sd: {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    params, params_inf = leaf(prob.ctrl.state_dict()), leaf(inf.state_dict())
+    tt = None
+    if spec["target"]["kind"] == "gmm":
+        tt = dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+    oracle = eo.Problem(spec, params, tt, params_inf)
+    ts = prob.ts.clone()
+    B, d, T = spec["batch"], spec["target"]["dim"], ts.numel() - 1
+    torch.manual_seed(case)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(T, B, d)
+    torch.set_num_threads(4)
+    ref = oracle.eval(ts, x0.clone(), noise, compute_weights=True)
+    if not math.isfinite(ref["log_norm_const_lb_ito"]):  # a random configuration that blows up in the reference itself
+        prob.to(DEV)
+        out = prob.eval(x0.to(DEV), compute_weights=True, noise=noise.to(DEV))
+        assert not math.isfinite(out.log_norm_const_preds["log_norm_const_lb_ito"])
+        return
+    ref_loss, _, _, _ = oracle.train_loss(ts, x0.clone(), noise, method=method)
+    ref_loss.backward()
+    prob.to(DEV)
+    tag = f"case {case}: bridge {method} / {spec['ctrl']['kind']} + {spec['inference_ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"
+    out = prob.eval(x0.to(DEV), compute_weights=True, noise=noise.to(DEV))
+    row_err = (out.samples.cpu() - ref["samples"]).abs().amax(dim=1)
+    scale = max(1.0, float(ref["samples"].abs().max()))
+    assert row_err.median().item() <= 1e-4 * scale and (row_err > 2e-3 * scale).float().mean().item() <= 0.25, f"{tag}: x_T"
+    got, want = out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"]
+    assert abs(got - want) <= 2e-3 * max(1.0, abs(want)), f"{tag}: lb_ito {got} vs {want}"
+    val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
+    val.backward()
+    assert abs(val.item() - ref_loss.item()) <= 2e-3 * max(1.0, abs(ref_loss.item())), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    for mod, pd in ((prob.ctrl, params), (inf, params_inf)):
+        gmax = max((p.grad.abs().max().item() for p in pd.values() if p.grad is not None), default=0.0)
+        for k, p in mod.named_parameters():
+            g_ref = pd[k].grad
+            if g_ref is None:
+                continue
+            g = p.grad.cpu() if p.grad is not None else torch.zeros_like(g_ref)
+            err = (g - g_ref).abs().max().item() / max(g_ref.abs().max().item(), 1e-4 * gmax, 1e-12)
+            assert err <= 5e-3, f"{tag}: grad {k} rel err {err:.2e}"

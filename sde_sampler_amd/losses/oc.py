@@ -55,6 +55,23 @@ def _resolve_gaussian_log_prob(fn: Callable | None):
     return None
 
 
+def _world_size(group=None) -> int:
+    import torch.distributed as dist
+
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def _all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """SUM all-reduce of a few scalars (RCCL on the device for the nccl backend, through the host for gloo); returned on the CPU."""
+    import torch.distributed as dist
+
+    t = t.detach()
+    t = t.cpu() if dist.get_backend(group) == "gloo" else t.to(torch.float64)
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu()
+
+
 class BaseOCLoss:
     #: set to a torch.distributed process group (or leave None for the default group); evaluation statistics are
     #: merged across ranks whenever torch.distributed is initialised with world_size > 1
@@ -93,17 +110,40 @@ class BaseOCLoss:
         return mask & (rnd < self.max_rnd)
 
     def compute_loss(self, rnd: torch.Tensor, samples: torch.Tensor | None = None) -> tuple[torch.Tensor, dict]:
+        """The reference's loss over the batch (losses/oc.py:72-92).  Data-parallel (torch.distributed initialised with
+        world_size > 1): the loss of the GLOBAL batch, returned as this rank's additive share -- the shares sum to the global
+        loss and, after a SUM all-reduce of the parameter gradients (`utils.distributed.all_reduce_gradients`), every rank
+        holds the gradient of the global loss.  The log-variance loss needs the global mean of `rnd` first (one 3-float
+        all-reduce); with the mean taken as a constant the per-row gradients 2 (rnd_i - mean) / (N - 1) are exact,
+        because the omitted term is proportional to sum_i (rnd_i - mean) = 0 over the global batch."""
         mask = self.filter(rnd, samples=samples)
         assert mask.shape == rnd.shape
+        world = _world_size(self.process_group)
         if self.method == "lv_traj":
             rnd = rnd.reshape(self.traj_per_sample, -1, 1)
             mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)
-            self.n_filtered += self.traj_per_sample * (mask.numel() - mask.sum()).item()
-            loss = rnd[:, mask].var(dim=0).mean()
+            filtered = self.traj_per_sample * (mask.numel() - mask.sum())
+            if world == 1:
+                self.n_filtered += filtered.item()
+                return rnd[:, mask].var(dim=0).mean(), {"train/n_filtered_cumulative": self.n_filtered}
+            per_sample = rnd[:, mask].var(dim=0)
+            tot = _all_reduce_sum(torch.stack([mask.sum().double(), filtered.double()]), self.process_group)
+            self.n_filtered += int(tot[1].item())
+            loss = per_sample.sum() / tot[0].item()
         else:
-            self.n_filtered += (mask.numel() - mask.sum()).item()
-            loss = rnd[mask].var() if self.method == "lv" else rnd[mask].mean()
-        return loss, {"train/n_filtered_cumulative": self.n_filtered}
+            filtered = mask.numel() - mask.sum()
+            if world == 1:
+                self.n_filtered += filtered.item()
+                loss = rnd[mask].var() if self.method == "lv" else rnd[mask].mean()
+                return loss, {"train/n_filtered_cumulative": self.n_filtered}
+            kept = rnd[mask]
+            tot = _all_reduce_sum(torch.stack([mask.sum().double(), kept.detach().double().sum(), filtered.double()]),
+                                  self.process_group)
+            n_glob, mean_glob = tot[0].item(), tot[1].item() / tot[0].item()
+            self.n_filtered += int(tot[2].item())
+            loss = ((kept - mean_glob) ** 2).sum() / (n_glob - 1) if self.method == "lv" else kept.sum() / n_glob
+        glob = _all_reduce_sum(loss.detach().double().reshape(1), self.process_group)
+        return loss, {"train/n_filtered_cumulative": self.n_filtered, "train/loss_global": glob.item()}
 
     # -- evaluation statistics (reference 94-123) ---------------------------------------------------------------
     @staticmethod

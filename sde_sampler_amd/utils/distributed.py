@@ -1,0 +1,34 @@
+"""Data-parallel training helpers: trajectories are independent given the weights, so ranks hold batch shards
+and replicated parameters; per step there is the loss's tiny all-reduce (global mean of rnd, losses/oc.py compute_loss) and ONE
+gradient all-reduce over a single flat bucket (the control networks have 4e4 .. 2e5 parameters = 0.15 .. 0.8 MB of fp32:
+latency-bound on xGMI, so one collective, not one per tensor)."""
+from __future__ import annotations
+
+from typing import Iterable
+
+import torch
+
+
+def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None) -> None:
+    """SUM all-reduce of the `.grad`s in one flat bucket (in place).  With the loss classes' data-parallel loss shares the
+    result is the gradient of the global-batch loss on every rank.  No-op without an initialised process group."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in parameters if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    if dist.get_backend(group) == "gloo" and flat.is_cuda:
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat = host.to(flat.device)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    offset = 0
+    for p in params:
+        n = p.numel()
+        p.grad.copy_(flat[offset:offset + n].view_as(p))
+        offset += n

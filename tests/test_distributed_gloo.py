@@ -60,3 +60,76 @@ def test_two_rank_estimator_merge():
         assert est["var_rnd"] == pytest.approx(rnd.var().item(), rel=1e-4)
         assert est["log_norm_const_is"] == pytest.approx(((neg - m).exp().mean().log() + m).item(), abs=1e-4)
     assert results[0] == results[1]
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sde_sampler_amd.losses.oc import BaseOCLoss
+    from sde_sampler_amd.utils.distributed import all_reduce_gradients
+
+    torch.manual_seed(7)
+    theta = torch.nn.Parameter(torch.tensor([0.3, -1.2, 0.7]))  # replicated "network"
+    feats = torch.randn(4096, 3)                                # global batch
+    n = 4096 // world
+    out = {}
+    for method in ("lv", "kl", "lv_traj"):
+        loss_obj = BaseOCLoss(generative_ctrl=None, method=method, max_rnd=1e3, traj_per_sample=2 if method == "lv_traj" else 1)
+        f = feats[rank * n:(rank + 1) * n]
+        if method == "lv_traj":  # [traj_per_sample * samples]: two trajectories per sample, both on this rank
+            f = torch.cat([f[: n // 2], f[: n // 2] * 1.1 + 0.05])
+        rnd = (f @ theta).reshape(-1, 1) + 30.0 + (rank == 1) * (torch.arange(f.shape[0]).reshape(-1, 1) == 5) * 1e6  # one filtered row
+        theta.grad = None
+        share, metrics = loss_obj.compute_loss(rnd)
+        share.backward()
+        all_reduce_gradients([theta])
+        out[method] = (share.item(), metrics["train/loss_global"], theta.grad.clone(), loss_obj.n_filtered)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_loss_is_the_global_batch_loss():
+    """compute_loss under torch.distributed: the ranks' shares sum to the loss of the global batch and the all-reduced gradient is
+    its gradient (single-process computation on the concatenated batch)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(7)
+    theta = torch.nn.Parameter(torch.tensor([0.3, -1.2, 0.7]))
+    feats = torch.randn(4096, 3)
+    n = 2048
+    for method in ("lv", "kl", "lv_traj"):
+        parts = []
+        for rank in range(world):
+            f = feats[rank * n:(rank + 1) * n]
+            if method == "lv_traj":
+                f = torch.cat([f[: n // 2], f[: n // 2] * 1.1 + 0.05])
+            r = (f @ theta).reshape(-1, 1) + 30.0 + (rank == 1) * (torch.arange(f.shape[0]).reshape(-1, 1) == 5) * 1e6
+            parts.append(r)
+        theta.grad = None
+        if method == "lv_traj":
+            per = []
+            for r in parts:
+                r2 = r.reshape(2, -1, 1)
+                keep = (r2 < 1e3).all(dim=0)
+                per.append(r2[:, keep].var(dim=0))
+            ref = torch.cat(per).mean()
+        else:
+            allr = torch.cat(parts)
+            kept = allr[allr < 1e3]
+            ref = kept.var() if method == "lv" else kept.mean()
+        ref.backward()
+        shares = [results[r][method][0] for r in range(world)]
+        assert sum(shares) == pytest.approx(ref.item(), rel=1e-5)
+        for r in range(world):
+            assert results[r][method][1] == pytest.approx(ref.item(), rel=1e-5)
+            assert torch.allclose(results[r][method][2], theta.grad, rtol=1e-4, atol=1e-6), method
+            assert results[r][method][3] == (2 if method == "lv_traj" else 1)

@@ -98,7 +98,7 @@ def test_random_problem_matches_oracle(case):
     out = prob.eval(x0.to(DEV), compute_weights=weights, return_traj=True, noise=noise.to(DEV))
     tag = f"case {case}: {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T} {spec['net']}"
     # Per-row criterion: the dynamics amplify 1-ulp differences -- stiff wells with large steps and active clamps
-    # can take single rows from 2e-6 to 0.2 within 20 steps (tools/fuzz_case_debug.py shows the step-by-step growth of such a
+    # can take single rows from 2e-6 to 0.2 within 20 steps (tests/perf/fuzz_case_debug.py shows the step-by-step growth of such a
     # case) -- so the bulk of the rows must agree tightly and only a minority may have drifted.
     scale = max(1.0, float(ref["xs"].abs().max()))
     row_err = (out.xs.cpu() - ref["xs"]).abs().amax(dim=(0, 2))

@@ -17,7 +17,7 @@ namespace sdeh {
 // tin / tout: column jt of input_embed.weight / row jt of out_layer.weight in accumulator order (WsLayout::tan_in/out).
 // VEC (Hutchinson probe, utils/autograd.py:25-42): the tangent direction is the per-trajectory vector `eps` instead of e_jt
 // (seed = W_in eps through the input layer's MFMAs) and the read-out is the whole vector tvec = J eps.
-template <int DP, int C, bool VEC = false>
+template <int DP, int C, bool VEC = false, bool HALF = false>
 __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ lds, const WsLayout& L, int act,
                                                     const float* __restrict__ emb_step, const float* __restrict__ tin,
                                                     const float* __restrict__ tout, const float (&x)[DP],
@@ -60,10 +60,10 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
       for (int ot = 0; ot < OT; ++ot) {
         const float a = w[(r * OT + ot) * 64];
         accA[ot] = SDEH_MFMA(a, xa[r], accA[ot]);
-        accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
+        if constexpr (!HALF) accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
         if constexpr (VEC) {
           tA[ot] = SDEH_MFMA(a, ea[r], tA[ot]);
-          tB[ot] = SDEH_MFMA(a, eb[r], tB[ot]);
+          if constexpr (!HALF) tB[ot] = SDEH_MFMA(a, eb[r], tB[ot]);
         }
         if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
       }
@@ -77,9 +77,10 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         tA[ot][q] *= act_grad(accA[ot][q], act);
-        tB[ot][q] *= act_grad(accB[ot][q], act);
+        if constexpr (!HALF) tB[ot][q] *= act_grad(accB[ot][q], act);
       }
-    activate<OT>(accA, accB, act);
+    if constexpr (HALF) activate_one<OT>(accA, act);
+    else activate<OT>(accA, accB, act);
     if (l < L.n_hidden) {
       f32x16 nA[OT], nB[OT], ntA[OT], ntB[OT];
       const float* bias = lds + L.b_hid + l * C;
@@ -98,9 +99,11 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
           for (int ot = 0; ot < OT; ++ot) {
             const float a = w[((it * 16 + q) * OT + ot) * 64];
             nA[ot] = SDEH_MFMA(a, accA[it][q], nA[ot]);
-            nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
             ntA[ot] = SDEH_MFMA(a, tA[it][q], ntA[ot]);
-            ntB[ot] = SDEH_MFMA(a, tB[it][q], ntB[ot]);
+            if constexpr (!HALF) {
+              nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
+              ntB[ot] = SDEH_MFMA(a, tB[it][q], ntB[ot]);
+            }
             if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
           }
 #pragma unroll
@@ -117,14 +120,14 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
           for (int t = 0; t < OTD; ++t) {
             const float a = w[((it * 16 + q) * OTD + t) * 64];
             uA[t] = SDEH_MFMA(a, accA[it][q], uA[t]);
-            uB[t] = SDEH_MFMA(a, accB[it][q], uB[t]);
+            if constexpr (!HALF) uB[t] = SDEH_MFMA(a, accB[it][q], uB[t]);
             if constexpr (VEC) {
               if (it == 0 && q == 0) {
 #pragma unroll
                 for (int qq = 0; qq < 16; ++qq) tuA[t][qq] = tuB[t][qq] = 0.0f;
               }
               tuA[t] = SDEH_MFMA(a, tA[it][q], tuA[t]);
-              tuB[t] = SDEH_MFMA(a, tB[it][q], tuB[t]);
+              if constexpr (!HALF) tuB[t] = SDEH_MFMA(a, tB[it][q], tuB[t]);
             }
             if (t == OTD - 1 && (q & 1)) SDEH_FENCE();
           }
@@ -165,7 +168,7 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
   }
 }
 
-template <int DP, int C, bool PAD>
+template <int DP, int C, bool PAD, bool HALF>
 __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                      const float* __restrict__ noise, float* __restrict__ xT,
                                                      float* __restrict__ rnd_out, float* __restrict__ xs,
@@ -188,10 +191,13 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
   float* lg_lds = lds + L.lds_floats + L2.lds_floats + tid;  // [K][256] mixture-logit scratch
   __syncthreads();
 
-  const long long row = (long long)blockIdx.x * 256 + tid;
-  const bool live = row < A.batch;
+  // half: a wave carries 32 trajectories (lanes 0..31 = MFMA column tile A): half the dependent MFMA chain per step, for batches
+  // that leave SIMDs idle anyway (the step of this kernel is 1 + 2d network passes long, all latency at small batches)
+  constexpr int rpw = HALF ? 32 : 64;
+  const long long row = (long long)blockIdx.x * (4 * rpw) + (tid >> 6) * rpw + lane;
+  const bool live = lane < rpw && row < A.batch;
   const long long lrow = live ? row : A.batch - 1;
-  if ((long long)blockIdx.x * 256 + (tid & ~63) >= A.batch) return;
+  if ((long long)blockIdx.x * (4 * rpw) + (tid >> 6) * rpw >= A.batch) return;  // whole wave out of range
 
   const int d = PAD ? A.d : DP;
   float x[DP];
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
       float sterm[DP];
       ctrl_score_term<DP>(ctrl_kind, A, L, ws, i, cf, sig, tsc, psc, sterm);
       SDEH_FENCE();
-      mlp_forward<DP, C>(lds, L, act, ws + L.emb + i * C, x, u, lane);
+      mlp_forward<DP, C, HALF>(lds, L, act, ws + L.emb + i * C, x, u, lane);
 #pragma unroll
       for (int j = 0; j < DP; ++j) {
         u[j] = clipf(u[j], A.clip_model) + sterm[j];
@@ -251,14 +257,14 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
         eps[j] = (!PAD || j < d) ? ep[PAD ? min(j, d - 1) : j] : 0.0f;
         eps2[j] = eps[j] * eps[j];
       }
-      mlp_forward_tangent<DP, C, true>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, nullptr, nullptr, x, v, dummy, lane, eps, tv);
+      mlp_forward_tangent<DP, C, true, HALF>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, nullptr, nullptr, x, v, dummy, lane, eps, tv);
 #pragma unroll
       for (int j = 0; j < DP; ++j)
         div += (v[j] >= -A.inf_clip_model && v[j] <= A.inf_clip_model) ? eps[j] * tv[j] : 0.0f;
     } else
     for (int jt = 0; jt < d; ++jt) {  // one forward-mode tangent per coordinate
       float djj;
-      mlp_forward_tangent<DP, C>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, ws2 + L2.tan_in + jt * C,
+      mlp_forward_tangent<DP, C, false, HALF>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, ws2 + L2.tan_in + jt * C,
                                  ws2 + L2.tan_out + jt * C, x, v, djj, lane);
       float vj = 0.0f;
 #pragma unroll
@@ -709,14 +715,25 @@ int launch_bridge(const TrajArgs& a, hipStream_t stream) {
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_kernel<DP, C, PAD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_kernel<DP, C, PAD, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_kernel<DP, C, PAD, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((a.batch + 255) / 256);
-  hipLaunchKernelGGL((bridge_kernel<DP, C, PAD>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT,
-                     a.rnd, a.xs, a);
+  // 32 trajectories per wave (HALF) while that still leaves a SIMD per wave: the step is 1 + 2d dependent network passes, so
+  // small batches are latency-bound and halving the MFMA chain is worth more than filling the lanes
+  if (a.batch <= 32 * 1024) {
+    const unsigned grid = (unsigned)((a.batch + 127) / 128);
+    hipLaunchKernelGGL((bridge_kernel<DP, C, PAD, true>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
+                       a.xT, a.rnd, a.xs, a);
+  } else {
+    const unsigned grid = (unsigned)((a.batch + 255) / 256);
+    hipLaunchKernelGGL((bridge_kernel<DP, C, PAD, false>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
+                       a.xT, a.rnd, a.xs, a);
+  }
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

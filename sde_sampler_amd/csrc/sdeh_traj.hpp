@@ -84,6 +84,15 @@ __device__ __forceinline__ void activate(f32x16 (&a)[N], f32x16 (&b)[N], int act
   }
 }
 
+template <int N>
+__device__ __forceinline__ void activate_one(f32x16 (&a)[N], int act) {
+#pragma unroll
+  for (int t = 0; t < N; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      a[t][q] = act == SDEH_ACT_GELU_ERF ? act_gelu(a[t][q]) : (act == SDEH_ACT_SILU ? act_silu(a[t][q]) : act_relu(a[t][q]));
+}
+
 __device__ __forceinline__ f32x16 load16(const float* p) {
   f32x16 v;
   const float4* p4 = reinterpret_cast<const float4*>(p);
@@ -104,10 +113,11 @@ __device__ __forceinline__ f32x16 load16(const float* p) {
 // ---------------------------------------------------------------------------------------------------------
 // FourierMLP forward for 64 trajectories (models/mlp.py:114-122).  x, out in the T layout.
 // ---------------------------------------------------------------------------------------------------------
-template <int DP, int C>
+template <int DP, int C, bool HALF = false>
 __device__ __forceinline__ void mlp_forward(const float* __restrict__ lds, const WsLayout& L, int act,
                                             const float* __restrict__ emb_step, const float (&x)[DP],
                                             float (&out)[DP], int lane) {
+  // HALF: only lanes 0..31 carry trajectories (column tile A); tile B's MFMAs and activations are skipped (small batches)
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5;
   f32x16 accA[OT], accB[OT];
@@ -131,13 +141,14 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ lds, const
       for (int ot = 0; ot < OT; ++ot) {
         const float a = w[(r * OT + ot) * 64];
         accA[ot] = SDEH_MFMA(a, xa[r], accA[ot]);
-        accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
+        if constexpr (!HALF) accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
         if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
       }
   }
   f32x16 uA[OTD], uB[OTD];
   for (int l = 0; l <= L.n_hidden; ++l) {
-    activate<OT>(accA, accB, act);
+    if constexpr (HALF) activate_one<OT>(accA, act);
+    else activate<OT>(accA, accB, act);
     if (l < L.n_hidden) {  // hidden layers: e = layer(act(e))
       f32x16 nA[OT], nB[OT];
       const float* bias = lds + L.b_hid + l * C;
@@ -152,7 +163,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ lds, const
           for (int ot = 0; ot < OT; ++ot) {
             const float a = w[((it * 16 + q) * OT + ot) * 64];
             nA[ot] = SDEH_MFMA(a, accA[it][q], nA[ot]);
-            nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
+            if constexpr (!HALF) nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
             if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
           }
 #pragma unroll
@@ -169,7 +180,7 @@ __device__ __forceinline__ void mlp_forward(const float* __restrict__ lds, const
           for (int t = 0; t < OTD; ++t) {
             const float a = w[((it * 16 + q) * OTD + t) * 64];
             uA[t] = SDEH_MFMA(a, accA[it][q], uA[t]);
-            uB[t] = SDEH_MFMA(a, accB[it][q], uB[t]);
+            if constexpr (!HALF) uB[t] = SDEH_MFMA(a, accB[it][q], uB[t]);
             if (t == OTD - 1 && (q & 1)) SDEH_FENCE();
           }
     }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SDEH_ABI_VERSION 1
+#define SDEH_ABI_VERSION 2
 #define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
 
 typedef enum {
@@ -158,6 +158,11 @@ typedef struct {
   SdehDensity prior;                        /* prior_score of Lerp*Ctrl / reference_ctrl */
   SdehDensity second;                       /* initial_log_prob (DIS) or reference_log_prob (PIS/DDS) density */
   SdehInferenceCtrl inference;              /* read only with SDEH_FLAG_INFERENCE_CTRL */
+  /* Optional device-resident Philox offset (NULL = none): one uint64 in device memory that every kernel ADDS to its by-value
+   * `offset` argument when it starts.  Lets a captured hipGraph (forward + backward + optimizer step) be replayed with fresh noise:
+   * the launch arguments are frozen at capture time, the counter is bumped by a node inside the graph (the reference's
+   * torch.randn_like draws advance the generator's device-side offset under graph capture in the same way). */
+  const uint64_t* rng_offset_dev;
 } SdehProblem;
 
 typedef struct {

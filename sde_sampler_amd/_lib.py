@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-SDEH_ABI_VERSION = 1
+SDEH_ABI_VERSION = 2
 SDEH_MAX_HIDDEN = 8
 SDEH_REDUCE_SCRATCH = 8192
 
@@ -76,6 +76,7 @@ class SdehProblem(C.Structure):
         ("base_model", SdehFourierMLP), ("score_model", SdehTimeEmbed),
         ("target", SdehDensity), ("prior", SdehDensity), ("second", SdehDensity),
         ("inference", SdehInferenceCtrl),
+        ("rng_offset_dev", C.c_void_p),
     ]
 
 

@@ -450,7 +450,7 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
   A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
   A.second = {pr->second.kind, pr->second.n_components, pr->second.log_norm_const, pr->second.p0, pr->second.p1};
-  A.seed = seed; A.offset = offset;
+  A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
   A.inf_clip_model = inf.clip_model; A.inf_clip_score = inf.clip_score; A.inf_scale_score = inf.scale_score;
   A.gp = gp; A.div_noise = div_noise;
@@ -508,7 +508,7 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
   A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
   A.second = {pr->second.kind, pr->second.n_components, pr->second.log_norm_const, pr->second.p0, pr->second.p1};
-  A.seed = seed; A.offset = offset;
+  A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   // The wave-specialised kernel needs GMM tables in LDS; mixtures too large for that use the single-wave kernel
   // with scalar-load tables (also selectable with SDEH_LEGACY=1 for A/B measurements).
@@ -622,7 +622,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
   A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
   A.clip_target = pr->clip_target;
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
-  A.seed = seed; A.offset = offset;
+  A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   rc = ck.v->fn_bwd(A, st);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward: kernel launch failed");
 }
@@ -680,7 +680,7 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, cons
   A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
   A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
-  A.seed = seed; A.offset = offset;
+  A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   A.int_kind = kind; A.n_out = n_out; A.ts_out = ts_out;
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   rc = plan->variant->fn_int(A, st);

@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
     const float c_x = fmaf(cf[CF_DRIFT], dt, 1.0f), c_u = sig * dt, c_n = sig * sqdt;
     const float* __restrict__ np = noise != nullptr ? noise + ((long long)i * A.batch + lrow) * d : nullptr;
     const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+    const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
 #pragma unroll
     for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
       float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
         for (int q = 0; q < 4; ++q)
           if (4 * jb + q < DP) n[q] = np[PAD ? min(4 * jb + q, d - 1) : 4 * jb + q];
       } else if (!PAD || 4 * jb < d) {
-        box_muller4(philox_block(A.seed, A.offset, grow, i, jb), n);
+        box_muller4(philox_block(A.seed, rng_off, grow, i, jb), n);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {

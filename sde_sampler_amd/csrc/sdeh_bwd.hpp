@@ -62,7 +62,7 @@ __device__ __forceinline__ float act_grad2(float v, int act) {
 
 // store / load one [C][N] plane in the M layout: register q of lane (j,h), row tile ot, column tile A/B is
 // channel 32 ot + rho(q,h) of row n0 + j (+32)
-template <int OT>
+template <int OT, bool HALF = false>
 __device__ __forceinline__ void store_plane(float* __restrict__ plane, long long N, long long n0, int nrows, int lane,
                                             const f32x16 (&a)[OT], const f32x16 (&b)[OT]) {
   const int h = lane >> 5, j = lane & 31;
@@ -72,10 +72,12 @@ __device__ __forceinline__ void store_plane(float* __restrict__ plane, long long
     for (int q = 0; q < 16; ++q) {
       float* row = plane + (long long)(32 * ot + rho(q, h)) * N + n0 + j;
       if (j < nrows) row[0] = a[ot][q];
-      if (j + 32 < nrows) row[32] = b[ot][q];
+      if constexpr (!HALF) {
+        if (j + 32 < nrows) row[32] = b[ot][q];
+      }
     }
 }
-template <int OT>
+template <int OT, bool HALF = false>
 __device__ __forceinline__ void load_plane(const float* __restrict__ plane, long long N, long long n0, int nrows, int lane,
                                            f32x16 (&a)[OT], f32x16 (&b)[OT]) {
   const int h = lane >> 5, j = lane & 31;
@@ -85,7 +87,7 @@ __device__ __forceinline__ void load_plane(const float* __restrict__ plane, long
     for (int q = 0; q < 16; ++q) {
       const float* row = plane + (long long)(32 * ot + rho(q, h)) * N + n0 + j;
       a[ot][q] = j < nrows ? row[0] : 0.0f;
-      b[ot][q] = j + 32 < nrows ? row[32] : 0.0f;
+      if constexpr (!HALF) b[ot][q] = j + 32 < nrows ? row[32] : 0.0f;
     }
 }
 
@@ -126,7 +128,9 @@ __device__ __forceinline__ void target_score_jt(const DensArgs& D, const float* 
 }
 
 // One 64-row tile (step t, trajectories i0..i0+63).  BPTT: `lam` holds dLoss/dx_{t+1} on entry and dLoss/dx_t on exit.
-template <int DP, int C, bool PAD, bool BPTT>
+// HALF: 32-row tiles (lanes 0..31 = MFMA column tile A only; nrows <= 32) -- half the dependent MFMA chain and half the
+// activation work per wave, for back-propagation through time at batches that leave SIMDs idle.
+template <int DP, int C, bool PAD, bool BPTT, bool HALF = false>
 __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restrict__ lds, int t, long long i0, int nrows,
                                          int lane, float (&lam)[DP]) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
@@ -172,13 +176,14 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
       for (int ot = 0; ot < OT; ++ot) {
         const float a = w[(r * OT + ot) * 64];
         accA[ot] = SDEH_MFMA(a, xa[r], accA[ot]);
-        accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
+        if constexpr (!HALF) accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
         if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
       }
   }
-  store_plane<OT>(A.zt, N, n0, nrows, lane, accA, accB);
+  store_plane<OT, HALF>(A.zt, N, n0, nrows, lane, accA, accB);
   for (int l = 0; l < L.n_hidden; ++l) {
-    activate<OT>(accA, accB, act);
+    if constexpr (HALF) activate_one<OT>(accA, act);
+    else activate<OT>(accA, accB, act);
     f32x16 nA[OT], nB[OT];
     const float* bias = lds + L.b_hid + l * C;
 #pragma unroll
@@ -192,16 +197,17 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
         for (int ot = 0; ot < OT; ++ot) {
           const float a = w[((it * 16 + q) * OT + ot) * 64];
           nA[ot] = SDEH_MFMA(a, accA[it][q], nA[ot]);
-          nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
+          if constexpr (!HALF) nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
           if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
         }
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) { accA[ot] = nA[ot]; accB[ot] = nB[ot]; }
-    store_plane<OT>(A.zt + (long long)(l + 1) * C * N, N, n0, nrows, lane, accA, accB);
+    store_plane<OT, HALF>(A.zt + (long long)(l + 1) * C * N, N, n0, nrows, lane, accA, accB);
   }
   float nn[DP];
   {
-    activate<OT>(accA, accB, act);
+    if constexpr (HALF) activate_one<OT>(accA, act);
+    else activate<OT>(accA, accB, act);
     f32x16 uA[OTD], uB[OTD];
 #pragma unroll
     for (int tt = 0; tt < OTD; ++tt) uA[tt] = uB[tt] = load16(lds + L.b_out + (tt * 2 + h) * 16);
@@ -214,7 +220,7 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
         for (int tt = 0; tt < OTD; ++tt) {
           const float a = w[((it * 16 + q) * OTD + tt) * 64];
           uA[tt] = SDEH_MFMA(a, accA[it][q], uA[tt]);
-          uB[tt] = SDEH_MFMA(a, accB[it][q], uB[tt]);
+          if constexpr (!HALF) uB[tt] = SDEH_MFMA(a, accB[it][q], uB[tt]);
           if (tt == OTD - 1 && (q & 1)) SDEH_FENCE();
         }
 #pragma unroll
@@ -270,10 +276,11 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
       for (int j = 0; j < DP; ++j) xi[j] = np[PAD ? min(j, d - 1) : j];
     } else {
       const unsigned long long grow = (unsigned long long)(A.row_offset + irow);
+      const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
 #pragma unroll
       for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
         float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (!PAD || 4 * jb < d) box_muller4(philox_block(A.seed, A.offset, grow, t, jb), n);
+        if (!PAD || 4 * jb < d) box_muller4(philox_block(A.seed, rng_off, grow, t, jb), n);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (4 * jb + q < DP) xi[4 * jb + q] = n[q];
@@ -356,22 +363,22 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
       for (int ot = 0; ot < OT; ++ot) {
         const float a = w[(r * OT + ot) * 64];
         dA[ot] = SDEH_MFMA(a, ga[r], dA[ot]);
-        dB[ot] = SDEH_MFMA(a, gb[r], dB[ot]);
+        if constexpr (!HALF) dB[ot] = SDEH_MFMA(a, gb[r], dB[ot]);
         if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
       }
   }
   // ---- back through the layers: dZ_k = dA_k * act'(Z_k);  dA_{k-1} = W_{k-1}^T dZ_k ------------------------------------
   for (int k = L.n_hidden; k >= 0; --k) {
     f32x16 zA[OT], zB[OT];
-    load_plane<OT>(A.zt + (long long)k * C * N, N, n0, nrows, lane, zA, zB);
+    load_plane<OT, HALF>(A.zt + (long long)k * C * N, N, n0, nrows, lane, zA, zB);
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         dA[ot][q] *= act_grad(zA[ot][q], act);
-        dB[ot][q] *= act_grad(zB[ot][q], act);
+        if constexpr (!HALF) dB[ot][q] *= act_grad(zB[ot][q], act);
       }
-    store_plane<OT>(A.dt + (long long)k * C * N, N, n0, nrows, lane, dA, dB);
+    store_plane<OT, HALF>(A.dt + (long long)k * C * N, N, n0, nrows, lane, dA, dB);
     if (k > 0) {
       f32x16 pA[OT], pB[OT];
 #pragma unroll
@@ -387,7 +394,7 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
           for (int ot = 0; ot < OT; ++ot) {
             const float a = w[((it * 16 + q) * OT + ot) * 64];
             pA[ot] = SDEH_MFMA(a, dA[it][q], pA[ot]);
-            pB[ot] = SDEH_MFMA(a, dB[it][q], pB[ot]);
+            if constexpr (!HALF) pB[ot] = SDEH_MFMA(a, dB[it][q], pB[ot]);
             if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
           }
 #pragma unroll
@@ -414,7 +421,7 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
           for (int tt = 0; tt < OTD; ++tt) {
             const float a = w[((it * 16 + q) * OTD + tt) * 64];
             xA[tt] = SDEH_MFMA(a, dA[it][q], xA[tt]);
-            xB[tt] = SDEH_MFMA(a, dB[it][q], xB[tt]);
+            if constexpr (!HALF) xB[tt] = SDEH_MFMA(a, dB[it][q], xB[tt]);
             if (tt == OTD - 1 && (q & 1)) SDEH_FENCE();
           }
 #pragma unroll
@@ -446,8 +453,10 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
   }
 }
 
-template <int DP, int C, bool PAD, bool BPTT>
+template <int DP, int C, bool PAD, bool BPTT, bool HALF = false>
 __global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
+  static_assert(BPTT || !HALF, "32-row tiles are for back-propagation through time");
+  constexpr int TR = HALF ? 32 : 64;  // trajectories per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WsLayout& L = A.lay;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -469,9 +478,9 @@ __global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
     for (int j = 0; j < DP; ++j) lam[j] = 0.0f;
     bwd_tile<DP, C, PAD, false>(A, lds, t, i0, (int)(B - i0 < 64 ? B - i0 : 64), lane, lam);
   } else {
-    if (tile >= tiles_per_t) return;
-    const long long i0 = tile * 64;
-    const int nrows = (int)(B - i0 < 64 ? B - i0 : 64);
+    if (tile >= (B + TR - 1) / TR) return;
+    const long long i0 = tile * TR;
+    const int nrows = (int)(B - i0 < TR ? B - i0 : TR);
     const long long irow = lane < nrows ? i0 + lane : B - 1;
     const int d = PAD ? A.d : DP;
     // lambda_T = w_i d(terminal costs)/dx_T  (losses/oc.py:225,337,449-450)
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
 #pragma unroll
       for (int j = 0; j < DP; ++j) lam[j] = j < d ? lam[j] : 0.0f;
     }
-    for (int t = A.n_steps - 1; t >= 0; --t) bwd_tile<DP, C, PAD, true>(A, lds, t, i0, nrows, lane, lam);
+    for (int t = A.n_steps - 1; t >= 0; --t) bwd_tile<DP, C, PAD, true, HALF>(A, lds, t, i0, nrows, lane, lam);
   }
 }
 
@@ -521,12 +530,18 @@ int launch_ctrl_bwd(const BwdArgs& a, hipStream_t stream) {
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
-  const long long tiles = ((a.batch + 63) / 64) * (bptt ? 1 : a.n_steps);
+  // back-propagation through time is one dependent chain per wave: 32 trajectories per wave while that leaves a SIMD per wave
+  const bool half = bptt && a.batch <= 32 * 1024;
+  const long long tiles = half ? (a.batch + 31) / 32 : ((a.batch + 63) / 64) * (bptt ? 1 : a.n_steps);
   const dim3 grid((unsigned)((tiles + 3) / 4));
-  if (bptt) hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, true>), grid, dim3(256), lds_bytes, stream, a);
+  if (half) hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, true, true>), grid, dim3(256), lds_bytes, stream, a);
+  else if (bptt) hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, true>), grid, dim3(256), lds_bytes, stream, a);
   else hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, false>), grid, dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }

@@ -92,6 +92,7 @@ struct TrajArgs {
   float exp_sigma;
   DensArgs target, prior, second;
   unsigned long long seed, offset;
+  const unsigned long long* rng_dev;  // optional device-resident addend of `offset` (SdehProblem.rng_offset_dev)
   // sdeh_integrate only
   int int_kind, n_out;
   const float* ts_out;
@@ -147,7 +148,13 @@ struct BwdArgs {
   float clip_model, clip_score, scale_score, clip_target;
   DensArgs target;
   unsigned long long seed, offset;
+  const unsigned long long* rng_dev;
 };
+
+// effective Philox offset of a launch: by-value part + the optional device-resident counter (hipGraph replays)
+__device__ __forceinline__ unsigned long long philox_offset(unsigned long long offset, const unsigned long long* dev) {
+  return dev != nullptr ? offset + *dev : offset;
+}
 
 struct PrepArgs {
   float* ws;

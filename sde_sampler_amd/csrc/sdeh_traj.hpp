@@ -582,6 +582,7 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
     const float c_i = expo ? cf[CF_SBK] : sqdt;  // Ito term: sum(g * xi) * c_i
     const float* __restrict__ np = noise != nullptr ? noise + ((long long)i * A.batch + lrow) * d : nullptr;
     const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+    const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
 #pragma unroll
     for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
       float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
           for (int q = 0; q < 4; ++q)
             n[q] = __uint_as_float((__float_as_uint(x[(4 * jb + q) % DP]) & 0x007fffffu) | 0x3f800000u) - 1.5f;
         } else {
-          box_muller4(philox_block(A.seed, A.offset, grow, i, jb), n);
+          box_muller4(philox_block(A.seed, rng_off, grow, i, jb), n);
         }
       }
 #pragma unroll

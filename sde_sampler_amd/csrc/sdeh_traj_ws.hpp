@@ -473,6 +473,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
   const bool refc = REFC >= 0 ? REFC != 0 : (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
   const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+  const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
   __syncthreads();  // barrier A: x_0 published
 
   for (int i = 0; i < n_steps; ++i) {
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
             for (int q = 0; q < 4; ++q)
               n[q] = __uint_as_float((__float_as_uint(x[(4 * jb + q) % DP]) & 0x007fffffu) | 0x3f800000u) - 1.5f;
           } else {
-            box_muller4(philox_block(A.seed, A.offset, grow, i, jb), n);
+            box_muller4(philox_block(A.seed, rng_off, grow, i, jb), n);
           }
         }
 #pragma unroll

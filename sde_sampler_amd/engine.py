@@ -271,9 +271,14 @@ class TrajectoryEngine:
     def build_problem(self, *, loss_kind: int, generative_ctrl, sde, flags: int, device, keep: _Keep,
                       terminal_target=None, clip_target=None, second=None, reference_prior=None,
                       alpha: float = 0.0, sigma: float = 0.0, allow_inference_sde: bool = False,
-                      dim: int | None = None, inference_ctrl=None) -> L.SdehProblem:
+                      dim: int | None = None, inference_ctrl=None, rng_counter: torch.Tensor | None = None) -> L.SdehProblem:
         pr = L.SdehProblem()
         pr.loss_kind, pr.flags = loss_kind, flags
+        if rng_counter is not None:  # device-resident Philox offset (hipGraph replays, utils/graphs.py)
+            if not (rng_counter.is_cuda and rng_counter.dtype == torch.int64 and rng_counter.numel() == 1):
+                raise ValueError("rng_counter must be a one-element int64 tensor on the GPU")
+            keep.append(rng_counter)
+            pr.rng_offset_dev = rng_counter.data_ptr()
         if generative_ctrl is None:  # sdeh_integrate only: LangevinSDE / bare OU / ControlledSDE(ctrl=None)
             if not allow_inference_sde:
                 raise ValueError("generative_ctrl is None")

@@ -99,6 +99,13 @@ class BaseOCLoss:
         #: row index of this rank's first trajectory in the global batch (keeps the Philox streams of data-parallel
         #: ranks disjoint); set by the caller, e.g. rank * local_batch
         self.row_offset = 0
+        #: optional one-element int64 device tensor ADDED to the Philox offset inside the kernels (SdehProblem.rng_offset_dev):
+        #: launch arguments are frozen when a step is captured into a hipGraph, this counter is what moves between replays
+        self.rng_counter: torch.Tensor | None = None
+        #: True: `compute_loss` runs without host synchronisation (masked reductions instead of boolean indexing, the
+        #: filtered-sample count kept on the device) so that a whole training step can be captured (utils/graphs.py)
+        self.graph_safe = False
+        self._n_filtered_dev: torch.Tensor | None = None
 
     # -- filtering / loss value (reference 50-92) ------------------------------------------------------------
     def filter(self, rnd: torch.Tensor, samples: torch.Tensor | None = None) -> torch.Tensor:
@@ -119,6 +126,10 @@ class BaseOCLoss:
         mask = self.filter(rnd, samples=samples)
         assert mask.shape == rnd.shape
         world = _world_size(self.process_group)
+        if self.graph_safe:
+            if world != 1:
+                raise L.SdehUnsupported(-2, "graph_safe losses are single-process (the data-parallel shares go through the host)")
+            return self._compute_loss_on_device(rnd, mask)
         if self.method == "lv_traj":
             rnd = rnd.reshape(self.traj_per_sample, -1, 1)
             mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)
@@ -144,6 +155,30 @@ class BaseOCLoss:
             loss = ((kept - mean_glob) ** 2).sum() / (n_glob - 1) if self.method == "lv" else kept.sum() / n_glob
         glob = _all_reduce_sum(loss.detach().double().reshape(1), self.process_group)
         return loss, {"train/n_filtered_cumulative": self.n_filtered, "train/loss_global": glob.item()}
+
+    def _compute_loss_on_device(self, rnd: torch.Tensor, mask: torch.Tensor) -> tuple[torch.Tensor, dict]:
+        """compute_loss without a host round trip: same estimators (losses/oc.py:72-92) as masked reductions.  Rows the filter
+        drops contribute exactly zero value and zero gradient, as `rnd[mask]` does."""
+        zero = torch.zeros((), device=rnd.device, dtype=rnd.dtype)
+        if self.method == "lv_traj":
+            rnd = rnd.reshape(self.traj_per_sample, -1, 1)
+            mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)
+            kept = mask.sum()
+            filtered = self.traj_per_sample * (mask.numel() - kept)
+            clean = torch.where(mask.expand_as(rnd), rnd, zero)
+            loss = torch.where(mask, clean.var(dim=0), zero).sum() / kept
+        else:
+            kept = mask.sum()
+            filtered = mask.numel() - kept
+            mean = torch.where(mask, rnd, zero).sum() / kept
+            if self.method == "lv":
+                loss = (torch.where(mask, rnd - mean, zero) ** 2).sum() / (kept - 1)
+            else:
+                loss = mean
+        if self._n_filtered_dev is None:
+            self._n_filtered_dev = torch.zeros((), device=rnd.device, dtype=torch.int64)
+        self._n_filtered_dev += filtered
+        return loss, {"train/n_filtered_cumulative": self._n_filtered_dev}
 
     # -- evaluation statistics (reference 94-123) ---------------------------------------------------------------
     @staticmethod
@@ -173,9 +208,12 @@ class BaseOCLoss:
 
     def load_state_dict(self, state_dict: dict):
         self.n_filtered = state_dict["n_filtered"]
+        if self._n_filtered_dev is not None:
+            self._n_filtered_dev.zero_()
 
     def state_dict(self) -> dict:
-        return {"n_filtered": self.n_filtered}
+        on_device = 0 if self._n_filtered_dev is None else int(self._n_filtered_dev.item())
+        return {"n_filtered": self.n_filtered + on_device}
 
     # -- shared plumbing ----------------------------------------------------------------------------------------
     _LOSS_KIND = None
@@ -199,7 +237,8 @@ class BaseOCLoss:
                 flags |= L.FLAG_TERMINAL_SECOND
         problem_kwargs = dict(loss_kind=self._LOSS_KIND, generative_ctrl=self.generative_ctrl, sde=self.sde, flags=flags,
                               terminal_target=target, clip_target=clip_target, second=second,
-                              reference_prior=reference_prior, alpha=alpha, sigma=sigma, inference_ctrl=inference_ctrl)
+                              reference_prior=reference_prior, alpha=alpha, sigma=sigma, inference_ctrl=inference_ctrl,
+                              rng_counter=self.rng_counter)
 
         def run(return_traj: bool, want_state: bool = False, want_gp: bool = False):
             keep = E._Keep()

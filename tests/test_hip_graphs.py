@@ -1,0 +1,111 @@
+"""hipGraph replay of a training step (sde_sampler_amd/utils/graphs.py) and the device-resident Philox offset
+(SdehProblem.rng_offset_dev, include/sdeh.h) it relies on.  The graph-safe loss reductions are also covered on the CPU."""
+import copy
+
+import pytest
+import torch
+
+from sde_sampler_amd import problems
+from sde_sampler_amd.losses.oc import TimeReversalLoss
+
+
+def _masked_case(method, tps):
+    torch.manual_seed(3)
+    rnd = torch.randn(24 * tps, 1, dtype=torch.float64) * 3.0
+    rnd[5] = float("inf")
+    rnd[11] = float("nan")
+    return rnd.requires_grad_(True)
+
+
+@pytest.mark.parametrize("method,tps", [("kl", 1), ("kl_ito", 1), ("lv", 1), ("lv_traj", 4)])
+def test_graph_safe_loss_matches_reference_reduction(method, tps):
+    """losses/oc.py:72-92 as masked reductions: same value and the same gradient w.r.t. every rnd row (zero on filtered rows)."""
+    out = []
+    for safe in (False, True):
+        lo = TimeReversalLoss(generative_ctrl=None, sde=None, method=method, traj_per_sample=tps)
+        lo.graph_safe = safe
+        rnd = _masked_case(method, tps)
+        value, metrics = lo.compute_loss(rnd)
+        (g,) = torch.autograd.grad(value, rnd)
+        out.append((value.detach(), g, int(metrics["train/n_filtered_cumulative"]), lo.state_dict()["n_filtered"]))
+    (v0, g0, n0, s0), (v1, g1, n1, s1) = out
+    assert n0 == n1 == s0 == s1 and n0 > 0
+    torch.testing.assert_close(v1, v0, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(g1, g0, rtol=1e-10, atol=1e-12)
+
+
+def _build(seed=0, method="lv"):
+    spec = problems.baseline_spec("cfg1_dw_dis_lv")
+    spec["loss"]["method"] = method
+    torch.manual_seed(seed)
+    return problems.build(spec, device="cuda:0")
+
+
+@pytest.mark.gpu
+def test_device_offset_equals_by_value_offset():
+    """offset = 2 by value + 3 on the device draws exactly the noise of offset = 5 by value."""
+    prob = _build()
+    x = prob.prior.sample((1024,))
+    with torch.no_grad():
+        prob.loss.engine.calls = 5
+        a = prob.loss.simulate(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob, train=False, compute_ito_int=True)
+        prob.loss.engine.calls = 2
+        prob.loss.rng_counter = torch.tensor([3], dtype=torch.int64, device="cuda:0")
+        b = prob.loss.simulate(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob, train=False, compute_ito_int=True)
+        prob.loss.rng_counter.add_(1)
+        c = prob.loss.simulate(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob, train=False, compute_ito_int=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert not torch.equal(a[0], c[0])
+    with pytest.raises(ValueError):
+        prob.loss.rng_counter = torch.tensor([3.0], device="cuda:0")
+        prob.loss.simulate(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob, train=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["lv", "kl"])
+def test_graphed_train_step_matches_eager(method):
+    """W eager warm-up steps + K graph replays leave the parameters where W + K eager steps (same Philox offsets) leave them."""
+    from sde_sampler_amd.utils.graphs import COUNTER_START, GraphedTrainStep
+
+    W, K, B = 2, 5, 1024
+    prob_g, prob_e = _build(1, method), _build(1, method)
+    x = prob_g.prior.sample((B,))
+    for p, q in zip(prob_g.ctrl.parameters(), prob_e.ctrl.parameters()):
+        assert torch.equal(p, q)
+
+    def make(prob):
+        params = list(prob.ctrl.parameters())
+        opt = torch.optim.Adam(params, lr=2e-3, capturable=True)
+        fn = lambda: prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
+        clip = lambda: torch.nn.utils.clip_grad_norm_(params, 1.0)
+        return params, opt, fn, clip
+
+    params_g, opt_g, fn_g, clip_g = make(prob_g)
+    graphed = GraphedTrainStep(fn_g, [prob_g.loss], opt_g, after_backward=clip_g, warmup=W)
+    losses_g = [graphed().clone() for _ in range(K)]
+    assert int(graphed.counter) == COUNTER_START + W + K
+
+    params_e, opt_e, fn_e, clip_e = make(prob_e)
+    lo = prob_e.loss
+    lo.graph_safe, lo.rng_counter = True, torch.full((1,), COUNTER_START, dtype=torch.int64, device="cuda:0")
+
+    def eager_step():
+        opt_e.zero_grad(set_to_none=True)
+        value = fn_e()
+        value.backward()
+        clip_e()
+        opt_e.step()
+        lo.rng_counter.add_(1)
+        return value.detach().clone()
+
+    for _ in range(W):
+        eager_step()
+    frozen = lo.engine.calls  # the by-value offset the capture froze
+    losses_e = []
+    for _ in range(K):
+        lo.engine.calls = frozen
+        losses_e.append(eager_step())
+    torch.testing.assert_close(torch.stack(losses_g), torch.stack(losses_e), rtol=2e-4, atol=1e-5)
+    assert len({float(v) for v in losses_g}) == K  # fresh noise in every replay
+    for p, q in zip(params_g, params_e):
+        torch.testing.assert_close(p, q, rtol=2e-3, atol=2e-5)

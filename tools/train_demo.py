@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--method", default=None)
     ap.add_argument("--lr", type=float, default=5e-3)
+    ap.add_argument("--graph", action="store_true", help="capture the whole optimisation step into one hipGraph (utils/graphs.py)")
     args = ap.parse_args()
     if args.name == "bridge_dw":  # a Bridge (conf/solver/bridge.yaml style) on the shifted double well
         lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)  # conf/solver/bridge.yaml
@@ -43,7 +44,7 @@ def main():
         inf_params = list(prob.loss.inference_ctrl.parameters())
         groups.append(dict(params=inf_params, lr=0.02 * args.lr))
         train_params = train_params + inf_params
-    opt = torch.optim.Adam(groups)
+    opt = torch.optim.Adam(groups, capturable=args.graph)
 
     def evaluate(tag):
         x = prob.prior.sample((16384,))
@@ -56,14 +57,27 @@ def main():
         return err
 
     e0 = evaluate("init")
+    graphed = None
+    if args.graph:
+        from sde_sampler_amd.utils.graphs import GraphedTrainStep
+
+        def loss_fn():
+            x = prob.prior.sample((args.batch,))
+            return prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
+
+        graphed = GraphedTrainStep(loss_fn, [prob.loss], opt, warmup=3,
+                                   after_backward=lambda: torch.nn.utils.clip_grad_norm_(train_params, 1.0))
     t0 = t_last = time.perf_counter()
     for step in range(args.steps):
-        x = prob.prior.sample((args.batch,))
-        loss, _ = prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(train_params, 1.0)
-        opt.step()
+        if graphed is not None:
+            loss = graphed()
+        else:
+            x = prob.prior.sample((args.batch,))
+            loss, _ = prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(train_params, 1.0)
+            opt.step()
         if (step + 1) % 100 == 0:
             torch.cuda.synchronize()
             now = time.perf_counter()

@@ -368,9 +368,11 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
       }
   }
   // ---- back through the layers: dZ_k = dA_k * act'(Z_k);  dA_{k-1} = W_{k-1}^T dZ_k ------------------------------------
+  // Z_k comes back from the plane this wave wrote in the forward sweep; the load of Z_{k-1} is issued before the MFMA block of
+  // layer k so that its round trip is covered (the time loop of BPTT is one dependent chain)
+  f32x16 zA[OT], zB[OT];
+  load_plane<OT, HALF>(A.zt + (long long)L.n_hidden * C * N, N, n0, nrows, lane, zA, zB);
   for (int k = L.n_hidden; k >= 0; --k) {
-    f32x16 zA[OT], zB[OT];
-    load_plane<OT, HALF>(A.zt + (long long)k * C * N, N, n0, nrows, lane, zA, zB);
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
@@ -380,6 +382,7 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
       }
     store_plane<OT, HALF>(A.dt + (long long)k * C * N, N, n0, nrows, lane, dA, dB);
     if (k > 0) {
+      load_plane<OT, HALF>(A.zt + (long long)(k - 1) * C * N, N, n0, nrows, lane, zA, zB);
       f32x16 pA[OT], pB[OT];
 #pragma unroll
       for (int ot = 0; ot < OT; ++ot)

@@ -17,7 +17,9 @@ __device__ __forceinline__ float lerp_torch(float a, float b, float w) {
   return w < 0.5f ? a + w * diff : b - diff * (1.0f - w);
 }
 
-template <int DP, int C, bool PAD>
+// HALF: 32 trajectories per wave (lanes 0..31 = MFMA column tile A), used with a control network at batches that leave SIMDs
+// idle: the step is one dependent network pass, so halving the MFMA chain is worth more than filling the lanes.
+template <int DP, int C, bool PAD, bool HALF>
 __global__ __launch_bounds__(256) void integrate_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                         const float* __restrict__ noise, float* __restrict__ out,
                                                         const TrajArgs A) {
@@ -38,10 +40,11 @@ __global__ __launch_bounds__(256) void integrate_kernel(const float* __restrict_
   float* lg_lds = lds + L.lds_floats + tid;  // [K][256] mixture-logit scratch, column = thread
   __syncthreads();
 
-  const long long row = (long long)blockIdx.x * 256 + tid;
-  const bool live = row < A.batch;
+  constexpr int rpw = HALF ? 32 : 64;  // trajectories per wave
+  const long long row = (long long)blockIdx.x * (4 * rpw) + (tid >> 6) * rpw + lane;
+  const bool live = lane < rpw && row < A.batch;
   const long long lrow = live ? row : A.batch - 1;
-  if ((long long)blockIdx.x * 256 + (tid & ~63) >= A.batch) return;
+  if ((long long)blockIdx.x * (4 * rpw) + (tid >> 6) * rpw >= A.batch) return;  // whole wave out of range
 
   const int d = PAD ? A.d : DP;
   float x[DP];
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(const float* __restrict_
       float sterm[DP], u[DP];
       ctrl_score_term<DP>(ctrl_kind, A, L, ws, i, cf, sig, tsc, psc, sterm);
       SDEH_FENCE();
-      mlp_forward<DP, C>(lds, L, A.act, ws + L.emb + i * C, x, u, lane);
+      mlp_forward<DP, C, HALF>(lds, L, A.act, ws + L.emb + i * C, x, u, lane);
 #pragma unroll
       for (int j = 0; j < DP; ++j) dr[j] = fmaf(sig, clipf(u[j], A.clip_model) + sterm[j], fco * x[j]);
     } else {
@@ -128,14 +131,23 @@ int launch_integrate(const TrajArgs& a, hipStream_t stream) {
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_kernel<DP, C, PAD>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_kernel<DP, C, PAD, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_kernel<DP, C, PAD, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
-  const unsigned grid = (unsigned)((a.batch + 255) / 256);
-  hipLaunchKernelGGL((integrate_kernel<DP, C, PAD>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
-                     a.xs, a);
+  if (a.ctrl_kind != SDEH_CTRL_NONE && a.batch <= 32 * 1024) {
+    const unsigned grid = (unsigned)((a.batch + 127) / 128);
+    hipLaunchKernelGGL((integrate_kernel<DP, C, PAD, true>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
+                       a.xs, a);
+  } else {
+    const unsigned grid = (unsigned)((a.batch + 255) / 256);
+    hipLaunchKernelGGL((integrate_kernel<DP, C, PAD, false>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
+                       a.xs, a);
+  }
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

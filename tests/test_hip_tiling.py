@@ -66,3 +66,26 @@ def test_bridge_forward_64_row_tiles_match_32_row_tiles():
     xT1, rnd1, _ = sim(x[B // 2:], B // 2)
     assert torch.equal(xT, torch.cat([xT0, xT1]))
     torch.testing.assert_close(rnd, torch.cat([rnd0, rnd1]), rtol=1e-5, atol=1e-4)
+
+
+def test_controlled_integrator_64_row_tiles_match_32_row_tiles():
+    from sde_sampler_amd.eq.integrator import EulerIntegrator
+
+    meta = dict(target=dict(kind="double_well", dim=1, separation=2.0, shift=1.5), prior=dict(kind="iso_gauss", dim=1, loc=0.0, scale=1.0),
+                sde=dict(kind="vp", beta_min=0.1, beta_max=10.0, scale=1.0, terminal_t=1.0, generative=True),
+                ctrl=dict(kind="lerp", clip_model=1e4, clip_score=1e4, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                net=dict(channels=64, num_layers=4, activation="gelu"),
+                integrate=dict(kind="controlled"), grid=dict(start=0.0, end=1.0, steps=30))
+    torch.manual_seed(9)
+    sde, *_ = problems.build_integration(meta, device="cuda:0")
+    x0 = torch.randn(B, 1, device="cuda:0")
+    ts = torch.linspace(0.0, 1.0, 4, device="cuda:0")
+
+    def run(x, row_offset=0):
+        integ = EulerIntegrator(dt=None, steps=30)
+        integ.row_offset = row_offset
+        return integ.integrate(sde, ts=ts, x_init=x, seed=77)
+
+    full = run(x0)
+    halves = torch.cat([run(x0[: B // 2]), run(x0[B // 2:], row_offset=B // 2)], dim=1)
+    assert torch.equal(full, halves)

@@ -440,7 +440,7 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
   P2.prob.target.kind = P2.prob.prior.kind = P2.prob.second.kind = SDEH_DENS_NONE;  // the density tables live in region 1
   rc = launch_prep(P2, st);
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd (bridge): second prep kernel launch failed");
-  TrajArgs A;
+  TrajArgs A{};
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = L1; A.ws2 = plan->ws + L1.total; A.lay2 = L2;
   A.x0 = x0; A.noise = noise; A.xT = x_T; A.rnd = rnd; A.xs = xs;
@@ -497,7 +497,7 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float
   rc = launch_prep(P, st);
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd: prep kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
 
-  TrajArgs A;
+  TrajArgs A{};
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = L;
   A.x0 = x0; A.noise = noise; A.xT = x_T; A.rnd = rnd; A.xs = xs;
@@ -671,7 +671,7 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, cons
   P.ts_out = ts_out; P.n_out = n_out; P.eps = eps;
   rc = launch_prep(P, st);
   if (rc != SDEH_OK) return fail(rc, "integrate: prep kernel launch failed");
-  TrajArgs A;
+  TrajArgs A{};
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = ck.L;
   A.x0 = x_init; A.noise = noise; A.xs = xs_out;

@@ -72,13 +72,12 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
   float sA = 0.0f, sB = 0.0f;
   for (int l = 0; l <= L.n_hidden; ++l) {
     // a_l = act(z_l);  d a_l = act'(z_l) d z_l
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        tA[ot][q] *= act_grad(accA[ot][q], act);
-        if constexpr (!HALF) tB[ot][q] *= act_grad(accB[ot][q], act);
-      }
+    SDEH_ACT_SWITCH(act, ACT,
+      _Pragma("unroll") for (int ot = 0; ot < OT; ++ot)
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {
+          tA[ot][q] *= act_grad(accA[ot][q], ACT);
+          if constexpr (!HALF) tB[ot][q] *= act_grad(accB[ot][q], ACT);
+        });
     if constexpr (HALF) activate_one<OT>(accA, act);
     else activate<OT>(accA, accB, act);
     if (l < L.n_hidden) {
@@ -166,6 +165,141 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
     sB += __shfl_xor(sB, 32);
     djj = lane < 32 ? sA : sB;  // T layout: lane = trajectory (tile A: 0..31, tile B: 32..63)
   }
+}
+
+// ---- 32-row tiles: the activation derivatives stay in registers ------------------------------------------------------
+// With 32 trajectories per wave a layer's act'(z_l) is 2 x 16 registers, so the base pass of the inference network can keep
+// them for every layer (KC layers) and each coordinate's tangent becomes the bare recursion
+//     dz_0 = W_in[:, j];   dz_{l+1} = W_l (act'(z_l) . dz_l);   J_jj = W_out[j, :] (act'(z_Lh) . dz_Lh)
+// -- no second evaluation of the base network, of act or act' per coordinate: 1 + d hidden-layer MFMA blocks per step
+// instead of 1 + 2 d full passes.  Same operations in the same order as mlp_forward_tangent, hence the same bits.
+constexpr int kTanCache = 4;  // pre-activation layers kept (networks with n_hidden <= 3; deeper ones take the generic path)
+
+template <int DP, int C>
+__device__ __forceinline__ void mlp_forward_dcache(const float* __restrict__ lds, const WsLayout& L, int act,
+                                                   const float* __restrict__ emb_step, const float (&x)[DP],
+                                                   float (&out)[DP], int lane, f32x16 (&dc)[kTanCache][C / 32]) {
+  constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
+  const int h = lane >> 5;
+  f32x16 accA[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) accA[ot] = load16(emb_step + (ot * 2 + h) * 16);
+  {
+    float xa[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float v0 = x[mdim(r, 0)];
+      float v1 = mdim(r, 1) < DP ? x[mdim(r, 1)] : 0.0f;
+      swap32(v0, v1);
+      xa[r] = v0;
+    }
+    const float* w = lds + L.w_in + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot) {
+        accA[ot] = SDEH_MFMA(w[(r * OT + ot) * 64], xa[r], accA[ot]);
+        if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
+      }
+  }
+  f32x16 uA[OTD];
+#pragma unroll
+  for (int l = 0; l < kTanCache; ++l) {
+    if (l <= L.n_hidden) {
+      SDEH_ACT_SWITCH(act, ACT,
+        _Pragma("unroll") for (int ot = 0; ot < OT; ++ot)
+          _Pragma("unroll") for (int q = 0; q < 16; ++q) dc[l][ot][q] = act_grad(accA[ot][q], ACT););
+      activate_one<OT>(accA, act);
+      if (l < L.n_hidden) {
+        f32x16 nA[OT];
+        const float* bias = lds + L.b_hid + l * C;
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) nA[ot] = load16(bias + (ot * 2 + h) * 16);
+        const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
+#pragma unroll
+        for (int it = 0; it < OT; ++it)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+              nA[ot] = SDEH_MFMA(w[((it * 16 + q) * OT + ot) * 64], accA[it][q], nA[ot]);
+              if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+            }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) accA[ot] = nA[ot];
+      } else {
+#pragma unroll
+        for (int t = 0; t < OTD; ++t) uA[t] = load16(lds + L.b_out + (t * 2 + h) * 16);
+        const float* w = lds + L.w_out + lane;
+#pragma unroll
+        for (int it = 0; it < OT; ++it)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int t = 0; t < OTD; ++t) {
+              uA[t] = SDEH_MFMA(w[((it * 16 + q) * OTD + t) * 64], accA[it][q], uA[t]);
+              if (t == OTD - 1 && (q & 1)) SDEH_FENCE();
+            }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float v0 = uA[r / 16][r % 16];
+    float v1 = 0.0f;
+    swap32(v0, v1);  // lanes 0..31: v0 = coordinate mdim(r,0), v1 = coordinate mdim(r,1) (from lanes 32..63) of trajectory `lane`
+    out[mdim(r, 0)] = v0;
+    if (mdim(r, 1) < DP) out[mdim(r, 1)] = v1;
+  }
+}
+
+// J_jj for the coordinate whose tables are tin (column of input_embed.weight) / tout (row of out_layer.weight)
+template <int C>
+__device__ __forceinline__ float mlp_tangent_cached(const float* __restrict__ lds, const WsLayout& L,
+                                                    const float* __restrict__ tin, const float* __restrict__ tout,
+                                                    const f32x16 (&dc)[kTanCache][C / 32], int lane) {
+  constexpr int OT = C / 32;
+  const int h = lane >> 5;
+  f32x16 tA[OT];
+#pragma unroll
+  for (int ot = 0; ot < OT; ++ot) tA[ot] = load16(tin + (ot * 2 + h) * 16);
+  float s = 0.0f;
+#pragma unroll
+  for (int l = 0; l < kTanCache; ++l) {
+    if (l <= L.n_hidden) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tA[ot][q] *= dc[l][ot][q];
+      if (l < L.n_hidden) {
+        f32x16 ntA[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) ntA[ot][q] = 0.0f;
+        const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
+#pragma unroll
+        for (int it = 0; it < OT; ++it)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot) {
+              ntA[ot] = SDEH_MFMA(w[((it * 16 + q) * OT + ot) * 64], tA[it][q], ntA[ot]);
+              if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+            }
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) tA[ot] = ntA[ot];
+      } else {
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const f32x16 wr = load16(tout + (ot * 2 + h) * 16);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) s = fmaf(wr[q], tA[ot][q], s);
+        }
+      }
+    }
+  }
+  return s + __shfl_xor(s, 32);  // the other lane half holds the remaining channels of the same trajectory column
 }
 
 template <int DP, int C, bool PAD, bool HALF>
@@ -261,6 +395,19 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
 #pragma unroll
       for (int j = 0; j < DP; ++j)
         div += (v[j] >= -A.inf_clip_model && v[j] <= A.inf_clip_model) ? eps[j] * tv[j] : 0.0f;
+    } else if (HALF && L2.n_hidden < kTanCache && !A.half) {  // 32-row tiles: act'(z_l) of the base pass stays in registers
+      if constexpr (HALF) {
+        f32x16 dc[kTanCache][C / 32];
+        mlp_forward_dcache<DP, C>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, x, v, lane, dc);
+        for (int jt = 0; jt < d; ++jt) {
+          const float djj = mlp_tangent_cached<C>(lds2, L2, ws2 + L2.tan_in + jt * C, ws2 + L2.tan_out + jt * C, dc, lane);
+          float vj = 0.0f;
+#pragma unroll
+          for (int k = 0; k < DP; ++k) vj = k == jt ? v[k] : vj;
+          div += (vj >= -A.inf_clip_model && vj <= A.inf_clip_model) ? djj : 0.0f;
+          SDEH_FENCE();
+        }
+      }
     } else
     for (int jt = 0; jt < d; ++jt) {  // one forward-mode tangent per coordinate
       float djj;
@@ -517,13 +664,12 @@ __global__ __launch_bounds__(256) void bridge_div_bwd_kernel(const BridgeBwdArgs
       f32x16 zA[OT], zB[OT];
       load_plane<OT>(A.zt + (long long)l * plane, N, n0, nrows, lane, zA, zB);
       store_plane<OT>(tzj + (long long)l * plane, N, n0, nrows, lane, tA, tB);
-#pragma unroll
-      for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          tA[ot][q] *= act_grad(zA[ot][q], act);
-          tB[ot][q] *= act_grad(zB[ot][q], act);
-        }
+      SDEH_ACT_SWITCH(act, ACT,
+        _Pragma("unroll") for (int ot = 0; ot < OT; ++ot)
+          _Pragma("unroll") for (int q = 0; q < 16; ++q) {
+            tA[ot][q] *= act_grad(zA[ot][q], ACT);
+            tB[ot][q] *= act_grad(zB[ot][q], ACT);
+          });
       store_plane<OT>(taj + (long long)l * plane, N, n0, nrows, lane, tA, tB);
       if (l < Lh) {
         f32x16 nA[OT], nB[OT];
@@ -586,17 +732,16 @@ __global__ __launch_bounds__(256) void bridge_div_bwd_kernel(const BridgeBwdArgs
       load_plane<OT>(A.zt + (long long)l * plane, N, n0, nrows, lane, zA, zB);
       load_plane<OT>(tzj + (long long)l * plane, N, n0, nrows, lane, dzA, dzB);
       if (jt > 0) load_plane<OT>(A.d2 + (long long)l * plane, N, n0, nrows, lane, sA, sB);
-#pragma unroll
-      for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float s0 = act_grad2(zA[ot][q], act) * dzA[ot][q] * gA[ot][q];
-          const float s1 = act_grad2(zB[ot][q], act) * dzB[ot][q] * gB[ot][q];
-          sA[ot][q] = jt > 0 ? sA[ot][q] + s0 : s0;
-          sB[ot][q] = jt > 0 ? sB[ot][q] + s1 : s1;
-          gA[ot][q] *= act_grad(zA[ot][q], act);
-          gB[ot][q] *= act_grad(zB[ot][q], act);
-        }
+      SDEH_ACT_SWITCH(act, ACT,
+        _Pragma("unroll") for (int ot = 0; ot < OT; ++ot)
+          _Pragma("unroll") for (int q = 0; q < 16; ++q) {
+            const float s0 = act_grad2(zA[ot][q], ACT) * dzA[ot][q] * gA[ot][q];
+            const float s1 = act_grad2(zB[ot][q], ACT) * dzB[ot][q] * gB[ot][q];
+            sA[ot][q] = jt > 0 ? sA[ot][q] + s0 : s0;
+            sB[ot][q] = jt > 0 ? sB[ot][q] + s1 : s1;
+            gA[ot][q] *= act_grad(zA[ot][q], ACT);
+            gB[ot][q] *= act_grad(zB[ot][q], ACT);
+          });
       store_plane<OT>(A.d2 + (long long)l * plane, N, n0, nrows, lane, sA, sB);
       store_plane<OT>(tdj + (long long)l * plane, N, n0, nrows, lane, gA, gB);
       if (l > 0) {
@@ -647,13 +792,12 @@ __global__ __launch_bounds__(256) void bridge_div_bwd_kernel(const BridgeBwdArgs
     f32x16 zA[OT], zB[OT];
     load_plane<OT>(A.zt + (long long)(l - 1) * plane, N, n0, nrows, lane, zA, zB);
     load_plane<OT>(A.d2 + (long long)(l - 1) * plane, N, n0, nrows, lane, bA, bB);
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        bA[ot][q] = fmaf(act_grad(zA[ot][q], act), pA[ot][q], bA[ot][q]);
-        bB[ot][q] = fmaf(act_grad(zB[ot][q], act), pB[ot][q], bB[ot][q]);
-      }
+    SDEH_ACT_SWITCH(act, ACT,
+      _Pragma("unroll") for (int ot = 0; ot < OT; ++ot)
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {
+          bA[ot][q] = fmaf(act_grad(zA[ot][q], ACT), pA[ot][q], bA[ot][q]);
+          bB[ot][q] = fmaf(act_grad(zB[ot][q], ACT), pB[ot][q], bB[ot][q]);
+        });
     store_plane<OT>(A.d2 + (long long)(l - 1) * plane, N, n0, nrows, lane, bA, bB);
   }
   // ---- d / d x_t of the divergence term: W_in^T adj(z_0)  (kl: joins the back-propagation through time) ----------------------
@@ -724,12 +868,18 @@ int launch_bridge(const TrajArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
-  // 32 trajectories per wave (HALF) while that still leaves a SIMD per wave: the step is 1 + 2d dependent network passes, so
+  // 32 trajectories per wave (HALF) while that still leaves a SIMD per wave: the step is a chain of dependent network passes, so
   // small batches are latency-bound and halving the MFMA chain is worth more than filling the lanes
-  if (a.batch <= 32 * 1024) {
+  static const char* tiles = getenv("SDEH_BRIDGE_TILES");  // testing aid: "64" = 64-row tiles, "32g" = 32-row, generic tangents
+  // exact divergence with act' kept in registers (32-row tiles only): fewer MFMA passes per row than the 64-row tiles at
+  // every batch size (d = 2: 6.6 vs 8.0 ms at B = 65 536; d = 10: 13.4 vs 33.3 ms)
+  const bool cached = a.div_noise == nullptr && a.lay2.n_hidden < kTanCache;
+  if (((a.batch <= 32 * 1024 || cached) && !(tiles && tiles[0] == '6')) || (tiles && tiles[0] == '3')) {
+    TrajArgs b = a;
+    b.half = tiles && tiles[0] == '3' && tiles[2] == 'g' ? 1 : 0;  // here: 1 = do not keep act' in registers
     const unsigned grid = (unsigned)((a.batch + 127) / 128);
     hipLaunchKernelGGL((bridge_kernel<DP, C, PAD, true>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
-                       a.xT, a.rnd, a.xs, a);
+                       a.xT, a.rnd, a.xs, b);
   } else {
     const unsigned grid = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL((bridge_kernel<DP, C, PAD, false>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,

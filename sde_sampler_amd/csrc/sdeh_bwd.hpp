@@ -373,13 +373,12 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
   f32x16 zA[OT], zB[OT];
   load_plane<OT, HALF>(A.zt + (long long)L.n_hidden * C * N, N, n0, nrows, lane, zA, zB);
   for (int k = L.n_hidden; k >= 0; --k) {
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        dA[ot][q] *= act_grad(zA[ot][q], act);
-        if constexpr (!HALF) dB[ot][q] *= act_grad(zB[ot][q], act);
-      }
+    SDEH_ACT_SWITCH(act, ACT,
+      _Pragma("unroll") for (int ot = 0; ot < OT; ++ot)
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) {
+          dA[ot][q] *= act_grad(zA[ot][q], ACT);
+          if constexpr (!HALF) dB[ot][q] *= act_grad(zB[ot][q], ACT);
+        });
     store_plane<OT, HALF>(A.dt + (long long)k * C * N, N, n0, nrows, lane, dA, dB);
     if (k > 0) {
       load_plane<OT, HALF>(A.zt + (long long)(k - 1) * C * N, N, n0, nrows, lane, zA, zB);

@@ -84,13 +84,26 @@ __device__ __forceinline__ void activate(f32x16 (&a)[N], f32x16 (&b)[N], int act
   }
 }
 
+// Runs `...` with ACT a compile-time copy of the (wave-uniform) activation id: the dispatch sits OUTSIDE the element loops.
+// Selecting per element makes the compiler branch per element, which serialises the polynomial / v_exp chains of 32-64
+// independent elements (measured: 2.5x on the activation-heavy generic kernels).
+#define SDEH_ACT_SWITCH(act, ACT, ...)                                                            \
+  do {                                                                                            \
+    if ((act) == SDEH_ACT_GELU_ERF) { constexpr int ACT = SDEH_ACT_GELU_ERF; __VA_ARGS__ }        \
+    else if ((act) == SDEH_ACT_SILU) { constexpr int ACT = SDEH_ACT_SILU; __VA_ARGS__ }           \
+    else { constexpr int ACT = SDEH_ACT_RELU; __VA_ARGS__ }                                       \
+  } while (0)
+
+template <int ACT>
+__device__ __forceinline__ float act_ct(float v) {
+  return ACT == SDEH_ACT_GELU_ERF ? act_gelu(v) : (ACT == SDEH_ACT_SILU ? act_silu(v) : act_relu(v));
+}
+
 template <int N>
 __device__ __forceinline__ void activate_one(f32x16 (&a)[N], int act) {
-#pragma unroll
-  for (int t = 0; t < N; ++t)
-#pragma unroll
-    for (int q = 0; q < 16; ++q)
-      a[t][q] = act == SDEH_ACT_GELU_ERF ? act_gelu(a[t][q]) : (act == SDEH_ACT_SILU ? act_silu(a[t][q]) : act_relu(a[t][q]));
+  SDEH_ACT_SWITCH(act, ACT,
+    _Pragma("unroll") for (int t = 0; t < N; ++t)
+      _Pragma("unroll") for (int q = 0; q < 16; ++q) a[t][q] = act_ct<ACT>(a[t][q]););
 }
 
 __device__ __forceinline__ f32x16 load16(const float* p) {

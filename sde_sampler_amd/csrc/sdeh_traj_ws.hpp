@@ -427,8 +427,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     __syncthreads();  // barrier A: x_0 published
     for (int i = 0; i < n_steps; ++i) {
       if constexpr ((SDEH_ABL & 1) == 0) {
-        if (A.half) ws_mlp_half<DP, C>(lds, xbuf, L, act, emb, lane);
-        else ws_mlp<DP, C>(lds, xbuf, L, act, emb, lane);
+        // generic variants (ACT < 0): the activation id becomes a compile-time constant of three copies of the network --
+        // selecting it per element costs a scalar branch per element pair inside the MFMA stages (1.5x on the whole kernel)
+        SDEH_ACT_SWITCH(act, ACTC,
+          if (A.half) ws_mlp_half<DP, C>(lds, xbuf, L, ACTC, emb, lane);
+          else ws_mlp<DP, C>(lds, xbuf, L, ACTC, emb, lane););
       }
       __syncthreads();  // barrier B: network output published
       if (i + 1 < n_steps) {

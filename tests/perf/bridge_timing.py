@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Times the Bridge evaluation kernel (two networks + d forward-mode tangent passes per step) at eval-batch size."""
+"""Times the Bridge evaluation kernel (two network passes + d tangent recursions through the hidden layers per step) at
+eval-batch size."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import time
@@ -24,7 +25,6 @@ for name, tspec, B, T in [("basic_bridge gmm-fab d=2", dict(kind="gmm", dim=2, n
         r = prob.eval(x0, compute_weights=False)
         ms.append(prob.loss.engine.last_kernel_ms())
     best = min(ms[4:])
-    passes = 1 + 2 * d  # generative MLP + (base + tangent) per coordinate
     # CPU oracle (the reference loop restated: d autograd backward passes per step for the divergence), bounded sample
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     tt = None
@@ -38,5 +38,5 @@ for name, tspec, B, T in [("basic_bridge gmm-fab d=2", dict(kind="gmm", dim=2, n
     oracle.eval(prob.ts[: ns + 1].cpu(), x0[:nb].cpu(), None, compute_weights=False)
     cpu = nb * ns / (time.perf_counter() - t0)
     print(f"{name:28s} B={B} T={T} d={d}: kernel {best:8.3f} ms  {B * T / best / 1e6:6.3f} G traj-steps/s  "
-          f"({passes} MLP-widths of MFMA work per step)  lb={r.log_norm_const_preds['log_norm_const_lb']:+.4f}  | CPU oracle "
+          f"(2 network passes + {d} tangent recursions per step)  lb={r.log_norm_const_preds['log_norm_const_lb']:+.4f}  | CPU oracle "
           f"{cpu / 1e3:7.1f} k traj-steps/s ({nb} x {ns} steps, 32 threads) -> x{B * T / best * 1e3 / cpu:,.0f}", flush=True)

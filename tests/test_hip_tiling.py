@@ -45,27 +45,70 @@ def test_bptt_64_row_tiles_match_32_row_tiles():
         assert err < 2e-4, float(err)
 
 
-def test_bridge_forward_64_row_tiles_match_32_row_tiles():
-    lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
-    spec = dict(batch=B, target=dict(kind="double_well", dim=1, separation=2.0, shift=1.5),
-                prior=dict(kind="iso_gauss", dim=1), sde=dict(kind="scaled_bm", diff_coeff=2.0, terminal_t=1.0),
-                ctrl=dict(kind="lerp_target", **lerp), inference_ctrl=dict(kind="lerp_prior", **lerp),
-                net=dict(channels=64, num_layers=4, activation="gelu"),
-                loss=dict(kind="time_reversal", method="lv"), grid=dict(start=0.0, end=1.0, steps=40))
-    prob = _build(spec)
+BRIDGE_SPEC = dict(batch=B, target=dict(kind="double_well", dim=1, separation=2.0, shift=1.5),
+                   prior=dict(kind="iso_gauss", dim=1), sde=dict(kind="scaled_bm", diff_coeff=2.0, terminal_t=1.0),
+                   ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                   inference_ctrl=dict(kind="lerp_prior", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1,
+                                       gamma_bias=1.0),
+                   net=dict(channels=64, num_layers=4, activation="gelu"),
+                   loss=dict(kind="time_reversal", method="lv"), grid=dict(start=0.0, end=1.0, steps=40))
+
+
+def test_bridge_hutchinson_64_row_tiles_match_32_row_tiles():
+    """The probe-vector estimator has no per-coordinate redundancy, so batches > 32768 keep 64 trajectories per wave."""
+    prob = _build(dict(BRIDGE_SPEC, loss=dict(kind="time_reversal", method="lv", div_estimator="rademacher")))
     x = prob.prior.sample((B,))
+    eps = torch.randint(0, 2, (40, B, 1), device="cuda:0").float() * 2 - 1
     lo = prob.loss
 
-    def sim(xx, row_offset):
+    def sim(xx, e, row_offset):
         lo.row_offset, lo.engine.calls = row_offset, 3
         with torch.no_grad():
-            return lo.simulate(prob.ts, xx, prob.target.unnorm_log_prob, prob.second_log_prob, train=False, compute_ito_int=True)
+            return lo.simulate(prob.ts, xx, prob.target.unnorm_log_prob, prob.second_log_prob, train=True, compute_ito_int=True,
+                               change_sde_ctrl=True, div_noise=e)
 
-    xT, rnd, _ = sim(x, 0)
-    xT0, rnd0, _ = sim(x[: B // 2], 0)
-    xT1, rnd1, _ = sim(x[B // 2:], B // 2)
+    xT, rnd, _ = sim(x, eps, 0)
+    xT0, rnd0, _ = sim(x[: B // 2], eps[:, : B // 2].contiguous(), 0)
+    xT1, rnd1, _ = sim(x[B // 2:], eps[:, B // 2:].contiguous(), B // 2)
     assert torch.equal(xT, torch.cat([xT0, xT1]))
     torch.testing.assert_close(rnd, torch.cat([rnd0, rnd1]), rtol=1e-5, atol=1e-4)
+
+
+_TILES_SCRIPT = """
+import sys, torch
+sys.path.insert(0, {root!r})
+from sde_sampler_amd import problems
+spec = {spec!r}
+torch.manual_seed(5)
+prob = problems.build(spec, device="cuda:0")
+x = prob.prior.sample((4096,))
+prob.loss.engine.calls = 3
+with torch.no_grad():
+    xT, rnd, _ = prob.loss.simulate(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob, train=False, compute_ito_int=True)
+torch.save(dict(xT=xT.cpu(), rnd=rnd.cpu()), {out!r})
+"""
+
+
+def test_bridge_exact_divergence_tilings_agree(tmp_path):
+    """Exact divergence: 32-row tiles with act' kept in registers (the default), 32-row and 64-row tiles with the generic
+    base + tangent passes (SDEH_BRIDGE_TILES, read once per process -> one subprocess per setting)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    results = {}
+    for mode in ("", "32g", "64"):
+        out = str(tmp_path / f"tiles_{mode or 'default'}.pt")
+        env = dict(os.environ, SDEH_BRIDGE_TILES=mode)
+        if not mode:
+            env.pop("SDEH_BRIDGE_TILES")
+        subprocess.run([sys.executable, "-c", _TILES_SCRIPT.format(root=root, spec=dict(BRIDGE_SPEC, batch=4096), out=out)],
+                       check=True, env=env, timeout=600)
+        results[mode] = torch.load(out)
+    assert torch.equal(results[""]["xT"], results["64"]["xT"]) and torch.equal(results[""]["xT"], results["32g"]["xT"])
+    assert torch.equal(results[""]["rnd"], results["32g"]["rnd"])  # same operations in the same order
+    torch.testing.assert_close(results[""]["rnd"], results["64"]["rnd"], rtol=1e-5, atol=1e-4)
 
 
 def test_controlled_integrator_64_row_tiles_match_32_row_tiles():

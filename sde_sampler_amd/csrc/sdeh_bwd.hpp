@@ -66,29 +66,48 @@ template <int OT, bool HALF = false>
 __device__ __forceinline__ void store_plane(float* __restrict__ plane, long long N, long long n0, int nrows, int lane,
                                             const f32x16 (&a)[OT], const f32x16 (&b)[OT]) {
   const int h = lane >> 5, j = lane & 31;
+  float* __restrict__ base = plane + n0 + j;
+  if (j < nrows) {  // one predicated region per tile (not one per element)
 #pragma unroll
-  for (int ot = 0; ot < OT; ++ot)
+    for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float* row = plane + (long long)(32 * ot + rho(q, h)) * N + n0 + j;
-      if (j < nrows) row[0] = a[ot][q];
-      if constexpr (!HALF) {
-        if (j + 32 < nrows) row[32] = b[ot][q];
-      }
+      for (int q = 0; q < 16; ++q) base[(long long)(32 * ot + rho(q, h)) * N] = a[ot][q];
+  }
+  if constexpr (!HALF) {
+    if (j + 32 < nrows) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) base[(long long)(32 * ot + rho(q, h)) * N + 32] = b[ot][q];
     }
+  }
 }
 template <int OT, bool HALF = false>
 __device__ __forceinline__ void load_plane(const float* __restrict__ plane, long long N, long long n0, int nrows, int lane,
                                            f32x16 (&a)[OT], f32x16 (&b)[OT]) {
   const int h = lane >> 5, j = lane & 31;
+  const float* __restrict__ base = plane + n0 + j;
 #pragma unroll
   for (int ot = 0; ot < OT; ++ot)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const float* row = plane + (long long)(32 * ot + rho(q, h)) * N + n0 + j;
-      a[ot][q] = j < nrows ? row[0] : 0.0f;
-      if constexpr (!HALF) b[ot][q] = j + 32 < nrows ? row[32] : 0.0f;
+      a[ot][q] = 0.0f;
+      if constexpr (!HALF) b[ot][q] = 0.0f;
     }
+  if (j < nrows) {
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) a[ot][q] = base[(long long)(32 * ot + rho(q, h)) * N];
+  }
+  if constexpr (!HALF) {
+    if (j + 32 < nrows) {
+#pragma unroll
+      for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) b[ot][q] = base[(long long)(32 * ot + rho(q, h)) * N + 32];
+    }
+  }
 }
 
 // v = J^T c for the closed-form scores (the reference differentiates these through x; the mixture's autograd score is a

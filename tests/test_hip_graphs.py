@@ -35,10 +35,24 @@ def test_graph_safe_loss_matches_reference_reduction(method, tps):
 
 
 def _build(seed=0, method="lv"):
-    spec = problems.baseline_spec("cfg1_dw_dis_lv")
-    spec["loss"]["method"] = method
+    if method == "bridge":  # two networks, exact divergence: conf/solver/bridge.yaml style on the shifted double well
+        lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
+        spec = dict(batch=1024, target=dict(kind="double_well", dim=1, separation=2.0, shift=1.5),
+                    prior=dict(kind="iso_gauss", dim=1), sde=dict(kind="scaled_bm", diff_coeff=2.0, terminal_t=1.0),
+                    ctrl=dict(kind="lerp_target", **lerp), inference_ctrl=dict(kind="lerp_prior", **lerp),
+                    net=dict(channels=64, num_layers=4, activation="gelu"),
+                    loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=50))
+    else:
+        spec = problems.baseline_spec("cfg1_dw_dis_lv")
+        spec["loss"]["method"] = method
     torch.manual_seed(seed)
     return problems.build(spec, device="cuda:0")
+
+
+def _params(prob):
+    params = list(prob.ctrl.parameters())
+    inf = getattr(prob.loss, "inference_ctrl", None)
+    return params + (list(inf.parameters()) if inf is not None else [])
 
 
 @pytest.mark.gpu
@@ -62,7 +76,7 @@ def test_device_offset_equals_by_value_offset():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method", ["lv", "kl"])
+@pytest.mark.parametrize("method", ["lv", "kl", "bridge"])
 def test_graphed_train_step_matches_eager(method):
     """W eager warm-up steps + K graph replays leave the parameters where W + K eager steps (same Philox offsets) leave them."""
     from sde_sampler_amd.utils.graphs import COUNTER_START, GraphedTrainStep
@@ -70,11 +84,11 @@ def test_graphed_train_step_matches_eager(method):
     W, K, B = 2, 5, 1024
     prob_g, prob_e = _build(1, method), _build(1, method)
     x = prob_g.prior.sample((B,))
-    for p, q in zip(prob_g.ctrl.parameters(), prob_e.ctrl.parameters()):
+    for p, q in zip(_params(prob_g), _params(prob_e)):
         assert torch.equal(p, q)
 
     def make(prob):
-        params = list(prob.ctrl.parameters())
+        params = _params(prob)
         opt = torch.optim.Adam(params, lr=2e-3, capturable=True)
         fn = lambda: prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
         clip = lambda: torch.nn.utils.clip_grad_norm_(params, 1.0)

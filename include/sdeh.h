@@ -57,7 +57,8 @@ typedef enum {
   SDEH_DENS_FUNNEL = 4      /* p0 = variance of the first coordinate (default dim-1) */
 } SdehDensityKind;
 /* activation callable injected by conf/model/base/fouriermlp.yaml:5-6 (default torch.nn.GELU, exact erf) */
-typedef enum { SDEH_ACT_GELU_ERF = 0, SDEH_ACT_SILU = 1, SDEH_ACT_RELU = 2 } SdehActivation;
+typedef enum { SDEH_ACT_GELU_ERF = 0, SDEH_ACT_SILU = 1, SDEH_ACT_RELU = 2,
+               SDEH_ACT_IDENTITY = 3 /* sdeh_weight_grad only */ } SdehActivation;
 
 /* flags of simulate(): losses/oc.py:156-166 (train, compute_ito_int, change_sde_ctrl, return_traj) */
 enum {
@@ -346,6 +347,19 @@ int32_t sdeh_sinkhorn(const float* x, int64_t n, const float* y, int64_t m, int3
 int64_t sdeh_sample_stats_scratch_floats(int32_t d);
 int32_t sdeh_sample_stats(const float* samples, int64_t batch, int32_t d, const float* weights, const float* domain,
                           float* scratch, float* out, void* stream);
+
+/*
+ * Weight-gradient contraction over the N = n_steps * batch rows of the coordinate-major planes that sdeh_ctrl_backward[_ex] /
+ * sdeh_bridge_div_backward write -- what the reference's autograd accumulates into Linear.weight.grad / .bias.grad through its
+ * T per-step backward calls (models/mlp.py:114-122 under losses/oc.py:232-256):
+ *   part_w[k][i][j] = sum_{n in chunk k} D[i][n] * act(Z[j][n])      part_b[k][i] = sum_{n in chunk k} D[i][n]
+ * D [m, N] (m <= 64: d loss / d pre-activation of the layer above), Z [c, N] (c <= 64: pre-activations of the layer below;
+ * act = SDEH_ACT_IDENTITY when Z already holds the layer input).  chunk: rows per partial, a multiple of 8;
+ * n_chunks = ceil(N / chunk);  part_w [n_chunks, 64, 64] and part_b [n_chunks, 64] (rows >= m, columns >= c are zero).
+ * The caller sums the partials over k (deterministic: no atomics).  One pass over D and Z, activation applied on the fly.
+ */
+int32_t sdeh_weight_grad(const float* D, int32_t m, const float* Z, int32_t c, int64_t N, int32_t act, int64_t chunk,
+                         float* part_w, float* part_b, void* stream);
 
 /* Philox4x32-10 known-answer hook used by the tests: fills out[4*n] with the generator's raw words for
  * counters (row_offset+i, step, block, offset) and the (seed) key -- the exact stream sdeh_simulate_fwd consumes. */

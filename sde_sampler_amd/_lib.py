@@ -19,7 +19,7 @@ LOSS_TIME_REVERSAL, LOSS_REFERENCE_SDE, LOSS_EXPONENTIAL = 0, 1, 2
 CTRL_CLIPPED, CTRL_SCORE, CTRL_LERP, CTRL_LERP_TARGET, CTRL_LERP_PRIOR, CTRL_NONE = 0, 1, 2, 3, 4, 5
 SDE_NONE, SDE_VP, SDE_CONST_OU = 0, 1, 2
 DENS_NONE, DENS_GMM, DENS_DIAG_GAUSS, DENS_MULTI_WELL, DENS_FUNNEL = 0, 1, 2, 3, 4
-ACT_GELU_ERF, ACT_SILU, ACT_RELU = 0, 1, 2
+ACT_GELU_ERF, ACT_SILU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
 FLAG_TRAIN, FLAG_ITO, FLAG_CHANGE_SDE_CTRL, FLAG_INIT_LOGP = 1, 2, 4, 8
 FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL = 16, 32, 64
 FLAG_INFERENCE_SDE, FLAG_INFERENCE_CTRL = 128, 256
@@ -128,6 +128,7 @@ PROTOTYPES = {
                                   fp, fp, fp, fp, C.c_void_p]),
     "sdeh_sample_stats_scratch_floats": (C.c_int64, [C.c_int32]),
     "sdeh_sample_stats": (C.c_int32, [fp, C.c_int64, C.c_int32, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_weight_grad": (C.c_int32, [fp, C.c_int32, fp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, fp, fp, C.c_void_p]),
     "sdeh_reduce_estimators": (C.c_int32, [fp, C.c_int64, C.c_float, fp, fp, C.c_void_p]),
     "sdeh_importance_weights": (C.c_int32, [fp, C.c_int64, fp, fp, C.c_void_p]),
     "sdeh_debug_philox": (C.c_int32, [C.c_uint64, C.c_uint64, C.c_int64, C.c_int32, C.c_int32, C.c_int64, fp, C.c_void_p]),

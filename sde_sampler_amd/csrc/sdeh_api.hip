@@ -21,6 +21,8 @@ int launch_sink_finalize(const float* pm, const float* ps, int splits, long long
                          int* err_bits, const int* done, hipStream_t st);
 int launch_sink_check(int* flags, float thresh, hipStream_t st);
 int launch_sink_dist_final(const float* part, int nb, const int* flags, float* out, hipStream_t st);
+int launch_weight_grad(const float* D, int m, const float* Z, int c, long long N, int act, long long chunk, float* part_w,
+                       float* part_b, hipStream_t stream);
 int launch_sample_stats(const float* x, const float* w, const float* domain, long long B, int d, float* scratch, int nb,
                         float* out, hipStream_t st);
 
@@ -768,6 +770,16 @@ int32_t sdeh_sample_stats(const float* samples, int64_t batch, int32_t d, const 
   if (nb > kStatBlocks) nb = kStatBlocks;
   const int rc = launch_sample_stats(samples, weights, domain, batch, d, scratch, (int)nb, out, (hipStream_t)stream);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "sample_stats: launch failed");
+}
+
+int32_t sdeh_weight_grad(const float* D, int32_t m, const float* Z, int32_t c, int64_t N, int32_t act, int64_t chunk,
+                         float* part_w, float* part_b, void* stream) {
+  if (D == nullptr || Z == nullptr || part_w == nullptr || part_b == nullptr || N < 1)
+    return fail(SDEH_ERR_INVALID, "weight_grad: bad argument");
+  if (m < 1 || m > 64 || c < 1 || c > 64) return fail(SDEH_ERR_UNSUPPORTED, "weight_grad: m=%d c=%d (1..64)", m, c);
+  if (chunk < 8 || (chunk & 7) != 0) return fail(SDEH_ERR_INVALID, "weight_grad: chunk=%lld must be a positive multiple of 8", (long long)chunk);
+  const int rc = launch_weight_grad(D, m, Z, c, N, act, chunk, part_w, part_b, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "weight_grad: launch failed (act=%d)", act);
 }
 
 int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, float* scratch, float* out, void* stream) {

@@ -1,0 +1,164 @@
+// Weight-gradient contraction of the training backward:
+//     dW_k = sum_n Dt[k+1][:, n] act(Zt[k][:, n])^T      db_k = sum_n Dt[k+1][:, n]      (n over the N = T*B rows)
+// i.e. the per-parameter sums the reference's autograd accumulates through its T per-step Linear backward calls
+// (models/mlp.py:114-122 under losses/oc.py:232-256).  The planes the backward kernels write are coordinate-major
+// ([C][N], N contiguous), so both MFMA operands are K-contiguous: lane (j, h) streams row j as float4s along n and the
+// contraction index is simply enumerated in the order the lanes hold it -- no LDS staging, no transposition.  The
+// activation is applied to Z on the fly (the host used to run one GELU kernel, one split-K bmm, one sum and one bias
+// reduction per layer over planes that reach 1.7 GB each at B = 65 536: 10 passes over HBM instead of one).
+// One wave = one chunk of n = one [64, 64] partial (+ [64] bias partial); the chunks are summed by the caller.
+#include "sdeh_traj.hpp"
+
+namespace sdeh {
+
+constexpr int kActIdentity = 3;  // SDEH_ACT_IDENTITY: Z already holds activations (or plain inputs)
+
+template <int ACT>
+__device__ __forceinline__ float wg_act(float v) {
+  if constexpr (ACT == kActIdentity) return v;
+  else return act_ct<ACT>(v);
+}
+
+constexpr int kWgV = 4;               // float4 per lane, tile and iteration
+constexpr int kWgStep = 8 * kWgV;     // rows of n per iteration: lane half h covers [base + 16 h, base + 16 h + 16) -> whole 128-byte lines
+
+struct WgTile {
+  float4 v[kWgV];
+};
+
+// one tile row of this lane for the iteration starting at `base`; rows >= nrows and n >= n_end read as zero
+__device__ __forceinline__ void wg_load(WgTile& t, const float* __restrict__ row, bool on, long long n, long long n_end, bool fast) {
+  if (!on) {
+#pragma unroll
+    for (int k = 0; k < kWgV; ++k) t.v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else if (fast) {  // whole iteration inside the chunk, rows 16-byte aligned
+#pragma unroll
+    for (int k = 0; k < kWgV; ++k) t.v[k] = *reinterpret_cast<const float4*>(row + n + 4 * k);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kWgV; ++k) {
+      const long long q = n + 4 * k;
+      t.v[k].x = q < n_end ? row[q] : 0.0f;
+      t.v[k].y = q + 1 < n_end ? row[q + 1] : 0.0f;
+      t.v[k].z = q + 2 < n_end ? row[q + 2] : 0.0f;
+      t.v[k].w = q + 3 < n_end ? row[q + 3] : 0.0f;
+    }
+  }
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ D, int m, const float* __restrict__ Z, int c,
+                                                    long long N, long long chunk, long long n_chunks,
+                                                    float* __restrict__ part_w, float* __restrict__ part_b) {
+  const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  const long long ck = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ck >= n_chunks) return;
+  const long long n_begin = ck * chunk;
+  const long long n_end = n_begin + chunk < N ? n_begin + chunk : N;
+  const bool two_d = m > 32, two_z = c > 32;
+  // float4 loads when every row start is 16-byte aligned (n_begin is a multiple of 8)
+  const bool vec = (N & 3) == 0 && ((reinterpret_cast<unsigned long long>(D) | reinterpret_cast<unsigned long long>(Z)) & 15) == 0;
+  const bool d0 = j < m, d1 = 32 + j < m, z0 = j < c, z1 = 32 + j < c;
+  const float* __restrict__ Dr0 = D + (long long)(d0 ? j : 0) * N;
+  const float* __restrict__ Dr1 = D + (long long)(d1 ? 32 + j : 0) * N;
+  const float* __restrict__ Zr0 = Z + (long long)(z0 ? j : 0) * N;
+  const float* __restrict__ Zr1 = Z + (long long)(z1 ? 32 + j : 0) * N;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+  float bs0 = 0.0f, bs1 = 0.0f;
+
+  // lane (j, h) holds n = base + 16 h + {0..15}: k-step s contracts the pair (base + s, base + 16 + s).
+  // The next iteration's 16 float4 are in flight while this one's 64 MFMAs and 32 activations issue.
+  WgTile cd0, cd1, cz0, cz1, nd0, nd1, nz0, nz1;
+  {
+    const bool fast = vec && n_begin + kWgStep <= n_end;
+    const long long n = n_begin + 16 * h;
+    wg_load(cd0, Dr0, d0, n, n_end, fast);
+    wg_load(cd1, Dr1, d1, n, n_end, fast);
+    wg_load(cz0, Zr0, z0, n, n_end, fast);
+    wg_load(cz1, Zr1, z1, n, n_end, fast);
+  }
+  for (long long base = n_begin; base < n_end; base += kWgStep) {
+    const long long nb = base + kWgStep;
+    if (nb < n_end) {
+      const bool fast = vec && nb + kWgStep <= n_end;
+      const long long n = nb + 16 * h;
+      wg_load(nd0, Dr0, d0, n, n_end, fast);
+      wg_load(nd1, Dr1, d1, n, n_end, fast);
+      wg_load(nz0, Zr0, z0, n, n_end, fast);
+      wg_load(nz1, Zr1, z1, n, n_end, fast);
+    }
+#pragma unroll
+    for (int k = 0; k < kWgV; ++k) {
+      const float dd0[4] = {cd0.v[k].x, cd0.v[k].y, cd0.v[k].z, cd0.v[k].w};
+      const float dd1[4] = {cd1.v[k].x, cd1.v[k].y, cd1.v[k].z, cd1.v[k].w};
+      // rows >= c: the loads already returned zeros, but act(0) need not be 0 -> mask after the activation.  Elements past n_end
+      // carry D = 0, so their activation value is immaterial.
+      float a0[4] = {wg_act<ACT>(cz0.v[k].x), wg_act<ACT>(cz0.v[k].y), wg_act<ACT>(cz0.v[k].z), wg_act<ACT>(cz0.v[k].w)};
+      float a1[4] = {wg_act<ACT>(cz1.v[k].x), wg_act<ACT>(cz1.v[k].y), wg_act<ACT>(cz1.v[k].z), wg_act<ACT>(cz1.v[k].w)};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (!z0) a0[s] = 0.0f;
+        if (!z1) a1[s] = 0.0f;
+      }
+      bs0 += (dd0[0] + dd0[1]) + (dd0[2] + dd0[3]);
+      bs1 += (dd1[0] + dd1[1]) + (dd1[2] + dd1[3]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc[0][0] = SDEH_MFMA(dd0[s], a0[s], acc[0][0]);
+        if (two_z) acc[0][1] = SDEH_MFMA(dd0[s], a1[s], acc[0][1]);
+        if (two_d) {
+          acc[1][0] = SDEH_MFMA(dd1[s], a0[s], acc[1][0]);
+          if (two_z) acc[1][1] = SDEH_MFMA(dd1[s], a1[s], acc[1][1]);
+        }
+      }
+    }
+    cd0 = nd0; cd1 = nd1; cz0 = nz0; cz1 = nz1;
+  }
+
+  // partial [64][64]: accumulator q of lane (j, h) in tile (a, b) is element (32 a + rho(q, h), 32 b + j)
+  float* __restrict__ pw = part_w + ck * 4096;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pw[(32 * a + rho(q, h)) * 64 + 32 * b + j] = acc[a][b][q];
+  bs0 += __shfl_xor(bs0, 32);
+  bs1 += __shfl_xor(bs1, 32);
+  if (h == 0) {
+    part_b[ck * 64 + j] = bs0;
+    part_b[ck * 64 + 32 + j] = bs1;
+  }
+}
+
+int launch_weight_grad(const float* D, int m, const float* Z, int c, long long N, int act, long long chunk, float* part_w,
+                       float* part_b, hipStream_t stream) {
+  const long long n_chunks = (N + chunk - 1) / chunk;
+  const dim3 grid((unsigned)((n_chunks + 3) / 4));
+  switch (act) {
+    case SDEH_ACT_GELU_ERF:
+      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_GELU_ERF>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);
+      break;
+    case SDEH_ACT_SILU:
+      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_SILU>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);
+      break;
+    case SDEH_ACT_RELU:
+      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_RELU>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);
+      break;
+    case kActIdentity:
+      hipLaunchKernelGGL(wgrad_kernel<kActIdentity>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);
+      break;
+    default:
+      return SDEH_ERR_INVALID;
+  }
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+}  // namespace sdeh

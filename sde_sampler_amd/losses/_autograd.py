@@ -3,8 +3,9 @@
 `simulate_with_grad(...)` returns `(x_T, rnd, None)` like `simulate()`, with `rnd` attached to the autograd graph of the
 control network's parameters.  Forward = the HIP trajectory kernel (keeping the trajectory `xs`); backward =
 `sdeh_ctrl_backward` (HIP: per-row re-evaluation + back-propagation on the matrix pipe, noise replayed from the
-Philox counters; back-propagation through time for method "kl" / "kl_ito") followed by plain library GEMMs over the
-N = T*B rows for the weight gradients and by autograd on the two time-only sub-networks' [T, .] tables.
+Philox counters; back-propagation through time for method "kl" / "kl_ito") followed by `sdeh_weight_grad` (one pass over
+the N = T*B rows per layer: activation on the fly, MFMA contraction, bias sums) and by autograd on the two time-only
+sub-networks' [T, .] tables.
 
 `simulate_bridge_with_grad(...)` does the same for a Bridge (TimeReversalLoss with an inference control) and the
 log-variance methods: the generative network as above, the inference network through `sdeh_ctrl_backward_ex` (upstream
@@ -48,61 +49,60 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
     return zt, dt, dout, dgam
 
 
-def _nt(a: torch.Tensor, b: torch.Tensor, chunk: int = 4096) -> torch.Tensor:
-    """a [P, N] @ b[Q, N]^T with the long contraction split into chunks (a strided batched GEMM + a sum over the chunks):
-    rocBLAS runs a 64 x 64 x 2e5 product 5-20x faster this way, and a [64, N] @ [N, 1] product 25x
-    (tools/ubench/splitk_gemm.py)."""
-    P, N = a.shape
-    Q = b.shape[0]
-    S = N // chunk
-    if S < 2:
-        return a @ b.t()
-    main = S * chunk
-    out = torch.bmm(a[:, :main].view(P, S, chunk).transpose(0, 1), b[:, :main].view(Q, S, chunk).permute(1, 2, 0)).sum(dim=0)
-    if main < N:
-        out += a[:, main:] @ b[:, main:].t()
-    return out
+def _wgrad(dmat: torch.Tensor, z: torch.Tensor, act_id: int) -> tuple[torch.Tensor, torch.Tensor]:
+    """(dmat @ act(z)^T [m, c], dmat.sum(1) [m]) for coordinate-major planes dmat [m, N], z [c, N] in ONE pass over both
+    (sdeh_weight_grad: activation on the fly, K-contiguous MFMA operands, per-chunk partials summed here)."""
+    m, N = dmat.shape
+    c = z.shape[0]
+    dmat, z = dmat.contiguous(), z.contiguous()
+    # ~8192 partials (a few waves per SIMD hide the HBM latency); at least 128 rows per partial keeps the partial sums small
+    chunk = max(128, -(-N // 8192))
+    chunk = (chunk + 31) // 32 * 32
+    n_chunks = -(-N // chunk)
+    part_w = torch.empty((n_chunks, 64, 64), device=dmat.device, dtype=torch.float32)
+    part_b = torch.empty((n_chunks, 64), device=dmat.device, dtype=torch.float32)
+    with torch.cuda.device(dmat.device):
+        L.check(L.load().sdeh_weight_grad(dmat.data_ptr(), m, z.data_ptr(), c, N, act_id, chunk, part_w.data_ptr(),
+                                          part_b.data_ptr(), torch.cuda.current_stream(dmat.device).cuda_stream))
+    return part_w.sum(dim=0)[:m, :c].contiguous(), part_b.sum(dim=0)[:m].contiguous()
 
 
 def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, torch.Tensor]:
-    """Parameter gradients of one control from the coordinate-major planes (GEMMs over N; autograd on the [T, .] tables of
-    the two time-only sub-networks).  `extra`: additive second-order contributions of the Bridge divergence term."""
+    """Parameter gradients of one control from the coordinate-major planes (sdeh_weight_grad over N; autograd on the [T, .]
+    tables of the two time-only sub-networks).  `extra`: additive second-order contributions of the Bridge divergence term."""
     base = ctrl.base_model
     T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
     N, Cn, Lh = T * B, base.channels, len(base.hidden_layer)
     score_model = getattr(ctrl, "score_model", None)
     g = 0 if score_model is None else score_model.out_layer.out_features
-    act = base.activation
+    act_id = E._activation_id(base.activation)
     grads: dict[int, torch.Tensor] = {}
     extra = extra or {}
     with torch.no_grad():
         Xt = xs[:T].reshape(N, d).t().contiguous()  # [d, N]
         d0 = dt[0] + extra["d2"][0] if "d2" in extra else dt[0]
-        grads[id(base.input_embed.weight)] = _nt(d0, Xt)
+        grads[id(base.input_embed.weight)] = _wgrad(d0, Xt, L.ACT_IDENTITY)[0]
         d_emb = d0.reshape(Cn, T, B).sum(dim=2).t().contiguous()  # [T, C]: gradient of the time embedding table
         grads[id(base.input_embed.bias)] = d_emb.sum(dim=0)
         for k in range(Lh + 1):
-            a_k = act(zt[k])
             if k < Lh:
                 lin = base.hidden_layer[k]
                 dk = dt[k + 1] + extra["d2"][k + 1] if "d2" in extra else dt[k + 1]
-                grads[id(lin.weight)] = _nt(dk, a_k)
-                grads[id(lin.bias)] = dk.sum(dim=1)
+                grads[id(lin.weight)], grads[id(lin.bias)] = _wgrad(dk, zt[k], act_id)
             else:
-                grads[id(base.out_layer.weight)] = _nt(dout, a_k)
-                grads[id(base.out_layer.bias)] = dout.sum(dim=1)
+                grads[id(base.out_layer.weight)], grads[id(base.out_layer.bias)] = _wgrad(dout, zt[k], act_id)
         if "td" in extra and extra.get("eps") is not None:  # Hutchinson: one tangent stream in direction eps
             td, ta, cj = extra["td"], extra["ta"], extra["cj"]
-            grads[id(base.input_embed.weight)] += _nt(td[0, 0], extra["eps"].reshape(N, d).t().contiguous())
+            grads[id(base.input_embed.weight)] += _wgrad(td[0, 0], extra["eps"].reshape(N, d).t().contiguous(), L.ACT_IDENTITY)[0]
             for k in range(Lh):
-                grads[id(base.hidden_layer[k].weight)] += _nt(td[0, k + 1], ta[0, k])
-            grads[id(base.out_layer.weight)] += _nt(cj, ta[0, Lh])
+                grads[id(base.hidden_layer[k].weight)] += _wgrad(td[0, k + 1], ta[0, k], L.ACT_IDENTITY)[0]
+            grads[id(base.out_layer.weight)] += _wgrad(cj, ta[0, Lh], L.ACT_IDENTITY)[0]
         elif "td" in extra:  # tangent streams of the divergence term, one per coordinate j
             td, ta, cj = extra["td"], extra["ta"], extra["cj"]
             for j in range(d):
                 grads[id(base.input_embed.weight)][:, j] += td[j, 0].sum(dim=1)
                 for k in range(Lh):
-                    grads[id(base.hidden_layer[k].weight)] += _nt(td[j, k + 1], ta[j, k])
+                    grads[id(base.hidden_layer[k].weight)] += _wgrad(td[j, k + 1], ta[j, k], L.ACT_IDENTITY)[0]
                 grads[id(base.out_layer.weight)][j] += (ta[j, Lh] * cj[j][None, :]).sum(dim=1)
     # the two time-only sub-networks: differentiate their [T, .] tables
     with torch.enable_grad():

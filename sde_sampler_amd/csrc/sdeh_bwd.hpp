@@ -476,7 +476,7 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
 
 template <int DP, int C, bool PAD, bool BPTT, bool HALF = false>
 __global__ __launch_bounds__(256) void ctrl_bwd_kernel(const BwdArgs A) {
-  static_assert(BPTT || !HALF, "32-row tiles are for back-propagation through time");
+  static_assert(BPTT == HALF, "row-parallel mode uses 64-row tiles, back-propagation through time 32-row tiles");
   constexpr int TR = HALF ? 32 : 64;  // trajectories per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WsLayout& L = A.lay;
@@ -549,20 +549,17 @@ int launch_ctrl_bwd(const BwdArgs& a, hipStream_t stream) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD, true, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
-  // back-propagation through time is one dependent chain per wave: 32 trajectories per wave while that leaves a SIMD per wave
-  const bool half = bptt && a.batch <= 32 * 1024;
-  const long long tiles = half ? (a.batch + 31) / 32 : ((a.batch + 63) / 64) * (bptt ? 1 : a.n_steps);
+  // Back-propagation through time is one dependent chain per wave and always runs 32-row tiles: half the MFMA chain per wave at
+  // small batches (latency), no register spills and the same MFMA work per row at large ones (measured equal or faster than
+  // 64-row tiles from B = 2048 to 131 072, tests/perf/bptt_tiles_timing.py history in DESIGN.md 3b).
+  const long long tiles = bptt ? (a.batch + 31) / 32 : ((a.batch + 63) / 64) * a.n_steps;
   const dim3 grid((unsigned)((tiles + 3) / 4));
-  if (half) hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, true, true>), grid, dim3(256), lds_bytes, stream, a);
-  else if (bptt) hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, true>), grid, dim3(256), lds_bytes, stream, a);
+  if (bptt) hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, true, true>), grid, dim3(256), lds_bytes, stream, a);
   else hipLaunchKernelGGL((ctrl_bwd_kernel<DP, C, PAD, false>), grid, dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }

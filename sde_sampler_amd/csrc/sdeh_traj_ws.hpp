@@ -382,6 +382,88 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
   for (int r = 0; r < R; ++r) xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j] = u[r / 16][r % 16];
 }
 
+// One output tile: out += W[s][tile] * in(s) for NS k-steps; `w` already points at the tile's column of the packed weights,
+// WOT = number of output tiles packed per k-step (the stride between k-steps).  Same operand prefetch as mfma_stage.
+template <int NS, int WOT, class IN>
+__device__ __forceinline__ void mfma_stage_one(const float* __restrict__ w, IN&& in, f32x16& out) {
+  constexpr int PF = NS < 6 ? NS : 6;
+  float wq[PF];
+#pragma unroll
+  for (int s = 0; s < PF; ++s) wq[s] = w[s * WOT * 64];
+  SDEH_FENCE();
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const float a = wq[s % PF];
+    if (s + PF < NS) wq[s % PF] = w[(s + PF) * WOT * 64];
+    out = SDEH_MFMA(a, in(s), out);
+    SDEH_FENCE();
+  }
+}
+
+// Pair mode for the smallest batches (TrajArgs::half == 2, C = 64): TWO M waves serve one group of 32 trajectories, wave `mw`
+// owning output-channel tile mw of every layer (half the MFMAs and half the activations of the dependent chain per wave).  Each
+// layer's input is both tiles, so after activating its tile a wave parks it in `abuf` (double-buffered by layer parity), the
+// workgroup barrier makes both tiles visible, and the other tile is read back in the same (register, lane) arrangement.  The
+// k-steps run in the order of ws_mlp_half (tile 0's channels, then tile 1's), so the results are bit-identical to it.
+template <int DP, int C, int ACT>
+__device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float* __restrict__ xbuf, float* __restrict__ abuf,
+                                            const WsLayout& L, const f32x16& emb_mine, int lane, int mw, int& parity) {
+  static_assert(C == 64, "pair mode splits the two 32-channel tiles of a 64-channel network");
+  constexpr int OT = 2, OTD = row_tiles(DP), R = mregs(DP);
+  const int h = lane >> 5, j = lane & 31;
+  f32x16 mine = emb_mine, other;
+  {
+    float xa[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) xa[r] = xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j];
+    mfma_stage_one<R, OT>(lds + L.w_in + mw * 64 + lane, [&](int s) { return xa[s]; }, mine);
+  }
+  auto exchange = [&]() {  // mine <- act(mine); other <- the partner's activated tile
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mine[q] = act_ct<ACT>(mine[q]);
+    float* __restrict__ mb = abuf + ((parity * 2 + mw) * 16) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) mb[q * 64] = mine[q];
+    __syncthreads();
+    const float* __restrict__ ob = abuf + ((parity * 2 + (1 - mw)) * 16) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) other[q] = ob[q * 64];
+    parity ^= 1;
+  };
+  // out += W[:, tile] . [a(tile 0 channels); a(tile 1 channels)], k-steps in channel order
+  auto layer = [&](const float* __restrict__ w, auto wot, f32x16& out) {
+    constexpr int WOT = decltype(wot)::value;
+    if (mw == 0) {
+      mfma_stage_one<16, WOT>(w, [&](int s) { return mine[s]; }, out);
+      mfma_stage_one<16, WOT>(w + 16 * WOT * 64, [&](int s) { return other[s]; }, out);
+    } else {
+      mfma_stage_one<16, WOT>(w, [&](int s) { return other[s]; }, out);
+      mfma_stage_one<16, WOT>(w + 16 * WOT * 64, [&](int s) { return mine[s]; }, out);
+    }
+  };
+  for (int l = 0; l < L.n_hidden; ++l) {
+    exchange();
+    f32x16 nxt = load16(lds + L.b_hid + l * C + (mw * 2 + h) * 16);
+    layer(lds + L.w_hid + l * L.w_hid_stride + mw * 64 + lane, std::integral_constant<int, OT>{}, nxt);
+    mine = nxt;
+  }
+  exchange();
+  if constexpr (OTD == 1) {  // d <= 32: one output tile, wave 0 computes it
+    if (mw == 0) {
+      f32x16 u = load16(lds + L.b_out + h * 16);
+      layer(lds + L.w_out + lane, std::integral_constant<int, 1>{}, u);
+#pragma unroll
+      for (int r = 0; r < R; ++r) xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j] = u[r];
+    }
+  } else {  // two output tiles: one each
+    f32x16 u = load16(lds + L.b_out + (mw * 2 + h) * 16);
+    layer(lds + L.w_out + mw * 64 + lane, std::integral_constant<int, OTD>{}, u);
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (r / 16 == mw) xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j] = u[r % 16];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------
@@ -397,8 +479,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_groups = (int)(blockDim.x >> 7);
+  const bool pair = A.half == 2;  // one group, three waves: V, M(tile 0), M(tile 1)
   const bool is_m = wave >= n_groups;
-  const int group = is_m ? wave - n_groups : wave;
+  const int group = pair ? 0 : (is_m ? wave - n_groups : wave);
 
   {  // stage the LDS image (packed weights + GMM tables) once per workgroup
     const float4* src = reinterpret_cast<const float4*>(ws);
@@ -421,6 +504,22 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     __builtin_amdgcn_s_setprio(SDEH_MPRIO);
 #endif
     __syncthreads();  // LDS image staged
+    if constexpr (C == 64) {
+      if (pair) {
+        const int mw = wave - 1;
+        float* __restrict__ abuf = xbuf + XR * 64;
+        int parity = 0;
+        f32x16 emb1 = load16(ws + L.emb + (mw * 2 + h) * 16);
+        __syncthreads();  // barrier A: x_0 published
+        for (int i = 0; i < n_steps; ++i) {
+          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC>(lds, xbuf, abuf, L, emb1, lane, mw, parity););
+          __syncthreads();  // barrier B: network output published
+          if (i + 1 < n_steps) emb1 = load16(ws + L.emb + (i + 1) * C + (mw * 2 + h) * 16);
+          __syncthreads();  // barrier A: x_{i+1} published
+        }
+        return;
+      }
+    }
     f32x16 emb[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (ot * 2 + h) * 16);
@@ -483,6 +582,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
     const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
 
+    // pair mode: the M waves exchange activations at n_hidden + 1 workgroup barriers per step; this wave joins them, spaced
+    // through its own work so that it never arrives late (input layer ~0.4 us, then ~1.1 us per layer)
+    if (pair) __syncthreads();
     // ---- score term of the control (needs x only; runs while the M wave evaluates the network) -----------
     float sterm[DP];
     if (ctrl_kind != SDEH_CTRL_CLIPPED) {
@@ -537,6 +639,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     }
     SDEH_FENCE();
 
+    if (pair && L.n_hidden >= 1) __syncthreads();
     // ---- Gaussian draws (independent of the control) --------------------------------------------------------
     float xi[DP];
     if (noise != nullptr) {
@@ -563,6 +666,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       }
     }
 
+    if (pair)
+      for (int k = 2; k <= L.n_hidden; ++k) __syncthreads();
     // exponential integrator (oc.py:428-443):  x <- x a_k + (b_k^2 s^2) u + (s b_k) xi
     // Euler-Maruyama (oc.py:213-219, 325-331): x <- x + (f x + sig u) dt + sig (xi sqrt(dt))
     const bool expo = loss_kind == SDEH_LOSS_EXPONENTIAL;
@@ -648,11 +753,17 @@ template <int DP>
 inline size_t ws_lds_bytes(const WsLayout& L) {
   return ((size_t)L.lds_floats + (size_t)kWsGroups * xrows<DP>() * 64) * sizeof(float);
 }
+// pair mode: one exchange buffer + the activation parking (2 parities x 2 tiles x 16 registers x 64 lanes)
+template <int DP>
+inline size_t ws_pair_lds_bytes(const WsLayout& L) {
+  return ((size_t)L.lds_floats + (size_t)xrows<DP>() * 64 + 2 * 2 * 16 * 64) * sizeof(float);
+}
 
 template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV>
 int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
-  const size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
+  size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  const bool pair_fits = C == 64 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>),
@@ -665,16 +776,21 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   //   B <= 32 768 : groups of 32 (one MFMA column tile per M wave: half the dependent chain per step), G = 4, sharing a SIMD
   //   B <= 16 384 : groups of 32, G = 2 -- every wave has a SIMD of its own, V and M really run concurrently; the reference's
   //                 default batch sizes (train 512 / 2048, eval 6000) live here and are latency-bound: 14.5 -> 7.1 us per step
-  static const char* force = getenv("SDEH_WS_GROUPS");  // testing aid: "2" | "4" | "2h" | "4h"
+  //   B <=  8 192 : pair mode -- one group of 32 per workgroup served by a V wave and TWO M waves (one output-channel tile each),
+  //                 three waves on three SIMDs of a CU: 7.1 -> ~5 us per step
+  static const char* force = getenv("SDEH_WS_GROUPS");  // testing aid: "2" | "4" | "2h" | "4h" | "p" (pair)
   int groups = a.batch <= 2 * 32 * 256 ? 2 : kWsGroups;
   int half = a.batch <= 4 * 32 * 256 ? 1 : 0;
+  if (pair_fits && a.batch <= 32 * 256) { groups = 1; half = 2; }
   if (force != nullptr && (force[0] == '2' || force[0] == '4')) { groups = force[0] - '0'; half = force[1] == 'h' ? 1 : 0; }
+  if (force != nullptr && force[0] == 'p' && pair_fits) { groups = 1; half = 2; }
+  if (half == 2 && ws_pair_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_pair_lds_bytes<DP>(a.lay);
   TrajArgs b = a;
   b.half = half;
   const int rows = (half ? 32 : 64) * groups;
   const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);
-  hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>), dim3(grid), dim3(128 * groups), lds_bytes, stream,
-                     a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+  hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>), dim3(grid),
+                     dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

@@ -361,6 +361,15 @@ int32_t sdeh_sample_stats(const float* samples, int64_t batch, int32_t d, const 
 int32_t sdeh_weight_grad(const float* D, int32_t m, const float* Z, int32_t c, int64_t N, int32_t act, int64_t chunk,
                          float* part_w, float* part_b, void* stream);
 
+/*
+ * out[i][e] = sum_k part[i][k][e] for part [n_items, n_chunks, width] (the partials of sdeh_weight_grad: width 4096 / 64).
+ * Deterministic two-pass sum without atomics or semaphores -- safe to replay inside a captured hipGraph, which the framework's
+ * multi-block reduction is not on this stack.  scratch: n_items * ceil(n_chunks / 32) * width floats.
+ */
+int64_t sdeh_partial_sums_scratch_floats(int64_t n_items, int64_t n_chunks, int64_t width);
+int32_t sdeh_partial_sums(const float* part, int64_t n_items, int64_t n_chunks, int64_t width, float* scratch, float* out,
+                          void* stream);
+
 /* Philox4x32-10 known-answer hook used by the tests: fills out[4*n] with the generator's raw words for
  * counters (row_offset+i, step, block, offset) and the (seed) key -- the exact stream sdeh_simulate_fwd consumes. */
 int32_t sdeh_debug_philox(uint64_t seed, uint64_t offset, int64_t row_offset, int32_t step, int32_t block,

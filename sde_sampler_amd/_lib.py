@@ -128,6 +128,8 @@ PROTOTYPES = {
                                   fp, fp, fp, fp, C.c_void_p]),
     "sdeh_sample_stats_scratch_floats": (C.c_int64, [C.c_int32]),
     "sdeh_sample_stats": (C.c_int32, [fp, C.c_int64, C.c_int32, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_partial_sums_scratch_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
+    "sdeh_partial_sums": (C.c_int32, [fp, C.c_int64, C.c_int64, C.c_int64, fp, fp, C.c_void_p]),
     "sdeh_weight_grad": (C.c_int32, [fp, C.c_int32, fp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, fp, fp, C.c_void_p]),
     "sdeh_reduce_estimators": (C.c_int32, [fp, C.c_int64, C.c_float, fp, fp, C.c_void_p]),
     "sdeh_importance_weights": (C.c_int32, [fp, C.c_int64, fp, fp, C.c_void_p]),

@@ -23,6 +23,8 @@ int launch_sink_check(int* flags, float thresh, hipStream_t st);
 int launch_sink_dist_final(const float* part, int nb, const int* flags, float* out, hipStream_t st);
 int launch_weight_grad(const float* D, int m, const float* Z, int c, long long N, int act, long long chunk, float* part_w,
                        float* part_b, hipStream_t stream);
+int launch_partial_sums(const float* part, long long n_items, long long n_chunks, long long width, float* scratch, float* out,
+                        hipStream_t stream);
 int launch_sample_stats(const float* x, const float* w, const float* domain, long long B, int d, float* scratch, int nb,
                         float* out, hipStream_t st);
 
@@ -780,6 +782,19 @@ int32_t sdeh_weight_grad(const float* D, int32_t m, const float* Z, int32_t c, i
   if (chunk < 8 || (chunk & 7) != 0) return fail(SDEH_ERR_INVALID, "weight_grad: chunk=%lld must be a positive multiple of 8", (long long)chunk);
   const int rc = launch_weight_grad(D, m, Z, c, N, act, chunk, part_w, part_b, (hipStream_t)stream);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "weight_grad: launch failed (act=%d)", act);
+}
+
+int64_t sdeh_partial_sums_scratch_floats(int64_t n_items, int64_t n_chunks, int64_t width) {
+  return n_items * ((n_chunks + 31) / 32) * width;
+}
+
+int32_t sdeh_partial_sums(const float* part, int64_t n_items, int64_t n_chunks, int64_t width, float* scratch, float* out,
+                          void* stream) {
+  if (part == nullptr || scratch == nullptr || out == nullptr || n_items < 1 || n_chunks < 1 || width < 1 || n_items > 65535 ||
+      (n_chunks + 31) / 32 > 65535)
+    return fail(SDEH_ERR_INVALID, "partial_sums: bad argument");
+  const int rc = launch_partial_sums(part, n_items, n_chunks, width, scratch, out, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "partial_sums: launch failed");
 }
 
 int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, float* scratch, float* out, void* stream) {

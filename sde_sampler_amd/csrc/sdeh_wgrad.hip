@@ -138,6 +138,44 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ D,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Sum of the per-chunk partials: out[i][e] = sum_k part[i][k][e].  Two passes (groups of kSumGroup chunks, then the groups), one
+// thread per element, consecutive threads on consecutive elements; no atomics and no host-zeroed semaphores -- the library
+// reduction this replaces (torch's multi-block sum) is not safe to replay inside a hipGraph on this ROCm stack: a second
+// reduction captured right after it gets the first one's semaphore / staging area as its output buffer and races with it
+// (tests/perf/rocm_graph_two_reductions.py reproduces it with PyTorch alone).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSumGroup = 32;
+
+__global__ __launch_bounds__(256) void partial_sum_kernel(const float* __restrict__ in, long long n_in, long long width,
+                                                          long long group, float* __restrict__ out, long long n_out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long g = blockIdx.y, item = blockIdx.z;
+  if (e >= width) return;
+  const long long k0 = g * group, k1 = k0 + group < n_in ? k0 + group : n_in;
+  const float* __restrict__ src = in + (item * n_in + k0) * width + e;
+  float acc0 = 0.0f, acc1 = 0.0f;  // two chains: fixed order, hence deterministic
+  long long k = k0;
+  for (; k + 1 < k1; k += 2) {
+    acc0 += src[0];
+    acc1 += src[width];
+    src += 2 * width;
+  }
+  if (k < k1) acc0 += src[0];
+  out[(item * n_out + g) * width + e] = acc0 + acc1;
+}
+
+int launch_partial_sums(const float* part, long long n_items, long long n_chunks, long long width, float* scratch, float* out,
+                        hipStream_t stream) {
+  const unsigned bx = width >= 256 ? 256 : 64;
+  const long long groups = (n_chunks + kSumGroup - 1) / kSumGroup;
+  const dim3 grid_a((unsigned)((width + bx - 1) / bx), (unsigned)groups, (unsigned)n_items);
+  hipLaunchKernelGGL(partial_sum_kernel, grid_a, dim3(bx), 0, stream, part, n_chunks, width, (long long)kSumGroup, scratch, groups);
+  const dim3 grid_b((unsigned)((width + bx - 1) / bx), 1, (unsigned)n_items);
+  hipLaunchKernelGGL(partial_sum_kernel, grid_b, dim3(bx), 0, stream, scratch, groups, width, groups, out, 1LL);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
 int launch_weight_grad(const float* D, int m, const float* Z, int c, long long N, int act, long long chunk, float* part_w,
                        float* part_b, hipStream_t stream) {
   const long long n_chunks = (N + chunk - 1) / chunk;

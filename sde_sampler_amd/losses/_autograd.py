@@ -49,22 +49,40 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
     return zt, dt, dout, dgam
 
 
-def _wgrad(dmat: torch.Tensor, z: torch.Tensor, act_id: int) -> tuple[torch.Tensor, torch.Tensor]:
-    """(dmat @ act(z)^T [m, c], dmat.sum(1) [m]) for coordinate-major planes dmat [m, N], z [c, N] in ONE pass over both
-    (sdeh_weight_grad: activation on the fly, K-contiguous MFMA operands, per-chunk partials summed here)."""
-    m, N = dmat.shape
-    c = z.shape[0]
-    dmat, z = dmat.contiguous(), z.contiguous()
+def _wgrad_batch(items: list[tuple[torch.Tensor, torch.Tensor, int]]) -> list[tuple[torch.Tensor, torch.Tensor]]:
+    """[(dmat @ act(z)^T [m, c], dmat.sum(1) [m]) for (dmat [m, N], z [c, N], act) in items], every product in ONE pass over its
+    two coordinate-major planes (sdeh_weight_grad: activation on the fly, K-contiguous MFMA operands) and ONE reduction of all
+    the per-chunk partials at the end (sdeh_partial_sums).  All items share N."""
+    N = items[0][0].shape[1]
+    dev = items[0][0].device
     # ~8192 partials (a few waves per SIMD hide the HBM latency); at least 128 rows per partial keeps the partial sums small
     chunk = max(128, -(-N // 8192))
     chunk = (chunk + 31) // 32 * 32
     n_chunks = -(-N // chunk)
-    part_w = torch.empty((n_chunks, 64, 64), device=dmat.device, dtype=torch.float32)
-    part_b = torch.empty((n_chunks, 64), device=dmat.device, dtype=torch.float32)
-    with torch.cuda.device(dmat.device):
-        L.check(L.load().sdeh_weight_grad(dmat.data_ptr(), m, z.data_ptr(), c, N, act_id, chunk, part_w.data_ptr(),
-                                          part_b.data_ptr(), torch.cuda.current_stream(dmat.device).cuda_stream))
-    return part_w.sum(dim=0)[:m, :c].contiguous(), part_b.sum(dim=0)[:m].contiguous()
+    part_w = torch.empty((len(items), n_chunks, 64, 64), device=dev, dtype=torch.float32)
+    part_b = torch.empty((len(items), n_chunks, 64), device=dev, dtype=torch.float32)
+    lib = L.load()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    keep = []
+    with torch.cuda.device(dev):
+        for i, (dmat, z, act_id) in enumerate(items):
+            dmat, z = dmat.contiguous(), z.contiguous()
+            keep.append((dmat, z))
+            L.check(lib.sdeh_weight_grad(dmat.data_ptr(), dmat.shape[0], z.data_ptr(), z.shape[0], N, act_id, chunk,
+                                         part_w[i].data_ptr(), part_b[i].data_ptr(), stream))
+        # the sums over the chunks are done by the library too (deterministic two-pass kernel): torch's multi-block reduction is
+        # not safe to replay inside a hipGraph on this stack (see csrc/sdeh_wgrad.hip)
+        n = len(items)
+        w = torch.empty((n, 64, 64), device=dev, dtype=torch.float32)
+        b = torch.empty((n, 64), device=dev, dtype=torch.float32)
+        scratch = torch.empty(lib.sdeh_partial_sums_scratch_floats(n, n_chunks, 4096), device=dev, dtype=torch.float32)
+        L.check(lib.sdeh_partial_sums(part_w.data_ptr(), n, n_chunks, 4096, scratch.data_ptr(), w.data_ptr(), stream))
+        L.check(lib.sdeh_partial_sums(part_b.data_ptr(), n, n_chunks, 64, scratch.data_ptr(), b.data_ptr(), stream))
+    return [(w[i, :dmat.shape[0], :z.shape[0]], b[i, :dmat.shape[0]]) for i, (dmat, z, _) in enumerate(items)]
+
+
+def _wgrad(dmat: torch.Tensor, z: torch.Tensor, act_id: int) -> tuple[torch.Tensor, torch.Tensor]:
+    return _wgrad_batch([(dmat, z, act_id)])[0]
 
 
 def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, torch.Tensor]:
@@ -79,31 +97,45 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, tor
     grads: dict[int, torch.Tensor] = {}
     extra = extra or {}
     with torch.no_grad():
+        # every product of this control goes into one batch: (parameter, wants_bias, planes...); products of the same parameter add
+        w_in, w_out = base.input_embed.weight, base.out_layer.weight
+        jobs: list[tuple[torch.nn.Parameter, torch.nn.Parameter | None, torch.Tensor, torch.Tensor, int]] = []
         Xt = xs[:T].reshape(N, d).t().contiguous()  # [d, N]
         d0 = dt[0] + extra["d2"][0] if "d2" in extra else dt[0]
-        grads[id(base.input_embed.weight)] = _wgrad(d0, Xt, L.ACT_IDENTITY)[0]
+        jobs.append((w_in, None, d0, Xt, L.ACT_IDENTITY))
         d_emb = d0.reshape(Cn, T, B).sum(dim=2).t().contiguous()  # [T, C]: gradient of the time embedding table
         grads[id(base.input_embed.bias)] = d_emb.sum(dim=0)
-        for k in range(Lh + 1):
-            if k < Lh:
-                lin = base.hidden_layer[k]
-                dk = dt[k + 1] + extra["d2"][k + 1] if "d2" in extra else dt[k + 1]
-                grads[id(lin.weight)], grads[id(lin.bias)] = _wgrad(dk, zt[k], act_id)
-            else:
-                grads[id(base.out_layer.weight)], grads[id(base.out_layer.bias)] = _wgrad(dout, zt[k], act_id)
+        for k in range(Lh):
+            lin = base.hidden_layer[k]
+            dk = dt[k + 1] + extra["d2"][k + 1] if "d2" in extra else dt[k + 1]
+            jobs.append((lin.weight, lin.bias, dk, zt[k], act_id))
+        jobs.append((w_out, base.out_layer.bias, dout, zt[Lh], act_id))
+        per_coord: list[tuple[int, int, int]] = []
         if "td" in extra and extra.get("eps") is not None:  # Hutchinson: one tangent stream in direction eps
             td, ta, cj = extra["td"], extra["ta"], extra["cj"]
-            grads[id(base.input_embed.weight)] += _wgrad(td[0, 0], extra["eps"].reshape(N, d).t().contiguous(), L.ACT_IDENTITY)[0]
+            jobs.append((w_in, None, td[0, 0], extra["eps"].reshape(N, d).t().contiguous(), L.ACT_IDENTITY))
             for k in range(Lh):
-                grads[id(base.hidden_layer[k].weight)] += _wgrad(td[0, k + 1], ta[0, k], L.ACT_IDENTITY)[0]
-            grads[id(base.out_layer.weight)] += _wgrad(cj, ta[0, Lh], L.ACT_IDENTITY)[0]
+                jobs.append((base.hidden_layer[k].weight, None, td[0, k + 1], ta[0, k], L.ACT_IDENTITY))
+            jobs.append((w_out, None, cj, ta[0, Lh], L.ACT_IDENTITY))
         elif "td" in extra:  # tangent streams of the divergence term, one per coordinate j
             td, ta, cj = extra["td"], extra["ta"], extra["cj"]
             for j in range(d):
-                grads[id(base.input_embed.weight)][:, j] += td[j, 0].sum(dim=1)
                 for k in range(Lh):
-                    grads[id(base.hidden_layer[k].weight)] += _wgrad(td[j, k + 1], ta[j, k], L.ACT_IDENTITY)[0]
-                grads[id(base.out_layer.weight)][j] += (ta[j, Lh] * cj[j][None, :]).sum(dim=1)
+                    jobs.append((base.hidden_layer[k].weight, None, td[j, k + 1], ta[j, k], L.ACT_IDENTITY))
+                # column j of input_embed.weight: sum_n td[j, 0][:, n] (the bias sum of that plane); row j of out_layer.weight:
+                # sum_n cj[j][n] ta[j, Lh][:, n] (a one-row product) -- through the same kernel, not through framework reductions
+                per_coord.append((j, len(jobs), len(jobs) + 1))
+                jobs.append((None, None, td[j, 0], cj[j:j + 1], L.ACT_IDENTITY))  # only its bias sum is used
+                jobs.append((None, None, cj[j:j + 1], ta[j, Lh], L.ACT_IDENTITY))
+        results = _wgrad_batch([(a, b, c) for _, _, a, b, c in jobs])
+        for (pw, pb, _, _, _), (wmat, bvec) in zip(jobs, results):
+            if pw is not None:
+                grads[id(pw)] = grads[id(pw)] + wmat if id(pw) in grads else wmat.clone()
+            if pb is not None:
+                grads[id(pb)] = bvec.clone()
+        for j, i_in, i_out in per_coord:
+            grads[id(w_in)][:, j] += results[i_in][1]
+            grads[id(w_out)][j] += results[i_out][0][0]
     # the two time-only sub-networks: differentiate their [T, .] tables
     with torch.enable_grad():
         te_params = [p for p in base.timestep_embed.parameters() if p.requires_grad]

@@ -72,6 +72,26 @@ def _all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     return t.cpu()
 
 
+class _MaskedMoment(torch.autograd.Function):
+    """mean (kl) or unbiased variance (lv) of the kept rows of rnd [B, 1] from the statistics vector of
+    engine.estimator_stats (n, sum(-rnd), M2, ...); the gradient is elementwise: 1/n, or 2 (rnd_i - mean) / (n - 1), zero on
+    dropped rows -- exactly what `rnd[mask].mean()` / `.var()` back-propagate (losses/oc.py:72-92)."""
+
+    @staticmethod
+    def forward(ctx, rnd, mask, stats, lv: bool):
+        n = stats[0]
+        mean = -stats[1] / n
+        ctx.save_for_backward(rnd, mask, n, mean)
+        ctx.lv = lv
+        return (stats[2] / (n - 1.0) if lv else mean).to(rnd.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rnd, mask, n, mean = ctx.saved_tensors
+        per_row = 2.0 * (rnd - mean) / (n - 1.0) if ctx.lv else (1.0 / n).expand_as(rnd)
+        return torch.where(mask, per_row * grad_out, torch.zeros_like(rnd)), None, None, None
+
+
 class BaseOCLoss:
     #: set to a torch.distributed process group (or leave None for the default group); evaluation statistics are
     #: merged across ranks whenever torch.distributed is initialised with world_size > 1
@@ -160,6 +180,15 @@ class BaseOCLoss:
         """compute_loss without a host round trip: same estimators (losses/oc.py:72-92) as masked reductions.  Rows the filter
         drops contribute exactly zero value and zero gradient, as `rnd[mask]` does."""
         zero = torch.zeros((), device=rnd.device, dtype=rnd.dtype)
+        if rnd.is_cuda and rnd.dtype == torch.float32 and self.method != "lv_traj":
+            # Sums through the library's own two-pass reduction (sdeh_reduce_estimators), elementwise ops otherwise: a captured
+            # step must not contain the framework's multi-block reductions (utils/graphs.py, tests/perf/rocm_graph_two_reductions.py)
+            stats = E.estimator_stats(torch.where(mask, rnd.detach(), torch.full_like(rnd, math.nan)), max_rnd=math.inf)  # +inf: keep finite rows
+            loss = _MaskedMoment.apply(rnd, mask, stats, self.method == "lv")
+            if self._n_filtered_dev is None:
+                self._n_filtered_dev = torch.zeros((), device=rnd.device, dtype=torch.int64)
+            self._n_filtered_dev += stats[6].to(torch.int64)
+            return loss, {"train/n_filtered_cumulative": self._n_filtered_dev}
         if self.method == "lv_traj":
             rnd = rnd.reshape(self.traj_per_sample, -1, 1)
             mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)

@@ -2,7 +2,7 @@
 optimizer step) for the launch-bound regime.
 
 At the reference's training sizes (batch 512 ... 4096, 100 ... 200 steps) one optimisation step of this package is about forty
-short kernels: the trajectory kernel itself is latency-bound (7 us per Euler-Maruyama step) and the host spends longer
+short kernels: the trajectory kernel itself is latency-bound (5 us per Euler-Maruyama step) and the host spends longer
 issuing the rest than the GPU spends running it.  `GraphedTrainStep` records the step once on a side stream
 (`torch.cuda.CUDAGraph`, i.e. hipStreamBeginCapture / hipGraphLaunch underneath; the ctypes launches of libsdeh.so go to
 torch's current stream and are captured like torch's own kernels) and replays it with one launch.
@@ -14,9 +14,18 @@ Two things make the step replayable:
   the backward launch replays the forward's draws because it reads the same counter value;
 * no host round trip -- `loss.graph_safe = True` switches `compute_loss` to masked reductions (losses/oc.py).
 
-What is NOT available in a captured step: the host-side `if loss_ok and grad_ok` of the reference trainer
-(solver/base.py:409-432) -- use `max_rnd` / `filter_samples` (they act on the device) and check `GraphedTrainStep.loss`
-from time to time instead; data-parallel loss shares (they go through the host).
+The reference trainer skips the optimizer step when the loss or a gradient is not finite (`if loss_ok and grad_ok`,
+solver/base.py:409-432) -- a host decision.  Here the same decision is taken on the device (`guard=True`): parameters and
+optimizer state are snapshotted before `optimizer.step()`, the step runs on sanitised gradients, and everything is put back
+when the step was not acceptable (exactly: new = ok * new + (1 - ok) * old with ok in {0, 1}); `n_skipped` counts those steps.
+Without it a single bad batch poisons Adam's moments for good.  Not available in a captured step: data-parallel loss shares
+(they go through the host).
+
+Platform caveat (torch 2.10 + ROCm 7.x): two consecutive multi-block framework reductions captured into one hipGraph return a
+corrupted second result from the second replay on (tests/perf/rocm_graph_two_reductions.py reproduces it with PyTorch alone).
+Everything this package puts into the step avoids them -- the weight-gradient partials and the loss statistics are reduced by
+libsdeh's own kernels -- and tests/test_hip_graphs.py compares replayed gradients with eager ones.  A `loss_fn` / `after_backward`
+of your own should keep its reductions small (one block: up to a few thousand elements) or check itself the same way.
 """
 from __future__ import annotations
 
@@ -40,10 +49,13 @@ class GraphedTrainStep:
     optimizer        for Adam/AdamW pass `capturable=True`
     after_backward   optional () -> None between backward and the optimizer step (gradient clipping, ...), also captured
     warmup           eager steps on the side stream before capturing (allocator warm-up; they DO update the parameters)
+    guard            skip the update on the device when the loss or a gradient is not finite (solver/base.py:409-432)
+    max_loss         with guard: additionally require |loss| <= max_loss (the reference's `max_loss`)
     """
 
     def __init__(self, loss_fn: Callable[[], torch.Tensor], losses: Iterable, optimizer: torch.optim.Optimizer, *,
-                 after_backward: Callable[[], None] | None = None, warmup: int = 3, device=None):
+                 after_backward: Callable[[], None] | None = None, warmup: int = 3, device=None, guard: bool = True,
+                 max_loss: float | None = None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a GPU (hipGraph capture)")
         for group in optimizer.param_groups:
@@ -58,6 +70,10 @@ class GraphedTrainStep:
             lo.rng_counter = self.counter
             lo.graph_safe = True
         self.replays = 0
+        self.guard, self.max_loss = guard, max_loss
+        self.n_skipped = torch.zeros((), dtype=torch.int64, device=self.device)
+        self._params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
+        self._snap: list[torch.Tensor] | None = None
 
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -72,13 +88,48 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.loss = self._step()  # static output: overwritten by every replay
 
+    def _guarded(self) -> list[torch.Tensor]:
+        """Parameters and every tensor of the optimizer state (moments, step counters): what `optimizer.step()` may change."""
+        out = list(self._params)
+        for p in self._params:
+            out += [v for v in self.optimizer.state.get(p, {}).values() if isinstance(v, torch.Tensor)]
+        return out
+
     def _step(self) -> torch.Tensor:
         self.optimizer.zero_grad(set_to_none=True)
         value = self._loss_fn()
         value.backward()
-        if self._after_backward is not None:
-            self._after_backward()
-        self.optimizer.step()
+        if not self.guard:
+            if self._after_backward is not None:
+                self._after_backward()
+            self.optimizer.step()
+        else:
+            with torch.no_grad():
+                # solver/base.py:409-421: loss finite (or within max_loss) and every gradient finite -- on one flat copy of the
+                # gradients (a handful of launches instead of a few per parameter)
+                grads = [p.grad for p in self._params if p.grad is not None]
+                flat = torch.cat([g.reshape(-1) for g in grads])
+                ok = torch.isfinite(value) if self.max_loss is None else value.abs() <= self.max_loss
+                ok = ok & torch.isfinite(flat).all()
+                # sanitise: the step below must not see NaN / Inf (its result is discarded when not ok)
+                flat = torch.where(ok, flat, torch.zeros_like(flat))
+                torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+            if self._after_backward is not None:
+                self._after_backward()
+            with torch.no_grad():
+                tensors = [t.detach() for t in self._guarded()]
+                if self._snap is None or len(self._snap) != len(tensors):  # (re)built while the optimizer state appears (warm-up)
+                    self._snap = [torch.empty_like(t) for t in tensors]
+                torch._foreach_copy_(self._snap, tensors)
+            self.optimizer.step()
+            with torch.no_grad():
+                tensors = [t.detach() for t in self._guarded()]
+                if len(tensors) == len(self._snap):
+                    # new <- ok * new + (1 - ok) * old, exact for ok in {0, 1} (everything is finite: the gradients were sanitised)
+                    keep = ok.to(torch.float32)
+                    torch._foreach_mul_(tensors, keep)
+                    torch._foreach_add_(tensors, torch._foreach_mul(self._snap, 1.0 - keep))
+                self.n_skipped += (~ok).to(torch.int64)
         self.counter.add_(1)
         return value.detach()
 

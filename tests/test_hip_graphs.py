@@ -123,3 +123,102 @@ def test_graphed_train_step_matches_eager(method):
     assert len({float(v) for v in losses_g}) == K  # fresh noise in every replay
     for p, q in zip(params_g, params_e):
         torch.testing.assert_close(p, q, rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_graphed_step_skips_non_finite_updates_on_device():
+    """solver/base.py:409-432 (`if loss_ok and grad_ok`) without a host round trip: a poisoned replay leaves parameters and
+    optimizer state untouched, is counted, and the following replays carry on."""
+    from sde_sampler_amd.utils.graphs import GraphedTrainStep
+
+    prob = _build(2, "lv")
+    x = prob.prior.sample((512,))
+    params = _params(prob)
+    opt = torch.optim.Adam(params, lr=2e-3, capturable=True)
+    poison = torch.ones((), device="cuda:0")
+    fn = lambda: prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0] * poison
+    graphed = GraphedTrainStep(fn, [prob.loss], opt, warmup=2)
+    graphed()
+    before = [p.detach().clone() for p in params]
+    state_before = [opt.state[p]["exp_avg"].clone() for p in params]
+    steps_before = float(opt.state[params[0]]["step"])
+    poison.fill_(float("nan"))
+    assert not torch.isfinite(graphed())
+    assert int(graphed.n_skipped) == 1
+    for p, q in zip(params, before):
+        assert torch.equal(p, q)
+    for p, m in zip(params, state_before):
+        assert torch.equal(opt.state[p]["exp_avg"], m)
+    assert float(opt.state[params[0]]["step"]) == steps_before
+    poison.fill_(1.0)
+    assert torch.isfinite(graphed())
+    assert int(graphed.n_skipped) == 1
+    assert any(not torch.equal(p, q) for p, q in zip(params, before))
+    assert all(torch.isfinite(p).all() for p in params)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,batch", [("lv", 2048), ("kl", 2048), ("bridge", 2048), ("lv", 65536), ("kl", 40000), ("bridge", 16384)])
+def test_replayed_gradients_equal_eager_gradients(method, batch):
+    """Every parameter gradient of forward + backward replayed from a hipGraph (three replays) against the eager launch at the
+    same Philox offset.  Guards against ordering / buffer-reuse hazards of captured steps (a multi-block framework reduction
+    inside the step corrupted the bias gradients from the second replay on, tests/perf/rocm_graph_two_reductions.py)."""
+    prob = _build(4, method)
+    params = _params(prob)
+    x = prob.prior.sample((batch,))
+    lo = prob.loss
+    lo.graph_safe = True
+    lo.rng_counter = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+
+    def run():
+        for p in params:
+            p.grad = None
+        lo.engine.calls = 5
+        value = lo(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
+        value.backward()
+        return value
+
+    eager_value = run().detach().clone()
+    eager = [p.grad.clone() for p in params]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        value = run()
+    inf = getattr(lo, "inference_ctrl", None)
+    names = [n for n, _ in prob.ctrl.named_parameters()] + (["inference." + n for n, _ in inf.named_parameters()] if inf is not None else [])
+    for rep in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(value, eager_value, rtol=1e-6, atol=1e-6)
+        for name, p, g in zip(names, params, eager):
+            scale = float(g.abs().max()) + 1e-12
+            err = float((p.grad - g).abs().max())
+            assert err <= 1e-5 * scale, (rep, name, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", ["kl", "lv"])
+def test_graph_safe_loss_on_device_matches_reference_reduction(method):
+    """On the GPU the graph-safe loss takes its sums from sdeh_reduce_estimators: same value / gradient as rnd[mask].mean() / .var()."""
+    out = []
+    for safe in (False, True):
+        lo = TimeReversalLoss(generative_ctrl=None, sde=None, method=method, max_rnd=50.0)
+        lo.graph_safe = safe
+        torch.manual_seed(11)
+        rnd = (torch.randn(4096, 1, device="cuda:0") * 3.0 + 1.0)
+        rnd[7], rnd[100], rnd[4000] = float("inf"), float("nan"), 77.0  # the last one exceeds max_rnd
+        rnd.requires_grad_(True)
+        value, metrics = lo.compute_loss(rnd)
+        (g,) = torch.autograd.grad(value, rnd)
+        out.append((value.detach(), g, int(metrics["train/n_filtered_cumulative"])))
+    (v0, g0, n0), (v1, g1, n1) = out
+    assert n0 == n1 == 3
+    torch.testing.assert_close(v1, v0, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-9)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--method", default=None)
     ap.add_argument("--lr", type=float, default=5e-3)
     ap.add_argument("--graph", action="store_true", help="capture the whole optimisation step into one hipGraph (utils/graphs.py)")
+    ap.add_argument("--no-guard", action="store_true", help="with --graph: no device-side skip of non-finite updates")
     args = ap.parse_args()
     if args.name == "bridge_dw":  # a Bridge (conf/solver/bridge.yaml style) on the shifted double well
         lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)  # conf/solver/bridge.yaml
@@ -65,7 +66,7 @@ def main():
             x = prob.prior.sample((args.batch,))
             return prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
 
-        graphed = GraphedTrainStep(loss_fn, [prob.loss], opt, warmup=3,
+        graphed = GraphedTrainStep(loss_fn, [prob.loss], opt, warmup=3, guard=not args.no_guard,
                                    after_backward=lambda: torch.nn.utils.clip_grad_norm_(train_params, 1.0))
     t0 = t_last = time.perf_counter()
     for step in range(args.steps):
@@ -84,6 +85,8 @@ def main():
             print(f"step {step + 1}: loss {loss.item():.4f}  ({1e3 * (now - t_last) / 100:.2f} ms/step over the last 100 steps, "
                   f"{1e3 * (now - t0) / (step + 1):.2f} since the start)", flush=True)
             t_last = now
+    if graphed is not None:
+        print(f"[graph] {graphed.replays} replays, {int(graphed.n_skipped)} updates skipped on the device (non-finite loss / gradient)")
     e1 = evaluate("trained")
     print(f"RESULT method={spec['loss']['method']} steps={args.steps} err_init={e0:.4f} err_trained={e1:.4f}")
 

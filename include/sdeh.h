@@ -264,7 +264,18 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* problem, const flo
  *   gextra    [T,B,d] or NULL (row-parallel): extra upstream gradient  w_i cdt gextra
  *   cost_ctrl [T,B,d] or NULL (BPTT): the control entering the running cost instead of u
  *   lam_extra [T,B,d] or NULL (BPTT): added to d loss / d x_t          dx_out [T,B,d] or NULL (row-parallel): written
+ *   nn_in     [T,B,d] or NULL: the raw network outputs written by sdeh_simulate_fwd_train; with it `zt` is an INPUT (the forward
+ *             launch's pre-activation planes) and the kernel does not re-evaluate the network
+ *
+ * sdeh_simulate_fwd_train == sdeh_simulate_fwd for a training step (xs required) that also keeps what the backward needs:
+ *   zt [(Lh+1), C, n_steps*batch]  pre-activations of every layer, coordinate-major (n = step * batch + row)
+ *   nn [n_steps, batch, d]         network output before the clamp
+ * Returns 0 when the planes were written, 1 when the launch was served by a kernel that keeps none (mixture tables too large
+ * for LDS, very deep networks): then call the backward with nn_in = NULL.  Not for problems with an inference control.
  */
+int32_t sdeh_simulate_fwd_train(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
+                                const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                                int64_t row_offset, float* x_T, float* rnd, float* xs, float* zt, float* nn, void* stream);
 int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                               const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, float* x_T, float* rnd, float* xs, float* gp, const float* div_noise,
@@ -273,7 +284,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* problem, const 
                               const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, const float* grad_rnd, const float* gextra, const float* cost_ctrl,
                               const float* lam_extra, float* dx_out, float* zt, float* dt, float* dout, float* dgam,
-                              void* stream);
+                              const float* nn_in, void* stream);
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                                  const float* xs, int64_t batch, const float* grad_rnd, const float* zt, float* tz,
                                  float* ta, float* td, float* d2, float* cj, float* dgam, float* dx_accum,

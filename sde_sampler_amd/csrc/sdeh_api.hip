@@ -473,9 +473,11 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
                                stream);
 }
 
-int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
-                              int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                              float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, void* stream) {
+static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                         int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                         float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, float* zt_out, float* nn_out,
+                         bool* planes_written, void* stream) {
+  if (planes_written != nullptr) *planes_written = false;
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
   if ((gp != nullptr || div_noise != nullptr) && (pr == nullptr || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)))
     return fail(SDEH_ERR_INVALID, "simulate_fwd_aux: gp / div_noise only exist for problems with an inference control");
@@ -521,20 +523,45 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float
     rc = v->fn_legacy(A, st);
     if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);
   } else {
+    A.zt_out = zt_out; A.nn_out = nn_out;  // only the wave-specialised kernel writes the training planes
     rc = v->fn(A, st);
+    if (rc == SDEH_OK && planes_written != nullptr) *planes_written = zt_out != nullptr && nn_out != nullptr;
     // image + exchange buffers beyond 160 KiB (deep networks): the single-wave kernel needs less LDS
-    if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) rc = plan->variant->fn_legacy(A, st);
+    if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) {
+      A.zt_out = nullptr; A.nn_out = nullptr;
+      rc = plan->variant->fn_legacy(A, st);
+    }
   }
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd: trajectory kernel launch failed (dp=%d)", v->dp);
   return SDEH_OK;
 }
 
+int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                              int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                              float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, void* stream) {
+  return simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, gp, div_noise, nullptr,
+                       nullptr, nullptr, stream);
+}
+
+int32_t sdeh_simulate_fwd_train(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                                int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                float* x_T, float* rnd, float* xs, float* zt, float* nn, void* stream) {
+  if (xs == nullptr || zt == nullptr || nn == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd_train: null argument");
+  if (pr != nullptr && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train: the Bridge forward keeps no planes (use sdeh_simulate_fwd_aux)");
+  bool written = false;
+  const int rc = simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, nullptr, nullptr,
+                               zt, nn, &written, stream);
+  if (rc != SDEH_OK) return rc;
+  return written ? SDEH_OK : 1;  // 1: integrated by a kernel that keeps no planes -- the backward re-evaluates the network
+}
+
 int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                            int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                            const float* grad_rnd, float* zt, float* dt, float* dout, float* dgam, void* stream) {
   return sdeh_ctrl_backward_ex(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, nullptr, nullptr,
-                               nullptr, nullptr, zt, dt, dout, dgam, stream);
+                               nullptr, nullptr, zt, dt, dout, dgam, nullptr, stream);
 }
 
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
@@ -590,7 +617,7 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const fl
 int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                               int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                               const float* grad_rnd, const float* gextra, const float* cost_ctrl, const float* lam_extra,
-                              float* dx_out, float* zt, float* dt, float* dout, float* dgam, void* stream) {
+                              float* dx_out, float* zt, float* dt, float* dout, float* dgam, const float* nn_in, void* stream) {
   if (xs == nullptr || grad_rnd == nullptr || zt == nullptr || dt == nullptr || dout == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward: null argument");
   Checked ck;
@@ -620,7 +647,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = L; A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.gextra = gextra;
   A.cost_ctrl = cost_ctrl; A.lam_extra = lam_extra; A.dx = dx_out;
-  A.zt = zt; A.dt = dt; A.dout = dout; A.dgam = dgam;
+  A.zt = zt; A.dt = dt; A.dout = dout; A.dgam = dgam; A.nn_in = nn_in;
   A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = pr->base_model.dim;
   A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = pr->base_model.activation;
   A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;

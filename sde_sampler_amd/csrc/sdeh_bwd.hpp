@@ -173,82 +173,90 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
   }
   cfp cf = as_const(ws + L.coef + t * kCoefStride);
 
-  // ---- forward, storing the pre-activations ------------------------------------------------------------------
-  f32x16 accA[OT], accB[OT];
-  {
-    const float* emb = ws + L.emb + t * C;
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) accA[ot] = accB[ot] = load16(emb + (ot * 2 + h) * 16);
-    float xa[R], xb[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float v0 = x[mdim(r, 0)];
-      float v1 = mdim(r, 1) < DP ? x[mdim(r, 1)] : 0.0f;
-      swap32(v0, v1);
-      xa[r] = v0;
-      xb[r] = v1;
-    }
-    const float* w = lds + L.w_in + lane;
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-#pragma unroll
-      for (int ot = 0; ot < OT; ++ot) {
-        const float a = w[(r * OT + ot) * 64];
-        accA[ot] = SDEH_MFMA(a, xa[r], accA[ot]);
-        if constexpr (!HALF) accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
-        if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
-      }
-  }
-  store_plane<OT, HALF>(A.zt, N, n0, nrows, lane, accA, accB);
-  for (int l = 0; l < L.n_hidden; ++l) {
-    if constexpr (HALF) activate_one<OT>(accA, act);
-    else activate<OT>(accA, accB, act);
-    f32x16 nA[OT], nB[OT];
-    const float* bias = lds + L.b_hid + l * C;
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) nA[ot] = nB[ot] = load16(bias + (ot * 2 + h) * 16);
-    const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
-#pragma unroll
-    for (int it = 0; it < OT; ++it)
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int ot = 0; ot < OT; ++ot) {
-          const float a = w[((it * 16 + q) * OT + ot) * 64];
-          nA[ot] = SDEH_MFMA(a, accA[it][q], nA[ot]);
-          if constexpr (!HALF) nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
-          if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
-        }
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot) { accA[ot] = nA[ot]; accB[ot] = nB[ot]; }
-    store_plane<OT, HALF>(A.zt + (long long)(l + 1) * C * N, N, n0, nrows, lane, accA, accB);
-  }
+  // The pre-activations Z_k and the raw network output nn either come from the training forward launch (A.nn_in != null: the
+  // wave-specialised kernel wrote the planes while it integrated, sdeh_simulate_fwd_train) or are re-evaluated here.
   float nn[DP];
-  {
-    if constexpr (HALF) activate_one<OT>(accA, act);
-    else activate<OT>(accA, accB, act);
-    f32x16 uA[OTD], uB[OTD];
+  if (A.nn_in != nullptr) {
+    const float* __restrict__ np = A.nn_in + ((long long)t * B + irow) * d;
 #pragma unroll
-    for (int tt = 0; tt < OTD; ++tt) uA[tt] = uB[tt] = load16(lds + L.b_out + (tt * 2 + h) * 16);
-    const float* w = lds + L.w_out + lane;
-#pragma unroll
-    for (int it = 0; it < OT; ++it)
-#pragma unroll
-      for (int q = 0; q < 16; ++q)
-#pragma unroll
-        for (int tt = 0; tt < OTD; ++tt) {
-          const float a = w[((it * 16 + q) * OTD + tt) * 64];
-          uA[tt] = SDEH_MFMA(a, accA[it][q], uA[tt]);
-          if constexpr (!HALF) uB[tt] = SDEH_MFMA(a, accB[it][q], uB[tt]);
-          if (tt == OTD - 1 && (q & 1)) SDEH_FENCE();
+    for (int j = 0; j < DP; ++j) nn[j] = (!PAD || j < d) ? np[PAD ? min(j, d - 1) : j] : 0.0f;
+  } else {
+    // ---- forward, storing the pre-activations ------------------------------------------------------------------
+    f32x16 accA[OT], accB[OT];
+    {
+      const float* emb = ws + L.emb + t * C;
+  #pragma unroll
+      for (int ot = 0; ot < OT; ++ot) accA[ot] = accB[ot] = load16(emb + (ot * 2 + h) * 16);
+      float xa[R], xb[R];
+  #pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float v0 = x[mdim(r, 0)];
+        float v1 = mdim(r, 1) < DP ? x[mdim(r, 1)] : 0.0f;
+        swap32(v0, v1);
+        xa[r] = v0;
+        xb[r] = v1;
+      }
+      const float* w = lds + L.w_in + lane;
+  #pragma unroll
+      for (int r = 0; r < R; ++r)
+  #pragma unroll
+        for (int ot = 0; ot < OT; ++ot) {
+          const float a = w[(r * OT + ot) * 64];
+          accA[ot] = SDEH_MFMA(a, xa[r], accA[ot]);
+          if constexpr (!HALF) accB[ot] = SDEH_MFMA(a, xb[r], accB[ot]);
+          if (ot == OT - 1 && (r & 1)) SDEH_FENCE();
         }
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float v0 = uA[r / 16][r % 16];
-      float v1 = uB[r / 16][r % 16];
-      swap32(v0, v1);
-      nn[mdim(r, 0)] = v0;
-      if (mdim(r, 1) < DP) nn[mdim(r, 1)] = v1;
+    }
+    store_plane<OT, HALF>(A.zt, N, n0, nrows, lane, accA, accB);
+    for (int l = 0; l < L.n_hidden; ++l) {
+      if constexpr (HALF) activate_one<OT>(accA, act);
+      else activate<OT>(accA, accB, act);
+      f32x16 nA[OT], nB[OT];
+      const float* bias = lds + L.b_hid + l * C;
+  #pragma unroll
+      for (int ot = 0; ot < OT; ++ot) nA[ot] = nB[ot] = load16(bias + (ot * 2 + h) * 16);
+      const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
+  #pragma unroll
+      for (int it = 0; it < OT; ++it)
+  #pragma unroll
+        for (int q = 0; q < 16; ++q)
+  #pragma unroll
+          for (int ot = 0; ot < OT; ++ot) {
+            const float a = w[((it * 16 + q) * OT + ot) * 64];
+            nA[ot] = SDEH_MFMA(a, accA[it][q], nA[ot]);
+            if constexpr (!HALF) nB[ot] = SDEH_MFMA(a, accB[it][q], nB[ot]);
+            if (ot == OT - 1 && (q & 1)) SDEH_FENCE();
+          }
+  #pragma unroll
+      for (int ot = 0; ot < OT; ++ot) { accA[ot] = nA[ot]; accB[ot] = nB[ot]; }
+      store_plane<OT, HALF>(A.zt + (long long)(l + 1) * C * N, N, n0, nrows, lane, accA, accB);
+    }
+    {
+      if constexpr (HALF) activate_one<OT>(accA, act);
+      else activate<OT>(accA, accB, act);
+      f32x16 uA[OTD], uB[OTD];
+  #pragma unroll
+      for (int tt = 0; tt < OTD; ++tt) uA[tt] = uB[tt] = load16(lds + L.b_out + (tt * 2 + h) * 16);
+      const float* w = lds + L.w_out + lane;
+  #pragma unroll
+      for (int it = 0; it < OT; ++it)
+  #pragma unroll
+        for (int q = 0; q < 16; ++q)
+  #pragma unroll
+          for (int tt = 0; tt < OTD; ++tt) {
+            const float a = w[((it * 16 + q) * OTD + tt) * 64];
+            uA[tt] = SDEH_MFMA(a, accA[it][q], uA[tt]);
+            if constexpr (!HALF) uB[tt] = SDEH_MFMA(a, accB[it][q], uB[tt]);
+            if (tt == OTD - 1 && (q & 1)) SDEH_FENCE();
+          }
+  #pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float v0 = uA[r / 16][r % 16];
+        float v1 = uB[r / 16][r % 16];
+        swap32(v0, v1);
+        nn[mdim(r, 0)] = v0;
+        if (mdim(r, 1) < DP) nn[mdim(r, 1)] = v1;
+      }
     }
   }
   SDEH_FENCE();

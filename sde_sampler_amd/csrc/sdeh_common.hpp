@@ -104,6 +104,9 @@ struct TrajArgs {
   float* gp;  // [T, B, d] or null: u + v per step (needed by the backward pass of the inference network)
   int half;   // wave-specialised kernel: a group is 32 trajectories (one MFMA column tile) instead of 64 -- small batches
   const float* div_noise;  // [T, B, d] or null: Hutchinson probe vectors (training with div_estimator); null = exact divergence
+  // training forward (sdeh_simulate_fwd_train): what the backward kernels would otherwise recompute
+  float* zt_out;  // [(Lh+1), C, T*B] or null: pre-activations of every layer, coordinate-major
+  float* nn_out;  // [T, B, d] or null: raw network output (before the clamp) per step
 };
 
 // sdeh_bridge_div_backward (sdeh_bridge.hpp): gradient of  sum_n w_i sigma dt div_x v(x_n)  w.r.t. the inference network
@@ -149,6 +152,7 @@ struct BwdArgs {
   DensArgs target;
   unsigned long long seed, offset;
   const unsigned long long* rng_dev;
+  const float* nn_in;  // [T, B, d] or null: with it, `zt` already holds the forward launch's pre-activations and is only read
 };
 
 // effective Philox offset of a launch: by-value part + the optional device-resident counter (hipGraph replays)

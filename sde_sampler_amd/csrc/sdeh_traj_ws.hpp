@@ -237,6 +237,22 @@ __device__ __forceinline__ void ws_target_score(const DensArgs& D, const float* 
 // shadow (one element per k-step, order pinned by scheduling fences):
 //   L0(A) | L0(B) + act(A0) | L1(A) + act(B0) | L1(B) + act(A1) | ... | out(A) + act(B_last) | out(B) + publish(A)
 // ---------------------------------------------------------------------------------------------------------
+// Pre-activation plane store of the training forward: accumulator q of lane (j, h) is channel 32 ot + rho(q, h) of the group's row j
+// (+ 32 for column tile B); plane layout [(Lh+1), C, N] coordinate-major, n = step * B + global row.
+struct ZStore {
+  float* base;       // zt_out + step * B + first row of the group, or null
+  long long N;       // T * B
+  int rows;          // live rows of the group (<= 64)
+};
+__device__ __forceinline__ void ws_store_z(const ZStore& Z, int layer, int C, int ot, int col_tile, int lane, const f32x16& v) {
+  const int h = lane >> 5, j = (lane & 31) + 32 * col_tile;
+  if (j < Z.rows) {
+    float* __restrict__ p = Z.base + ((long long)layer * C + 32 * ot) * Z.N + j;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) p[(long long)rho(q, h) * Z.N] = v[q];
+  }
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   return act == SDEH_ACT_GELU_ERF ? act_gelu(v) : (act == SDEH_ACT_SILU ? act_silu(v) : act_relu(v));
 }
@@ -292,9 +308,9 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ w, IN&& in,
   }
 }
 
-template <int DP, int C>
+template <int DP, int C, bool ZS>
 __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
-                                       int act, const f32x16 (&emb)[C / 32], int lane) {
+                                       int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
   f32x16 curA[OT], curB[OT], nxtA[OT], nxtB[OT];
@@ -310,7 +326,11 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
     for (int ot = 0; ot < OT; ++ot) curA[ot] = curB[ot] = emb[ot];
     const float* w = lds + L.w_in + lane;
     mfma_stage<R, OT, OT>(w, [&](int s) { return xa[s]; }, curA, curB, false, act);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) if constexpr (ZS) ws_store_z(Z, 0, C, ot, 0, lane, curA[ot]);
     mfma_stage<R, OT, OT>(w, [&](int s) { return xb[s]; }, curB, curA, true, act);  // + act(A0)
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) if constexpr (ZS) ws_store_z(Z, 0, C, ot, 1, lane, curB[ot]);
   }
   // invariant at the top of each layer: curA activated, curB not yet
   for (int l = 0; l < L.n_hidden; ++l) {
@@ -319,9 +339,11 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
     for (int ot = 0; ot < OT; ++ot) nxtA[ot] = nxtB[ot] = load16(bias + (ot * 2 + h) * 16);
     const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
     mfma_stage<C / 2, OT, OT>(w, [&](int s) { return curA[s / 16][s % 16]; }, nxtA, curB, true, act);  // + act(B)
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) if constexpr (ZS) ws_store_z(Z, l + 1, C, ot, 0, lane, nxtA[ot]);
     mfma_stage<C / 2, OT, OT>(w, [&](int s) { return curB[s / 16][s % 16]; }, nxtB, nxtA, true, act);  // + act(A')
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) { curA[ot] = nxtA[ot]; curB[ot] = nxtB[ot]; }
+    for (int ot = 0; ot < OT; ++ot) { if constexpr (ZS) ws_store_z(Z, l + 1, C, ot, 1, lane, nxtB[ot]); curA[ot] = nxtA[ot]; curB[ot] = nxtB[ot]; }
   }
   {  // out_layer(act(e)); the A tile's result is published while the B tile's MFMAs run
     f32x16 uA[OTD], uB[OTD];
@@ -343,9 +365,9 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
 
 // Single-tile variant for small batches (TrajArgs::half): the group is 32 trajectories = one MFMA column tile, so the chain of
 // dependent layers is half as long (the launch is latency-bound: a handful of wavefronts on 1024 SIMDs).
-template <int DP, int C>
+template <int DP, int C, bool ZS>
 __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
-                                            int act, const f32x16 (&emb)[C / 32], int lane) {
+                                            int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
   f32x16 cur[OT], nxt[OT], none[1];
@@ -362,6 +384,8 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) cur[ot] = emb[ot];
     mfma_stage<R, OT, 1>(lds + L.w_in + lane, [&](int s) { return xa[s]; }, cur, none, false, act);
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) if constexpr (ZS) ws_store_z(Z, 0, C, ot, 0, lane, cur[ot]);
   }
   for (int l = 0; l < L.n_hidden; ++l) {
     activate_all();
@@ -371,7 +395,7 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
     mfma_stage<C / 2, OT, 1>(lds + L.w_hid + l * L.w_hid_stride + lane, [&](int s) { return cur[s / 16][s % 16]; }, nxt, none,
                              false, act);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) cur[ot] = nxt[ot];
+    for (int ot = 0; ot < OT; ++ot) { cur[ot] = nxt[ot]; if constexpr (ZS) ws_store_z(Z, l + 1, C, ot, 0, lane, cur[ot]); }
   }
   activate_all();
   f32x16 u[OTD];
@@ -405,9 +429,10 @@ __device__ __forceinline__ void mfma_stage_one(const float* __restrict__ w, IN&&
 // layer's input is both tiles, so after activating its tile a wave parks it in `abuf` (double-buffered by layer parity), the
 // workgroup barrier makes both tiles visible, and the other tile is read back in the same (register, lane) arrangement.  The
 // k-steps run in the order of ws_mlp_half (tile 0's channels, then tile 1's), so the results are bit-identical to it.
-template <int DP, int C, int ACT>
+template <int DP, int C, int ACT, bool ZS>
 __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float* __restrict__ xbuf, float* __restrict__ abuf,
-                                            const WsLayout& L, const f32x16& emb_mine, int lane, int mw, int& parity) {
+                                            const WsLayout& L, const f32x16& emb_mine, int lane, int mw, int& parity,
+                                            const ZStore& Z) {
   static_assert(C == 64, "pair mode splits the two 32-channel tiles of a 64-channel network");
   constexpr int OT = 2, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
@@ -417,6 +442,7 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
 #pragma unroll
     for (int r = 0; r < R; ++r) xa[r] = xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j];
     mfma_stage_one<R, OT>(lds + L.w_in + mw * 64 + lane, [&](int s) { return xa[s]; }, mine);
+    if constexpr (ZS) ws_store_z(Z, 0, C, mw, 0, lane, mine);
   }
   auto exchange = [&]() {  // mine <- act(mine); other <- the partner's activated tile
 #pragma unroll
@@ -446,6 +472,7 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
     f32x16 nxt = load16(lds + L.b_hid + l * C + (mw * 2 + h) * 16);
     layer(lds + L.w_hid + l * L.w_hid_stride + mw * 64 + lane, std::integral_constant<int, OT>{}, nxt);
     mine = nxt;
+    if constexpr (ZS) ws_store_z(Z, l + 1, C, mw, 0, lane, mine);
   }
   exchange();
   if constexpr (OTD == 1) {  // d <= 32: one output tile, wave 0 computes it
@@ -467,7 +494,9 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
 // ---------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------
-template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV>
+// PLANES: the training forward (sdeh_simulate_fwd_train) -- the M waves also store the pre-activation planes, the V wave the raw
+// network output; a separate instantiation so that the evaluation kernel carries none of it.
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV, bool PLANES>
 __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                       const float* __restrict__ noise, float* __restrict__ xT,
                                                       float* __restrict__ rnd_out, float* __restrict__ xs,
@@ -511,8 +540,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         int parity = 0;
         f32x16 emb1 = load16(ws + L.emb + (mw * 2 + h) * 16);
         __syncthreads();  // barrier A: x_0 published
+        const long long row0 = (long long)blockIdx.x * 32;
+        ZStore Z{nullptr, (long long)n_steps * A.batch, (int)(A.batch - row0 < 32 ? A.batch - row0 : 32)};
         for (int i = 0; i < n_steps; ++i) {
-          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC>(lds, xbuf, abuf, L, emb1, lane, mw, parity););
+          if constexpr (PLANES) Z.base = A.zt_out + (long long)i * A.batch + row0;
+          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, PLANES>(lds, xbuf, abuf, L, emb1, lane, mw, parity, Z););
           __syncthreads();  // barrier B: network output published
           if (i + 1 < n_steps) emb1 = load16(ws + L.emb + (i + 1) * C + (mw * 2 + h) * 16);
           __syncthreads();  // barrier A: x_{i+1} published
@@ -524,13 +556,22 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (ot * 2 + h) * 16);
     __syncthreads();  // barrier A: x_0 published
+    ZStore Z{nullptr, 0, 0};
+    long long row0 = 0;
+    if constexpr (PLANES) {
+      const int rpg_m = A.half ? 32 : 64;
+      row0 = (long long)blockIdx.x * (rpg_m * n_groups) + group * rpg_m;
+      Z.N = (long long)n_steps * A.batch;
+      Z.rows = (int)(A.batch - row0 < rpg_m ? (A.batch - row0 > 0 ? A.batch - row0 : 0) : rpg_m);
+    }
     for (int i = 0; i < n_steps; ++i) {
+      if constexpr (PLANES) Z.base = A.zt_out + (long long)i * A.batch + row0;
       if constexpr ((SDEH_ABL & 1) == 0) {
         // generic variants (ACT < 0): the activation id becomes a compile-time constant of three copies of the network --
         // selecting it per element costs a scalar branch per element pair inside the MFMA stages (1.5x on the whole kernel)
         SDEH_ACT_SWITCH(act, ACTC,
-          if (A.half) ws_mlp_half<DP, C>(lds, xbuf, L, ACTC, emb, lane);
-          else ws_mlp<DP, C>(lds, xbuf, L, ACTC, emb, lane););
+          if (A.half) ws_mlp_half<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z);
+          else ws_mlp<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z););
       }
       __syncthreads();  // barrier B: network output published
       if (i + 1 < n_steps) {
@@ -692,6 +733,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
       const float nn = (SDEH_ABL & 1) ? 0.01f * xi[j] : xbuf[j * 64 + lane];
+      if constexpr (PLANES) {
+        if (live && (!PAD || j < d)) A.nn_out[((long long)i * A.batch + lrow) * d + j] = nn;
+      }
       u[j] = clipf(nn, A.clip_model) + sterm[j];
       if (PAD) u[j] = j < d ? u[j] : 0.0f;
       x[j] = fmaf(c_u, u[j], x[j]);
@@ -764,10 +808,14 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   const bool pair_fits = C == 64 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
+  const bool planes = a.zt_out != nullptr && a.nn_out != nullptr;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
   }
@@ -789,8 +837,12 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   b.half = half;
   const int rows = (half ? 32 : 64) * groups;
   const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);
-  hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV>), dim3(grid),
-                     dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+  if (planes)
+    hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, true>), dim3(grid),
+                       dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+  else
+    hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, false>), dim3(grid),
+                       dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

@@ -454,9 +454,10 @@ class TrajectoryEngine:
     # ------------------------------------------------------------------------------------------------------
     def run(self, pr: L.SdehProblem, ts: torch.Tensor, x: torch.Tensor, *, noise: torch.Tensor | None,
             return_traj: bool, keep: _Keep, row_offset: int = 0, seed: int | None = None, want_gp: bool = False,
-            div_noise: torch.Tensor | None = None):
+            div_noise: torch.Tensor | None = None, want_planes: bool = False):
         """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None); with `want_gp`
-        (Bridge training) additionally the plane u + v [T,B,d] as a fourth element."""
+        (Bridge training) additionally the plane u + v [T,B,d] as a fourth element; with `want_planes` (training without an
+        inference control) a fourth element (zt [(Lh+1),C,T*B], nn [T,B,d]) or None when the launch kept no planes."""
         if not x.is_cuda:
             raise RuntimeError("the HIP trajectory engine needs CUDA/HIP tensors (got a CPU tensor); "
                                "there is no CPU path in this package")
@@ -496,6 +497,18 @@ class TrajectoryEngine:
             if tuple(div_noise.shape) != (n_steps, batch, dim):
                 raise ValueError(f"div_noise must be [{n_steps}, {batch}, {dim}], got {tuple(div_noise.shape)}")
             dn_p = keep.ptr(div_noise, device, "div_noise")
+        if want_planes:  # training forward: keep the pre-activations and network outputs the backward kernels need
+            if xs is None or want_gp or div_noise is not None:
+                raise ValueError("want_planes goes with return_traj=True and without the Bridge outputs")
+            zt = torch.empty((pr.base_model.n_hidden + 1, pr.base_model.channels, n_steps * batch), device=device, dtype=torch.float32)
+            nn = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32)
+            with torch.cuda.device(device):
+                status = lib.sdeh_simulate_fwd_train(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
+                                                     seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
+                                                     rnd.data_ptr(), xs.data_ptr(), zt.data_ptr(), nn.data_ptr(), stream)
+            if status < 0:
+                L.check(status)
+            return x_T, rnd, xs, ((zt, nn) if status == 0 else None)  # 1: served by a kernel that keeps no planes
         with torch.cuda.device(device):
             L.check(lib.sdeh_simulate_fwd_aux(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
                                               seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),

@@ -26,13 +26,15 @@ def _ctrl_parameters(ctrl) -> list[torch.nn.Parameter]:
     return [p for p in ctrl.parameters() if p.requires_grad]
 
 
-def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None, lam_extra=None, dx_out=None):
-    """Runs sdeh_ctrl_backward_ex for the control in the problem's generative slots; returns the planes."""
+def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None, lam_extra=None, dx_out=None, planes=None):
+    """Runs sdeh_ctrl_backward_ex for the control in the problem's generative slots; returns the planes.  `planes` = (zt, nn) kept
+    by the training forward (sdeh_simulate_fwd_train): the kernel then reads them instead of re-evaluating the network."""
     dev = xs.device
     T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
     N, Cn, Lh = T * B, pr.base_model.channels, pr.base_model.n_hidden
     g = 0 if pr.ctrl_kind == L.CTRL_CLIPPED else (pr.score_model.dim_out if pr.score_model.n_hidden > 0 else 1)
-    zt = torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
+    zt = planes[0] if planes is not None else torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
+    nn_in = planes[1] if planes is not None else None
     dt = torch.empty_like(zt)
     dout = torch.empty((d, N), device=dev, dtype=torch.float32)
     dgam = torch.zeros((max(g, 1), N), device=dev, dtype=torch.float32)
@@ -45,7 +47,7 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
             plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
             None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
             w.data_ptr(), ptr(gextra), ptr(cost_ctrl), ptr(lam_extra), ptr(dx_out), zt.data_ptr(), dt.data_ptr(),
-            dout.data_ptr(), dgam.data_ptr(), stream))
+            dout.data_ptr(), dgam.data_ptr(), ptr(nn_in), stream))
     return zt, dt, dout, dgam
 
 
@@ -160,7 +162,7 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, tor
 class _TrajectoryFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, loss, launch, ts, x, *params):
-        x_T, rnd, xs, state = launch(return_traj=True, want_state=True)
+        x_T, rnd, xs, state = launch(return_traj=True, want_state=True, want_planes=True)
         ctx.loss, ctx.state, ctx.n_params = loss, state, len(params)
         ctx.save_for_backward(ts, xs)
         ctx.mark_non_differentiable(x_T)
@@ -174,7 +176,7 @@ class _TrajectoryFn(torch.autograd.Function):
         w = grad_rnd.reshape(-1).contiguous().float()
         keep = E._Keep()
         pr = loss.engine.build_problem(device=xs.device, keep=keep, **st["problem_kwargs"])
-        planes = _ctrl_backward(loss.engine, pr, keep, ts, xs, w, st)
+        planes = _ctrl_backward(loss.engine, pr, keep, ts, xs, w, st, planes=st.get("planes"))
         grads = _weight_grads(loss.generative_ctrl, ts, xs, *planes)
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
@@ -248,8 +250,8 @@ def simulate_with_grad(loss, launch, ts, x):
     """`launch(return_traj, want_state)` runs the HIP forward; returns (x_T, rnd attached to the parameters, None)."""
     params = _ctrl_parameters(loss.generative_ctrl)
 
-    def wrapped(return_traj, want_state):
-        x_T, rnd, xs, state = launch(return_traj=return_traj, want_state=want_state)
+    def wrapped(return_traj, want_state, want_planes=False):
+        x_T, rnd, xs, state = launch(return_traj=return_traj, want_state=want_state, want_planes=want_planes)
         state["params"] = params
         return x_T, rnd, xs, state
 

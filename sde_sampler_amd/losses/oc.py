@@ -269,13 +269,14 @@ class BaseOCLoss:
                               reference_prior=reference_prior, alpha=alpha, sigma=sigma, inference_ctrl=inference_ctrl,
                               rng_counter=self.rng_counter)
 
-        def run(return_traj: bool, want_state: bool = False, want_gp: bool = False):
+        def run(return_traj: bool, want_state: bool = False, want_gp: bool = False, want_planes: bool = False):
             keep = E._Keep()
             pr = self.engine.build_problem(device=x.device, keep=keep, **problem_kwargs)
             offset = self.engine.calls
             seed = torch.initial_seed()
             out = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
-                                  row_offset=self.row_offset, seed=seed, want_gp=want_gp, div_noise=div_noise)
+                                  row_offset=self.row_offset, seed=seed, want_gp=want_gp, div_noise=div_noise,
+                                  want_planes=want_planes)
             x_T, rnd, xs = out[:3]
             # user-supplied callables the engine does not recognise are evaluated as given (device tensors in/out)
             if second is None and second_log_prob is not None:
@@ -289,6 +290,8 @@ class BaseOCLoss:
             if want_state:
                 state = dict(problem_kwargs=problem_kwargs, noise=noise, seed=seed & 0xFFFFFFFFFFFFFFFF, offset=offset,
                              row_offset=self.row_offset, div_noise=div_noise)
+                if want_planes:
+                    state["planes"] = out[3]  # (zt, nn) of the forward launch, or None
                 return (x_T, rnd, xs, out[3], state) if want_gp else (x_T, rnd, xs, state)
             return x_T, rnd, xs
 

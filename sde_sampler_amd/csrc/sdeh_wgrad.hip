@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ D,
 // Sum of the per-chunk partials: out[i][e] = sum_k part[i][k][e].  Two passes (groups of kSumGroup chunks, then the groups), one
 // thread per element, consecutive threads on consecutive elements; no atomics and no host-zeroed semaphores -- the library
 // reduction this replaces (torch's multi-block sum) is not safe to replay inside a hipGraph on this ROCm stack: a second
-// reduction captured right after it gets the first one's semaphore / staging area as its output buffer and races with it
+// reduction captured right after it comes back corrupted from the second replay on (its output block holds what look like the
+// first reduction's semaphore counters / staging values; plain memset -> kernel ordering is fine, tests/perf/rocm_graph_memset_order.py)
 // (tests/perf/rocm_graph_two_reductions.py reproduces it with PyTorch alone).
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSumGroup = 32;

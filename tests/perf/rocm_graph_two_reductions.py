@@ -1,6 +1,7 @@
 """Reproducer (pure PyTorch, no libsdeh): on torch 2.10 + ROCm 7.0/7.2 two consecutive multi-block reductions captured into one
 hipGraph give a corrupted SECOND result from the second replay on -- the first reduction's semaphore / staging block is reused as
-the second one's output and the two kernels are not ordered through the memset node between them.  This is why the partial sums of
+the second one's output (the corrupted words look like its counters / partial sums; kernel -> memset -> kernel ordering as such
+is fine, rocm_graph_memset_order.py).  This is why the partial sums of
 sdeh_weight_grad are reduced by the library's own kernel (csrc/sdeh_wgrad.hip) and why tests/test_hip_graphs.py compares replayed
 gradients with eager ones."""
 import torch

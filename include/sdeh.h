@@ -373,6 +373,19 @@ int32_t sdeh_weight_grad(const float* D, int32_t m, const float* Z, int32_t c, i
                          float* part_w, float* part_b, void* stream);
 
 /*
+ * Parameter gradients of a TimeEmbed sub-network (models/mlp.py:43-82: FourierMLP.timestep_embed, the gamma(t) network of the
+ * score controls) from the gradient of its [n_steps, dim_out] table -- what the reference's autograd accumulates for these
+ * parameters through its T per-step evaluations.  grad_flat (sdeh_time_embed_param_floats(te) floats) receives, in this order:
+ *   timestep_phase [C] | for every hidden layer k: weight [C, 2C (k = 0) or C], bias [C] | out_layer.weight [dim_out, C] | bias [dim_out]
+ * clip_out: the table entered the loss through clamp(-clip_out, clip_out) (reparam.py: clip(gamma(t)); +INF = no clamp): entries
+ * outside carry no gradient.  1 <= te->n_hidden <= 4.  workspace: sdeh_time_embed_workspace_floats(te, n_steps) floats.
+ */
+int64_t sdeh_time_embed_param_floats(const SdehTimeEmbed* te);
+int64_t sdeh_time_embed_workspace_floats(const SdehTimeEmbed* te, int32_t n_steps);
+int32_t sdeh_time_embed_backward(const SdehTimeEmbed* te, int32_t activation, const float* ts, int32_t n_steps,
+                                 const float* grad_table, float clip_out, float* workspace, float* grad_flat, void* stream);
+
+/*
  * out[i][e] = sum_k part[i][k][e] for part [n_items, n_chunks, width] (the partials of sdeh_weight_grad: width 4096 / 64).
  * Deterministic two-pass sum without atomics or semaphores -- safe to replay inside a captured hipGraph, which the framework's
  * multi-block reduction is not on this stack.  scratch: n_items * ceil(n_chunks / 32) * width floats.

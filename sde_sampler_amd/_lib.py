@@ -130,6 +130,9 @@ PROTOTYPES = {
                                   fp, fp, fp, fp, C.c_void_p]),
     "sdeh_sample_stats_scratch_floats": (C.c_int64, [C.c_int32]),
     "sdeh_sample_stats": (C.c_int32, [fp, C.c_int64, C.c_int32, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_time_embed_param_floats": (C.c_int64, [C.POINTER(SdehTimeEmbed)]),
+    "sdeh_time_embed_workspace_floats": (C.c_int64, [C.POINTER(SdehTimeEmbed), C.c_int32]),
+    "sdeh_time_embed_backward": (C.c_int32, [C.POINTER(SdehTimeEmbed), C.c_int32, fp, C.c_int32, fp, C.c_float, fp, fp, C.c_void_p]),
     "sdeh_partial_sums_scratch_floats": (C.c_int64, [C.c_int64, C.c_int64, C.c_int64]),
     "sdeh_partial_sums": (C.c_int32, [fp, C.c_int64, C.c_int64, C.c_int64, fp, fp, C.c_void_p]),
     "sdeh_weight_grad": (C.c_int32, [fp, C.c_int32, fp, C.c_int32, C.c_int64, C.c_int32, C.c_int64, fp, fp, C.c_void_p]),

@@ -25,6 +25,10 @@ int launch_weight_grad(const float* D, int m, const float* Z, int c, long long N
                        float* part_b, hipStream_t stream);
 int launch_partial_sums(const float* part, long long n_items, long long n_chunks, long long width, float* scratch, float* out,
                         hipStream_t stream);
+int launch_time_embed_bwd(const SdehTimeEmbed& te, int act, const float* ts, int n_steps, const float* gout, float clip,
+                          float* workspace, float* grad_flat, hipStream_t stream);
+long long time_embed_param_floats(const SdehTimeEmbed& te);
+long long time_embed_workspace_floats(const SdehTimeEmbed& te, int n_steps);
 int launch_sample_stats(const float* x, const float* w, const float* domain, long long B, int d, float* scratch, int nb,
                         float* out, hipStream_t st);
 
@@ -809,6 +813,26 @@ int32_t sdeh_weight_grad(const float* D, int32_t m, const float* Z, int32_t c, i
   if (chunk < 8 || (chunk & 7) != 0) return fail(SDEH_ERR_INVALID, "weight_grad: chunk=%lld must be a positive multiple of 8", (long long)chunk);
   const int rc = launch_weight_grad(D, m, Z, c, N, act, chunk, part_w, part_b, (hipStream_t)stream);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "weight_grad: launch failed (act=%d)", act);
+}
+
+int64_t sdeh_time_embed_param_floats(const SdehTimeEmbed* te) { return te == nullptr || te->n_hidden < 1 ? 0 : time_embed_param_floats(*te); }
+int64_t sdeh_time_embed_workspace_floats(const SdehTimeEmbed* te, int32_t n_steps) {
+  return te == nullptr || te->n_hidden < 1 || n_steps < 1 ? 0 : time_embed_workspace_floats(*te, n_steps);
+}
+
+int32_t sdeh_time_embed_backward(const SdehTimeEmbed* te, int32_t activation, const float* ts, int32_t n_steps,
+                                 const float* grad_table, float clip_out, float* workspace, float* grad_flat, void* stream) {
+  if (te == nullptr || ts == nullptr || grad_table == nullptr || workspace == nullptr || grad_flat == nullptr || n_steps < 1)
+    return fail(SDEH_ERR_INVALID, "time_embed_backward: bad argument");
+  if (te->channels < 1 || te->dim_out < 1 || te->coeff == nullptr || te->phase == nullptr || te->out_w == nullptr ||
+      te->out_b == nullptr)
+    return fail(SDEH_ERR_INVALID, "time_embed_backward: null parameter pointer");
+  for (int k = 0; k < te->n_hidden && k < SDEH_MAX_HIDDEN; ++k)
+    if (te->hidden_w[k] == nullptr || te->hidden_b[k] == nullptr)
+      return fail(SDEH_ERR_INVALID, "time_embed_backward: null hidden layer %d", k);
+  if (activation < SDEH_ACT_GELU_ERF || activation > SDEH_ACT_RELU) return fail(SDEH_ERR_INVALID, "time_embed_backward: activation");
+  const int rc = launch_time_embed_bwd(*te, activation, ts, n_steps, grad_table, clip_out, workspace, grad_flat, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "time_embed_backward: n_hidden=%d channels=%d not supported by this kernel", te->n_hidden, te->channels);
 }
 
 int64_t sdeh_partial_sums_scratch_floats(int64_t n_items, int64_t n_chunks, int64_t width) {

@@ -15,6 +15,7 @@ tangents, see include/sdeh.h).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -87,6 +88,37 @@ def _wgrad(dmat: torch.Tensor, z: torch.Tensor, act_id: int) -> tuple[torch.Tens
     return _wgrad_batch([(dmat, z, act_id)])[0]
 
 
+def _time_embed_grads(te, act_id: int, steps: torch.Tensor, table_grad: torch.Tensor, clip) -> dict[int, torch.Tensor] | None:
+    """{id(parameter): gradient} of a TimeEmbed module from the gradient of its [T, dim_out] table (one kernel launch), or None
+    when the module is not one the kernel takes (then the caller differentiates the table with autograd)."""
+    if "TimeEmbed" not in E._mro_names(te) or os.environ.get("SDEH_TE_AUTOGRAD"):  # testing aid: differentiate the table with autograd
+        return None
+    dev = table_grad.device
+    keep = E._Keep()
+    st = L.SdehTimeEmbed()
+    E._fill_time_embed(te, st, keep, dev, "time embedding")
+    if not 1 <= st.n_hidden <= 4:
+        return None
+    layers = list(E._sub(te, "hidden_layer"))
+    out_layer, phase = E._sub(te, "out_layer"), E._sub(te, "timestep_phase")
+    lib = L.load()
+    flat = torch.empty(lib.sdeh_time_embed_param_floats(C.byref(st)), device=dev, dtype=torch.float32)
+    work = torch.empty(lib.sdeh_time_embed_workspace_floats(C.byref(st), steps.numel()), device=dev, dtype=torch.float32)
+    table_grad = table_grad.contiguous().float()
+    with torch.cuda.device(dev):
+        L.check(lib.sdeh_time_embed_backward(C.byref(st), act_id, keep.ptr(steps, dev, "ts"), steps.numel(), table_grad.data_ptr(),
+                                             float("inf") if clip is None else float(clip), work.data_ptr(), flat.data_ptr(),
+                                             torch.cuda.current_stream(dev).cuda_stream))
+    # flat layout (include/sdeh.h): phase | (weight, bias) per hidden layer | out_layer weight, bias
+    out: dict[int, torch.Tensor] = {}
+    pos = 0
+    for param in [phase] + [t for lin in layers for t in (lin.weight, lin.bias)] + [out_layer.weight, out_layer.bias]:
+        n = param.numel()
+        out[id(param)] = flat[pos:pos + n].view(param.shape)
+        pos += n
+    return out
+
+
 def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, torch.Tensor]:
     """Parameter gradients of one control from the coordinate-major planes (sdeh_weight_grad over N; autograd on the [T, .]
     tables of the two time-only sub-networks).  `extra`: additive second-order contributions of the Bridge divergence term."""
@@ -138,24 +170,32 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, tor
         for j, i_in, i_out in per_coord:
             grads[id(w_in)][:, j] += results[i_in][1]
             grads[id(w_out)][j] += results[i_out][0][0]
-    # the two time-only sub-networks: differentiate their [T, .] tables
-    with torch.enable_grad():
-        te_params = [p for p in base.timestep_embed.parameters() if p.requires_grad]
-        if te_params:
-            emb = base.timestep_embed(ts[:-1])
-            for p, gp in zip(te_params, torch.autograd.grad(emb, te_params, d_emb, allow_unused=True)):
-                grads[id(p)] = gp
-        if score_model is not None:
-            sm_params = [p for p in score_model.parameters() if p.requires_grad]
-            if sm_params:
-                gam = score_model(ts[:-1])
-                clip_model = getattr(ctrl, "clip_model", None)
-                if clip_model is not None:
-                    gam = gam.clip(min=-clip_model, max=clip_model)
+    # the two time-only sub-networks: parameter gradients from the gradients of their [T, .] tables (sdeh_time_embed_backward;
+    # autograd on the tables only for shapes that kernel does not take)
+    steps = ts[:-1].contiguous()
+    te_params = [p for p in base.timestep_embed.parameters() if p.requires_grad]
+    if te_params:
+        got = _time_embed_grads(base.timestep_embed, act_id, steps, d_emb, None)
+        if got is None:
+            with torch.enable_grad():
+                emb = base.timestep_embed(steps)
+                got = {id(p): gp for p, gp in zip(te_params, torch.autograd.grad(emb, te_params, d_emb, allow_unused=True))}
+        grads.update(got)
+    if score_model is not None:
+        sm_params = [p for p in score_model.parameters() if p.requires_grad]
+        if sm_params:
+            clip_model = getattr(ctrl, "clip_model", None)
+            with torch.no_grad():
                 dg = dgam[:g] + extra["dgam"][:g] if "dgam" in extra else dgam[:g]
                 d_gam = dg.reshape(g, T, B).sum(dim=2).t().contiguous()  # [T, g]
-                for p, gp in zip(sm_params, torch.autograd.grad(gam, sm_params, d_gam, allow_unused=True)):
-                    grads[id(p)] = gp
+            got = _time_embed_grads(score_model, E._activation_id(score_model.activation), steps, d_gam, clip_model)
+            if got is None:
+                with torch.enable_grad():
+                    gam = score_model(steps)
+                    if clip_model is not None:
+                        gam = gam.clip(min=-clip_model, max=clip_model)
+                    got = {id(p): gp for p, gp in zip(sm_params, torch.autograd.grad(gam, sm_params, d_gam, allow_unused=True))}
+            grads.update(got)
     return grads
 
 

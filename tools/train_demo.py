@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--method", default=None)
     ap.add_argument("--lr", type=float, default=5e-3)
+    ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--graph", action="store_true", help="capture the whole optimisation step into one hipGraph (utils/graphs.py)")
     ap.add_argument("--no-guard", action="store_true", help="with --graph: no device-side skip of non-finite updates")
     args = ap.parse_args()
@@ -35,7 +36,7 @@ def main():
     if args.method:
         spec["loss"]["method"] = args.method
     prob = problems.build(spec, device="cuda:0")
-    torch.manual_seed(0)
+    torch.manual_seed(args.seed)
     if hasattr(prob.target, "compute_stats"):
         prob.target.compute_stats()
     true_logz = prob.target.log_norm_const

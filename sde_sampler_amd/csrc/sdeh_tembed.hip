@@ -8,7 +8,7 @@
 
 namespace sdeh {
 
-constexpr int kTeRows = 8;        // rows of t per chunk = per workgroup
+constexpr int kTeRows = 8;        // rows of t per chunk = per workgroup (1024 threads: the phases are short loops over 512 ... 8192 elements)
 constexpr int kTeMaxHidden = 4;   // hidden layers this kernel keeps in LDS (the reference uses 1 and 3)
 
 struct TeBwdArgs {
@@ -36,7 +36,7 @@ __device__ __forceinline__ float te_act_grad(float v, int act) {
   return v > 0.0f ? 1.0f : 0.0f;
 }
 
-__global__ __launch_bounds__(256) void time_embed_bwd_kernel(const TeBwdArgs A) {
+__global__ __launch_bounds__(1024) void time_embed_bwd_kernel(const TeBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int C = A.te.channels, H = A.te.n_hidden, DO = A.te.dim_out, T = A.n_steps, act = A.act;
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -44,6 +44,14 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const TeBwdArgs A) 
   float* zb = feat + kTeRows * 2 * C;            // [H][kTeRows][C]   pre-activations, later d loss / d pre-activation
   float* ab = zb + H * kTeRows * C;              // [H][kTeRows][C]   activations
   float* gb = ab + H * kTeRows * C;              // [kTeRows][DO]     upstream gradient of the chunk
+  float* wbuf = gb + kTeRows * DO;               // [C][2C + 1]       the current layer's weight, staged coalesced, padded rows
+  // lanes index the output channel in the forward (rows of W, stride nin + 1: conflict-free) and the input channel in the
+  // backward (columns): reading W straight from global memory costs a cache line per lane and k-step
+  auto stage = [&](const float* __restrict__ w, int rows, int nin) {
+    __syncthreads();
+    for (int i = tid; i < rows * nin; i += nt) wbuf[(i / nin) * (nin + 1) + i % nin] = w[i];
+    __syncthreads();
+  };
   auto W = [&](int k) { return A.te.hidden_w[k]; };
   // flat layout of this chunk's gradients
   float* base = A.part + (long long)blockIdx.x * A.P;
@@ -68,13 +76,13 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const TeBwdArgs A) 
     for (int k = 0; k < H; ++k) {
       const int nin = k == 0 ? 2 * C : C;
       const float* in = k == 0 ? feat : ab + (k - 1) * kTeRows * C;
-      const float* __restrict__ w = W(k);
+      stage(W(k), C, nin);
       const float* __restrict__ b = A.te.hidden_b[k];
       for (int i = tid; i < nr * C; i += nt) {
         const int r = i / C, c = i % C;
         float acc = b[c];
-        const float* __restrict__ wr = w + (size_t)c * nin;
-        const float* __restrict__ ir = in + r * nin;
+        const float* wr = wbuf + c * (nin + 1);
+        const float* ir = in + r * nin;
         for (int j = 0; j < nin; ++j) acc = fmaf(wr[j], ir[j], acc);
         zb[(k * kTeRows + r) * C + c] = acc;
         ab[(k * kTeRows + r) * C + c] = te_act(acc, act);
@@ -83,10 +91,11 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const TeBwdArgs A) 
     }
     const float* alast = ab + (H - 1) * kTeRows * C;
     // ---- output (for the clamp mask) and upstream gradient of the chunk
+    stage(A.te.out_w, DO, C);
     for (int i = tid; i < nr * DO; i += nt) {
       const int r = i / DO, o = i % DO;
       float acc = A.te.out_b[o];
-      const float* __restrict__ wr = A.te.out_w + (size_t)o * C;
+      const float* wr = wbuf + o * (C + 1);
       for (int c = 0; c < C; ++c) acc = fmaf(wr[c], alast[r * C + c], acc);
       const float g = A.gout[(size_t)(r0 + r) * DO + o];
       gb[r * DO + o] = (acc >= -A.clip && acc <= A.clip) ? g : 0.0f;
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const TeBwdArgs A) 
     for (int i = tid; i < nr * C; i += nt) {
       const int r = i / C, c = i % C;
       float da = 0.0f;
-      for (int o = 0; o < DO; ++o) da = fmaf(gb[r * DO + o], A.te.out_w[(size_t)o * C + c], da);
+      for (int o = 0; o < DO; ++o) da = fmaf(gb[r * DO + o], wbuf[o * (C + 1) + c], da);
       float* z = zb + ((H - 1) * kTeRows + r) * C + c;
       *z = da * te_act_grad(*z, act);
     }
@@ -128,13 +137,12 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const TeBwdArgs A) 
         for (int r = 0; r < nr; ++r) s += dz[r * C + c];
         gbias(k)[c] = s;
       }
-      __syncthreads();  // a[k-1] / feat are still being read above; the in-place updates below touch z[k-1] and a[0] only
-      const float* __restrict__ w = W(k);
+      stage(W(k), C, nin);  // (its barriers also separate the reads of a[k-1] / feat above from the in-place updates below)
       if (k > 0) {
         for (int i = tid; i < nr * C; i += nt) {
           const int r = i / C, j = i % C;
           float da = 0.0f;
-          for (int c = 0; c < C; ++c) da = fmaf(dz[r * C + c], w[(size_t)c * C + j], da);
+          for (int c = 0; c < C; ++c) da = fmaf(dz[r * C + c], wbuf[c * (C + 1) + j], da);
           float* z = zb + ((k - 1) * kTeRows + r) * C + j;
           *z = da * te_act_grad(*z, act);
         }
@@ -145,8 +153,8 @@ __global__ __launch_bounds__(256) void time_embed_bwd_kernel(const TeBwdArgs A) 
           float ds = 0.0f, dc = 0.0f;
           for (int cc = 0; cc < C; ++cc) {
             const float d = dz[r * C + cc];
-            ds = fmaf(d, w[(size_t)cc * 2 * C + c], ds);
-            dc = fmaf(d, w[(size_t)cc * 2 * C + C + c], dc);
+            ds = fmaf(d, wbuf[cc * (2 * C + 1) + c], ds);
+            dc = fmaf(d, wbuf[cc * (2 * C + 1) + C + c], dc);
           }
           ab[r * C + c] = ds * feat[r * 2 * C + C + c] - dc * feat[r * 2 * C + c];
         }
@@ -174,13 +182,15 @@ int launch_partial_sums(const float* part, long long n_items, long long n_chunks
 int launch_time_embed_bwd(const SdehTimeEmbed& te, int act, const float* ts, int n_steps, const float* gout, float clip,
                           float* workspace, float* grad_flat, hipStream_t stream) {
   if (te.n_hidden < 1 || te.n_hidden > kTeMaxHidden) return SDEH_ERR_UNSUPPORTED;
-  const size_t lds = (size_t)kTeRows * (2 * te.channels + 2 * te.n_hidden * te.channels + te.dim_out) * sizeof(float);
+  const int wrows = te.channels > te.dim_out ? te.channels : te.dim_out;
+  const size_t lds = ((size_t)kTeRows * (2 * te.channels + 2 * te.n_hidden * te.channels + te.dim_out) +
+                      (size_t)wrows * (2 * te.channels + 1)) * sizeof(float);
   if (lds > 64 * 1024) return SDEH_ERR_UNSUPPORTED;
   const long long P = time_embed_param_floats(te);
   const long long n_chunks = (n_steps + kTeRows - 1) / kTeRows;
   TeBwdArgs A;
   A.te = te; A.part = workspace; A.P = P; A.act = act; A.n_steps = n_steps; A.ts = ts; A.gout = gout; A.clip = clip;
-  hipLaunchKernelGGL(time_embed_bwd_kernel, dim3((unsigned)n_chunks), dim3(256), lds, stream, A);
+  hipLaunchKernelGGL(time_embed_bwd_kernel, dim3((unsigned)n_chunks), dim3(1024), lds, stream, A);
   if (hipGetLastError() != hipSuccess) return SDEH_ERR_HIP;
   return launch_partial_sums(workspace, 1, n_chunks, P, workspace + n_chunks * P, grad_flat, stream);
 }

@@ -286,6 +286,19 @@ class _BridgeFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
 
+def _leaves(loss, params):
+    """The tensors the autograd Function is attached to.  Normally the parameters themselves.  Inside a captured step
+    (utils/graphs.py sets `loss._graph_leaves = []`) fresh leaves aliasing the parameters' storage: the real parameters'
+    AccumulateGrad nodes may have been left alive by an earlier eager step (a `loss` tensor the caller still holds); they are
+    bound to the default stream and abort a capture they take part in.  GraphedTrainStep differentiates w.r.t. the aliases."""
+    record = getattr(loss, "_graph_leaves", None)
+    if record is None:
+        return params
+    leaves = [p.detach().requires_grad_() for p in params]
+    record.append((params, leaves))
+    return leaves
+
+
 def simulate_with_grad(loss, launch, ts, x):
     """`launch(return_traj, want_state)` runs the HIP forward; returns (x_T, rnd attached to the parameters, None)."""
     params = _ctrl_parameters(loss.generative_ctrl)
@@ -295,7 +308,7 @@ def simulate_with_grad(loss, launch, ts, x):
         state["params"] = params
         return x_T, rnd, xs, state
 
-    x_T, rnd = _TrajectoryFn.apply(loss, wrapped, ts, x, *params)
+    x_T, rnd = _TrajectoryFn.apply(loss, wrapped, ts, x, *_leaves(loss, params))
     return x_T, rnd, None
 
 
@@ -308,5 +321,5 @@ def simulate_bridge_with_grad(loss, launch, ts, x, inference_ctrl):
         state["params"] = params
         return x_T, rnd, xs, gp, state
 
-    x_T, rnd = _BridgeFn.apply(loss, wrapped, ts, x, *params)
+    x_T, rnd = _BridgeFn.apply(loss, wrapped, ts, x, *_leaves(loss, params))
     return x_T, rnd, None

@@ -7,12 +7,14 @@ issuing the rest than the GPU spends running it.  `GraphedTrainStep` records the
 (`torch.cuda.CUDAGraph`, i.e. hipStreamBeginCapture / hipGraphLaunch underneath; the ctypes launches of libsdeh.so go to
 torch's current stream and are captured like torch's own kernels) and replays it with one launch.
 
-Two things make the step replayable:
+Three things make the step replayable:
 
 * fresh noise per replay -- launch arguments (seed, offset) are frozen at capture time, so the kernels add a device-resident
   counter to the Philox offset (`SdehProblem.rng_offset_dev`, include/sdeh.h) and the graph bumps it after the optimizer step;
   the backward launch replays the forward's draws because it reads the same counter value;
-* no host round trip -- `loss.graph_safe = True` switches `compute_loss` to masked reductions (losses/oc.py).
+* no host round trip -- `loss.graph_safe = True` switches `compute_loss` to masked reductions (losses/oc.py);
+* no stale autograd state -- the captured step differentiates w.r.t. fresh aliases of the parameters, so AccumulateGrad nodes
+  that earlier eager steps left alive (bound to the default stream) never enter the captured graph.
 
 The reference trainer skips the optimizer step when the loss or a gradient is not finite (`if loss_ok and grad_ok`,
 solver/base.py:409-432) -- a host decision.  Here the same decision is taken on the device (`guard=True`): parameters and
@@ -97,8 +99,24 @@ class GraphedTrainStep:
 
     def _step(self) -> torch.Tensor:
         self.optimizer.zero_grad(set_to_none=True)
+        for lo in self.losses:
+            lo._graph_leaves = []  # the losses attach their autograd Functions to fresh aliases of the parameters (losses/_autograd.py)
         value = self._loss_fn()
-        value.backward()
+        # Gradients by torch.autograd.grad w.r.t. those aliases, never through the real parameters' AccumulateGrad nodes: a node that
+        # an earlier EAGER step left alive (e.g. through a `loss` tensor the caller still holds) is bound to the default stream, and
+        # its mere presence in the captured autograd graph aborts the process at the end of the capture on this stack.
+        owners, leaves = [], []
+        for lo in self.losses:
+            for params, aliases in lo._graph_leaves:
+                owners += params
+                leaves += aliases
+            lo._graph_leaves = None
+        covered = {id(p) for p in owners}
+        rest = [p for p in self._params if id(p) not in covered]  # parameters the loss_fn uses outside the library's losses
+        grads = torch.autograd.grad(value, leaves + rest, allow_unused=True)
+        for p, g in zip(owners + rest, grads):
+            if g is not None:
+                p.grad = g if p.grad is None else p.grad + g
         if not self.guard:
             if self._after_backward is not None:
                 self._after_backward()

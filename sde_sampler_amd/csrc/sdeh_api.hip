@@ -637,8 +637,10 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
                                       "configuration the reference produces");
   if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && dgam == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward: dgam is null");
   const WsLayout& L = ck.L;
-  if (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0 && pr->ctrl_kind != SDEH_CTRL_CLIPPED &&
-      pr->ctrl_kind != SDEH_CTRL_LERP_PRIOR)
+  // The backward kernel reads mixture tables from LDS only.  It needs them for the control's target score and -- in
+  // back-propagation through time -- for the terminal cost's d/dx_T; ClippedCtrl / LerpPriorCtrl in the row-parallel mode need neither.
+  const bool ctrl_uses_target = pr->ctrl_kind != SDEH_CTRL_CLIPPED && pr->ctrl_kind != SDEH_CTRL_LERP_PRIOR;
+  if (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0 && (ctrl_uses_target || (bptt && (pr->flags & SDEH_FLAG_TERMINAL_TARGET))))
     return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: mixture tables do not fit in LDS next to the transposed weights");
   if (ck.v->fn_bwd == nullptr) return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward: no backward kernel for this variant");
   hipStream_t st = (hipStream_t)stream;

@@ -210,7 +210,7 @@ def build(spec: dict, params: dict | None = None, target_tensors: dict | None = 
         assert not unexpected and all("timestep_coeff" in m for m in missing), (missing, unexpected)
     ls = spec["loss"]
     common = dict(generative_ctrl=ctrl, sde=sde, method=ls["method"], max_rnd=ls.get("max_rnd"),
-                  filter_samples=getattr(target, "filter", None))
+                  traj_per_sample=ls.get("traj_per_sample", 1), filter_samples=getattr(target, "filter", None))
     reference = None
     if ls["kind"] == "time_reversal":
         inference = None

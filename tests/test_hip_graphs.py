@@ -244,3 +244,70 @@ def test_graphed_step_after_eager_steps_with_live_autograd_graph():
         value = graphed()
     assert torch.isfinite(value) and torch.isfinite(kept)
     assert any(not torch.equal(p, q) for p, q in zip(params, before))
+
+
+_N_RANDOM = 12 * int(__import__("os").environ.get("SDEH_FUZZ_SCALE", "1"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(_N_RANDOM))
+def test_random_problem_replayed_gradients_equal_eager(case):
+    """The replay-vs-eager gradient check over random problems (loss x control x SDE x target x network shape x method): every
+    code path a training step can take must be capture-safe, not only the configurations picked above."""
+    import numpy as np
+    import test_hip_fuzz as F
+    from sde_sampler_amd import SdehUnsupported
+
+    rng = np.random.default_rng(21000 + case)
+    spec = F.random_spec(rng)
+    method = str(rng.choice(["kl", "kl_ito", "lv", "lv_traj"]))
+    spec["loss"]["method"] = method
+    spec["loss"]["max_rnd"] = 1e8 if method.startswith("lv") else None
+    if method == "lv_traj":
+        spec["loss"]["traj_per_sample"] = 2
+    B = int(rng.choice([64, 100, 2048]))
+    torch.manual_seed(case)
+    prob = problems.build(spec, device="cuda:0")
+    params = _params(prob)
+    x = prob.prior.sample((B,))
+    lo = prob.loss
+    lo.graph_safe = True
+    lo.rng_counter = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+
+    def run():
+        for p in params:
+            p.grad = None
+        lo.engine.calls = 9
+        value = lo(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
+        value.backward()
+        return value
+
+    try:
+        eager_value = run().detach().clone()
+    except SdehUnsupported as exc:
+        pytest.skip(str(exc)[:120])
+    eager = [None if p.grad is None else p.grad.clone() for p in params]
+    if not torch.isfinite(eager_value) or any(g is not None and not torch.isfinite(g).all() for g in eager):
+        pytest.skip("random configuration without a finite loss / gradient")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for p in params:
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        value = run()
+    for rep in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(value, eager_value, rtol=1e-5, atol=1e-6)
+        for (name, _), p, g in zip(prob.ctrl.named_parameters(), params, eager):
+            if g is None:
+                assert p.grad is None
+                continue
+            scale = float(g.abs().max()) + 1e-12
+            err = float((p.grad - g).abs().max())
+            assert err <= 1e-5 * scale, (rep, method, spec["loss"]["kind"], spec["ctrl"]["kind"], spec["target"]["kind"], name, err, scale)

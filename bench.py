@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: trajectory-steps/s of the fused Euler-Maruyama engine on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric "trajectory-steps/sec ... GMM-40 d=50"): target = 40-mode GMM in d=50
-(fab means in the first two coordinates, scale softplus(1)), solver basic_pis (ScoreCtrl + FourierMLP C=64/4 layers
-GELU, Delta prior, ScaledBM(sqrt 0.2, T=5)), batch 65 536 trajectories PER GPU, T = 100 steps, fp32, in-kernel
-Philox noise, random-init weights (last layers N(0, 0.05^2)), x0 resident in HBM.
-One "step" = one pass of the hot path over the batch with the reference's `eval/sample_time` semantics
-(solver/oc.py:88-97): loss.eval(ts, x, ..., compute_weights=False, return_traj=False) under no_grad, i.e. the
-trajectory kernel + the log-Z lower-bound reduction (+ the 8-float all-gather when N > 1).
-Prints ONE JSON line (rank 0).
+N > 1 works both ways: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the ranks read
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or invoked plainly -- then this script spawns the N ranks itself
+(one process per GPU, RCCL) and errors out when the node has fewer GPUs than ranks.
+
+Workload at N = 1 (BASELINE.json metric "trajectory-steps/sec ... GMM-40 d=50"): target = 40-mode GMM in d=50 (fab means in the
+first two coordinates, scale softplus(1)), solver basic_pis (ScoreCtrl + FourierMLP C=64 / 4 layers GELU, Delta prior,
+ScaledBM(sqrt 0.2, T=5)), batch 65 536 trajectories PER GPU, T = 100 steps, fp32, in-kernel Philox noise, random-init weights
+(last layers N(0, 0.05^2)), x0 resident in HBM.  One "step" = one pass of the hot path over the batch with the reference's
+`eval/sample_time` semantics (solver/oc.py:88-97): loss.eval(ts, x, ..., compute_weights=False, return_traj=False) under
+no_grad, i.e. the trajectory kernel + the log-Z lower-bound reduction (+ the 8-float all-gather when N > 1).
+`--workload` selects the other measured configurations (see WORKLOADS).  Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -26,18 +31,30 @@ import torch
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-WORKLOAD = "gmm50_pis_headline"
 PEAK_FP32_TFLOPS = 157.3  # MI355X fp32 MFMA (= fp32 vector) dense peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+#: name -> (problems.py spec name, metric label, description).  The first entry is the metric's configuration.
+WORKLOADS = {
+    "gmm50_pis_headline": ("gmm50_pis_headline", "trajectory-steps/sec (batch x steps / s), GMM-40 d=50",
+                           "GMM-40 d=50 (explicit loc/scale), basic_pis (ScoreCtrl, FourierMLP C=64 L=4 GELU, Delta prior, "
+                           "ScaledBM sqrt(0.2) T=5), eval sample_time semantics"),
+    "gmm50_dense_shared": ("gmm50_dense_shared", "trajectory-steps/sec, GMM-40 d=50 with means varying in ALL coordinates",
+                           "as the headline, but loc ~ U(-40, 40) in every coordinate (shared scale softplus(1))"),
+    "gmm50_dense_general": ("gmm50_dense_general", "trajectory-steps/sec, GMM-40 d=50 dense means, per-component scales",
+                            "as the headline, but loc ~ U(-40, 40) and scale ~ U(1, 1.5) per (component, coordinate)"),
+    "wide_pis_funnel196": ("wide_pis_funnel196", "trajectory-steps/sec, funnel d=196, FourierMLP C=256",
+                           "funnel d=196, basic_pis-style (ScoreCtrl, FourierMLP C=256 L=4 GELU, ScaledBM), wide-network kernel"),
+    "cfg5_like_bridge196": ("cfg5_like_bridge196", "trajectory-steps/sec, Bridge d=196 C=256 (BASELINE configs[4] shape)",
+                            "Bridge (LerpTargetCtrl + LerpPriorCtrl inference control, exact divergence), funnel d=196 target "
+                            "in place of the unfusable NICE flow, two FourierMLP C=256 L=4 GELU, ScaledBM(1, T=1)"),
+}
 
-def measured_hbm_traffic():
-    """HBM bytes per trajectory-kernel launch from the committed rocprofv3 PMC passes (tools/pmc_profile.sh):
-    2 x FETCH_SIZE (gfx950 correction for wide coalesced reads, MI355X_MICROARCH.md section HBM) + WRITE_SIZE, KiB -> bytes."""
-    path = ROOT / "profiles" / "pmc_traffic.json"
+
+def pmc_record():
+    """Per-launch PMC counters of the headline trajectory kernel from the committed rocprofv3 passes (tools/pmc_profile.sh)."""
     try:
-        rec = json.loads(path.read_text())
-        return (2.0 * rec["FETCH_SIZE_KiB"] + rec["WRITE_SIZE_KiB"]) * 1024.0
-    except (OSError, KeyError, ValueError):
+        return json.loads((ROOT / "profiles" / "pmc_headline.json").read_text())
+    except (OSError, ValueError):
         return None
 
 
@@ -46,69 +63,152 @@ def flops_per_traj_step(d: int, c: int, lh: int, k: int) -> float:
     return 4 * d * c + 2 * lh * c * c + 6 * d * k + 4 * k + 20 * d
 
 
-def cpu_baseline(spec, prob_cpu_state, budget_s: float = 20.0) -> dict:
-    """The reference's CPU path (oracle = op-for-op PyTorch-CPU restatement) on a bounded sample of the workload:
-    chunks of 2048 trajectories, each integrated for all T steps, until ~budget_s of CPU time is spent."""
+def algorithmic_flops(spec: dict) -> float:
+    d, c, lh = spec["target"]["dim"], spec["net"]["channels"], spec["net"]["num_layers"] - 2
+    k = 40 if spec["target"]["kind"] == "gmm" else 0
+    f = flops_per_traj_step(d, c, lh, k)
+    if spec.get("inference_ctrl"):
+        # Bridge (losses/oc.py:189-202): a second network pass + the exact divergence of the inference control.  Minimal
+        # formulation: per coordinate two C x C products (forward tangent through hidden layer 1, adjoint through
+        # hidden layer 2) and a length-C dot product -- the reference's d backward passes cost about twice that.
+        ci, lhi = spec.get("inference_net", spec["net"])["channels"], spec.get("inference_net", spec["net"])["num_layers"] - 2
+        f += 4 * d * ci + 2 * lhi * ci * ci + d * (2 * lhi * ci * ci + 2 * ci)
+    return f
+
+
+def physical_cores() -> int:
+    try:
+        import psutil
+
+        return psutil.cpu_count(logical=False) or (os.cpu_count() or 1)
+    except Exception:  # pragma: no cover
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | None = None) -> dict:
+    """The reference's CPU path (oracle = op-for-op PyTorch-CPU restatement, bit-exact on the reference-generated fixtures) on a
+    bounded sample of the same workload, SURVEY.md 8d: torch.set_num_threads(all physical cores) AND one thread, median of >= 5
+    full-T chunks after one warm-up chunk, `sample_time` semantics (compute_weights=False, no trajectory)."""
     from oracle import em_oracle as eo
 
     params, tt = prob_cpu_state
-    oracle = eo.Problem(spec, params, tt)
+    oracle = eo.Problem(spec, params, tt, params_inf=None) if not spec.get("inference_ctrl") else None
+    if oracle is None:
+        return {"value": None, "unit": "trajectory-steps/s", "cores": 0, "kind": "port", "sample": "not run for this workload"}
     ts = oracle.grid()
     T, d = ts.numel() - 1, spec["target"]["dim"]
-    chunk = 2048
-    x0 = torch.zeros(chunk, d)  # Delta prior: x0 = 0 (distr/delta.py:25-28)
-    ncpu = os.cpu_count() or 1
-    # pick the intra-op thread count on a short probe (all hardware threads is not always the fastest)
-    best = None
-    for threads in sorted({ncpu, max(1, ncpu // 2), min(ncpu, 32)}, reverse=True):
+    cores = physical_cores()
+
+    def timed(threads: int, chunk: int, budget: float):
         torch.set_num_threads(threads)
-        oracle.eval(ts[:3], x0, None, compute_weights=False)  # warm-up
-        t0 = time.perf_counter()
-        oracle.eval(ts[:6], x0, None, compute_weights=False)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[1]:
-            best = (threads, dt)
-    threads = best[0]
-    torch.set_num_threads(threads)
-    torch.manual_seed(7)
-    done, lbs = 0, []
-    t0 = time.perf_counter()
-    while True:
-        res = oracle.eval(ts, x0, None, compute_weights=False)
-        lbs.append(res["log_norm_const_lb"])
-        done += chunk
-        dt = time.perf_counter() - t0
-        if dt > budget_s or done >= spec["batch"]:
-            break
-    return {"value": done * T / dt, "unit": "trajectory-steps/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/em_oracle.py (PyTorch-CPU restatement of the reference loop, torch.randn noise), same "
-                      f"workload, {done} of {spec['batch']} trajectories in chunks of {chunk}, T={T}, {threads} torch "
-                      f"threads of {ncpu} hardware threads, {dt:.1f} s, log_norm_const_lb={sum(lbs) / len(lbs):.4f}"}
+        torch.manual_seed(7)
+        x0 = torch.zeros(chunk, d) if spec["prior"]["kind"] == "delta" else torch.randn(chunk, d)
+        oracle.eval(ts, x0, None, compute_weights=False)  # warm-up chunk
+        rates, lbs, t_begin = [], [], time.perf_counter()
+        while len(rates) < 5 or (time.perf_counter() - t_begin < budget and len(rates) < 9):
+            t0 = time.perf_counter()
+            res = oracle.eval(ts, x0, None, compute_weights=False)
+            rates.append(chunk * T / (time.perf_counter() - t0))
+            lbs.append(res["log_norm_const_lb"])
+        return statistics.median(rates), len(rates), sum(lbs) / len(lbs), time.perf_counter() - t_begin
+
+    scale = max(1.0, algorithmic_flops(spec) / 42344.0)  # keep the CPU work bounded for the heavier workloads
+    chunk_all, chunk_one = max(64, int(4096 / scale)), max(16, int(256 / scale))
+    rate_all, n_all, lb_all, s_all = timed(cores, chunk_all, budget_s * 0.5)
+    rate_one, n_one, lb_one, s_one = timed(1, chunk_one, budget_s * 0.5)
+    torch.set_num_threads(cores)
+    parity_out = None
+    if parity is not None:  # the trained control on the GPU leg's x0 / noise: what the reference's CPU path computes for them
+        ref = eo.Problem(spec, parity["params"], tt).eval(parity["ts"], parity["x0"], parity["noise"], compute_weights=True)
+        parity_out = {"cpu_log_norm_const_is": ref["log_norm_const_is"], "cpu_log_norm_const_lb_ito": ref["log_norm_const_lb_ito"],
+                      "delta_vs_cpu": parity["gpu_is"] - ref["log_norm_const_is"],
+                      "delta_lb_ito_vs_cpu": parity["gpu_lb_ito"] - ref["log_norm_const_lb_ito"]}
+    return {"parity_log_z": parity_out, "value": rate_all, "unit": "trajectory-steps/s", "cores": cores, "kind": "port",
+            "value_1_thread": rate_one,
+            "sample": f"oracle/em_oracle.py (PyTorch-CPU restatement of the reference loop, torch.randn noise), same workload; "
+                      f"{cores} torch threads (= physical cores; {os.cpu_count()} hardware threads): median of {n_all} chunks of "
+                      f"{chunk_all} trajectories x T={T} after 1 warm-up ({s_all:.1f} s, log_norm_const_lb={lb_all:.4f}); "
+                      f"1 thread: median of {n_one} chunks of {chunk_one} ({s_one:.1f} s) -> {rate_one:.3e} trajectory-steps/s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=10,
-                    help="untimed steps (the first ~8 launches after idle run while the GPU clock is still ramping up)")
-    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the workload's 65 536)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the cpu_baseline leg")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--same-device", action="store_true",
-                    help="testing aid: all ranks use cuda:0 (with --backend gloo) to exercise the N > 1 path on one GPU")
-    args = ap.parse_args()
+def timed_kernel_ms(prob, x0, n_warm: int = 3, n: int = 5) -> float:
+    for _ in range(n_warm):
+        prob.eval(x0, compute_weights=False, return_traj=False)
+    ms = []
+    for _ in range(n):
+        prob.eval(x0, compute_weights=False, return_traj=False)
+        ms.append(prob.loss.engine.last_kernel_ms())
+    return sum(ms) / len(ms)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+def extra_block(device, B: int) -> dict:
+    """Kernel time of the workloads the headline's specialisations do not apply to, same B and T: dense-mean
+    mixtures (no varying-prefix shortcut), and the headline forced onto the generic run-time-switched kernel."""
+    from sde_sampler_amd import problems
+
+    out = {}
+    for name in ("gmm50_dense_shared", "gmm50_dense_general", "gmm50_pis_headline"):
+        spec = problems.baseline_spec(name)
+        spec["batch"] = B
+        generic = name == "gmm50_pis_headline"
+        if generic:
+            os.environ["SDEH_GENERIC_ONLY"] = "1"
+        try:
+            prob = problems.build(spec, device=device)
+            prob.loss.engine.timing = True
+            x0 = prob.prior.sample((B,))
+            ms = timed_kernel_ms(prob, x0)
+        finally:
+            os.environ.pop("SDEH_GENERIC_ONLY", None)
+        T = prob.ts.numel() - 1
+        tf = algorithmic_flops(spec) * B * T / (ms * 1e-3) / 1e12
+        out["headline_generic_kernel" if generic else name] = {"kernel_ms": ms, "algorithmic_tflops": tf,
+                                                               "frac": tf / PEAK_FP32_TFLOPS}
+    return out
+
+
+def log_z_block(spec, device, B: int, rank: int, world: int) -> dict | None:
+    """log-Z quality on the headline target with a TRAINED control (tests/golden/trained_pis_gmm50.pt, produced by
+    tools/train_demo.py with the HIP training path): importance-sampling log Z in fast mode (in-kernel noise) with its standard
+    error and ESS, and -- parity mode, identical noise -- against the CPU oracle on a sub-batch."""
+    path = ROOT / "tests" / "golden" / "trained_pis_gmm50.pt"
+    if not path.exists() or world != 1:
+        return None
+    from sde_sampler_amd import engine as E
+    from sde_sampler_amd import problems
+
+    state = torch.load(path, map_location="cpu")
+    prob = problems.build(spec, params=state["params"], device=device)
+    x0 = prob.prior.sample((B,))
+    with torch.no_grad():
+        _, rnd, _ = prob.loss.simulate(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, compute_ito_int=True)
+    est = E.estimators_from_stats(E.merge_stats(E.estimator_stats(rnd)))
+    w = torch.exp(-rnd.double() - est["log_weight_max"]).flatten()
+    se = float(w.std() / w.mean() / math.sqrt(B))  # delta method: s.e.(log mean w) = cv(w) / sqrt(B)
+    out = {"control": "trained (tests/golden/trained_pis_gmm50.pt: %s)" % state.get("note", ""),
+           "log_norm_const_is": est["log_norm_const_is"], "se": se, "ess": est["ess"], "ess_frac": est["ess"] / B,
+           "log_norm_const_lb_ito": est["mean_neg_rnd"], "true_log_norm_const": 0.0, "batch": B}
+    # parity mode on a sub-batch (identical x0 and noise): the GPU half here, the CPU half inside the cpu_baseline leg
+    Bs, T, d = 4096, prob.ts.numel() - 1, spec["target"]["dim"]
+    torch.manual_seed(11)
+    noise = torch.randn(T, Bs, d)
+    got = prob.eval(x0[:Bs], compute_weights=True, return_traj=False, noise=noise.to(device))
+    out["parity_batch"] = Bs
+    out["_parity"] = dict(params=state["params"], x0=x0[:Bs].cpu(), noise=noise, ts=prob.ts.cpu(),
+                          gpu_is=got.log_norm_const_preds["log_norm_const_is"],
+                          gpu_lb_ito=got.log_norm_const_preds["log_norm_const_lb_ito"])
+    return out
+
+
+def run(args, rank: int, world: int, local_rank: int):
     import torch.distributed as dist
 
     if args.same_device:
         local_rank = 0
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        raise SystemExit(f"rank {rank}: needs cuda:{local_rank} but the node has {n_dev} GPU(s) "
+                         f"(--same-device --backend gloo exercises the N > 1 path on one GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
@@ -120,17 +220,20 @@ def main():
 
     from sde_sampler_amd import problems
 
-    spec = problems.baseline_spec(WORKLOAD)
+    spec_name, metric, description = WORKLOADS[args.workload]
+    spec = problems.baseline_spec(spec_name)
     if args.batch:
         spec["batch"] = args.batch
+    if args.em_steps:
+        spec["grid"]["steps"] = args.em_steps
     prob = problems.build(spec)
     cpu_state = ({k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()},
                  dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(),
-                      mixture_weights=prob.target.mixture_weights.clone()))
+                      mixture_weights=prob.target.mixture_weights.clone()) if spec["target"]["kind"] == "gmm" else None)
     prob.to(device)
     B, T, d = spec["batch"], prob.ts.numel() - 1, spec["target"]["dim"]
     # the same seed on every rank: the in-kernel Philox stream is keyed by (seed, call, GLOBAL row), so the N-rank job draws
-    # exactly the noise a single launch over the N*B rows would (x0 of the Delta prior is zero on every rank)
+    # exactly the noise a single launch over the N*B rows would (the prior draw below is per rank)
     torch.manual_seed(1)
     x0 = prob.prior.sample((B,))
     prob.loss.row_offset = rank * B
@@ -166,42 +269,111 @@ def main():
             dist.destroy_process_group()
         return
 
-    flops = flops_per_traj_step(d, 64, spec["net"]["num_layers"] - 2, 40)
+    flops = algorithmic_flops(spec)
     k_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = flops * B * T / (k_ms * 1e-3) / 1e12
+    headline = args.workload == "gmm50_pis_headline" and B == 65536 and T == 100
+    pmc = pmc_record() if headline else None
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "traffic": (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None,
+                "algorithmic_hbm_bytes": B * (8 * d + 4),
+                "kernel": prob.loss.engine.last_kernel_name(), "kernel_ms": k_ms, "kernel_ms_min": min(kernel_ms),
+                "flops_per_traj_step": flops,
+                "note": "fp32 MFMA and fp32 VALU share one datapath on gfx950 (profiles/r01_ubench_coexec.txt): 157.3 TFLOP/s is "
+                        "the budget for both; `achieved` counts SURVEY 8d's ALGORITHMIC FLOPs; `executed_tflops` counts the "
+                        "instructions the kernel really issued (committed PMC pass of this workload): SQ_INSTS_MFMA x 4096 "
+                        "(v_mfma_f32_32x32x2_f32) + SQ_INSTS_VALU_FMA_F32 x 128 (64 lanes x 2), divided by this run's kernel time"}
+    if pmc and "SQ_INSTS_MFMA" in pmc:
+        executed = (pmc["SQ_INSTS_MFMA"] * 4096.0 + pmc["SQ_INSTS_VALU_FMA_F32"] * 128.0) / (k_ms * 1e-3) / 1e12
+        roofline["executed_tflops"] = executed
+        roofline["frac_executed"] = executed / PEAK_FP32_TFLOPS
+        roofline["pmc_source"] = pmc.get("source")
     out = {
-        "metric": "trajectory-steps/sec (batch x steps / s), GMM-40 d=50",
+        "metric": metric,
         "value": world * B * T * args.steps / elapsed,
         "unit": "trajectory-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{WORKLOAD}: GMM-40 d=50 (explicit loc/scale), basic_pis (ScoreCtrl, FourierMLP C=64 "
-                               f"L=4 GELU, Delta prior, ScaledBM sqrt(0.2) T=5), eval sample_time semantics",
-                   "batch_per_gpu": B, "global_batch": world * B, "em_steps": T, "dim": d, "gmm_components": 40,
+        "config": {"workload": f"{args.workload}: {description}",
+                   "batch_per_gpu": B, "global_batch": world * B, "em_steps": T, "dim": d,
+                   "channels": spec["net"]["channels"],
                    "noise": "in-kernel Philox4x32-10 + Box-Muller", "parallelism": f"batch-sharded x{world}"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_hbm_traffic(),
-                     "algorithmic_hbm_bytes": B * (8 * d + 4),
-                     "kernel": "sdeh::traj_ws_kernel<50,64,...> (wave-specialised; pis_gmm4 variant)", "kernel_ms": k_ms,
-                     "kernel_ms_min": min(kernel_ms),
-                     "flops_per_traj_step": flops,
-                     "note": "fp32 MFMA and fp32 VALU share one datapath on gfx950 (profiles/r01_ubench_coexec.txt): "
-                             "157.3 TFLOP/s is the budget for both; F counts SURVEY 8d's algorithmic FLOPs"},
-        "log_z": {"log_norm_const_is": full.log_norm_const_preds["log_norm_const_is"],
-                  "log_norm_const_lb_ito": full.log_norm_const_preds["log_norm_const_lb_ito"],
-                  "log_norm_const_lb": res.log_norm_const_preds["log_norm_const_lb"],
-                  "true_log_norm_const": 0.0},
+        "roofline": roofline,
+        "log_z_untrained_control": {"log_norm_const_is": full.log_norm_const_preds["log_norm_const_is"],
+                                    "log_norm_const_lb_ito": full.log_norm_const_preds["log_norm_const_lb_ito"],
+                                    "log_norm_const_lb": res.log_norm_const_preds["log_norm_const_lb"],
+                                    "true_log_norm_const": 0.0,
+                                    "note": "random-init control: importance weights are degenerate, only the bound is meaningful"},
     }
-    print("[bench] gpu leg done: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline", "log_z")}),
+    print("[bench] gpu leg done: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline")}),
           file=sys.stderr, flush=True)
+    if world == 1 and headline and not args.no_extra:
+        out["log_z"] = log_z_block(spec, device, B, rank, world)
+        out["extra"] = extra_block(device, B)
+    parity = out["log_z"].pop("_parity", None) if out.get("log_z") else None
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(spec, cpu_state, args.cpu_budget)
-        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-    print(json.dumps(out))
+        out["cpu_baseline"] = cpu_baseline(spec, cpu_state, args.cpu_budget, parity)
+        checked = out["cpu_baseline"].pop("parity_log_z", None)
+        if checked:
+            out["log_z"].update(checked)
+        if out["cpu_baseline"]["value"]:
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _spawned(rank: int, args, port: int):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    run(args, rank, args.gpus, rank)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 1000 for the headline so that the timed region is > 2 s; fewer for the heavy workloads)")
+    ap.add_argument("--warmup", type=int, default=None,
+                    help="untimed steps (the first ~8 launches after idle run while the GPU clock is still ramping up)")
+    ap.add_argument("--workload", default="gmm50_pis_headline", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the workload's)")
+    ap.add_argument("--em-steps", type=int, default=None, help="Euler-Maruyama steps T (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the log_z / extra blocks of the headline line")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="testing aid: all ranks use cuda:0 (with --backend gloo) to exercise the N > 1 path on one GPU")
+    args = ap.parse_args()
+    heavy = args.workload in ("wide_pis_funnel196", "cfg5_like_bridge196")
+    if args.steps is None:
+        args.steps = 5 if heavy else 1000
+    if args.warmup is None:
+        args.warmup = 2 if heavy else 20
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:  # launched by torch.distributed.run (or an equivalent launcher)
+        world = int(env_world)
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        run(args, int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0")))
+    elif args.gpus > 1:  # plain invocation: spawn one rank per GPU ourselves
+        if not args.same_device and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s)")
+        import socket
+
+        import torch.multiprocessing as mp
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_spawned, args=(args, port), nprocs=args.gpus, join=True)
+    else:
+        run(args, 0, 1, 0)
 
 
 if __name__ == "__main__":

@@ -71,8 +71,15 @@ enum {
   SDEH_FLAG_REFERENCE_CTRL = 64, /* ReferenceSDELoss.reference_ctrl = sigma(t) * prior.score(x) (solver/oc.py:305-306) */
   SDEH_FLAG_INFERENCE_SDE = 128, /* sdeh_integrate only: the sde was built with generative=False (eq/sdes.py:76-77: sign -1,
                                     VP schedule min->max) and ControlledSDE evaluates its ctrl at terminal_t - t (sdes.py:301-303) */
-  SDEH_FLAG_INFERENCE_CTRL = 256 /* TimeReversalLoss.inference_ctrl is set (Bridge, losses/oc.py:189-202): SdehProblem.inference
+  SDEH_FLAG_INFERENCE_CTRL = 256,/* TimeReversalLoss.inference_ctrl is set (Bridge, losses/oc.py:189-202): SdehProblem.inference
                                     describes it; rnd += sigma div_x(v) dt with the EXACT divergence, costs on u + v / u - v */
+  /* Backward passes only (sdeh_ctrl_backward[_ex] in back-propagation-through-time mode): which score terms of the control are
+   * CONSTANTS of the autograd graph in the reference.  generative_ctrl.detach_score = True detaches x in front of every score
+   * (models/reparam.py:58,134,169,188); with detach_score = False a score obtained by autograd (Distribution.score with
+   * create_graph=False, distr/base.py:130-137: GMM, also a one-component GMM that the engine evaluates as a Gaussian) is still
+   * a constant, closed-form scores are differentiated.  Mixture targets are always treated as constants by the kernel. */
+  SDEH_FLAG_DETACH_SCORE = 512,       /* target AND prior score terms of the control carry no d/dx */
+  SDEH_FLAG_TARGET_SCORE_CONST = 1024 /* only the target score term carries no d/dx */
 };
 
 /* GMM only: scale[k,d] == scale[0,d] for every component k (true for every named mixture of the reference,
@@ -192,6 +199,9 @@ void sdeh_plan_destroy(SdehPlan* plan);
  * it is launched on; sdeh_plan_last_kernel_ms waits for the stop event and returns the elapsed time. */
 int32_t sdeh_plan_set_timing(SdehPlan* plan, int32_t enable);
 int32_t sdeh_plan_last_kernel_ms(SdehPlan* plan, float* ms);
+/* Which compiled trajectory kernel served the plan's last sdeh_simulate_fwd* call (e.g. "traj_ws<50_0_pis_gmm4>",
+ * "traj_legacy<64_1_g>", "traj_wide<C=256,CT=2>", "bridge_wide<C=256>"); "" before the first call.  The string is owned by the plan. */
+const char* sdeh_plan_last_kernel_name(SdehPlan* plan);
 
 /*
  * The hot path.  Replaces {TimeReversalLoss,ReferenceSDELoss,ExponentialIntegratorSDELoss}.simulate

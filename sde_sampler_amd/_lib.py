@@ -23,6 +23,7 @@ ACT_GELU_ERF, ACT_SILU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
 FLAG_TRAIN, FLAG_ITO, FLAG_CHANGE_SDE_CTRL, FLAG_INIT_LOGP = 1, 2, 4, 8
 FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL = 16, 32, 64
 FLAG_INFERENCE_SDE, FLAG_INFERENCE_CTRL = 128, 256
+FLAG_DETACH_SCORE, FLAG_TARGET_SCORE_CONST = 512, 1024
 INT_LANGEVIN, INT_CONTROLLED = 0, 1
 DENS_FLAG_SHARED_SCALE = 1
 
@@ -111,6 +112,7 @@ PROTOTYPES = {
     "sdeh_plan_destroy": (None, [C.c_void_p]),
     "sdeh_plan_set_timing": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sdeh_plan_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
+    "sdeh_plan_last_kernel_name": (C.c_char_p, [C.c_void_p]),
     "sdeh_simulate_fwd": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
                                       C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, C.c_void_p]),
     "sdeh_ctrl_backward": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64,

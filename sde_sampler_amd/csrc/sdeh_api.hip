@@ -181,6 +181,7 @@ struct SdehPlan {
   bool timing;
   bool timed;
   hipEvent_t ev0, ev1;
+  char last_kernel[96];
 };
 static constexpr int kRedBlocks = SDEH_REDUCE_SCRATCH / 8;
 
@@ -222,6 +223,7 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
                  (size_t)make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, 0, v->dp, false, true, 0, true, true).total + 64;
   p->timing = p->timed = false;
   p->ev0 = p->ev1 = nullptr;
+  p->last_kernel[0] = 0;
   int prev = 0;
   hipError_t e = hipGetDevice(&prev);
   if (e == hipSuccess) e = hipSetDevice(desc->device);
@@ -256,6 +258,8 @@ int32_t sdeh_plan_last_kernel_ms(SdehPlan* plan, float* ms) {
   if (e == hipSuccess) e = hipEventElapsedTime(ms, plan->ev0, plan->ev1);
   return e == hipSuccess ? SDEH_OK : fail(SDEH_ERR_HIP, "plan_last_kernel_ms: %s", hipGetErrorString(e));
 }
+
+const char* sdeh_plan_last_kernel_name(SdehPlan* plan) { return plan == nullptr ? "" : plan->last_kernel; }
 
 void sdeh_plan_destroy(SdehPlan* plan) {
   if (plan == nullptr) return;
@@ -373,8 +377,8 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   const Variant* v = plan->variant;
   const bool shared = pr->target.kind == SDEH_DENS_GMM && (pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE);
   const int nvary = shared ? SDEH_DENS_FLAG_GET_NVARY(pr->target.flags) : -1;
-  static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
-  static const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing aid: force the generic variants
+  const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
+  const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing / measurement aid: force the generic variants (read per call)
   // which GMM table form would the layout give?  (0: tables do not fit LDS, 1: general, 2: shared scale)
   // the integrator runs on the single-wave code path of the generic variant (mixture tables in LDS when they fit)
   WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, 0, backward);
@@ -465,6 +469,7 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   rc = v->fn_bridge(A, st);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bridge<%s>", v->name);
   if (rc == SDEH_ERR_UNSUPPORTED)
     return fail(rc, "simulate_fwd (bridge): two packed networks (+ mixture scratch) exceed 160 KiB of LDS at dim=%d", d);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "simulate_fwd (bridge): kernel launch failed");
@@ -494,7 +499,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise);
   const WsLayout& L = ck.L;
   const Variant* v = ck.v;
-  static const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;
+  const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;
 
   hipStream_t st = (hipStream_t)stream;
   PrepArgs P;
@@ -523,6 +528,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   // The wave-specialised kernel needs GMM tables in LDS; mixtures too large for that use the single-wave kernel
   // with scalar-load tables (also selectable with SDEH_LEGACY=1 for A/B measurements).
   const bool legacy = force_legacy || (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0);
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "%s<%s>", legacy ? "traj_legacy" : "traj_ws", v->name);
   if (legacy) {
     rc = v->fn_legacy(A, st);
     if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);
@@ -534,6 +540,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) {
       A.zt_out = nullptr; A.nn_out = nullptr;
       rc = plan->variant->fn_legacy(A, st);
+      snprintf(plan->last_kernel, sizeof(plan->last_kernel), "traj_legacy<%s>", plan->variant->name);
     }
   }
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }

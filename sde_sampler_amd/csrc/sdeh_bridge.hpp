@@ -841,7 +841,8 @@ template <int DP, int C, bool PAD>
 int launch_bridge_div_bwd(const BridgeBwdArgs& a, hipStream_t stream) {
   const size_t lds_bytes = (size_t)a.lay2.lds_floats * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
-  static bool attr_set = false;
+  static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
+  bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_div_bwd_kernel<DP, C, PAD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -858,7 +859,8 @@ int launch_bridge(const TrajArgs& a, hipStream_t stream) {
   const int k_scratch = a.lay.k_max > 0 ? a.lay.k_max : 0;
   const size_t lds_bytes = ((size_t)a.lay.lds_floats + (size_t)a.lay2.lds_floats + (size_t)k_scratch * 256) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
-  static bool attr_set = false;
+  static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
+  bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_kernel<DP, C, PAD, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

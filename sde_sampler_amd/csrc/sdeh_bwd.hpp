@@ -465,12 +465,15 @@ __device__ __forceinline__ void bwd_tile(const BwdArgs& A, const float* __restri
     float cvec[DP], vt[DP];
 #pragma unroll
     for (int j = 0; j < DP; ++j) cvec[j] = fabsf(sc[j]) <= A.clip_score ? mfac[j] * G[j] : 0.0f;
-    if (coef_t != 0.0f) target_score_jt<DP>(A.target, ws, L, d, x, cvec, vt);
+    // score terms the reference detaches (reparam.py:58,134,169,188) or obtains by autograd without a graph carry no Jacobian
+    const float jac_t = (A.flags & (SDEH_FLAG_DETACH_SCORE | SDEH_FLAG_TARGET_SCORE_CONST)) ? 0.0f : coef_t;
+    const float jac_p = (A.flags & SDEH_FLAG_DETACH_SCORE) ? 0.0f : coef_p;
+    if (jac_t != 0.0f) target_score_jt<DP>(A.target, ws, L, d, x, cvec, vt);
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
       float v = BPTT ? fmaf(c_x, lam[j], dx[j]) : dx[j];
-      if (coef_t != 0.0f) v = fmaf(coef_t, vt[j], v);
-      if (coef_p != 0.0f) v = fmaf(-coef_p * ptab[j].y, cvec[j], v);   // Gaussian prior: J = -1/sigma^2
+      if (jac_t != 0.0f) v = fmaf(jac_t, vt[j], v);
+      if (jac_p != 0.0f) v = fmaf(-jac_p * ptab[j].y, cvec[j], v);   // Gaussian prior: J = -1/sigma^2
       if (refc) v = fmaf(sig * ptab[j].y, Gc[j], v);                   // cost depends on x through sigma * prior.score(x)
       if (BPTT) {
         if (A.lam_extra != nullptr) v += A.lam_extra[((long long)t * B + irow) * d + (PAD ? min(j, d - 1) : j)];
@@ -552,7 +555,8 @@ int launch_ctrl_bwd(const BwdArgs& a, hipStream_t stream) {
   const size_t lds_bytes = (size_t)a.lay.lds_floats * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   const bool bptt = !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL);
-  static bool attr_set = false;
+  static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
+  bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ctrl_bwd_kernel<DP, C, PAD, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -211,6 +211,14 @@ struct SinkArgs {
   float inv_eps;
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: the launchers remember it per device ordinal
+constexpr int kMaxDevices = 64;
+inline int current_device_slot() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
+
 // launchers implemented in the per-DP translation units (sdeh_traj_inst.hip)
 typedef int (*TrajLauncher)(const TrajArgs& a, hipStream_t stream);
 typedef int (*SinkLauncher)(const SinkArgs& a, int mode, int splits, hipStream_t stream);

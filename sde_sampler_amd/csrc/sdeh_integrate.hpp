@@ -129,7 +129,8 @@ int launch_integrate(const TrajArgs& a, hipStream_t stream) {
   const int k_scratch = (a.lay.k_max > 0 && a.lay.gmm_lds == 0) ? a.lay.k_max : 0;
   const size_t lds_bytes = ((size_t)a.lay.lds_floats + (size_t)k_scratch * 256) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
-  static bool attr_set = false;
+  static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
+  bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&integrate_kernel<DP, C, PAD, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

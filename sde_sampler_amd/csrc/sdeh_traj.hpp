@@ -16,11 +16,6 @@ namespace sdeh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// Ablation switches for tools/ablate.py (never set in the shipped library): 1 = no MLP, 2 = no target score,
-// 4 = no Philox/Box-Muller, 8 = no activation.  Each stub keeps its consumers live (guide rule 17).
-#ifndef SDEH_ABL
-#define SDEH_ABL 0
-#endif
 // Tables that are uniform across the wave are read through the constant address space so that hipcc emits
 // scalar loads (s_load_dwordx*) and feeds them to the VALU as SGPR operands.
 typedef const float __attribute__((address_space(4))) * cfp;
@@ -65,7 +60,6 @@ __device__ __forceinline__ float act_relu(float v) { return fmaxf(v, 0.0f); }
 
 template <int N>
 __device__ __forceinline__ void activate(f32x16 (&a)[N], f32x16 (&b)[N], int act) {
-  if constexpr (SDEH_ABL & 8) return;
   if (act == SDEH_ACT_GELU_ERF) {
 #pragma unroll
     for (int t = 0; t < N; ++t)
@@ -521,26 +515,14 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
 
     // ---- generative_ctrl(s, x): score term first (it only needs x), then the network ----------------------
     float tsc[DP], psc[DP];
-    if (need_t) {
-      if constexpr (SDEH_ABL & 2) {
-#pragma unroll
-        for (int j = 0; j < DP; ++j) tsc[j] = -x[j];
-      } else {
-        target_score<DP>(tgt, ws, lds, L, gmmv, d, lg_lds, x, tsc);
-      }
-    }
+    if (need_t) target_score<DP>(tgt, ws, lds, L, gmmv, d, lg_lds, x, tsc);
     if (need_p) dgauss_score<DP>(ws + L.dg[1], x, psc);
     float sterm[DP];  // mult * scale_score * clip(score) * clip(gamma(t))
     ctrl_score_term<DP>(ctrl_kind, A, L, ws, i, cf, sig, tsc, psc, sterm);
     SDEH_FENCE();
 
     float u[DP];
-    if constexpr (SDEH_ABL & 1) {
-#pragma unroll
-      for (int j = 0; j < DP; ++j) u[j] = 0.01f * x[j];
-    } else {
-      mlp_forward<DP, C>(lds, L, act, ws + L.emb + i * C, x, u, lane);
-    }
+    mlp_forward<DP, C>(lds, L, act, ws + L.emb + i * C, x, u, lane);
 #pragma unroll
     for (int j = 0; j < DP; ++j) {  // ClippedCtrl (reparam.py:25-36) + score term
       u[j] = clipf(u[j], A.clip_model) + sterm[j];
@@ -604,13 +586,7 @@ __global__ __launch_bounds__(256) void traj_kernel(const float* __restrict__ ws,
         for (int q = 0; q < 4; ++q)
           if (4 * jb + q < DP) n[q] = np[PAD ? min(4 * jb + q, d - 1) : 4 * jb + q];
       } else if (!PAD || 4 * jb < d) {
-        if constexpr (SDEH_ABL & 4) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            n[q] = __uint_as_float((__float_as_uint(x[(4 * jb + q) % DP]) & 0x007fffffu) | 0x3f800000u) - 1.5f;
-        } else {
-          box_muller4(philox_block(A.seed, rng_off, grow, i, jb), n);
-        }
+        box_muller4(philox_block(A.seed, rng_off, grow, i, jb), n);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -653,7 +629,8 @@ int launch_traj(const TrajArgs& a, hipStream_t stream) {
   const int k_scratch = a.lay.k_max > 0 ? a.lay.k_max : 0;
   const size_t lds_bytes = ((size_t)a.lay.lds_floats + (size_t)k_scratch * 256) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
-  static bool attr_set = false;
+  static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
+  bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

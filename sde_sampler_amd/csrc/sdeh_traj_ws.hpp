@@ -289,7 +289,7 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ w, IN&& in,
     const float b = in(s);
 #pragma unroll
     for (int ot = 0; ot < OTO; ++ot) out[ot] = SDEH_MFMA(a[ot], b, out[ot]);
-    if (do_side && !(SDEH_ABL & 8)) {
+    if (do_side) {
       // the NE/2 element pairs (2i, 2i+1) are spread evenly over the NS k-steps
 #pragma unroll
       for (int i = s * (NE / 2) / NS; i < (s + 1) * (NE / 2) / NS; ++i) {
@@ -566,13 +566,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     }
     for (int i = 0; i < n_steps; ++i) {
       if constexpr (PLANES) Z.base = A.zt_out + (long long)i * A.batch + row0;
-      if constexpr ((SDEH_ABL & 1) == 0) {
-        // generic variants (ACT < 0): the activation id becomes a compile-time constant of three copies of the network --
-        // selecting it per element costs a scalar branch per element pair inside the MFMA stages (1.5x on the whole kernel)
-        SDEH_ACT_SWITCH(act, ACTC,
-          if (A.half) ws_mlp_half<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z);
-          else ws_mlp<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z););
-      }
+      // generic variants (ACT < 0): the activation id becomes a compile-time constant of three copies of the network --
+      // selecting it per element costs a scalar branch per element pair inside the MFMA stages (1.5x on the whole kernel)
+      SDEH_ACT_SWITCH(act, ACTC,
+        if (A.half) ws_mlp_half<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z);
+        else ws_mlp<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z););
       __syncthreads();  // barrier B: network output published
       if (i + 1 < n_steps) {
 #pragma unroll
@@ -630,14 +628,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     float sterm[DP];
     if (ctrl_kind != SDEH_CTRL_CLIPPED) {
       float tsc[DP], psc[DP];
-      if (need_t) {
-        if constexpr (SDEH_ABL & 2) {
-#pragma unroll
-          for (int j = 0; j < DP; ++j) tsc[j] = -x[j];
-        } else {
-          ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, tsc);
-        }
-      }
+      if (need_t) ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, tsc);
       if (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR) dgauss_score<DP>(ws + L.dg[1], x, psc);
       const float w = cf[CF_W];
       if (ctrl_kind == SDEH_CTRL_SCORE) {  // reparam.py:56-83
@@ -692,13 +683,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       for (int jb = 0; jb < (DP + 3) / 4; ++jb) {
         float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (!PAD || 4 * jb < d) {
-          if constexpr (SDEH_ABL & 4) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              n[q] = __uint_as_float((__float_as_uint(x[(4 * jb + q) % DP]) & 0x007fffffu) | 0x3f800000u) - 1.5f;
-          } else {
-            box_muller4(philox_block(A.seed, rng_off, grow, i, jb), n);
-          }
+          box_muller4(philox_block(A.seed, rng_off, grow, i, jb), n);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -732,7 +717,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     float u[DP];
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
-      const float nn = (SDEH_ABL & 1) ? 0.01f * xi[j] : xbuf[j * 64 + lane];
+      const float nn = xbuf[j * 64 + lane];
       if constexpr (PLANES) {
         if (live && (!PAD || j < d)) A.nn_out[((long long)i * A.batch + lrow) * d + j] = nn;
       }
@@ -809,7 +794,8 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   const bool pair_fits = C == 64 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
   const bool planes = a.zt_out != nullptr && a.nn_out != nullptr;
-  static bool attr_set = false;
+  static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
+  bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -202,6 +202,15 @@ def _mixture_structure(loc: torch.Tensor, scale: torch.Tensor) -> tuple[bool, in
     return shared, n_vary
 
 
+def _has_analytic_score(dist) -> bool:
+    """False when `dist.score` is Distribution.score itself (autograd of unnorm_log_prob, distr/base.py:130-137), i.e. a plain
+    GMM; Gauss / IsotropicGauss / Delta / the wells / Funnel override it with a closed form."""
+    for cls in type(dist).__mro__:
+        if "score" in vars(cls):
+            return cls.__name__ != "Distribution"
+    return True
+
+
 def _known_distribution(obj) -> bool:
     names = set(_mro_names(obj))
     return bool(names & (_GAUSS_NAMES | {"GMM", "DoubleWell", "MultiWell", "Funnel"}))
@@ -241,6 +250,11 @@ class TrajectoryEngine:
     def __init__(self):
         self._plans: dict[tuple, _Plan] = {}
         self.calls = 0  # advances the Philox stream: one `offset` per simulate() call
+        #: distinguishes the Philox streams of several engines in one process (bits 40.. of the offset): two objects with the
+        #: same `stream_id`, seed, call count and row offsets draw IDENTICAL noise.  Loss objects default to 0, the
+        #: EulerIntegrator to 1 (a loss plus the inference-process integrator is the combination the reference's solvers build);
+        #: give further loss objects of one process their own id.
+        self.stream_id = 0
         self.timing = False  # record HIP events around the trajectory kernel (bench.py)
         self._last_plan = None
 
@@ -261,11 +275,21 @@ class TrajectoryEngine:
         self._last_plan = plan
         return plan
 
+    def offset(self) -> int:
+        """The Philox offset of the NEXT launch: call count in the low 40 bits, `stream_id` above."""
+        return (int(self.stream_id) << 40) + int(self.calls)
+
     def last_kernel_ms(self) -> float:
         """Duration of the last trajectory-kernel launch (HIP events on its stream); needs `timing = True`."""
         ms = C.c_float()
         L.check(self._last_plan.lib.sdeh_plan_last_kernel_ms(self._last_plan.handle, C.byref(ms)))
         return ms.value
+
+    def last_kernel_name(self) -> str:
+        """Name of the compiled kernel variant that served the last launch (sdeh_plan_last_kernel_name)."""
+        if self._last_plan is None:
+            return ""
+        return self._last_plan.lib.sdeh_plan_last_kernel_name(self._last_plan.handle).decode()
 
     # ------------------------------------------------------------------------------------------------------
     def build_problem(self, *, loss_kind: int, generative_ctrl, sde, flags: int, device, keep: _Keep,
@@ -339,6 +363,15 @@ class TrajectoryEngine:
             _fill_density(target_obj, pr.target, keep, device, "target")
             if pr.target.dim != dim:
                 raise ValueError(f"target dim {pr.target.dim} != model dim {dim}")
+        if kind != L.CTRL_CLIPPED:
+            # which score terms are constants of the autograd graph (only the back-propagation-through-time kernel reads this):
+            # detach_score=True detaches x in front of every score (reparam.py:58,134,169,188); otherwise a score obtained through
+            # Distribution.score's autograd call (distr/base.py:130-137, create_graph=False) is a constant as well -- mixtures are
+            # handled as such inside the kernel, a ONE-component GMM (evaluated here as a Gaussian) needs the flag
+            if bool(getattr(generative_ctrl, "detach_score", False)):
+                pr.flags |= L.FLAG_DETACH_SCORE
+            elif target_obj is not None and pr.target.kind == L.DENS_DIAG_GAUSS and not _has_analytic_score(target_obj):
+                pr.flags |= L.FLAG_TARGET_SCORE_CONST
         if reference_prior is not None:
             _fill_density(reference_prior, pr.prior, keep, device, "prior")
             if pr.prior.kind != L.DENS_DIAG_GAUSS:
@@ -442,7 +475,7 @@ class TrajectoryEngine:
         plan = self._plan(device, dim, 64, pr.base_model.n_hidden, max(n_steps, n_out), k)
         if seed is None:
             seed = torch.initial_seed()
-        offset = self.calls
+        offset = self.offset()
         self.calls += 1
         stream = torch.cuda.current_stream(device).cuda_stream
         with torch.cuda.device(device):
@@ -488,7 +521,7 @@ class TrajectoryEngine:
         plan = self._plan(device, dim, pr.base_model.channels, n_hidden, n_steps, k)
         if seed is None:
             seed = torch.initial_seed()
-        offset = self.calls
+        offset = self.offset()
         self.calls += 1
         stream = torch.cuda.current_stream(device).cuda_stream
         gp = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32) if want_gp else None

@@ -32,6 +32,7 @@ class EulerIntegrator(Integrator):
         self.rescale_t = rescale_t
         self.eps = eps
         self.engine = TrajectoryEngine()
+        self.engine.stream_id = 1  # never the noise of a loss object (stream 0) evaluated in the same process
         self.row_offset = 0  # global index of x_init row 0 (rank * local batch for sharded runs)
 
     # ------------------------------------------------------------------------------------------------------

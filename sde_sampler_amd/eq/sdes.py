@@ -172,3 +172,17 @@ class ControlledSDE(TorchSDE):
 
     def diff(self, t, x):
         return self.sde.diff(t, x)
+
+    def f_and_g(self, t, x):
+        """Host-side definition (reference eq/sdes.py:293-305) for code that evaluates the controlled process directly
+        (torchsde-style `f` / `g`); `EulerIntegrator.integrate` does not call it -- it hands the whole process to libsdeh."""
+        sde_diff = self.sde.diff(t, x)
+        sde_drift = self.sde.drift(t, x)
+        if self.ctrl is not None:
+            if not self.sde.generative:
+                t = self.terminal_t - t
+            sde_drift = sde_drift + sde_diff * self.ctrl(t, x)
+        return sde_drift, sde_diff.expand_as(x)
+
+    def drift(self, t, x):
+        return self.f_and_g(t, x)[0]

@@ -14,8 +14,10 @@ ReferenceSDELoss 281-391, ExponentialIntegratorSDELoss 394-505), selected by poi
 
 Training: `loss(...)` back-propagates through the fused kernels for every method (losses/_autograd.py +
 `sdeh_ctrl_backward`): row-parallel for "lv" / "lv_traj" (detached SDE control), back-propagation through time with the
-adjoint kept in registers for "kl" / "kl_ito".  Not built in (raises `SdehUnsupported`, never falls back): the Bridge
-inference control / divergence term and `sde_ctrl_noise` / `sde_ctrl_dropout` -- SURVEY.md 8f row f2.
+adjoint kept in registers for "kl" / "kl_ito"; the Bridge (`inference_ctrl`, exact or Hutchinson divergence) trains through
+`sdeh_ctrl_backward_ex` + `sdeh_bridge_div_backward`.  Not built in (raises `SdehUnsupported`, never falls back):
+`sde_ctrl_noise` / `sde_ctrl_dropout` (dead code in the reference) and training of the wide-network
+(channels > 64) kernels, which are evaluation-only.
 """
 from __future__ import annotations
 
@@ -117,8 +119,8 @@ class BaseOCLoss:
         self.n_filtered = 0
         self.engine = E.TrajectoryEngine()
         #: row index of this rank's first trajectory in the global batch (keeps the Philox streams of data-parallel
-        #: ranks disjoint); set by the caller, e.g. rank * local_batch
-        self.row_offset = 0
+        #: ranks disjoint).  None (default): rank * local batch when torch.distributed is initialised, else 0.
+        self.row_offset: int | None = None
         #: optional one-element int64 device tensor ADDED to the Philox offset inside the kernels (SdehProblem.rng_offset_dev):
         #: launch arguments are frozen when a step is captured into a hipGraph, this counter is what moves between replays
         self.rng_counter: torch.Tensor | None = None
@@ -239,10 +241,21 @@ class BaseOCLoss:
         self.n_filtered = state_dict["n_filtered"]
         if self._n_filtered_dev is not None:
             self._n_filtered_dev.zero_()
+        # extension of the reference's {"n_filtered"} (losses/oc.py:133-137): a resumed run continues the noise stream
+        self.engine.calls = int(state_dict.get("rng_calls", self.engine.calls))
 
     def state_dict(self) -> dict:
         on_device = 0 if self._n_filtered_dev is None else int(self._n_filtered_dev.item())
-        return {"n_filtered": self.n_filtered + on_device}
+        return {"n_filtered": self.n_filtered + on_device, "rng_calls": self.engine.calls}
+
+    def _row_offset(self, local_batch: int) -> int:
+        if self.row_offset is not None:
+            return int(self.row_offset)
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(self.process_group) * int(local_batch)
+        return 0
 
     # -- shared plumbing ----------------------------------------------------------------------------------------
     _LOSS_KIND = None
@@ -272,10 +285,11 @@ class BaseOCLoss:
         def run(return_traj: bool, want_state: bool = False, want_gp: bool = False, want_planes: bool = False):
             keep = E._Keep()
             pr = self.engine.build_problem(device=x.device, keep=keep, **problem_kwargs)
-            offset = self.engine.calls
+            row_offset = self._row_offset(x.shape[0])
+            offset = self.engine.offset()
             seed = torch.initial_seed()
             out = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
-                                  row_offset=self.row_offset, seed=seed, want_gp=want_gp, div_noise=div_noise,
+                                  row_offset=row_offset, seed=seed, want_gp=want_gp, div_noise=div_noise,
                                   want_planes=want_planes)
             x_T, rnd, xs = out[:3]
             # user-supplied callables the engine does not recognise are evaluated as given (device tensors in/out)
@@ -289,7 +303,7 @@ class BaseOCLoss:
             assert rnd.shape == (x.shape[0], 1)
             if want_state:
                 state = dict(problem_kwargs=problem_kwargs, noise=noise, seed=seed & 0xFFFFFFFFFFFFFFFF, offset=offset,
-                             row_offset=self.row_offset, div_noise=div_noise)
+                             row_offset=row_offset, div_noise=div_noise)
                 if want_planes:
                     state["planes"] = out[3]  # (zt, nn) of the forward launch, or None
                 return (x_T, rnd, xs, out[3], state) if want_gp else (x_T, rnd, xs, state)
@@ -375,9 +389,10 @@ class TimeReversalLoss(BaseOCLoss):
 
     def eval(self, ts, x, terminal_unnorm_log_prob: Callable, initial_log_prob: Callable | None = None,
              compute_weights: bool = True, return_traj: bool = True, *, noise=None) -> Results:
-        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
-                                         initial_log_prob=initial_log_prob, compute_ito_int=compute_weights,
-                                         train=False, return_traj=return_traj, noise=noise)
+        with torch.no_grad():  # evaluation never builds a graph (the solver calls it under no_grad, solver/base.py:335-346)
+            samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                             initial_log_prob=initial_log_prob, compute_ito_int=compute_weights,
+                                             train=False, return_traj=return_traj, noise=noise)
         return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs,
                                           group=self.process_group)
 
@@ -423,9 +438,10 @@ class ReferenceSDELoss(BaseOCLoss):
 
     def eval(self, ts, x, terminal_unnorm_log_prob: Callable, reference_log_prob: Callable | None = None,
              compute_weights: bool = True, return_traj: bool = True, *, noise=None) -> Results:
-        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
-                                         reference_log_prob=reference_log_prob, compute_ito_int=compute_weights,
-                                         change_sde_ctrl=False, return_traj=return_traj, noise=noise)
+        with torch.no_grad():  # evaluation never builds a graph (the solver calls it under no_grad, solver/base.py:335-346)
+            samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                             reference_log_prob=reference_log_prob, compute_ito_int=compute_weights,
+                                             change_sde_ctrl=False, return_traj=return_traj, noise=noise)
         return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs,
                                           group=self.process_group)
 
@@ -455,8 +471,9 @@ class ExponentialIntegratorSDELoss(BaseOCLoss):
 
     def eval(self, ts, x, terminal_unnorm_log_prob: Callable, reference_log_prob: Callable | None = None,
              compute_weights: bool = True, return_traj: bool = True, *, noise=None) -> Results:
-        samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
-                                         reference_log_prob=reference_log_prob, compute_ito_int=compute_weights,
-                                         change_sde_ctrl=False, return_traj=return_traj, noise=noise)
+        with torch.no_grad():  # evaluation never builds a graph (the solver calls it under no_grad, solver/base.py:335-346)
+            samples, rnd, xs = self.simulate(ts, x, terminal_unnorm_log_prob=terminal_unnorm_log_prob,
+                                             reference_log_prob=reference_log_prob, compute_ito_int=compute_weights,
+                                             change_sde_ctrl=False, return_traj=return_traj, noise=noise)
         return BaseOCLoss.compute_results(rnd, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs,
                                           group=self.process_group)

@@ -70,8 +70,11 @@ class FourierMLP(Model):
         Model.init_linear(self.out_layer, bias_init=last_bias_init, weight_init=last_weight_init)
 
     def forward(self, t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-        # the time embedding depends on t only: evaluate it on one row and broadcast
-        h = self.input_embed(x) + self.timestep_embed(t.reshape(-1, 1)[:1].float())
+        # a scalar time: the embedding is one row, broadcast over the batch; per-row times are embedded row by row
+        t = t.reshape(-1, 1).float()
+        if t.shape[0] not in (1, x.shape[0]):
+            raise ValueError(f"t has {t.shape[0]} entries for a batch of {x.shape[0]}")
+        h = self.input_embed(x) + self.timestep_embed(t)
         for layer in self.hidden_layer:
             h = layer(self.activation(h))
         return self.out_layer(self.activation(h))

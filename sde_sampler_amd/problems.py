@@ -67,6 +67,16 @@ def build_target(spec: dict, tensors: dict | None = None):
             scale = torch.nn.functional.softplus(torch.tensor(1.0)) * torch.ones(40, d)
             return GMM(dim=d, loc=fab_loc(d), scale=scale, mixture_weights=torch.ones(40), n_reference_samples=1000,
                        domain_tol=None)
+        if name in ("dense40_shared", "dense40_general"):
+            # bench.py "extra": 40 modes whose means vary in EVERY coordinate (no varying-prefix shortcut), U(-40, 40) like the
+            # "fab" means (distr/gauss.py:42-47); shared scale softplus(1), or per-(component, coordinate) scales in [1, 1.5)
+            gen = torch.Generator()
+            gen.manual_seed(43)
+            loc = (torch.rand((40, d), generator=gen) - 0.5) * 2 * 40
+            scale = torch.nn.functional.softplus(torch.tensor(1.0)) * torch.ones(40, d)
+            if name == "dense40_general":
+                scale = 1.0 + 0.5 * torch.rand((40, d), generator=gen)
+            return GMM(dim=d, loc=loc, scale=scale, mixture_weights=torch.ones(40), n_reference_samples=1000, domain_tol=None)
         if name == "random7":
             loc, scale, w = random_gmm(d, 7, 1234)
             return GMM(dim=d, loc=loc, scale=scale, mixture_weights=w, n_reference_samples=1000, domain_tol=None)
@@ -140,7 +150,7 @@ def build_ctrl(spec: dict, net: dict, dim: int, sde, prior, target, live_last_la
         gamma = TimeEmbed(dim_out=spec.get("gamma_dim", 1), activation=act, num_layers=4, channels=net["channels"],
                           last_bias_init=partial(nn.init.constant_, val=spec.get("gamma_bias", 1.0)),
                           last_weight_init=zeros_)
-        common = dict(base_model=base, score_model=gamma, target_score=target.score, detach_score=False,
+        common = dict(base_model=base, score_model=gamma, target_score=target.score, detach_score=spec.get("detach_score", False),
                       clip_score=spec.get("clip_score"), clip_model=spec.get("clip_model"),
                       scale_score=spec.get("scale_score", 1.0))
         if kind == "score":
@@ -262,6 +272,15 @@ BASELINE_SPECS = {
     # the metric's headline: GMM-40 d=50, solver=basic_pis (ScoreCtrl, Delta prior, ScaledBM), batch 65 536, T=100
     "gmm50_pis_headline": dict(
         batch=65536, target=dict(kind="gmm", dim=50, name="fab50"),
+        prior=dict(kind="delta", dim=50), sde=dict(kind="scaled_bm", diff_coeff=math.sqrt(0.2), terminal_t=5.0),
+        ctrl=_SCORE, net=_NET, loss=dict(kind="reference_sde", method="kl"), grid=dict(start=0.0, end=5.0, steps=100)),
+    # bench.py "extra": the headline with mixture means varying in all 50 coordinates
+    "gmm50_dense_shared": dict(
+        batch=65536, target=dict(kind="gmm", dim=50, name="dense40_shared"),
+        prior=dict(kind="delta", dim=50), sde=dict(kind="scaled_bm", diff_coeff=math.sqrt(0.2), terminal_t=5.0),
+        ctrl=_SCORE, net=_NET, loss=dict(kind="reference_sde", method="kl"), grid=dict(start=0.0, end=5.0, steps=100)),
+    "gmm50_dense_general": dict(
+        batch=65536, target=dict(kind="gmm", dim=50, name="dense40_general"),
         prior=dict(kind="delta", dim=50), sde=dict(kind="scaled_bm", diff_coeff=math.sqrt(0.2), terminal_t=5.0),
         ctrl=_SCORE, net=_NET, loss=dict(kind="reference_sde", method="kl"), grid=dict(start=0.0, end=5.0, steps=100)),
     # configs[2]: same target, batch 262 144 over 8 GPUs (32 768 per GPU), 200 steps

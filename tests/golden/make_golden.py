@@ -196,6 +196,19 @@ CASES = {
 }
 
 
+# models/reparam.py:58,134: detach_score=True (the constructor default; every shipped YAML sets False) detaches x in front of the
+# score terms -- the kl gradients then carry no score Jacobian
+CASES["funnel_lerp_detach_kl"] = dict(
+    B=32, seed=29,
+    target=dict(kind="funnel", dim=10),
+    prior=dict(kind="iso_gauss", dim=10, loc=0.0, scale=1.0),
+    sde=dict(kind="vp", beta_min=0.1, beta_max=6.0, scale=1.0, terminal_t=1.0),
+    ctrl=dict(kind="lerp", clip_model=1e4, clip_score=1e4, scale_score=1.0, gamma_dim=1, gamma_bias=1.0, detach_score=True),
+    net=dict(channels=64, num_layers=4, activation="gelu"),
+    loss=dict(kind="time_reversal", method="kl", max_rnd=None),
+    grid=dict(start=0.0, end=1.0, steps=20, rescale_t=None),
+)
+
 EXTRA_METHODS = {"cfg1_dw_dis_lv", "cfg4_funnel_dds_lv", "eulerdds_funnel_kl"}
 
 
@@ -268,7 +281,7 @@ def build_ctrl(spec, net, dim, sde, prior, target):
         score_model = TimeEmbed(dim_out=spec["gamma_dim"], activation=act, num_layers=4, channels=net["channels"],
                                 last_bias_init=partial(torch.nn.init.constant_, val=spec["gamma_bias"]),
                                 last_weight_init=zeros_)
-        kw = dict(base_model=base, score_model=score_model, target_score=target.score, detach_score=False,
+        kw = dict(base_model=base, score_model=score_model, target_score=target.score, detach_score=spec.get("detach_score", False),
                   clip_score=spec["clip_score"], clip_model=spec["clip_model"], scale_score=spec["scale_score"])
         if kind == "score":
             ctrl = ScoreCtrl(**kw)
@@ -428,8 +441,10 @@ def run_case(name, case):
 
 def main():
     torch.set_num_threads(1)
+    only = set(sys.argv[1:])  # optional: names of the cases to (re)generate
     for name, case in CASES.items():
-        run_case(name, case)
+        if not only or name in only:
+            run_case(name, case)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,62 @@
+"""bench.py end to end on one GPU: the single-rank line, and the N > 1 path (self-spawned ranks, estimator merge through
+torch.distributed) exercised with two ranks sharing cuda:0 over gloo."""
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _bench(*flags, timeout=600):
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), *flags], capture_output=True, text=True, timeout=timeout,
+                          cwd=str(ROOT))
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_on_one_device_equal_one_launch_over_the_global_batch():
+    """`python bench.py --gpus 2` without a launcher spawns its own ranks; the merged lower bound equals what ONE launch over the
+    2B global rows gives (global-row Philox counters: the two shards draw exactly the noise of rows [0,B) and [B,2B))."""
+    from sde_sampler_amd import problems
+
+    B = 4096
+    out = _bench("--gpus", "2", "--same-device", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--batch", str(B),
+                 "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * B and out["config"]["batch_per_gpu"] == B
+    assert out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    spec = problems.baseline_spec("gmm50_pis_headline")
+    spec["batch"] = 2 * B
+    prob = problems.build(spec, device="cuda:0")
+    torch.manual_seed(1)
+    x0 = prob.prior.sample((2 * B,))
+    # bench.py: warm-up + timed steps advance the per-call Philox offset; its last timed step is call (warmup + steps - 1)
+    prob.loss.engine.calls = 1 + 3 - 1
+    single = prob.eval(x0, compute_weights=False, return_traj=False)
+    got = out["log_z_untrained_control"]["log_norm_const_lb"]
+    want = single.log_norm_const_preds["log_norm_const_lb"]
+    assert abs(got - want) <= 1e-5 * max(1.0, abs(want)), (got, want)
+
+
+def test_more_ranks_than_gpus_is_an_error_not_a_silent_single_gpu_run():
+    n = torch.cuda.device_count() + 1
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", str(n), "--steps", "1", "--no-cpu-baseline"],
+                          capture_output=True, text=True, timeout=300, cwd=str(ROOT))
+    assert proc.returncode != 0 and "GPU(s)" in (proc.stderr + proc.stdout)
+
+
+def test_single_rank_line_has_the_contract_fields():
+    out = _bench("--steps", "5", "--warmup", "2", "--batch", "8192", "--no-cpu-baseline", "--no-extra")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    r = out["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"].startswith("traj_") and r["kernel_ms"] > 0

@@ -166,9 +166,13 @@ def test_loss_contract():
     with pytest.raises(ValueError, match="single trajectory"):
         ReferenceSDELoss(generative_ctrl=None, method="lv_traj", traj_per_sample=1)
     loss = ExponentialIntegratorSDELoss(generative_ctrl=None, alpha=1.0, sigma=2.0, method="lv", max_rnd=1e8, unknown_kw=1)
-    assert loss.state_dict() == {"n_filtered": 0}
-    loss.load_state_dict({"n_filtered": 7})
-    assert loss.n_filtered == 7 and (loss.alpha, loss.sigma) == (1.0, 2.0)
+    assert loss.state_dict() == {"n_filtered": 0, "rng_calls": 0}  # reference keys + the position in the noise stream
+    loss.load_state_dict({"n_filtered": 7})  # a reference checkpoint (losses/oc.py:133-137) loads as is
+    assert loss.n_filtered == 7 and (loss.alpha, loss.sigma) == (1.0, 2.0) and loss.engine.calls == 0
+    loss.load_state_dict({"n_filtered": 7, "rng_calls": 12})
+    assert loss.engine.calls == 12 and loss.engine.offset() == 12
+    from sde_sampler_amd.eq.integrator import EulerIntegrator
+    assert EulerIntegrator().engine.offset() == 1 << 40  # its own Philox stream
     rnd = torch.tensor([[1.0], [float("nan")], [2e9], [3.0]])
     val, met = loss.compute_loss(rnd)
     assert val.item() == pytest.approx(torch.tensor([1.0, 3.0]).var().item()) and met["train/n_filtered_cumulative"] == 9

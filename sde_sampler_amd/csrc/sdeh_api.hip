@@ -31,6 +31,8 @@ long long time_embed_param_floats(const SdehTimeEmbed& te);
 long long time_embed_workspace_floats(const SdehTimeEmbed& te, int n_steps);
 int launch_sample_stats(const float* x, const float* w, const float* domain, long long B, int d, float* scratch, int nb,
                         float* out, hipStream_t st);
+int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used);           // sdeh_wide.hip
+int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used); // sdeh_wide.hip
 
 #define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv)                           \
   int launch_ws_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                 \
@@ -168,6 +170,39 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   return L;
 }
 
+// Workspace layout of a wide network (C in {128, 256}, d <= 256; sdeh_wide.hip): everything lives in global memory.
+static WsLayout make_wide_layout(int d, int c, int n_hidden, int t_max, int g, bool with_tan) {
+  WsLayout L;
+  memset(&L, 0, sizeof(L));
+  L.wide = 1;
+  L.otd = row_tiles(d);
+  L.dp = 32 * L.otd;  // padded coordinate count of the per-coordinate tables
+  L.dp8 = (d + 7) & ~7;
+  L.c = c; L.ot = c / 32; L.r_in = 0;
+  L.n_hidden = n_hidden; L.t_max = t_max; L.k_max = 0; L.g = g;
+  int o = 0;
+  L.w_in = o; o += (L.dp8 / 8) * L.ot * 256;
+  L.w_hid = o; L.w_hid_stride = (c / 8) * L.ot * 256; o += n_hidden * L.w_hid_stride;
+  L.w_out = o; o += (c / 8) * L.otd * 256;
+  L.b_hid = o; o += n_hidden * c;
+  L.b_out = o; o += L.otd * 32;
+  L.wt_out = L.wt_hid = L.wt_in = -1;
+  L.tan_in = L.tan_out = -1;
+  if (with_tan) {
+    L.wt_hid = o; o += n_hidden * L.w_hid_stride;
+    L.tan_in = o; o += d * c;
+    L.tan_out = o; o += d * c;
+  }
+  L.lds_floats = 0;
+  L.coef = o; o += t_max * kCoefStride;
+  L.emb = o; o += t_max * c;
+  L.gam = o; o += align4(t_max * g);
+  L.out_cnt = o; o += align4(t_max + 1);
+  for (int i = 0; i < 3; ++i) { L.dg[i] = o; o += align4(2 * L.dp + 1); }
+  L.total = align4(o);
+  return L;
+}
+
 }  // namespace sdeh
 
 using namespace sdeh;
@@ -175,7 +210,8 @@ using namespace sdeh;
 struct SdehPlan {
   SdehPlanDesc desc;
   int device;
-  const Variant* variant;
+  const Variant* variant;  // narrow networks (C = 64, d <= 64); null for wide plans
+  bool wide;               // C in {128, 256}, d <= 256: the channel-split kernels of sdeh_wide.hip (evaluation only)
   float* ws;          // workspace
   size_t ws_floats;
   bool timing;
@@ -194,33 +230,46 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   if (desc == nullptr || out == nullptr) return fail(SDEH_ERR_INVALID, "plan_create: null argument");
   *out = nullptr;
   if (desc->dim < 1) return fail(SDEH_ERR_INVALID, "plan_create: dim=%d", desc->dim);
-  if (desc->channels != 64)
-    return fail(SDEH_ERR_UNSUPPORTED, "plan_create: channels=%d (this build compiles the trajectory kernel for C=64)",
+  const bool wide = desc->channels == 128 || desc->channels == 256;
+  if (desc->channels != 64 && !wide)
+    return fail(SDEH_ERR_UNSUPPORTED, "plan_create: channels=%d (trajectory kernels are compiled for C = 64, 128 and 256)",
                 desc->channels);
   if (desc->max_hidden < 0 || desc->max_hidden > SDEH_MAX_HIDDEN)
     return fail(SDEH_ERR_UNSUPPORTED, "plan_create: %d hidden layers (max %d)", desc->max_hidden, SDEH_MAX_HIDDEN);
   if (desc->max_steps < 1) return fail(SDEH_ERR_INVALID, "plan_create: max_steps=%d", desc->max_steps);
-  const Variant* v = pick_variant(desc->dim);
-  if (v == nullptr) return fail(SDEH_ERR_UNSUPPORTED, "plan_create: no trajectory kernel compiled for dim=%d", desc->dim);
   const int k_max = desc->max_components > 0 ? desc->max_components : 0;
-  WsLayout L = make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp);
-  // LDS: the wave-specialised kernel needs image + exchange buffers, the single-wave kernel image + logit scratch;
-  // a plan is usable when either fits (deep networks fall back to the single-wave kernel at launch time)
-  const size_t img = (size_t)L.lds_floats * sizeof(float);
-  const size_t lds_ws = img + (size_t)4 * (mdim(mregs(v->dp) - 1, 1) + 1) * 64 * sizeof(float);
-  const size_t lds_legacy = img + (size_t)k_max * 256 * sizeof(float);
-  if ((lds_ws < lds_legacy ? lds_ws : lds_legacy) > 160 * 1024)
-    return fail(SDEH_ERR_UNSUPPORTED, "plan_create: needs %zu B of LDS (> 160 KiB): hidden=%d K=%d",
-                lds_ws < lds_legacy ? lds_ws : lds_legacy, desc->max_hidden, k_max);
+  const Variant* v = nullptr;
+  size_t ws_floats = 0;
+  if (wide) {
+    if (desc->dim > 256) return fail(SDEH_ERR_UNSUPPORTED, "plan_create: dim=%d (the wide-network kernels cover d <= 256)", desc->dim);
+    // two regions (generative + inference network of a Bridge), each with the tangent tables / transposed hidden layers
+    ws_floats = 2 * (size_t)make_wide_layout(desc->dim, desc->channels, desc->max_hidden, desc->max_steps, 32 * row_tiles(desc->dim), true).total + 64;
+  } else {
+    v = pick_variant(desc->dim);
+    if (v == nullptr)
+      return fail(SDEH_ERR_UNSUPPORTED, "plan_create: no trajectory kernel compiled for dim=%d with channels=64 (d <= 64; wider "
+                                        "states need channels 128 or 256)", desc->dim);
+    WsLayout L = make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp);
+    // LDS: the wave-specialised kernel needs image + exchange buffers, the single-wave kernel image + logit scratch;
+    // a plan is usable when either fits (deep networks fall back to the single-wave kernel at launch time)
+    const size_t img = (size_t)L.lds_floats * sizeof(float);
+    const size_t lds_ws = img + (size_t)4 * (mdim(mregs(v->dp) - 1, 1) + 1) * 64 * sizeof(float);
+    const size_t lds_legacy = img + (size_t)k_max * 256 * sizeof(float);
+    if ((lds_ws < lds_legacy ? lds_ws : lds_legacy) > 160 * 1024)
+      return fail(SDEH_ERR_UNSUPPORTED, "plan_create: needs %zu B of LDS (> 160 KiB): hidden=%d K=%d",
+                  lds_ws < lds_legacy ? lds_ws : lds_legacy, desc->max_hidden, k_max);
+    // region 1: the largest layout of any call (backward packs transposed weights too); region 2: the Bridge paths pack a
+    // second (inference) network with transposed weights and tangent tables
+    ws_floats = (size_t)make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp, false, false, 0, true).total +
+                (size_t)make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, 0, v->dp, false, true, 0, true, true).total + 64;
+  }
   SdehPlan* p = new (std::nothrow) SdehPlan();
   if (p == nullptr) return fail(SDEH_ERR_INVALID, "plan_create: out of host memory");
   p->desc = *desc;
   p->device = desc->device;
   p->variant = v;
-  // region 1: the largest layout of any call (backward packs transposed weights too); region 2: the Bridge paths pack a
-  // second (inference) network with transposed weights and tangent tables
-  p->ws_floats = (size_t)make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp, false, false, 0, true).total +
-                 (size_t)make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, 0, v->dp, false, true, 0, true, true).total + 64;
+  p->wide = wide;
+  p->ws_floats = ws_floats;
   p->timing = p->timed = false;
   p->ev0 = p->ev1 = nullptr;
   p->last_kernel[0] = 0;
@@ -352,7 +401,7 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     if (rc != SDEH_OK) return rc;
     if (pr->score_model.dim_out != 1 && pr->score_model.dim_out != d)
       return fail(SDEH_ERR_UNSUPPORTED, "score_model.dim_out=%d (1 or dim supported)", pr->score_model.dim_out);
-    g = pr->score_model.dim_out == 1 ? 1 : plan->variant->dp;
+    g = pr->score_model.dim_out == 1 ? 1 : (plan->wide ? 32 * row_tiles(d) : plan->variant->dp);
   }
   const bool need_target_score = pr->ctrl_kind == SDEH_CTRL_SCORE || pr->ctrl_kind == SDEH_CTRL_LERP ||
                                  pr->ctrl_kind == SDEH_CTRL_LERP_TARGET;
@@ -374,6 +423,17 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   if (k > plan->desc.max_components)
     return fail(SDEH_ERR_CAPACITY, "simulate_fwd: GMM with %d components > plan max %d", k, plan->desc.max_components);
 
+  if (plan->wide) {  // wide networks (sdeh_wide.hip): evaluation kernels; closed-form targets
+    if (backward || integrate)
+      return fail(SDEH_ERR_UNSUPPORTED, "networks with %d channels are evaluated by the wide-network kernels, which have no "
+                                        "backward pass / plain integrator (channels = 64 has)", net.channels);
+    if (need_target && pr->target.kind == SDEH_DENS_GMM)
+      return fail(SDEH_ERR_UNSUPPORTED, "wide-network kernels: mixture targets are not built in (Gaussian, double-well and funnel targets are)");
+    out->L = make_wide_layout(d, net.channels, net.n_hidden, n_steps, g, false);
+    if ((size_t)out->L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd: workspace too small");
+    out->v = nullptr; out->refc = refc; out->g = g; out->k = 0;
+    return SDEH_OK;
+  }
   const Variant* v = plan->variant;
   const bool shared = pr->target.kind == SDEH_DENS_GMM && (pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE);
   const int nvary = shared ? SDEH_DENS_FLAG_GET_NVARY(pr->target.flags) : -1;
@@ -475,6 +535,92 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "simulate_fwd (bridge): kernel launch failed");
 }
 
+static void fill_traj_args(TrajArgs& A, const SdehProblem* pr, const float* x0, int64_t batch, const float* noise, uint64_t seed,
+                           uint64_t offset, int64_t row_offset, float* x_T, float* rnd, float* xs, int32_t n_steps) {
+  memset(&A, 0, sizeof(A));
+  A.x0 = x0; A.noise = noise; A.xT = x_T; A.rnd = rnd; A.xs = xs;
+  A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = pr->base_model.dim;
+  A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = pr->base_model.activation;
+  A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
+  A.clip_target = pr->clip_target; A.exp_sigma = pr->exp_sigma;
+  A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
+  A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
+  A.second = {pr->second.kind, pr->second.n_components, pr->second.log_norm_const, pr->second.p0, pr->second.p1};
+  A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
+}
+
+// Wide networks (C = 128 / 256, d <= 256): the channel-split kernels of sdeh_wide.hip, with or without an inference control.
+static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0, int64_t batch,
+                         const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, float* x_T, float* rnd, float* xs,
+                         void* stream, const Checked& ck, float* gp, const float* div_noise, bool want_planes) {
+  if (want_planes || gp != nullptr || div_noise != nullptr)
+    return fail(SDEH_ERR_UNSUPPORTED, "wide-network kernels are evaluation-only: no training planes / Hutchinson probes "
+                                      "(train with channels = 64, or evaluate under torch.no_grad())");
+  const SdehFourierMLP& net = pr->base_model;
+  const int d = net.dim;
+  const bool bridge = pr->flags & SDEH_FLAG_INFERENCE_CTRL;
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = ck.L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
+  int rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "simulate_fwd (wide): prep kernel launch failed");
+  TrajArgs A{};
+  fill_traj_args(A, pr, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, n_steps);
+  A.ws = plan->ws; A.lay = ck.L;
+  if (bridge) {
+    const SdehInferenceCtrl& inf = pr->inference;
+    const SdehFourierMLP& net2 = inf.base_model;
+    if (inf.ctrl_kind != SDEH_CTRL_CLIPPED && inf.ctrl_kind != SDEH_CTRL_LERP_PRIOR)
+      return fail(SDEH_ERR_UNSUPPORTED, "inference control kind %d: ClippedCtrl and LerpPriorCtrl have a built-in divergence", inf.ctrl_kind);
+    if (net2.dim != d || net2.channels != net.channels)
+      return fail(SDEH_ERR_INVALID, "inference control: dim/channels (%d,%d) differ from the generative control's (%d,%d)", net2.dim,
+                  net2.channels, d, net.channels);
+    if (net2.n_hidden < 0 || net2.n_hidden > 2)
+      return fail(SDEH_ERR_UNSUPPORTED, "wide Bridge: the divergence is built for inference networks with at most 2 hidden layers "
+                                        "(num_layers <= 4; got %d hidden)", net2.n_hidden);
+    if (net2.n_hidden > plan->desc.max_hidden) return fail(SDEH_ERR_CAPACITY, "inference control: %d hidden layers > plan max %d", net2.n_hidden, plan->desc.max_hidden);
+    if (net2.activation < SDEH_ACT_GELU_ERF || net2.activation > SDEH_ACT_RELU) return fail(SDEH_ERR_UNSUPPORTED, "inference control: activation %d", net2.activation);
+    if (net2.input_w == nullptr || net2.input_b == nullptr || net2.out_w == nullptr || net2.out_b == nullptr)
+      return fail(SDEH_ERR_INVALID, "inference control: null base_model parameter");
+    for (int i = 0; i < net2.n_hidden; ++i)
+      if (net2.hidden_w[i] == nullptr || net2.hidden_b[i] == nullptr) return fail(SDEH_ERR_INVALID, "inference control: null hidden layer %d", i);
+    rc = check_time_embed(net2.timestep_embed, net2.channels, "inference base_model.timestep_embed");
+    if (rc != SDEH_OK) return rc;
+    int g2 = 1;
+    if (inf.ctrl_kind == SDEH_CTRL_LERP_PRIOR) {
+      if (pr->prior.kind != SDEH_DENS_DIAG_GAUSS) return fail(SDEH_ERR_UNSUPPORTED, "LerpPriorCtrl inference control needs a Gaussian prior");
+      if (pr->sde_kind == SDEH_SDE_NONE) return fail(SDEH_ERR_INVALID, "Lerp controls need an sde");
+      if (inf.score_model.n_hidden > 0) {
+        rc = check_time_embed(inf.score_model, net2.channels, "inference score_model");
+        if (rc != SDEH_OK) return rc;
+        if (inf.score_model.dim_out != 1 && inf.score_model.dim_out != d)
+          return fail(SDEH_ERR_UNSUPPORTED, "inference score_model.dim_out=%d (1 or dim supported)", inf.score_model.dim_out);
+        g2 = inf.score_model.dim_out == 1 ? 1 : 32 * row_tiles(d);
+      }
+    }
+    const WsLayout L2 = make_wide_layout(d, net2.channels, net2.n_hidden, n_steps, g2, true);
+    if ((size_t)ck.L.total + (size_t)L2.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd (wide bridge): workspace too small");
+    PrepArgs P2 = P;  // second region: the inference control's network, time embeddings and gamma table
+    P2.ws = plan->ws + ck.L.total; P2.lay = L2;
+    P2.prob.ctrl_kind = inf.ctrl_kind; P2.prob.clip_model = inf.clip_model; P2.prob.clip_score = inf.clip_score;
+    P2.prob.scale_score = inf.scale_score; P2.prob.base_model = inf.base_model; P2.prob.score_model = inf.score_model;
+    P2.prob.target.kind = P2.prob.prior.kind = P2.prob.second.kind = SDEH_DENS_NONE;  // the density tables live in region 1
+    rc = launch_prep(P2, st);
+    if (rc != SDEH_OK) return fail(rc, "simulate_fwd (wide bridge): second prep kernel launch failed");
+    A.ws2 = plan->ws + ck.L.total; A.lay2 = L2;
+    A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
+    A.inf_clip_model = inf.clip_model; A.inf_clip_score = inf.clip_score; A.inf_scale_score = inf.scale_score;
+  }
+  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  int detail = 0;
+  rc = bridge ? launch_bridge_wide(A, st, &detail) : launch_wide(A, st, &detail);
+  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), bridge ? "bridge_wide<C=%d,split=%d>" : "traj_wide<C=%d,CT=%d>", net.channels, detail);
+  if (rc == SDEH_ERR_UNSUPPORTED) return fail(rc, "simulate_fwd (wide): the problem needs more than 160 KiB of LDS (d=%d, C=%d)", d, net.channels);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "simulate_fwd (wide): kernel launch failed");
+}
+
 int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                           int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                           float* x_T, float* rnd, float* xs, void* stream) {
@@ -495,6 +641,9 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   if (rc != SDEH_OK) return rc;
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
+  if (plan->wide)
+    return simulate_wide(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise,
+                         zt_out != nullptr || nn_out != nullptr);
   if (pr->flags & SDEH_FLAG_INFERENCE_CTRL)
     return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise);
   const WsLayout& L = ck.L;
@@ -582,6 +731,7 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const fl
       ta == nullptr || td == nullptr || d2 == nullptr || cj == nullptr)
     return fail(SDEH_ERR_INVALID, "bridge_div_backward: null argument");
   if (!(pr->flags & SDEH_FLAG_INFERENCE_CTRL)) return fail(SDEH_ERR_INVALID, "bridge_div_backward: the problem has no inference control");
+  if (plan->wide) return fail(SDEH_ERR_UNSUPPORTED, "bridge_div_backward: wide-network plans are evaluation-only");
   if (batch < 1 || n_steps < 1 || n_steps > plan->desc.max_steps) return fail(SDEH_ERR_INVALID, "bridge_div_backward: batch=%lld n_steps=%d", (long long)batch, n_steps);
   const SdehInferenceCtrl& inf = pr->inference;
   const SdehFourierMLP& net2 = inf.base_model;
@@ -678,6 +828,7 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, cons
   if (plan == nullptr || pr == nullptr || timesteps == nullptr || ts_out == nullptr || x_init == nullptr || xs_out == nullptr)
     return fail(SDEH_ERR_INVALID, "integrate: null argument");
   if (kind != SDEH_INT_LANGEVIN && kind != SDEH_INT_CONTROLLED) return fail(SDEH_ERR_INVALID, "integrate: kind %d", kind);
+  if (plan->wide) return fail(SDEH_ERR_UNSUPPORTED, "integrate: the plain integrator is compiled for channels = 64 plans (d <= 64)");
   if (n_out < 1 || n_out > plan->desc.max_steps + 1)
     return fail(SDEH_ERR_CAPACITY, "integrate: %d output times (plan allows %d)", n_out, plan->desc.max_steps + 1);
   if (pr->sde_kind == SDEH_SDE_NONE) return fail(SDEH_ERR_INVALID, "integrate: needs an sde");

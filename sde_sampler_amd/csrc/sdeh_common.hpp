@@ -69,6 +69,14 @@ struct WsLayout {
   int gmm_c;      // [K]  log_softmax(log w)_k - sum_d (log sigma_kd + 0.5 log 2pi)
   int dg[3];      // diag-gauss tables for target / prior / second: [dp][2] (mu, 1/sigma^2) then 1 float const
   int total;
+  // Wide networks (sdeh_wide.hip: C in {128, 256}, d <= 256): no LDS image; the A operands stream from this workspace (L2), packed
+  // in NATURAL k order as float4 groups of four k-steps:  pk[((S * n_tiles + t) * 64 + lane) * 4 + e] = W[32 t + (lane & 31)][8 S + 2 e + (lane >> 5)]
+  //   w_in  [dp8/8][ot][64] float4 (k = coordinate, zero beyond d)      w_hid  n_hidden x [c/8][ot][64] float4
+  //   w_out [c/8][otd][64] float4 (rows = coordinates, zero beyond d)   b_hid / b_out / emb: accumulator (M) order as above
+  // Bridge (inference network): tan_in / tan_out [d][c] in the B-operand order of a k-group: idx(ch) = (ch / 8) * 8 + (ch & 1) * 4 + ((ch & 7) >> 1)
+  //   (column j of input_embed.weight / row j of out_layer.weight), and wt_hid = the hidden layers transposed, packed like w_hid.
+  int wide;       // 1: the layout above
+  int dp8;        // d rounded up to a multiple of 8 (k extent of the input layer)
 };
 
 struct DensArgs {

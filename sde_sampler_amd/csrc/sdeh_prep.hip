@@ -172,7 +172,36 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
   const SdehFourierMLP& net = pr.base_model;
   const int d = net.dim, C = L.c, OT = L.ot, OTD = L.otd;
 
-  if (pr.ctrl_kind != SDEH_CTRL_NONE) {
+  if (pr.ctrl_kind != SDEH_CTRL_NONE && L.wide) {
+    // wide networks: natural k order, four k-steps per float4 (see WsLayout)
+    auto pack = [&](float* dst, const float* W, int ld, int n_rows, int n_cols, int n_tiles, int n_groups, bool transposed) {
+      // dst[((S * n_tiles + t) * 64 + lane) * 4 + e] = M[32 t + (lane & 31)][8 S + 2 e + (lane >> 5)],  M = W or W^T
+      const int total = n_groups * n_tiles * 256;
+      for (int idx = gid; idx < total; idx += stride) {
+        const int e = idx & 3, lane = (idx >> 2) & 63, t = (idx >> 8) % n_tiles, S = (idx >> 8) / n_tiles;
+        const int row = 32 * t + (lane & 31), col = 8 * S + 2 * e + (lane >> 5);
+        float v = 0.0f;
+        if (row < n_rows && col < n_cols) v = transposed ? W[(size_t)col * ld + row] : W[(size_t)row * ld + col];
+        dst[idx] = v;
+      }
+    };
+    pack(ws + L.w_in, net.input_w, d, C, d, OT, L.dp8 / 8, false);        // input_embed.weight [C, d]
+    for (int l = 0; l < L.n_hidden; ++l) {
+      pack(ws + L.w_hid + l * L.w_hid_stride, net.hidden_w[l], C, C, C, OT, C / 8, false);  // hidden_layer[l].weight [C, C]
+      for (int c = gid; c < C; c += stride) ws[L.b_hid + l * C + morder(c)] = net.hidden_b[l][c];
+      if (L.wt_hid >= 0) pack(ws + L.wt_hid + l * L.w_hid_stride, net.hidden_w[l], C, C, C, OT, C / 8, true);
+    }
+    pack(ws + L.w_out, net.out_w, C, d, C, OTD, C / 8, false);            // out_layer.weight [d, C]
+    for (int c = gid; c < OTD * 32; c += stride) ws[L.b_out + morder(c)] = c < d ? net.out_b[c] : 0.0f;
+    if (L.tan_in >= 0) {
+      for (int e = gid; e < d * C; e += stride) {
+        const int jt = e / C, ch = e % C;
+        const int o = (ch >> 3) * 8 + (ch & 1) * 4 + ((ch & 7) >> 1);
+        ws[L.tan_in + jt * C + o] = net.input_w[(size_t)ch * d + jt];
+        ws[L.tan_out + jt * C + o] = net.out_w[(size_t)jt * C + ch];
+      }
+    }
+  } else if (pr.ctrl_kind != SDEH_CTRL_NONE) {
   for (int e = gid; e < L.r_in * OT * 64; e += stride) {  // input_embed.weight [C, d]
     const int lane = e & 63, ot = (e >> 6) % OT, r = (e >> 6) / OT;
     const int dimidx = mdim(r, lane >> 5);

@@ -295,6 +295,22 @@ BASELINE_SPECS = {
         ctrl=dict(_SCORE, clip_model=10.0, clip_score=10.0), net=_NET,
         loss=dict(kind="exponential", method="lv", max_rnd=1e8, alpha=1.0, sigma=1.0),
         grid=dict(start=0.0, end=12.8, steps=400, rescale_t="cosine")),
+    # Wide-network workloads (bench.py --workload): the geometry of configs[4] -- d = 196 (MNIST 14 x 14 after NICE's preprocessing
+    # would be 784; the task's configs[4] is quoted with channels = 256), two FourierMLP C = 256 -- on a FUSABLE target (the NICE flow
+    # of distr/nice.py needs torchvision and data/nice.pt; SURVEY.md section 2 marks it out of scope); clips of conf/solver/bridge.yaml
+    "wide_pis_funnel196": dict(
+        batch=32768, target=dict(kind="funnel", dim=196),
+        prior=dict(kind="delta", dim=196), sde=dict(kind="scaled_bm", diff_coeff=math.sqrt(0.2), terminal_t=5.0),
+        ctrl=dict(_SCORE, clip_model=10.0, clip_score=10.0), net=dict(channels=256, num_layers=4, activation="gelu"),
+        loss=dict(kind="reference_sde", method="kl"), grid=dict(start=0.0, end=5.0, steps=200)),
+    # configs[4]: solver=bridge, channels=256, batch 32 768 over 8 GPUs (4096 per GPU), 200 steps
+    "cfg5_like_bridge196": dict(
+        batch=4096, target=dict(kind="funnel", dim=196),
+        prior=dict(kind="iso_gauss", dim=196), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+        ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        inference_ctrl=dict(kind="lerp_prior", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        net=dict(channels=256, num_layers=4, activation="gelu"),
+        loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=200)),
 }
 
 

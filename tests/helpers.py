@@ -8,7 +8,9 @@ import torch
 
 GOLDEN_DIR = Path(__file__).parent / "golden"
 _ALL = sorted(glob.glob(str(GOLDEN_DIR / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_"))]  # loss-loop fixtures (make_golden.py)
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide"))]  # loss-loop fixtures (make_golden.py)
+GOLDEN_WIDE = [p for p in _ALL if Path(p).name.startswith("wide_")]              # wide-network fixtures (make_golden_wide.py)
+GOLDEN_WIDE_BRIDGE = [p for p in _ALL if Path(p).name.startswith("widebridge_")]  # wide-network Bridge fixtures
 GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]      # Euler-integrator fixtures (make_golden_integrator.py)
 GOLDEN_BRIDGE = [p for p in _ALL if Path(p).name.startswith("bridge_")]    # Bridge fixtures (make_golden_bridge.py)
 GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]  # get_metrics fixtures (make_golden_metrics.py)

@@ -1,0 +1,126 @@
+"""GPU parity tests of the wide-network kernels (sdeh_wide.hip: FourierMLP with 128 / 256 channels, d up to 196) through the C ABI:
+against the reference's golden vectors on identical noise (tests/golden/make_golden_wide.py), the CPU oracle at larger batches,
+and size-independent properties (tiling / sharding invariance, determinism)."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN_WIDE, GOLDEN_WIDE_BRIDGE, hip_problem, inference_params, load_fixture
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rows(name, got, ref, max_tol=1e-2, med_tol=1e-4):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = np.maximum(1.0, np.abs(ref))
+    err = np.abs(got - ref) / scale
+    assert err.max() <= max_tol, f"{name}: max err {err.max():.3e}"
+    assert np.median(err) <= med_tol, f"{name}: median err {np.median(err):.3e}"
+
+
+class _ct:
+    """forces the column tiles per workgroup (32 or 64 trajectories) of the wide kernels"""
+
+    def __init__(self, ct):
+        self.ct = ct
+
+    def __enter__(self):
+        if self.ct:
+            os.environ["SDEH_WIDE_CT"] = str(self.ct)
+
+    def __exit__(self, *a):
+        os.environ.pop("SDEH_WIDE_CT", None)
+
+
+@pytest.mark.parametrize("ct", [1, 2])
+@pytest.mark.parametrize("path", GOLDEN_WIDE, ids=lambda p: Path(p).stem)
+def test_wide_eval_matches_reference_golden(path, ct):
+    fx, meta, params, tt = load_fixture(path)
+    prob = hip_problem(meta, params, tt)
+    x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
+    with _ct(ct):
+        r1 = prob.eval(x0, compute_weights=True, return_traj=True, noise=noise)
+        assert prob.loss.engine.last_kernel_name() == f"traj_wide<C={meta['net']['channels']},CT={ct}>"
+        r2 = prob.eval(x0, compute_weights=False, return_traj=False, noise=noise)
+        with torch.no_grad():
+            kw = dict(compute_ito_int=True, return_traj=False, noise=noise)
+            if meta["loss"]["kind"] == "time_reversal":
+                kw["train"] = False
+            _, rnd1, _ = prob.loss.simulate(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, **kw)
+            kw["compute_ito_int"] = False
+            _, rnd2, _ = prob.loss.simulate(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, **kw)
+    _rows("x_T", r1.samples.cpu().numpy(), fx["eval1/x_T"])
+    _rows("rnd (ito)", rnd1.cpu().numpy(), fx["eval1/rnd"])
+    _rows("rnd", rnd2.cpu().numpy(), fx["eval2/rnd"])
+    scale = max(1.0, float(np.abs(fx["eval1/rnd"]).max()))
+    for key in ("log_norm_const_lb_ito", "log_norm_const_is"):
+        assert abs(r1.log_norm_const_preds[key] - float(fx["eval1/" + key])) <= 1e-4 * scale, key
+    assert abs(r2.log_norm_const_preds["log_norm_const_lb"] - float(fx["eval2/log_norm_const_lb"])) <= 1e-4 * scale
+    lv = float(fx["eval1/lv_loss"])
+    assert abs(r1.metrics["eval/lv_loss"] - lv) <= 2e-3 * max(1.0, abs(lv))
+    assert torch.equal(r1.samples, r2.samples)  # the Ito integral only enters rnd
+    xs = r1.xs.cpu().numpy()
+    assert xs.shape == (prob.ts.numel(), *fx["x0"].shape)
+    assert np.array_equal(xs[0], fx["x0"]) and np.array_equal(xs[-1], r1.samples.cpu().numpy())
+
+
+@pytest.mark.parametrize("path", GOLDEN_WIDE, ids=lambda p: Path(p).stem)
+def test_wide_tilings_and_shards_are_bitwise_identical(path):
+    """32- and 64-trajectory workgroups run the same arithmetic per trajectory; two shards with row offsets draw the Philox
+    stream of the corresponding rows of one launch."""
+    fx, meta, params, tt = load_fixture(path)
+    prob = hip_problem(meta, params, tt)
+    torch.manual_seed(3)
+    B = 200
+    x0 = prob.prior.sample((B,)).to(DEV)
+    eng = prob.loss.engine
+    out = {}
+    for ct in (1, 2):
+        with _ct(ct):
+            eng.calls, prob.loss.row_offset = 7, 0
+            out[ct] = prob.eval(x0, compute_weights=True)
+    assert torch.equal(out[1].samples, out[2].samples) and torch.equal(out[1].weights, out[2].weights)
+    eng.calls, prob.loss.row_offset = 7, 0
+    a = prob.eval(x0[:72], compute_weights=False)
+    eng.calls, prob.loss.row_offset = 7, 72
+    b = prob.eval(x0[72:], compute_weights=False)
+    assert torch.equal(torch.cat([a.samples, b.samples]), out[1].samples)
+    assert torch.isfinite(out[1].samples).all()
+
+
+def test_wide_fast_mode_agrees_with_oracle_statistics():
+    """In-kernel noise at B = 2048 against the oracle with torch noise: the lower bound within 4 standard errors."""
+    from oracle import em_oracle as eo
+
+    fx, meta, params, tt = load_fixture([p for p in GOLDEN_WIDE if "pis_funnel100" in p][0])
+    prob = hip_problem(meta, params, tt)
+    B = 2048
+    x0 = torch.zeros(B, meta["target"]["dim"])
+    with torch.no_grad():
+        _, rnd, _ = prob.loss.simulate(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob)
+    oracle, _ = eo.problem_from_fixture(fx)
+    torch.manual_seed(5)
+    _, rnd_o, _ = oracle.simulate(torch.from_numpy(fx["ts"]), x0, None)
+    g, o = rnd.cpu().double().flatten(), rnd_o.double().flatten()
+    se = float(torch.sqrt(g.var() / B + o.var() / B))
+    assert abs(float(g.mean() - o.mean())) <= 4 * se + 1e-3, (float(g.mean()), float(o.mean()), se)
+    assert 0.8 < float(g.std() / o.std()) < 1.25
+
+
+def test_wide_training_and_mixture_targets_fail_loudly():
+    from sde_sampler_amd import SdehUnsupported, problems
+
+    fx, meta, params, tt = load_fixture([p for p in GOLDEN_WIDE if "pis_funnel100" in p][0])
+    prob = hip_problem(meta, params, tt)
+    x0 = torch.from_numpy(fx["x0"]).to(DEV)
+    with pytest.raises(SdehUnsupported, match="evaluation"):
+        prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+    spec = problems.baseline_spec("gmm50_pis_headline")
+    spec["net"] = dict(spec["net"], channels=128)
+    gm = problems.build(spec, device=DEV)
+    with pytest.raises(SdehUnsupported, match="mixture"):
+        gm.eval(gm.prior.sample((64,)))

@@ -11,7 +11,8 @@ import torch
 from oracle import em_oracle as eo
 
 _ALL = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_"))]
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide"))]
+GOLDEN_WIDE = [p for p in _ALL if Path(p).name.startswith(("wide_", "widebridge_"))]
 GOLDEN_BRIDGE = [p for p in _ALL if Path(p).name.startswith("bridge_")]
 GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]
 GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]
@@ -212,3 +213,23 @@ def test_bridge_hutchinson_estimators_bit_exact(path, est):
             key = f"hutch_{est}/{prefix}/{k}"
             if key in fx.files and p.grad is not None:
                 assert np.array_equal(p.grad.numpy(), fx[key]), key
+
+
+@pytest.mark.parametrize("path", GOLDEN_WIDE, ids=lambda p: Path(p).stem)
+def test_wide_network_eval_passes_bit_exact(path):
+    """The wide-network fixtures (C = 128 / 256, d up to 196; tests/golden/make_golden_wide.py) -- evaluation passes of the three
+    loops and of the Bridge branch.  The reference ran them with four intra-op threads."""
+    torch.set_num_threads(4)
+    fx, prob, params, ts, x0, noise = load(path)
+    assert torch.equal(prob.grid(), ts)
+    r1 = prob.eval(ts, x0, noise, compute_weights=True)
+    assert np.array_equal(r1["samples"].numpy(), fx["eval1/x_T"])
+    assert np.array_equal(r1["rnd"].numpy(), fx["eval1/rnd"])
+    assert np.array_equal(r1["weights"].numpy(), fx["eval1/weights"])
+    assert r1["log_norm_const_lb_ito"] == float(fx["eval1/log_norm_const_lb_ito"])
+    assert r1["log_norm_const_is"] == float(fx["eval1/log_norm_const_is"])
+    assert r1["lv_loss"] == float(fx["eval1/lv_loss"])
+    r2 = prob.eval(ts, x0, noise, compute_weights=False)
+    assert np.array_equal(r2["samples"].numpy(), fx["eval2/x_T"])
+    assert np.array_equal(r2["rnd"].numpy(), fx["eval2/rnd"])
+    assert r2["log_norm_const_lb"] == float(fx["eval2/log_norm_const_lb"])

@@ -40,81 +40,133 @@ enum WideSlot { WSL_COST = 0, WSL_ITO = 1, WSL_PRESQ = 2, WSL_X0 = 3, WSL_LOGP_A
 //   actl : the input plane + h * RS + j
 // A operands are prefetched two groups ahead (global / L2 latency), B operands one group ahead (LDS latency).
 // ---------------------------------------------------------------------------------------------------------
-template <int NT, int CT>
-__device__ __forceinline__ void wide_layer(const float4* __restrict__ wp, int ntot, int NS4, const float* __restrict__ actl,
-                                           int RS, f32x16 (&acc)[NT][CT]) {
-  float4 a0[NT], a1[NT], a2[NT];
-  float b0[4][CT], b1[4][CT], b2[4][CT];
-  auto loadA = [&](int S, float4 (&a)[NT]) {
+// What a layer needs before its first MFMA, fetched EARLY (before the previous layer's activation, LDS stores and barrier) so that
+// the L2 latency of a layer's first operands is not paid four times per step: its first kWidePD groups of A operands.
+constexpr int kWidePD = 3;  // A-operand prefetch distance in k-groups (one group = 4 k-steps = 4 NT CT MFMAs = 256 NT CT cycles)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// The ring of A groups of one layer: entries 0 .. kWidePD-1 are filled by wide_prefetch, the layer loop rotates through all of
+// them IN PLACE (an asm load's destination must not be copied before its wait: hipcc believes it is written when the statement ends).
+template <int NT>
+struct WidePre {
+  f32x4 a[kWidePD + 1][NT];
+};
+
+// The A-operand stream is issued and awaited by hand.  Left to hipcc, the loads carry a 64-bit multiply-add per address and --
+// worse -- the s_waitcnt in front of the first MFMA group of every loop iteration degrades to "all but the newest loads"
+// (vmcnt(2) instead of vmcnt(6): the insertion pass merges the loop-entry state, where few loads are younger than the ring's
+// oldest entry), i.e. the prefetch distance collapses to one group once per iteration.  Here: scalar base pointer advanced per
+// group (saddr form: no VALU in the address path), one 32-bit lane offset per tile, and COUNTED waits -- loads return in order, so
+// "at most N younger loads outstanding" is exact; loads hipcc itself issues in between only make the wait stricter.
+__device__ __forceinline__ void wide_gload(f32x4& dst, unsigned voff, const float* sbase) {
+  // s_nop 4: the base pointer may have been restored from a spill lane by v_readlane (a VALU write of an SGPR) right in front of
+  // this statement -- a VMEM read of that SGPR needs 5 wait states, and hipcc's hazard recogniser does not look inside asm
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N, int NT>
+__device__ __forceinline__ void wide_vmwait(f32x4 (&a)[NT]) {
+  static_assert(NT == 1 || NT == 2, "tiles per wave");
+  if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(a[0]) : "n"(N));
+  else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a[0]), "+v"(a[1]) : "n"(N));
+}
+// wgrp: first group of the layer's packed weights (wave-uniform pointer); voff[k]: byte offset of (tile k of this wave, lane)
+template <int NT>
+__device__ __forceinline__ void wide_prefetch(WidePre<NT>& P, const float* __restrict__ wgrp, int grp_floats, int NS4,
+                                              const unsigned (&voff)[NT]) {
 #pragma unroll
-    for (int k = 0; k < NT; ++k) a[k] = wp[((long long)S * ntot + 4 * k) * 64];
-  };
-  auto loadB = [&](int S, float (&b)[4][CT]) {
+  for (int g = 0; g < kWidePD; ++g)
+#pragma unroll
+    for (int k = 0; k < NT; ++k) wide_gload(P.a[g][k], voff[k], wgrp + (long long)(g < NS4 ? g : NS4 - 1) * grp_floats);
+}
+
+// acc[k][c] = sum over NS4 groups of W[tile t0 + 4 k][:] . act[:, column tile c]   (the accumulators start at zero: the layer's
+// bias / time embedding is added when the result is activated).  grp_floats: floats per k-group of the packed layer (n_tiles * 256).
+template <int NT, int CT>
+__device__ __forceinline__ void wide_layer(WidePre<NT>& P, const float* __restrict__ wgrp, int grp_floats, int NS4,
+                                           const unsigned (&voff)[NT], const float* __restrict__ actl, int RS,
+                                           f32x16 (&acc)[NT][CT]) {
+  constexpr int U = kWidePD + 1;  // ring of A groups; the B ring (LDS, distance 1) has two entries: U is even
+  static_assert(U % 2 == 0, "the two-entry B ring rotates statically only under an even unroll");
+  f32x4 (&a)[U][NT] = P.a;
+  float b[2][4][CT];
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[k][c][q] = 0.0f;
+  auto loadB = [&](int S, float (&bv)[4][CT]) {
     const float* __restrict__ ap = actl + (8 * S) * RS;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int c = 0; c < CT; ++c) b[e][c] = ap[2 * e * RS + 32 * c];
+      for (int c = 0; c < CT; ++c) bv[e][c] = ap[2 * e * RS + 32 * c];
   };
-  auto compute = [&](const float4 (&a)[NT], const float (&b)[4][CT]) {
+  auto compute = [&](const f32x4 (&av)[NT], const float (&bv)[4][CT], int e0, int e1) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = e0; e < e1; ++e)
 #pragma unroll
-      for (int k = 0; k < NT; ++k) {
-        const float av = e == 0 ? a[k].x : (e == 1 ? a[k].y : (e == 2 ? a[k].z : a[k].w));
+      for (int k = 0; k < NT; ++k)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[k][c] = SDEH_MFMA(av, b[e][c], acc[k][c]);
-      }
+        for (int c = 0; c < CT; ++c) acc[k][c] = SDEH_MFMA(av[k][e], bv[e][c], acc[k][c]);
   };
-  loadA(0, a0);
-  loadB(0, b0);
-  if (NS4 > 1) loadA(1, a1);
-  for (int S = 0; S < NS4; S += 3) {
-    if (S + 2 < NS4) loadA(S + 2, a2);
-    if (S + 1 < NS4) loadB(S + 1, b1);
-    SDEH_FENCE();
-    compute(a0, b0);
-    SDEH_FENCE();
-    if (S + 1 < NS4) {
-      if (S + 3 < NS4) loadA(S + 3, a0);
-      if (S + 2 < NS4) loadB(S + 2, b2);
+  const int last = NS4 - 1;
+  auto cl = [&](int S) { return S < last ? S : last; };  // loads past the end re-read the last group (harmless)
+  loadB(0, b[0]);
+  const int main_end = NS4 - NS4 % U;
+  const float* __restrict__ wnext = wgrp + (long long)cl(kWidePD) * grp_floats;  // group S + kWidePD of the stream
+  for (int S = 0; S < main_end; S += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      // The next operands are requested in the MIDDLE of the group's MFMAs: hipcc's wait for the B operands at the top of a loop
+      // iteration degrades to lgkmcnt(0) (as its vmcnt would), and by then these reads are half a group (>= 128 cycles) old.
+      wide_vmwait<(kWidePD - 1) * NT, NT>(a[u]);  // everything older than the kWidePD - 1 newest groups has landed
       SDEH_FENCE();
-      compute(a1, b1);
+      compute(a[u], b[u % 2], 0, 2);
       SDEH_FENCE();
-      if (S + 2 < NS4) {
-        if (S + 4 < NS4) loadA(S + 4, a1);
-        if (S + 3 < NS4) loadB(S + 3, b0);
-        SDEH_FENCE();
-        compute(a2, b2);
-        SDEH_FENCE();
-      }
+#pragma unroll
+      for (int k = 0; k < NT; ++k) wide_gload(a[(u + kWidePD) % U][k], voff[k], wnext);
+      wnext = S + u + kWidePD < last ? wnext + grp_floats : wnext;
+      loadB(cl(S + u + 1), b[(u + 1) % 2]);
+      SDEH_FENCE();
+      compute(a[u], b[u % 2], 2, 4);
+      SDEH_FENCE();
+    }
+  }
+  // NS4 % U groups left: their A operands are in flight (ring entries 0 ..), b[0] holds the first one's B operands
+#pragma unroll
+  for (int u = 0; u < U - 1; ++u) {
+    if (main_end + u < NS4) {
+      if (u + 1 < U - 1) loadB(cl(main_end + u + 1), b[(u + 1) % 2]);
+      wide_vmwait<0, NT>(a[u]);
+      SDEH_FENCE();
+      compute(a[u], b[u % 2], 0, 4);
+      SDEH_FENCE();
     }
   }
 }
 
-// accumulators <- a [tiles][(ot * 2 + h) * 16 + q] table in accumulator order (time embedding + input bias, layer biases)
-template <int NT, int CT>
-__device__ __forceinline__ void wide_init(const float* __restrict__ tab, int t0, int h, f32x16 (&acc)[NT][CT]) {
-#pragma unroll
-  for (int k = 0; k < NT; ++k) {
-    const f32x16 v = load16(tab + ((t0 + 4 * k) * 2 + h) * 16);
-#pragma unroll
-    for (int c = 0; c < CT; ++c) acc[k][c] = v;
-  }
-}
-
-// out[channel][trajectory] <- act(acc) for this wave's tiles; DSTORE: also act'(acc) into `dout` (Bridge: the inference network)
+// out[channel][trajectory] <- act(acc + bias) for this wave's tiles (bias: this lane half's 16 values per tile, accumulator order);
+// DSTORE: also act'(acc + bias) into `dout` (Bridge: the inference network)
 template <int NT, int CT, bool DSTORE>
-__device__ __forceinline__ void wide_act_store(f32x16 (&acc)[NT][CT], int act, float* __restrict__ outl, float* __restrict__ doutl,
-                                               int RS, int t0, int h) {
+__device__ __forceinline__ void wide_act_store(f32x16 (&acc)[NT][CT], const f32x16 (&bias)[NT], int act, float* __restrict__ outl,
+                                               float* __restrict__ doutl, int RS, int t0, int h) {
   SDEH_ACT_SWITCH(act, ACT,
     _Pragma("unroll") for (int k = 0; k < NT; ++k)
       _Pragma("unroll") for (int c = 0; c < CT; ++c)
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {
           const int o = (32 * (t0 + 4 * k) + rho(q, h)) * RS + 32 * c;
-          if constexpr (DSTORE) doutl[o] = act_grad(acc[k][c][q], ACT);
-          outl[o] = act_ct<ACT>(acc[k][c][q]);
+          const float z = acc[k][c][q] + bias[k][q];
+          if constexpr (DSTORE) doutl[o] = act_grad(z, ACT);
+          outl[o] = act_ct<ACT>(z);
         });
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release/acquire fence for ALL address spaces: hipcc
+// emits s_waitcnt vmcnt(0) in front of it, i.e. every barrier would wait for the next layer's just-issued operand prefetch (the
+// full L2 latency, four times per step: measured 7 ms of a 34 ms launch).  The planes exchanged between the waves live in LDS, so
+// lgkmcnt(0) is all the barrier needs; global loads stay in flight across it.
+__device__ __forceinline__ void wide_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32); }
@@ -126,6 +178,7 @@ struct WideCtx {
   const float* tab0;   // LDS copies of the Gaussian tables (target / prior / second): (mu, 1/sigma^2) per coordinate, then the constant
   const float* tab1;
   const float* tab2;
+  const float* bias;   // LDS copy of the hidden-layer biases [n_hidden][C] and the out-layer bias [32 otd], accumulator order
   int RS, d;
   int wave, lane, j, h;
   __device__ __forceinline__ float* plane(int p) const { return planes + p * plane_floats; }
@@ -136,34 +189,52 @@ struct WideCtx {
 // hidden activation was written to (the out-layer's input); the state may be published into the other one.
 // single: only buf[0] exists (Bridge): every layer reads, barrier, writes in place, barrier.
 template <int OTW, int CT, bool DSTORE>
-__device__ __forceinline__ int wide_mlp(const WideCtx& cx, const float* __restrict__ ws, const WsLayout& L, int act, int step, int p,
-                                        bool single, float* __restrict__ dplanes, f32x16 (&out)[2][CT], int nto) {
+__device__ __forceinline__ int wide_mlp(const WideCtx& cx, const float* __restrict__ ws, const WsLayout& L, int act, int p,
+                                        bool single, float* __restrict__ dplanes, WidePre<OTW>& pre_in,
+                                        const f32x16 (&emb)[OTW], const float* __restrict__ bias_lds, f32x16 (&out)[2][CT], int nto) {
   const int RS = cx.RS, C = L.c, OT = L.ot, w = cx.wave, h = cx.h, j = cx.j;
   const int plane = C * RS;  // floats per act' plane
   f32x16 acc[OTW][CT];
-  wide_init<OTW, CT>(ws + L.emb + step * C, w, h, acc);
-  const float4* wbase = reinterpret_cast<const float4*>(ws) + cx.lane;
-  wide_layer<OTW, CT>(wbase + L.w_in / 4 + w * 64, OT, L.dp8 / 8, cx.plane(p) + h * RS + j, RS, acc);
+  unsigned voff[OTW], voff_o[2];  // byte offsets of (tile w + 4 k, lane) inside a k-group
+#pragma unroll
+  for (int k = 0; k < OTW; ++k) voff[k] = (unsigned)(((w + 4 * k) * 64 + cx.lane) * 16);
+  voff_o[0] = (unsigned)((w * 64 + cx.lane) * 16);
+  voff_o[1] = nto > 1 ? (unsigned)(((w + 4) * 64 + cx.lane) * 16) : voff_o[0];
+  wide_layer<OTW, CT>(pre_in, ws + L.w_in, OT * 256, L.dp8 / 8, voff, cx.plane(p) + h * RS + j, RS, acc);
   int q = single ? 0 : 1 - p;
+  WidePre<OTW> pre_h;
+  WidePre<2> pre_o;
   for (int l = 0; l <= L.n_hidden; ++l) {
-    if (single) __syncthreads();  // everyone has read the plane that is about to be overwritten
-    wide_act_store<OTW, CT, DSTORE>(acc, act, cx.plane(q) + j, DSTORE ? dplanes + l * plane + j : nullptr, RS, w, h);
-    __syncthreads();
+    // the next layer's first operands travel while this layer's output is activated, stored and the barrier is crossed
+    if (l < L.n_hidden) wide_prefetch<OTW>(pre_h, ws + L.w_hid + l * L.w_hid_stride, OT * 256, C / 8, voff);
+    else wide_prefetch<2>(pre_o, ws + L.w_out, L.otd * 256, C / 8, voff_o);
+    f32x16 bias[OTW];
+#pragma unroll
+    for (int k = 0; k < OTW; ++k) bias[k] = l == 0 ? emb[k] : load16(bias_lds + (l - 1) * C + ((w + 4 * k) * 2 + h) * 16);
+    if (single) wide_barrier();  // everyone has read the plane that is about to be overwritten
+    wide_act_store<OTW, CT, DSTORE>(acc, bias, act, cx.plane(q) + j, DSTORE ? dplanes + l * plane + j : nullptr, RS, w, h);
+    wide_barrier();
     if (l == L.n_hidden) break;
-    wide_init<OTW, CT>(ws + L.b_hid + l * C, w, h, acc);
-    wide_layer<OTW, CT>(wbase + (L.w_hid + l * L.w_hid_stride) / 4 + w * 64, OT, C / 8, cx.plane(q) + h * RS + j, RS, acc);
+    wide_layer<OTW, CT>(pre_h, ws + L.w_hid + l * L.w_hid_stride, OT * 256, C / 8, voff, cx.plane(q) + h * RS + j, RS, acc);
     if (!single) q = 1 - q;
   }
-  // out_layer on this wave's coordinate tiles {w, w + 4}
+  // out_layer on this wave's coordinate tiles {w, w + 4}; its bias is added by the caller
   if (nto == 2) {
-    wide_init<2, CT>(ws + L.b_out, w, h, out);
-    wide_layer<2, CT>(wbase + L.w_out / 4 + w * 64, L.otd, C / 8, cx.plane(q) + h * RS + j, RS, out);
-  } else if (nto == 1) {
-    f32x16 o1[1][CT];
-    wide_init<1, CT>(ws + L.b_out, w, h, o1);
-    wide_layer<1, CT>(wbase + L.w_out / 4 + w * 64, L.otd, C / 8, cx.plane(q) + h * RS + j, RS, o1);
+    wide_layer<2, CT>(pre_o, ws + L.w_out, L.otd * 256, C / 8, voff_o, cx.plane(q) + h * RS + j, RS, out);
+  } else {  // one tile (or none: the wave still drains its prefetch)
+    WidePre<1> p1;
+    unsigned v1[1] = {voff_o[0]};
 #pragma unroll
-    for (int c = 0; c < CT; ++c) out[0][c] = o1[0][c];
+    for (int g = 0; g < kWidePD; ++g) {
+      wide_vmwait<0, 2>(pre_o.a[g]);  // landed (and tied to the wait) before it is copied
+      p1.a[g][0] = pre_o.a[g][0];
+    }
+    if (nto == 1) {
+      f32x16 o1[1][CT];
+      wide_layer<1, CT>(p1, ws + L.w_out, L.otd * 256, C / 8, v1, cx.plane(q) + h * RS + j, RS, o1);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) out[0][c] = o1[0][c];
+    }
   }
   return q;
 }
@@ -298,6 +369,9 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     tabs[i] = o <= 2 * L.dp ? ws[L.dg[which] + o] : 0.0f;
   }
   cx.tab0 = tabs; cx.tab1 = tabs + tab_stride; cx.tab2 = tabs + 2 * tab_stride;
+  float* bias_lds = tabs + 3 * tab_stride;  // hidden biases [n_hidden][C] then the out-layer bias [32 otd] (b_hid and b_out are adjacent)
+  for (int i = tid; i < L.n_hidden * C + 32 * OTD; i += 256) bias_lds[i] = ws[L.b_hid + i];
+  cx.bias = bias_lds;
 
   const int nto = (OTD > w ? 1 : 0) + (OTD > w + 4 ? 1 : 0);  // coordinate tiles of this wave: w, w + 4
   const long long row0 = (long long)blockIdx.x * RS;
@@ -353,6 +427,14 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     if (flags & SDEH_FLAG_INIT_LOGP) rnd[c] = cx.tab2[2 * L.dp] - 0.5f * wide_slot_sum(cx, WSL_LOGP_A, 32 * c + j);
   }
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
+  unsigned voff_in[OTW];
+#pragma unroll
+  for (int k = 0; k < OTW; ++k) voff_in[k] = (unsigned)(((w + 4 * k) * 64 + lane) * 16);
+  WidePre<OTW> pre_in;
+  wide_prefetch<OTW>(pre_in, ws + L.w_in, L.ot * 256, L.dp8 / 8, voff_in);
+  f32x16 emb[OTW];  // FourierMLP.timestep_embed(t_i) + input_embed.bias for this wave's channels (added when layer 0 is activated)
+#pragma unroll
+  for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + ((w + 4 * k) * 2 + h) * 16);
 
   for (int i = 0; i < A.n_steps; ++i) {
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
@@ -370,10 +452,13 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     }
     // ---- network pass ---------------------------------------------------------------------------------------------
     f32x16 nn[2][CT];
-    const int pout = wide_mlp<OTW, CT, false>(cx, ws, L, act, i, p, false, nullptr, nn, nto);
+    const int pout = wide_mlp<OTW, CT, false>(cx, ws, L, (A.int_kind & 2) ? SDEH_ACT_RELU : act, p, false, nullptr, pre_in, emb, bias_lds, nn, nto);
     p = 1 - pout;  // the plane no wave reads any more: the new state goes there
 
     // ---- elementwise part on this wave's coordinates (reparam.py controls, oc.py cost / update) ---------------------------
+    // One (tile, column tile) pair = 16 registers at a time, in stages whose wave-uniform switches (target kind, control kind,
+    // noise source, cost form) sit OUTSIDE the 16-element loops -- selected per element they cost ~250 instructions per element
+    // (a third of a step); staged, ~40.
     const float c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], dt, 1.0f);
     const float c_u = expo ? cf[CF_B2S2] : sig * dt;
     const float c_n = expo ? cf[CF_SBK] : sig * sqdt;
@@ -390,77 +475,148 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     // of registers held across the step loop) -- an opaque copy of h per step keeps it recomputed where it is used.
     int hv = h;
     asm volatile("" : "+v"(hv));
-    auto tile = [&](auto KK) {
-      constexpr int k = decltype(KK)::value;
-      {
+    auto vtile = [&](f32x16& x, const f32x16& nnv, int t, int c) {
+      const int cb = 32 * t + 4 * hv;  // register q <-> coordinate cb + (q & 3) + 8 (q >> 2)
+      auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
+      float sterm[16];
+      float psc[16];
+      if (need_p) {
 #pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          const unsigned long long grow = (unsigned long long)(A.row_offset + lrow[c]);
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int cbase = 32 * (w + 4 * k) + 8 * g4 + 4 * hv;  // four consecutive coordinates = Philox block cbase / 4
-            float n[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (cbase < d) {
-              if (A.noise != nullptr) {
-                const float* __restrict__ np = A.noise + ((long long)i * A.batch + lrow[c]) * d + cbase;
-                if (vec4) {
-                  const float4 t4 = *reinterpret_cast<const float4*>(np);
-                  n[0] = t4.x; n[1] = t4.y; n[2] = t4.z; n[3] = t4.w;
-                } else {
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) n[e] = cbase + e < d ? np[e] : 0.0f;
-                }
-              } else {
-                box_muller4(philox_block(A.seed, rng_off, grow, i, cbase >> 2), n);
-              }
-            }
-            float xo[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int q = 4 * g4 + e, cc = cbase + e;
-              const bool valid = cc < d;
-              const float x = xr[k][c][q];
-              float sterm = 0.0f, psc = 0.0f;
-              if (need_p) {
-                const float2 pp = *reinterpret_cast<const float2*>(cx.tab1 + 2 * cc);
-                psc = (pp.x - x) * pp.y;
-              }
-              if (ctrl_kind != SDEH_CTRL_CLIPPED) {
-                const float tsc = need_t ? wide_target_score(tgt, cx.tab0, cc, d, x, fs[c], fx0[c], fiv[c]) : 0.0f;
-                float sc;
-                if (ctrl_kind == SDEH_CTRL_SCORE) sc = tsc;
-                else if (ctrl_kind == SDEH_CTRL_LERP) sc = wl < 0.5f ? psc + wl * (tsc - psc) : tsc - (tsc - psc) * (1.0f - wl);
-                else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) sc = wl * tsc;
-                else sc = (1.0f - wl) * psc;
-                const float gq = L.g == 1 ? g0 : ws[L.gam + i * L.g + cc];
-                sterm = mult * ((A.scale_score * clipf(sc, A.clip_score)) * gq);
-              }
-              const float u = valid ? clipf(nn[k][c][q], A.clip_model) + sterm : 0.0f;
-              const float rs = refc ? sig * psc : 0.0f;  // reference_ctrl = sigma prior.score (solver/oc.py:305-306)
-              const float gm = valid ? u - rs : 0.0f;
-              if (!refc) costl[c] = fmaf(u, u, costl[c]);
-              else if (lv) costl[c] = fmaf(gm, u - 0.5f * (rs + u), costl[c]);
-              else costl[c] = fmaf(gm, gm, costl[c]);
-              itol[c] = fmaf(gm, n[e], itol[c]);
-              const float xn = valid ? fmaf(c_u, u, fmaf(c_n, n[e], c_x * x)) : 0.0f;
-              xr[k][c][q] = xn;
-              xo[e] = xn;
-            }
-            if (A.xs != nullptr && live[c] && cbase < d) {
-              float* __restrict__ xp = A.xs + ((long long)(i + 1) * A.batch + lrow[c]) * d + cbase;
-              if (vec4) *reinterpret_cast<float4*>(xp) = float4{xo[0], xo[1], xo[2], xo[3]};
-              else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) if (cbase + e < d) xp[e] = xo[e];
-              }
-            }
-            SDEH_FENCE();
-          }
+        for (int q = 0; q < 16; ++q) {
+          const float2 pp = *reinterpret_cast<const float2*>(cx.tab1 + 2 * coord(q));
+          psc[q] = (pp.x - x[q]) * pp.y;
         }
       }
+      if (ctrl_kind != SDEH_CTRL_CLIPPED) {
+        float sc[16];
+        if (need_t) {
+          if (tgt.kind == SDEH_DENS_DIAG_GAUSS) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float2 pp = *reinterpret_cast<const float2*>(cx.tab0 + 2 * coord(q));
+              sc[q] = (pp.x - x[q]) * pp.y;
+            }
+          } else if (tgt.kind == SDEH_DENS_MULTI_WELL) {  // distr/double_well.py:43-45,174-179
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float y = x[q] - tgt.p1;
+              sc[q] = coord(q) < tgt.n_comp ? -4.0f * (y * y - tgt.p0) * y : -y;
+            }
+          } else if (tgt.kind == SDEH_DENS_FUNNEL) {  // distr/funnel.py:71-80
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sc[q] = -x[q] * fiv[c];
+            const float s0 = -fx0[c] / tgt.p0 - 0.5f * (float)(d - 1) + 0.5f * fs[c] * fiv[c];
+            sc[0] = cb == 0 ? s0 : sc[0];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sc[q] = 0.0f;
+          }
+        }
+        if (ctrl_kind == SDEH_CTRL_LERP) {  // reparam.py:131-144; torch.lerp's two-sided formula
+          if (wl < 0.5f) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sc[q] = psc[q] + wl * (sc[q] - psc[q]);
+          } else {
+            const float w1 = 1.0f - wl;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sc[q] = sc[q] - (sc[q] - psc[q]) * w1;
+          }
+        } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {  // reparam.py:185-197
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sc[q] = wl * sc[q];
+        } else if (ctrl_kind == SDEH_CTRL_LERP_PRIOR) {  // reparam.py:166-178
+          const float w1 = 1.0f - wl;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sc[q] = w1 * psc[q];
+        }
+        if (L.g == 1) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sterm[q] = mult * ((A.scale_score * clipf(sc[q], A.clip_score)) * g0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sterm[q] = mult * ((A.scale_score * clipf(sc[q], A.clip_score)) * ws[L.gam + i * L.g + coord(q)]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sterm[q] = 0.0f;
+      }
+      SDEH_FENCE();
+      // ---- Gaussian draws: register group g4 = coordinates cb + 8 g4 .. + 3 = Philox block (cb + 8 g4) / 4 ------------------------
+      float n[16];
+      if (A.noise != nullptr) {
+        const float* __restrict__ np = A.noise + ((long long)i * A.batch + lrow[c]) * d + cb;
+        if (vec4) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            float4 t4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (cb + 8 * g4 < d) t4 = *reinterpret_cast<const float4*>(np + 8 * g4);
+            n[4 * g4] = t4.x; n[4 * g4 + 1] = t4.y; n[4 * g4 + 2] = t4.z; n[4 * g4 + 3] = t4.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) n[q] = coord(q) < d ? np[(q & 3) + 8 * (q >> 2)] : 0.0f;
+        }
+      } else {
+        const unsigned long long grow = (unsigned long long)(A.row_offset + lrow[c]);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          float n4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (cb + 8 * g4 < d) box_muller4(philox_block(A.seed, rng_off, grow, i, (cb + 8 * g4) >> 2), n4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) n[4 * g4 + e] = n4[e];
+          SDEH_FENCE();
+        }
+      }
+      // ---- u = clip(nn) + score term; running-cost / Ito partial sums; state update ------------------------------------------
+      const f32x16 bo = load16(bias_lds + L.n_hidden * C + (t * 2 + hv) * 16);  // out_layer.bias of these 16 coordinates
+      float u[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float uq = clipf(nnv[q] + bo[q], A.clip_model) + sterm[q];
+        u[q] = coord(q) < d ? uq : 0.0f;
+      }
+      if (!refc) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          costl[c] = fmaf(u[q], u[q], costl[c]);
+          itol[c] = fmaf(u[q], n[q], itol[c]);
+        }
+      } else {  // reference_ctrl = sigma prior.score (solver/oc.py:305-306), evaluated at the step's input
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float rs = sig * psc[q];
+          const float gm = coord(q) < d ? u[q] - rs : 0.0f;
+          costl[c] = lv ? fmaf(gm, u[q] - 0.5f * (rs + u[q]), costl[c]) : fmaf(gm, gm, costl[c]);
+          itol[c] = fmaf(gm, n[q], itol[c]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float xn = fmaf(c_u, u[q], fmaf(c_n, n[q], c_x * x[q]));
+        x[q] = coord(q) < d ? xn : 0.0f;
+      }
+      if (A.xs != nullptr && live[c]) {
+        float* __restrict__ xp = A.xs + ((long long)(i + 1) * A.batch + lrow[c]) * d + cb;
+        if (vec4) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4)
+            if (cb + 8 * g4 < d) *reinterpret_cast<float4*>(xp + 8 * g4) = float4{x[4 * g4], x[4 * g4 + 1], x[4 * g4 + 2], x[4 * g4 + 3]};
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (coord(q) < d) xp[(q & 3) + 8 * (q >> 2)] = x[q];
+        }
+      }
+      SDEH_FENCE();
     };
-    if (nto > 0) tile(std::integral_constant<int, 0>{});
-    if (nto > 1) tile(std::integral_constant<int, 1>{});
+    if (nto > 0 && !(A.int_kind & 1)) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) vtile(xr[0][c], nn[0][c], w, c);
+    }
+    if (nto > 1 && !(A.int_kind & 1)) {
+#pragma unroll
+      for (int c = 0; c < CT; ++c) vtile(xr[1][c], nn[1][c], w + 4, c);
+    }
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       const float cs = half_sum(costl[c]), is = half_sum(itol[c]);
@@ -469,8 +625,12 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
         cx.scr[(WSL_ITO * 4 + w) * RS + 32 * c + j] = is;
       }
     }
+    // the next step's first operands (input layer A groups, time embedding of step i + 1) travel across the publish barrier
+    wide_prefetch<OTW>(pre_in, ws + L.w_in, L.ot * 256, L.dp8 / 8, voff_in);
+#pragma unroll
+    for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + (i + 1 < A.n_steps ? i + 1 : i) * C + ((w + 4 * k) * 2 + h) * 16);
     wide_publish<CT>(cx, cx.plane(p), xr, nto);
-    __syncthreads();  // x_{i+1}, its statistics and this step's cost partials are visible
+    wide_barrier();  // x_{i+1}, its statistics and this step's cost partials are visible
     // ---- running cost (losses/oc.py:204-211, 319-323, 418-431) and Ito term -----------------------------------------------
     if (w == 0) {
 #pragma unroll
@@ -525,7 +685,8 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
 
 inline size_t wide_lds_bytes(const WsLayout& L, int ct, int n_planes) {
   const int rows = L.c > 32 * L.otd ? L.c : 32 * L.otd;
-  return ((size_t)n_planes * rows * 32 * ct + (size_t)kWideSlots * 4 * 32 * ct + 3 * (2 * L.dp + 4)) * sizeof(float);
+  return ((size_t)n_planes * rows * 32 * ct + (size_t)kWideSlots * 4 * 32 * ct + 3 * (2 * L.dp + 4) + L.n_hidden * L.c + 32 * L.otd) *
+         sizeof(float);
 }
 
 template <int OTW, int CT>
@@ -552,9 +713,14 @@ int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used) {
   int ct = a.batch > 32 * 256 ? 2 : 1;
   if (force != nullptr && (force[0] == '1' || force[0] == '2')) ct = force[0] - '0';
   if (ct_used != nullptr) *ct_used = ct;
+  TrajArgs dbg = a;
+  if (getenv("SDEH_WIDE_DBG") != nullptr) {
+    dbg.int_kind = atoi(getenv("SDEH_WIDE_DBG"));
+    if (dbg.int_kind & 4) { dbg.lay.dp8 = -8; dbg.lay.c = 0; }
+  }
   const int otw = a.lay.c / 128;
-  if (otw == 2) return ct == 2 ? launch_wide_t<2, 2>(a, stream) : launch_wide_t<2, 1>(a, stream);
-  if (otw == 1) return ct == 2 ? launch_wide_t<1, 2>(a, stream) : launch_wide_t<1, 1>(a, stream);
+  if (otw == 2) return ct == 2 ? launch_wide_t<2, 2>(dbg, stream) : launch_wide_t<2, 1>(dbg, stream);
+  if (otw == 1) return ct == 2 ? launch_wide_t<1, 2>(dbg, stream) : launch_wide_t<1, 1>(dbg, stream);
   return SDEH_ERR_UNSUPPORTED;
 }
 

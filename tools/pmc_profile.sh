@@ -3,12 +3,19 @@
 # Counters are collected in separate passes WITHOUT trace domains (only --kernel-trace), as the pool requires.
 set -u
 OUT=${1:-gpurun_out/pmc}
+# optional: the command to profile (default: 4 launches of the headline workload), e.g.
+#   tools/pmc_profile.sh gpurun_out/pmc_wide "python tools/wide_timing.py wide_pis_funnel196 32768"
+CMD=${2:-}
 ROOT=$(pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d "$ROOT/$OUT/$name" -- python "$ROOT/tools/quick_time.py" 4 > "$ROOT/$OUT/$name.log" 2>&1
+  if [ -z "$CMD" ]; then
+    timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d "$ROOT/$OUT/$name" -- python "$ROOT/tools/quick_time.py" 4 > "$ROOT/$OUT/$name.log" 2>&1
+  else
+    (cd "$ROOT" && timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d "$ROOT/$OUT/$name" -- $CMD > "$ROOT/$OUT/$name.log" 2>&1)
+  fi
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL

@@ -345,7 +345,9 @@ __device__ __forceinline__ float wide_target_score(const DensArgs& D, const floa
 // ---------------------------------------------------------------------------------------------------------
 // the kernel (no inference control)
 // ---------------------------------------------------------------------------------------------------------
-template <int OTW, int CT>
+// SINGLE: one activation plane instead of two (128 trajectories per workgroup: 4 column tiles x 256 channels x 4 B = 128 KB): a
+// layer's output overwrites its input in place, behind an extra barrier.
+template <int OTW, int CT, bool SINGLE>
 __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WsLayout& L = A.lay;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
   cx.RS = RS; cx.d = d;
   cx.wave = w; cx.lane = lane; cx.j = j; cx.h = h;
   cx.planes = lds; cx.plane_floats = rows * RS;
-  cx.scr = lds + 2 * rows * RS;
+  cx.scr = lds + (SINGLE ? 1 : 2) * rows * RS;
   float* tabs = cx.scr + kWideSlots * 4 * RS;
   const int tab_stride = 2 * L.dp + 4;
   for (int i = tid; i < 3 * tab_stride; i += 256) {
@@ -452,8 +454,8 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     }
     // ---- network pass ---------------------------------------------------------------------------------------------
     f32x16 nn[2][CT];
-    const int pout = wide_mlp<OTW, CT, false>(cx, ws, L, (A.int_kind & 2) ? SDEH_ACT_RELU : act, p, false, nullptr, pre_in, emb, bias_lds, nn, nto);
-    p = 1 - pout;  // the plane no wave reads any more: the new state goes there
+    const int pout = wide_mlp<OTW, CT, false>(cx, ws, L, act, p, SINGLE, nullptr, pre_in, emb, bias_lds, nn, nto);
+    p = SINGLE ? 0 : 1 - pout;  // the plane no wave reads any more: the new state goes there
 
     // ---- elementwise part on this wave's coordinates (reparam.py controls, oc.py cost / update) ---------------------------
     // One (tile, column tile) pair = 16 registers at a time, in stages whose wave-uniform switches (target kind, control kind,
@@ -609,11 +611,11 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
       }
       SDEH_FENCE();
     };
-    if (nto > 0 && !(A.int_kind & 1)) {
+    if (nto > 0) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) vtile(xr[0][c], nn[0][c], w, c);
     }
-    if (nto > 1 && !(A.int_kind & 1)) {
+    if (nto > 1) {
 #pragma unroll
       for (int c = 0; c < CT; ++c) vtile(xr[1][c], nn[1][c], w + 4, c);
     }
@@ -625,6 +627,7 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
         cx.scr[(WSL_ITO * 4 + w) * RS + 32 * c + j] = is;
       }
     }
+    if (SINGLE) wide_barrier();  // every wave has finished reading the (only) plane in its out-layer
     // the next step's first operands (input layer A groups, time embedding of step i + 1) travel across the publish barrier
     wide_prefetch<OTW>(pre_in, ws + L.w_in, L.ot * 256, L.dp8 / 8, voff_in);
 #pragma unroll
@@ -691,18 +694,19 @@ inline size_t wide_lds_bytes(const WsLayout& L, int ct, int n_planes) {
 
 template <int OTW, int CT>
 static int launch_wide_t(const TrajArgs& a, hipStream_t stream) {
-  const size_t lds_bytes = wide_lds_bytes(a.lay, CT, 2);
+  constexpr bool SINGLE = CT > 2;
+  const size_t lds_bytes = wide_lds_bytes(a.lay, CT, SINGLE ? 1 : 2);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_wide_kernel<OTW, CT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_wide_kernel<OTW, CT, SINGLE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
   const unsigned grid = (unsigned)((a.batch + 32 * CT - 1) / (32 * CT));
-  hipLaunchKernelGGL((traj_wide_kernel<OTW, CT>), dim3(grid), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((traj_wide_kernel<OTW, CT, SINGLE>), dim3(grid), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
@@ -710,17 +714,12 @@ static int launch_wide_t(const TrajArgs& a, hipStream_t stream) {
 // a launch needs >= 256 workgroups to use every CU: below 16 384 trajectories the 32-trajectory form fills more CUs.
 int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used) {
   const char* force = getenv("SDEH_WIDE_CT");  // testing aid: "1" | "2" (read per call)
-  int ct = a.batch > 32 * 256 ? 2 : 1;
-  if (force != nullptr && (force[0] == '1' || force[0] == '2')) ct = force[0] - '0';
+  int ct = a.batch >= 128 * 256 ? 4 : (a.batch > 32 * 256 ? 2 : 1);
+  if (force != nullptr && (force[0] == '1' || force[0] == '2' || force[0] == '4')) ct = force[0] - '0';
   if (ct_used != nullptr) *ct_used = ct;
-  TrajArgs dbg = a;
-  if (getenv("SDEH_WIDE_DBG") != nullptr) {
-    dbg.int_kind = atoi(getenv("SDEH_WIDE_DBG"));
-    if (dbg.int_kind & 4) { dbg.lay.dp8 = -8; dbg.lay.c = 0; }
-  }
   const int otw = a.lay.c / 128;
-  if (otw == 2) return ct == 2 ? launch_wide_t<2, 2>(dbg, stream) : launch_wide_t<2, 1>(dbg, stream);
-  if (otw == 1) return ct == 2 ? launch_wide_t<1, 2>(dbg, stream) : launch_wide_t<1, 1>(dbg, stream);
+  if (otw == 2) return ct == 4 ? launch_wide_t<2, 4>(a, stream) : (ct == 2 ? launch_wide_t<2, 2>(a, stream) : launch_wide_t<2, 1>(a, stream));
+  if (otw == 1) return ct == 4 ? launch_wide_t<1, 4>(a, stream) : (ct == 2 ? launch_wide_t<1, 2>(a, stream) : launch_wide_t<1, 1>(a, stream));
   return SDEH_ERR_UNSUPPORTED;
 }
 

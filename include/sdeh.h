@@ -12,7 +12,8 @@
  *     nn.Linear.weight[out,in]).  Struct fields that are pointers are device pointers as well; the structs
  *     themselves live in host memory.
  *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the null stream), never
- *     synchronises, never allocates after sdeh_plan_create, never retains caller buffers.
+ *     synchronises, never allocates after sdeh_plan_create, never retains caller buffers.  (One exception: a plan for
+ *     channels >= 128 that evaluates a Bridge grows a per-trajectory scratch buffer the first time it sees a larger batch.)
  *   - return value: 0 on success, a negative SdehStatus otherwise (never throws across the ABI);
  *     sdeh_last_error() returns a thread-local message for the last failure.
  *   - parameters are re-read from the given pointers on EVERY call (the reference swaps EMA weights in and
@@ -174,8 +175,9 @@ typedef struct {
 } SdehProblem;
 
 typedef struct {
-  int32_t dim;         /* d */
-  int32_t channels;    /* C (multiple of 32) */
+  int32_t dim;         /* d:  <= 64 with channels = 64;  <= 256 with channels = 128 / 256 (evaluation-only "wide" kernels:
+                          Gaussian / double-well / funnel targets, inference networks with <= 2 hidden layers) */
+  int32_t channels;    /* C: 64, 128 or 256 */
   int32_t max_hidden;  /* largest n_hidden of base_model */
   int32_t max_steps;   /* largest T = len(ts)-1 */
   int32_t max_components; /* largest GMM K (0 if unused) */

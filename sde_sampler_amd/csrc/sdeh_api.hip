@@ -32,7 +32,8 @@ long long time_embed_workspace_floats(const SdehTimeEmbed& te, int n_steps);
 int launch_sample_stats(const float* x, const float* w, const float* domain, long long B, int d, float* scratch, int nb,
                         float* out, hipStream_t st);
 int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used);           // sdeh_wide.hip
-int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used); // sdeh_wide.hip
+int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used, float* scratch);  // sdeh_wide.hip
+long long bridge_wide_scratch_floats(long long batch);                                           // sdeh_wide.hip
 
 #define SDEH_DECL(dp, pad, tag, loss, ctrl, tgt, gmm, act, refc, gnv)                           \
   int launch_ws_dp##dp##_p##pad##_##tag(const TrajArgs& a, hipStream_t stream);                 \
@@ -214,6 +215,8 @@ struct SdehPlan {
   bool wide;               // C in {128, 256}, d <= 256: the channel-split kernels of sdeh_wide.hip (evaluation only)
   float* ws;          // workspace
   size_t ws_floats;
+  float* scratch;     // wide Bridge only: per-(column tile, coordinate group) divergence sums (grown on first use at a larger batch)
+  size_t scratch_floats;
   bool timing;
   bool timed;
   hipEvent_t ev0, ev1;
@@ -270,6 +273,8 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   p->variant = v;
   p->wide = wide;
   p->ws_floats = ws_floats;
+  p->scratch = nullptr;
+  p->scratch_floats = 0;
   p->timing = p->timed = false;
   p->ev0 = p->ev1 = nullptr;
   p->last_kernel[0] = 0;
@@ -315,6 +320,7 @@ void sdeh_plan_destroy(SdehPlan* plan) {
   if (plan->ev0) (void)hipEventDestroy(plan->ev0);
   if (plan->ev1) (void)hipEventDestroy(plan->ev1);
   if (plan->ws) (void)hipFree(plan->ws);
+  if (plan->scratch) (void)hipFree(plan->scratch);
   delete plan;
 }
 
@@ -612,9 +618,24 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
     A.inf_clip_model = inf.clip_model; A.inf_clip_score = inf.clip_score; A.inf_scale_score = inf.scale_score;
   }
+  if (bridge) {
+    // the one buffer a plan grows after creation: 32 group sums per trajectory of the network part of the divergence
+    const size_t need = (size_t)bridge_wide_scratch_floats(batch);
+    if (need > plan->scratch_floats) {
+      int prev = 0;
+      (void)hipGetDevice(&prev);
+      hipError_t e = hipSetDevice(plan->device);
+      if (e == hipSuccess && plan->scratch != nullptr) e = hipFree(plan->scratch);
+      plan->scratch = nullptr; plan->scratch_floats = 0;
+      if (e == hipSuccess) e = hipMalloc((void**)&plan->scratch, need * sizeof(float));
+      (void)hipSetDevice(prev);
+      if (e != hipSuccess) return fail(SDEH_ERR_HIP, "simulate_fwd (wide bridge): scratch allocation failed: %s", hipGetErrorString(e));
+      plan->scratch_floats = need;
+    }
+  }
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   int detail = 0;
-  rc = bridge ? launch_bridge_wide(A, st, &detail) : launch_wide(A, st, &detail);
+  rc = bridge ? launch_bridge_wide(A, st, &detail, plan->scratch) : launch_wide(A, st, &detail);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
   snprintf(plan->last_kernel, sizeof(plan->last_kernel), bridge ? "bridge_wide<C=%d,split=%d>" : "traj_wide<C=%d,CT=%d>", net.channels, detail);
   if (rc == SDEH_ERR_UNSUPPORTED) return fail(rc, "simulate_fwd (wide): the problem needs more than 160 KiB of LDS (d=%d, C=%d)", d, net.channels);

@@ -342,6 +342,113 @@ __device__ __forceinline__ float wide_target_score(const DensArgs& D, const floa
   }
 }
 
+// Score term of a control on 16 registers (one tile x column tile): mult * scale_score * clip(score mix, clip_score) * gamma
+// (reparam.py:56-83 ScoreCtrl, 131-162 LerpCtrl, 166-178 LerpPriorCtrl, 185-197 LerpTargetCtrl); zeros for ClippedCtrl.  The
+// wave-uniform switches (target kind, control kind) sit outside the 16-element loops.  psc: prior score (when need_p).
+struct WideScore {
+  int ctrl_kind, g;       // g: gamma row length (1 or padded d)
+  bool need_t, need_p;
+  DensArgs tgt;
+  float wl, mult, scale_score, clip_score, g0;
+  int d;
+};
+__device__ __forceinline__ void wide_score_term16(const WideScore& S, const WideCtx& cx, const f32x16& x, int cb, int c, float fs,
+                                                  float fx0, float fiv, const float* __restrict__ gam_row, float (&sterm)[16],
+                                                  float (&psc)[16]) {
+  (void)c;
+  auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
+  if (S.need_p) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float2 pp = *reinterpret_cast<const float2*>(cx.tab1 + 2 * coord(q));
+      psc[q] = (pp.x - x[q]) * pp.y;
+    }
+  }
+  if (S.ctrl_kind != SDEH_CTRL_CLIPPED) {
+    float sc[16];
+    if (S.need_t) {
+      if (S.tgt.kind == SDEH_DENS_DIAG_GAUSS) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float2 pp = *reinterpret_cast<const float2*>(cx.tab0 + 2 * coord(q));
+          sc[q] = (pp.x - x[q]) * pp.y;
+        }
+      } else if (S.tgt.kind == SDEH_DENS_MULTI_WELL) {  // distr/double_well.py:43-45,174-179
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float y = x[q] - S.tgt.p1;
+          sc[q] = coord(q) < S.tgt.n_comp ? -4.0f * (y * y - S.tgt.p0) * y : -y;
+        }
+      } else if (S.tgt.kind == SDEH_DENS_FUNNEL) {  // distr/funnel.py:71-80
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sc[q] = -x[q] * fiv;
+        const float s0 = -fx0 / S.tgt.p0 - 0.5f * (float)(S.d - 1) + 0.5f * fs * fiv;
+        sc[0] = cb == 0 ? s0 : sc[0];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sc[q] = 0.0f;
+      }
+    }
+    if (S.ctrl_kind == SDEH_CTRL_LERP) {  // reparam.py:131-144; torch.lerp's two-sided formula
+      if (S.wl < 0.5f) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sc[q] = psc[q] + S.wl * (sc[q] - psc[q]);
+      } else {
+        const float w1 = 1.0f - S.wl;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sc[q] = sc[q] - (sc[q] - psc[q]) * w1;
+      }
+    } else if (S.ctrl_kind == SDEH_CTRL_LERP_TARGET) {  // reparam.py:185-197
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sc[q] = S.wl * sc[q];
+    } else if (S.ctrl_kind == SDEH_CTRL_LERP_PRIOR) {  // reparam.py:166-178
+      const float w1 = 1.0f - S.wl;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sc[q] = w1 * psc[q];
+    }
+    if (S.g == 1) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sterm[q] = S.mult * ((S.scale_score * clipf(sc[q], S.clip_score)) * S.g0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sterm[q] = S.mult * ((S.scale_score * clipf(sc[q], S.clip_score)) * gam_row[coord(q)]);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sterm[q] = 0.0f;
+  }
+}
+
+// Four Philox blocks -> the 16 standard normals of one tile x column tile (register group g4 = coordinates cb + 8 g4 .. + 3 = block
+// (cb + 8 g4) / 4), or the same 16 values read from the caller's noise tensor (parity mode)
+__device__ __forceinline__ void wide_noise16(const float* __restrict__ noise_row, bool vec4, int cb, int d, unsigned long long seed,
+                                             unsigned long long rng_off, unsigned long long grow, int step, float (&n)[16]) {
+  auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
+  if (noise_row != nullptr) {
+    const float* __restrict__ np = noise_row + cb;
+    if (vec4) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        float4 t4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (cb + 8 * g4 < d) t4 = *reinterpret_cast<const float4*>(np + 8 * g4);
+        n[4 * g4] = t4.x; n[4 * g4 + 1] = t4.y; n[4 * g4 + 2] = t4.z; n[4 * g4 + 3] = t4.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) n[q] = coord(q) < d ? np[(q & 3) + 8 * (q >> 2)] : 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      float n4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (cb + 8 * g4 < d) box_muller4(philox_block(seed, rng_off, grow, step, (cb + 8 * g4) >> 2), n4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) n[4 * g4 + e] = n4[e];
+      SDEH_FENCE();
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // the kernel (no inference control)
 // ---------------------------------------------------------------------------------------------------------
@@ -477,98 +584,19 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     // of registers held across the step loop) -- an opaque copy of h per step keeps it recomputed where it is used.
     int hv = h;
     asm volatile("" : "+v"(hv));
+    WideScore sq;
+    sq.ctrl_kind = ctrl_kind; sq.g = L.g; sq.need_t = need_t; sq.need_p = need_p; sq.tgt = tgt; sq.wl = wl; sq.mult = mult;
+    sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = g0; sq.d = d;
     auto vtile = [&](f32x16& x, const f32x16& nnv, int t, int c) {
       const int cb = 32 * t + 4 * hv;  // register q <-> coordinate cb + (q & 3) + 8 (q >> 2)
       auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
-      float sterm[16];
-      float psc[16];
-      if (need_p) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float2 pp = *reinterpret_cast<const float2*>(cx.tab1 + 2 * coord(q));
-          psc[q] = (pp.x - x[q]) * pp.y;
-        }
-      }
-      if (ctrl_kind != SDEH_CTRL_CLIPPED) {
-        float sc[16];
-        if (need_t) {
-          if (tgt.kind == SDEH_DENS_DIAG_GAUSS) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const float2 pp = *reinterpret_cast<const float2*>(cx.tab0 + 2 * coord(q));
-              sc[q] = (pp.x - x[q]) * pp.y;
-            }
-          } else if (tgt.kind == SDEH_DENS_MULTI_WELL) {  // distr/double_well.py:43-45,174-179
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const float y = x[q] - tgt.p1;
-              sc[q] = coord(q) < tgt.n_comp ? -4.0f * (y * y - tgt.p0) * y : -y;
-            }
-          } else if (tgt.kind == SDEH_DENS_FUNNEL) {  // distr/funnel.py:71-80
-#pragma unroll
-            for (int q = 0; q < 16; ++q) sc[q] = -x[q] * fiv[c];
-            const float s0 = -fx0[c] / tgt.p0 - 0.5f * (float)(d - 1) + 0.5f * fs[c] * fiv[c];
-            sc[0] = cb == 0 ? s0 : sc[0];
-          } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) sc[q] = 0.0f;
-          }
-        }
-        if (ctrl_kind == SDEH_CTRL_LERP) {  // reparam.py:131-144; torch.lerp's two-sided formula
-          if (wl < 0.5f) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) sc[q] = psc[q] + wl * (sc[q] - psc[q]);
-          } else {
-            const float w1 = 1.0f - wl;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) sc[q] = sc[q] - (sc[q] - psc[q]) * w1;
-          }
-        } else if (ctrl_kind == SDEH_CTRL_LERP_TARGET) {  // reparam.py:185-197
-#pragma unroll
-          for (int q = 0; q < 16; ++q) sc[q] = wl * sc[q];
-        } else if (ctrl_kind == SDEH_CTRL_LERP_PRIOR) {  // reparam.py:166-178
-          const float w1 = 1.0f - wl;
-#pragma unroll
-          for (int q = 0; q < 16; ++q) sc[q] = w1 * psc[q];
-        }
-        if (L.g == 1) {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) sterm[q] = mult * ((A.scale_score * clipf(sc[q], A.clip_score)) * g0);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) sterm[q] = mult * ((A.scale_score * clipf(sc[q], A.clip_score)) * ws[L.gam + i * L.g + coord(q)]);
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sterm[q] = 0.0f;
-      }
+      float sterm[16], psc[16];
+      wide_score_term16(sq, cx, x, cb, c, fs[c], fx0[c], fiv[c], ws + L.gam + i * L.g, sterm, psc);
       SDEH_FENCE();
       // ---- Gaussian draws: register group g4 = coordinates cb + 8 g4 .. + 3 = Philox block (cb + 8 g4) / 4 ------------------------
       float n[16];
-      if (A.noise != nullptr) {
-        const float* __restrict__ np = A.noise + ((long long)i * A.batch + lrow[c]) * d + cb;
-        if (vec4) {
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            float4 t4 = float4{0.0f, 0.0f, 0.0f, 0.0f};
-            if (cb + 8 * g4 < d) t4 = *reinterpret_cast<const float4*>(np + 8 * g4);
-            n[4 * g4] = t4.x; n[4 * g4 + 1] = t4.y; n[4 * g4 + 2] = t4.z; n[4 * g4 + 3] = t4.w;
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) n[q] = coord(q) < d ? np[(q & 3) + 8 * (q >> 2)] : 0.0f;
-        }
-      } else {
-        const unsigned long long grow = (unsigned long long)(A.row_offset + lrow[c]);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          float n4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (cb + 8 * g4 < d) box_muller4(philox_block(A.seed, rng_off, grow, i, (cb + 8 * g4) >> 2), n4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) n[4 * g4 + e] = n4[e];
-          SDEH_FENCE();
-        }
-      }
+      wide_noise16(A.noise != nullptr ? A.noise + ((long long)i * A.batch + lrow[c]) * d : nullptr, vec4, cb, d, A.seed, rng_off,
+                   (unsigned long long)(A.row_offset + lrow[c]), i, n);
       // ---- u = clip(nn) + score term; running-cost / Ito partial sums; state update ------------------------------------------
       const f32x16 bo = load16(bias_lds + L.n_hidden * C + (t * 2 + hv) * 16);  // out_layer.bias of these 16 coordinates
       float u[16];
@@ -723,9 +751,442 @@ int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used) {
   return SDEH_ERR_UNSUPPORTED;
 }
 
-int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used) {
-  (void)a; (void)stream;
-  if (split_used != nullptr) *split_used = 0;
+// =========================================================================================================
+// Bridge: TimeReversalLoss with an inference control (losses/oc.py:189-202) on wide networks -- BASELINE.json configs[4].
+//
+//   u = generative_ctrl(s, x);  (div, v) = compute_divx(inference_ctrl, s, x)   [exact divergence, utils/autograd.py:14-22]
+//   rnd += sigma div dt;  cost on u + v (kl) / (u + v).(u_sde - (u - v)/2) (lv);  Ito term on u + v;  x driven by u alone.
+//
+// The reference takes d backward passes through the inference network per step.  Here a workgroup owns ONE column
+// tile of 32 trajectories; per step it runs the two network passes channel-split as above (the inference network's pass also
+// leaves act'(z_l) of every layer in LDS planes), then the diagonal of the Jacobian, one coordinate per wave at a time:
+//     J_jj = sum_ch F[ch] D[ch] G[ch]      with, for an inference network with Lh hidden layers,
+//       Lh = 0:  F = W_in[:, j]                            D = act'(z_0)   G = W_out[j, :]
+//       Lh = 1:  F = W_1 (act'(z_0) . W_in[:, j])          D = act'(z_1)   G = W_out[j, :]
+//       Lh = 2:  F = W_1 (act'(z_0) . W_in[:, j])          D = act'(z_1)   G = W_2^T (act'(z_2) . W_out[j, :])
+// i.e. a forward-mode tangent through the first hidden layer meets a reverse-mode adjoint through the second: two C x C products
+// per coordinate on the matrix pipe (A operands: the packed W_1 / transposed W_2 streamed from L2, all C/32 row tiles per wave;
+// B operands: an act' plane row times one column / row of the in / out layer, formed on the fly), no dependence between them, and
+// run-time loops only.  ClippedCtrl's clamp contributes the 0/1 mask d clip(v_j)/d v_j, the LerpPriorCtrl score term its
+// closed-form derivative.  Coordinates are dealt to waves in 32 fixed groups (j mod 32) whose sums are kept apart and added in a
+// fixed order at the very end, so the result does not depend on how many workgroups (`split`) share a column tile: small batches
+// put 2 .. 8 workgroups on one tile (each repeats the cheap network passes and state update bit-identically and takes its share
+// of the coordinates), which is what fills the chip at configs[4]'s 4096 trajectories per GPU.
+// =========================================================================================================
+constexpr int kDivGroups = 32;
+
+// acc[t] += Wp[tile t][:] . (dplane[:, traj] * col[:])  for all OT row tiles (t0 .. t0 + NT - 1) of one hidden layer.
+//   wgrp: packed layer (k-groups of OT tiles);  dpl: act' plane + h * 32 + j;  col: LDS row of C floats in B order (+ 4 h)
+template <int NT>
+__device__ __forceinline__ void wide_tangent_pass(const float* __restrict__ wgrp, int OT, int t0, int NS4, unsigned lane_off,
+                                                  const float* __restrict__ dpl, const float* __restrict__ col, f32x16 (&acc)[NT]) {
+  f32x4 a[2][NT];  // ring of two k-groups (a group is 4 NT MFMAs = 256 NT cycles: one group of distance hides the L2 latency)
+  const int grp_floats = OT * 256;
+  auto issue = [&](int S, f32x4 (&av)[NT]) {
+    const float* base = wgrp + (long long)(S < NS4 ? S : NS4 - 1) * grp_floats;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) wide_gload(av[k], lane_off + (unsigned)((t0 + k) * 1024), base);
+  };
+  auto wait_all = [&](f32x4 (&av)[NT], auto N) {
+#pragma unroll
+    for (int k = 0; k < NT; k += 2) {
+      f32x4 (&pr)[2] = reinterpret_cast<f32x4 (&)[2]>(av[k]);
+      wide_vmwait<decltype(N)::value, 2>(pr);
+    }
+  };
+  static_assert(NT % 2 == 0, "tiles are awaited in pairs");
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
+  issue(0, a[0]);
+  float b[2][4];
+  auto loadB = [&](int S, float (&bv)[4]) {
+    const int Sc = S < NS4 ? S : NS4 - 1;
+    const float4 cv = *reinterpret_cast<const float4*>(col + 8 * Sc);
+    const float* __restrict__ dp = dpl + (8 * Sc) * 32;
+    bv[0] = dp[0] * cv.x; bv[1] = dp[64] * cv.y; bv[2] = dp[128] * cv.z; bv[3] = dp[192] * cv.w;
+  };
+  loadB(0, b[0]);
+  for (int S = 0; S < NS4; S += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      issue(S + u + 1, a[(u + 1) % 2]);
+      loadB(S + u + 1, b[(u + 1) % 2]);
+      wait_all(a[u], std::integral_constant<int, NT>{});  // all but the NT newest loads have landed
+      SDEH_FENCE();
+      if (S + u < NS4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < NT; ++k) acc[k] = SDEH_MFMA(a[u][k][e], b[u][e], acc[k]);
+      }
+      SDEH_FENCE();
+    }
+  }
+  wait_all(a[0], std::integral_constant<int, 0>{});  // drain the clamped re-read issued by the last iteration
+}
+
+template <int OTW>  // C = 128 OTW
+__global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int split, float* __restrict__ divparts) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int CT = 1, RS = 32, OT = 4 * OTW, C = 128 * OTW;
+  const WsLayout& L = A.lay;
+  const WsLayout& L2 = A.lay2;
+  const float* __restrict__ ws = A.ws;
+  const float* __restrict__ ws2 = A.ws2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int d = A.d, OTD = L.otd;
+  const int rows = C > 32 * OTD ? C : 32 * OTD;
+  const int tile = (int)blockIdx.x / split, sp = (int)blockIdx.x % split;
+  const bool lead = sp == 0;  // the workgroup that owns the tile's outputs (x_T, rnd without the network-divergence part)
+
+  WideCtx cx;
+  cx.RS = RS; cx.d = d;
+  cx.wave = w; cx.lane = lane; cx.j = j; cx.h = h;
+  cx.planes = lds; cx.plane_floats = rows * RS;
+  float* dplanes = lds + rows * RS;                       // act'(z_l) of the inference network, l = 0 .. Lh: [Lh + 1][C][32]
+  cx.scr = dplanes + (L2.n_hidden + 1) * C * RS;          // [kWideSlots][4][32]
+  float* divacc = cx.scr + kWideSlots * 4 * RS;           // [4 waves][8 groups][32]: sigma dt mask J_jj accumulated over the steps
+  float* cols = divacc + 4 * 8 * RS;                      // [4 waves][2][C]: column j of W_in / row j of W_out of the coordinate at hand
+  float* tabs = cols + 4 * 2 * C;
+  const int tab_stride = 2 * L.dp + 4;
+  for (int i = tid; i < 3 * tab_stride; i += 256) {
+    const int which = i / tab_stride, o = i % tab_stride;
+    tabs[i] = o <= 2 * L.dp ? ws[L.dg[which] + o] : 0.0f;
+  }
+  cx.tab0 = tabs; cx.tab1 = tabs + tab_stride; cx.tab2 = tabs + 2 * tab_stride;
+  float* bias_u = tabs + 3 * tab_stride;                  // generative network: hidden biases then out-layer bias
+  float* bias_v = bias_u + L.n_hidden * C + 32 * OTD;     // inference network
+  for (int i = tid; i < L.n_hidden * C + 32 * OTD; i += 256) bias_u[i] = ws[L.b_hid + i];
+  for (int i = tid; i < L2.n_hidden * C + 32 * OTD; i += 256) bias_v[i] = ws2[L2.b_hid + i];
+  for (int i = tid; i < 4 * 8 * RS; i += 256) divacc[i] = 0.0f;
+  cx.bias = bias_u;
+
+  const int nto = (OTD > w ? 1 : 0) + (OTD > w + 4 ? 1 : 0);
+  const long long row0 = (long long)tile * RS;
+  const int flags = A.flags, ctrl_kind = A.ctrl_kind;
+  const DensArgs tgt = A.target;
+  const bool lv = flags & SDEH_FLAG_CHANGE_SDE_CTRL;
+  const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
+  const bool inf_lerp = A.inf_kind == SDEH_CTRL_LERP_PRIOR;
+  const bool need_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR || inf_lerp;
+  const bool vec4 = (d & 3) == 0;
+  const int Lh2 = L2.n_hidden;
+
+  f32x16 xr[2][CT];
+  const long long r = row0 + j;
+  const bool live = r < A.batch;
+  const long long lrow = live ? r : A.batch - 1;
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int cc = 32 * (w + 4 * k) + rho(q, h);
+      xr[k][0][q] = (k < nto && cc < d) ? A.x0[lrow * d + cc] : 0.0f;
+      if (A.xs != nullptr && lead && k < nto && cc < d && live) A.xs[lrow * d + cc] = xr[k][0][q];
+    }
+  __syncthreads();  // tables staged
+  wide_publish<CT>(cx, cx.plane(0), xr, nto);
+  if (flags & SDEH_FLAG_INIT_LOGP) wide_gauss_quad<CT>(cx, cx.tab2, xr, nto, WSL_LOGP_A);
+  __syncthreads();
+  float rnd = 0.0f;  // wave 0, lane half 0 of the lead workgroup
+  if (flags & SDEH_FLAG_INIT_LOGP) rnd = cx.tab2[2 * L.dp] - 0.5f * wide_slot_sum(cx, WSL_LOGP_A, j);
+  const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
+  const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+  unsigned voff_in[OTW];
+#pragma unroll
+  for (int k = 0; k < OTW; ++k) voff_in[k] = (unsigned)(((w + 4 * k) * 64 + lane) * 16);
+  // coordinate groups of this wave: g = gw, gw + TW, ... (gw = global wave index among the TW waves sharing the tile)
+  const int TW = 4 * split, gw = sp * 4 + w, ngw = kDivGroups / TW;
+
+  for (int i = 0; i < A.n_steps; ++i) {
+    cfp cf = as_const(ws + L.coef + i * kCoefStride);
+    const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
+    float fs = 0.0f, fx0 = 0.0f, fiv = 0.0f;  // funnel statistics of x_i
+    if (need_t && tgt.kind == SDEH_DENS_FUNNEL) {
+      fs = wide_slot_sum(cx, WSL_PRESQ, j);
+      fx0 = cx.scr[(WSL_X0 * 4) * RS + j];
+      fiv = __expf(-fx0);
+    }
+    // ---- generative network u (plane: x -> ... -> last hidden activation) ------------------------------------------------
+    f32x16 nu[2][CT], nv[2][CT];
+    {
+      WidePre<OTW> pre;
+      wide_prefetch<OTW>(pre, ws + L.w_in, OT * 256, L.dp8 / 8, voff_in);
+      f32x16 emb[OTW];
+#pragma unroll
+      for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + i * C + ((w + 4 * k) * 2 + h) * 16);
+      (void)wide_mlp<OTW, CT, false>(cx, ws, L, A.act, 0, true, nullptr, pre, emb, bias_u, nu, nto);
+    }
+    wide_barrier();  // every wave is through its out-layer: the plane may take x again
+    {
+      float* __restrict__ pl = cx.plane(0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < nto) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) pl[(32 * (w + 4 * k) + rho(q, h)) * RS + j] = xr[k][0][q];
+        }
+    }
+    wide_barrier();
+    // ---- inference network v, keeping act'(z_l) of every layer ----------------------------------------------------------------
+    {
+      WidePre<OTW> pre;
+      wide_prefetch<OTW>(pre, ws2 + L2.w_in, OT * 256, L2.dp8 / 8, voff_in);
+      f32x16 emb[OTW];
+#pragma unroll
+      for (int k = 0; k < OTW; ++k) emb[k] = load16(ws2 + L2.emb + i * C + ((w + 4 * k) * 2 + h) * 16);
+      (void)wide_mlp<OTW, CT, true>(cx, ws2, L2, A.inf_act, 0, true, dplanes, pre, emb, bias_v, nv, nto);
+    }
+    wide_barrier();
+    // raw inference-network output (+ bias) -> plane rows [coordinate][trajectory]: the clamp mask of every coordinate
+    {
+      float* __restrict__ pl = cx.plane(0);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < nto) {
+          const f32x16 bo = load16(bias_v + L2.n_hidden * C + ((w + 4 * k) * 2 + h) * 16);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            nv[k][0][q] += bo[q];
+            pl[(32 * (w + 4 * k) + rho(q, h)) * RS + j] = nv[k][0][q];
+          }
+        }
+    }
+    wide_barrier();
+    // ---- diagonal of the inference network's Jacobian: this wave's coordinates ------------------------------------------------
+    {
+      const float sdt = sig * dt;
+      float* __restrict__ mycol = cols + w * 2 * C;
+      const float* __restrict__ d0 = dplanes + h * RS + j;
+      const unsigned lane_off = (unsigned)(lane * 16);
+      for (int gi = 0; gi < ngw; ++gi) {
+        const int g = gw + gi * TW;
+        float part = 0.0f;
+        for (int jc = g; jc < d; jc += kDivGroups) {
+          // column jc of W_in and row jc of W_out (B order) -> this wave's LDS rows
+          {
+            const float4 ci = *reinterpret_cast<const float4*>(ws2 + L2.tan_in + jc * C + lane * 4);
+            const float4 co = *reinterpret_cast<const float4*>(ws2 + L2.tan_out + jc * C + lane * 4);
+            if (lane * 4 < C) {
+              *reinterpret_cast<float4*>(mycol + lane * 4) = ci;
+              *reinterpret_cast<float4*>(mycol + C + lane * 4) = co;
+            }
+          }
+          float jj = 0.0f;
+          auto idx = [&](int ot, int q) { return (4 * ot + (q >> 2)) * 8 + (q & 1) * 4 + ((q >> 1) & 1) + 2 * h; };  // B order of channel 32 ot + rho(q, h)
+          if (Lh2 == 0) {
+#pragma unroll
+            for (int ot = 0; ot < OT; ++ot)
+#pragma unroll
+              for (int q = 0; q < 16; ++q)
+                jj = fmaf(mycol[idx(ot, q)] * dplanes[(32 * ot + rho(q, h)) * RS + j], mycol[C + idx(ot, q)], jj);
+          } else {
+            // Channel by channel F meets only its own D and G: the row tiles are processed in two halves, so that the
+            // accumulators of F and G together stay at half of the wave's AGPRs
+            const float* __restrict__ d1 = dplanes + C * RS;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              constexpr int NH = OT / 2;
+              f32x16 F[NH];
+              wide_tangent_pass<NH>(ws2 + L2.w_hid, OT, half * NH, C / 8, lane_off, d0, mycol + 4 * h, F);
+              if (Lh2 == 1) {
+#pragma unroll
+                for (int k = 0; k < NH; ++k)
+#pragma unroll
+                  for (int q = 0; q < 16; ++q) {
+                    const int ot = half * NH + k;
+                    jj = fmaf(F[k][q] * d1[(32 * ot + rho(q, h)) * RS + j], mycol[C + idx(ot, q)], jj);
+                  }
+              } else {
+                f32x16 G[NH];  // adjoint through the second hidden layer
+                wide_tangent_pass<NH>(ws2 + L2.wt_hid + L2.w_hid_stride, OT, half * NH, C / 8, lane_off, d0 + 2 * C * RS,
+                                      mycol + C + 4 * h, G);
+#pragma unroll
+                for (int k = 0; k < NH; ++k)
+#pragma unroll
+                  for (int q = 0; q < 16; ++q) {
+                    const int ot = half * NH + k;
+                    jj = fmaf(F[k][q] * d1[(32 * ot + rho(q, h)) * RS + j], G[k][q], jj);
+                  }
+              }
+            }
+          }
+          jj = half_sum(jj);
+          // d clip(v_j, -m, m) / d v_j = 1 on [-m, m] (torch.clamp's backward), else 0
+          const float vj = cx.plane(0)[jc * RS + j];
+          part += (vj >= -A.inf_clip_model && vj <= A.inf_clip_model) ? jj : 0.0f;
+        }
+        if (h == 0) divacc[(w * 8 + gi) * RS + j] = fmaf(sdt, part, divacc[(w * 8 + gi) * RS + j]);
+      }
+    }
+    // ---- elementwise part on this wave's coordinates -----------------------------------------------------------------------------
+    const float c_x = fmaf(cf[CF_DRIFT], dt, 1.0f), c_u = sig * dt, c_n = sig * sqdt;
+    const float wl = cf[CF_W];
+    int hv = h;
+    asm volatile("" : "+v"(hv));
+    WideScore sq;
+    sq.ctrl_kind = ctrl_kind; sq.g = L.g; sq.need_t = need_t; sq.need_p = need_p; sq.tgt = tgt; sq.wl = wl;
+    sq.mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;
+    sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = as_const(ws + L.gam + i * L.g)[0]; sq.d = d;
+    const float g20 = as_const(ws2 + L2.gam + i * L2.g)[0];
+    float costl = 0.0f, itol = 0.0f, divs = 0.0f;
+    auto vtile = [&](f32x16& x, const f32x16& nuv, const f32x16& nvv, int t) {
+      const int cb = 32 * t + 4 * hv;
+      auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
+      float sterm[16], psc[16];
+      wide_score_term16(sq, cx, x, cb, 0, fs, fx0, fiv, ws + L.gam + i * L.g, sterm, psc);
+      SDEH_FENCE();
+      float n[16];
+      wide_noise16(A.noise != nullptr ? A.noise + ((long long)i * A.batch + lrow) * d : nullptr, vec4, cb, d, A.seed, rng_off, grow, i, n);
+      const f32x16 bo = load16(bias_u + L.n_hidden * C + (t * 2 + hv) * 16);
+      float u[16], v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float uq = clipf(nuv[q] + bo[q], A.clip_model) + sterm[q];
+        u[q] = coord(q) < d ? uq : 0.0f;
+      }
+      if (inf_lerp) {  // LerpPriorCtrl (reparam.py:165-178,149-162): v += sigma [scale clip((1 - t/T) prior_score(x)) gamma(t)]
+        const float w1 = 1.0f - wl;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float gq = L2.g == 1 ? g20 : ws2[L2.gam + i * L2.g + coord(q)];
+          const float sc = w1 * psc[q];
+          const bool inside = sc >= -A.inf_clip_score && sc <= A.inf_clip_score;
+          const float vq = clipf(nvv[q], A.inf_clip_model) + sig * ((A.inf_scale_score * clipf(sc, A.inf_clip_score)) * gq);
+          const float dsc = inside ? -(w1 * cx.tab1[2 * coord(q) + 1]) : 0.0f;
+          const bool valid = coord(q) < d;
+          divs = valid ? fmaf(sig * A.inf_scale_score * gq, dsc, divs) : divs;
+          v[q] = valid ? vq : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = coord(q) < d ? clipf(nvv[q], A.inf_clip_model) : 0.0f;
+      }
+      // running cost on gen_plus_inf = u + v, gen_minus_inf = u - v (losses/oc.py:201-211); Ito term on u + v
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float gp = u[q] + v[q];
+        costl = lv ? fmaf(gp, u[q] - 0.5f * (u[q] - v[q]), costl) : fmaf(gp, gp, costl);
+        itol = fmaf(gp, n[q], itol);
+        const float xn = fmaf(c_n, n[q], fmaf(c_u, u[q], c_x * x[q]));
+        x[q] = coord(q) < d ? xn : 0.0f;
+      }
+      if (A.xs != nullptr && live && lead) {
+        float* __restrict__ xp = A.xs + ((long long)(i + 1) * A.batch + lrow) * d + cb;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (coord(q) < d) xp[(q & 3) + 8 * (q >> 2)] = x[q];
+      }
+      SDEH_FENCE();
+    };
+    if (nto > 0) vtile(xr[0][0], nu[0][0], nv[0][0], w);
+    if (nto > 1) vtile(xr[1][0], nu[1][0], nv[1][0], w + 4);
+    {
+      const float cs = half_sum(costl), is = half_sum(itol), ds = half_sum(divs);
+      if (h == 0) {
+        cx.scr[(WSL_COST * 4 + w) * RS + j] = cs;
+        cx.scr[(WSL_ITO * 4 + w) * RS + j] = is;
+        cx.scr[(WSL_DIV * 4 + w) * RS + j] = ds;
+      }
+    }
+    wide_barrier();  // everyone has read the clamp-mask rows of the plane
+    wide_publish<CT>(cx, cx.plane(0), xr, nto);
+    wide_barrier();
+    if (w == 0 && lead) {
+      float cost = wide_slot_sum(cx, WSL_COST, j);
+      if (!lv) cost *= 0.5f;
+      rnd = fmaf(sig * wide_slot_sum(cx, WSL_DIV, j), dt, rnd);  // score part of the divergence (losses/oc.py:199-200)
+      rnd = fmaf(cost, dt, rnd);
+      if (!(flags & SDEH_FLAG_TRAIN)) rnd -= cf[CF_DDIV];
+      if (flags & SDEH_FLAG_ITO) rnd = fmaf(wide_slot_sum(cx, WSL_ITO, j), sqdt, rnd);
+    }
+  }
+
+  // ---- network part of the divergence: this wave's group sums -> divparts[tile][group][trajectory] ---------------------------
+  if (h == 0)
+    for (int gi = 0; gi < ngw; ++gi) divparts[((long long)tile * kDivGroups + gw + gi * TW) * RS + j] = divacc[(w * 8 + gi) * RS + j];
+  if (!lead) return;
+  if (flags & SDEH_FLAG_TERMINAL_TARGET) {
+    if (tgt.kind == SDEH_DENS_DIAG_GAUSS) wide_gauss_quad<CT>(cx, cx.tab0, xr, nto, WSL_LOGP_B);
+    else if (tgt.kind == SDEH_DENS_MULTI_WELL) wide_mwell_sum<CT>(cx, tgt, xr, nto, WSL_LOGP_B);
+  }
+  __syncthreads();
+  if (w == 0 && h == 0) {
+    float rr = rnd;
+    if (flags & SDEH_FLAG_TERMINAL_TARGET) {
+      float lp = 0.0f;
+      if (tgt.kind == SDEH_DENS_DIAG_GAUSS) lp = cx.tab0[2 * L.dp] - 0.5f * wide_slot_sum(cx, WSL_LOGP_B, j) + tgt.lnc;
+      else if (tgt.kind == SDEH_DENS_MULTI_WELL) lp = -wide_slot_sum(cx, WSL_LOGP_B, j);
+      else if (tgt.kind == SDEH_DENS_FUNNEL) {
+        const float x0v = cx.scr[(WSL_X0 * 4) * RS + j], sqs = wide_slot_sum(cx, WSL_PRESQ, j);
+        const float first = -0.5f * __logf(6.283185307179586f * tgt.p0) - 0.5f * x0v * x0v / tgt.p0;
+        const float other = -(float)(d - 1) * (x0v + 1.8378770664093453f) * 0.5f - 0.5f * sqs * __expf(-x0v);
+        lp = first + other + tgt.lnc;
+      }
+      rr -= clipf(lp, A.clip_target);
+    }
+    if (live) A.rnd[row0 + j] = rr;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int cc = 32 * (w + 4 * k) + rho(q, h);
+      if (k < nto && cc < d && live) A.xT[lrow * d + cc] = xr[k][0][q];
+    }
+}
+
+// rnd[row] += the 32 group sums of sigma dt div_x(network part), in fixed order (independent of `split`)
+__global__ void bridge_wide_finish(float* __restrict__ rnd, const float* __restrict__ divparts, long long batch) {
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= batch) return;
+  const float* p = divparts + (row >> 5) * kDivGroups * 32 + (row & 31);
+  float s = 0.0f;
+  for (int g = 0; g < kDivGroups; ++g) s += p[g * 32];
+  rnd[row] += s;
+}
+
+inline size_t bridge_wide_lds_bytes(const WsLayout& L, const WsLayout& L2) {
+  const int rows = L.c > 32 * L.otd ? L.c : 32 * L.otd;
+  return ((size_t)rows * 32 + (size_t)(L2.n_hidden + 1) * L.c * 32 + kWideSlots * 4 * 32 + 4 * 8 * 32 + 4 * 2 * L.c + 3 * (2 * L.dp + 4) +
+          (L.n_hidden + L2.n_hidden) * L.c + 64 * L.otd) * sizeof(float);
+}
+
+long long bridge_wide_scratch_floats(long long batch) { return ((batch + 31) / 32) * kDivGroups * 32; }
+
+template <int OTW>
+static int launch_bridge_wide_t(const TrajArgs& a, hipStream_t stream, int split, float* scratch) {
+  const size_t lds_bytes = bridge_wide_lds_bytes(a.lay, a.lay2);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  static bool attr_done[kMaxDevices] = {};
+  bool& attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_wide_kernel<OTW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  const long long tiles = (a.batch + 31) / 32;
+  hipLaunchKernelGGL((bridge_wide_kernel<OTW>), dim3((unsigned)(tiles * split)), dim3(256), lds_bytes, stream, a, split, scratch);
+  hipLaunchKernelGGL(bridge_wide_finish, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a.rnd, scratch, a.batch);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+// split: workgroups per column tile of 32 trajectories (1, 2, 4, 8): enough of them to occupy the 256 CUs
+int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used, float* scratch) {
+  const char* force = getenv("SDEH_WIDE_SPLIT");  // testing aid: "1" | "2" | "4" | "8"
+  const long long tiles = (a.batch + 31) / 32;
+  int split = 1;
+  while (split < 8 && tiles * split < 256) split *= 2;
+  if (force != nullptr && (force[0] == '1' || force[0] == '2' || force[0] == '4' || force[0] == '8')) split = force[0] - '0';
+  if (split_used != nullptr) *split_used = split;
+  const int otw = a.lay.c / 128;
+  if (otw == 2) return launch_bridge_wide_t<2>(a, stream, split, scratch);
+  if (otw == 1) return launch_bridge_wide_t<1>(a, stream, split, scratch);
   return SDEH_ERR_UNSUPPORTED;
 }
 

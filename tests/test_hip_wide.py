@@ -124,3 +124,72 @@ def test_wide_training_and_mixture_targets_fail_loudly():
     gm = problems.build(spec, device=DEV)
     with pytest.raises(SdehUnsupported, match="mixture"):
         gm.eval(gm.prior.sample((64,)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Bridge on wide networks (bridge_wide_kernel): exact divergence of the inference control, configs[4] geometry
+# ---------------------------------------------------------------------------------------------------------------------------
+class _split:
+    def __init__(self, n):
+        self.n = n
+
+    def __enter__(self):
+        if self.n:
+            os.environ["SDEH_WIDE_SPLIT"] = str(self.n)
+
+    def __exit__(self, *a):
+        os.environ.pop("SDEH_WIDE_SPLIT", None)
+
+
+def _bridge(path):
+    from sde_sampler_amd import problems
+
+    fx, meta, params, tt = load_fixture(path)
+    prob = problems.build(meta, params, tt, device=DEV, params_inf=inference_params(fx))
+    return fx, meta, prob
+
+
+@pytest.mark.parametrize("split", [1, 4])
+@pytest.mark.parametrize("path", GOLDEN_WIDE_BRIDGE, ids=lambda p: Path(p).stem)
+def test_wide_bridge_eval_matches_reference_golden(path, split):
+    fx, meta, prob = _bridge(path)
+    x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
+    with _split(split):
+        r1 = prob.eval(x0, compute_weights=True, noise=noise)
+        assert prob.loss.engine.last_kernel_name() == f"bridge_wide<C={meta['net']['channels']},split={split}>"
+        r2 = prob.eval(x0, compute_weights=False, noise=noise)
+        with torch.no_grad():
+            _, rnd, xs = prob.loss.simulate(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, train=False,
+                                            compute_ito_int=False, return_traj=True, noise=noise)
+    _rows("x_T", r1.samples.cpu().numpy(), fx["eval1/x_T"], max_tol=2e-3)
+    # the divergence sums d Jacobian entries of magnitude O(1) per step, accumulated over T steps into rnd
+    _rows("rnd", rnd.cpu().numpy(), fx["eval2/rnd"], max_tol=1e-3, med_tol=1e-4)
+    scale = max(1.0, float(np.abs(fx["eval1/rnd"]).max()))
+    assert abs(r1.log_norm_const_preds["log_norm_const_is"] - float(fx["eval1/log_norm_const_is"])) <= 1e-4 * scale
+    assert abs(r1.log_norm_const_preds["log_norm_const_lb_ito"] - float(fx["eval1/log_norm_const_lb_ito"])) <= 1e-4 * scale
+    assert abs(r2.log_norm_const_preds["log_norm_const_lb"] - float(fx["eval2/log_norm_const_lb"])) <= 1e-4 * scale
+    assert xs.shape == (prob.ts.numel(), *x0.shape) and torch.equal(xs[-1], r1.samples)
+
+
+@pytest.mark.parametrize("path", GOLDEN_WIDE_BRIDGE, ids=lambda p: Path(p).stem)
+def test_wide_bridge_is_invariant_to_the_workgroup_split_and_to_sharding(path):
+    """1, 2, 4 or 8 workgroups per column tile add the same 32 coordinate-group sums in the same order: bitwise equal results;
+    two shards with row offsets == one launch."""
+    fx, meta, prob = _bridge(path)
+    torch.manual_seed(3)
+    B = 80
+    x0 = prob.prior.sample((B,)).to(DEV)
+    eng = prob.loss.engine
+    out = {}
+    for split in (1, 2, 8):
+        with _split(split):
+            eng.calls, prob.loss.row_offset = 5, 0
+            out[split] = prob.eval(x0, compute_weights=True)
+    for split in (2, 8):
+        assert torch.equal(out[1].samples, out[split].samples) and torch.equal(out[1].weights, out[split].weights), split
+    eng.calls, prob.loss.row_offset = 5, 0
+    a = prob.eval(x0[:32], compute_weights=False)
+    eng.calls, prob.loss.row_offset = 5, 32
+    b = prob.eval(x0[32:], compute_weights=False)
+    assert torch.equal(torch.cat([a.samples, b.samples]), out[1].samples)
+    assert torch.isfinite(out[1].weights).all()

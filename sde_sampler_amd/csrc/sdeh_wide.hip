@@ -742,7 +742,10 @@ static int launch_wide_t(const TrajArgs& a, hipStream_t stream) {
 // a launch needs >= 256 workgroups to use every CU: below 16 384 trajectories the 32-trajectory form fills more CUs.
 int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used) {
   const char* force = getenv("SDEH_WIDE_CT");  // testing aid: "1" | "2" (read per call)
-  int ct = a.batch >= 128 * 256 ? 4 : (a.batch > 32 * 256 ? 2 : 1);
+  // (128 trajectories per workgroup -- CT = 4, one plane -- would quarter the operand loads per MFMA, but the state and the network
+  // output of 128 trajectories do not fit the wave's registers next to the elementwise phase: it spills and measures 36.7 ms against
+  // 29.6 ms for CT = 2 at B = 32 768; it stays available through SDEH_WIDE_CT=4 for experiments)
+  int ct = a.batch > 32 * 256 ? 2 : 1;
   if (force != nullptr && (force[0] == '1' || force[0] == '2' || force[0] == '4')) ct = force[0] - '0';
   if (ct_used != nullptr) *ct_used = ct;
   const int otw = a.lay.c / 128;

@@ -17,6 +17,9 @@ N_CASES = 96 * _SCALE
 N_TRAIN = 32 * _SCALE
 N_BRIDGE = 24 * _SCALE
 N_INT = 32 * _SCALE
+#: largest fraction of the rows of a case that may still differ by more than 2e-3 x scale AFTER the oracle's own response to a
+#: one-in-a-million perturbation of the inputs has been subtracted (set from the observed distribution, profiles/r02_fuzz_drift.txt)
+DRIFT_MAX = float(os.environ.get("SDEH_FUZZ_DRIFT_MAX", "0.25"))
 
 
 def random_spec(rng: np.random.Generator) -> dict:
@@ -133,7 +136,11 @@ def test_random_problem_matches_oracle(case):
     row_err = (row_err - cond_rows).clamp_min(0.0)  # beyond what the conditioning of the row explains
     assert row_err.median().item() <= 1e-4 * scale, f"{tag}: median row error {row_err.median().item():.3e} (scale {scale:.2f})"
     drifted = (row_err > 2e-3 * scale).float().mean().item()
-    assert drifted <= 0.25, f"{tag}: {drifted:.0%} of the rows differ by more than {2e-3 * scale:.1e}"
+    if os.environ.get("SDEH_FUZZ_REPORT"):  # observed distribution of the criteria (profiles/r02_fuzz_drift.txt)
+        with open(os.environ["SDEH_FUZZ_REPORT"], "a") as fh:
+            fh.write(f"{case} B={B} T={T} d={d} median={row_err.median().item() / scale:.3e} max={row_err.max().item() / scale:.3e} "
+                     f"drifted={drifted:.4f} n_drifted={int((row_err > 2e-3 * scale).sum())}\n")
+    assert drifted <= DRIFT_MAX, f"{tag}: {drifted:.0%} of the rows differ by more than {2e-3 * scale:.1e}"
     assert (out.xs[0].cpu() == ref["xs"][0]).all()  # the initial state is passed through
     key = "log_norm_const_lb_ito" if weights else "log_norm_const_lb"
     got, want = out.log_norm_const_preds[key], ref[key]

@@ -4,7 +4,8 @@
 Tolerances (fp32, parity mode; SURVEY.md 8d / section 0.6: even re-associating one product in the reference
 itself moves x_T by 5.8e-3 after 100 steps because the dynamics amplify 1-ulp changes):
   per-row x_T, rnd : median |d| <= 1e-4 (x scale), max |d| <= 1e-2 (+1e-4 relative for large-magnitude rnd)
-  estimators       : |d| <= 1e-3 * max(1, |value|) at the fixtures' small batch sizes
+  estimators       : |d| <= 1e-4 absolute, SURVEY 8d's bar (4e-6 relative beyond 25: tests/test_hip_contract.py::est_tol, which also
+                     asserts the contract at its own batch size, B = 4096, for every BASELINE configuration)
 """
 import math
 from pathlib import Path
@@ -29,7 +30,9 @@ def _row_check(name, got, ref):
 
 
 def _est_check(name, got, ref):
-    assert abs(got - ref) <= 1e-3 * max(1.0, abs(ref)), f"{name}: {got} vs {ref}"
+    from tests.test_hip_contract import est_tol
+
+    assert abs(got - ref) <= est_tol(ref), f"{name}: {got} vs {ref}"
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
@@ -44,7 +47,7 @@ def test_eval_matches_reference_golden(path):
     _est_check("lb_ito", r1.log_norm_const_preds["log_norm_const_lb_ito"], float(fx["eval1/log_norm_const_lb_ito"]))
     _est_check("logZ_is", r1.log_norm_const_preds["log_norm_const_is"], float(fx["eval1/log_norm_const_is"]))
     lv_ref = float(fx["eval1/lv_loss"])
-    assert abs(r1.metrics["eval/lv_loss"] - lv_ref) <= 2e-3 * max(1.0, abs(lv_ref))
+    assert abs(r1.metrics["eval/lv_loss"] - lv_ref) <= 1e-4 * max(1.0, abs(lv_ref))  # a variance of O(B) rows at fixture size
     w, w_ref = r1.weights.cpu().numpy(), fx["eval1/weights"]
     assert w.shape == w_ref.shape and np.all(np.abs(w - w_ref) <= 2e-2 * np.maximum(w_ref, 1e-3) + 1e-4)
     if want_xs:

@@ -17,7 +17,7 @@ def main(out):
         cols = [d[1] for d in con.execute(f"pragma table_info({view})")]
         namecol = "name" if "name" in cols else ("kernel_name" if "kernel_name" in cols else None)
         rows = con.execute(f"select counter_name, avg(value), count(*) from (select dispatch_id, counter_name, sum(value) as value "
-                           f"from {view} where {namecol} like '%traj%' group by dispatch_id, counter_name) group by counter_name").fetchall()
+                           f"from {view} where ({namecol} like '%traj%' or {namecol} like '%bridge_wide_kernel%') group by dispatch_id, counter_name) group by counter_name").fetchall()
         print(f"# {db.split('/')[-3]}")
         for name, val, n in rows:
             print(f"  {name:34s} {val:20.1f}   (avg over {n} dispatches)")

@@ -33,6 +33,12 @@
 
 namespace sdeh {
 
+// Per-step workgroup barrier that orders LDS traffic only.  __syncthreads() carries a fence for ALL address spaces, i.e. hipcc puts
+// s_waitcnt vmcnt(0) in front of it: the M wave's prefetch of the next step's time embedding (a global load issued between the two
+// barriers of a step), the V wave's xs / plane stores and parity-mode noise loads would all be drained at every barrier.  What the
+// waves exchange lives in LDS (the exchange buffers, the pair mode's activation parking), so lgkmcnt(0) is all a step needs.
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int kWsGroups = 4;  // most trajectory groups (of 64) per workgroup; the launcher picks 4 or 2 (blockDim.x = 128 G)
 
 // rows of the exchange buffer: every coordinate an M-layout register can address
@@ -450,7 +456,7 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
     float* __restrict__ mb = abuf + ((parity * 2 + mw) * 16) * 64 + lane;
 #pragma unroll
     for (int q = 0; q < 16; ++q) mb[q * 64] = mine[q];
-    __syncthreads();
+    ws_barrier();
     const float* __restrict__ ob = abuf + ((parity * 2 + (1 - mw)) * 16) * 64 + lane;
 #pragma unroll
     for (int q = 0; q < 16; ++q) other[q] = ob[q * 64];
@@ -539,15 +545,15 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         float* __restrict__ abuf = xbuf + XR * 64;
         int parity = 0;
         f32x16 emb1 = load16(ws + L.emb + (mw * 2 + h) * 16);
-        __syncthreads();  // barrier A: x_0 published
+        ws_barrier();  // barrier A: x_0 published
         const long long row0 = (long long)blockIdx.x * 32;
         ZStore Z{nullptr, (long long)n_steps * A.batch, (int)(A.batch - row0 < 32 ? A.batch - row0 : 32)};
         for (int i = 0; i < n_steps; ++i) {
           if constexpr (PLANES) Z.base = A.zt_out + (long long)i * A.batch + row0;
           SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, PLANES>(lds, xbuf, abuf, L, emb1, lane, mw, parity, Z););
-          __syncthreads();  // barrier B: network output published
+          ws_barrier();  // barrier B: network output published
           if (i + 1 < n_steps) emb1 = load16(ws + L.emb + (i + 1) * C + (mw * 2 + h) * 16);
-          __syncthreads();  // barrier A: x_{i+1} published
+          ws_barrier();  // barrier A: x_{i+1} published
         }
         return;
       }
@@ -555,7 +561,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     f32x16 emb[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (ot * 2 + h) * 16);
-    __syncthreads();  // barrier A: x_0 published
+    ws_barrier();  // barrier A: x_0 published
     ZStore Z{nullptr, 0, 0};
     long long row0 = 0;
     if constexpr (PLANES) {
@@ -571,12 +577,12 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       SDEH_ACT_SWITCH(act, ACTC,
         if (A.half) ws_mlp_half<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z);
         else ws_mlp<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z););
-      __syncthreads();  // barrier B: network output published
+      ws_barrier();  // barrier B: network output published
       if (i + 1 < n_steps) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (i + 1) * C + (ot * 2 + h) * 16);
       }
-      __syncthreads();  // barrier A: x_{i+1} published
+      ws_barrier();  // barrier A: x_{i+1} published
     }
     return;
   }
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   const bool refc = REFC >= 0 ? REFC != 0 : (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
   const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
-  __syncthreads();  // barrier A: x_0 published
+  ws_barrier();  // barrier A: x_0 published
 
   for (int i = 0; i < n_steps; ++i) {
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 
     // pair mode: the M waves exchange activations at n_hidden + 1 workgroup barriers per step; this wave joins them, spaced
     // through its own work so that it never arrives late (input layer ~0.4 us, then ~1.1 us per layer)
-    if (pair) __syncthreads();
+    if (pair) ws_barrier();
     // ---- score term of the control (needs x only; runs while the M wave evaluates the network) -----------
     float sterm[DP];
     if (ctrl_kind != SDEH_CTRL_CLIPPED) {
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     }
     SDEH_FENCE();
 
-    if (pair && L.n_hidden >= 1) __syncthreads();
+    if (pair && L.n_hidden >= 1) ws_barrier();
     // ---- Gaussian draws (independent of the control) --------------------------------------------------------
     float xi[DP];
     if (noise != nullptr) {
@@ -693,7 +699,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     }
 
     if (pair)
-      for (int k = 2; k <= L.n_hidden; ++k) __syncthreads();
+      for (int k = 2; k <= L.n_hidden; ++k) ws_barrier();
     // exponential integrator (oc.py:428-443):  x <- x a_k + (b_k^2 s^2) u + (s b_k) xi
     // Euler-Maruyama (oc.py:213-219, 325-331): x <- x + (f x + sig u) dt + sig (xi sqrt(dt))
     const bool expo = loss_kind == SDEH_LOSS_EXPONENTIAL;
@@ -712,7 +718,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j) x[j] = fmaf(c_n, xi[j], c_x * x[j]);
     SDEH_FENCE();
 
-    __syncthreads();  // barrier B: the M wave has published the network output
+    ws_barrier();  // barrier B: the M wave has published the network output
     // ---- u = clip(nn) + score term; publish x_{i+1} first: the M wave is idle until barrier A ------------------------
     float u[DP];
 #pragma unroll
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       if (PAD) x[j] = j < d ? x[j] : 0.0f;
       xbuf[j * 64 + lane] = x[j];
     }
-    __syncthreads();  // barrier A: x_{i+1} published
+    ws_barrier();  // barrier A: x_{i+1} published
     // ---- running cost (losses/oc.py:204-211, 319-323, 418-431) and Ito term, in the shadow of the next network pass -----
     float cost = 0.0f;
     if (!refc) {

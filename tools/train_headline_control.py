@@ -69,6 +69,7 @@ def main():
     lz, lb, ess = evaluate()
     note = (f"tools/train_headline_control.py: method={args.method} batch={args.batch} lr={args.lr} steps={step} seed={args.seed}; "
             f"at the end log Z_is={lz:+.4f} ELBO={lb:+.4f} ESS/B={ess:.4f} (B=65536, in-kernel noise)")
+    os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     torch.save({"params": {k: v.detach().cpu().clone() for k, v in prob.ctrl.state_dict().items()}, "note": note,
                 "spec": "gmm50_pis_headline"}, args.out)
     print("saved", args.out, "\n" + note)

@@ -19,7 +19,10 @@ N_BRIDGE = 24 * _SCALE
 N_INT = 32 * _SCALE
 #: largest fraction of the rows of a case that may still differ by more than 2e-3 x scale AFTER the oracle's own response to a
 #: one-in-a-million perturbation of the inputs has been subtracted (set from the observed distribution, profiles/r02_fuzz_drift.txt)
-DRIFT_MAX = float(os.environ.get("SDEH_FUZZ_DRIFT_MAX", "0.25"))
+#: Observed over 1532 cases (SDEH_FUZZ_SCALE=16): 1523 have no such row at all, 7 have <= 2 %, two small-batch cases with stiff clamped
+#: wells have 11 % and 18 % under the three standard probes -- those are re-examined with eight more probes before the verdict.
+DRIFT_MAX = float(os.environ.get("SDEH_FUZZ_DRIFT_MAX", "0.05"))
+_MORE_PERTS = (2e-6, -2e-6, -4e-6, 8e-6, -8e-6, 5e-7, -5e-7, 1.6e-5)
 
 
 def random_spec(rng: np.random.Generator) -> dict:
@@ -133,13 +136,27 @@ def test_random_problem_matches_oracle(case):
     # case) -- so the bulk of the rows must agree tightly and only a minority may have drifted.
     scale = max(1.0, float(torch.nan_to_num(ref["xs"], nan=0.0, posinf=0.0, neginf=0.0).abs().max()))
     row_err = torch.nan_to_num((out.xs.cpu() - ref["xs"]).abs().amax(dim=(0, 2)), nan=0.0, posinf=0.0)  # non-finite rows: see estimators
-    row_err = (row_err - cond_rows).clamp_min(0.0)  # beyond what the conditioning of the row explains
+    raw_err = row_err
+    row_err = (raw_err - cond_rows).clamp_min(0.0)  # beyond what the conditioning of the row explains
     assert row_err.median().item() <= 1e-4 * scale, f"{tag}: median row error {row_err.median().item():.3e} (scale {scale:.2f})"
-    drifted = (row_err > 2e-3 * scale).float().mean().item()
+
+    def drift(cond):
+        # rows whose REFERENCE trajectory moves by more than 5 % of the state scale under a one-in-a-million perturbation are
+        # chaotic in the reference itself (case 432: a stiff double well under the exponential integrator, differences grow from 1e-6
+        # to the size of the attractor within 20 steps, for the perturbed oracle exactly as for the kernel): subtracting two O(scale)
+        # numbers says nothing, such rows are not counted either way
+        chaotic = cond >= 0.05 * scale
+        return ((((raw_err - cond).clamp_min(0.0) > 2e-3 * scale) & ~chaotic).float().mean().item(), int(chaotic.sum()))
+
+    drifted, n_chaotic = drift(cond_rows)
+    if drifted > DRIFT_MAX:  # three probes under-estimate the conditioning of a discontinuous (clamped) map: look again with eight more
+        more = [oracle.eval(ts, *_perturbed(x0, noise, eps), compute_weights=weights, return_traj=True) for eps in _MORE_PERTS]
+        cond_more = torch.stack([torch.nan_to_num((q["xs"] - ref["xs"]).abs().amax(dim=(0, 2)), nan=math.inf) for q in more]).amax(dim=0)
+        drifted, n_chaotic = drift(torch.maximum(cond_rows, cond_more))
     if os.environ.get("SDEH_FUZZ_REPORT"):  # observed distribution of the criteria (profiles/r02_fuzz_drift.txt)
         with open(os.environ["SDEH_FUZZ_REPORT"], "a") as fh:
             fh.write(f"{case} B={B} T={T} d={d} median={row_err.median().item() / scale:.3e} max={row_err.max().item() / scale:.3e} "
-                     f"drifted={drifted:.4f} n_drifted={int((row_err > 2e-3 * scale).sum())}\n")
+                     f"drifted={drifted:.4f} chaotic_rows={n_chaotic}\n")
     assert drifted <= DRIFT_MAX, f"{tag}: {drifted:.0%} of the rows differ by more than {2e-3 * scale:.1e}"
     assert (out.xs[0].cpu() == ref["xs"][0]).all()  # the initial state is passed through
     key = "log_norm_const_lb_ito" if weights else "log_norm_const_lb"

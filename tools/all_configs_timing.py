@@ -28,7 +28,11 @@ for name, spec in problems.BASELINE_SPECS.items():
     assert torch.equal(a.samples, b.samples) and torch.equal(a.weights, b.weights), name
     assert torch.isfinite(a.samples).all(), name
     k = 40 if spec["target"]["kind"] == "gmm" else 0
-    f = flops(d, 64, 2, k, k == 0)
+    if spec["net"]["channels"] > 64:  # wide-network workloads: bench.py's count (network + Bridge divergence)
+        import bench
+        f = bench.algorithmic_flops(spec)
+    else:
+        f = flops(d, 64, 2, k, k == 0)
     best = min(ms[8:])
     print(f"{name:22s} B={B:6d} T={T:4d} d={d:3d}  kernel {best:8.3f} ms  {B * T / best / 1e6:8.3f} G traj-steps/s  "
           f"{f * B * T / best / 1e9:7.1f} TFLOP/s (F={f})  logZ_is={a.log_norm_const_preds['log_norm_const_is']:+.4f} "

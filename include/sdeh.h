@@ -175,8 +175,9 @@ typedef struct {
 } SdehProblem;
 
 typedef struct {
-  int32_t dim;         /* d:  <= 64 with channels = 64;  <= 256 with channels = 128 / 256 (evaluation-only "wide" kernels:
-                          Gaussian / double-well / funnel targets, inference networks with <= 2 hidden layers) */
+  int32_t dim;         /* d <= 64 with channels = 64: every entry point.  d <= 256 with channels = 128 / 256, and 64 < d <= 256 with
+                          channels = 64: the evaluation-only "wide" kernels (sdeh_simulate_fwd; a Bridge needs channels >= 128, a
+                          closed-form target and an inference network with <= 2 hidden layers) */
   int32_t channels;    /* C: 64, 128 or 256 */
   int32_t max_hidden;  /* largest n_hidden of base_model */
   int32_t max_steps;   /* largest T = len(ts)-1 */

@@ -172,7 +172,7 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
 }
 
 // Workspace layout of a wide network (C in {128, 256}, d <= 256; sdeh_wide.hip): everything lives in global memory.
-static WsLayout make_wide_layout(int d, int c, int n_hidden, int t_max, int g, bool with_tan) {
+static WsLayout make_wide_layout(int d, int c, int n_hidden, int t_max, int g, bool with_tan, int k_max = 0) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.wide = 1;
@@ -200,6 +200,11 @@ static WsLayout make_wide_layout(int d, int c, int n_hidden, int t_max, int g, b
   L.gam = o; o += align4(t_max * g);
   L.out_cnt = o; o += align4(t_max + 1);
   for (int i = 0; i < 3; ++i) { L.dg[i] = o; o += align4(2 * L.dp + 1); }
+  // mixture target: mu[K][d4], a = 1/(2 sigma^2) [K][d4] (rows padded to four coordinates with zeros), c[K]
+  L.k_max = k_max; L.gmm_lds = 0; L.gmm_row = align4(d); L.gmm_rows = k_max;
+  L.gmm_lg = o; o += k_max * L.gmm_row;
+  L.gmm_sc = o; o += k_max * L.gmm_row;
+  L.gmm_c = o; o += align4(k_max);
   L.total = align4(o);
   return L;
 }
@@ -233,7 +238,8 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   if (desc == nullptr || out == nullptr) return fail(SDEH_ERR_INVALID, "plan_create: null argument");
   *out = nullptr;
   if (desc->dim < 1) return fail(SDEH_ERR_INVALID, "plan_create: dim=%d", desc->dim);
-  const bool wide = desc->channels == 128 || desc->channels == 256;
+  // wide-network kernels: 128 / 256 channels at any d <= 256, and 64 channels once the state no longer fits the d <= 64 kernels
+  const bool wide = desc->channels == 128 || desc->channels == 256 || (desc->channels == 64 && desc->dim > 64 && desc->dim <= 256);
   if (desc->channels != 64 && !wide)
     return fail(SDEH_ERR_UNSUPPORTED, "plan_create: channels=%d (trajectory kernels are compiled for C = 64, 128 and 256)",
                 desc->channels);
@@ -246,12 +252,11 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   if (wide) {
     if (desc->dim > 256) return fail(SDEH_ERR_UNSUPPORTED, "plan_create: dim=%d (the wide-network kernels cover d <= 256)", desc->dim);
     // two regions (generative + inference network of a Bridge), each with the tangent tables / transposed hidden layers
-    ws_floats = 2 * (size_t)make_wide_layout(desc->dim, desc->channels, desc->max_hidden, desc->max_steps, 32 * row_tiles(desc->dim), true).total + 64;
+    ws_floats = 2 * (size_t)make_wide_layout(desc->dim, desc->channels, desc->max_hidden, desc->max_steps, 32 * row_tiles(desc->dim), true, k_max).total + 64;
   } else {
     v = pick_variant(desc->dim);
     if (v == nullptr)
-      return fail(SDEH_ERR_UNSUPPORTED, "plan_create: no trajectory kernel compiled for dim=%d with channels=64 (d <= 64; wider "
-                                        "states need channels 128 or 256)", desc->dim);
+      return fail(SDEH_ERR_UNSUPPORTED, "plan_create: no trajectory kernel compiled for dim=%d with channels=64", desc->dim);
     WsLayout L = make_layout(v->dp, desc->channels, desc->max_hidden, desc->max_steps, k_max, v->dp);
     // LDS: the wave-specialised kernel needs image + exchange buffers, the single-wave kernel image + logit scratch;
     // a plan is usable when either fits (deep networks fall back to the single-wave kernel at launch time)
@@ -433,11 +438,13 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     if (backward || integrate)
       return fail(SDEH_ERR_UNSUPPORTED, "networks with %d channels are evaluated by the wide-network kernels, which have no "
                                         "backward pass / plain integrator (channels = 64 has)", net.channels);
-    if (need_target && pr->target.kind == SDEH_DENS_GMM)
-      return fail(SDEH_ERR_UNSUPPORTED, "wide-network kernels: mixture targets are not built in (Gaussian, double-well and funnel targets are)");
-    out->L = make_wide_layout(d, net.channels, net.n_hidden, n_steps, g, false);
+    if (need_target && pr->target.kind == SDEH_DENS_GMM && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
+      return fail(SDEH_ERR_UNSUPPORTED, "wide Bridge kernel: mixture targets are not built in (Gaussian, double-well and funnel targets are)");
+    if ((pr->flags & SDEH_FLAG_INFERENCE_CTRL) && net.channels < 128)
+      return fail(SDEH_ERR_UNSUPPORTED, "Bridge with d > 64 needs channels = 128 or 256 (the wide Bridge kernel splits >= 4 row tiles over its waves)");
+    out->L = make_wide_layout(d, net.channels, net.n_hidden, n_steps, g, false, need_target && pr->target.kind == SDEH_DENS_GMM ? k : 0);
     if ((size_t)out->L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd: workspace too small");
-    out->v = nullptr; out->refc = refc; out->g = g; out->k = 0;
+    out->v = nullptr; out->refc = refc; out->g = g; out->k = k;
     return SDEH_OK;
   }
   const Variant* v = plan->variant;
@@ -638,7 +645,8 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   rc = bridge ? launch_bridge_wide(A, st, &detail, plan->scratch) : launch_wide(A, st, &detail);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
   snprintf(plan->last_kernel, sizeof(plan->last_kernel), bridge ? "bridge_wide<C=%d,split=%d>" : "traj_wide<C=%d,CT=%d>", net.channels, detail);
-  if (rc == SDEH_ERR_UNSUPPORTED) return fail(rc, "simulate_fwd (wide): the problem needs more than 160 KiB of LDS (d=%d, C=%d)", d, net.channels);
+  if (rc == SDEH_ERR_UNSUPPORTED)
+    return fail(rc, "simulate_fwd (wide): the problem needs more than 160 KiB of LDS (d=%d, C=%d, K=%d mixture components)", d, net.channels, ck.k);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "simulate_fwd (wide): kernel launch failed");
 }
 

@@ -251,7 +251,27 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
   }  // ctrl_kind != NONE
 
   // GMM tables (distr/gauss.py:123-135 via torch.distributions.MixtureSameFamily)
-  if (pr.target.kind == SDEH_DENS_GMM) {
+  if (pr.target.kind == SDEH_DENS_GMM && L.wide) {
+    if (L.k_max > 0) {  // wide kernels: mu[K][d4], a = 1 / (2 sigma^2) [K][d4] (zero beyond d), c[K]
+      const SdehDensity& G = pr.target;
+      const int K = G.n_components, rs = L.gmm_row;
+      for (int e = gid; e < K * rs; e += stride) {
+        const int k = e / rs, j = e % rs;
+        const bool ok = j < G.dim;
+        const float sg = ok ? G.scale[(size_t)k * G.dim + j] : 1.0f;
+        ws[L.gmm_lg + e] = ok ? G.loc[(size_t)k * G.dim + j] : 0.0f;
+        ws[L.gmm_sc + e] = ok ? 0.5f / (sg * sg) : 0.0f;
+      }
+      for (int k = gid; k < K; k += stride) {
+        float wsum = 0.0f;
+        if (G.mixture_weights != nullptr)
+          for (int q = 0; q < K; ++q) wsum += G.mixture_weights[q];
+        float c = G.mixture_weights != nullptr ? logf(G.mixture_weights[k]) - logf(wsum) : 0.0f;
+        for (int j = 0; j < G.dim; ++j) c -= logf(G.scale[(size_t)k * G.dim + j]) + 0.91893853320467274178f;
+        ws[L.gmm_c + k] = c;
+      }
+    }
+  } else if (pr.target.kind == SDEH_DENS_GMM) {
     const SdehDensity& G = pr.target;
     const int K = G.n_components;
     const int K2 = L.gmm_rows;  // K rounded up to a multiple of 8; padding rows have logit -inf

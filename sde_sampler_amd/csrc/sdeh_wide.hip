@@ -196,10 +196,15 @@ __device__ __forceinline__ int wide_mlp(const WideCtx& cx, const float* __restri
   const int plane = C * RS;  // floats per act' plane
   f32x16 acc[OTW][CT];
   unsigned voff[OTW], voff_o[2];  // byte offsets of (tile w + 4 k, lane) inside a k-group
+  const int wh = w & (OT - 1);  // hidden-layer tile of this wave (OT = 2, 4 or 8: waves 2, 3 of a 64-channel network double 0, 1)
 #pragma unroll
-  for (int k = 0; k < OTW; ++k) voff[k] = (unsigned)(((w + 4 * k) * 64 + cx.lane) * 16);
+  for (int k = 0; k < OTW; ++k) voff[k] = (unsigned)(((wh + 4 * k) * 64 + cx.lane) * 16);
   voff_o[0] = (unsigned)((w * 64 + cx.lane) * 16);
   voff_o[1] = nto > 1 ? (unsigned)(((w + 4) * 64 + cx.lane) * 16) : voff_o[0];
+  // C = 64 (two row tiles per layer, d > 64): waves 2 and 3 own no hidden tile.  They run the SAME instruction stream on a tile of
+  // waves 0 / 1 and only skip the store: the hand-issued operand loads must not sit behind control flow (at a merge point hipcc
+  // copies their destination registers -- before the data has landed: measured, every result off by 1e-2).
+  const bool has = w < OT;
   wide_layer<OTW, CT>(pre_in, ws + L.w_in, OT * 256, L.dp8 / 8, voff, cx.plane(p) + h * RS + j, RS, acc);
   int q = single ? 0 : 1 - p;
   WidePre<OTW> pre_h;
@@ -210,9 +215,9 @@ __device__ __forceinline__ int wide_mlp(const WideCtx& cx, const float* __restri
     else wide_prefetch<2>(pre_o, ws + L.w_out, L.otd * 256, C / 8, voff_o);
     f32x16 bias[OTW];
 #pragma unroll
-    for (int k = 0; k < OTW; ++k) bias[k] = l == 0 ? emb[k] : load16(bias_lds + (l - 1) * C + ((w + 4 * k) * 2 + h) * 16);
+    for (int k = 0; k < OTW; ++k) bias[k] = l == 0 ? emb[k] : load16(bias_lds + (l - 1) * C + ((wh + 4 * k) * 2 + h) * 16);
     if (single) wide_barrier();  // everyone has read the plane that is about to be overwritten
-    wide_act_store<OTW, CT, DSTORE>(acc, bias, act, cx.plane(q) + j, DSTORE ? dplanes + l * plane + j : nullptr, RS, w, h);
+    if (has) wide_act_store<OTW, CT, DSTORE>(acc, bias, act, cx.plane(q) + j, DSTORE ? dplanes + l * plane + j : nullptr, RS, wh, h);
     wide_barrier();
     if (l == L.n_hidden) break;
     wide_layer<OTW, CT>(pre_h, ws + L.w_hid + l * L.w_hid_stride, OT * 256, C / 8, voff, cx.plane(q) + h * RS + j, RS, acc);
@@ -342,6 +347,105 @@ __device__ __forceinline__ float wide_target_score(const DensArgs& D, const floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Mixture targets (distr/gauss.py:123-140 via torch.distributions.MixtureSameFamily) in the accumulator layout.
+//   log p(x) = logsumexp_k( c_k - sum_c a_kc (x_c - mu_kc)^2 ),  a = 1 / (2 sigma^2),  c_k = log w~_k - sum_c (log sigma_kc + log sqrt(2 pi))
+//   score_c  = sum_k r_k (mu_kc - x_c) 2 a_kc,  r = softmax_k(...)         (what the reference obtains by autograd, distr/base.py:130-137)
+// The tables mu[K][d4], a[K][d4] live in LDS.  Each wave forms the partial logits of its own coordinates when it publishes a new
+// state ([wave][k][trajectory]); after the publish barrier wave 0 adds the four partials, normalises (online max / sum) and leaves
+// the responsibilities r[k][trajectory] for everyone; the elementwise phase then accumulates the score of its coordinates.
+// ---------------------------------------------------------------------------------------------------------
+struct WideGmm {
+  const float* mu;   // LDS [K][d4]
+  const float* a;    // LDS [K][d4]
+  const float* ck;   // LDS [K]
+  float* part;       // LDS [4][K][RS]
+  float* resp;       // LDS [K][RS]
+  float* lse;        // LDS [RS]: logsumexp of the published state (terminal log-density)
+  int K, d4;
+};
+
+template <int CT>
+__device__ __forceinline__ void wide_gmm_partials(const WideCtx& cx, const WideGmm& G, const f32x16 (&xr)[2][CT], int nto) {
+  const int w = cx.wave, h = cx.h, j = cx.j, RS = cx.RS;
+  for (int k = 0; k < G.K; ++k) {
+    float acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+      if (kk < nto) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int cb = 32 * (w + 4 * kk) + 8 * g4 + 4 * h;
+          if (cb < cx.d) {  // d4 >= cb + 4: rows are padded to a multiple of four coordinates (mu = 0, a = 0 there; x is 0)
+            const float4 m4 = *reinterpret_cast<const float4*>(G.mu + k * G.d4 + cb);
+            const float4 a4 = *reinterpret_cast<const float4*>(G.a + k * G.d4 + cb);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+              const float t0 = xr[kk][c][4 * g4] - m4.x, t1 = xr[kk][c][4 * g4 + 1] - m4.y;
+              const float t2 = xr[kk][c][4 * g4 + 2] - m4.z, t3 = xr[kk][c][4 * g4 + 3] - m4.w;
+              acc[c] = fmaf(t0 * t0, a4.x, acc[c]); acc[c] = fmaf(t1 * t1, a4.y, acc[c]);
+              acc[c] = fmaf(t2 * t2, a4.z, acc[c]); acc[c] = fmaf(t3 * t3, a4.w, acc[c]);
+            }
+          }
+        }
+      }
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const float v = half_sum(acc[c]);
+      if (h == 0) G.part[(w * G.K + k) * RS + 32 * c + j] = v;
+    }
+  }
+}
+
+// wave 0, after the publish barrier: responsibilities and log-density of the published state
+template <int CT>
+__device__ __forceinline__ void wide_gmm_normalise(const WideCtx& cx, const WideGmm& G) {
+  const int RS = cx.RS, j = cx.j, h = cx.h;
+  if (h != 0) return;
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    const int col = 32 * c + j;
+    float m = -INFINITY;
+    for (int k = 0; k < G.K; ++k) {
+      const float* pp = G.part + k * RS + col;
+      const float l = G.ck[k] - (((pp[0] + pp[G.K * RS]) + pp[2 * G.K * RS]) + pp[3 * G.K * RS]);
+      G.resp[k * RS + col] = l;
+      m = fmaxf(m, l);
+    }
+    float z = 0.0f;
+    for (int k = 0; k < G.K; ++k) {
+      const float e = __expf(G.resp[k * RS + col] - m);
+      G.resp[k * RS + col] = e;
+      z += e;
+    }
+    const float iz = 1.0f / z;
+    for (int k = 0; k < G.K; ++k) G.resp[k * RS + col] *= iz;
+    G.lse[col] = m + __logf(z);
+  }
+}
+
+// score of the 16 coordinates of one tile x column tile (coordinate base cb = 32 t + 4 h)
+__device__ __forceinline__ void wide_gmm_score16(const WideCtx& cx, const WideGmm& G, const f32x16& x, int cb, int col, float (&sc)[16]) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) sc[q] = 0.0f;
+  for (int k = 0; k < G.K; ++k) {
+    const float r = G.resp[k * cx.RS + col];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      if (cb + 8 * g4 < cx.d) {
+        const float4 m4 = *reinterpret_cast<const float4*>(G.mu + k * G.d4 + cb + 8 * g4);
+        const float4 a4 = *reinterpret_cast<const float4*>(G.a + k * G.d4 + cb + 8 * g4);
+        sc[4 * g4] = fmaf(r * (a4.x + a4.x), m4.x - x[4 * g4], sc[4 * g4]);
+        sc[4 * g4 + 1] = fmaf(r * (a4.y + a4.y), m4.y - x[4 * g4 + 1], sc[4 * g4 + 1]);
+        sc[4 * g4 + 2] = fmaf(r * (a4.z + a4.z), m4.z - x[4 * g4 + 2], sc[4 * g4 + 2]);
+        sc[4 * g4 + 3] = fmaf(r * (a4.w + a4.w), m4.w - x[4 * g4 + 3], sc[4 * g4 + 3]);
+      }
+    }
+  }
+}
+
 // Score term of a control on 16 registers (one tile x column tile): mult * scale_score * clip(score mix, clip_score) * gamma
 // (reparam.py:56-83 ScoreCtrl, 131-162 LerpCtrl, 166-178 LerpPriorCtrl, 185-197 LerpTargetCtrl); zeros for ClippedCtrl.  The
 // wave-uniform switches (target kind, control kind) sit outside the 16-element loops.  psc: prior score (when need_p).
@@ -351,11 +455,12 @@ struct WideScore {
   DensArgs tgt;
   float wl, mult, scale_score, clip_score, g0;
   int d;
+  const WideGmm* gmm;  // mixture target (null otherwise)
 };
+template <bool GMM = false>
 __device__ __forceinline__ void wide_score_term16(const WideScore& S, const WideCtx& cx, const f32x16& x, int cb, int c, float fs,
                                                   float fx0, float fiv, const float* __restrict__ gam_row, float (&sterm)[16],
                                                   float (&psc)[16]) {
-  (void)c;
   auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
   if (S.need_p) {
 #pragma unroll
@@ -384,6 +489,8 @@ __device__ __forceinline__ void wide_score_term16(const WideScore& S, const Wide
         for (int q = 0; q < 16; ++q) sc[q] = -x[q] * fiv;
         const float s0 = -fx0 / S.tgt.p0 - 0.5f * (float)(S.d - 1) + 0.5f * fs * fiv;
         sc[0] = cb == 0 ? s0 : sc[0];
+      } else if (GMM && S.tgt.kind == SDEH_DENS_GMM) {
+        if constexpr (GMM) wide_gmm_score16(cx, *S.gmm, x, cb, 32 * c + cx.j, sc);
       } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) sc[q] = 0.0f;
@@ -454,7 +561,9 @@ __device__ __forceinline__ void wide_noise16(const float* __restrict__ noise_row
 // ---------------------------------------------------------------------------------------------------------
 // SINGLE: one activation plane instead of two (128 trajectories per workgroup: 4 column tiles x 256 channels x 4 B = 128 KB): a
 // layer's output overwrites its input in place, behind an extra barrier.
-template <int OTW, int CT, bool SINGLE>
+// GMM: the mixture-target code (tables in LDS, partial logits, responsibilities) is compiled in -- a separate instantiation, so that
+// the closed-form targets' kernels carry none of its registers.
+template <int OTW, int CT, bool SINGLE, bool GMM>
 __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WsLayout& L = A.lay;
@@ -481,6 +590,19 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
   float* bias_lds = tabs + 3 * tab_stride;  // hidden biases [n_hidden][C] then the out-layer bias [32 otd] (b_hid and b_out are adjacent)
   for (int i = tid; i < L.n_hidden * C + 32 * OTD; i += 256) bias_lds[i] = ws[L.b_hid + i];
   cx.bias = bias_lds;
+  WideGmm gm;  // mixture target: tables and per-trajectory scratch behind the biases
+  gm.K = GMM && A.target.kind == SDEH_DENS_GMM ? A.target.n_comp : 0;
+  gm.d4 = L.gmm_row;
+  {
+    float* g0p = bias_lds + ((L.n_hidden * C + 32 * OTD + 3) & ~3);
+    float* mu = g0p; float* aa = mu + gm.K * gm.d4; float* ck = aa + gm.K * gm.d4;
+    gm.mu = mu; gm.a = aa; gm.ck = ck;
+    gm.part = ck + ((gm.K + 3) & ~3); gm.resp = gm.part + 4 * gm.K * RS; gm.lse = gm.resp + gm.K * RS;
+    if constexpr (GMM) {
+      for (int i = tid; i < gm.K * gm.d4; i += 256) { mu[i] = ws[L.gmm_lg + i]; aa[i] = ws[L.gmm_sc + i]; }
+      for (int i = tid; i < gm.K; i += 256) ck[i] = ws[L.gmm_c + i];
+    }
+  }
 
   const int nto = (OTD > w ? 1 : 0) + (OTD > w + 4 ? 1 : 0);  // coordinate tiles of this wave: w, w + 4
   const long long row0 = (long long)blockIdx.x * RS;
@@ -526,8 +648,10 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
   __syncthreads();  // tables staged
   int p = 0;
   wide_publish<CT>(cx, cx.plane(p), xr, nto);
+  if constexpr (GMM) wide_gmm_partials<CT>(cx, gm, xr, nto);
   if (flags & SDEH_FLAG_INIT_LOGP) wide_gauss_quad<CT>(cx, cx.tab2, xr, nto, WSL_LOGP_A);
   __syncthreads();  // x_0 published
+  if constexpr (GMM) { if (w == 0) wide_gmm_normalise<CT>(cx, gm); }  // visible to the other waves behind the first layer barrier
   float rnd[CT];  // owned by wave 0, lanes of half 0
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
@@ -536,14 +660,15 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     if (flags & SDEH_FLAG_INIT_LOGP) rnd[c] = cx.tab2[2 * L.dp] - 0.5f * wide_slot_sum(cx, WSL_LOGP_A, 32 * c + j);
   }
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
+  const int wt = w & (L.ot - 1);  // hidden-layer tile of this wave (C = 64: waves 2, 3 double the tiles of waves 0, 1; see wide_mlp)
   unsigned voff_in[OTW];
 #pragma unroll
-  for (int k = 0; k < OTW; ++k) voff_in[k] = (unsigned)(((w + 4 * k) * 64 + lane) * 16);
+  for (int k = 0; k < OTW; ++k) voff_in[k] = (unsigned)(((wt + 4 * k) * 64 + lane) * 16);
   WidePre<OTW> pre_in;
   wide_prefetch<OTW>(pre_in, ws + L.w_in, L.ot * 256, L.dp8 / 8, voff_in);
   f32x16 emb[OTW];  // FourierMLP.timestep_embed(t_i) + input_embed.bias for this wave's channels (added when layer 0 is activated)
 #pragma unroll
-  for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + ((w + 4 * k) * 2 + h) * 16);
+  for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + ((wt + 4 * k) * 2 + h) * 16);
 
   for (int i = 0; i < A.n_steps; ++i) {
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
@@ -586,12 +711,12 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     asm volatile("" : "+v"(hv));
     WideScore sq;
     sq.ctrl_kind = ctrl_kind; sq.g = L.g; sq.need_t = need_t; sq.need_p = need_p; sq.tgt = tgt; sq.wl = wl; sq.mult = mult;
-    sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = g0; sq.d = d;
+    sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = g0; sq.d = d; sq.gmm = &gm;
     auto vtile = [&](f32x16& x, const f32x16& nnv, int t, int c) {
       const int cb = 32 * t + 4 * hv;  // register q <-> coordinate cb + (q & 3) + 8 (q >> 2)
       auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
       float sterm[16], psc[16];
-      wide_score_term16(sq, cx, x, cb, c, fs[c], fx0[c], fiv[c], ws + L.gam + i * L.g, sterm, psc);
+      wide_score_term16<GMM>(sq, cx, x, cb, c, fs[c], fx0[c], fiv[c], ws + L.gam + i * L.g, sterm, psc);
       SDEH_FENCE();
       // ---- Gaussian draws: register group g4 = coordinates cb + 8 g4 .. + 3 = Philox block (cb + 8 g4) / 4 ------------------------
       float n[16];
@@ -659,9 +784,11 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     // the next step's first operands (input layer A groups, time embedding of step i + 1) travel across the publish barrier
     wide_prefetch<OTW>(pre_in, ws + L.w_in, L.ot * 256, L.dp8 / 8, voff_in);
 #pragma unroll
-    for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + (i + 1 < A.n_steps ? i + 1 : i) * C + ((w + 4 * k) * 2 + h) * 16);
+    for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + (i + 1 < A.n_steps ? i + 1 : i) * C + ((wt + 4 * k) * 2 + h) * 16);
     wide_publish<CT>(cx, cx.plane(p), xr, nto);
+    if constexpr (GMM) wide_gmm_partials<CT>(cx, gm, xr, nto);
     wide_barrier();  // x_{i+1}, its statistics and this step's cost partials are visible
+    if constexpr (GMM) { if (w == 0) wide_gmm_normalise<CT>(cx, gm); }
     // ---- running cost (losses/oc.py:204-211, 319-323, 418-431) and Ito term -----------------------------------------------
     if (w == 0) {
 #pragma unroll
@@ -697,6 +824,8 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
           const float first = -0.5f * __logf(6.283185307179586f * tgt.p0) - 0.5f * x0v * x0v / tgt.p0;
           const float other = -(float)(d - 1) * (x0v + 1.8378770664093453f) * 0.5f - 0.5f * sq * __expf(-x0v);
           lp = first + other + tgt.lnc;
+        } else if (GMM && tgt.kind == SDEH_DENS_GMM) {
+          lp = gm.lse[col] + tgt.lnc;  // normalised with the last publish
         }
         r -= clipf(lp, A.clip_target);
       }
@@ -714,27 +843,28 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
       }
 }
 
-inline size_t wide_lds_bytes(const WsLayout& L, int ct, int n_planes) {
+inline size_t wide_lds_bytes(const WsLayout& L, int ct, int n_planes, int K) {
   const int rows = L.c > 32 * L.otd ? L.c : 32 * L.otd;
-  return ((size_t)n_planes * rows * 32 * ct + (size_t)kWideSlots * 4 * 32 * ct + 3 * (2 * L.dp + 4) + L.n_hidden * L.c + 32 * L.otd) *
+  const size_t gmm = K > 0 ? (size_t)2 * K * L.gmm_row + ((K + 3) & ~3) + (size_t)5 * K * 32 * ct + 32 * ct : 0;
+  return ((size_t)n_planes * rows * 32 * ct + (size_t)kWideSlots * 4 * 32 * ct + 3 * (2 * L.dp + 4) + L.n_hidden * L.c + 32 * L.otd + 4 + gmm) *
          sizeof(float);
 }
 
-template <int OTW, int CT>
+template <int OTW, int CT, bool GMM = false>
 static int launch_wide_t(const TrajArgs& a, hipStream_t stream) {
   constexpr bool SINGLE = CT > 2;
-  const size_t lds_bytes = wide_lds_bytes(a.lay, CT, SINGLE ? 1 : 2);
+  const size_t lds_bytes = wide_lds_bytes(a.lay, CT, SINGLE ? 1 : 2, a.target.kind == SDEH_DENS_GMM ? a.target.n_comp : 0);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_wide_kernel<OTW, CT, SINGLE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_wide_kernel<OTW, CT, SINGLE, GMM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
   const unsigned grid = (unsigned)((a.batch + 32 * CT - 1) / (32 * CT));
-  hipLaunchKernelGGL((traj_wide_kernel<OTW, CT, SINGLE>), dim3(grid), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((traj_wide_kernel<OTW, CT, SINGLE, GMM>), dim3(grid), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
@@ -747,8 +877,11 @@ int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used) {
   // 29.6 ms for CT = 2 at B = 32 768; it stays available through SDEH_WIDE_CT=4 for experiments)
   int ct = a.batch > 32 * 256 ? 2 : 1;
   if (force != nullptr && (force[0] == '1' || force[0] == '2' || force[0] == '4')) ct = force[0] - '0';
+  const int K = a.target.kind == SDEH_DENS_GMM ? a.target.n_comp : 0;
+  if (K > 0) ct = 1;  // mixture targets: tables, partial logits and responsibilities take the LDS of the second column tile
   if (ct_used != nullptr) *ct_used = ct;
-  const int otw = a.lay.c / 128;
+  const int otw = a.lay.c == 64 ? 1 : a.lay.c / 128;  // C = 64 (d > 64): one tile per wave, two waves with hidden tiles
+  if (K > 0) return otw == 2 ? launch_wide_t<2, 1, true>(a, stream) : launch_wide_t<1, 1, true>(a, stream);
   if (otw == 2) return ct == 4 ? launch_wide_t<2, 4>(a, stream) : (ct == 2 ? launch_wide_t<2, 2>(a, stream) : launch_wide_t<2, 1>(a, stream));
   if (otw == 1) return ct == 4 ? launch_wide_t<1, 4>(a, stream) : (ct == 2 ? launch_wide_t<1, 2>(a, stream) : launch_wide_t<1, 1>(a, stream));
   return SDEH_ERR_UNSUPPORTED;
@@ -1034,7 +1167,7 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
     WideScore sq;
     sq.ctrl_kind = ctrl_kind; sq.g = L.g; sq.need_t = need_t; sq.need_p = need_p; sq.tgt = tgt; sq.wl = wl;
     sq.mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;
-    sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = as_const(ws + L.gam + i * L.g)[0]; sq.d = d;
+    sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = as_const(ws + L.gam + i * L.g)[0]; sq.d = d; sq.gmm = nullptr;
     const float g20 = as_const(ws2 + L2.gam + i * L2.g)[0];
     float costl = 0.0f, itol = 0.0f, divs = 0.0f;
     auto vtile = [&](f32x16& x, const f32x16& nuv, const f32x16& nvv, int t) {

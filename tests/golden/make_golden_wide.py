@@ -56,6 +56,30 @@ CASES = {
         net=dict(channels=256, num_layers=5, activation="relu"),
         loss=dict(kind="reference_sde", method="kl", max_rnd=None, reference_ctrl="prior_score"),
         grid=dict(start=0.0, end=1.0, steps=10, rescale_t=None)),
+    # mixture targets in the wide kernels: general scales / weights (7 components, d = 100, C = 128) ...
+    "wide_pis_gmm100_c128": dict(
+        B=40, seed=61, target=dict(kind="gmm", dim=100, name="random7"), prior=dict(kind="delta", dim=100),
+        sde=dict(kind="scaled_bm", diff_coeff=math.sqrt(0.2), terminal_t=5.0),
+        ctrl=dict(kind="score", clip_model=1e4, clip_score=1e4, scale_score=1.0, gamma_dim=1, gamma_bias=0.01),
+        net=dict(channels=128, num_layers=4, activation="gelu"),
+        loss=dict(kind="reference_sde", method="kl", max_rnd=None),
+        grid=dict(start=0.0, end=5.0, steps=12, rescale_t=None)),
+    # ... and the reference's own padded 40-mode mixture at d = 72 with the DEFAULT 64 channels (d > 64: two of the four waves hold
+    # the hidden layers' row tiles), basic_dis shape
+    "wide_dis_gmm72_c64": dict(
+        B=36, seed=67, target=dict(kind="gmm", dim=72, name="fab50"), prior=ISO(72),
+        sde=dict(kind="vp", beta_min=0.1, beta_max=8.0, scale=1.0, terminal_t=1.0),
+        ctrl=dict(kind="lerp", clip_model=1e4, clip_score=1e4, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        net=dict(channels=64, num_layers=4, activation="gelu"),
+        loss=dict(kind="time_reversal", method="kl", max_rnd=None),
+        grid=dict(start=0.0, end=1.0, steps=10, rescale_t=None)),
+    # the default 64 channels on a funnel in d = 90 (exponential integrator, lv, clips)
+    "wide_dds_funnel90_c64": dict(
+        B=32, seed=71, target=dict(kind="funnel", dim=90), prior=ISO(90, truncate_quartile=1e-4), sde=None,
+        ctrl=dict(kind="score", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=0.01),
+        net=dict(channels=64, num_layers=4, activation="gelu"),
+        loss=dict(kind="exponential", method="lv", max_rnd=1e8, alpha=1.0, sigma=1.0),
+        grid=dict(start=0.0, end=6.4, steps=12, rescale_t="cosine")),
 }
 
 BRIDGE_CASES = {
@@ -118,6 +142,9 @@ def run_case(name, case):
     out.update(ts=ts.numpy(), x0=x0.numpy(), noise=noise.numpy())
     train_kw = {"train": False} if case["loss"]["kind"] == "time_reversal" else {}
     _eval_passes(out, loss, ts, x0, state, target.unnorm_log_prob, second, train_kw)
+    if case["target"]["kind"] == "gmm":
+        out["target/loc"], out["target/scale"] = target.loc.numpy(), target.scale.numpy()
+        out["target/mixture_weights"] = target.mixture_weights.numpy()
     _finish(name, case, out, ts, x0)
 
 

@@ -44,7 +44,8 @@ def test_wide_eval_matches_reference_golden(path, ct):
     x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
     with _ct(ct):
         r1 = prob.eval(x0, compute_weights=True, return_traj=True, noise=noise)
-        assert prob.loss.engine.last_kernel_name() == f"traj_wide<C={meta['net']['channels']},CT={ct}>"
+        ct_eff = 1 if meta["target"]["kind"] == "gmm" else ct  # mixture targets always run one column tile per workgroup
+        assert prob.loss.engine.last_kernel_name() == f"traj_wide<C={meta['net']['channels']},CT={ct_eff}>"
         r2 = prob.eval(x0, compute_weights=False, return_traj=False, noise=noise)
         with torch.no_grad():
             kw = dict(compute_ito_int=True, return_traj=False, noise=noise)
@@ -111,7 +112,7 @@ def test_wide_fast_mode_agrees_with_oracle_statistics():
     assert 0.8 < float(g.std() / o.std()) < 1.25
 
 
-def test_wide_training_and_mixture_targets_fail_loudly():
+def test_wide_training_fails_loudly_and_wide_mixture_agrees_with_the_narrow_kernels():
     from sde_sampler_amd import SdehUnsupported, problems
 
     fx, meta, params, tt = load_fixture([p for p in GOLDEN_WIDE if "pis_funnel100" in p][0])
@@ -119,11 +120,21 @@ def test_wide_training_and_mixture_targets_fail_loudly():
     x0 = torch.from_numpy(fx["x0"]).to(DEV)
     with pytest.raises(SdehUnsupported, match="evaluation"):
         prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+    # the headline mixture (GMM-40 d=50) through a 128-channel network runs in the wide kernel ...
     spec = problems.baseline_spec("gmm50_pis_headline")
     spec["net"] = dict(spec["net"], channels=128)
     gm = problems.build(spec, device=DEV)
+    out = gm.eval(gm.prior.sample((300,)))
+    assert gm.loss.engine.last_kernel_name() == "traj_wide<C=128,CT=1>" and torch.isfinite(out.samples).all()
+    # ... a Bridge on a mixture with wide networks is refused
+    lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
+    bspec = dict(batch=64, target=dict(kind="gmm", dim=2, name="fab"), prior=dict(kind="iso_gauss", dim=2),
+                 sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0), ctrl=dict(kind="lerp_target", **lerp),
+                 inference_ctrl=dict(kind="lerp_prior", **lerp), net=dict(channels=128, num_layers=4, activation="gelu"),
+                 loss=dict(kind="time_reversal", method="kl"), grid=dict(start=0.0, end=1.0, steps=8))
+    br = problems.build(bspec, device=DEV)
     with pytest.raises(SdehUnsupported, match="mixture"):
-        gm.eval(gm.prior.sample((64,)))
+        br.eval(br.prior.sample((64,)))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDEH_ABI_VERSION 2
+#define SDEH_ABI_VERSION 3
 #define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
 
 typedef enum {
@@ -293,6 +293,41 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const 
                               const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, float* x_T, float* rnd, float* xs, float* gp, const float* div_noise,
                               void* stream);
+
+/*
+ * Fused training backward (csrc/sdeh_bwdf.hip): what `loss.backward()` does in the reference (solver/base.py:407 through the
+ * unrolled loops of losses/oc.py:176-222, 301-334, 416-446) for the control's FourierMLP in ONE kernel -- back-propagation at the
+ * stored trajectory (through time for methods "kl" / "kl_ito") and the weight-gradient contractions, with no [C, n_steps*batch] plane
+ * in device memory.  Compiled for channels = 64, two hidden layers (conf/model/base/fouriermlp.yaml: num_layers 4), d <= 64, no
+ * inference control: sdeh_ctrl_backward_fused_supported says whether a problem qualifies; sdeh_ctrl_backward_ex + sdeh_weight_grad
+ * take the rest.
+ *
+ * sdeh_simulate_fwd_train2 == sdeh_simulate_fwd for a training step (xs required) that also keeps what only the forward launch
+ * knows cheaply:
+ *   sc     [n_steps, batch, d]  the score entering the control before clip_score and gamma(t) (models/reparam.py:56-83,131-197:
+ *                               target score, lerp of prior and target score, ...); NULL for ClippedCtrl
+ *   tscore [batch, d] or NULL   1[|target.unnorm_log_prob(x_T)| <= clip_target] * target.score(x_T)  (needed by "kl" methods
+ *                               with SDEH_FLAG_TERMINAL_TARGET)
+ * Returns 0, or 1 when the launch was served by a kernel that writes neither (then use the plane-based backward).
+ *
+ * sdeh_ctrl_backward_fused: same problem / ts / noise / seed / offset / row_offset as the forward call, grad_rnd [batch] =
+ * d loss / d rnd_i.  `scratch` (sdeh_ctrl_backward_fused_sizes) holds per-team partial gradients, summed deterministically (no
+ * atomics).  `out` (floats, with P = 32 * ceil(d / 32), gw = 2 if gamma(t) is scalar else 64):
+ *   input_embed.weight [64, P] (columns >= d unused) | hidden_layer[l].weight [2][64, 64] | out_layer.weight [P, 64] |
+ *   hidden_layer[l].bias [2][64] | out_layer.bias [P] | d loss / d (timestep_embed(t) + input_embed.bias) [n_steps, 64] |
+ *   d loss / d gamma(t) [n_steps, gw]  (scalar gamma: the sum of the two columns; vector gamma: columns < d)
+ * The two [n_steps, .] tables are the inputs of sdeh_time_embed_backward.
+ */
+int32_t sdeh_simulate_fwd_train2(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
+                                 const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                                 int64_t row_offset, float* x_T, float* rnd, float* xs, float* sc, float* tscore, void* stream);
+int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProblem* problem);
+int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_steps, int64_t batch, int32_t gamma_dim, int32_t bptt,
+                                       int64_t* scratch_floats, int64_t* out_floats);
+int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
+                                 const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                                 int64_t row_offset, const float* grad_rnd, const float* sc, const float* tscore,
+                                 float* scratch, int64_t scratch_floats, float* out, void* stream);
 int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                               const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, const float* grad_rnd, const float* gextra, const float* cost_ctrl,

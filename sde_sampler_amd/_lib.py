@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-SDEH_ABI_VERSION = 2
+SDEH_ABI_VERSION = 3
 SDEH_MAX_HIDDEN = 8
 SDEH_REDUCE_SCRATCH = 8192
 
@@ -121,6 +121,13 @@ PROTOTYPES = {
                                           C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_simulate_fwd_train": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
                                             C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_simulate_fwd_train2": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
+                                             C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_ctrl_backward_fused_supported": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem)]),
+    "sdeh_ctrl_backward_fused_sizes": (C.c_int32, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                                   C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sdeh_ctrl_backward_fused": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64,
+                                             C.c_uint64, C.c_int64, fp, fp, fp, fp, C.c_int64, fp, C.c_void_p]),
     "sdeh_ctrl_backward_ex": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64,
                                           C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_bridge_div_backward": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, fp, fp, fp,

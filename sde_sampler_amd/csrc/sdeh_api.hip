@@ -660,7 +660,7 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
 static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                          float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, float* zt_out, float* nn_out,
-                         bool* planes_written, void* stream) {
+                         bool* planes_written, void* stream, float* sc_out = nullptr, float* tsc_out = nullptr) {
   if (planes_written != nullptr) *planes_written = false;
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
   if ((gp != nullptr || div_noise != nullptr) && (pr == nullptr || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)))
@@ -672,7 +672,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   const int d = net.dim;
   if (plan->wide)
     return simulate_wide(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise,
-                         zt_out != nullptr || nn_out != nullptr);
+                         zt_out != nullptr || nn_out != nullptr || sc_out != nullptr || tsc_out != nullptr);
   if (pr->flags & SDEH_FLAG_INFERENCE_CTRL)
     return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise);
   const WsLayout& L = ck.L;
@@ -712,11 +712,14 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);
   } else {
     A.zt_out = zt_out; A.nn_out = nn_out;  // only the wave-specialised kernel writes the training planes
+    A.sc_out = sc_out; A.tsc_out = tsc_out;
     rc = v->fn(A, st);
-    if (rc == SDEH_OK && planes_written != nullptr) *planes_written = zt_out != nullptr && nn_out != nullptr;
+    if (rc == SDEH_OK && planes_written != nullptr)
+      *planes_written = (zt_out != nullptr && nn_out != nullptr) || sc_out != nullptr || tsc_out != nullptr;
     // image + exchange buffers beyond 160 KiB (deep networks): the single-wave kernel needs less LDS
     if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) {
-      A.zt_out = nullptr; A.nn_out = nullptr;
+      A.zt_out = nullptr; A.nn_out = nullptr; A.sc_out = nullptr; A.tsc_out = nullptr;
+      if (planes_written != nullptr) *planes_written = false;
       rc = plan->variant->fn_legacy(A, st);
       snprintf(plan->last_kernel, sizeof(plan->last_kernel), "traj_legacy<%s>", plan->variant->name);
     }
@@ -744,6 +747,21 @@ int32_t sdeh_simulate_fwd_train(SdehPlan* plan, const SdehProblem* pr, const flo
                                zt, nn, &written, stream);
   if (rc != SDEH_OK) return rc;
   return written ? SDEH_OK : 1;  // 1: integrated by a kernel that keeps no planes -- the backward re-evaluates the network
+}
+
+int32_t sdeh_simulate_fwd_train2(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                                 int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                 float* x_T, float* rnd, float* xs, float* sc, float* tscore, void* stream) {
+  if (xs == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd_train2: xs is required");
+  if (pr != nullptr && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train2: the Bridge forward keeps no planes (use sdeh_simulate_fwd_aux)");
+  if (pr != nullptr && pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_train2: sc is required for controls with a score term");
+  bool written = false;
+  const int rc = simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, nullptr, nullptr,
+                               nullptr, nullptr, &written, stream, sc, tscore);
+  if (rc != SDEH_OK) return rc;
+  return written || (sc == nullptr && tscore == nullptr) ? SDEH_OK : 1;  // 1: integrated by a kernel that writes neither plane
 }
 
 int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
@@ -848,6 +866,105 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   rc = ck.v->fn_bwd(A, st);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward: kernel launch failed");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused training backward (sdeh_bwdf.hip)
+// ---------------------------------------------------------------------------------------------------------
+int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProblem* pr) {
+  if (plan == nullptr || pr == nullptr || plan->wide) return 0;
+  const SdehFourierMLP& net = pr->base_model;
+  if (net.channels != 64 || net.n_hidden != 2 || net.dim < 1 || net.dim > 64) return 0;
+  if (pr->flags & (SDEH_FLAG_INFERENCE_CTRL | SDEH_FLAG_INFERENCE_SDE)) return 0;
+  if (getenv("SDEH_BWD_PLANES") != nullptr) return 0;  // A/B aid: the plane-writing kernels (read per call)
+  const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  if (bptt && (pr->flags & SDEH_FLAG_INIT_LOGP)) return 0;
+  const bool target_jac = bptt && !(pr->flags & (SDEH_FLAG_DETACH_SCORE | SDEH_FLAG_TARGET_SCORE_CONST)) &&
+                          (pr->ctrl_kind == SDEH_CTRL_SCORE || pr->ctrl_kind == SDEH_CTRL_LERP || pr->ctrl_kind == SDEH_CTRL_LERP_TARGET);
+  if (target_jac && pr->target.kind == SDEH_DENS_FUNNEL && net.dim > 32) return 0;  // cross-coordinate sums span two waves
+  return 1;
+}
+
+static void bwdf_sizes(int d, int n_steps, long long batch, int g, bool bptt, long long* wpart, long long* epart, long long* gpart,
+                       long long* sums, long long* out) {
+  const long long tiles = (batch + 31) / 32, slots = bwdf_slots(batch, n_steps, bptt), ws = bwdf_wsize(d);
+  const long long gw = g == 1 ? 2 : 64;
+  *wpart = slots * ws;
+  *epart = tiles * n_steps * 64;
+  *gpart = tiles * n_steps * gw;
+  *sums = ((slots + 31) / 32) * ws + ((tiles + 31) / 32) * n_steps * (64 + gw);
+  *out = ws + (long long)n_steps * (64 + gw);
+}
+
+int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_steps, int64_t batch, int32_t gamma_dim, int32_t bptt,
+                                       int64_t* scratch_floats, int64_t* out_floats) {
+  if (dim < 1 || dim > 64 || n_steps < 1 || batch < 1 || gamma_dim < 1 || scratch_floats == nullptr || out_floats == nullptr)
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_fused_sizes: bad argument");
+  long long w, e, g, s, o;
+  bwdf_sizes(dim, n_steps, batch, gamma_dim == 1 ? 1 : 64, bptt != 0, &w, &e, &g, &s, &o);
+  *scratch_floats = w + e + g + s;
+  *out_floats = o;
+  return SDEH_OK;
+}
+
+int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                 int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                 const float* grad_rnd, const float* sc, const float* tscore, float* scratch,
+                                 int64_t scratch_floats, float* out, void* stream) {
+  if (xs == nullptr || grad_rnd == nullptr || scratch == nullptr || out == nullptr)
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: null argument");
+  Checked ck;
+  int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, false, &ck);
+  if (rc != SDEH_OK) return rc;
+  if (!sdeh_ctrl_backward_fused_supported(plan, pr))
+    return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward_fused: compiled for channels = 64, two hidden layers, d <= 64, no inference control "
+                                      "(sdeh_ctrl_backward_ex + sdeh_weight_grad take the rest)");
+  const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: sc is null");
+  if (bptt && (pr->flags & SDEH_FLAG_TERMINAL_TARGET) && tscore == nullptr)
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: tscore is null (back-propagation through time with a terminal target cost)");
+  const WsLayout& L = ck.L;
+  const SdehFourierMLP& net = pr->base_model;
+  const int d = net.dim;
+  long long n_w, n_e, n_g, n_s, n_o;
+  bwdf_sizes(d, n_steps, batch, L.g == 1 ? 1 : 64, bptt, &n_w, &n_e, &n_g, &n_s, &n_o);
+  if (scratch_floats < n_w + n_e + n_g + n_s) return fail(SDEH_ERR_CAPACITY, "ctrl_backward_fused: scratch too small (%lld < %lld floats)",
+                                                          (long long)scratch_floats, n_w + n_e + n_g + n_s);
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
+  rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "ctrl_backward_fused: prep kernel launch failed");
+  BwdfArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = L;
+  A.w_in = net.input_w; A.w_out = net.out_w; A.b_out = net.out_b;
+  for (int l = 0; l < 2; ++l) { A.w_hid[l] = net.hidden_w[l]; A.b_hid[l] = net.hidden_b[l]; }
+  A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.sc = sc; A.tscore = tscore;
+  A.wpart = scratch; A.epart = scratch + n_w; A.gpart = scratch + n_w + n_e;
+  float* sums = scratch + n_w + n_e + n_g;
+  A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d; A.n_kg = (d + 7) / 8;
+  A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = net.activation;
+  A.g = L.g; A.gw = L.g == 1 ? 2 : 64;
+  A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
+  A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
+  A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
+  A.n_tiles = (int)((batch + 31) / 32); A.n_slots = bwdf_slots(batch, n_steps, bptt); A.wsize = bwdf_wsize(d);
+  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  rc = launch_bwdf(A, st);
+  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused<%s,tiles=%d>", bptt ? "bptt" : "rows", d <= 32 ? 1 : 2);
+  if (rc != SDEH_OK) return fail(rc, "ctrl_backward_fused: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  // deterministic sums over the teams / tiles
+  float* s1 = sums;
+  float* s2 = s1 + ((A.n_slots + 31) / 32) * (long long)A.wsize;
+  rc = launch_partial_sums(A.wpart, 1, A.n_slots, A.wsize, s1, out, st);
+  if (rc == SDEH_OK) rc = launch_partial_sums(A.epart, 1, A.n_tiles, (long long)n_steps * 64, s2, out + A.wsize, st);
+  if (rc == SDEH_OK && pr->ctrl_kind != SDEH_CTRL_CLIPPED)
+    rc = launch_partial_sums(A.gpart, 1, A.n_tiles, (long long)n_steps * A.gw, s2 + ((A.n_tiles + 31) / 32) * (long long)n_steps * 64,
+                             out + A.wsize + (long long)n_steps * 64, st);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward_fused: partial sums failed");
 }
 
 int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, const float* timesteps, int32_t n_steps,

@@ -1,0 +1,546 @@
+// Fused training backward of the control network: back-propagation through the
+// FourierMLP at the stored trajectory AND the weight-gradient contractions in one kernel -- no [C, T*B] planes in HBM.
+//
+// What the reference does here: loss.backward() through the unrolled Python loop of losses/oc.py:176-222 / 301-334 / 416-446
+// (solver/base.py:407), i.e. autograd through T copies of models/mlp.py:114-122 and models/reparam.py:56-83,131-197.  The older
+// path of this library (sdeh_bwd.hpp + sdeh_wgrad.hip) writes the pre-activations Z_k and their adjoints as coordinate-major planes
+// (10 GB at B = 65 536, T = 100) and contracts them in a second pass; this kernel keeps everything on chip:
+//
+//   * a TEAM of two wavefronts owns 32 trajectories (one MFMA column tile); wave r computes row tile r (channels 32r .. 32r+31) of
+//     every layer, forward (re-evaluation at x_t) and backward (transposed weights).  A layer's input is both tiles, so the waves
+//     exchange their halves through LDS planes [row][trajectory] -- one workgroup barrier per layer.
+//   * the SAME planes are the operands of the weight gradients: dW_k += delta_k a_k^T contracts over the trajectories, i.e. both
+//     MFMA operands are the planes read TRANSPOSED (lane = row, 4 consecutive trajectories per ds_read_b128; row stride 36 floats
+//     keeps the reads conflict-free).  The [64, 64] accumulators stay in registers for the whole launch (8 tiles per wave) and are
+//     written once per team; a deterministic two-pass sum over the teams finishes them (launch_partial_sums).
+//   * one natural-layout copy of each weight matrix sits in LDS (row stride 68 floats) and serves both directions: the forward
+//     pass reads rows (lane = output row, ds_read_b128 along k), the backward pass reads columns (lane = output column, four
+//     ds_read_b32 down k) -- half the LDS of the packed forward + transposed images of the older kernels.
+//   * all per-coordinate work (upstream gradient of the control, clip masks, score-term Jacobians, the adjoint lambda_t) runs in
+//     the accumulator layout (lane (j, h), register q  <->  coordinate 32 tile + (q & 3) + 8 (q >> 2) + 4 h of trajectory j), wave r
+//     owning coordinate tile r (d <= 32: both waves mirror tile 0) -- all 64 lanes work, no T-layout shuffles.
+//   * what only the forward launch can know cheaply comes from it (sdeh_simulate_fwd_train2): the combined score entering the control
+//     sc [T, B, d] (before clip and gamma; for mixture targets this is the expensive part) and d(terminal target cost)/dx_T [B, d].
+//
+// Modes: BPTT (method kl / kl_ito: a team walks its 32 trajectories backwards through time carrying lambda_t) and row-parallel
+// (lv / lv_traj: the trajectory is a constant of the graph, (step, tile) items are independent).  The semantics (what is constant,
+// what is differentiated) are those of sdeh_bwd.hpp, which stays the path for Bridges and for networks this kernel is not compiled
+// for (n_hidden != 2).
+#include "sdeh_bwd.hpp"
+
+namespace sdeh {
+
+namespace bwdf {
+
+constexpr int C = 64, LH = 2;
+constexpr int RSW = 68;             // row stride of the [., 64] weight copies: 4 x odd -> conflict-free ds_read_b128 across 16 rows
+constexpr int RS = 36;              // row stride of the exchange planes [row][32 trajectories]
+constexpr int PLANE = 64 * RS;
+constexpr int TABS = 6 * 64;        // (mu, 1/sigma^2) x {prior, second, target}
+template <int OTD> constexpr int rsi() { return OTD == 1 ? 36 : 68; }  // row stride of input_embed.weight [64][d]
+template <int OTD> constexpr int lds_floats() { return 64 * rsi<OTD>() + LH * 64 * RSW + 32 * OTD * RSW + LH * 64 + 64 + TABS + 2 * 4 * PLANE; }
+// partial-gradient record of one team
+template <int OTD> constexpr int off_whid() { return 64 * 32 * OTD; }
+template <int OTD> constexpr int off_wout() { return off_whid<OTD>() + LH * 4096; }
+template <int OTD> constexpr int off_bhid() { return off_wout<OTD>() + 32 * OTD * 64; }
+template <int OTD> constexpr int off_bout() { return off_bhid<OTD>() + LH * 64; }
+template <int OTD> constexpr int wsize() { return off_bout<OTD>() + 32 * OTD; }
+
+__device__ __forceinline__ int rrow(int q) { return (q & 3) + 8 * (q >> 2); }
+
+// accumulator-layout tile <-> plane [row][trajectory]
+__device__ __forceinline__ void plane_put(float* __restrict__ plane, int tile, int j, int h, const f32x16& v) {
+  float* __restrict__ p = plane + (32 * tile + 4 * h) * RS + j;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) p[rrow(q) * RS] = v[q];
+}
+__device__ __forceinline__ f32x16 plane_get(const float* __restrict__ plane, int tile, int j, int h) {
+  const float* __restrict__ p = plane + (32 * tile + 4 * h) * RS + j;
+  f32x16 v;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = p[rrow(q) * RS];
+  return v;
+}
+// transposed read: lane (i, h) gets row 32 tile + i, trajectories 8 c + 4 h .. + 3
+__device__ __forceinline__ float4 plane_getT(const float* __restrict__ plane, int tile, int i, int h, int c) {
+  return *reinterpret_cast<const float4*>(plane + (32 * tile + i) * RS + 8 * c + 4 * h);
+}
+// 16 values of a per-row table in accumulator order: p = &table[32 tile + 4 h]
+__device__ __forceinline__ f32x16 rows16(const float* __restrict__ p) {
+  f32x16 v;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 8 * m);
+    v[4 * m] = t.x; v[4 * m + 1] = t.y; v[4 * m + 2] = t.z; v[4 * m + 3] = t.w;
+  }
+  return v;
+}
+
+// out = init + W[rows of this lane's tile][:] . b     (wrow = &W[(32 R + i) * ld + 4 h]; k-group s covers columns 8 s + 4 h .. + 3,
+// the channels of accumulator registers 4 s .. 4 s + 3 of the B operand)
+template <int NT>
+__device__ __forceinline__ f32x16 mm_rows(const float* __restrict__ wrow, const f32x16 (&b)[NT], int ng, const f32x16& init) {
+  f32x16 a0 = init, a1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a1[q] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4 * NT; ++s) {
+    if (s < ng) {
+      const float4 w = *reinterpret_cast<const float4*>(wrow + 8 * s);
+      if (s & 1) {
+        a1 = SDEH_MFMA(w.x, b[s / 4][4 * (s % 4) + 0], a1); a1 = SDEH_MFMA(w.y, b[s / 4][4 * (s % 4) + 1], a1);
+        a1 = SDEH_MFMA(w.z, b[s / 4][4 * (s % 4) + 2], a1); a1 = SDEH_MFMA(w.w, b[s / 4][4 * (s % 4) + 3], a1);
+      } else {
+        a0 = SDEH_MFMA(w.x, b[s / 4][4 * (s % 4) + 0], a0); a0 = SDEH_MFMA(w.y, b[s / 4][4 * (s % 4) + 1], a0);
+        a0 = SDEH_MFMA(w.z, b[s / 4][4 * (s % 4) + 2], a0); a0 = SDEH_MFMA(w.w, b[s / 4][4 * (s % 4) + 3], a0);
+      }
+    }
+  }
+  return a0 + a1;
+}
+
+// out = W[:, columns of this lane's tile]^T . b     (wcol = &W[(4 h) * LD + 32 R + i]; k-group s covers rows 8 s + 4 h .. + 3)
+template <int NT, int LD>
+__device__ __forceinline__ f32x16 mm_cols(const float* __restrict__ wcol, const f32x16 (&b)[NT], int ng) {
+  f32x16 a0, a1;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) a0[q] = a1[q] = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4 * NT; ++s) {
+    if (s < ng) {
+      const float* __restrict__ p = wcol + 8 * s * LD;
+      const float w0 = p[0], w1 = p[LD], w2 = p[2 * LD], w3 = p[3 * LD];
+      if (s & 1) {
+        a1 = SDEH_MFMA(w0, b[s / 4][4 * (s % 4) + 0], a1); a1 = SDEH_MFMA(w1, b[s / 4][4 * (s % 4) + 1], a1);
+        a1 = SDEH_MFMA(w2, b[s / 4][4 * (s % 4) + 2], a1); a1 = SDEH_MFMA(w3, b[s / 4][4 * (s % 4) + 3], a1);
+      } else {
+        a0 = SDEH_MFMA(w0, b[s / 4][4 * (s % 4) + 0], a0); a0 = SDEH_MFMA(w1, b[s / 4][4 * (s % 4) + 1], a0);
+        a0 = SDEH_MFMA(w2, b[s / 4][4 * (s % 4) + 2], a0); a0 = SDEH_MFMA(w3, b[s / 4][4 * (s % 4) + 3], a0);
+      }
+    }
+  }
+  return a0 + a1;
+}
+
+// acc0 (+ acc1) += delta[tile R] . a[tile c0 (, c0 + 1)]^T over the 32 trajectories of the planes; bsum += this lane's 16 delta
+// values (lane (i, h): row 32 R + i, trajectories with bit 2 == h -- summed over h at the end they are the bias gradient)
+template <bool TWO>
+__device__ __forceinline__ void dw_acc(const float* __restrict__ dplane, int R, const float* __restrict__ aplane, int c0,
+                                       f32x16& acc0, f32x16& acc1, float& bsum, int i, int h) {
+  float4 dv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) dv[c] = plane_getT(dplane, R, i, h, c);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bsum += (dv[c].x + dv[c].y) + (dv[c].z + dv[c].w);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float4 a0 = plane_getT(aplane, c0, i, h, c);
+    float4 a1 = a0;
+    if constexpr (TWO) a1 = plane_getT(aplane, c0 + 1, i, h, c);
+    acc0 = SDEH_MFMA(dv[c].x, a0.x, acc0);
+    if constexpr (TWO) acc1 = SDEH_MFMA(dv[c].x, a1.x, acc1);
+    acc0 = SDEH_MFMA(dv[c].y, a0.y, acc0);
+    if constexpr (TWO) acc1 = SDEH_MFMA(dv[c].y, a1.y, acc1);
+    acc0 = SDEH_MFMA(dv[c].z, a0.z, acc0);
+    if constexpr (TWO) acc1 = SDEH_MFMA(dv[c].z, a1.z, acc1);
+    acc0 = SDEH_MFMA(dv[c].w, a0.w, acc0);
+    if constexpr (TWO) acc1 = SDEH_MFMA(dv[c].w, a1.w, acc1);
+  }
+}
+
+// act(z) and act'(z) of one tile
+template <int ACT>
+__device__ __forceinline__ void act_both(const f32x16& z, f32x16& a, f32x16& g) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    a[q] = act_ct<ACT>(z[q]);
+    g[q] = act_grad(z[q], ACT);
+  }
+}
+
+// accumulator tile -> natural [rows][ld] matrix block (row tile R, column tile Cc): coalesced over the lanes
+__device__ __forceinline__ void store_tile(float* __restrict__ m, int ld, int R, int Cc, int j, int h, const f32x16& v) {
+  float* __restrict__ p = m + (32 * R + 4 * h) * ld + 32 * Cc + j;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) p[rrow(q) * ld] = v[q];
+}
+
+}  // namespace bwdf
+
+template <int OTD, bool BPTT>
+__global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
+  using namespace bwdf;
+  constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
+  constexpr int NDW = OTD + 2 * LH + (OTD == 2 ? 2 : 1);  // weight-gradient tiles of a wave: input_embed, hidden, out_layer
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ Win = lds;
+  float* __restrict__ Whid = Win + 64 * RSI;
+  float* __restrict__ Wout = Whid + LH * 64 * RSW;
+  float* __restrict__ bh = Wout + DPP * RSW;
+  float* __restrict__ bo = bh + LH * 64;
+  float* __restrict__ tabs = bo + 64;
+  const WsLayout& L = A.lay;
+  const float* __restrict__ ws = A.ws;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 1, r = wave & 1;
+  const int j = lane & 31, h = lane >> 5;
+  const int ct = OTD == 2 ? r : 0;  // coordinate tile this wave owns (d <= 32: both waves mirror tile 0)
+  float* __restrict__ pl = tabs + TABS + team * 4 * PLANE;  // planes: A[0], A[1], D[0], D[1]
+  const int d = A.d, T = A.n_steps;
+  const long long B = A.batch;
+
+  // ---- stage the parameters (natural layouts, zero padding) and the Gaussian tables ----------------------------------------
+  for (int idx = tid; idx < 64 * RSI; idx += 256) {
+    const int row = idx / RSI, col = idx - row * RSI;
+    Win[idx] = col < d ? A.w_in[row * d + col] : 0.0f;
+  }
+  for (int idx = tid; idx < LH * 64 * RSW; idx += 256) {
+    const int l = idx / (64 * RSW), rem = idx - l * 64 * RSW, row = rem / RSW, col = rem - row * RSW;
+    Whid[idx] = col < 64 ? A.w_hid[l][row * 64 + col] : 0.0f;
+  }
+  for (int idx = tid; idx < DPP * RSW; idx += 256) {
+    const int row = idx / RSW, col = idx - row * RSW;
+    Wout[idx] = (row < d && col < 64) ? A.w_out[row * 64 + col] : 0.0f;
+  }
+  if (tid < LH * 64) bh[tid] = A.b_hid[tid >> 6][tid & 63];
+  if (tid < 64) bo[tid] = tid < d ? A.b_out[tid] : 0.0f;
+  for (int idx = tid; idx < TABS; idx += 256) {  // tabs[(2 k + c) * 64 + coordinate]: c = 0 mean, 1 inverse variance; k = prior, second, target
+    const int k = idx / 128, c = (idx >> 6) & 1, cj = idx & 63;
+    const int which = k == 0 ? 1 : (k == 1 ? 2 : 0);
+    tabs[idx] = cj < d && cj < L.dp ? ws[L.dg[which] + 2 * cj + c] : 0.0f;
+  }
+  // planes start zeroed: rows / trajectories that are never written must not hold NaNs (they meet zero weights)
+  for (int idx = tid; idx < 2 * 4 * PLANE; idx += 256) tabs[TABS + idx] = 0.0f;
+  __syncthreads();
+
+  const int act = A.act, ctrl_kind = A.ctrl_kind, flags = A.flags;
+  const bool has_score = ctrl_kind != SDEH_CTRL_CLIPPED;
+  const bool refc = (flags & SDEH_FLAG_REFERENCE_CTRL) && A.loss_kind == SDEH_LOSS_REFERENCE_SDE;
+  const bool expo = A.loss_kind == SDEH_LOSS_EXPONENTIAL;
+  const bool ito = (flags & SDEH_FLAG_ITO) != 0;
+  const int cb = 32 * ct + 4 * h;  // first coordinate of this lane's registers: coordinate(q) = cb + rrow(q)
+  const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
+
+  // per-coordinate tables of the own coordinate tile
+  const f32x16 pmu = rows16(tabs + 0 * 64 + cb), pis = rows16(tabs + 1 * 64 + cb);
+  f32x16 valid;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) valid[q] = cb + rrow(q) < d ? 1.0f : 0.0f;
+
+  // weight-gradient accumulators: [0, OTD) input_embed (row tile r x coordinate tiles); then hidden layer l: row tile r x 2;
+  // then out_layer: OTD == 2: coordinate tile r x 2 channel tiles; OTD == 1: coordinate tile 0 x channel tile r
+  f32x16 dw[NDW];
+#pragma unroll
+  for (int k = 0; k < NDW; ++k)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dw[k][q] = 0.0f;
+  float bs_hid[LH] = {0.0f, 0.0f}, bs_out = 0.0f;
+
+  const int n_teams = (int)gridDim.x * 2, team_g = (int)blockIdx.x * 2 + team;
+  const long long n_items = BPTT ? (long long)A.n_tiles : (long long)A.n_tiles * T;
+  const long long n_rounds = (n_items + n_teams - 1) / n_teams;
+  int par = 0;
+
+  for (long long round = 0; round < n_rounds; ++round) {
+    const long long item = round * n_teams + team_g;
+    const bool live_item = item < n_items;
+    const long long item_c = live_item ? item : n_items - 1;
+    const long long tile = BPTT ? item_c : item_c % A.n_tiles;
+    const long long row = tile * 32 + j;
+    const bool live = live_item && row < B;
+    const long long lrow = row < B ? row : B - 1;
+    const float wi = live ? A.grad_rnd[lrow] : 0.0f;
+    const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+
+    auto load16c = [&](const float* __restrict__ rowp) {  // 16 coordinates of the own tile from a [.., d] row
+      f32x16 v;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = cb + rrow(q) < d ? rowp[cb + rrow(q)] : 0.0f;
+      return v;
+    };
+
+    f32x16 lam;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) lam[q] = 0.0f;
+    if constexpr (BPTT) {  // lambda_T = w_i d(terminal costs)/dx_T  (losses/oc.py:225,337,449-450)
+      if (flags & SDEH_FLAG_TERMINAL_SECOND) {
+        const f32x16 xT = load16c(A.xs + ((long long)T * B + lrow) * d);
+        const f32x16 smu = rows16(tabs + 2 * 64 + cb), sis = rows16(tabs + 3 * 64 + cb);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) lam[q] = wi * (smu[q] - xT[q]) * sis[q] * valid[q];
+      }
+      if ((flags & SDEH_FLAG_TERMINAL_TARGET) && A.tscore != nullptr) {
+        const f32x16 st = load16c(A.tscore + lrow * d);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) lam[q] = fmaf(-wi, st[q], lam[q]);
+      }
+    }
+    const int t_first = BPTT ? T - 1 : (int)(item_c / A.n_tiles);
+    const int t_last = BPTT ? 0 : t_first;
+    f32x16 xnext = load16c(A.xs + ((long long)t_first * B + lrow) * d);
+
+    for (int t = t_first; t >= t_last; --t) {
+      float* __restrict__ Acur = pl + par * PLANE;        // x, later a_2
+      float* __restrict__ Aoth = pl + (1 - par) * PLANE;  // a_1, later a_3
+      float* __restrict__ D0 = pl + 2 * PLANE;
+      float* __restrict__ D1 = pl + 3 * PLANE;
+      const f32x16 x = xnext;
+      if (t > t_last) xnext = load16c(A.xs + ((long long)(t - 1) * B + lrow) * d);
+      f32x16 scv, xi;
+      if (has_score) scv = load16c(A.sc + ((long long)t * B + lrow) * d);
+      if (ito) {
+        float n[16];
+        if (A.noise != nullptr) {
+          const f32x16 nv = load16c(A.noise + ((long long)t * B + lrow) * d);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) n[q] = nv[q];
+        } else {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            float n4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (cb + 8 * g4 < d) box_muller4(philox_block(A.seed, rng_off, grow, t, (cb + 8 * g4) >> 2), n4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) n[4 * g4 + e] = n4[e];
+            SDEH_FENCE();
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) xi[q] = n[q] * valid[q];
+      }
+      cfp cf = as_const(ws + L.coef + t * kCoefStride);
+      const float sig = cf[CF_SIGMA], wl = cf[CF_W];
+      const float c_i = expo ? cf[CF_SBK] : cf[CF_SQDT];
+      const float cdt = expo ? cf[CF_B2S2] : cf[CF_DT];
+      const float c_u = expo ? cf[CF_B2S2] : sig * cf[CF_DT];
+      const float c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], cf[CF_DT], 1.0f);
+
+      // ======================================================================================= forward (re-evaluation at x_t)
+      plane_put(Acur, ct, j, h, x);
+      ws_barrier();  // 1
+      f32x16 full[2], g0, g1, g2, a1own;
+      {
+        f32x16 xf[OTD];
+#pragma unroll
+        for (int k = 0; k < OTD; ++k) xf[k] = plane_get(Acur, k, j, h);
+        const f32x16 z0 = mm_rows<OTD>(Win + (32 * r + j) * RSI + 4 * h, xf, A.n_kg, load16(ws + L.emb + t * C + (r * 2 + h) * 16));
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z0, a1own, g0););
+      }
+      plane_put(Aoth, r, j, h, a1own);
+      ws_barrier();  // 2
+      {
+        full[0] = plane_get(Aoth, 0, j, h); full[1] = plane_get(Aoth, 1, j, h);
+        const f32x16 z1 = mm_rows<2>(Whid + (32 * r + j) * RSW + 4 * h, full, 8, rows16(bh + 32 * r + 4 * h));
+        f32x16 a2;
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z1, a2, g1););
+        plane_put(Acur, r, j, h, a2);
+      }
+      ws_barrier();  // 3
+      {
+        full[0] = plane_get(Acur, 0, j, h); full[1] = plane_get(Acur, 1, j, h);
+        const f32x16 z2 = mm_rows<2>(Whid + 64 * RSW + (32 * r + j) * RSW + 4 * h, full, 8, rows16(bh + 64 + 32 * r + 4 * h));
+        f32x16 a3;
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z2, a3, g2););
+        plane_put(Aoth, r, j, h, a3);
+      }
+      ws_barrier();  // 4
+      full[0] = plane_get(Aoth, 0, j, h); full[1] = plane_get(Aoth, 1, j, h);
+      const f32x16 nn = mm_rows<2>(Wout + (32 * ct + j) * RSW + 4 * h, full, 8, rows16(bo + cb));
+
+      // ======================================================================================= upstream gradient of the control
+      f32x16 G, Gc, cvec, dout;
+      {
+        float gsum = 0.0f;
+        f32x16 gcoord;
+        const float mult = (ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig) * A.scale_score;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float mfac = 0.0f, csc = 0.0f, keep_s = 0.0f;
+          if (has_score) {
+            const float gam = A.g == 1 ? ws[L.gam + t * L.g] : ws[L.gam + t * L.g + min(cb + rrow(q), L.g - 1)];
+            mfac = mult * gam;
+            csc = clipf(scv[q], A.clip_score);
+            keep_s = fabsf(scv[q]) <= A.clip_score ? 1.0f : 0.0f;
+          }
+          float gc = ito ? wi * c_i * xi[q] : 0.0f;
+          if constexpr (BPTT) {
+            const float u = clipf(nn[q], A.clip_model) + mfac * csc;
+            const float rr = refc ? sig * (pmu[q] - x[q]) * pis[q] : 0.0f;
+            gc = wi * fmaf(u - rr, cdt, ito ? c_i * xi[q] : 0.0f);
+          }
+          gc *= valid[q];
+          const float gq = BPTT ? fmaf(c_u, lam[q], gc) * valid[q] : gc;
+          Gc[q] = gc;
+          G[q] = gq;
+          const float gg = gq * mult * csc;
+          gcoord[q] = gg;
+          gsum += gg;
+          cvec[q] = keep_s * mfac * gq;
+          dout[q] = fabsf(nn[q]) <= A.clip_model ? gq : 0.0f;
+        }
+        if (has_score && live_item) {  // d loss / d gamma(t): summed over the team's trajectories
+          if (A.g == 1) {
+            gsum += __shfl_xor(gsum, 32);
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) gsum += __shfl_xor(gsum, m);
+            if (lane == 0) A.gpart[(tile * T + t) * A.gw + r] = (OTD == 2 || r == 0) ? gsum : 0.0f;
+          } else if (OTD == 2 || r == 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              float v = gcoord[q];
+#pragma unroll
+              for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+              if (j == 0) A.gpart[(tile * T + t) * A.gw + cb + rrow(q)] = v;
+            }
+          }
+        }
+      }
+
+      // ======================================================================================= backward + weight gradients
+      plane_put(D0, ct, j, h, dout);
+      ws_barrier();  // 5: delta_out | a_3 (Aoth)
+      f32x16 dl;
+      {
+        if constexpr (OTD == 2) dw_acc<true>(D0, r, Aoth, 0, dw[OTD + 2 * LH], dw[NDW - 1], bs_out, j, h);
+        else dw_acc<false>(D0, 0, Aoth, r, dw[OTD + 2 * LH], dw[OTD + 2 * LH], bs_out, j, h);
+        f32x16 df[OTD];
+#pragma unroll
+        for (int k = 0; k < OTD; ++k) df[k] = plane_get(D0, k, j, h);
+        dl = mm_cols<OTD, RSW>(Wout + (4 * h) * RSW + 32 * r + j, df, A.n_kg) * g2;
+      }
+      plane_put(D1, r, j, h, dl);
+      ws_barrier();  // 6: delta_2 | a_2 (Acur)
+      {
+        dw_acc<true>(D1, r, Acur, 0, dw[OTD + 2], dw[OTD + 3], bs_hid[1], j, h);
+        full[0] = plane_get(D1, 0, j, h); full[1] = plane_get(D1, 1, j, h);
+        dl = mm_cols<2, RSW>(Whid + 64 * RSW + (4 * h) * RSW + 32 * r + j, full, 8) * g1;
+      }
+      plane_put(D0, r, j, h, dl);
+      plane_put(Aoth, r, j, h, a1own);
+      ws_barrier();  // 7: delta_1 | a_1 (Aoth)
+      {
+        dw_acc<true>(D0, r, Aoth, 0, dw[OTD], dw[OTD + 1], bs_hid[0], j, h);
+        full[0] = plane_get(D0, 0, j, h); full[1] = plane_get(D0, 1, j, h);
+        dl = mm_cols<2, RSW>(Whid + (4 * h) * RSW + 32 * r + j, full, 8) * g0;
+      }
+      plane_put(D1, r, j, h, dl);
+      plane_put(Acur, ct, j, h, x);
+      ws_barrier();  // 8: delta_0 | x (Acur)
+      {
+        float esum = 0.0f;
+        dw_acc<(OTD == 2)>(D1, r, Acur, 0, dw[0], dw[OTD - 1], esum, j, h);
+        esum += __shfl_xor(esum, 32);  // d loss / d (time embedding + input bias)[t][32 r + j]
+        if (live_item && h == 0) A.epart[(tile * T + t) * 64 + 32 * r + j] = esum;
+      }
+      if constexpr (BPTT) {
+        // ===================================================================================== adjoint update
+        full[0] = plane_get(D1, 0, j, h); full[1] = plane_get(D1, 1, j, h);
+        const f32x16 dx = mm_cols<2, RSI>(Win + (4 * h) * RSI + 32 * ct + j, full, 8);
+        // score terms the reference detaches (reparam.py:58,134,169,188) or obtains by autograd without a graph carry no Jacobian
+        const float coef_t = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET ? wl : 0.0f);
+        const float coef_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR ? 1.0f - wl : 0.0f;
+        const float jac_t = (!has_score || (flags & (SDEH_FLAG_DETACH_SCORE | SDEH_FLAG_TARGET_SCORE_CONST))) ? 0.0f : coef_t;
+        const float jac_p = (!has_score || (flags & SDEH_FLAG_DETACH_SCORE)) ? 0.0f : coef_p;
+        f32x16 vt;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vt[q] = 0.0f;
+        if (jac_t != 0.0f) {
+          if (A.target.kind == SDEH_DENS_DIAG_GAUSS) {
+            const f32x16 tis = rows16(tabs + 5 * 64 + cb);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vt[q] = -tis[q] * cvec[q];
+          } else if (A.target.kind == SDEH_DENS_MULTI_WELL) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float y = x[q] - A.target.p1;
+              vt[q] = (cb + rrow(q) < A.target.n_comp ? -4.0f * (3.0f * y * y - A.target.p0) : -1.0f) * cvec[q];
+            }
+          } else if (A.target.kind == SDEH_DENS_FUNNEL) {  // OTD == 1 (checked by the host): every coordinate lives in this wave
+            // s_0 = -x0/var - (d-1)/2 + e^{-x0} sum x_j^2 / 2,  s_j = -x_j e^{-x0}   (coordinate 0 = register 0 of the h = 0 half)
+            const float x0 = __shfl(x[0], j), c0 = __shfl(cvec[0], j);
+            const float iv = __expf(-x0);
+            float sq = 0.0f, cx = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const bool first = q == 0 && h == 0;
+              sq = fmaf(first ? 0.0f : x[q], x[q], sq);
+              cx = fmaf(first ? 0.0f : cvec[q], x[q], cx);
+            }
+            sq += __shfl_xor(sq, 32);
+            cx += __shfl_xor(cx, 32);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vt[q] = iv * (c0 * x[q] - cvec[q]);
+            if (h == 0) vt[0] = c0 * (-1.0f / A.target.p0 - 0.5f * iv * sq) + iv * cx;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float v = fmaf(c_x, lam[q], dx[q]);
+          v = fmaf(jac_t, vt[q], v);
+          v = fmaf(-jac_p * pis[q], cvec[q], v);           // Gaussian prior: J = -1/sigma^2
+          if (refc) v = fmaf(sig * pis[q], Gc[q], v);      // cost depends on x through sigma * prior.score(x)
+          lam[q] = v * valid[q];
+        }
+      }
+      par ^= 1;
+    }
+  }
+
+  // ---- the team's partial gradients ---------------------------------------------------------------------------------------
+  float* __restrict__ rec = A.wpart + (long long)team_g * A.wsize;
+#pragma unroll
+  for (int k = 0; k < OTD; ++k) store_tile(rec, DPP, r, k, j, h, dw[k]);
+#pragma unroll
+  for (int l = 0; l < LH; ++l) {
+    store_tile(rec + off_whid<OTD>() + l * 4096, 64, r, 0, j, h, dw[OTD + 2 * l]);
+    store_tile(rec + off_whid<OTD>() + l * 4096, 64, r, 1, j, h, dw[OTD + 2 * l + 1]);
+    float b = bs_hid[l];
+    b += __shfl_xor(b, 32);
+    if (h == 0) rec[off_bhid<OTD>() + l * 64 + 32 * r + j] = b;
+  }
+  {
+    float b = bs_out;
+    b += __shfl_xor(b, 32);
+    if constexpr (OTD == 2) {
+      store_tile(rec + off_wout<OTD>(), 64, r, 0, j, h, dw[OTD + 2 * LH]);
+      store_tile(rec + off_wout<OTD>(), 64, r, 1, j, h, dw[OTD + 2 * LH + 1]);
+      if (h == 0) rec[off_bout<OTD>() + 32 * r + j] = b;
+    } else {
+      store_tile(rec + off_wout<OTD>(), 64, 0, r, j, h, dw[OTD + 2 * LH]);
+      if (h == 0 && r == 0) rec[off_bout<OTD>() + j] = b;
+    }
+  }
+}
+
+template <int OTD, bool BPTT>
+static int launch_bwdf_t(const BwdfArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = (size_t)bwdf::lds_floats<OTD>() * sizeof(float);
+  static bool attr_done[kMaxDevices] = {};
+  bool& attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf_kernel<OTD, BPTT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bwdf_kernel<OTD, BPTT>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+int bwdf_wsize(int d) { return d <= 32 ? bwdf::wsize<1>() : bwdf::wsize<2>(); }
+
+// teams (of 32 trajectories) the launch uses: two per workgroup, one workgroup per CU (the LDS image is ~130-146 KB)
+int bwdf_slots(long long batch, int n_steps, bool bptt) {
+  const long long tiles = (batch + 31) / 32;
+  const long long items = bptt ? tiles : tiles * n_steps;
+  const long long wgs = (items + 1) / 2;
+  return 2 * (int)(wgs < 256 ? wgs : 256);
+}
+
+int launch_bwdf(const BwdfArgs& a, hipStream_t stream) {
+  const bool bptt = !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  if (a.d <= 32) return bptt ? launch_bwdf_t<1, true>(a, stream) : launch_bwdf_t<1, false>(a, stream);
+  return bptt ? launch_bwdf_t<2, true>(a, stream) : launch_bwdf_t<2, false>(a, stream);
+}
+
+}  // namespace sdeh

@@ -115,6 +115,9 @@ struct TrajArgs {
   // training forward (sdeh_simulate_fwd_train): what the backward kernels would otherwise recompute
   float* zt_out;  // [(Lh+1), C, T*B] or null: pre-activations of every layer, coordinate-major
   float* nn_out;  // [T, B, d] or null: raw network output (before the clamp) per step
+  // training forward for the fused backward (sdeh_simulate_fwd_train2)
+  float* sc_out;  // [T, B, d] or null: combined score entering the control, before clip_score and gamma(t)
+  float* tsc_out; // [B, d] or null: 1[|log rho(x_T)| <= clip_target] * target.score(x_T)  (d terminal target cost / d x_T, negated)
 };
 
 // sdeh_bridge_div_backward (sdeh_bridge.hpp): gradient of  sum_n w_i sigma dt div_x v(x_n)  w.r.t. the inference network
@@ -162,6 +165,36 @@ struct BwdArgs {
   const unsigned long long* rng_dev;
   const float* nn_in;  // [T, B, d] or null: with it, `zt` already holds the forward launch's pre-activations and is only read
 };
+
+// sdeh_ctrl_backward_fused (sdeh_bwdf.hip): back-propagation + weight gradients in one kernel
+struct BwdfArgs {
+  const float* ws;  // prep'd workspace: per-step coefficients, time embedding (accumulator order), gamma table, Gaussian tables
+  WsLayout lay;
+  const float* w_in;      // [64, d]      raw parameters of the FourierMLP (models/mlp.py:85-112)
+  const float* w_hid[2];  // [64, 64]
+  const float* b_hid[2];  // [64]
+  const float* w_out;     // [d, 64]
+  const float* b_out;     // [d]
+  const float* xs;        // [T+1, B, d]
+  const float* noise;     // [T, B, d] or null (Philox replay)
+  const float* grad_rnd;  // [B]
+  const float* sc;        // [T, B, d] or null (ClippedCtrl)
+  const float* tscore;    // [B, d] or null
+  float* wpart;           // [n_slots][wsize]
+  float* epart;           // [n_tiles][T][64]
+  float* gpart;           // [n_tiles][T][gw]
+  long long batch, row_offset;
+  int n_steps, d, n_kg;   // n_kg: k-groups (of 4 accumulator registers) covering the d coordinates
+  int loss_kind, ctrl_kind, flags, act, g, gw;
+  float clip_model, clip_score, scale_score;
+  DensArgs target;
+  unsigned long long seed, offset;
+  const unsigned long long* rng_dev;
+  int n_tiles, n_slots, wsize;
+};
+int launch_bwdf(const BwdfArgs& a, hipStream_t stream);
+int bwdf_wsize(int d);                                     // floats of one team's partial-gradient record
+int bwdf_slots(long long batch, int n_steps, bool bptt);  // teams (partial records) a launch uses
 
 // effective Philox offset of a launch: by-value part + the optional device-resident counter (hipGraph replays)
 __device__ __forceinline__ unsigned long long philox_offset(unsigned long long offset, const unsigned long long* dev) {

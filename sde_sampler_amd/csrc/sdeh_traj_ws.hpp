@@ -547,7 +547,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         f32x16 emb1 = load16(ws + L.emb + (mw * 2 + h) * 16);
         ws_barrier();  // barrier A: x_0 published
         const long long row0 = (long long)blockIdx.x * 32;
-        ZStore Z{nullptr, (long long)n_steps * A.batch, (int)(A.batch - row0 < 32 ? A.batch - row0 : 32)};
+        ZStore Z{nullptr, (long long)n_steps * A.batch, A.zt_out == nullptr ? 0 : (int)(A.batch - row0 < 32 ? A.batch - row0 : 32)};
         for (int i = 0; i < n_steps; ++i) {
           if constexpr (PLANES) Z.base = A.zt_out + (long long)i * A.batch + row0;
           SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, PLANES>(lds, xbuf, abuf, L, emb1, lane, mw, parity, Z););
@@ -569,6 +569,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       row0 = (long long)blockIdx.x * (rpg_m * n_groups) + group * rpg_m;
       Z.N = (long long)n_steps * A.batch;
       Z.rows = (int)(A.batch - row0 < rpg_m ? (A.batch - row0 > 0 ? A.batch - row0 : 0) : rpg_m);
+      if (A.zt_out == nullptr) Z.rows = 0;  // fused backward (sdeh_simulate_fwd_train2): no pre-activation planes
     }
     for (int i = 0; i < n_steps; ++i) {
       if constexpr (PLANES) Z.base = A.zt_out + (long long)i * A.batch + row0;
@@ -657,6 +658,14 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < DP; ++j) sterm[j] = w1 * psc[j];
       }
+      if constexpr (PLANES) {  // the fused backward reads the combined score instead of re-evaluating the densities
+        if (A.sc_out != nullptr && live) {
+          float* __restrict__ sp = A.sc_out + ((long long)i * A.batch + lrow) * d;
+#pragma unroll
+          for (int j = 0; j < DP; ++j)
+            if (!PAD || j < d) sp[j] = sterm[j];
+        }
+      }
       cfp gam = as_const(ws + L.gam + i * L.g);
       const float mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;  // Lerp*: ctrl + sde.diff(t) * score
       const float g0 = gam[0];
@@ -725,7 +734,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j) {
       const float nn = xbuf[j * 64 + lane];
       if constexpr (PLANES) {
-        if (live && (!PAD || j < d)) A.nn_out[((long long)i * A.batch + lrow) * d + j] = nn;
+        if (A.nn_out != nullptr && live && (!PAD || j < d)) A.nn_out[((long long)i * A.batch + lrow) * d + j] = nn;
       }
       u[j] = clipf(nn, A.clip_model) + sterm[j];
       if (PAD) u[j] = j < d ? u[j] : 0.0f;
@@ -782,6 +791,20 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j)
       if (!PAD || j < d) xT[row * d + j] = x[j];
   }
+  if constexpr (PLANES) {  // d(terminal target cost)/dx_T, negated: the clamp's mask times target.score(x_T)  (oc.py:225)
+    if (A.tsc_out != nullptr && (flags & SDEH_FLAG_TERMINAL_TARGET)) {
+      float st[DP];
+      ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, st);
+      float keep = 1.0f;
+      if (A.clip_target < 3.0e38f)
+        keep = fabsf(ws_target_logp<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x)) <= A.clip_target ? 1.0f : 0.0f;
+      if (live) {
+#pragma unroll
+        for (int j = 0; j < DP; ++j)
+          if (!PAD || j < d) A.tsc_out[row * d + j] = keep * st[j];
+      }
+    }
+  }
 }
 
 template <int DP>
@@ -799,7 +822,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   const bool pair_fits = C == 64 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
-  const bool planes = a.zt_out != nullptr && a.nn_out != nullptr;
+  const bool planes = (a.zt_out != nullptr && a.nn_out != nullptr) || a.sc_out != nullptr || a.tsc_out != nullptr;
   static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {

@@ -52,6 +52,87 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
     return zt, dt, dout, dgam
 
 
+def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torch.Tensor]:
+    """Parameter gradients of the generative control from sdeh_ctrl_backward_fused (back-propagation and weight gradients in one
+    kernel; csrc/sdeh_bwdf.hip) + sdeh_time_embed_backward on the two [T, .] tables."""
+    ctrl, engine = loss.generative_ctrl, loss.engine
+    base = ctrl.base_model
+    dev = xs.device
+    T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+    score_model = getattr(ctrl, "score_model", None) if pr.ctrl_kind != L.CTRL_CLIPPED else None
+    g = 1 if score_model is None else score_model.out_layer.out_features
+    bptt = not (pr.flags & L.FLAG_CHANGE_SDE_CTRL)
+    lib = L.load()
+    n_scratch, n_out = C.c_int64(), C.c_int64()
+    L.check(lib.sdeh_ctrl_backward_fused_sizes(d, T, B, g, int(bptt), C.byref(n_scratch), C.byref(n_out)))
+    scratch = torch.empty(n_scratch.value, device=dev, dtype=torch.float32)
+    out = torch.empty(n_out.value, device=dev, dtype=torch.float32)
+    plan = engine._plan(dev, d, base.channels, len(base.hidden_layer), T, pr.target.n_components if pr.target.kind == L.DENS_GMM else 0)
+    noise = st["noise"]
+    ptr = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(dev):
+        L.check(lib.sdeh_ctrl_backward_fused(
+            plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
+            None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
+            w.data_ptr(), ptr(sc), ptr(tscore), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream))
+    P, gw = 32 * ((d + 31) // 32), (2 if g == 1 else 64)
+    grads: dict[int, torch.Tensor] = {}
+    pos = 0
+
+    def take(n, *shape):
+        nonlocal pos
+        v = out[pos:pos + n].view(*shape)
+        pos += n
+        return v
+
+    with torch.no_grad():
+        grads[id(base.input_embed.weight)] = take(64 * P, 64, P)[:, :d].contiguous()
+        w_hid = take(2 * 4096, 2, 64, 64)
+        grads[id(base.out_layer.weight)] = take(P * 64, P, 64)[:d]
+        b_hid = take(128, 2, 64)
+        grads[id(base.out_layer.bias)] = take(P, P)[:d]
+        for k, lin in enumerate(base.hidden_layer):
+            grads[id(lin.weight)], grads[id(lin.bias)] = w_hid[k], b_hid[k]
+        d_emb = take(T * 64, T, 64)
+        d_gam = take(T * gw, T, gw)
+        grads[id(base.input_embed.bias)] = d_emb.sum(dim=0)
+        d_gam = d_gam.sum(dim=1, keepdim=True) if g == 1 else d_gam[:, :d].contiguous()
+    grads.update(_time_table_grads(ctrl, ts, d_emb, d_gam if score_model is not None else None))
+    return grads
+
+
+def _time_table_grads(ctrl, ts, d_emb, d_gam) -> dict[int, torch.Tensor]:
+    """Parameter gradients of the two time-only sub-networks from the gradients of their [T, .] tables (sdeh_time_embed_backward;
+    autograd on the tables only for shapes that kernel does not take)."""
+    base = ctrl.base_model
+    act_id = E._activation_id(base.activation)
+    grads: dict[int, torch.Tensor] = {}
+    steps = ts[:-1].contiguous()
+    te_params = [p for p in base.timestep_embed.parameters() if p.requires_grad]
+    if te_params:
+        got = _time_embed_grads(base.timestep_embed, act_id, steps, d_emb, None)
+        if got is None:
+            with torch.enable_grad():
+                emb = base.timestep_embed(steps)
+                got = {id(p): gp for p, gp in zip(te_params, torch.autograd.grad(emb, te_params, d_emb, allow_unused=True))}
+        grads.update(got)
+    score_model = getattr(ctrl, "score_model", None)
+    if score_model is not None and d_gam is not None:
+        sm_params = [p for p in score_model.parameters() if p.requires_grad]
+        if sm_params:
+            clip_model = getattr(ctrl, "clip_model", None)
+            got = _time_embed_grads(score_model, E._activation_id(score_model.activation), steps, d_gam, clip_model)
+            if got is None:
+                with torch.enable_grad():
+                    gam = score_model(steps)
+                    if clip_model is not None:
+                        gam = gam.clip(min=-clip_model, max=clip_model)
+                    got = {id(p): gp for p, gp in zip(sm_params, torch.autograd.grad(gam, sm_params, d_gam, allow_unused=True))}
+            grads.update(got)
+    return grads
+
+
 def _wgrad_batch(items: list[tuple[torch.Tensor, torch.Tensor, int]]) -> list[tuple[torch.Tensor, torch.Tensor]]:
     """[(dmat @ act(z)^T [m, c], dmat.sum(1) [m]) for (dmat [m, N], z [c, N], act) in items], every product in ONE pass over its
     two coordinate-major planes (sdeh_weight_grad: activation on the fly, K-contiguous MFMA operands) and ONE reduction of all
@@ -170,32 +251,12 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, tor
         for j, i_in, i_out in per_coord:
             grads[id(w_in)][:, j] += results[i_in][1]
             grads[id(w_out)][j] += results[i_out][0][0]
-    # the two time-only sub-networks: parameter gradients from the gradients of their [T, .] tables (sdeh_time_embed_backward;
-    # autograd on the tables only for shapes that kernel does not take)
-    steps = ts[:-1].contiguous()
-    te_params = [p for p in base.timestep_embed.parameters() if p.requires_grad]
-    if te_params:
-        got = _time_embed_grads(base.timestep_embed, act_id, steps, d_emb, None)
-        if got is None:
-            with torch.enable_grad():
-                emb = base.timestep_embed(steps)
-                got = {id(p): gp for p, gp in zip(te_params, torch.autograd.grad(emb, te_params, d_emb, allow_unused=True))}
-        grads.update(got)
+    d_gam = None
     if score_model is not None:
-        sm_params = [p for p in score_model.parameters() if p.requires_grad]
-        if sm_params:
-            clip_model = getattr(ctrl, "clip_model", None)
-            with torch.no_grad():
-                dg = dgam[:g] + extra["dgam"][:g] if "dgam" in extra else dgam[:g]
-                d_gam = dg.reshape(g, T, B).sum(dim=2).t().contiguous()  # [T, g]
-            got = _time_embed_grads(score_model, E._activation_id(score_model.activation), steps, d_gam, clip_model)
-            if got is None:
-                with torch.enable_grad():
-                    gam = score_model(steps)
-                    if clip_model is not None:
-                        gam = gam.clip(min=-clip_model, max=clip_model)
-                    got = {id(p): gp for p, gp in zip(sm_params, torch.autograd.grad(gam, sm_params, d_gam, allow_unused=True))}
-            grads.update(got)
+        with torch.no_grad():
+            dg = dgam[:g] + extra["dgam"][:g] if "dgam" in extra else dgam[:g]
+            d_gam = dg.reshape(g, T, B).sum(dim=2).t().contiguous()  # [T, g]
+    grads.update(_time_table_grads(ctrl, ts, d_emb, d_gam))
     return grads
 
 
@@ -216,8 +277,12 @@ class _TrajectoryFn(torch.autograd.Function):
         w = grad_rnd.reshape(-1).contiguous().float()
         keep = E._Keep()
         pr = loss.engine.build_problem(device=xs.device, keep=keep, **st["problem_kwargs"])
-        planes = _ctrl_backward(loss.engine, pr, keep, ts, xs, w, st, planes=st.get("planes"))
-        grads = _weight_grads(loss.generative_ctrl, ts, xs, *planes)
+        kept = st.get("planes")
+        if kept is not None and kept[0] == "fused":
+            grads = _fused_backward(loss, pr, keep, ts, xs, w, st, kept[1], kept[2])
+        else:
+            planes = _ctrl_backward(loss.engine, pr, keep, ts, xs, w, st, planes=kept)
+            grads = _weight_grads(loss.generative_ctrl, ts, xs, *planes)
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
 

@@ -1,0 +1,142 @@
+"""The fused training backward (csrc/sdeh_bwdf.hip: back-propagation + weight gradients in one kernel, no [C, T*B] planes) against
+(i) the reference's autograd gradients on the golden fixtures and (ii) the plane-writing kernels it replaces (sdeh_ctrl_backward_ex +
+sdeh_weight_grad, selected with SDEH_BWD_PLANES=1) over random problems: every loss / control / target kind, d = 1 .. 64 (one and two
+coordinate tiles), ragged batches, supplied and replayed noise, methods kl / kl_ito / lv / lv_traj."""
+import os
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import GOLDEN, hip_problem, load_fixture
+from tests.test_hip_fuzz import random_spec
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _grads(prob, x0, noise, planes: bool):
+    if planes:
+        os.environ["SDEH_BWD_PLANES"] = "1"
+    try:
+        prob.ctrl.zero_grad()
+        val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
+        val.backward()
+        name = prob.loss.engine.last_kernel_name()
+        return val.item(), {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in prob.ctrl.named_parameters()}, name
+    finally:
+        os.environ.pop("SDEH_BWD_PLANES", None)
+
+
+@pytest.mark.parametrize("method", ["lv", "kl"])
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: Path(p).stem)
+def test_fused_backward_serves_the_golden_configurations(path, method):
+    """The reference-gradient comparison itself is tests/test_hip_parity.py::test_training_gradients_match_reference; here: the
+    fused kernel is what produced those gradients, and they agree with the plane-based path far inside that test's tolerance."""
+    fx, meta, params, tt = load_fixture(path)
+    prob = hip_problem(meta, params, tt)
+    prob.loss.method = method
+    x0 = torch.from_numpy(fx["x0"]).cuda()
+    noise = torch.from_numpy(fx["noise"]).cuda()
+    v1, g1, name1 = _grads(prob, x0, noise, planes=False)
+    v2, g2, name2 = _grads(prob, x0, noise, planes=True)
+    if meta["net"]["num_layers"] == 4:  # the depth the fused kernel is compiled for (conf/model/base/fouriermlp.yaml)
+        assert name1.startswith("bwd_fused<" + ("bptt" if method == "kl" else "rows")), name1
+    else:
+        assert not name1.startswith("bwd_fused"), name1
+    assert not name2.startswith("bwd_fused"), name2
+    assert v1 == v2
+    for k in g1:
+        ref = fx[f"train_{method}/grad/{k}"]
+        a = g1[k].cpu().numpy() if g1[k] is not None else np.zeros_like(ref)
+        b = g2[k].cpu().numpy() if g2[k] is not None else np.zeros_like(ref)
+        scale = max(np.abs(ref).max(), 1e-6)
+        assert np.abs(a - ref).max() <= 2e-4 * scale + 1e-7, f"{k}: fused vs reference {np.abs(a - ref).max():.3e} / {scale:.3e}"
+        assert np.abs(a - b).max() <= 5e-5 * scale + 1e-7, f"{k}: fused vs planes {np.abs(a - b).max():.3e} / {scale:.3e}"
+
+
+@pytest.mark.parametrize("case", range(48))
+def test_fused_backward_equals_plane_backward_on_random_problems(case):
+    from sde_sampler_amd import SdehUnsupported, problems
+
+    rng = np.random.default_rng(9000 + case)
+    spec = random_spec(rng)
+    spec["net"]["num_layers"] = 4  # the depth the fused kernel is compiled for (conf/model/base/fouriermlp.yaml)
+    method = str(rng.choice(["kl", "kl_ito", "lv", "lv_traj"]))
+    spec["loss"]["method"] = method
+    spec["loss"]["max_rnd"] = 1e8 if method.startswith("lv") else None
+    if method == "lv_traj":
+        spec["loss"]["traj_per_sample"] = 2
+    spec["batch"] = int(rng.choice([33, 64, 100, 257]))
+    if case % 4 == 3:  # two coordinate tiles
+        d = int(rng.choice([33, 40, 64]))
+        for part in ("target", "prior"):
+            if spec[part] is not None and "dim" in spec[part]:
+                spec[part]["dim"] = d
+        if spec["target"]["kind"] == "gmm":
+            spec["target"]["name"] = "random7"
+        if spec["target"]["kind"] == "multi_well":
+            spec["target"]["n_double_wells"] = min(spec["target"]["n_double_wells"], d)
+        if spec["ctrl"].get("gamma_dim", 1) != 1:
+            spec["ctrl"]["gamma_dim"] = d
+    prob = problems.build(spec)
+    prob.to(DEV)
+    B, d, T = spec["batch"], spec["target"]["dim"], prob.ts.numel() - 1
+    torch.manual_seed(case)
+    x0 = prob.prior.sample((B,)).to(DEV)
+    rows = B * spec["loss"].get("traj_per_sample", 1)
+    noise = torch.randn(T, rows, d, device=DEV) if case % 3 else None  # every third case replays the Philox draws
+    tag = f"case {case}: {method} {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"
+    eng = prob.loss.engine
+    calls = eng.calls
+    try:
+        v1, g1, name1 = _grads(prob, x0, noise, planes=False)
+        eng.calls = calls  # same Philox offset for the second run
+        v2, g2, name2 = _grads(prob, x0, noise, planes=True)
+    except SdehUnsupported as exc:
+        if "do not fit in LDS" in str(exc):
+            pytest.skip(str(exc)[:120])
+        raise
+    if method.startswith("kl") and spec["target"]["kind"] == "funnel" and d > 32 and spec["ctrl"]["kind"] in ("score", "lerp", "lerp_target"):
+        assert not name1.startswith("bwd_fused"), f"{tag}: {name1}"
+        return
+    assert name1.startswith("bwd_fused"), f"{tag}: {name1}"
+    assert not name2.startswith("bwd_fused"), f"{tag}: {name2}"
+    assert v1 == v2 or (np.isnan(v1) and np.isnan(v2)), f"{tag}: loss {v1} vs {v2}"
+    if not np.isfinite(v1):
+        return
+    gmax = max((torch.nan_to_num(g).abs().max().item() for g in g2.values() if g is not None), default=0.0)
+    for k in g1:
+        a, b = g1[k], g2[k]
+        if a is None and b is None:
+            continue
+        a = torch.zeros_like(b) if a is None else a
+        b = torch.zeros_like(a) if b is None else b
+        if not torch.isfinite(b).all():
+            continue
+        denom = max(b.abs().max().item(), 1e-4 * gmax, 1e-12)
+        err = (a - b).abs().max().item() / denom
+        assert err <= 2e-4, f"{tag}: grad {k} fused vs planes rel err {err:.2e}"
+
+
+def test_fused_backward_large_batch_is_deterministic():
+    """B = 16 384 (more teams than workgroups: the persistent loop), kl: two launches give bitwise identical gradients (fixed-order
+    partial sums, no atomics)."""
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec("cfg3_gmm50_pis_kl")
+    spec["batch"] = 16384 + 17
+    prob = problems.build(spec, device=DEV)
+    torch.manual_seed(0)
+    x0 = prob.prior.sample((spec["batch"],))
+    eng = prob.loss.engine
+    calls = eng.calls
+    v1, g1, name = _grads(prob, x0, None, planes=False)
+    eng.calls = calls
+    v2, g2, _ = _grads(prob, x0, None, planes=False)
+    assert name.startswith("bwd_fused<bptt"), name
+    assert v1 == v2
+    for k in g1:
+        if g1[k] is not None:
+            assert torch.equal(g1[k], g2[k]), k

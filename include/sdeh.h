@@ -302,15 +302,17 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const 
  * inference control: sdeh_ctrl_backward_fused_supported says whether a problem qualifies; sdeh_ctrl_backward_ex + sdeh_weight_grad
  * take the rest.
  *
- * sdeh_simulate_fwd_train2 == sdeh_simulate_fwd for a training step (xs required) that also keeps what only the forward launch
- * knows cheaply:
- *   sc     [n_steps, batch, d]  the score entering the control before clip_score and gamma(t) (models/reparam.py:56-83,131-197:
- *                               target score, lerp of prior and target score, ...); NULL for ClippedCtrl
- *   tscore [batch, d] or NULL   1[|target.unnorm_log_prob(x_T)| <= clip_target] * target.score(x_T)  (needed by "kl" methods
- *                               with SDEH_FLAG_TERMINAL_TARGET)
- * Returns 0, or 1 when the launch was served by a kernel that writes neither (then use the plane-based backward).
+ * sdeh_simulate_fwd_train2 == sdeh_simulate_fwd for a training step that keeps what the fused backward reads, all
+ * COORDINATE-MAJOR (consecutive trajectories at consecutive addresses: both kernels move whole cache lines):
+ *   xs     [n_steps+1, d, batch]  the trajectory
+ *   sc     [n_steps, d, batch]    the score entering the control before clip_score and gamma(t) (models/reparam.py:56-83,131-197:
+ *                                 target score, lerp of prior and target score, ...); NULL for ClippedCtrl
+ *   tscore [d, batch] or NULL     1[|target.unnorm_log_prob(x_T)| <= clip_target] * target.score(x_T)  (needed by "kl" methods
+ *                                 with SDEH_FLAG_TERMINAL_TARGET)
+ * Returns 0, or 1 when the launch was served by a kernel that writes none of them (then use the plane-based backward).
  *
- * sdeh_ctrl_backward_fused: same problem / ts / noise / seed / offset / row_offset as the forward call, grad_rnd [batch] =
+ * sdeh_ctrl_backward_fused: xs / sc / tscore as written by sdeh_simulate_fwd_train2 (noise, if given, is the caller's
+ * [n_steps, batch, d] tensor); same problem / ts / noise / seed / offset / row_offset as the forward call, grad_rnd [batch] =
  * d loss / d rnd_i.  `scratch` (sdeh_ctrl_backward_fused_sizes) holds per-team partial gradients, summed deterministically (no
  * atomics).  `out` (floats, with P = 32 * ceil(d / 32), gw = 2 if gamma(t) is scalar else 64):
  *   input_embed.weight [64, P] (columns >= d unused) | hidden_layer[l].weight [2][64, 64] | out_layer.weight [P, 64] |

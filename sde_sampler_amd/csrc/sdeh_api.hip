@@ -660,7 +660,7 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
 static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                          float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, float* zt_out, float* nn_out,
-                         bool* planes_written, void* stream, float* sc_out = nullptr, float* tsc_out = nullptr) {
+                         bool* planes_written, void* stream, float* sc_out = nullptr, float* tsc_out = nullptr, float* xs_cm = nullptr) {
   if (planes_written != nullptr) *planes_written = false;
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
   if ((gp != nullptr || div_noise != nullptr) && (pr == nullptr || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)))
@@ -672,7 +672,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   const int d = net.dim;
   if (plan->wide)
     return simulate_wide(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise,
-                         zt_out != nullptr || nn_out != nullptr || sc_out != nullptr || tsc_out != nullptr);
+                         zt_out != nullptr || nn_out != nullptr || sc_out != nullptr || tsc_out != nullptr || xs_cm != nullptr);
   if (pr->flags & SDEH_FLAG_INFERENCE_CTRL)
     return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise);
   const WsLayout& L = ck.L;
@@ -712,13 +712,13 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);
   } else {
     A.zt_out = zt_out; A.nn_out = nn_out;  // only the wave-specialised kernel writes the training planes
-    A.sc_out = sc_out; A.tsc_out = tsc_out;
+    A.sc_out = sc_out; A.tsc_out = tsc_out; A.xs_cm = xs_cm;
     rc = v->fn(A, st);
     if (rc == SDEH_OK && planes_written != nullptr)
-      *planes_written = (zt_out != nullptr && nn_out != nullptr) || sc_out != nullptr || tsc_out != nullptr;
+      *planes_written = (zt_out != nullptr && nn_out != nullptr) || xs_cm != nullptr;
     // image + exchange buffers beyond 160 KiB (deep networks): the single-wave kernel needs less LDS
     if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) {
-      A.zt_out = nullptr; A.nn_out = nullptr; A.sc_out = nullptr; A.tsc_out = nullptr;
+      A.zt_out = nullptr; A.nn_out = nullptr; A.sc_out = nullptr; A.tsc_out = nullptr; A.xs_cm = nullptr;
       if (planes_written != nullptr) *planes_written = false;
       rc = plan->variant->fn_legacy(A, st);
       snprintf(plan->last_kernel, sizeof(plan->last_kernel), "traj_legacy<%s>", plan->variant->name);
@@ -752,16 +752,16 @@ int32_t sdeh_simulate_fwd_train(SdehPlan* plan, const SdehProblem* pr, const flo
 int32_t sdeh_simulate_fwd_train2(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                                  int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                                  float* x_T, float* rnd, float* xs, float* sc, float* tscore, void* stream) {
-  if (xs == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd_train2: xs is required");
+  if (xs == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd_train2: xs (the coordinate-major trajectory plane) is required");
   if (pr != nullptr && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
     return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train2: the Bridge forward keeps no planes (use sdeh_simulate_fwd_aux)");
   if (pr != nullptr && pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr)
     return fail(SDEH_ERR_INVALID, "simulate_fwd_train2: sc is required for controls with a score term");
   bool written = false;
-  const int rc = simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, nullptr, nullptr,
-                               nullptr, nullptr, &written, stream, sc, tscore);
+  const int rc = simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, &written, stream, sc, tscore, xs);
   if (rc != SDEH_OK) return rc;
-  return written || (sc == nullptr && tscore == nullptr) ? SDEH_OK : 1;  // 1: integrated by a kernel that writes neither plane
+  return written ? SDEH_OK : 1;  // 1: integrated by a kernel that writes none of the planes
 }
 
 int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,

@@ -20,7 +20,9 @@
 //     the accumulator layout (lane (j, h), register q  <->  coordinate 32 tile + (q & 3) + 8 (q >> 2) + 4 h of trajectory j), wave r
 //     owning coordinate tile r (d <= 32: both waves mirror tile 0) -- all 64 lanes work, no T-layout shuffles.
 //   * what only the forward launch can know cheaply comes from it (sdeh_simulate_fwd_train2): the combined score entering the control
-//     sc [T, B, d] (before clip and gamma; for mixture targets this is the expensive part) and d(terminal target cost)/dx_T [B, d].
+//     sc (before clip and gamma; for mixture targets this is the expensive part) and d(terminal target cost)/dx_T.  These planes and
+//     the trajectory itself are coordinate-major ([T+1][d][B]): the forward kernel (lane = trajectory) stores and this kernel
+//     (lane = trajectory, register = coordinate) loads whole 128-byte lines.
 //
 // Modes: BPTT (method kl / kl_ito: a team walks its 32 trajectories backwards through time carrying lambda_t) and row-parallel
 // (lv / lv_traj: the trajectory is a constant of the graph, (step, tile) items are independent).  The semantics (what is constant,
@@ -77,49 +79,42 @@ __device__ __forceinline__ f32x16 rows16(const float* __restrict__ p) {
 }
 
 // out = init + W[rows of this lane's tile][:] . b     (wrow = &W[(32 R + i) * ld + 4 h]; k-group s covers columns 8 s + 4 h .. + 3,
-// the channels of accumulator registers 4 s .. 4 s + 3 of the B operand)
+// the channels of accumulator registers 4 s .. 4 s + 3 of the B operand).  One accumulator: a dependent v_mfma_f32_32x32x2_f32
+// issues every 69.5 cycles instead of 64.6 (profiles/r02_ubench.txt) -- cheaper than a second accumulator's registers and adds.
 template <int NT>
 __device__ __forceinline__ f32x16 mm_rows(const float* __restrict__ wrow, const f32x16 (&b)[NT], int ng, const f32x16& init) {
-  f32x16 a0 = init, a1;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) a1[q] = 0.0f;
+  f32x16 acc = init;
 #pragma unroll
   for (int s = 0; s < 4 * NT; ++s) {
     if (s < ng) {
       const float4 w = *reinterpret_cast<const float4*>(wrow + 8 * s);
-      if (s & 1) {
-        a1 = SDEH_MFMA(w.x, b[s / 4][4 * (s % 4) + 0], a1); a1 = SDEH_MFMA(w.y, b[s / 4][4 * (s % 4) + 1], a1);
-        a1 = SDEH_MFMA(w.z, b[s / 4][4 * (s % 4) + 2], a1); a1 = SDEH_MFMA(w.w, b[s / 4][4 * (s % 4) + 3], a1);
-      } else {
-        a0 = SDEH_MFMA(w.x, b[s / 4][4 * (s % 4) + 0], a0); a0 = SDEH_MFMA(w.y, b[s / 4][4 * (s % 4) + 1], a0);
-        a0 = SDEH_MFMA(w.z, b[s / 4][4 * (s % 4) + 2], a0); a0 = SDEH_MFMA(w.w, b[s / 4][4 * (s % 4) + 3], a0);
-      }
+      acc = SDEH_MFMA(w.x, b[s / 4][4 * (s % 4) + 0], acc);
+      acc = SDEH_MFMA(w.y, b[s / 4][4 * (s % 4) + 1], acc);
+      acc = SDEH_MFMA(w.z, b[s / 4][4 * (s % 4) + 2], acc);
+      acc = SDEH_MFMA(w.w, b[s / 4][4 * (s % 4) + 3], acc);
     }
   }
-  return a0 + a1;
+  return acc;
 }
 
 // out = W[:, columns of this lane's tile]^T . b     (wcol = &W[(4 h) * LD + 32 R + i]; k-group s covers rows 8 s + 4 h .. + 3)
 template <int NT, int LD>
 __device__ __forceinline__ f32x16 mm_cols(const float* __restrict__ wcol, const f32x16 (&b)[NT], int ng) {
-  f32x16 a0, a1;
+  f32x16 acc;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) a0[q] = a1[q] = 0.0f;
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
 #pragma unroll
   for (int s = 0; s < 4 * NT; ++s) {
     if (s < ng) {
       const float* __restrict__ p = wcol + 8 * s * LD;
       const float w0 = p[0], w1 = p[LD], w2 = p[2 * LD], w3 = p[3 * LD];
-      if (s & 1) {
-        a1 = SDEH_MFMA(w0, b[s / 4][4 * (s % 4) + 0], a1); a1 = SDEH_MFMA(w1, b[s / 4][4 * (s % 4) + 1], a1);
-        a1 = SDEH_MFMA(w2, b[s / 4][4 * (s % 4) + 2], a1); a1 = SDEH_MFMA(w3, b[s / 4][4 * (s % 4) + 3], a1);
-      } else {
-        a0 = SDEH_MFMA(w0, b[s / 4][4 * (s % 4) + 0], a0); a0 = SDEH_MFMA(w1, b[s / 4][4 * (s % 4) + 1], a0);
-        a0 = SDEH_MFMA(w2, b[s / 4][4 * (s % 4) + 2], a0); a0 = SDEH_MFMA(w3, b[s / 4][4 * (s % 4) + 3], a0);
-      }
+      acc = SDEH_MFMA(w0, b[s / 4][4 * (s % 4) + 0], acc);
+      acc = SDEH_MFMA(w1, b[s / 4][4 * (s % 4) + 1], acc);
+      acc = SDEH_MFMA(w2, b[s / 4][4 * (s % 4) + 2], acc);
+      acc = SDEH_MFMA(w3, b[s / 4][4 * (s % 4) + 3], acc);
     }
   }
-  return a0 + a1;
+  return acc;
 }
 
 // acc0 (+ acc1) += delta[tile R] . a[tile c0 (, c0 + 1)]^T over the 32 trajectories of the planes; bsum += this lane's 16 delta
@@ -222,11 +217,8 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   const int cb = 32 * ct + 4 * h;  // first coordinate of this lane's registers: coordinate(q) = cb + rrow(q)
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
 
-  // per-coordinate tables of the own coordinate tile
-  const f32x16 pmu = rows16(tabs + 0 * 64 + cb), pis = rows16(tabs + 1 * 64 + cb);
-  f32x16 valid;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) valid[q] = cb + rrow(q) < d ? 1.0f : 0.0f;
+  // Coordinates >= d of a tile need no masks: their x / sc / xi are loaded or drawn as zeros, the weight copies and Gaussian tables
+  // are zero-padded, so every quantity derived from them stays exactly zero.
 
   // weight-gradient accumulators: [0, OTD) input_embed (row tile r x coordinate tiles); then hidden layer l: row tile r x 2;
   // then out_layer: OTD == 2: coordinate tile r x 2 channel tiles; OTD == 1: coordinate tile 0 x channel tile r
@@ -253,7 +245,13 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
     const float wi = live ? A.grad_rnd[lrow] : 0.0f;
     const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
 
-    auto load16c = [&](const float* __restrict__ rowp) {  // 16 coordinates of the own tile from a [.., d] row
+    auto load16c = [&](const float* __restrict__ plane) {  // 16 coordinates of the own tile from a coordinate-major [d][B] plane
+      f32x16 v;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = cb + rrow(q) < d ? plane[(long long)(cb + rrow(q)) * B + lrow] : 0.0f;
+      return v;
+    };
+    auto load16r = [&](const float* __restrict__ rowp) {  // ... from a row of a [.., d] tensor (the caller's noise)
       f32x16 v;
 #pragma unroll
       for (int q = 0; q < 16; ++q) v[q] = cb + rrow(q) < d ? rowp[cb + rrow(q)] : 0.0f;
@@ -265,20 +263,20 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
     for (int q = 0; q < 16; ++q) lam[q] = 0.0f;
     if constexpr (BPTT) {  // lambda_T = w_i d(terminal costs)/dx_T  (losses/oc.py:225,337,449-450)
       if (flags & SDEH_FLAG_TERMINAL_SECOND) {
-        const f32x16 xT = load16c(A.xs + ((long long)T * B + lrow) * d);
+        const f32x16 xT = load16c(A.xs + (long long)T * d * B);
         const f32x16 smu = rows16(tabs + 2 * 64 + cb), sis = rows16(tabs + 3 * 64 + cb);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) lam[q] = wi * (smu[q] - xT[q]) * sis[q] * valid[q];
+        for (int q = 0; q < 16; ++q) lam[q] = wi * (smu[q] - xT[q]) * sis[q];
       }
       if ((flags & SDEH_FLAG_TERMINAL_TARGET) && A.tscore != nullptr) {
-        const f32x16 st = load16c(A.tscore + lrow * d);
+        const f32x16 st = load16c(A.tscore);
 #pragma unroll
         for (int q = 0; q < 16; ++q) lam[q] = fmaf(-wi, st[q], lam[q]);
       }
     }
     const int t_first = BPTT ? T - 1 : (int)(item_c / A.n_tiles);
     const int t_last = BPTT ? 0 : t_first;
-    f32x16 xnext = load16c(A.xs + ((long long)t_first * B + lrow) * d);
+    f32x16 xnext = load16c(A.xs + (long long)t_first * d * B);
 
     for (int t = t_first; t >= t_last; --t) {
       float* __restrict__ Acur = pl + par * PLANE;        // x, later a_2
@@ -286,13 +284,14 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       float* __restrict__ D0 = pl + 2 * PLANE;
       float* __restrict__ D1 = pl + 3 * PLANE;
       const f32x16 x = xnext;
-      if (t > t_last) xnext = load16c(A.xs + ((long long)(t - 1) * B + lrow) * d);
+      if (t > t_last) xnext = load16c(A.xs + (long long)(t - 1) * d * B);
+      // the step's other inputs: requested first, consumed after the forward pass
       f32x16 scv, xi;
-      if (has_score) scv = load16c(A.sc + ((long long)t * B + lrow) * d);
+      if (has_score) scv = load16c(A.sc + (long long)t * d * B);
       if (ito) {
         float n[16];
         if (A.noise != nullptr) {
-          const f32x16 nv = load16c(A.noise + ((long long)t * B + lrow) * d);
+          const f32x16 nv = load16r(A.noise + ((long long)t * B + lrow) * d);
 #pragma unroll
           for (int q = 0; q < 16; ++q) n[q] = nv[q];
         } else {
@@ -306,7 +305,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
           }
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) xi[q] = n[q] * valid[q];
+        for (int q = 0; q < 16; ++q) xi[q] = cb + rrow(q) < d ? n[q] : 0.0f;
       }
       cfp cf = as_const(ws + L.coef + t * kCoefStride);
       const float sig = cf[CF_SIGMA], wl = cf[CF_W];
@@ -353,6 +352,14 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         float gsum = 0.0f;
         f32x16 gcoord;
         const float mult = (ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig) * A.scale_score;
+        f32x16 rr;  // reference control sigma * prior.score(x) (solver/oc.py:305-306)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rr[q] = 0.0f;
+        if (BPTT && refc) {
+          const f32x16 pmu = rows16(tabs + 0 * 64 + cb), pis = rows16(tabs + 1 * 64 + cb);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) rr[q] = sig * (pmu[q] - x[q]) * pis[q];
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           float mfac = 0.0f, csc = 0.0f, keep_s = 0.0f;
@@ -365,11 +372,9 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
           float gc = ito ? wi * c_i * xi[q] : 0.0f;
           if constexpr (BPTT) {
             const float u = clipf(nn[q], A.clip_model) + mfac * csc;
-            const float rr = refc ? sig * (pmu[q] - x[q]) * pis[q] : 0.0f;
-            gc = wi * fmaf(u - rr, cdt, ito ? c_i * xi[q] : 0.0f);
+            gc = wi * fmaf(u - rr[q], cdt, ito ? c_i * xi[q] : 0.0f);
           }
-          gc *= valid[q];
-          const float gq = BPTT ? fmaf(c_u, lam[q], gc) * valid[q] : gc;
+          const float gq = BPTT ? fmaf(c_u, lam[q], gc) : gc;
           Gc[q] = gc;
           G[q] = gq;
           const float gg = gq * mult * csc;
@@ -434,6 +439,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       }
       if constexpr (BPTT) {
         // ===================================================================================== adjoint update
+        //   lambda_t = c_x lambda_{t+1} + W_in^T delta_0 + (d score term / d x)^T G + direct cost terms
         full[0] = plane_get(D1, 0, j, h); full[1] = plane_get(D1, 1, j, h);
         const f32x16 dx = mm_cols<2, RSI>(Win + (4 * h) * RSI + 32 * ct + j, full, 8);
         // score terms the reference detaches (reparam.py:58,134,169,188) or obtains by autograd without a graph carry no Jacobian
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         f32x16 vt;
 #pragma unroll
         for (int q = 0; q < 16; ++q) vt[q] = 0.0f;
-        if (jac_t != 0.0f) {
+        if (jac_t != 0.0f) {  // closed-form target scores are differentiated through x
           if (A.target.kind == SDEH_DENS_DIAG_GAUSS) {
             const f32x16 tis = rows16(tabs + 5 * 64 + cb);
 #pragma unroll
@@ -474,12 +480,15 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
           }
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          float v = fmaf(c_x, lam[q], dx[q]);
-          v = fmaf(jac_t, vt[q], v);
-          v = fmaf(-jac_p * pis[q], cvec[q], v);           // Gaussian prior: J = -1/sigma^2
-          if (refc) v = fmaf(sig * pis[q], Gc[q], v);      // cost depends on x through sigma * prior.score(x)
-          lam[q] = v * valid[q];
+        for (int q = 0; q < 16; ++q) lam[q] = fmaf(jac_t, vt[q], fmaf(c_x, lam[q], dx[q]));
+        if (jac_p != 0.0f || refc) {
+          const f32x16 pis = rows16(tabs + 1 * 64 + cb);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            float v = fmaf(-jac_p * pis[q], cvec[q], lam[q]);  // Gaussian prior: J = -1/sigma^2
+            if (refc) v = fmaf(sig * pis[q], Gc[q], v);         // cost depends on x through sigma * prior.score(x)
+            lam[q] = v;
+          }
         }
       }
       par ^= 1;

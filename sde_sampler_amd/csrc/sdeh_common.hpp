@@ -116,8 +116,10 @@ struct TrajArgs {
   float* zt_out;  // [(Lh+1), C, T*B] or null: pre-activations of every layer, coordinate-major
   float* nn_out;  // [T, B, d] or null: raw network output (before the clamp) per step
   // training forward for the fused backward (sdeh_simulate_fwd_train2)
-  float* sc_out;  // [T, B, d] or null: combined score entering the control, before clip_score and gamma(t)
-  float* tsc_out; // [B, d] or null: 1[|log rho(x_T)| <= clip_target] * target.score(x_T)  (d terminal target cost / d x_T, negated)
+  // (coordinate-major planes: consecutive trajectories at consecutive addresses -- coalesced for both kernels)
+  float* xs_cm;   // [T+1, d, B] or null: the trajectory
+  float* sc_out;  // [T, d, B] or null: combined score entering the control, before clip_score and gamma(t)
+  float* tsc_out; // [d, B] or null: 1[|log rho(x_T)| <= clip_target] * target.score(x_T)  (d terminal target cost / d x_T, negated)
 };
 
 // sdeh_bridge_div_backward (sdeh_bridge.hpp): gradient of  sum_n w_i sigma dt div_x v(x_n)  w.r.t. the inference network
@@ -175,11 +177,11 @@ struct BwdfArgs {
   const float* b_hid[2];  // [64]
   const float* w_out;     // [d, 64]
   const float* b_out;     // [d]
-  const float* xs;        // [T+1, B, d]
+  const float* xs;        // [T+1, d, B]  (coordinate-major, as sdeh_simulate_fwd_train2 writes it)
   const float* noise;     // [T, B, d] or null (Philox replay)
   const float* grad_rnd;  // [B]
-  const float* sc;        // [T, B, d] or null (ClippedCtrl)
-  const float* tscore;    // [B, d] or null
+  const float* sc;        // [T, d, B] or null (ClippedCtrl)
+  const float* tscore;    // [d, B] or null
   float* wpart;           // [n_slots][wsize]
   float* epart;           // [n_tiles][T][64]
   float* gpart;           // [n_tiles][T][gw]

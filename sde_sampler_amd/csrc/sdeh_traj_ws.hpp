@@ -617,6 +617,13 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j)
       if (!PAD || j < d) xs[lrow * d + j] = x[j];
   }
+  if constexpr (PLANES) {
+    if (A.xs_cm != nullptr && live) {  // the trajectory for the fused backward, coordinate-major [T+1][d][B]
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        if (!PAD || j < d) A.xs_cm[(long long)j * A.batch + lrow] = x[j];
+    }
+  }
   const bool lv = flags & SDEH_FLAG_CHANGE_SDE_CTRL;
   const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
   const bool refc = REFC >= 0 ? REFC != 0 : (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
@@ -659,11 +666,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         for (int j = 0; j < DP; ++j) sterm[j] = w1 * psc[j];
       }
       if constexpr (PLANES) {  // the fused backward reads the combined score instead of re-evaluating the densities
-        if (A.sc_out != nullptr && live) {
-          float* __restrict__ sp = A.sc_out + ((long long)i * A.batch + lrow) * d;
+        if (A.sc_out != nullptr && live) {  // coordinate-major [T][d][B]: consecutive lanes, consecutive addresses
+          float* __restrict__ sp = A.sc_out + (long long)i * d * A.batch + lrow;
 #pragma unroll
           for (int j = 0; j < DP; ++j)
-            if (!PAD || j < d) sp[j] = sterm[j];
+            if (!PAD || j < d) sp[(long long)j * A.batch] = sterm[j];
         }
       }
       cfp gam = as_const(ws + L.gam + i * L.g);
@@ -780,6 +787,14 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       for (int j = 0; j < DP; ++j)
         if (!PAD || j < d) xp[j] = x[j];
     }
+    if constexpr (PLANES) {
+      if (A.xs_cm != nullptr && live) {
+        float* __restrict__ xp = A.xs_cm + (long long)(i + 1) * d * A.batch + lrow;
+#pragma unroll
+        for (int j = 0; j < DP; ++j)
+          if (!PAD || j < d) xp[(long long)j * A.batch] = x[j];
+      }
+    }
   }
 
   // ---- terminal costs (oc.py:225, 337, 449-450) ----------------------------------------------------------
@@ -801,7 +816,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       if (live) {
 #pragma unroll
         for (int j = 0; j < DP; ++j)
-          if (!PAD || j < d) A.tsc_out[row * d + j] = keep * st[j];
+          if (!PAD || j < d) A.tsc_out[(long long)j * A.batch + row] = keep * st[j];
       }
     }
   }
@@ -822,7 +837,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   const bool pair_fits = C == 64 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
-  const bool planes = (a.zt_out != nullptr && a.nn_out != nullptr) || a.sc_out != nullptr || a.tsc_out != nullptr;
+  const bool planes = (a.zt_out != nullptr && a.nn_out != nullptr) || a.sc_out != nullptr || a.tsc_out != nullptr || a.xs_cm != nullptr;
   static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {

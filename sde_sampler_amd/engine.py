@@ -490,8 +490,8 @@ class TrajectoryEngine:
             div_noise: torch.Tensor | None = None, want_planes: bool = False):
         """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None); with `want_gp`
         (Bridge training) additionally the plane u + v [T,B,d] as a fourth element; with `want_planes` (training without an
-        inference control) a fourth element: ("fused", sc [T,B,d] | None, tscore [B,d] | None) when the fused backward takes the
-        problem, else (zt [(Lh+1),C,T*B], nn [T,B,d]); None when the launch kept nothing."""
+        inference control) a fourth element: ("fused", sc [T,d,B] | None, tscore [d,B] | None) when the fused backward takes the
+        problem (xs is then the coordinate-major [T+1,d,B] plane), else (zt [(Lh+1),C,T*B], nn [T,B,d]); None when the launch kept nothing."""
         if not x.is_cuda:
             raise RuntimeError("the HIP trajectory engine needs CUDA/HIP tensors (got a CPU tensor); "
                                "there is no CPU path in this package")
@@ -536,21 +536,23 @@ class TrajectoryEngine:
                 raise ValueError("want_planes goes with return_traj=True and without the Bridge outputs")
             if lib.sdeh_ctrl_backward_fused_supported(plan.handle, C.byref(pr)):
                 # fused backward (csrc/sdeh_bwdf.hip): the combined score per step and the terminal target score, no [C, T*B] planes
-                sc = (torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32)
+                # (coordinate-major planes: [.., d, B])
+                xs_cm = torch.empty((n_steps + 1, dim, batch), device=device, dtype=torch.float32)
+                sc = (torch.empty((n_steps, dim, batch), device=device, dtype=torch.float32)
                       if pr.ctrl_kind != L.CTRL_CLIPPED else None)
                 bptt = not (pr.flags & L.FLAG_CHANGE_SDE_CTRL)
-                tscore = (torch.empty((batch, dim), device=device, dtype=torch.float32)
+                tscore = (torch.empty((dim, batch), device=device, dtype=torch.float32)
                           if bptt and (pr.flags & L.FLAG_TERMINAL_TARGET) else None)
                 with torch.cuda.device(device):
                     status = lib.sdeh_simulate_fwd_train2(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
                                                           seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
-                                                          rnd.data_ptr(), xs.data_ptr(), None if sc is None else sc.data_ptr(),
+                                                          rnd.data_ptr(), xs_cm.data_ptr(), None if sc is None else sc.data_ptr(),
                                                           None if tscore is None else tscore.data_ptr(), stream)
                 if status < 0:
                     L.check(status)
                 if status == 0:
-                    return x_T, rnd, xs, ("fused", sc, tscore)
-                return x_T, rnd, xs, None  # served by a kernel that keeps nothing: the plane-based backward re-evaluates
+                    return x_T, rnd, xs_cm, ("fused", sc, tscore)
+                del xs_cm, sc, tscore  # integrated by a kernel that keeps no planes (mixture tables beyond LDS): once more, the plane way
             zt = torch.empty((pr.base_model.n_hidden + 1, pr.base_model.channels, n_steps * batch), device=device, dtype=torch.float32)
             nn = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32)
             with torch.cuda.device(device):

@@ -58,7 +58,7 @@ def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torc
     ctrl, engine = loss.generative_ctrl, loss.engine
     base = ctrl.base_model
     dev = xs.device
-    T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+    T, d, B = xs.shape[0] - 1, xs.shape[1], xs.shape[2]  # coordinate-major planes of sdeh_simulate_fwd_train2
     score_model = getattr(ctrl, "score_model", None) if pr.ctrl_kind != L.CTRL_CLIPPED else None
     g = 1 if score_model is None else score_model.out_layer.out_features
     bptt = not (pr.flags & L.FLAG_CHANGE_SDE_CTRL)

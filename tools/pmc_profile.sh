@@ -24,6 +24,6 @@ run grbm GRBM_GUI_ACTIVE GRBM_COUNT
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 cd "$ROOT"
-python tools/pmc_summary.py "$OUT" | tee "$OUT/summary.txt"
+python tools/pmc_summary.py "$OUT" ${KERNEL:-} | tee "$OUT/summary.txt"   # KERNEL=bwdf_kernel: another kernel's counters
 # the raw rocprofv3 databases are large (gpurun_out is capped at 64 MiB): keep only the summary and logs
 find "$OUT" -name "*.db" -delete

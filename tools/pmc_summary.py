@@ -6,7 +6,8 @@ import sqlite3
 import sys
 
 
-def main(out):
+def main(out, pattern=None):
+    like = (f"{{c}} like '%{pattern}%'" if pattern else "({c} like '%traj%' or {c} like '%bridge_wide_kernel%')")
     for db in sorted(glob.glob(f"{out}/*/**/*.db", recursive=True)):
         con = sqlite3.connect(db)
         tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
@@ -17,11 +18,11 @@ def main(out):
         cols = [d[1] for d in con.execute(f"pragma table_info({view})")]
         namecol = "name" if "name" in cols else ("kernel_name" if "kernel_name" in cols else None)
         rows = con.execute(f"select counter_name, avg(value), count(*) from (select dispatch_id, counter_name, sum(value) as value "
-                           f"from {view} where ({namecol} like '%traj%' or {namecol} like '%bridge_wide_kernel%') group by dispatch_id, counter_name) group by counter_name").fetchall()
+                           f"from {view} where {like.format(c=namecol)} group by dispatch_id, counter_name) group by counter_name").fetchall()
         print(f"# {db.split('/')[-3]}")
         for name, val, n in rows:
             print(f"  {name:34s} {val:20.1f}   (avg over {n} dispatches)")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)  # optional: kernel-name pattern (default: the trajectory kernels)

@@ -182,6 +182,34 @@ def extra_block(device, B: int) -> dict:
         tf = algorithmic_flops(spec) * B * T / (ms * 1e-3) / 1e12
         out["headline_generic_kernel" if generic else name] = {"kernel_ms": ms, "algorithmic_tflops": tf,
                                                                "frac": tf / PEAK_FP32_TFLOPS}
+    # One training step of BASELINE configs[1] (DIS, method kl, GMM d = 2, T = 100) and of configs[2]'s shape (PIS kl, GMM-40 d = 50,
+    # T = 200) at this batch: kernel times of the training forward and of the fused backward (back-propagation through time + weight
+    # gradients, csrc/sdeh_bwdf.hip), and the backward's rate -- 2 x (4dC + 2 Lh C^2) FLOPs per trajectory-step (adjoint chain +
+    # weight gradients; its re-evaluation of the network is not counted).
+    for name in ("cfg2_gmm2_dis_kl", "cfg3_gmm50_pis_kl"):
+        spec = problems.baseline_spec(name)
+        spec["batch"] = B
+        prob = problems.build(spec, device=device)
+        eng = prob.loss.engine
+        eng.timing = True
+        x0 = prob.prior.sample((B,))
+        t_f, t_b = [], []
+        for rep in range(4):
+            prob.ctrl.zero_grad()
+            val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+            torch.cuda.synchronize()
+            t_f.append(eng.last_kernel_ms())
+            val.backward()
+            torch.cuda.synchronize()
+            t_b.append(eng.last_kernel_ms())
+            bwd_name = eng.last_kernel_name()
+        T = prob.ts.numel() - 1
+        d, c, lh = spec["target"]["dim"], spec["net"]["channels"], spec["net"]["num_layers"] - 2
+        tb = min(t_b[1:])
+        tf = 2 * (4 * d * c + 2 * lh * c * c) * B * T / (tb * 1e-3) / 1e12
+        out["train_step_" + name] = {"method": "kl", "steps": T, "forward_kernel_ms": min(t_f[1:]), "backward_kernel_ms": tb,
+                                     "backward_kernel": bwd_name, "backward_algorithmic_tflops": tf,
+                                     "backward_frac": tf / PEAK_FP32_TFLOPS}
     return out
 
 

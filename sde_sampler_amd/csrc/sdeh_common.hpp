@@ -110,6 +110,7 @@ struct TrajArgs {
   int inf_kind, inf_act;
   float inf_clip_model, inf_clip_score, inf_scale_score;
   float* gp;  // [T, B, d] or null: u + v per step (needed by the backward pass of the inference network)
+  int flag_sync;  // wave-specialised kernel: pair-level LDS counters instead of workgroup barriers for the V <-> M hand-off
   int half;   // wave-specialised kernel: a group is 32 trajectories (one MFMA column tile) instead of 64 -- small batches
   const float* div_noise;  // [T, B, d] or null: Hutchinson probe vectors (training with div_estimator); null = exact divergence
   // training forward (sdeh_simulate_fwd_train): what the backward kernels would otherwise recompute

@@ -39,6 +39,22 @@ namespace sdeh {
 // waves exchange lives in LDS (the exchange buffers, the pair mode's activation parking), so lgkmcnt(0) is all a step needs.
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Pair-level hand-off without the workgroup barrier: a group's V and M wave only ever wait for EACH OTHER (x from V to M, the
+// network output from M to V), but s_barrier makes all groups of the workgroup wait for the slowest pair twice per step.  Each
+// group owns two step counters in LDS; the producer bumps its counter after its LDS writes (a wave's LDS operations execute in
+// order, so the data is visible before the counter), the consumer polls with s_sleep between the reads (it shares its SIMD with
+// the producer at G = 4: a sleeping wave issues nothing).
+__device__ __forceinline__ void ws_flag_set(int* flag, int value) {
+  asm volatile("" ::: "memory");
+  *reinterpret_cast<volatile int*>(flag) = value;
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void ws_flag_wait(int* flag, int value) {
+  asm volatile("" ::: "memory");
+  while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(flag)) < value) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+
 constexpr int kWsGroups = 4;  // most trajectory groups (of 64) per workgroup; the launcher picks 4 or 2 (blockDim.x = 128 G)
 
 // rows of the exchange buffer: every coordinate an M-layout register can address
@@ -524,6 +540,10 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int i = tid; i < L.lds_floats / 4; i += (int)blockDim.x) dst[i] = src[i];
   }
   float* __restrict__ xbuf = lds + L.lds_floats + group * (XR * 64);
+  // hand-off counters of the group (behind the exchange buffers): [0] x published by V, [1] network output published by M
+  int* hand = reinterpret_cast<int*>(lds + L.lds_floats + kWsGroups * (XR * 64)) + 2 * group;
+  const bool fsync = A.flag_sync != 0 && !pair;
+  if (fsync && tid < 2 * kWsGroups) reinterpret_cast<int*>(lds + L.lds_floats + kWsGroups * (XR * 64))[tid] = 0;
 
   const int ctrl_kind = CTRL >= 0 ? CTRL : A.ctrl_kind, loss_kind = LOSS >= 0 ? LOSS : A.loss_kind;
   const int gmmv = GMMV >= 0 ? GMMV : L.gmm_lds, act = ACT >= 0 ? ACT : A.act;
@@ -561,7 +581,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     f32x16 emb[OT];
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (ot * 2 + h) * 16);
-    ws_barrier();  // barrier A: x_0 published
+    if (fsync) ws_flag_wait(hand, 1);
+    else ws_barrier();  // barrier A: x_0 published
     ZStore Z{nullptr, 0, 0};
     long long row0 = 0;
     if constexpr (PLANES) {
@@ -578,12 +599,14 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       SDEH_ACT_SWITCH(act, ACTC,
         if (A.half) ws_mlp_half<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z);
         else ws_mlp<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z););
-      ws_barrier();  // barrier B: network output published
+      if (fsync) ws_flag_set(hand + 1, i + 1);
+      else ws_barrier();  // barrier B: network output published
       if (i + 1 < n_steps) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (i + 1) * C + (ot * 2 + h) * 16);
       }
-      ws_barrier();  // barrier A: x_{i+1} published
+      if (fsync) ws_flag_wait(hand, i + 2);
+      else ws_barrier();  // barrier A: x_{i+1} published
     }
     return;
   }
@@ -629,7 +652,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   const bool refc = REFC >= 0 ? REFC != 0 : (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
   const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
-  ws_barrier();  // barrier A: x_0 published
+  if (fsync) ws_flag_set(hand, 1);
+  else ws_barrier();  // barrier A: x_0 published
 
   for (int i = 0; i < n_steps; ++i) {
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
@@ -734,7 +758,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j) x[j] = fmaf(c_n, xi[j], c_x * x[j]);
     SDEH_FENCE();
 
-    ws_barrier();  // barrier B: the M wave has published the network output
+    if (fsync) ws_flag_wait(hand + 1, i + 1);
+    else ws_barrier();  // barrier B: the M wave has published the network output
     // ---- u = clip(nn) + score term; publish x_{i+1} first: the M wave is idle until barrier A ------------------------
     float u[DP];
 #pragma unroll
@@ -749,7 +774,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       if (PAD) x[j] = j < d ? x[j] : 0.0f;
       xbuf[j * 64 + lane] = x[j];
     }
-    ws_barrier();  // barrier A: x_{i+1} published
+    if (fsync) ws_flag_set(hand, i + 2);
+    else ws_barrier();  // barrier A: x_{i+1} published
     // ---- running cost (losses/oc.py:204-211, 319-323, 418-431) and Ito term, in the shadow of the next network pass -----
     float cost = 0.0f;
     if (!refc) {
@@ -824,7 +850,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 
 template <int DP>
 inline size_t ws_lds_bytes(const WsLayout& L) {
-  return ((size_t)L.lds_floats + (size_t)kWsGroups * xrows<DP>() * 64) * sizeof(float);
+  return ((size_t)L.lds_floats + (size_t)kWsGroups * xrows<DP>() * 64 + 2 * kWsGroups) * sizeof(float);  // + the hand-off counters
 }
 // pair mode: one exchange buffer + the activation parking (2 parities x 2 tiles x 16 registers x 64 lanes)
 template <int DP>
@@ -865,6 +891,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   if (half == 2 && ws_pair_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_pair_lds_bytes<DP>(a.lay);
   TrajArgs b = a;
   b.half = half;
+  b.flag_sync = getenv("SDEH_WS_BARRIER") == nullptr ? 1 : 0;  // A/B aid (read per call): the workgroup-barrier hand-off
   const int rows = (half ? 32 : 64) * groups;
   const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);
   if (planes)

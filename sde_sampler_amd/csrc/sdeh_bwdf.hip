@@ -78,40 +78,45 @@ __device__ __forceinline__ f32x16 rows16(const float* __restrict__ p) {
   return v;
 }
 
-// out = init + W[rows of this lane's tile][:] . b     (wrow = &W[(32 R + i) * ld + 4 h]; k-group s covers columns 8 s + 4 h .. + 3,
-// the channels of accumulator registers 4 s .. 4 s + 3 of the B operand).  One accumulator: a dependent v_mfma_f32_32x32x2_f32
-// issues every 69.5 cycles instead of 64.6 (profiles/r02_ubench.txt) -- cheaper than a second accumulator's registers and adds.
-template <int NT>
-__device__ __forceinline__ f32x16 mm_rows(const float* __restrict__ wrow, const f32x16 (&b)[NT], int ng, const f32x16& init) {
+// out = init + W[rows of this lane's tile][:] . B     (wrow = &W[(32 R + i) * ld + 4 h]; k-group s covers columns 8 s + 4 h .. + 3 of W
+// and rows 8 s + 4 h .. + 3 of the B operand, which is read from its plane [row][trajectory] group by group: bcol = &plane[4 h * RS + j]).
+// One accumulator: a dependent v_mfma_f32_32x32x2_f32 issues every 69.5 cycles instead of 64.6 (profiles/r02_ubench.txt) -- cheaper
+// than a second accumulator's registers and adds.
+template <int NG>
+__device__ __forceinline__ f32x16 mm_rows(const float* __restrict__ wrow, const float* __restrict__ bcol, int ng, const f32x16& init) {
   f32x16 acc = init;
 #pragma unroll
-  for (int s = 0; s < 4 * NT; ++s) {
+  for (int s = 0; s < NG; ++s) {
     if (s < ng) {
       const float4 w = *reinterpret_cast<const float4*>(wrow + 8 * s);
-      acc = SDEH_MFMA(w.x, b[s / 4][4 * (s % 4) + 0], acc);
-      acc = SDEH_MFMA(w.y, b[s / 4][4 * (s % 4) + 1], acc);
-      acc = SDEH_MFMA(w.z, b[s / 4][4 * (s % 4) + 2], acc);
-      acc = SDEH_MFMA(w.w, b[s / 4][4 * (s % 4) + 3], acc);
+      const float* __restrict__ bp = bcol + 8 * s * RS;
+      const float b0 = bp[0], b1 = bp[RS], b2 = bp[2 * RS], b3 = bp[3 * RS];
+      acc = SDEH_MFMA(w.x, b0, acc);
+      acc = SDEH_MFMA(w.y, b1, acc);
+      acc = SDEH_MFMA(w.z, b2, acc);
+      acc = SDEH_MFMA(w.w, b3, acc);
     }
   }
   return acc;
 }
 
-// out = W[:, columns of this lane's tile]^T . b     (wcol = &W[(4 h) * LD + 32 R + i]; k-group s covers rows 8 s + 4 h .. + 3)
-template <int NT, int LD>
-__device__ __forceinline__ f32x16 mm_cols(const float* __restrict__ wcol, const f32x16 (&b)[NT], int ng) {
+// out = W[:, columns of this lane's tile]^T . B     (wcol = &W[(4 h) * LD + 32 R + i]; k-group s covers rows 8 s + 4 h .. + 3 of both)
+template <int NG, int LD>
+__device__ __forceinline__ f32x16 mm_cols(const float* __restrict__ wcol, const float* __restrict__ bcol, int ng) {
   f32x16 acc;
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
 #pragma unroll
-  for (int s = 0; s < 4 * NT; ++s) {
+  for (int s = 0; s < NG; ++s) {
     if (s < ng) {
       const float* __restrict__ p = wcol + 8 * s * LD;
+      const float* __restrict__ bp = bcol + 8 * s * RS;
       const float w0 = p[0], w1 = p[LD], w2 = p[2 * LD], w3 = p[3 * LD];
-      acc = SDEH_MFMA(w0, b[s / 4][4 * (s % 4) + 0], acc);
-      acc = SDEH_MFMA(w1, b[s / 4][4 * (s % 4) + 1], acc);
-      acc = SDEH_MFMA(w2, b[s / 4][4 * (s % 4) + 2], acc);
-      acc = SDEH_MFMA(w3, b[s / 4][4 * (s % 4) + 3], acc);
+      const float b0 = bp[0], b1 = bp[RS], b2 = bp[2 * RS], b3 = bp[3 * RS];
+      acc = SDEH_MFMA(w0, b0, acc);
+      acc = SDEH_MFMA(w1, b1, acc);
+      acc = SDEH_MFMA(w2, b2, acc);
+      acc = SDEH_MFMA(w3, b3, acc);
     }
   }
   return acc;
@@ -317,34 +322,29 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       // ======================================================================================= forward (re-evaluation at x_t)
       plane_put(Acur, ct, j, h, x);
       ws_barrier();  // 1
-      f32x16 full[2], g0, g1, g2, a1own;
+      f32x16 g0, g1, g2, a1own;
+      const int bofs = 4 * h * RS + j;  // this lane's column of a plane as an MFMA B operand
       {
-        f32x16 xf[OTD];
-#pragma unroll
-        for (int k = 0; k < OTD; ++k) xf[k] = plane_get(Acur, k, j, h);
-        const f32x16 z0 = mm_rows<OTD>(Win + (32 * r + j) * RSI + 4 * h, xf, A.n_kg, load16(ws + L.emb + t * C + (r * 2 + h) * 16));
+        const f32x16 z0 = mm_rows<4 * OTD>(Win + (32 * r + j) * RSI + 4 * h, Acur + bofs, A.n_kg, load16(ws + L.emb + t * C + (r * 2 + h) * 16));
         SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z0, a1own, g0););
       }
       plane_put(Aoth, r, j, h, a1own);
       ws_barrier();  // 2
       {
-        full[0] = plane_get(Aoth, 0, j, h); full[1] = plane_get(Aoth, 1, j, h);
-        const f32x16 z1 = mm_rows<2>(Whid + (32 * r + j) * RSW + 4 * h, full, 8, rows16(bh + 32 * r + 4 * h));
+        const f32x16 z1 = mm_rows<8>(Whid + (32 * r + j) * RSW + 4 * h, Aoth + bofs, 8, rows16(bh + 32 * r + 4 * h));
         f32x16 a2;
         SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z1, a2, g1););
         plane_put(Acur, r, j, h, a2);
       }
       ws_barrier();  // 3
       {
-        full[0] = plane_get(Acur, 0, j, h); full[1] = plane_get(Acur, 1, j, h);
-        const f32x16 z2 = mm_rows<2>(Whid + 64 * RSW + (32 * r + j) * RSW + 4 * h, full, 8, rows16(bh + 64 + 32 * r + 4 * h));
+        const f32x16 z2 = mm_rows<8>(Whid + 64 * RSW + (32 * r + j) * RSW + 4 * h, Acur + bofs, 8, rows16(bh + 64 + 32 * r + 4 * h));
         f32x16 a3;
         SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z2, a3, g2););
         plane_put(Aoth, r, j, h, a3);
       }
       ws_barrier();  // 4
-      full[0] = plane_get(Aoth, 0, j, h); full[1] = plane_get(Aoth, 1, j, h);
-      const f32x16 nn = mm_rows<2>(Wout + (32 * ct + j) * RSW + 4 * h, full, 8, rows16(bo + cb));
+      const f32x16 nn = mm_rows<8>(Wout + (32 * ct + j) * RSW + 4 * h, Aoth + bofs, 8, rows16(bo + cb));
 
       // ======================================================================================= upstream gradient of the control
       f32x16 G, Gc, cvec, dout;
@@ -408,25 +408,20 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       {
         if constexpr (OTD == 2) dw_acc<true>(D0, r, Aoth, 0, dw[OTD + 2 * LH], dw[NDW - 1], bs_out, j, h);
         else dw_acc<false>(D0, 0, Aoth, r, dw[OTD + 2 * LH], dw[OTD + 2 * LH], bs_out, j, h);
-        f32x16 df[OTD];
-#pragma unroll
-        for (int k = 0; k < OTD; ++k) df[k] = plane_get(D0, k, j, h);
-        dl = mm_cols<OTD, RSW>(Wout + (4 * h) * RSW + 32 * r + j, df, A.n_kg) * g2;
+        dl = mm_cols<4 * OTD, RSW>(Wout + (4 * h) * RSW + 32 * r + j, D0 + bofs, A.n_kg) * g2;
       }
       plane_put(D1, r, j, h, dl);
       ws_barrier();  // 6: delta_2 | a_2 (Acur)
       {
         dw_acc<true>(D1, r, Acur, 0, dw[OTD + 2], dw[OTD + 3], bs_hid[1], j, h);
-        full[0] = plane_get(D1, 0, j, h); full[1] = plane_get(D1, 1, j, h);
-        dl = mm_cols<2, RSW>(Whid + 64 * RSW + (4 * h) * RSW + 32 * r + j, full, 8) * g1;
+        dl = mm_cols<8, RSW>(Whid + 64 * RSW + (4 * h) * RSW + 32 * r + j, D1 + bofs, 8) * g1;
       }
       plane_put(D0, r, j, h, dl);
       plane_put(Aoth, r, j, h, a1own);
       ws_barrier();  // 7: delta_1 | a_1 (Aoth)
       {
         dw_acc<true>(D0, r, Aoth, 0, dw[OTD], dw[OTD + 1], bs_hid[0], j, h);
-        full[0] = plane_get(D0, 0, j, h); full[1] = plane_get(D0, 1, j, h);
-        dl = mm_cols<2, RSW>(Whid + (4 * h) * RSW + 32 * r + j, full, 8) * g0;
+        dl = mm_cols<8, RSW>(Whid + (4 * h) * RSW + 32 * r + j, D0 + bofs, 8) * g0;
       }
       plane_put(D1, r, j, h, dl);
       plane_put(Acur, ct, j, h, x);
@@ -440,8 +435,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       if constexpr (BPTT) {
         // ===================================================================================== adjoint update
         //   lambda_t = c_x lambda_{t+1} + W_in^T delta_0 + (d score term / d x)^T G + direct cost terms
-        full[0] = plane_get(D1, 0, j, h); full[1] = plane_get(D1, 1, j, h);
-        const f32x16 dx = mm_cols<2, RSI>(Win + (4 * h) * RSI + 32 * ct + j, full, 8);
+        const f32x16 dx = mm_cols<8, RSI>(Win + (4 * h) * RSI + 32 * ct + j, D1 + bofs, 8);
         // score terms the reference detaches (reparam.py:58,134,169,188) or obtains by autograd without a graph carry no Jacobian
         const float coef_t = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET ? wl : 0.0f);
         const float coef_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR ? 1.0f - wl : 0.0f;

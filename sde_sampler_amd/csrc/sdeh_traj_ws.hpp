@@ -518,7 +518,10 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
 // ---------------------------------------------------------------------------------------------------------
 // PLANES: the training forward (sdeh_simulate_fwd_train) -- the M waves also store the pre-activation planes, the V wave the raw
 // network output; a separate instantiation so that the evaluation kernel carries none of it.
-template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV, bool PLANES>
+// PLANES: 0 = evaluation; 1 = training forward that keeps the pre-activation planes and raw network outputs (sdeh_simulate_fwd_train);
+// 2 = training forward for the fused backward (sdeh_simulate_fwd_train2: coordinate-major trajectory / score planes from the V wave
+// only -- the M waves run the evaluation code: with the plane stores compiled in they lose 1 ms per 100 steps at B = 65 536).
+template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV, int PLANES>
 __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                       const float* __restrict__ noise, float* __restrict__ xT,
                                                       float* __restrict__ rnd_out, float* __restrict__ xs,
@@ -569,8 +572,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         const long long row0 = (long long)blockIdx.x * 32;
         ZStore Z{nullptr, (long long)n_steps * A.batch, A.zt_out == nullptr ? 0 : (int)(A.batch - row0 < 32 ? A.batch - row0 : 32)};
         for (int i = 0; i < n_steps; ++i) {
-          if constexpr (PLANES) Z.base = A.zt_out + (long long)i * A.batch + row0;
-          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, PLANES>(lds, xbuf, abuf, L, emb1, lane, mw, parity, Z););
+          if constexpr (PLANES == 1) Z.base = A.zt_out + (long long)i * A.batch + row0;
+          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, (PLANES == 1)>(lds, xbuf, abuf, L, emb1, lane, mw, parity, Z););
           ws_barrier();  // barrier B: network output published
           if (i + 1 < n_steps) emb1 = load16(ws + L.emb + (i + 1) * C + (mw * 2 + h) * 16);
           ws_barrier();  // barrier A: x_{i+1} published
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     else ws_barrier();  // barrier A: x_0 published
     ZStore Z{nullptr, 0, 0};
     long long row0 = 0;
-    if constexpr (PLANES) {
+    if constexpr (PLANES == 1) {
       const int rpg_m = A.half ? 32 : 64;
       row0 = (long long)blockIdx.x * (rpg_m * n_groups) + group * rpg_m;
       Z.N = (long long)n_steps * A.batch;
@@ -593,12 +596,12 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       if (A.zt_out == nullptr) Z.rows = 0;  // fused backward (sdeh_simulate_fwd_train2): no pre-activation planes
     }
     for (int i = 0; i < n_steps; ++i) {
-      if constexpr (PLANES) Z.base = A.zt_out + (long long)i * A.batch + row0;
+      if constexpr (PLANES == 1) Z.base = A.zt_out + (long long)i * A.batch + row0;
       // generic variants (ACT < 0): the activation id becomes a compile-time constant of three copies of the network --
       // selecting it per element costs a scalar branch per element pair inside the MFMA stages (1.5x on the whole kernel)
       SDEH_ACT_SWITCH(act, ACTC,
-        if (A.half) ws_mlp_half<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z);
-        else ws_mlp<DP, C, PLANES>(lds, xbuf, L, ACTC, emb, lane, Z););
+        if (A.half) ws_mlp_half<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z);
+        else ws_mlp<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z););
       if (fsync) ws_flag_set(hand + 1, i + 1);
       else ws_barrier();  // barrier B: network output published
       if (i + 1 < n_steps) {
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j)
       if (!PAD || j < d) xs[lrow * d + j] = x[j];
   }
-  if constexpr (PLANES) {
+  if constexpr (PLANES == 2) {
     if (A.xs_cm != nullptr && live) {  // the trajectory for the fused backward, coordinate-major [T+1][d][B]
 #pragma unroll
       for (int j = 0; j < DP; ++j)
@@ -689,7 +692,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < DP; ++j) sterm[j] = w1 * psc[j];
       }
-      if constexpr (PLANES) {  // the fused backward reads the combined score instead of re-evaluating the densities
+      if constexpr (PLANES == 2) {  // the fused backward reads the combined score instead of re-evaluating the densities
         if (A.sc_out != nullptr && live) {  // coordinate-major [T][d][B]: consecutive lanes, consecutive addresses
           float* __restrict__ sp = A.sc_out + (long long)i * d * A.batch + lrow;
 #pragma unroll
@@ -765,7 +768,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
       const float nn = xbuf[j * 64 + lane];
-      if constexpr (PLANES) {
+      if constexpr (PLANES == 1) {
         if (A.nn_out != nullptr && live && (!PAD || j < d)) A.nn_out[((long long)i * A.batch + lrow) * d + j] = nn;
       }
       u[j] = clipf(nn, A.clip_model) + sterm[j];
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       for (int j = 0; j < DP; ++j)
         if (!PAD || j < d) xp[j] = x[j];
     }
-    if constexpr (PLANES) {
+    if constexpr (PLANES == 2) {
       if (A.xs_cm != nullptr && live) {
         float* __restrict__ xp = A.xs_cm + (long long)(i + 1) * d * A.batch + lrow;
 #pragma unroll
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j)
       if (!PAD || j < d) xT[row * d + j] = x[j];
   }
-  if constexpr (PLANES) {  // d(terminal target cost)/dx_T, negated: the clamp's mask times target.score(x_T)  (oc.py:225)
+  if constexpr (PLANES == 2) {  // d(terminal target cost)/dx_T, negated: the clamp's mask times target.score(x_T)  (oc.py:225)
     if (A.tsc_out != nullptr && (flags & SDEH_FLAG_TERMINAL_TARGET)) {
       float st[DP];
       ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, st);
@@ -863,14 +866,17 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   const bool pair_fits = C == 64 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
-  const bool planes = (a.zt_out != nullptr && a.nn_out != nullptr) || a.sc_out != nullptr || a.tsc_out != nullptr || a.xs_cm != nullptr;
+  const int planes = (a.zt_out != nullptr && a.nn_out != nullptr) ? 1 : (a.sc_out != nullptr || a.tsc_out != nullptr || a.xs_cm != nullptr ? 2 : 0);
   static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, false>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 0>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, true>),
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 1>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 2>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
@@ -894,11 +900,14 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   b.flag_sync = getenv("SDEH_WS_BARRIER") == nullptr ? 1 : 0;  // A/B aid (read per call): the workgroup-barrier hand-off
   const int rows = (half ? 32 : 64) * groups;
   const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);
-  if (planes)
-    hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, true>), dim3(grid),
+  if (planes == 1)
+    hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 1>), dim3(grid),
+                       dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+  else if (planes == 2)
+    hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 2>), dim3(grid),
                        dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   else
-    hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, false>), dim3(grid),
+    hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 0>), dim3(grid),
                        dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }

@@ -152,10 +152,9 @@ __device__ __forceinline__ void dw_acc(const float* __restrict__ dplane, int R, 
 template <int ACT>
 __device__ __forceinline__ void act_both(const f32x16& z, f32x16& a, f32x16& g) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    a[q] = act_ct<ACT>(z[q]);
-    g[q] = act_grad(z[q], ACT);
-  }
+  for (int q = 0; q < 16; ++q) g[q] = act_grad(z[q], ACT);
+  a = z;
+  act_tile<ACT>(a);
 }
 
 // accumulator tile -> natural [rows][ld] matrix block (row tile R, column tile Cc): coalesced over the lanes

@@ -52,7 +52,9 @@ __device__ __forceinline__ float act_gelu(float v) {
   q = fmaf(q, t, -1.1512017029e+00f);
   q = fmaf(q, t, -9.9999306093e-01f);
   float relu;  // one v_max_f32: written in C (fmaxf, or med3 with +inf) hipcc adds a canonicalising v_max_f32 v, v, v in front
-  asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(v));
+  // (t as an extra input: orders this read of v -- an MFMA result, and the hazard recogniser does not look into assembly -- behind the
+  // v_med3 above, which the compiler has given the wait states)
+  asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(v), "v"(t));
   return fmaf(-t, __builtin_amdgcn_exp2f(q), relu);
 }
 __device__ __forceinline__ float act_silu(float v) { return v / (1.0f + __expf(-v)); }

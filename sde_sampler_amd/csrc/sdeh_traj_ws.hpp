@@ -279,10 +279,56 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return act == SDEH_ACT_GELU_ERF ? act_gelu(v) : (act == SDEH_ACT_SILU ? act_silu(v) : act_relu(v));
 }
 
-// Two activations at once.  (A v_pk_fma_f32 formulation of the polynomial does not survive: hipcc unpacks packed fp32
-// ops whose second operand is a splat SGPR constant back into two v_fma_f32 -- and a packed op costs ~5.3 cycles against
-// 2 x 4, so little is lost.)
-__device__ __forceinline__ f2 act_gelu2(f2 v) { return f2{act_gelu(v.x), act_gelu(v.y)}; }
+// Two activations at once: the polynomial and the final product as v_pk_fma_f32 on the element pair (IEEE fma per component: the
+// results are those of act_gelu bit for bit).  Written in assembly -- hipcc unpacks packed fp32 ops whose constant operand is a splat
+// back into two v_fma_f32.  The coefficients sit in SGPR pairs (one scalar source per instruction; the leading one in a VGPR pair).
+// 13 instructions per pair instead of 20.
+__device__ __forceinline__ f2 pk_fma_sc(f2 a, f2 b, unsigned long long c2) {
+  f2 r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c2));
+  return r;
+}
+__device__ __forceinline__ unsigned long long splat_bits(float c) {
+  const unsigned long long b = __float_as_uint(c);
+  return (b << 32) | b;
+}
+__device__ __forceinline__ f2 act_gelu2(f2 v) {
+#ifdef SDEH_NO_PK_GELU
+  return f2{act_gelu(v.x), act_gelu(v.y)};
+#else
+  const f2 t = f2{__builtin_amdgcn_fmed3f(fabsf(v.x), 0.0f, 6.0f), __builtin_amdgcn_fmed3f(fabsf(v.y), 0.0f, 6.0f)};
+  f2 q = pk_fma_sc(splat(3.3092907814e-05f), t, splat_bits(-7.6922050644e-04f));
+  q = pk_fma_sc(q, t, splat_bits(8.0807191412e-03f));
+  q = pk_fma_sc(q, t, splat_bits(-5.3412108121e-02f));
+  q = pk_fma_sc(q, t, splat_bits(-4.5877097054e-01f));
+  q = pk_fma_sc(q, t, splat_bits(-1.1512017029e+00f));
+  q = pk_fma_sc(q, t, splat_bits(-9.9999306093e-01f));
+  const f2 e = f2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+  // The hazard recogniser does not look into assembly: the statements that READ v (written by MFMAs) take t as an extra input, so
+  // they are ordered behind the v_med3 the compiler emitted (with its wait states) for the same registers; and the value handed back
+  // to the MFMAs is produced by a compiler-visible instruction.
+  f2 relu;
+  asm("v_max_f32 %0, 0, %1" : "=v"(relu.x) : "v"(v.x), "v"(t.x));
+  asm("v_max_f32 %0, 0, %1" : "=v"(relu.y) : "v"(v.y), "v"(t.y));
+  return pk_fma(-t, e, relu);
+#endif
+}
+
+// one accumulator tile in place (pairs of elements for the GELU)
+template <int ACT>
+__device__ __forceinline__ void act_tile(f32x16& v) {
+  if constexpr (ACT == SDEH_ACT_GELU_ERF) {
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      const f2 r = act_gelu2(f2{v[q], v[q + 1]});
+      v[q] = r.x;
+      v[q + 1] = r.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = act_ct<ACT>(v[q]);
+  }
+}
 
 // out[OTO] += W[s][ot] * in-operand(s) for NS k-steps, while activating the NE elements of `side` in place.
 // The A operands (packed weights in LDS) are fetched PF k-steps ahead through a rotating register window: the LDS
@@ -394,10 +440,8 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
   const int h = lane >> 5, j = lane & 31;
   f32x16 cur[OT], nxt[OT], none[1];
   auto activate_all = [&]() {
-#pragma unroll
-    for (int ot = 0; ot < OT; ++ot)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) cur[ot][q] = act_apply(cur[ot][q], act);
+    SDEH_ACT_SWITCH(act, ACTC,
+      _Pragma("unroll") for (int ot = 0; ot < OT; ++ot) act_tile<ACTC>(cur[ot]););
   };
   {
     float xa[R];
@@ -467,8 +511,7 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
     if constexpr (ZS) ws_store_z(Z, 0, C, mw, 0, lane, mine);
   }
   auto exchange = [&]() {  // mine <- act(mine); other <- the partner's activated tile
-#pragma unroll
-    for (int q = 0; q < 16; ++q) mine[q] = act_ct<ACT>(mine[q]);
+    act_tile<ACT>(mine);
     float* __restrict__ mb = abuf + ((parity * 2 + mw) * 16) * 64 + lane;
 #pragma unroll
     for (int q = 0; q < 16; ++q) mb[q * 64] = mine[q];

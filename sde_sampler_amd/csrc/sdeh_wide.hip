@@ -152,13 +152,14 @@ __device__ __forceinline__ void wide_act_store(f32x16 (&acc)[NT][CT], const f32x
                                                float* __restrict__ doutl, int RS, int t0, int h) {
   SDEH_ACT_SWITCH(act, ACT,
     _Pragma("unroll") for (int k = 0; k < NT; ++k)
-      _Pragma("unroll") for (int c = 0; c < CT; ++c)
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) {
-          const int o = (32 * (t0 + 4 * k) + rho(q, h)) * RS + 32 * c;
-          const float z = acc[k][c][q] + bias[k][q];
-          if constexpr (DSTORE) doutl[o] = act_grad(z, ACT);
-          outl[o] = act_ct<ACT>(z);
-        });
+      _Pragma("unroll") for (int c = 0; c < CT; ++c) {
+        f32x16 z = acc[k][c] + bias[k];
+        if constexpr (DSTORE) {
+          _Pragma("unroll") for (int q = 0; q < 16; ++q) doutl[(32 * (t0 + 4 * k) + rho(q, h)) * RS + 32 * c] = act_grad(z[q], ACT);
+        }
+        act_tile<ACT>(z);
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) outl[(32 * (t0 + 4 * k) + rho(q, h)) * RS + 32 * c] = z[q];
+      });
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a release/acquire fence for ALL address spaces: hipcc

@@ -8,7 +8,8 @@
 //
 //   * a TEAM of two wavefronts owns 32 trajectories (one MFMA column tile); wave r computes row tile r (channels 32r .. 32r+31) of
 //     every layer, forward (re-evaluation at x_t) and backward (transposed weights).  A layer's input is both tiles, so the waves
-//     exchange their halves through LDS planes [row][trajectory] -- one workgroup barrier per layer.
+//     exchange their halves through LDS planes [row][trajectory] -- one workgroup barrier per layer; the MFMA B operands are read
+//     from the planes k-group by k-group (lane (j, h): rows 8 s + 4 h .. + 3 of column j).
 //   * the SAME planes are the operands of the weight gradients: dW_k += delta_k a_k^T contracts over the trajectories, i.e. both
 //     MFMA operands are the planes read TRANSPOSED (lane = row, 4 consecutive trajectories per ds_read_b128; row stride 36 floats
 //     keeps the reads conflict-free).  The [64, 64] accumulators stay in registers for the whole launch (8 tiles per wave) and are
@@ -55,13 +56,6 @@ __device__ __forceinline__ void plane_put(float* __restrict__ plane, int tile, i
   float* __restrict__ p = plane + (32 * tile + 4 * h) * RS + j;
 #pragma unroll
   for (int q = 0; q < 16; ++q) p[rrow(q) * RS] = v[q];
-}
-__device__ __forceinline__ f32x16 plane_get(const float* __restrict__ plane, int tile, int j, int h) {
-  const float* __restrict__ p = plane + (32 * tile + 4 * h) * RS + j;
-  f32x16 v;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) v[q] = p[rrow(q) * RS];
-  return v;
 }
 // transposed read: lane (i, h) gets row 32 tile + i, trajectories 8 c + 4 h .. + 3
 __device__ __forceinline__ float4 plane_getT(const float* __restrict__ plane, int tile, int i, int h, int c) {

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from tests.helpers import GOLDEN, hip_problem, load_fixture
-from tests.test_hip_fuzz import random_spec
+from tests.test_hip_fuzz import check_training_case, random_spec
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -119,6 +119,13 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case):
         denom = max(b.abs().max().item(), 1e-4 * gmax, 1e-12)
         err = (a - b).abs().max().item() / denom
         assert err <= 2e-4, f"{tag}: grad {k} fused vs planes rel err {err:.2e}"
+
+
+@pytest.mark.parametrize("case", range(32 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))
+def test_fused_backward_matches_oracle_autograd_on_random_problems(case):
+    """The random training problems of tests/test_hip_fuzz.py with the network depth the fused kernel is compiled for: loss and
+    every parameter gradient against the ORACLE's autograd (conditioning-aware criteria of that test)."""
+    check_training_case(1000 + case, num_layers=4, expect_kernel="bwd_fused")
 
 
 def test_fused_backward_large_batch_is_deterministic():

@@ -171,10 +171,18 @@ def test_random_problem_matches_oracle(case):
 @pytest.mark.parametrize("case", range(N_TRAIN))
 def test_random_training_gradients_match_oracle(case):
     """loss(...).backward() through the HIP forward + backward kernels vs the oracle's autograd, methods kl / kl_ito / lv."""
+    check_training_case(case)
+
+
+def check_training_case(case, num_layers=None, expect_kernel=None):
+    """One random training problem against the oracle's autograd.  `num_layers`: force the network depth (4 = the depth the fused
+    backward kernel is compiled for); `expect_kernel`: prefix the backward kernel's name must have."""
     from sde_sampler_amd import problems
 
     rng = np.random.default_rng(5000 + case)
     spec = random_spec(rng)
+    if num_layers is not None:
+        spec["net"]["num_layers"] = num_layers
     method = str(rng.choice(["kl", "kl_ito", "lv"]))
     spec["loss"]["method"] = method
     spec["loss"]["max_rnd"] = 1e8 if method == "lv" else None
@@ -209,11 +217,18 @@ def test_random_training_gradients_match_oracle(case):
     try:
         val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
         val.backward()
+        kernel = prob.loss.engine.last_kernel_name()
+        funnel_two_tiles = spec["target"]["kind"] == "funnel" and d > 32 and method.startswith("kl")  # documented fall-back
+        if expect_kernel is not None and not funnel_two_tiles:
+            assert kernel.startswith(expect_kernel), kernel
     except SdehUnsupported as exc:  # a documented limit, e.g. a wide mixture next to the transposed weights in LDS
         if "do not fit in LDS" in str(exc):
             pytest.skip(str(exc)[:120])
         raise
     tag = f"case {case}: {method} {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"
+    if math.isfinite(ref_loss.item()) and abs(ref_loss.item()) > 1e15:  # the reference's own trajectories have exploded (finite by luck)
+        assert not math.isfinite(val.item()) or abs(val.item()) > 1e12, f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+        return
     assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item())) + cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
     if not math.isfinite(ref_loss.item()):
         return
@@ -312,6 +327,9 @@ def test_random_bridge_matches_oracle(case):
     assert _close(got, want, 2e-3 * max(1.0, abs(want)) + cond_lb), f"{tag}: lb_ito {got} vs {want}"
     val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
     val.backward()
+    if math.isfinite(ref_loss.item()) and abs(ref_loss.item()) > 1e15:  # the reference's own trajectories have exploded (finite by luck)
+        assert not math.isfinite(val.item()) or abs(val.item()) > 1e12, f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+        return
     assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item())) + cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
     if not math.isfinite(ref_loss.item()):
         return

@@ -964,6 +964,59 @@ __device__ __forceinline__ void wide_tangent_pass(const float* __restrict__ wgrp
   wait_all(a[0], std::integral_constant<int, 0>{});  // drain the clamped re-read issued by the last iteration
 }
 
+// The same for TWO coordinates at once: one stream of A operands (the packed weights -- each 1 KB operand load costs the issuing wave
+// ~35 cycles, tools/ubench/wide_loop.hip) feeds both coordinates' MFMAs, i.e. half the loads per MFMA.  The per-coordinate sequence
+// of MFMAs is the one of wide_tangent_pass, so each result is bit-identical to it.
+template <int NT>
+__device__ __forceinline__ void wide_tangent_pass2(const float* __restrict__ wgrp, int OT, int t0, int NS4, unsigned lane_off,
+                                                   const float* __restrict__ dpl, const float* __restrict__ colA,
+                                                   const float* __restrict__ colB, f32x16 (&accA)[NT], f32x16 (&accB)[NT]) {
+  static_assert(NT == 2, "tiles are awaited in pairs");
+  f32x4 a[2][NT];
+  const int grp_floats = OT * 256;
+  auto issue = [&](int S, f32x4 (&av)[NT]) {
+    const float* base = wgrp + (long long)(S < NS4 ? S : NS4 - 1) * grp_floats;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) wide_gload(av[k], lane_off + (unsigned)((t0 + k) * 1024), base);
+  };
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accA[k][q] = accB[k][q] = 0.0f;
+  issue(0, a[0]);
+  float bA[2][4], bB[2][4];
+  auto loadB = [&](int S, float (&va)[4], float (&vb)[4]) {
+    const int Sc = S < NS4 ? S : NS4 - 1;
+    const float4 ca = *reinterpret_cast<const float4*>(colA + 8 * Sc);
+    const float4 cb = *reinterpret_cast<const float4*>(colB + 8 * Sc);
+    const float* __restrict__ dp = dpl + (8 * Sc) * 32;
+    const float d0 = dp[0], d1 = dp[64], d2 = dp[128], d3 = dp[192];
+    va[0] = d0 * ca.x; va[1] = d1 * ca.y; va[2] = d2 * ca.z; va[3] = d3 * ca.w;
+    vb[0] = d0 * cb.x; vb[1] = d1 * cb.y; vb[2] = d2 * cb.z; vb[3] = d3 * cb.w;
+  };
+  loadB(0, bA[0], bB[0]);
+  for (int S = 0; S < NS4; S += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      issue(S + u + 1, a[(u + 1) % 2]);
+      loadB(S + u + 1, bA[(u + 1) % 2], bB[(u + 1) % 2]);
+      wide_vmwait<NT, 2>(a[u]);  // all but the NT newest loads have landed
+      SDEH_FENCE();
+      if (S + u < NS4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < NT; ++k) {
+            accA[k] = SDEH_MFMA(a[u][k][e], bA[u][e], accA[k]);
+            accB[k] = SDEH_MFMA(a[u][k][e], bB[u][e], accB[k]);
+          }
+      }
+      SDEH_FENCE();
+    }
+  }
+  wide_vmwait<0, 2>(a[0]);  // drain the clamped re-read issued by the last iteration
+}
+
 template <int OTW>  // C = 128 OTW
 __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int split, float* __restrict__ divparts) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -987,18 +1040,18 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
   float* dplanes = lds + rows * RS;                       // act'(z_l) of the inference network, l = 0 .. Lh: [Lh + 1][C][32]
   cx.scr = dplanes + (L2.n_hidden + 1) * C * RS;          // [kWideSlots][4][32]
   float* divacc = cx.scr + kWideSlots * 4 * RS;           // [4 waves][8 groups][32]: sigma dt mask J_jj accumulated over the steps
-  float* cols = divacc + 4 * 8 * RS;                      // [4 waves][2][C]: column j of W_in / row j of W_out of the coordinate at hand
-  float* tabs = cols + 4 * 2 * C;
+  float* cols = divacc + 4 * 8 * RS;                      // [4 waves][2 coordinates][2][C]: column j of W_in / row j of W_out of the coordinates at hand
+  float* tabs = cols + 4 * 4 * C;
   const int tab_stride = 2 * L.dp + 4;
   for (int i = tid; i < 3 * tab_stride; i += 256) {
     const int which = i / tab_stride, o = i % tab_stride;
     tabs[i] = o <= 2 * L.dp ? ws[L.dg[which] + o] : 0.0f;
   }
   cx.tab0 = tabs; cx.tab1 = tabs + tab_stride; cx.tab2 = tabs + 2 * tab_stride;
-  float* bias_u = tabs + 3 * tab_stride;                  // generative network: hidden biases then out-layer bias
-  float* bias_v = bias_u + L.n_hidden * C + 32 * OTD;     // inference network
-  for (int i = tid; i < L.n_hidden * C + 32 * OTD; i += 256) bias_u[i] = ws[L.b_hid + i];
-  for (int i = tid; i < L2.n_hidden * C + 32 * OTD; i += 256) bias_v[i] = ws2[L2.b_hid + i];
+  // biases (hidden layers, then the out layer): read from the workspace (L2) -- the network passes are < 1 % of this kernel, and the
+  // LDS they would take is what the second coordinate's columns of the paired divergence pass need at d = 196, C = 256
+  const float* bias_u = ws + L.b_hid;    // generative network
+  const float* bias_v = ws2 + L2.b_hid;  // inference network
   for (int i = tid; i < 4 * 8 * RS; i += 256) divacc[i] = 0.0f;
   cx.bias = bias_u;
 
@@ -1097,13 +1150,70 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
     // ---- diagonal of the inference network's Jacobian: this wave's coordinates ------------------------------------------------
     {
       const float sdt = sig * dt;
-      float* __restrict__ mycol = cols + w * 2 * C;
+      float* __restrict__ mycol = cols + w * 4 * C;
+      float* __restrict__ mycolB = mycol + 2 * C;  // the second coordinate of a pair
       const float* __restrict__ d0 = dplanes + h * RS + j;
       const unsigned lane_off = (unsigned)(lane * 16);
       for (int gi = 0; gi < ngw; ++gi) {
         const int g = gw + gi * TW;
         float part = 0.0f;
-        for (int jc = g; jc < d; jc += kDivGroups) {
+        int jc = g;
+        // Coordinates of the group two at a time (hidden layers present): one operand stream for both.  Each coordinate's own sums
+        // keep their order, so the result does not change with the pairing.
+        for (; Lh2 >= 1 && jc + kDivGroups < d; jc += 2 * kDivGroups) {
+          const int jb = jc + kDivGroups;
+          {
+            const float4 ci = *reinterpret_cast<const float4*>(ws2 + L2.tan_in + jc * C + lane * 4);
+            const float4 co = *reinterpret_cast<const float4*>(ws2 + L2.tan_out + jc * C + lane * 4);
+            const float4 di = *reinterpret_cast<const float4*>(ws2 + L2.tan_in + jb * C + lane * 4);
+            const float4 dq = *reinterpret_cast<const float4*>(ws2 + L2.tan_out + jb * C + lane * 4);
+            if (lane * 4 < C) {
+              *reinterpret_cast<float4*>(mycol + lane * 4) = ci;
+              *reinterpret_cast<float4*>(mycol + C + lane * 4) = co;
+              *reinterpret_cast<float4*>(mycolB + lane * 4) = di;
+              *reinterpret_cast<float4*>(mycolB + C + lane * 4) = dq;
+            }
+          }
+          float jjA = 0.0f, jjB = 0.0f;
+          auto idx = [&](int ot, int q) { return (4 * ot + (q >> 2)) * 8 + (q & 1) * 4 + ((q >> 1) & 1) + 2 * h; };  // B order of channel 32 ot + rho(q, h)
+          const float* __restrict__ d1 = dplanes + C * RS;
+#pragma unroll
+          for (int part_i = 0; part_i < OT / 2; ++part_i) {
+            f32x16 FA[2], FB[2];
+            wide_tangent_pass2<2>(ws2 + L2.w_hid, OT, 2 * part_i, C / 8, lane_off, d0, mycol + 4 * h, mycolB + 4 * h, FA, FB);
+            if (Lh2 == 1) {
+#pragma unroll
+              for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                  const int ot = 2 * part_i + k;
+                  const float dv = d1[(32 * ot + rho(q, h)) * RS + j];
+                  jjA = fmaf(FA[k][q] * dv, mycol[C + idx(ot, q)], jjA);
+                  jjB = fmaf(FB[k][q] * dv, mycolB[C + idx(ot, q)], jjB);
+                }
+            } else {
+              f32x16 GA[2], GB[2];  // adjoints through the second hidden layer
+              wide_tangent_pass2<2>(ws2 + L2.wt_hid + L2.w_hid_stride, OT, 2 * part_i, C / 8, lane_off, d0 + 2 * C * RS,
+                                    mycol + C + 4 * h, mycolB + C + 4 * h, GA, GB);
+#pragma unroll
+              for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                  const int ot = 2 * part_i + k;
+                  const float dv = d1[(32 * ot + rho(q, h)) * RS + j];
+                  jjA = fmaf(FA[k][q] * dv, GA[k][q], jjA);
+                  jjB = fmaf(FB[k][q] * dv, GB[k][q], jjB);
+                }
+            }
+          }
+          jjA = half_sum(jjA);
+          jjB = half_sum(jjB);
+          // d clip(v_j, -m, m) / d v_j = 1 on [-m, m] (torch.clamp's backward), else 0
+          const float vA = cx.plane(0)[jc * RS + j], vB = cx.plane(0)[jb * RS + j];
+          part += (vA >= -A.inf_clip_model && vA <= A.inf_clip_model) ? jjA : 0.0f;
+          part += (vB >= -A.inf_clip_model && vB <= A.inf_clip_model) ? jjB : 0.0f;
+        }
+        for (; jc < d; jc += kDivGroups) {
           // column jc of W_in and row jc of W_out (B order) -> this wave's LDS rows
           {
             const float4 ci = *reinterpret_cast<const float4*>(ws2 + L2.tan_in + jc * C + lane * 4);
@@ -1289,8 +1399,7 @@ __global__ void bridge_wide_finish(float* __restrict__ rnd, const float* __restr
 
 inline size_t bridge_wide_lds_bytes(const WsLayout& L, const WsLayout& L2) {
   const int rows = L.c > 32 * L.otd ? L.c : 32 * L.otd;
-  return ((size_t)rows * 32 + (size_t)(L2.n_hidden + 1) * L.c * 32 + kWideSlots * 4 * 32 + 4 * 8 * 32 + 4 * 2 * L.c + 3 * (2 * L.dp + 4) +
-          (L.n_hidden + L2.n_hidden) * L.c + 64 * L.otd) * sizeof(float);
+  return ((size_t)rows * 32 + (size_t)(L2.n_hidden + 1) * L.c * 32 + kWideSlots * 4 * 32 + 4 * 8 * 32 + 4 * 4 * L.c + 3 * (2 * L.dp + 4)) * sizeof(float);
 }
 
 long long bridge_wide_scratch_floats(long long batch) { return ((batch + 31) / 32) * kDivGroups * 32; }

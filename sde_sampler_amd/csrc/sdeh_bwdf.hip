@@ -232,11 +232,42 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   const long long n_rounds = (n_items + n_teams - 1) / n_teams;
   int par = 0;
 
+  // Items: tiles (through time) or (step, tile) pairs, step-major (row-parallel); a team takes item team_g, team_g + n_teams, ...
+  // The (step, tile) of an item is carried along incrementally: 64-bit divisions per item cost more than the item's bookkeeping.
+  const int n_tiles = A.n_tiles;
+  const int d_t = BPTT ? 0 : n_teams / n_tiles, d_tile = BPTT ? n_teams : n_teams % n_tiles;
+  int it_t = BPTT ? T - 1 : team_g / n_tiles, it_tile = BPTT ? team_g : team_g % n_tiles;  // the current item
+  auto advance = [&](int& t_io, int& tile_io) {  // -> the team's next item
+    tile_io += d_tile;
+    if constexpr (!BPTT) {
+      t_io += d_t;
+      if (tile_io >= n_tiles) { tile_io -= n_tiles; t_io += 1; }
+    }
+  };
+  auto item_live = [&](int t_i, int tile_i) { return BPTT ? tile_i < n_tiles : t_i < T; };
+  // x of the step that comes next -- also across items: in the row-parallel mode an item is a single step
+  auto load_x = [&](int t, int tile_i) {
+    f32x16 v;
+    const long long rw = (long long)tile_i * 32 + j;
+    const float* __restrict__ plane = A.xs + (long long)t * d * B + (rw < B ? rw : B - 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = cb + rrow(q) < d ? plane[(long long)(cb + rrow(q)) * B] : 0.0f;
+    return v;
+  };
+  auto clamp_item = [&](int& t_io, int& tile_io) {  // a team without an item shadows the last one (and contributes zeros)
+    if (!item_live(t_io, tile_io)) { t_io = BPTT ? T - 1 : T - 1; tile_io = n_tiles - 1; }
+  };
+  f32x16 xnext;
+  {
+    int t0 = it_t, tl0 = it_tile;
+    clamp_item(t0, tl0);
+    xnext = load_x(t0, tl0);
+  }
   for (long long round = 0; round < n_rounds; ++round) {
-    const long long item = round * n_teams + team_g;
-    const bool live_item = item < n_items;
-    const long long item_c = live_item ? item : n_items - 1;
-    const long long tile = BPTT ? item_c : item_c % A.n_tiles;
+    const bool live_item = item_live(it_t, it_tile);
+    int cur_t = it_t, cur_tile = it_tile;
+    clamp_item(cur_t, cur_tile);
+    const long long tile = cur_tile;
     const long long row = tile * 32 + j;
     const bool live = live_item && row < B;
     const long long lrow = row < B ? row : B - 1;
@@ -272,9 +303,9 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         for (int q = 0; q < 16; ++q) lam[q] = fmaf(-wi, st[q], lam[q]);
       }
     }
-    const int t_first = BPTT ? T - 1 : (int)(item_c / A.n_tiles);
+    const int t_first = cur_t;
     const int t_last = BPTT ? 0 : t_first;
-    f32x16 xnext = load16c(A.xs + (long long)t_first * d * B);
+    advance(it_t, it_tile);  // from here on: the team's NEXT item
 
     for (int t = t_first; t >= t_last; --t) {
       float* __restrict__ Acur = pl + par * PLANE;        // x, later a_2
@@ -282,7 +313,13 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       float* __restrict__ D0 = pl + 2 * PLANE;
       float* __restrict__ D1 = pl + 3 * PLANE;
       const f32x16 x = xnext;
-      if (t > t_last) xnext = load16c(A.xs + (long long)(t - 1) * d * B);
+      if (t > t_last) {
+        xnext = load_x(t - 1, cur_tile);
+      } else if (round + 1 < n_rounds) {
+        int tn = it_t, tln = it_tile;
+        clamp_item(tn, tln);
+        xnext = load_x(tn, tln);
+      }
       // the step's other inputs: requested first, consumed after the forward pass
       f32x16 scv, xi;
       if (has_score) scv = load16c(A.sc + (long long)t * d * B);
@@ -305,6 +342,8 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) xi[q] = cb + rrow(q) < d ? n[q] : 0.0f;
       }
+      const f32x16 embv = load16(ws + L.emb + t * C + (r * 2 + h) * 16);  // timestep_embed(t) + input bias of this wave's channels
+      const float gam0 = has_score ? ws[L.gam + t * L.g] : 0.0f;           // gamma(t) (its first entry), requested early as well
       cfp cf = as_const(ws + L.coef + t * kCoefStride);
       const float sig = cf[CF_SIGMA], wl = cf[CF_W];
       const float c_i = expo ? cf[CF_SBK] : cf[CF_SQDT];
@@ -318,7 +357,11 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       f32x16 g0, g1, g2, a1own;
       const int bofs = 4 * h * RS + j;  // this lane's column of a plane as an MFMA B operand
       {
-        const f32x16 z0 = mm_rows<4 * OTD>(Win + (32 * r + j) * RSI + 4 * h, Acur + bofs, A.n_kg, load16(ws + L.emb + t * C + (r * 2 + h) * 16));
+        // (the time embedding is added behind the products: its load, requested at the top of the step, must not hold up the first MFMA)
+        f32x16 zero;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
+        const f32x16 z0 = mm_rows<4 * OTD>(Win + (32 * r + j) * RSI + 4 * h, Acur + bofs, A.n_kg, zero) + embv;
         SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z0, a1own, g0););
       }
       plane_put(Aoth, r, j, h, a1own);
@@ -357,7 +400,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         for (int q = 0; q < 16; ++q) {
           float mfac = 0.0f, csc = 0.0f, keep_s = 0.0f;
           if (has_score) {
-            const float gam = A.g == 1 ? ws[L.gam + t * L.g] : ws[L.gam + t * L.g + min(cb + rrow(q), L.g - 1)];
+            const float gam = A.g == 1 ? gam0 : ws[L.gam + t * L.g + min(cb + rrow(q), L.g - 1)];
             mfac = mult * gam;
             csc = clipf(scv[q], A.clip_score);
             keep_s = fabsf(scv[q]) <= A.clip_score ? 1.0f : 0.0f;

@@ -47,6 +47,12 @@ WORKLOADS = {
     "cfg5_like_bridge196": ("cfg5_like_bridge196", "trajectory-steps/sec, Bridge d=196 C=256 (BASELINE configs[4] shape)",
                             "Bridge (LerpTargetCtrl + LerpPriorCtrl inference control, exact divergence), funnel d=196 target "
                             "in place of the unfusable NICE flow, two FourierMLP C=256 L=4 GELU, ScaledBM(1, T=1)"),
+    # one optimisation step (loss forward, backward, Adam) -- the reference's Trainable.step (solver/base.py:399-454) on the HIP path
+    "train_gmm2_dis_kl": ("cfg2_gmm2_dis_kl", "trajectory-steps/sec of one optimisation step (forward + backward + Adam), DIS kl, GMM-40 d=2",
+                          "BASELINE configs[1]: GMM-40 d=2, basic_dis (LerpCtrl, FourierMLP C=64 L=4 GELU, VP), loss.method=kl, "
+                          "one training step per bench step"),
+    "train_gmm50_pis_kl": ("cfg3_gmm50_pis_kl", "trajectory-steps/sec of one optimisation step (forward + backward + Adam), PIS kl, GMM-40 d=50",
+                           "BASELINE configs[2]'s shape: GMM-40 d=50, basic_pis, loss.method=kl, T=200, one training step per bench step"),
 }
 
 
@@ -85,13 +91,31 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
-def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | None = None) -> dict:
+def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | None = None, train_method: str | None = None) -> dict:
     """The reference's CPU path (oracle = op-for-op PyTorch-CPU restatement, bit-exact on the reference-generated fixtures) on a
     bounded sample of the same workload, SURVEY.md 8d: torch.set_num_threads(all physical cores) AND one thread, median of >= 5
     full-T chunks after one warm-up chunk, `sample_time` semantics (compute_weights=False, no trajectory)."""
     from oracle import em_oracle as eo
 
     params, tt, params_inf = prob_cpu_state
+    if train_method is not None:  # the training workloads: the oracle's loss + autograd backward on a bounded sample
+        threads = min(8, physical_cores())
+        leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+        oracle = eo.Problem(spec, leaves, tt)
+        ts = oracle.grid()
+        T, d, rows, rates = ts.numel() - 1, spec["target"]["dim"], 256, []
+        torch.set_num_threads(threads)
+        for _ in range(4):
+            x0c = torch.zeros(rows, d) if spec["prior"]["kind"] == "delta" else torch.randn(rows, d)
+            for v in leaves.values():
+                v.grad = None
+            t0 = time.perf_counter()
+            l_ref, _, _, _ = oracle.train_loss(ts, x0c, None, method=train_method)
+            l_ref.backward()
+            rates.append(rows * T / (time.perf_counter() - t0))
+        return {"value": statistics.median(rates[1:]), "unit": "trajectory-steps/s", "cores": threads, "kind": "port",
+                "sample": f"oracle/em_oracle.py train_loss + autograd backward (no optimizer step), {rows} trajectories x T={T}, "
+                          f"median of 3 after 1 warm-up, {threads} torch threads"}
     oracle = eo.Problem(spec, params, tt, params_inf=params_inf)
     ts = oracle.grid()
     bridge = bool(spec.get("inference_ctrl"))
@@ -244,6 +268,71 @@ def log_z_block(spec, device, B: int, rank: int, world: int) -> dict | None:
                           gpu_is=got.log_norm_const_preds["log_norm_const_is"],
                           gpu_lb_ito=got.log_norm_const_preds["log_norm_const_lb_ito"])
     return out
+
+
+def run_train(args, device):
+    """Training workloads (single GPU): a bench step = loss(...) forward, backward (fused kernel), Adam.  Roofline: the backward
+    kernel, 2 x (4dC + 2 Lh C^2) algorithmic FLOPs per trajectory-step; cpu_baseline: the oracle's loss + autograd backward on a
+    bounded sample."""
+    from sde_sampler_amd import problems
+
+    spec_name, metric, description = WORKLOADS[args.workload]
+    spec = problems.baseline_spec(spec_name)
+    spec["batch"] = args.batch or 65536
+    if args.em_steps:
+        spec["grid"]["steps"] = args.em_steps
+    prob = problems.build(spec)
+    params_cpu = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
+    tt = (dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+          if spec["target"]["kind"] == "gmm" else None)
+    prob.to(device)
+    B, T, d = spec["batch"], prob.ts.numel() - 1, spec["target"]["dim"]
+    c, lh = spec["net"]["channels"], spec["net"]["num_layers"] - 2
+    method = spec["loss"]["method"]
+    opt = torch.optim.Adam(prob.ctrl.parameters(), lr=1e-4)
+    eng = prob.loss.engine
+    eng.timing = True
+    torch.manual_seed(1)
+    fwd_ms, bwd_ms = [], []
+
+    def step(record):
+        x0 = prob.prior.sample((B,))
+        opt.zero_grad(set_to_none=True)
+        loss, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+        if record:
+            fwd_ms.append(eng.last_kernel_ms())  # (waits for the forward kernel: the reference's step synchronises on loss.item() too)
+        loss.backward()
+        if record:
+            bwd_ms.append(eng.last_kernel_ms())
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms = sum(bwd_ms) / len(bwd_ms)
+    flops_b = 2 * (4 * d * c + 2 * lh * c * c)
+    achieved = flops_b * B * T / (k_ms * 1e-3) / 1e12
+    out = {"metric": metric, "value": B * T * args.steps / elapsed, "unit": "trajectory-steps/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{args.workload}: {description}", "batch_per_gpu": B, "global_batch": B, "em_steps": T, "dim": d,
+                      "channels": c, "method": method, "noise": "in-kernel Philox4x32-10 + Box-Muller (replayed by the backward)"},
+           "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                        "traffic": None, "kernel": eng.last_kernel_name(), "kernel_ms": k_ms, "forward_kernel_ms": sum(fwd_ms) / len(fwd_ms),
+                        "flops_per_traj_step": flops_b,
+                        "note": "dominant kernel = the fused backward (csrc/sdeh_bwdf.hip); algorithmic FLOPs: adjoint chain + weight "
+                                "gradients = 2 x (4dC + 2 Lh C^2); the kernel also re-evaluates the network (a third on top, not counted)"},
+           "final_loss": float(loss)}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(spec, (params_cpu, tt, None), train_method=method)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
 
 
 def run(args, rank: int, world: int, local_rank: int):
@@ -400,10 +489,17 @@ def main():
                     help="testing aid: all ranks use cuda:0 (with --backend gloo) to exercise the N > 1 path on one GPU")
     args = ap.parse_args()
     heavy = args.workload in ("wide_pis_funnel196", "cfg5_like_bridge196")
+    train = args.workload.startswith("train_")
     if args.steps is None:
-        args.steps = 5 if heavy else 1000
+        args.steps = 5 if heavy else (100 if train else 1000)
     if args.warmup is None:
-        args.warmup = 2 if heavy else 20
+        args.warmup = 2 if heavy else (5 if train else 20)
+    if train:
+        if args.gpus != 1 or os.environ.get("WORLD_SIZE") not in (None, "1"):
+            raise SystemExit("the training workloads are single-GPU measurements (data-parallel training: tests/test_distributed_gloo.py)")
+        torch.cuda.set_device(0)
+        run_train(args, torch.device("cuda", 0))
+        return
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is not None:  # launched by torch.distributed.run (or an equivalent launcher)

@@ -298,8 +298,8 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const 
  * Fused training backward (csrc/sdeh_bwdf.hip): what `loss.backward()` does in the reference (solver/base.py:407 through the
  * unrolled loops of losses/oc.py:176-222, 301-334, 416-446) for the control's FourierMLP in ONE kernel -- back-propagation at the
  * stored trajectory (through time for methods "kl" / "kl_ito") and the weight-gradient contractions, with no [C, n_steps*batch] plane
- * in device memory.  Compiled for channels = 64, two hidden layers (conf/model/base/fouriermlp.yaml: num_layers 4), d <= 64, no
- * inference control: sdeh_ctrl_backward_fused_supported says whether a problem qualifies; sdeh_ctrl_backward_ex + sdeh_weight_grad
+ * in device memory.  Compiled for channels = 64, one to three hidden layers (conf/model/base/fouriermlp.yaml: num_layers 4 = two),
+ * d <= 64, no inference control: sdeh_ctrl_backward_fused_supported says whether a problem qualifies; sdeh_ctrl_backward_ex + sdeh_weight_grad
  * take the rest.
  *
  * sdeh_simulate_fwd_train2 == sdeh_simulate_fwd for a training step that keeps what the fused backward reads, all
@@ -315,8 +315,8 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const 
  * [n_steps, batch, d] tensor); same problem / ts / noise / seed / offset / row_offset as the forward call, grad_rnd [batch] =
  * d loss / d rnd_i.  `scratch` (sdeh_ctrl_backward_fused_sizes) holds per-team partial gradients, summed deterministically (no
  * atomics).  `out` (floats, with P = 32 * ceil(d / 32), gw = 2 if gamma(t) is scalar else 64):
- *   input_embed.weight [64, P] (columns >= d unused) | hidden_layer[l].weight [2][64, 64] | out_layer.weight [P, 64] |
- *   hidden_layer[l].bias [2][64] | out_layer.bias [P] | d loss / d (timestep_embed(t) + input_embed.bias) [n_steps, 64] |
+ *   input_embed.weight [64, P] (columns >= d unused) | hidden_layer[l].weight [Lh][64, 64] | out_layer.weight [P, 64] |
+ *   hidden_layer[l].bias [Lh][64] | out_layer.bias [P] | d loss / d (timestep_embed(t) + input_embed.bias) [n_steps, 64] |
  *   d loss / d gamma(t) [n_steps, gw]  (scalar gamma: the sum of the two columns; vector gamma: columns < d)
  * The two [n_steps, .] tables are the inputs of sdeh_time_embed_backward.
  */
@@ -324,7 +324,7 @@ int32_t sdeh_simulate_fwd_train2(SdehPlan* plan, const SdehProblem* problem, con
                                  const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                                  int64_t row_offset, float* x_T, float* rnd, float* xs, float* sc, float* tscore, void* stream);
 int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProblem* problem);
-int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_steps, int64_t batch, int32_t gamma_dim, int32_t bptt,
+int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_steps, int64_t batch, int32_t gamma_dim, int32_t bptt,
                                        int64_t* scratch_floats, int64_t* out_floats);
 int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                                  const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,

@@ -124,7 +124,7 @@ PROTOTYPES = {
     "sdeh_simulate_fwd_train2": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
                                              C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_ctrl_backward_fused_supported": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem)]),
-    "sdeh_ctrl_backward_fused_sizes": (C.c_int32, [C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+    "sdeh_ctrl_backward_fused_sizes": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                                    C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "sdeh_ctrl_backward_fused": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64,
                                              C.c_uint64, C.c_int64, fp, fp, fp, fp, C.c_int64, fp, C.c_void_p]),

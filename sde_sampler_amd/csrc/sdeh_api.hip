@@ -874,7 +874,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
 int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProblem* pr) {
   if (plan == nullptr || pr == nullptr || plan->wide) return 0;
   const SdehFourierMLP& net = pr->base_model;
-  if (net.channels != 64 || net.n_hidden != 2 || net.dim < 1 || net.dim > 64) return 0;
+  if (net.channels != 64 || !bwdf_fits(net.dim, net.n_hidden)) return 0;
   if (pr->flags & (SDEH_FLAG_INFERENCE_CTRL | SDEH_FLAG_INFERENCE_SDE)) return 0;
   if (getenv("SDEH_BWD_PLANES") != nullptr) return 0;  // A/B aid: the plane-writing kernels (read per call)
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
@@ -885,9 +885,9 @@ int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProbl
   return 1;
 }
 
-static void bwdf_sizes(int d, int n_steps, long long batch, int g, bool bptt, long long* wpart, long long* epart, long long* gpart,
-                       long long* sums, long long* out) {
-  const long long tiles = (batch + 31) / 32, slots = bwdf_slots(batch, n_steps, bptt), ws = bwdf_wsize(d);
+static void bwdf_sizes(int d, int n_hidden, int n_steps, long long batch, int g, bool bptt, long long* wpart, long long* epart,
+                       long long* gpart, long long* sums, long long* out) {
+  const long long tiles = (batch + 31) / 32, slots = bwdf_slots(batch, n_steps, bptt), ws = bwdf_wsize(d, n_hidden);
   const long long gw = g == 1 ? 2 : 64;
   *wpart = slots * ws;
   *epart = tiles * n_steps * 64;
@@ -896,12 +896,12 @@ static void bwdf_sizes(int d, int n_steps, long long batch, int g, bool bptt, lo
   *out = ws + (long long)n_steps * (64 + gw);
 }
 
-int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_steps, int64_t batch, int32_t gamma_dim, int32_t bptt,
+int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_steps, int64_t batch, int32_t gamma_dim, int32_t bptt,
                                        int64_t* scratch_floats, int64_t* out_floats) {
-  if (dim < 1 || dim > 64 || n_steps < 1 || batch < 1 || gamma_dim < 1 || scratch_floats == nullptr || out_floats == nullptr)
+  if (!bwdf_fits(dim, n_hidden) || n_steps < 1 || batch < 1 || gamma_dim < 1 || scratch_floats == nullptr || out_floats == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward_fused_sizes: bad argument");
   long long w, e, g, s, o;
-  bwdf_sizes(dim, n_steps, batch, gamma_dim == 1 ? 1 : 64, bptt != 0, &w, &e, &g, &s, &o);
+  bwdf_sizes(dim, n_hidden, n_steps, batch, gamma_dim == 1 ? 1 : 64, bptt != 0, &w, &e, &g, &s, &o);
   *scratch_floats = w + e + g + s;
   *out_floats = o;
   return SDEH_OK;
@@ -917,8 +917,8 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, false, &ck);
   if (rc != SDEH_OK) return rc;
   if (!sdeh_ctrl_backward_fused_supported(plan, pr))
-    return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward_fused: compiled for channels = 64, two hidden layers, d <= 64, no inference control "
-                                      "(sdeh_ctrl_backward_ex + sdeh_weight_grad take the rest)");
+    return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward_fused: compiled for channels = 64, one to three hidden layers, "
+                                      "d <= 64, no inference control (sdeh_ctrl_backward_ex + sdeh_weight_grad take the rest)");
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
   if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: sc is null");
   if (bptt && (pr->flags & SDEH_FLAG_TERMINAL_TARGET) && tscore == nullptr)
@@ -927,7 +927,7 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   long long n_w, n_e, n_g, n_s, n_o;
-  bwdf_sizes(d, n_steps, batch, L.g == 1 ? 1 : 64, bptt, &n_w, &n_e, &n_g, &n_s, &n_o);
+  bwdf_sizes(d, net.n_hidden, n_steps, batch, L.g == 1 ? 1 : 64, bptt, &n_w, &n_e, &n_g, &n_s, &n_o);
   if (scratch_floats < n_w + n_e + n_g + n_s) return fail(SDEH_ERR_CAPACITY, "ctrl_backward_fused: scratch too small (%lld < %lld floats)",
                                                           (long long)scratch_floats, n_w + n_e + n_g + n_s);
   hipStream_t st = (hipStream_t)stream;
@@ -940,7 +940,8 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = L;
   A.w_in = net.input_w; A.w_out = net.out_w; A.b_out = net.out_b;
-  for (int l = 0; l < 2; ++l) { A.w_hid[l] = net.hidden_w[l]; A.b_hid[l] = net.hidden_b[l]; }
+  for (int l = 0; l < net.n_hidden; ++l) { A.w_hid[l] = net.hidden_w[l]; A.b_hid[l] = net.hidden_b[l]; }
+  A.n_hidden = net.n_hidden;
   A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.sc = sc; A.tscore = tscore;
   A.wpart = scratch; A.epart = scratch + n_w; A.gpart = scratch + n_w + n_e;
   float* sums = scratch + n_w + n_e + n_g;
@@ -950,7 +951,7 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
-  A.n_tiles = (int)((batch + 31) / 32); A.n_slots = bwdf_slots(batch, n_steps, bptt); A.wsize = bwdf_wsize(d);
+  A.n_tiles = (int)((batch + 31) / 32); A.n_slots = bwdf_slots(batch, n_steps, bptt); A.wsize = bwdf_wsize(d, net.n_hidden);
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   rc = launch_bwdf(A, st);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }

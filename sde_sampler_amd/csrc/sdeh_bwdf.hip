@@ -28,26 +28,27 @@
 // Modes: BPTT (method kl / kl_ito: a team walks its 32 trajectories backwards through time carrying lambda_t) and row-parallel
 // (lv / lv_traj: the trajectory is a constant of the graph, (step, tile) items are independent).  The semantics (what is constant,
 // what is differentiated) are those of sdeh_bwd.hpp, which stays the path for Bridges and for networks this kernel is not compiled
-// for (n_hidden != 2).
+// for (more than three hidden layers).
 #include "sdeh_bwd.hpp"
 
 namespace sdeh {
 
 namespace bwdf {
 
-constexpr int C = 64, LH = 2;
+constexpr int C = 64;
+constexpr int kMaxLH = 3;  // hidden layers the kernel is instantiated for: 1 .. 3 (num_layers 3 .. 5; the shipped configurations have 2)
 constexpr int RSW = 68;             // row stride of the [., 64] weight copies: 4 x odd -> conflict-free ds_read_b128 across 16 rows
 constexpr int RS = 36;              // row stride of the exchange planes [row][32 trajectories]
 constexpr int PLANE = 64 * RS;
 constexpr int TABS = 6 * 64;        // (mu, 1/sigma^2) x {prior, second, target}
 template <int OTD> constexpr int rsi() { return OTD == 1 ? 36 : 68; }  // row stride of input_embed.weight [64][d]
-template <int OTD> constexpr int lds_floats() { return 64 * rsi<OTD>() + LH * 64 * RSW + 32 * OTD * RSW + LH * 64 + 64 + TABS + 2 * 4 * PLANE; }
+template <int OTD, int LH> constexpr int lds_floats() { return 64 * rsi<OTD>() + LH * 64 * RSW + 32 * OTD * RSW + LH * 64 + 64 + TABS + 2 * 4 * PLANE; }
 // partial-gradient record of one team
 template <int OTD> constexpr int off_whid() { return 64 * 32 * OTD; }
-template <int OTD> constexpr int off_wout() { return off_whid<OTD>() + LH * 4096; }
-template <int OTD> constexpr int off_bhid() { return off_wout<OTD>() + 32 * OTD * 64; }
-template <int OTD> constexpr int off_bout() { return off_bhid<OTD>() + LH * 64; }
-template <int OTD> constexpr int wsize() { return off_bout<OTD>() + 32 * OTD; }
+template <int OTD, int LH> constexpr int off_wout() { return off_whid<OTD>() + LH * 4096; }
+template <int OTD, int LH> constexpr int off_bhid() { return off_wout<OTD, LH>() + 32 * OTD * 64; }
+template <int OTD, int LH> constexpr int off_bout() { return off_bhid<OTD, LH>() + LH * 64; }
+template <int OTD, int LH> constexpr int wsize() { return off_bout<OTD, LH>() + 32 * OTD; }
 
 __device__ __forceinline__ int rrow(int q) { return (q & 3) + 8 * (q >> 2); }
 
@@ -160,7 +161,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ m, int ld, int R,
 
 }  // namespace bwdf
 
-template <int OTD, bool BPTT>
+template <int OTD, bool BPTT, int LH>
 __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   using namespace bwdf;
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
@@ -225,7 +226,9 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   for (int k = 0; k < NDW; ++k)
 #pragma unroll
     for (int q = 0; q < 16; ++q) dw[k][q] = 0.0f;
-  float bs_hid[LH] = {0.0f, 0.0f}, bs_out = 0.0f;
+  float bs_hid[LH], bs_out = 0.0f;
+#pragma unroll
+  for (int l = 0; l < LH; ++l) bs_hid[l] = 0.0f;
 
   const int n_teams = (int)gridDim.x * 2, team_g = (int)blockIdx.x * 2 + team;
   const long long n_items = BPTT ? (long long)A.n_tiles : (long long)A.n_tiles * T;
@@ -308,10 +311,6 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
     advance(it_t, it_tile);  // from here on: the team's NEXT item
 
     for (int t = t_first; t >= t_last; --t) {
-      float* __restrict__ Acur = pl + par * PLANE;        // x, later a_2
-      float* __restrict__ Aoth = pl + (1 - par) * PLANE;  // a_1, later a_3
-      float* __restrict__ D0 = pl + 2 * PLANE;
-      float* __restrict__ D1 = pl + 3 * PLANE;
       const f32x16 x = xnext;
       if (t > t_last) {
         xnext = load_x(t - 1, cur_tile);
@@ -352,35 +351,36 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       const float c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], cf[CF_DT], 1.0f);
 
       // ======================================================================================= forward (re-evaluation at x_t)
-      plane_put(Acur, ct, j, h, x);
-      ws_barrier();  // 1
-      f32x16 g0, g1, g2, a1own;
+      // planes: a_0 = x in A[par], a_k = act(Z_{k-1}) in A[(par + k) & 1] (k = 1 .. LH + 1); the last two stay intact for the backward
+      // pass, the earlier ones (and x) are re-published from registers when their weight gradient is due
+      float* __restrict__ Ap[2] = {pl + par * PLANE, pl + (1 - par) * PLANE};
+      float* __restrict__ Dp[2] = {pl + 2 * PLANE, pl + 3 * PLANE};
+      plane_put(Ap[0], ct, j, h, x);
+      ws_barrier();
+      f32x16 g[LH + 1], aown[LH > 1 ? LH - 1 : 1];
       const int bofs = 4 * h * RS + j;  // this lane's column of a plane as an MFMA B operand
       {
         // (the time embedding is added behind the products: its load, requested at the top of the step, must not hold up the first MFMA)
         f32x16 zero;
 #pragma unroll
         for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
-        const f32x16 z0 = mm_rows<4 * OTD>(Win + (32 * r + j) * RSI + 4 * h, Acur + bofs, A.n_kg, zero) + embv;
-        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z0, a1own, g0););
+        const f32x16 z0 = mm_rows<4 * OTD>(Win + (32 * r + j) * RSI + 4 * h, Ap[0] + bofs, A.n_kg, zero) + embv;
+        f32x16 a1;
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z0, a1, g[0]););
+        if constexpr (LH > 1) aown[0] = a1;
+        plane_put(Ap[1], r, j, h, a1);
       }
-      plane_put(Aoth, r, j, h, a1own);
-      ws_barrier();  // 2
-      {
-        const f32x16 z1 = mm_rows<8>(Whid + (32 * r + j) * RSW + 4 * h, Aoth + bofs, 8, rows16(bh + 32 * r + 4 * h));
-        f32x16 a2;
-        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z1, a2, g1););
-        plane_put(Acur, r, j, h, a2);
+      ws_barrier();
+#pragma unroll
+      for (int l = 0; l < LH; ++l) {  // hidden layer l: Z_{l+1} = W_l a_{l+1} + b_l;  a_{l+2} = act(Z_{l+1})
+        const f32x16 z = mm_rows<8>(Whid + l * 64 * RSW + (32 * r + j) * RSW + 4 * h, Ap[(l + 1) & 1] + bofs, 8, rows16(bh + l * 64 + 32 * r + 4 * h));
+        f32x16 an;
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z, an, g[l + 1]););
+        if (l + 2 <= LH - 1) aown[l + 2 <= LH - 1 ? l + 1 : 0] = an;  // a_{l+2} is re-published later iff l + 2 <= LH - 1
+        plane_put(Ap[l & 1], r, j, h, an);
+        ws_barrier();
       }
-      ws_barrier();  // 3
-      {
-        const f32x16 z2 = mm_rows<8>(Whid + 64 * RSW + (32 * r + j) * RSW + 4 * h, Acur + bofs, 8, rows16(bh + 64 + 32 * r + 4 * h));
-        f32x16 a3;
-        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z2, a3, g2););
-        plane_put(Aoth, r, j, h, a3);
-      }
-      ws_barrier();  // 4
-      const f32x16 nn = mm_rows<8>(Wout + (32 * ct + j) * RSW + 4 * h, Aoth + bofs, 8, rows16(bo + cb));
+      const f32x16 nn = mm_rows<8>(Wout + (32 * ct + j) * RSW + 4 * h, Ap[(LH + 1) & 1] + bofs, 8, rows16(bo + cb));
 
       // ======================================================================================= upstream gradient of the control
       f32x16 G, Gc, cvec, dout;
@@ -438,40 +438,38 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       }
 
       // ======================================================================================= backward + weight gradients
-      plane_put(D0, ct, j, h, dout);
-      ws_barrier();  // 5: delta_out | a_3 (Aoth)
+      // delta planes alternate between D[0] and D[1]; each stage: publish delta_k (and a_k unless its plane is still intact), barrier,
+      // dW_k += delta_k a_k^T, then the adjoint of the layer below
+      plane_put(Dp[0], ct, j, h, dout);
+      ws_barrier();  // delta_out | a_{LH+1}
       f32x16 dl;
-      {
-        if constexpr (OTD == 2) dw_acc<true>(D0, r, Aoth, 0, dw[OTD + 2 * LH], dw[NDW - 1], bs_out, j, h);
-        else dw_acc<false>(D0, 0, Aoth, r, dw[OTD + 2 * LH], dw[OTD + 2 * LH], bs_out, j, h);
-        dl = mm_cols<4 * OTD, RSW>(Wout + (4 * h) * RSW + 32 * r + j, D0 + bofs, A.n_kg) * g2;
+      if constexpr (OTD == 2) dw_acc<true>(Dp[0], r, Ap[(LH + 1) & 1], 0, dw[OTD + 2 * LH], dw[NDW - 1], bs_out, j, h);
+      else dw_acc<false>(Dp[0], 0, Ap[(LH + 1) & 1], r, dw[OTD + 2 * LH], dw[OTD + 2 * LH], bs_out, j, h);
+      dl = mm_cols<4 * OTD, RSW>(Wout + (4 * h) * RSW + 32 * r + j, Dp[0] + bofs, A.n_kg) * g[LH];
+#pragma unroll
+      for (int l = LH - 1; l >= 0; --l) {  // hidden layer l: dl = d loss / d Z_{l+1}
+        float* __restrict__ Dl = Dp[(LH - l) & 1];
+        float* __restrict__ Al = Ap[(l + 1) & 1];
+        plane_put(Dl, r, j, h, dl);
+        if (l + 1 <= LH - 1) plane_put(Al, r, j, h, aown[l + 1 <= LH - 1 ? l : 0]);  // a_{l+1}: its plane was overwritten by a_{l+3}
+        ws_barrier();
+        dw_acc<true>(Dl, r, Al, 0, dw[OTD + 2 * l], dw[OTD + 2 * l + 1], bs_hid[l], j, h);
+        dl = mm_cols<8, RSW>(Whid + l * 64 * RSW + (4 * h) * RSW + 32 * r + j, Dl + bofs, 8) * g[l];
       }
-      plane_put(D1, r, j, h, dl);
-      ws_barrier();  // 6: delta_2 | a_2 (Acur)
-      {
-        dw_acc<true>(D1, r, Acur, 0, dw[OTD + 2], dw[OTD + 3], bs_hid[1], j, h);
-        dl = mm_cols<8, RSW>(Whid + 64 * RSW + (4 * h) * RSW + 32 * r + j, D1 + bofs, 8) * g1;
-      }
-      plane_put(D0, r, j, h, dl);
-      plane_put(Aoth, r, j, h, a1own);
-      ws_barrier();  // 7: delta_1 | a_1 (Aoth)
-      {
-        dw_acc<true>(D0, r, Aoth, 0, dw[OTD], dw[OTD + 1], bs_hid[0], j, h);
-        dl = mm_cols<8, RSW>(Whid + (4 * h) * RSW + 32 * r + j, D0 + bofs, 8) * g0;
-      }
-      plane_put(D1, r, j, h, dl);
-      plane_put(Acur, ct, j, h, x);
-      ws_barrier();  // 8: delta_0 | x (Acur)
+      float* __restrict__ Din = Dp[(LH + 1) & 1];
+      plane_put(Din, r, j, h, dl);
+      plane_put(Ap[0], ct, j, h, x);
+      ws_barrier();  // delta_0 | x
       {
         float esum = 0.0f;
-        dw_acc<(OTD == 2)>(D1, r, Acur, 0, dw[0], dw[OTD - 1], esum, j, h);
+        dw_acc<(OTD == 2)>(Din, r, Ap[0], 0, dw[0], dw[OTD - 1], esum, j, h);
         esum += __shfl_xor(esum, 32);  // d loss / d (time embedding + input bias)[t][32 r + j]
         if (live_item && h == 0) A.epart[(tile * T + t) * 64 + 32 * r + j] = esum;
       }
       if constexpr (BPTT) {
         // ===================================================================================== adjoint update
         //   lambda_t = c_x lambda_{t+1} + W_in^T delta_0 + (d score term / d x)^T G + direct cost terms
-        const f32x16 dx = mm_cols<8, RSI>(Win + (4 * h) * RSI + 32 * ct + j, D1 + bofs, 8);
+        const f32x16 dx = mm_cols<8, RSI>(Win + (4 * h) * RSI + 32 * ct + j, Din + bofs, 8);
         // score terms the reference detaches (reparam.py:58,134,169,188) or obtains by autograd without a graph carry no Jacobian
         const float coef_t = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET ? wl : 0.0f);
         const float coef_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR ? 1.0f - wl : 0.0f;
@@ -535,38 +533,52 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
     store_tile(rec + off_whid<OTD>() + l * 4096, 64, r, 1, j, h, dw[OTD + 2 * l + 1]);
     float b = bs_hid[l];
     b += __shfl_xor(b, 32);
-    if (h == 0) rec[off_bhid<OTD>() + l * 64 + 32 * r + j] = b;
+    if (h == 0) rec[off_bhid<OTD, LH>() + l * 64 + 32 * r + j] = b;
   }
   {
     float b = bs_out;
     b += __shfl_xor(b, 32);
     if constexpr (OTD == 2) {
-      store_tile(rec + off_wout<OTD>(), 64, r, 0, j, h, dw[OTD + 2 * LH]);
-      store_tile(rec + off_wout<OTD>(), 64, r, 1, j, h, dw[OTD + 2 * LH + 1]);
-      if (h == 0) rec[off_bout<OTD>() + 32 * r + j] = b;
+      store_tile(rec + off_wout<OTD, LH>(), 64, r, 0, j, h, dw[OTD + 2 * LH]);
+      store_tile(rec + off_wout<OTD, LH>(), 64, r, 1, j, h, dw[OTD + 2 * LH + 1]);
+      if (h == 0) rec[off_bout<OTD, LH>() + 32 * r + j] = b;
     } else {
-      store_tile(rec + off_wout<OTD>(), 64, 0, r, j, h, dw[OTD + 2 * LH]);
-      if (h == 0 && r == 0) rec[off_bout<OTD>() + j] = b;
+      store_tile(rec + off_wout<OTD, LH>(), 64, 0, r, j, h, dw[OTD + 2 * LH]);
+      if (h == 0 && r == 0) rec[off_bout<OTD, LH>() + j] = b;
     }
   }
 }
 
-template <int OTD, bool BPTT>
+template <int OTD, bool BPTT, int LH>
 static int launch_bwdf_t(const BwdfArgs& a, hipStream_t stream) {
-  const size_t lds_bytes = (size_t)bwdf::lds_floats<OTD>() * sizeof(float);
+  const size_t lds_bytes = (size_t)bwdf::lds_floats<OTD, LH>() * sizeof(float);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf_kernel<OTD, BPTT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf_kernel<OTD, BPTT, LH>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwdf_kernel<OTD, BPTT>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((bwdf_kernel<OTD, BPTT, LH>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
-int bwdf_wsize(int d) { return d <= 32 ? bwdf::wsize<1>() : bwdf::wsize<2>(); }
+// floats of one team's partial-gradient record
+int bwdf_wsize(int d, int n_hidden) {
+  const int otd = d <= 32 ? 1 : 2;
+  return 64 * 32 * otd + n_hidden * 4096 + 32 * otd * 64 + n_hidden * 64 + 32 * otd;
+}
+
+// compiled for this shape, and does the LDS image (one natural copy of every weight matrix + 8 exchange planes) fit?
+bool bwdf_fits(int d, int n_hidden) {
+  if (n_hidden < 1 || n_hidden > bwdf::kMaxLH || d < 1 || d > 64) return false;
+  const int otd = d <= 32 ? 1 : 2;
+  const long long floats = 64 * (otd == 1 ? 36 : 68) + (long long)n_hidden * 64 * bwdf::RSW + 32 * otd * bwdf::RSW + n_hidden * 64 + 64 + bwdf::TABS +
+                           2 * 4 * bwdf::PLANE;
+  return floats * 4 <= 160 * 1024;
+}
 
 // teams (of 32 trajectories) the launch uses: two per workgroup, one workgroup per CU (the LDS image is ~130-146 KB)
 int bwdf_slots(long long batch, int n_steps, bool bptt) {
@@ -576,10 +588,20 @@ int bwdf_slots(long long batch, int n_steps, bool bptt) {
   return 2 * (int)(wgs < 256 ? wgs : 256);
 }
 
+template <int OTD, bool BPTT>
+static int launch_bwdf_l(const BwdfArgs& a, hipStream_t stream) {
+  switch (a.n_hidden) {
+    case 1: return launch_bwdf_t<OTD, BPTT, 1>(a, stream);
+    case 2: return launch_bwdf_t<OTD, BPTT, 2>(a, stream);
+    case 3: return launch_bwdf_t<OTD, BPTT, 3>(a, stream);  // (with two coordinate tiles the LDS image is 159.5 of the 160 KB)
+    default: return SDEH_ERR_UNSUPPORTED;
+  }
+}
+
 int launch_bwdf(const BwdfArgs& a, hipStream_t stream) {
   const bool bptt = !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL);
-  if (a.d <= 32) return bptt ? launch_bwdf_t<1, true>(a, stream) : launch_bwdf_t<1, false>(a, stream);
-  return bptt ? launch_bwdf_t<2, true>(a, stream) : launch_bwdf_t<2, false>(a, stream);
+  if (a.d <= 32) return bptt ? launch_bwdf_l<1, true>(a, stream) : launch_bwdf_l<1, false>(a, stream);
+  return bptt ? launch_bwdf_l<2, true>(a, stream) : launch_bwdf_l<2, false>(a, stream);
 }
 
 }  // namespace sdeh

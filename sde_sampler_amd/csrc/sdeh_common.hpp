@@ -174,8 +174,8 @@ struct BwdfArgs {
   const float* ws;  // prep'd workspace: per-step coefficients, time embedding (accumulator order), gamma table, Gaussian tables
   WsLayout lay;
   const float* w_in;      // [64, d]      raw parameters of the FourierMLP (models/mlp.py:85-112)
-  const float* w_hid[2];  // [64, 64]
-  const float* b_hid[2];  // [64]
+  const float* w_hid[3];  // [64, 64]  (n_hidden of them)
+  const float* b_hid[3];  // [64]
   const float* w_out;     // [d, 64]
   const float* b_out;     // [d]
   const float* xs;        // [T+1, d, B]  (coordinate-major, as sdeh_simulate_fwd_train2 writes it)
@@ -194,9 +194,11 @@ struct BwdfArgs {
   unsigned long long seed, offset;
   const unsigned long long* rng_dev;
   int n_tiles, n_slots, wsize;
+  int n_hidden;           // 1 .. 3
 };
 int launch_bwdf(const BwdfArgs& a, hipStream_t stream);
-int bwdf_wsize(int d);                                     // floats of one team's partial-gradient record
+int bwdf_wsize(int d, int n_hidden);                       // floats of one team's partial-gradient record
+bool bwdf_fits(int d, int n_hidden);                        // compiled for this shape and its LDS image fits
 int bwdf_slots(long long batch, int n_steps, bool bptt);  // teams (partial records) a launch uses
 
 // effective Philox offset of a launch: by-value part + the optional device-resident counter (hipGraph replays)

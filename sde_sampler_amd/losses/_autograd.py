@@ -64,7 +64,8 @@ def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torc
     bptt = not (pr.flags & L.FLAG_CHANGE_SDE_CTRL)
     lib = L.load()
     n_scratch, n_out = C.c_int64(), C.c_int64()
-    L.check(lib.sdeh_ctrl_backward_fused_sizes(d, T, B, g, int(bptt), C.byref(n_scratch), C.byref(n_out)))
+    Lh = len(base.hidden_layer)
+    L.check(lib.sdeh_ctrl_backward_fused_sizes(d, Lh, T, B, g, int(bptt), C.byref(n_scratch), C.byref(n_out)))
     scratch = torch.empty(n_scratch.value, device=dev, dtype=torch.float32)
     out = torch.empty(n_out.value, device=dev, dtype=torch.float32)
     plan = engine._plan(dev, d, base.channels, len(base.hidden_layer), T, pr.target.n_components if pr.target.kind == L.DENS_GMM else 0)
@@ -88,9 +89,9 @@ def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torc
 
     with torch.no_grad():
         grads[id(base.input_embed.weight)] = take(64 * P, 64, P)[:, :d].contiguous()
-        w_hid = take(2 * 4096, 2, 64, 64)
+        w_hid = take(Lh * 4096, Lh, 64, 64)
         grads[id(base.out_layer.weight)] = take(P * 64, P, 64)[:d]
-        b_hid = take(128, 2, 64)
+        b_hid = take(Lh * 64, Lh, 64)
         grads[id(base.out_layer.bias)] = take(P, P)[:d]
         for k, lin in enumerate(base.hidden_layer):
             grads[id(lin.weight)], grads[id(lin.bias)] = w_hid[k], b_hid[k]

@@ -42,10 +42,8 @@ def test_fused_backward_serves_the_golden_configurations(path, method):
     noise = torch.from_numpy(fx["noise"]).cuda()
     v1, g1, name1 = _grads(prob, x0, noise, planes=False)
     v2, g2, name2 = _grads(prob, x0, noise, planes=True)
-    if meta["net"]["num_layers"] == 4:  # the depth the fused kernel is compiled for (conf/model/base/fouriermlp.yaml)
-        assert name1.startswith("bwd_fused<" + ("bptt" if method == "kl" else "rows")), name1
-    else:
-        assert not name1.startswith("bwd_fused"), name1
+    # every golden network (num_layers 3 .. 5) is one the fused kernel is compiled for
+    assert name1.startswith("bwd_fused<" + ("bptt" if method == "kl" else "rows")), name1
     assert not name2.startswith("bwd_fused"), name2
     assert v1 == v2
     for k in g1:
@@ -63,7 +61,8 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case):
 
     rng = np.random.default_rng(9000 + case)
     spec = random_spec(rng)
-    spec["net"]["num_layers"] = 4  # the depth the fused kernel is compiled for (conf/model/base/fouriermlp.yaml)
+    if case % 2 == 0:
+        spec["net"]["num_layers"] = 4  # the shipped depth (conf/model/base/fouriermlp.yaml); odd cases keep the random 3 .. 5
     method = str(rng.choice(["kl", "kl_ito", "lv", "lv_traj"]))
     spec["loss"]["method"] = method
     spec["loss"]["max_rnd"] = 1e8 if method.startswith("lv") else None
@@ -93,14 +92,17 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case):
     calls = eng.calls
     try:
         v1, g1, name1 = _grads(prob, x0, noise, planes=False)
-        eng.calls = calls  # same Philox offset for the second run
-        v2, g2, name2 = _grads(prob, x0, noise, planes=True)
     except SdehUnsupported as exc:
         if "do not fit in LDS" in str(exc):
             pytest.skip(str(exc)[:120])
         raise
+    eng.calls = calls  # same Philox offset for the second run
+    try:
+        v2, g2, name2 = _grads(prob, x0, noise, planes=True)
+    except SdehUnsupported as exc:  # shapes only the fused kernel takes (three hidden layers at d > 32: the plane kernels' packed +
+        pytest.skip("plane path: " + str(exc)[:100])  # transposed LDS images do not fit); test_..._matches_oracle_autograd covers them
     if method.startswith("kl") and spec["target"]["kind"] == "funnel" and d > 32 and spec["ctrl"]["kind"] in ("score", "lerp", "lerp_target"):
-        assert not name1.startswith("bwd_fused"), f"{tag}: {name1}"
+        assert not name1.startswith("bwd_fused"), f"{tag}: {name1}"  # the documented fall-back to the plane path
         return
     assert name1.startswith("bwd_fused"), f"{tag}: {name1}"
     assert not name2.startswith("bwd_fused"), f"{tag}: {name2}"
@@ -123,9 +125,9 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case):
 
 @pytest.mark.parametrize("case", range(32 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))
 def test_fused_backward_matches_oracle_autograd_on_random_problems(case):
-    """The random training problems of tests/test_hip_fuzz.py with the network depth the fused kernel is compiled for: loss and
-    every parameter gradient against the ORACLE's autograd (conditioning-aware criteria of that test)."""
-    check_training_case(1000 + case, num_layers=4, expect_kernel="bwd_fused")
+    """The random training problems of tests/test_hip_fuzz.py (even cases: the shipped depth; odd cases: 1 .. 3 hidden layers): loss
+    and every parameter gradient against the ORACLE's autograd (conditioning-aware criteria of that test)."""
+    check_training_case(1000 + case, num_layers=4 if case % 2 == 0 else None, expect_kernel="bwd_fused")
 
 
 def test_fused_backward_large_batch_is_deterministic():

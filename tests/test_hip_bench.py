@@ -60,3 +60,14 @@ def test_single_rank_line_has_the_contract_fields():
     r = out["roofline"]
     assert r["bound"] == "mfma" and r["peak"] == 157.3 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["kernel"].startswith("traj_") and r["kernel_ms"] > 0
+
+
+def test_training_workload_line():
+    """`bench.py --workload train_*`: one optimisation step per bench step; the roofline block is the fused backward kernel's."""
+    out = _bench("--workload", "train_gmm2_dis_kl", "--batch", "4096", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "higher_is_better", "dtype", "config", "roofline"):
+        assert key in out, key
+    r = out["roofline"]
+    assert r["kernel"].startswith("bwd_fused<bptt") and r["kernel_ms"] > 0 and r["forward_kernel_ms"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert out["config"]["method"] == "kl" and out["value"] > 0 and torch.isfinite(torch.tensor(out["final_loss"]))

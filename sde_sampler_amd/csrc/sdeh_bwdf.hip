@@ -30,8 +30,23 @@
 // what is differentiated) are those of sdeh_bwd.hpp, which stays the path for Bridges and for networks this kernel is not compiled
 // for (more than three hidden layers).
 #include "sdeh_bwd.hpp"
+#ifdef SDEH_BWDF_PROFILE
+#include <cstdio>
+#endif
 
 namespace sdeh {
+
+// -DSDEH_BWDF_PROFILE: per-phase cycle counts of one wave (block 0, wave 0) in bwdf_prof[] -- a measurement build, never shipped
+// (tools/bwdf_phase_profile.sh); phases: 0 forward in-layer, 1 hidden layers, 2 out layer, 3 elementwise, 4 dW_out + adjoint,
+// 5 hidden stages, 6 in-layer stage (dW_in, dx, lambda), 7 whole step, 8 steps counted
+#ifdef SDEH_BWDF_PROFILE
+__device__ unsigned long long bwdf_prof[16];
+#define BWDF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define BWDF_ADD(k, t0, t1) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&bwdf_prof[k], (t1) - (t0)); } while (0)
+#else
+#define BWDF_T(var) do {} while (0)
+#define BWDF_ADD(k, t0, t1) do {} while (0)
+#endif
 
 namespace bwdf {
 
@@ -355,6 +370,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       // pass, the earlier ones (and x) are re-published from registers when their weight gradient is due
       float* __restrict__ Ap[2] = {pl + par * PLANE, pl + (1 - par) * PLANE};
       float* __restrict__ Dp[2] = {pl + 2 * PLANE, pl + 3 * PLANE};
+      BWDF_T(tp0);
       plane_put(Ap[0], ct, j, h, x);
       ws_barrier();
       f32x16 g[LH + 1], aown[LH > 1 ? LH - 1 : 1];
@@ -371,6 +387,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         plane_put(Ap[1], r, j, h, a1);
       }
       ws_barrier();
+      BWDF_T(tp1);
 #pragma unroll
       for (int l = 0; l < LH; ++l) {  // hidden layer l: Z_{l+1} = W_l a_{l+1} + b_l;  a_{l+2} = act(Z_{l+1})
         const f32x16 z = mm_rows<8>(Whid + l * 64 * RSW + (32 * r + j) * RSW + 4 * h, Ap[(l + 1) & 1] + bofs, 8, rows16(bh + l * 64 + 32 * r + 4 * h));
@@ -380,7 +397,9 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         plane_put(Ap[l & 1], r, j, h, an);
         ws_barrier();
       }
+      BWDF_T(tp2);
       const f32x16 nn = mm_rows<8>(Wout + (32 * ct + j) * RSW + 4 * h, Ap[(LH + 1) & 1] + bofs, 8, rows16(bo + cb));
+      BWDF_T(tp3);
 
       // ======================================================================================= upstream gradient of the control
       f32x16 G, Gc, cvec, dout;
@@ -440,12 +459,14 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       // ======================================================================================= backward + weight gradients
       // delta planes alternate between D[0] and D[1]; each stage: publish delta_k (and a_k unless its plane is still intact), barrier,
       // dW_k += delta_k a_k^T, then the adjoint of the layer below
+      BWDF_T(tp4);
       plane_put(Dp[0], ct, j, h, dout);
       ws_barrier();  // delta_out | a_{LH+1}
       f32x16 dl;
       if constexpr (OTD == 2) dw_acc<true>(Dp[0], r, Ap[(LH + 1) & 1], 0, dw[OTD + 2 * LH], dw[NDW - 1], bs_out, j, h);
       else dw_acc<false>(Dp[0], 0, Ap[(LH + 1) & 1], r, dw[OTD + 2 * LH], dw[OTD + 2 * LH], bs_out, j, h);
       dl = mm_cols<4 * OTD, RSW>(Wout + (4 * h) * RSW + 32 * r + j, Dp[0] + bofs, A.n_kg) * g[LH];
+      BWDF_T(tp5);
 #pragma unroll
       for (int l = LH - 1; l >= 0; --l) {  // hidden layer l: dl = d loss / d Z_{l+1}
         float* __restrict__ Dl = Dp[(LH - l) & 1];
@@ -456,6 +477,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         dw_acc<true>(Dl, r, Al, 0, dw[OTD + 2 * l], dw[OTD + 2 * l + 1], bs_hid[l], j, h);
         dl = mm_cols<8, RSW>(Whid + l * 64 * RSW + (4 * h) * RSW + 32 * r + j, Dl + bofs, 8) * g[l];
       }
+      BWDF_T(tp6);
       float* __restrict__ Din = Dp[(LH + 1) & 1];
       plane_put(Din, r, j, h, dl);
       plane_put(Ap[0], ct, j, h, x);
@@ -519,6 +541,9 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
           }
         }
       }
+      BWDF_T(tp7);
+      BWDF_ADD(0, tp0, tp1); BWDF_ADD(1, tp1, tp2); BWDF_ADD(2, tp2, tp3); BWDF_ADD(3, tp3, tp4); BWDF_ADD(4, tp4, tp5);
+      BWDF_ADD(5, tp5, tp6); BWDF_ADD(6, tp6, tp7); BWDF_ADD(7, tp0, tp7); BWDF_ADD(8, 0ull, 1ull);
       par ^= 1;
     }
   }
@@ -598,7 +623,23 @@ static int launch_bwdf_l(const BwdfArgs& a, hipStream_t stream) {
   }
 }
 
+#ifdef SDEH_BWDF_PROFILE
+static void bwdf_prof_dump(hipStream_t stream) {
+  (void)hipStreamSynchronize(stream);
+  unsigned long long v[16];
+  (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(bwdf_prof), sizeof(v));
+  const double n = v[8] ? (double)v[8] : 1.0;
+  fprintf(stderr, "bwdf phases (cycles per step of block 0 / wave 0, %llu steps): in %.0f | hidden %.0f | out %.0f | elementwise %.0f | dW_out+adj %.0f | "
+          "hidden stages %.0f | in stage %.0f | step %.0f\n", v[8], v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5] / n, v[6] / n, v[7] / n);
+  unsigned long long z[16] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(bwdf_prof), z, sizeof(z));
+}
+#endif
+
 int launch_bwdf(const BwdfArgs& a, hipStream_t stream) {
+#ifdef SDEH_BWDF_PROFILE
+  struct Dump { hipStream_t s; ~Dump() { bwdf_prof_dump(s); } } dump{stream};
+#endif
   const bool bptt = !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL);
   if (a.d <= 32) return bptt ? launch_bwdf_l<1, true>(a, stream) : launch_bwdf_l<1, false>(a, stream);
   return bptt ? launch_bwdf_l<2, true>(a, stream) : launch_bwdf_l<2, false>(a, stream);

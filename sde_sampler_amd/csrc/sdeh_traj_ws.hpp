@@ -23,6 +23,9 @@
 //   M: read x, MLP(x), publish nn | barrier B | (prefetch next step's time embedding)                  | barrier A
 #pragma once
 #include "sdeh_traj.hpp"
+#ifdef SDEH_WS_PROFILE
+#include <cstdio>
+#endif
 
 #ifndef SDEH_MPRIO
 #define SDEH_MPRIO 3
@@ -54,6 +57,18 @@ __device__ __forceinline__ void ws_flag_wait(int* flag, int value) {
   while (__builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(flag)) < value) __builtin_amdgcn_s_sleep(1);
   asm volatile("" ::: "memory");
 }
+
+// -DSDEH_WS_PROFILE: cycle counts of the M and the V wave of group 0 in block 0 (measurement build, tools/ws_phase_profile.sh):
+// [0] M: network pass  [1] M: waiting for x  [2] V: score + noise + partial update  [3] V: waiting for the network output
+// [4] V: hand-off work (u, x, publish)  [5] V: cost / Ito / stores  [6] steps
+#ifdef SDEH_WS_PROFILE
+static __device__ unsigned long long ws_prof[8];
+#define WS_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define WS_ADD(k, t0, t1) do { if (blockIdx.x == 0 && lane == 0) atomicAdd(&ws_prof[k], (t1) - (t0)); } while (0)
+#else
+#define WS_T(var) do {} while (0)
+#define WS_ADD(k, t0, t1) do {} while (0)
+#endif
 
 constexpr int kWsGroups = 4;  // most trajectory groups (of 64) per workgroup; the launcher picks 4 or 2 (blockDim.x = 128 G)
 
@@ -639,6 +654,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       if (A.zt_out == nullptr) Z.rows = 0;  // fused backward (sdeh_simulate_fwd_train2): no pre-activation planes
     }
     for (int i = 0; i < n_steps; ++i) {
+      WS_T(tm0);
       if constexpr (PLANES == 1) Z.base = A.zt_out + (long long)i * A.batch + row0;
       // generic variants (ACT < 0): the activation id becomes a compile-time constant of three copies of the network --
       // selecting it per element costs a scalar branch per element pair inside the MFMA stages (1.5x on the whole kernel)
@@ -647,12 +663,15 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         else ws_mlp<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z););
       if (fsync) ws_flag_set(hand + 1, i + 1);
       else ws_barrier();  // barrier B: network output published
+      WS_T(tm1);
       if (i + 1 < n_steps) {
 #pragma unroll
         for (int ot = 0; ot < OT; ++ot) emb[ot] = load16(ws + L.emb + (i + 1) * C + (ot * 2 + h) * 16);
       }
       if (fsync) ws_flag_wait(hand, i + 2);
       else ws_barrier();  // barrier A: x_{i+1} published
+      WS_T(tm2);
+      if (group == 0) { WS_ADD(0, tm0, tm1); WS_ADD(1, tm1, tm2); }
     }
     return;
   }
@@ -702,6 +721,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   else ws_barrier();  // barrier A: x_0 published
 
   for (int i = 0; i < n_steps; ++i) {
+    WS_T(tv0);
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
     const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
 
@@ -804,8 +824,10 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j) x[j] = fmaf(c_n, xi[j], c_x * x[j]);
     SDEH_FENCE();
 
+    WS_T(tv1);
     if (fsync) ws_flag_wait(hand + 1, i + 1);
     else ws_barrier();  // barrier B: the M wave has published the network output
+    WS_T(tv2);
     // ---- u = clip(nn) + score term; publish x_{i+1} first: the M wave is idle until barrier A ------------------------
     float u[DP];
 #pragma unroll
@@ -822,6 +844,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     }
     if (fsync) ws_flag_set(hand, i + 2);
     else ws_barrier();  // barrier A: x_{i+1} published
+    WS_T(tv3);
     // ---- running cost (losses/oc.py:204-211, 319-323, 418-431) and Ito term, in the shadow of the next network pass -----
     float cost = 0.0f;
     if (!refc) {
@@ -867,6 +890,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
           if (!PAD || j < d) xp[(long long)j * A.batch] = x[j];
       }
     }
+    WS_T(tv4);
+    if (group == 0) { WS_ADD(2, tv0, tv1); WS_ADD(3, tv1, tv2); WS_ADD(4, tv2, tv3); WS_ADD(5, tv3, tv4); WS_ADD(6, 0ull, 1ull); }
   }
 
   // ---- terminal costs (oc.py:225, 337, 449-450) ----------------------------------------------------------
@@ -952,6 +977,18 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   else
     hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 0>), dim3(grid),
                        dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+#ifdef SDEH_WS_PROFILE
+  {
+    (void)hipStreamSynchronize(stream);
+    unsigned long long v[8];
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(ws_prof), sizeof(v));
+    const double n = v[6] ? (double)v[6] : 1.0;
+    fprintf(stderr, "ws phases (cycles per step, block 0 / group 0, %llu steps): M network %.0f | M waits for x %.0f || V score+noise %.0f | "
+            "V waits for nn %.0f | V hand-off %.0f | V cost/stores %.0f\n", v[6], v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5] / n);
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ws_prof), z, sizeof(z));
+  }
+#endif
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

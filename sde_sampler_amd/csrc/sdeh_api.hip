@@ -879,9 +879,6 @@ int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProbl
   if (getenv("SDEH_BWD_PLANES") != nullptr) return 0;  // A/B aid: the plane-writing kernels (read per call)
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
   if (bptt && (pr->flags & SDEH_FLAG_INIT_LOGP)) return 0;
-  const bool target_jac = bptt && !(pr->flags & (SDEH_FLAG_DETACH_SCORE | SDEH_FLAG_TARGET_SCORE_CONST)) &&
-                          (pr->ctrl_kind == SDEH_CTRL_SCORE || pr->ctrl_kind == SDEH_CTRL_LERP || pr->ctrl_kind == SDEH_CTRL_LERP_TARGET);
-  if (target_jac && pr->target.kind == SDEH_DENS_FUNNEL && net.dim > 32) return 0;  // cross-coordinate sums span two waves
   return 1;
 }
 

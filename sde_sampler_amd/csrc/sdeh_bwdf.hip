@@ -275,11 +275,15 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   auto clamp_item = [&](int& t_io, int& tile_io) {  // a team without an item shadows the last one (and contributes zeros)
     if (!item_live(t_io, tile_io)) { t_io = BPTT ? T - 1 : T - 1; tile_io = n_tiles - 1; }
   };
-  f32x16 xnext;
+  // (the time embedding of the next step travels with it: it must be the FIRST addend of the input layer's sum -- the re-evaluated
+  // pre-activations then are bit for bit the forward launch's, so a ReLU unit near its kink is on the same side in both passes --
+  // and must not hold up the first MFMA of the step)
+  f32x16 xnext, embnext;
   {
     int t0 = it_t, tl0 = it_tile;
     clamp_item(t0, tl0);
     xnext = load_x(t0, tl0);
+    embnext = load16(ws + L.emb + t0 * C + (r * 2 + h) * 16);
   }
   for (long long round = 0; round < n_rounds; ++round) {
     const bool live_item = item_live(it_t, it_tile);
@@ -327,12 +331,15 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
 
     for (int t = t_first; t >= t_last; --t) {
       const f32x16 x = xnext;
+      const f32x16 embv = embnext;  // timestep_embed(t) + input bias of this wave's channels
       if (t > t_last) {
         xnext = load_x(t - 1, cur_tile);
+        embnext = load16(ws + L.emb + (t - 1) * C + (r * 2 + h) * 16);
       } else if (round + 1 < n_rounds) {
         int tn = it_t, tln = it_tile;
         clamp_item(tn, tln);
         xnext = load_x(tn, tln);
+        embnext = load16(ws + L.emb + tn * C + (r * 2 + h) * 16);
       }
       // the step's other inputs: requested first, consumed after the forward pass
       f32x16 scv, xi;
@@ -356,7 +363,6 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) xi[q] = cb + rrow(q) < d ? n[q] : 0.0f;
       }
-      const f32x16 embv = load16(ws + L.emb + t * C + (r * 2 + h) * 16);  // timestep_embed(t) + input bias of this wave's channels
       const float gam0 = has_score ? ws[L.gam + t * L.g] : 0.0f;           // gamma(t) (its first entry), requested early as well
       cfp cf = as_const(ws + L.coef + t * kCoefStride);
       const float sig = cf[CF_SIGMA], wl = cf[CF_W];
@@ -376,11 +382,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       f32x16 g[LH + 1], aown[LH > 1 ? LH - 1 : 1];
       const int bofs = 4 * h * RS + j;  // this lane's column of a plane as an MFMA B operand
       {
-        // (the time embedding is added behind the products: its load, requested at the top of the step, must not hold up the first MFMA)
-        f32x16 zero;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
-        const f32x16 z0 = mm_rows<4 * OTD>(Win + (32 * r + j) * RSI + 4 * h, Ap[0] + bofs, A.n_kg, zero) + embv;
+        const f32x16 z0 = mm_rows<4 * OTD>(Win + (32 * r + j) * RSI + 4 * h, Ap[0] + bofs, A.n_kg, embv);
         f32x16 a1;
         SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z0, a1, g[0]););
         if constexpr (LH > 1) aown[0] = a1;
@@ -511,22 +513,38 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
               const float y = x[q] - A.target.p1;
               vt[q] = (cb + rrow(q) < A.target.n_comp ? -4.0f * (3.0f * y * y - A.target.p0) : -1.0f) * cvec[q];
             }
-          } else if (A.target.kind == SDEH_DENS_FUNNEL) {  // OTD == 1 (checked by the host): every coordinate lives in this wave
-            // s_0 = -x0/var - (d-1)/2 + e^{-x0} sum x_j^2 / 2,  s_j = -x_j e^{-x0}   (coordinate 0 = register 0 of the h = 0 half)
-            const float x0 = __shfl(x[0], j), c0 = __shfl(cvec[0], j);
-            const float iv = __expf(-x0);
+          } else if (A.target.kind == SDEH_DENS_FUNNEL) {
+            // s_0 = -x0/var - (d-1)/2 + e^{-x0} sum x_j^2 / 2,  s_j = -x_j e^{-x0}   (coordinate 0 = register 0 of the h = 0 half of
+            // coordinate tile 0).  The sums run over all coordinates: two lane halves, and with d > 32 the two waves of the team --
+            // they meet in the delta plane that has been free since the last barrier (one more barrier, this configuration only).
+            const bool tile0 = ct == 0;
+            float x0 = __shfl(x[0], j), c0 = __shfl(cvec[0], j);
             float sq = 0.0f, cx = 0.0f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-              const bool first = q == 0 && h == 0;
+              const bool first = q == 0 && h == 0 && tile0;
               sq = fmaf(first ? 0.0f : x[q], x[q], sq);
               cx = fmaf(first ? 0.0f : cvec[q], x[q], cx);
             }
             sq += __shfl_xor(sq, 32);
             cx += __shfl_xor(cx, 32);
+            if constexpr (OTD == 2) {
+              float* __restrict__ sx = Dp[LH & 1];
+              if (h == 0) {
+                sx[(4 * r) * RS + j] = sq;
+                sx[(4 * r + 1) * RS + j] = cx;
+                if (tile0) { sx[8 * RS + j] = x0; sx[9 * RS + j] = c0; }
+              }
+              ws_barrier();
+              sq = sx[j] + sx[4 * RS + j];
+              cx = sx[RS + j] + sx[5 * RS + j];
+              x0 = sx[8 * RS + j];
+              c0 = sx[9 * RS + j];
+            }
+            const float iv = __expf(-x0);
 #pragma unroll
             for (int q = 0; q < 16; ++q) vt[q] = iv * (c0 * x[q] - cvec[q]);
-            if (h == 0) vt[0] = c0 * (-1.0f / A.target.p0 - 0.5f * iv * sq) + iv * cx;
+            if (h == 0 && tile0) vt[0] = c0 * (-1.0f / A.target.p0 - 0.5f * iv * sq) + iv * cx;
           }
         }
 #pragma unroll

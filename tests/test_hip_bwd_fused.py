@@ -55,8 +55,16 @@ def test_fused_backward_serves_the_golden_configurations(path, method):
         assert np.abs(a - b).max() <= 5e-5 * scale + 1e-7, f"{k}: fused vs planes {np.abs(a - b).max():.3e} / {scale:.3e}"
 
 
+def test_relu_units_near_the_kink_follow_the_forward_pass():
+    """The fused kernel re-evaluates the network; its pre-activations must be bit for bit the forward launch's (same first addend,
+    same k order), or a ReLU unit within rounding of its kink takes the other side in the backward pass.  Case 697 of the wide
+    sweep (ReLU, three hidden layers, lv_traj, 9252 row-steps) has such units: with the time embedding added BEHIND the input
+    layer's products instead of in front, input_embed.bias came out 6e-4 off (float64 oracle: 3e-7)."""
+    test_fused_backward_equals_plane_backward_on_random_problems(697, tol=1e-5)
+
+
 @pytest.mark.parametrize("case", range(N_RANDOM))
-def test_fused_backward_equals_plane_backward_on_random_problems(case):
+def test_fused_backward_equals_plane_backward_on_random_problems(case, tol=2e-4):
     from sde_sampler_amd import SdehUnsupported, problems
 
     rng = np.random.default_rng(9000 + case)
@@ -101,9 +109,8 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case):
         v2, g2, name2 = _grads(prob, x0, noise, planes=True)
     except SdehUnsupported as exc:  # shapes only the fused kernel takes (three hidden layers at d > 32: the plane kernels' packed +
         pytest.skip("plane path: " + str(exc)[:100])  # transposed LDS images do not fit); test_..._matches_oracle_autograd covers them
-    if method.startswith("kl") and spec["target"]["kind"] == "funnel" and d > 32 and spec["ctrl"]["kind"] in ("score", "lerp", "lerp_target"):
-        assert not name1.startswith("bwd_fused"), f"{tag}: {name1}"  # the documented fall-back to the plane path
-        return
+    if name1.startswith("traj_legacy"):  # mixture tables beyond LDS: the forward keeps no planes, the plane path serves
+        pytest.skip(f"{tag}: forward served by {name1}")
     assert name1.startswith("bwd_fused"), f"{tag}: {name1}"
     assert not name2.startswith("bwd_fused"), f"{tag}: {name2}"
     assert v1 == v2 or (np.isnan(v1) and np.isnan(v2)), f"{tag}: loss {v1} vs {v2}"
@@ -118,9 +125,11 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case):
         b = torch.zeros_like(a) if b is None else b
         if not torch.isfinite(b).all():
             continue
-        denom = max(b.abs().max().item(), 1e-4 * gmax, 1e-12)
+        # relative to the tensor's own scale, with a floor at 1e-3 of the network's largest gradient: a bias gradient that is the
+        # cancelling sum of T * B terms carries the summation order's rounding (1e-7 of the terms), not its own 1e-7
+        denom = max(b.abs().max().item(), 1e-3 * gmax, 1e-12)
         err = (a - b).abs().max().item() / denom
-        assert err <= 2e-4, f"{tag}: grad {k} fused vs planes rel err {err:.2e}"
+        assert err <= tol, f"{tag}: grad {k} fused vs planes rel err {err:.2e}"
 
 
 @pytest.mark.parametrize("case", range(32 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))

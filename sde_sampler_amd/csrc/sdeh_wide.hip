@@ -143,6 +143,13 @@ __device__ __forceinline__ void wide_layer(WidePre<NT>& P, const float* __restri
       SDEH_FENCE();
     }
   }
+  // The last iterations of the main loop requested groups past the end (clamped re-reads that nobody consumes).  They MUST have
+  // landed before this function returns: the compiler sees their destination registers as dead and hands them to whatever comes
+  // next, and a load that lands late overwrites that value (found by the wide random sweep: 64-channel networks at d > 128 -- a
+  // short out layer with two tiles per wave -- came out wrong at one step of a launch).  Every ring entry is tied to the wait, so
+  // none of them is handed out before it (when NS4 % U != 0 the tail above has already drained the queue: the waits are free).
+#pragma unroll
+  for (int u = 0; u < U; ++u) wide_vmwait<0, NT>(a[u]);
 }
 
 // out[channel][trajectory] <- act(acc + bias) for this wave's tiles (bias: this lane half's 16 values per tile, accumulator order);
@@ -802,6 +809,11 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
       }
     }
   }
+
+  // the prefetch issued behind the LAST step has no consumer: it must land before its registers are handed to the terminal phase
+  // (a late load there showed up as a wrong terminal log-density in a golden test under a loaded GPU, once in a few hundred runs)
+#pragma unroll
+  for (int g = 0; g < kWidePD; ++g) wide_vmwait<0, OTW>(pre_in.a[g]);
 
   // ---- terminal costs (oc.py:225, 337, 449-450) -------------------------------------------------------------------------
   if (flags & SDEH_FLAG_TERMINAL_SECOND) wide_gauss_quad<CT>(cx, cx.tab2, xr, nto, WSL_LOGP_A);

@@ -101,10 +101,18 @@ def _close(got: float, want: float, tol: float) -> bool:
 
 @pytest.mark.parametrize("case", range(N_CASES))
 def test_random_problem_matches_oracle(case):
+    check_eval_case(case)
+
+
+def check_eval_case(case, spec_hook=None, expect_kernel=None):
+    """One random evaluation problem against the oracle on identical noise.  `spec_hook(spec, rng)` may reshape the problem (the wide
+    sweep of tests/test_hip_wide.py: 128 / 256 channels, d up to 250); `expect_kernel`: prefix of the kernel that must serve it."""
     from sde_sampler_amd import problems
 
     rng = np.random.default_rng(1000 + case)
     spec = random_spec(rng)
+    if spec_hook is not None:
+        spec_hook(spec, rng)
     prob = problems.build(spec)
     params = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
     tt = None
@@ -131,6 +139,8 @@ def test_random_problem_matches_oracle(case):
     prob.to(DEV)
     out = prob.eval(x0.to(DEV), compute_weights=weights, return_traj=True, noise=noise.to(DEV))
     tag = f"case {case}: {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T} {spec['net']}"
+    if expect_kernel is not None:
+        assert prob.loss.engine.last_kernel_name().startswith(expect_kernel), f"{tag}: {prob.loss.engine.last_kernel_name()}"
     # Per-row criterion: the dynamics amplify 1-ulp differences -- stiff wells with large steps and active clamps
     # can take single rows from 2e-6 to 0.2 within 20 steps (tests/perf/fuzz_case_debug.py shows the step-by-step growth of such a
     # case) -- so the bulk of the rows must agree tightly and only a minority may have drifted.

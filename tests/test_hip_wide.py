@@ -204,3 +204,35 @@ def test_wide_bridge_is_invariant_to_the_workgroup_split_and_to_sharding(path):
     b = prob.eval(x0[32:], compute_weights=False)
     assert torch.equal(torch.cat([a.samples, b.samples]), out[1].samples)
     assert torch.isfinite(out[1].weights).all()
+
+
+def _widen(spec, rng):
+    """Reshape a random problem of tests/test_hip_fuzz.py into a wide one: 128 / 256 channels (or 64 with d > 64), d = 33 .. 250."""
+    c = int(rng.choice([64, 128, 256]))
+    d = int(rng.choice([70, 100, 130, 196, 250] if c == 64 else [33, 40, 70, 100, 130, 196, 250]))
+    spec["net"]["channels"] = c
+    spec["net"]["num_layers"] = int(rng.choice([3, 4]))  # the wide kernels take any depth; keep the oracle's CPU time bounded
+    for part in ("target", "prior"):
+        if spec[part] is not None and "dim" in spec[part]:
+            spec[part]["dim"] = d
+    tk = spec["target"]["kind"]
+    if tk == "double_well":  # one-dimensional: take its many-dimensional sibling
+        spec["target"] = dict(kind="multi_well", dim=d, n_double_wells=int(rng.integers(1, 6)), separation=spec["target"]["separation"],
+                              shift=spec["target"]["shift"])
+    elif tk == "multi_well":
+        spec["target"]["n_double_wells"] = min(spec["target"]["n_double_wells"], d)
+    elif tk == "gmm":
+        spec["target"]["name"] = "random7"
+    if spec["ctrl"].get("gamma_dim", 1) != 1:
+        spec["ctrl"]["gamma_dim"] = d
+    spec["grid"]["steps"] = min(spec["grid"]["steps"], 12)
+    spec["batch"] = int(rng.choice([7, 33, 64, 100]))
+
+
+@pytest.mark.parametrize("case", range(24 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))
+def test_random_wide_problem_matches_oracle(case):
+    """Seeded random problems (loss x control x SDE x target x clip activity x ragged batch) on WIDE networks through the HIP engine vs
+    the CPU oracle on identical noise, with the conditioning-aware criteria of tests/test_hip_fuzz.py."""
+    from tests.test_hip_fuzz import check_eval_case
+
+    check_eval_case(3000 + case, spec_hook=_widen, expect_kernel="traj_wide")

@@ -236,3 +236,78 @@ def test_random_wide_problem_matches_oracle(case):
     from tests.test_hip_fuzz import check_eval_case
 
     check_eval_case(3000 + case, spec_hook=_widen, expect_kernel="traj_wide")
+
+
+def _random_wide_bridge_spec(rng):
+    from tests.test_hip_fuzz import random_spec
+
+    while True:
+        spec = random_spec(rng)
+        if spec["loss"]["kind"] == "time_reversal" and spec["target"]["kind"] != "gmm":  # (the wide Bridge takes closed-form targets)
+            break
+    c = int(rng.choice([128, 256]))
+    d = int(rng.choice([33, 44, 70, 100, 150, 196]))
+    for part in ("target", "prior"):
+        if spec[part] is not None and "dim" in spec[part]:
+            spec[part]["dim"] = d
+    if spec["target"]["kind"] == "double_well":
+        spec["target"] = dict(kind="multi_well", dim=d, n_double_wells=int(rng.integers(1, 6)), separation=spec["target"]["separation"],
+                              shift=spec["target"]["shift"])
+    elif spec["target"]["kind"] == "multi_well":
+        spec["target"]["n_double_wells"] = min(spec["target"]["n_double_wells"], d)
+    if spec["ctrl"].get("gamma_dim", 1) != 1:
+        spec["ctrl"]["gamma_dim"] = d
+    clip_active = rng.random() < 0.4
+    inf = dict(kind=str(rng.choice(["lerp_prior", "clipped"])), clip_model=float(rng.uniform(0.02, 0.5)) if clip_active else 1e4)
+    if inf["kind"] == "lerp_prior":
+        inf.update(clip_score=float(rng.uniform(0.5, 3.0)) if clip_active else 1e4, scale_score=float(rng.choice([1.0, 0.5])),
+                   gamma_dim=int(rng.choice([1, d])), gamma_bias=1.0)
+    spec["inference_ctrl"] = inf
+    spec["net"] = dict(channels=c, num_layers=int(rng.choice([3, 4])), activation=spec["net"]["activation"])
+    spec["inference_net"] = dict(channels=c, num_layers=int(rng.choice([2, 3, 4])), activation=str(rng.choice(["gelu", "silu", "relu"])))
+    spec["grid"]["steps"] = int(rng.integers(2, 6))
+    spec["batch"] = int(rng.choice([5, 33, 40]))
+    spec["loss"].update(method="kl", max_rnd=None)
+    return spec
+
+
+@pytest.mark.parametrize("case", range(12 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))
+def test_random_wide_bridge_matches_oracle(case):
+    """Random Bridges (TimeReversalLoss with an inference control, exact divergence) on wide networks: x_T rows and the estimators
+    against the oracle (d backward passes per step through the inference network) on identical noise."""
+    import math
+
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
+    from tests.test_hip_fuzz import _close, _perturbed
+
+    rng = np.random.default_rng(7000 + case)
+    spec = _random_wide_bridge_spec(rng)
+    prob = problems.build(spec)
+    inf = prob.loss.inference_ctrl
+    params = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
+    params_inf = {k: v.detach().clone() for k, v in inf.state_dict().items()}
+    oracle = eo.Problem(spec, params, None, params_inf)
+    ts = prob.ts.clone()
+    B, d, T = spec["batch"], spec["target"]["dim"], ts.numel() - 1
+    torch.manual_seed(case)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(T, B, d)
+    torch.set_num_threads(4)
+    ref = oracle.eval(ts, x0.clone(), noise, compute_weights=True)
+    ref_p = oracle.eval(ts, *_perturbed(x0, noise), compute_weights=True)
+    tag = (f"case {case}: wide bridge {spec['ctrl']['kind']} + {spec['inference_ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T} "
+           f"{spec['net']} inf {spec['inference_net']}")
+    prob.to(DEV)
+    out = prob.eval(x0.to(DEV), compute_weights=True, noise=noise.to(DEV))
+    assert prob.loss.engine.last_kernel_name().startswith("bridge_wide"), tag
+    if not math.isfinite(ref["log_norm_const_lb_ito"]):  # a random configuration that blows up in the reference itself
+        assert not math.isfinite(out.log_norm_const_preds["log_norm_const_lb_ito"]), tag
+        return
+    cond_rows = torch.nan_to_num((ref_p["samples"] - ref["samples"]).abs().amax(dim=1), nan=math.inf)
+    cond_lb = abs(ref_p["log_norm_const_lb_ito"] - ref["log_norm_const_lb_ito"]) if math.isfinite(ref_p["log_norm_const_lb_ito"]) else math.inf
+    row_err = ((out.samples.cpu() - ref["samples"]).abs().amax(dim=1) - cond_rows).clamp_min(0.0)
+    scale = max(1.0, float(ref["samples"].abs().max()))
+    assert row_err.median().item() <= 1e-4 * scale and (row_err > 2e-3 * scale).float().mean().item() <= 0.25, f"{tag}: x_T {row_err.max().item():.2e}"
+    got, want = out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"]
+    assert _close(got, want, 2e-3 * max(1.0, abs(want)) + 2.0 * cond_lb), f"{tag}: lb_ito {got} vs {want}"

@@ -76,7 +76,7 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case, tol=2e-4)
     spec["loss"]["max_rnd"] = 1e8 if method.startswith("lv") else None
     if method == "lv_traj":
         spec["loss"]["traj_per_sample"] = 2
-    spec["batch"] = int(rng.choice([33, 64, 100, 257]))
+    spec["batch"] = int(rng.choice([33, 64, 100, 257]) if case % 5 else rng.choice([2, 7, 31]))  # every fifth: less than one tile
     if case % 4 == 3 and spec["target"]["kind"] != "double_well":  # two coordinate tiles (the double well is one-dimensional)
         d = int(rng.choice([33, 40, 64]))
         for part in ("target", "prior"):

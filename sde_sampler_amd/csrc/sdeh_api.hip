@@ -882,9 +882,10 @@ int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProbl
   return 1;
 }
 
-static void bwdf_sizes(int d, int n_hidden, int n_steps, long long batch, int g, bool bptt, long long* wpart, long long* epart,
+static void bwdf_sizes(int d, int n_hidden, int n_steps, long long batch, int g, bool bptt, int tile, long long* wpart, long long* epart,
                        long long* gpart, long long* sums, long long* out) {
-  const long long tiles = (batch + 31) / 32, slots = bwdf_slots(batch, n_steps, bptt), ws = bwdf_wsize(d, n_hidden);
+  const long long tiles = (batch + tile - 1) / tile, slots = tile == 16 ? bwdf16_slots(batch) : bwdf_slots(batch, n_steps, bptt);
+  const long long ws = bwdf_wsize(d, n_hidden);
   const long long gw = g == 1 ? 2 : 64;
   *wpart = slots * ws;
   *epart = tiles * n_steps * 64;
@@ -898,9 +899,14 @@ int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_
   if (!bwdf_fits(dim, n_hidden) || n_steps < 1 || batch < 1 || gamma_dim < 1 || scratch_floats == nullptr || out_floats == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward_fused_sizes: bad argument");
   long long w, e, g, s, o;
-  bwdf_sizes(dim, n_hidden, n_steps, batch, gamma_dim == 1 ? 1 : 64, bptt != 0, &w, &e, &g, &s, &o);
+  bwdf_sizes(dim, n_hidden, n_steps, batch, gamma_dim == 1 ? 1 : 64, bptt != 0, 32, &w, &e, &g, &s, &o);
   *scratch_floats = w + e + g + s;
   *out_floats = o;
+  // the activation decides between the two tilings as well (sdeh_bwdf16.hip) and is not an argument here: room for either
+  if (bwdf_tile(batch, bptt != 0, SDEH_ACT_GELU_ERF) == 16) {
+    bwdf_sizes(dim, n_hidden, n_steps, batch, gamma_dim == 1 ? 1 : 64, true, 16, &w, &e, &g, &s, &o);
+    if (w + e + g + s > *scratch_floats) *scratch_floats = w + e + g + s;
+  }
   return SDEH_OK;
 }
 
@@ -924,7 +930,8 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   long long n_w, n_e, n_g, n_s, n_o;
-  bwdf_sizes(d, net.n_hidden, n_steps, batch, L.g == 1 ? 1 : 64, bptt, &n_w, &n_e, &n_g, &n_s, &n_o);
+  const int tile = bwdf_tile(batch, bptt, net.activation);  // 16: small batches through time (sdeh_bwdf16.hip)
+  bwdf_sizes(d, net.n_hidden, n_steps, batch, L.g == 1 ? 1 : 64, bptt, tile, &n_w, &n_e, &n_g, &n_s, &n_o);
   if (scratch_floats < n_w + n_e + n_g + n_s) return fail(SDEH_ERR_CAPACITY, "ctrl_backward_fused: scratch too small (%lld < %lld floats)",
                                                           (long long)scratch_floats, n_w + n_e + n_g + n_s);
   hipStream_t st = (hipStream_t)stream;
@@ -948,11 +955,13 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
-  A.n_tiles = (int)((batch + 31) / 32); A.n_slots = bwdf_slots(batch, n_steps, bptt); A.wsize = bwdf_wsize(d, net.n_hidden);
+  A.n_tiles = (int)((batch + tile - 1) / tile);
+  A.n_slots = tile == 16 ? bwdf16_slots(batch) : bwdf_slots(batch, n_steps, bptt);
+  A.wsize = bwdf_wsize(d, net.n_hidden);
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
-  rc = launch_bwdf(A, st);
+  rc = tile == 16 ? launch_bwdf16(A, st) : launch_bwdf(A, st);
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
-  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused<%s,tiles=%d>", bptt ? "bptt" : "rows", d <= 32 ? 1 : 2);
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused%s<%s,tiles=%d>", tile == 16 ? "16" : "", bptt ? "bptt" : "rows", d <= 32 ? 1 : 2);
   if (rc != SDEH_OK) return fail(rc, "ctrl_backward_fused: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   // deterministic sums over the teams / tiles
   float* s1 = sums;

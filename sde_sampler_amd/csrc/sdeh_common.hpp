@@ -200,6 +200,10 @@ int launch_bwdf(const BwdfArgs& a, hipStream_t stream);
 int bwdf_wsize(int d, int n_hidden);                       // floats of one team's partial-gradient record
 bool bwdf_fits(int d, int n_hidden);                        // compiled for this shape and its LDS image fits
 int bwdf_slots(long long batch, int n_steps, bool bptt);  // teams (partial records) a launch uses
+// the same backward on tiles of 16 trajectories (sdeh_bwdf16.hip): back-propagation through time at small batches
+int launch_bwdf16(const BwdfArgs& a, hipStream_t stream);
+int bwdf_tile(long long batch, bool bptt, int act);  // 16 or 32: trajectories per team of the launch that serves this problem
+int bwdf16_slots(long long batch);
 
 // effective Philox offset of a launch: by-value part + the optional device-resident counter (hipGraph replays)
 __device__ __forceinline__ unsigned long long philox_offset(unsigned long long offset, const unsigned long long* dev) {

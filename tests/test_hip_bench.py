@@ -68,6 +68,6 @@ def test_training_workload_line():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "higher_is_better", "dtype", "config", "roofline"):
         assert key in out, key
     r = out["roofline"]
-    assert r["kernel"].startswith("bwd_fused<bptt") and r["kernel_ms"] > 0 and r["forward_kernel_ms"] > 0
+    assert r["kernel"].startswith("bwd_fused16<bptt") and r["kernel_ms"] > 0 and r["forward_kernel_ms"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert out["config"]["method"] == "kl" and out["value"] > 0 and torch.isfinite(torch.tensor(out["final_loss"]))

@@ -442,16 +442,12 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         }
         if (has_score && live_item) {  // d loss / d gamma(t): summed over the team's trajectories
           if (A.g == 1) {
-            gsum += __shfl_xor(gsum, 32);
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) gsum += __shfl_xor(gsum, m);
+            gsum = sum_wave(gsum);
             if (lane == 0) A.gpart[(tile * T + t) * A.gw + r] = (OTD == 2 || r == 0) ? gsum : 0.0f;
           } else if (OTD == 2 || r == 0) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-              float v = gcoord[q];
-#pragma unroll
-              for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+              const float v = sum_xor16(sum_row16(gcoord[q]));  // over the 32 trajectories of this lane half
               if (j == 0) A.gpart[(tile * T + t) * A.gw + cb + rrow(q)] = v;
             }
           }
@@ -487,7 +483,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       {
         float esum = 0.0f;
         dw_acc<(OTD == 2)>(Din, r, Ap[0], 0, dw[0], dw[OTD - 1], esum, j, h);
-        esum += __shfl_xor(esum, 32);  // d loss / d (time embedding + input bias)[t][32 r + j]
+        esum = sum_xor32(esum);  // d loss / d (time embedding + input bias)[t][32 r + j]
         if (live_item && h == 0) A.epart[(tile * T + t) * 64 + 32 * r + j] = esum;
       }
       if constexpr (BPTT) {
@@ -526,8 +522,8 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
               sq = fmaf(first ? 0.0f : x[q], x[q], sq);
               cx = fmaf(first ? 0.0f : cvec[q], x[q], cx);
             }
-            sq += __shfl_xor(sq, 32);
-            cx += __shfl_xor(cx, 32);
+            sq = sum_xor32(sq);
+            cx = sum_xor32(cx);
             if constexpr (OTD == 2) {
               float* __restrict__ sx = Dp[LH & 1];
               if (h == 0) {

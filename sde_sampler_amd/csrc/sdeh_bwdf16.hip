@@ -444,17 +444,14 @@ __global__ __launch_bounds__(128) void bwdf16_kernel(const BwdfArgs A) {
           }
         if (has_score && live_item) {  // d loss / d gamma(t): summed over the team's trajectories
           if (A.g == 1) {
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) gsum += __shfl_xor(gsum, s);
+            gsum = sum_wave(gsum);
             if (lane == 0) A.gpart[(tile * T + t) * A.gw + r] = (OTD == 2 || r == 0) ? gsum : 0.0f;
           } else if (OTD == 2 || r == 0) {
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                float v = gcoord.m[m][q];
-#pragma unroll
-                for (int s = 8; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+                const float v = sum_row16(gcoord.m[m][q]);
                 if (n == 0) A.gpart[(tile * T + t) * A.gw + cb + 16 * m + q] = v;
               }
           }
@@ -489,9 +486,7 @@ __global__ __launch_bounds__(128) void bwdf16_kernel(const BwdfArgs A) {
         dw_acc<NCI>(Din, 32 * r, Ap[0], 0, dw_in, esum, n, g);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {  // d loss / d (time embedding + input bias)[t][32 r + 16 m + n]
-          float e = esum[m];
-          e += __shfl_xor(e, 16);
-          e += __shfl_xor(e, 32);
+          const float e = sum_xor32(sum_xor16(esum[m]));
           if (live_item && g == 0) A.epart[(tile * T + t) * 64 + 32 * r + 16 * m + n] = e;
         }
       }
@@ -532,10 +527,8 @@ __global__ __launch_bounds__(128) void bwdf16_kernel(const BwdfArgs A) {
               sq = fmaf(first ? 0.0f : x.m[m][q], x.m[m][q], sq);
               cx = fmaf(first ? 0.0f : cvec.m[m][q], x.m[m][q], cx);
             }
-          sq += __shfl_xor(sq, 16);
-          cx += __shfl_xor(cx, 16);
-          sq += __shfl_xor(sq, 32);
-          cx += __shfl_xor(cx, 32);
+          sq = sum_xor32(sum_xor16(sq));
+          cx = sum_xor32(sum_xor16(cx));
           if constexpr (OTD == 2) {
             float* __restrict__ sx = Dp[LH & 1];
             if (g == 0) {

@@ -33,6 +33,32 @@ __device__ __forceinline__ void swap32(float& a, float& b) {
   b = __uint_as_float(r[1]);
 }
 
+// Cross-lane sums without the LDS crossbar (__shfl_xor compiles to ds_bpermute_b32: a full LDS round trip per butterfly stage, ~700
+// cycles for a wave-wide sum).  Rows are the 16-lane groups of the DPP hardware.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+// every lane: the sum over the 16 lanes of its row (four v_add_f32_dpp)
+__device__ __forceinline__ float sum_row16(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+// every lane: v + (v of lane ^ 16)   (v_permlane16_swap exchanges the odd rows of one operand with the even rows of the other)
+__device__ __forceinline__ float sum_xor16(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// every lane: v + (v of lane ^ 32)
+__device__ __forceinline__ float sum_xor32(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float sum_wave(float v) { return sum_xor32(sum_xor16(sum_row16(v))); }
+
 // clamp(v, -m, m) as one v_med3_f32 (m = +inf: identity; NaN -> -m, as fminf(fmaxf(v, -m), m) gives)
 __device__ __forceinline__ float clipf(float v, float m) { return __builtin_amdgcn_fmed3f(v, -m, m); }
 

@@ -161,8 +161,8 @@ __device__ __forceinline__ void mlp_forward_tangent(const float* __restrict__ ld
   }
   if constexpr (!VEC) {
     // the other lane half holds the remaining channels of the same trajectory column
-    sA += __shfl_xor(sA, 32);
-    sB += __shfl_xor(sB, 32);
+    sA = sum_xor32(sA);
+    sB = sum_xor32(sB);
     djj = lane < 32 ? sA : sB;  // T layout: lane = trajectory (tile A: 0..31, tile B: 32..63)
   }
 }
@@ -299,7 +299,7 @@ __device__ __forceinline__ float mlp_tangent_cached(const float* __restrict__ ld
       }
     }
   }
-  return s + __shfl_xor(s, 32);  // the other lane half holds the remaining channels of the same trajectory column
+  return sum_xor32(s);  // the other lane half holds the remaining channels of the same trajectory column
 }
 
 template <int DP, int C, bool PAD, bool HALF>

@@ -177,7 +177,7 @@ __device__ __forceinline__ void wide_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-__device__ __forceinline__ float half_sum(float v) { return v + __shfl_xor(v, 32); }
+__device__ __forceinline__ float half_sum(float v) { return sum_xor32(v); }  // v_permlane32_swap + add (no LDS round trip)
 
 struct WideCtx {
   float* planes;       // LDS: plane p = planes + p * plane_floats ([channel | coordinate][trajectory])

@@ -300,7 +300,7 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const 
  * stored trajectory (through time for methods "kl" / "kl_ito") and the weight-gradient contractions, with no [C, n_steps*batch] plane
  * in device memory.  Compiled for channels = 64, one to three hidden layers (conf/model/base/fouriermlp.yaml: num_layers 4 = two),
  * d <= 64, no inference control: sdeh_ctrl_backward_fused_supported says whether a problem qualifies; sdeh_ctrl_backward_ex + sdeh_weight_grad
- * take the rest.  Through time, batches up to 8192 trajectories run the same kernel on tiles of 16 trajectories (csrc/sdeh_bwdf16.hip:
+ * take the rest.  Through time, batches below 16 384 trajectories run the same kernel on tiles of 16 trajectories (csrc/sdeh_bwdf16.hip:
  * the chain of a step is half as long -- the reference's training batches are 512 and 2048); same arguments, same results up to rounding.
  *
  * sdeh_simulate_fwd_train2 == sdeh_simulate_fwd for a training step that keeps what the fused backward reads, all

@@ -6,10 +6,11 @@
 // each running the whole per-step chain of sdeh_bwdf.hip (37 k cycles: 296 matrix instructions of 64 cycles, activation and
 // derivative of 48 elements per lane, eight LDS round trips).  Both matrix shapes retire 32 multiply-adds per cycle, so halving the
 // tile halves every lane's chain -- 8 accumulator registers per row tile instead of 16 -- and doubles the number of teams.  A team
-// is its own workgroup here (two wavefronts, a barrier couples only them), two of which fit a CU's LDS.  Above 8192 trajectories
-// every SIMD already has a wave of the 32-trajectory kernel and that one is used (fewer, longer instructions per trajectory).
-// Up to 4096 trajectories (256 tiles) a team is FOUR wavefronts -- wave (r, mb) owns the 16 rows 32 r + 16 mb .. of every layer, one
-// accumulator tile instead of two -- so that all 1024 SIMDs work and the chain halves once more (NW = 4).
+// is its own workgroup here (a barrier couples only its waves), two of which fit a CU's LDS at d <= 32.  From 16 384 trajectories on
+// every SIMD has a wave of the 32-trajectory kernel and that one is used (fewer, longer instructions per trajectory).
+// A team is FOUR wavefronts (NW = 4): wave (r, mb) owns the 16 rows 32 r + 16 mb .. of every layer -- one accumulator tile, the chain
+// halves once more, and at 252-288 registers two such waves share a SIMD when the batch asks for it.  (NW = 2, two tiles per wave,
+// is kept for the comparison.)
 //
 // Same semantics and the same reference (losses/oc.py:176-222 / 301-334 / 416-446 through models/mlp.py:114-122 and
 // models/reparam.py:56-83,131-197) as sdeh_bwdf.hip; same inputs (the coordinate-major planes of sdeh_simulate_fwd_train2), the same
@@ -659,14 +660,16 @@ static int launch_bwdf16_l(const BwdfArgs& a, hipStream_t stream) {
   }
 }
 
-// Tiles of 16 serve back-propagation through time while the 32-trajectory kernel would leave SIMDs empty (one wave per SIMD at
-// 256 tiles of 32 = 8192 trajectories), for activations without a kink (header).  SDEH_BWD_TILE=16 | 32 forces either (tests).
+// Tiles of 16 serve back-propagation through time below 16 384 trajectories, for activations without a kink (header).  Measured
+// (profiles/r02_tile16_timing.txt; d = 2, T = 100 / d = 50, T = 200, backward kernel in ms, tiles of 16 against tiles of 32):
+// B = 2048: 0.63 / 1.73 and 1.40 / 4.85; 8192: 0.89 / 1.75 and 2.82 / 5.17; 16 384: 1.73 / 1.77 and 5.39 / 5.29 -- from there on
+// the 32-trajectory kernel fills the chip as well and needs fewer instructions per trajectory.  SDEH_BWD_TILE=16 | 32 forces either.
 int bwdf_tile(long long batch, bool bptt, int act) {
   if (!bptt || act == SDEH_ACT_RELU) return 32;
   const char* force = getenv("SDEH_BWD_TILE");  // (read per call: tests switch it)
   if (force != nullptr && force[0] == '1') return 16;
   if (force != nullptr && force[0] == '3') return 32;
-  return batch <= 8192 ? 16 : 32;
+  return batch < 16384 ? 16 : 32;
 }
 
 // teams (= workgroups = partial records) of a 16-trajectory launch: one per tile up to two per CU, persistent beyond
@@ -675,11 +678,14 @@ int bwdf16_slots(long long batch) {
   return (int)(tiles < 512 ? tiles : 512);
 }
 
-// waves per team: four while every wave still gets a SIMD of its own (256 tiles x 4 = 1024), two above.  SDEH_BWD_WAVES=2 | 4 forces it.
+// waves per team: four.  Measured against two (tools/tile16_waves_timing.sh): 0.63 against 0.97 ms at B <= 4096 (d = 2, T = 100: every
+// wave has a SIMD of its own), and still 0.89 against 0.99 ms at 8192, where two workgroups of four share a CU -- two waves per SIMD
+// (252-288 registers each) fill each other's LDS round trips.  SDEH_BWD_WAVES=2 keeps the two-wave teams reachable (tests).
 int bwdf16_waves(long long batch) {
   const char* force = getenv("SDEH_BWD_WAVES");
   if (force != nullptr && (force[0] == '2' || force[0] == '4')) return force[0] - '0';
-  return batch <= 4096 ? 4 : 2;
+  (void)batch;
+  return 4;
 }
 
 int launch_bwdf16(const BwdfArgs& a, hipStream_t stream) {

@@ -17,13 +17,16 @@ DEV = "cuda:0"
 N_RANDOM = 48 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))  # SDEH_FUZZ_SCALE=8: an occasional wider sweep (same seeds + more)
 
 
-def _grads(prob, x0, noise, planes: bool, tile: int | None = None):
+def _grads(prob, x0, noise, planes: bool, tile: int | None = None, waves: int | None = None):
     """Loss, gradients and the name of the backward kernel; `planes`: the plane-writing kernels instead of the fused one; `tile`: 16 |
-    32 forces the trajectories per team of the fused backward (csrc/sdeh_bwdf16.hip serves kl / kl_ito up to 8192 trajectories)."""
+    32 forces the trajectories per team of the fused backward (csrc/sdeh_bwdf16.hip serves kl / kl_ito below 16 384 trajectories);
+    `waves`: 2 | 4 forces the wavefronts per 16-trajectory team (default: 4)."""
     if planes:
         os.environ["SDEH_BWD_PLANES"] = "1"
     if tile is not None:
         os.environ["SDEH_BWD_TILE"] = str(tile)
+    if waves is not None:
+        os.environ["SDEH_BWD_WAVES"] = str(waves)
     try:
         prob.ctrl.zero_grad()
         val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
@@ -33,6 +36,7 @@ def _grads(prob, x0, noise, planes: bool, tile: int | None = None):
     finally:
         os.environ.pop("SDEH_BWD_PLANES", None)
         os.environ.pop("SDEH_BWD_TILE", None)
+        os.environ.pop("SDEH_BWD_WAVES", None)
 
 
 @pytest.mark.parametrize("method", ["lv", "kl"])
@@ -48,8 +52,11 @@ def test_fused_backward_serves_the_golden_configurations(path, method):
     v2, g2, name2 = _grads(prob, x0, noise, planes=True)
     assert not name2.startswith("bwd_fused"), name2
     relu = type(prob.ctrl.base_model.activation).__name__ == "ReLU"
-    for tile in (16, 32):  # through time the fixture batches belong to the 16-trajectory kernel (activations without a kink)
-        v1, g1, name1 = _grads(prob, x0, noise, planes=False, tile=tile)
+    # through time the fixture batches belong to the 16-trajectory kernel (activations without a kink), teams of four waves
+    for tile, waves in ((16, 4), (16, 2), (32, None)):
+        if method != "kl" and waves == 2:
+            continue
+        v1, g1, name1 = _grads(prob, x0, noise, planes=False, tile=tile, waves=waves)
         # every golden network (num_layers 3 .. 5) is one the fused kernel is compiled for
         expect = "bwd_fused16<bptt" if method == "kl" and tile == 16 and not relu else "bwd_fused<" + ("bptt" if method == "kl" else "rows")
         assert name1.startswith(expect), (name1, expect)
@@ -59,8 +66,8 @@ def test_fused_backward_serves_the_golden_configurations(path, method):
             a = g1[k].cpu().numpy() if g1[k] is not None else np.zeros_like(ref)
             b = g2[k].cpu().numpy() if g2[k] is not None else np.zeros_like(ref)
             scale = max(np.abs(ref).max(), 1e-6)
-            assert np.abs(a - ref).max() <= 2e-4 * scale + 1e-7, f"{k}: fused({tile}) vs reference {np.abs(a - ref).max():.3e} / {scale:.3e}"
-            assert np.abs(a - b).max() <= 5e-5 * scale + 1e-7, f"{k}: fused({tile}) vs planes {np.abs(a - b).max():.3e} / {scale:.3e}"
+            assert np.abs(a - ref).max() <= 2e-4 * scale + 1e-7, f"{k}: fused({tile}, {waves}) vs reference {np.abs(a - ref).max():.3e} / {scale:.3e}"
+            assert np.abs(a - b).max() <= 5e-5 * scale + 1e-7, f"{k}: fused({tile}, {waves}) vs planes {np.abs(a - b).max():.3e} / {scale:.3e}"
 
 
 def test_relu_units_near_the_kink_follow_the_forward_pass():
@@ -108,8 +115,9 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case, tol=2e-4)
     calls = eng.calls
     # odd cases through time: the 32-trajectory kernel although the batch is small (even ones: the launcher's choice, 16)
     tile = 32 if method.startswith("kl") and case % 2 else None
+    waves = 2 if case % 4 == 0 else None  # (16-trajectory teams: two waves instead of the four these batch sizes get)
     try:
-        v1, g1, name1 = _grads(prob, x0, noise, planes=False, tile=tile)
+        v1, g1, name1 = _grads(prob, x0, noise, planes=False, tile=tile, waves=waves)
     except SdehUnsupported as exc:
         if "do not fit in LDS" in str(exc):
             pytest.skip(str(exc)[:120])
@@ -151,13 +159,14 @@ def test_fused_backward_matches_oracle_autograd_on_random_problems(case):
     check_training_case(1000 + case, num_layers=4 if case % 2 == 0 else None, expect_kernel="bwd_fused")
 
 
-def test_fused_backward_large_batch_is_deterministic():
-    """B = 16 384 (more teams than workgroups: the persistent loop), kl: two launches give bitwise identical gradients (fixed-order
-    partial sums, no atomics)."""
+@pytest.mark.parametrize("batch,kernel", [(16384 + 17, "bwd_fused<bptt"), (12000 + 5, "bwd_fused16<bptt")])
+def test_fused_backward_large_batch_is_deterministic(batch, kernel):
+    """More tiles than teams (the persistent loop of either tiling), kl: two launches give bitwise identical gradients (fixed-order
+    partial sums, no atomics), and the 16-trajectory launch agrees with the 32-trajectory one."""
     from sde_sampler_amd import problems
 
     spec = problems.baseline_spec("cfg3_gmm50_pis_kl")
-    spec["batch"] = 16384 + 17
+    spec["batch"] = batch
     prob = problems.build(spec, device=DEV)
     torch.manual_seed(0)
     x0 = prob.prior.sample((spec["batch"],))
@@ -166,8 +175,17 @@ def test_fused_backward_large_batch_is_deterministic():
     v1, g1, name = _grads(prob, x0, None, planes=False)
     eng.calls = calls
     v2, g2, _ = _grads(prob, x0, None, planes=False)
-    assert name.startswith("bwd_fused<bptt"), name
+    assert name.startswith(kernel), name
     assert v1 == v2
     for k in g1:
         if g1[k] is not None:
             assert torch.equal(g1[k], g2[k]), k
+    if "16" in kernel:
+        eng.calls = calls
+        v3, g3, name3 = _grads(prob, x0, None, planes=False, tile=32)
+        assert name3.startswith("bwd_fused<bptt"), name3
+        gmax = max(g.abs().max().item() for g in g3.values() if g is not None)
+        for k in g1:
+            if g1[k] is not None:
+                err = (g1[k] - g3[k]).abs().max().item() / max(g3[k].abs().max().item(), 1e-3 * gmax)
+                assert err <= 2e-4, f"{k}: tiles of 16 vs 32 rel err {err:.2e}"

@@ -328,10 +328,19 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
   // half: a wave carries 32 trajectories (lanes 0..31 = MFMA column tile A): half the dependent MFMA chain per step, for batches
   // that leave SIMDs idle anyway (the step of this kernel is 1 + 2d network passes long, all latency at small batches)
   constexpr int rpw = HALF ? 32 : 64;
-  const long long row = (long long)blockIdx.x * (4 * rpw) + (tid >> 6) * rpw + lane;
-  const bool live = lane < rpw && row < A.batch;
-  const long long lrow = live ? row : A.batch - 1;
-  if ((long long)blockIdx.x * (4 * rpw) + (tid >> 6) * rpw >= A.batch) return;  // whole wave out of range
+  // Coordinate split (small batches, exact divergence): the step is 2 network passes + d tangent recursions in ONE wave, and up to
+  // 8192 trajectories there are fewer 32-row tiles than CUs.  With csplit = 4 the workgroup's four waves carry the same 32
+  // trajectories: each repeats the two base passes and the state update (identical results), takes the tangents of coordinates
+  // wave, wave + 4, ..., and the per-coordinate diagonal entries meet in LDS, where every wave sums them in coordinate order --
+  // the sum the single wave forms, bit for bit.  Wave 0 stores.
+  const int wave = tid >> 6;
+  const int csplit = (HALF && A.csplit > 1) ? A.csplit : 1;
+  const long long wave_row0 = csplit > 1 ? (long long)blockIdx.x * rpw : (long long)blockIdx.x * (4 * rpw) + wave * rpw;
+  const long long row = wave_row0 + lane;
+  const bool live = lane < rpw && row < A.batch && (csplit == 1 || wave == 0);
+  const long long lrow = (lane < rpw && row < A.batch) ? row : A.batch - 1;
+  if (wave_row0 >= A.batch) return;  // whole wave (with csplit: whole workgroup) out of range
+  float* __restrict__ dj_lds = lds + L.lds_floats + L2.lds_floats + (A.lay.k_max > 0 ? A.lay.k_max : 0) * 256;  // [2][d][32]
 
   const int d = PAD ? A.d : DP;
   float x[DP];
@@ -399,6 +408,19 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
       if constexpr (HALF) {
         f32x16 dc[kTanCache][C / 32];
         mlp_forward_dcache<DP, C>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, x, v, lane, dc);
+        if (csplit > 1) {
+          float* __restrict__ dj = dj_lds + (i & 1) * d * 32;  // two buffers: one barrier per step orders writes and reads
+          for (int jt = wave; jt < d; jt += 4) {
+            const float djj = mlp_tangent_cached<C>(lds2, L2, ws2 + L2.tan_in + jt * C, ws2 + L2.tan_out + jt * C, dc, lane);
+            float vj = 0.0f;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) vj = k == jt ? v[k] : vj;
+            if (lane < 32) dj[jt * 32 + lane] = (vj >= -A.inf_clip_model && vj <= A.inf_clip_model) ? djj : 0.0f;
+            SDEH_FENCE();
+          }
+          ws_barrier();
+          for (int jt = 0; jt < d; ++jt) div += dj[jt * 32 + (lane & 31)];
+        } else
         for (int jt = 0; jt < d; ++jt) {
           const float djj = mlp_tangent_cached<C>(lds2, L2, ws2 + L2.tan_in + jt * C, ws2 + L2.tan_out + jt * C, dc, lane);
           float vj = 0.0f;
@@ -879,9 +901,17 @@ int launch_bridge(const TrajArgs& a, hipStream_t stream) {
   if (((a.batch <= 32 * 1024 || cached) && !(tiles && tiles[0] == '6')) || (tiles && tiles[0] == '3')) {
     TrajArgs b = a;
     b.half = tiles && tiles[0] == '3' && tiles[2] == 'g' ? 1 : 0;  // here: 1 = do not keep act' in registers
-    const unsigned grid = (unsigned)((a.batch + 127) / 128);
-    hipLaunchKernelGGL((bridge_kernel<DP, C, PAD, true>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,
-                       a.xT, a.rnd, a.xs, b);
+    // coordinate split (kernel header): while the 32-row tiles are fewer than the CUs and there is more than one tangent to share.
+    // SDEH_BRIDGE_SPLIT=1 | 4 forces it (read per call: tests compare the two).
+    const char* split = getenv("SDEH_BRIDGE_SPLIT");
+    const size_t split_bytes = lds_bytes + (size_t)2 * a.d * 32 * sizeof(float);
+    b.csplit = 1;
+    if (cached && !b.half && a.d >= 2 && split_bytes <= 160 * 1024 &&
+        (split != nullptr ? split[0] == '4' : a.batch <= 32 * 256))
+      b.csplit = 4;
+    const unsigned grid = b.csplit > 1 ? (unsigned)((a.batch + 31) / 32) : (unsigned)((a.batch + 127) / 128);
+    hipLaunchKernelGGL((bridge_kernel<DP, C, PAD, true>), dim3(grid), dim3(256), b.csplit > 1 ? split_bytes : lds_bytes, stream, a.ws,
+                       a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   } else {
     const unsigned grid = (unsigned)((a.batch + 255) / 256);
     hipLaunchKernelGGL((bridge_kernel<DP, C, PAD, false>), dim3(grid), dim3(256), lds_bytes, stream, a.ws, a.x0, a.noise,

@@ -134,3 +134,35 @@ def test_controlled_integrator_64_row_tiles_match_32_row_tiles():
     full = run(x0)
     halves = torch.cat([run(x0[: B // 2]), run(x0[B // 2:], row_offset=B // 2)], dim=1)
     assert torch.equal(full, halves)
+
+
+@pytest.mark.parametrize("d,batch", [(2, 2048), (5, 777), (10, 2048), (33, 96)])
+def test_bridge_coordinate_split_is_bitwise_the_single_wave_result(d, batch):
+    """Small batches, exact divergence: the four waves of a workgroup carry the same 32 trajectories and share the d tangent passes
+    (csrc/sdeh_bridge.hpp, `csplit`); the diagonal entries are summed in coordinate order by every wave, so samples, rnd, the
+    trajectory and the training gradients of both networks are bit for bit those of one wave per tile (SDEH_BRIDGE_SPLIT=1)."""
+    import os
+
+    spec = dict(BRIDGE_SPEC, batch=batch, target=dict(kind="funnel", dim=d) if d >= 5 else dict(kind="gmm", dim=d, name="random7"),
+                prior=dict(kind="iso_gauss", dim=d))
+    for part in ("ctrl", "inference_ctrl"):
+        spec[part] = dict(spec[part], clip_model=0.5 if d == 5 else 10.0)  # d = 5: the clamp's mask on the diagonal is active
+    prob = _build(spec)
+    x = prob.prior.sample((batch,))
+    out = {}
+    for split in ("1", "4"):
+        os.environ["SDEH_BRIDGE_SPLIT"] = split
+        try:
+            prob.loss.engine.calls = 11
+            res = prob.eval(x, compute_weights=True, return_traj=True)
+            value, grads = _grads(prob, x, 0, 12)
+            out[split] = (res.samples.clone(), res.weights.clone(), res.xs.clone(), value, grads)
+        finally:
+            os.environ.pop("SDEH_BRIDGE_SPLIT", None)
+    a, b = out["1"], out["4"]
+    assert torch.isfinite(a[0]).all()
+    for k in range(3):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a[3], b[3])
+    for ga, gb in zip(a[4], b[4]):
+        assert torch.equal(ga, gb)

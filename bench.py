@@ -210,13 +210,15 @@ def extra_block(device, B: int) -> dict:
     # T = 200) at this batch: kernel times of the training forward and of the fused backward (back-propagation through time + weight
     # gradients, csrc/sdeh_bwdf.hip), and the backward's rate -- 2 x (4dC + 2 Lh C^2) FLOPs per trajectory-step (adjoint chain +
     # weight gradients; its re-evaluation of the network is not counted).
-    for name in ("cfg2_gmm2_dis_kl", "cfg3_gmm50_pis_kl"):
+    # (+ the same two at the reference's training batch of 2048 -- conf/solver/*.yaml --, where back-propagation through time is
+    # latency-bound and runs on tiles of 16 trajectories with four waves per tile, csrc/sdeh_bwdf16.hip)
+    for name, bt in (("cfg2_gmm2_dis_kl", B), ("cfg3_gmm50_pis_kl", B), ("cfg2_gmm2_dis_kl", 2048), ("cfg3_gmm50_pis_kl", 2048)):
         spec = problems.baseline_spec(name)
-        spec["batch"] = B
+        spec["batch"] = bt
         prob = problems.build(spec, device=device)
         eng = prob.loss.engine
         eng.timing = True
-        x0 = prob.prior.sample((B,))
+        x0 = prob.prior.sample((bt,))
         t_f, t_b = [], []
         for rep in range(4):
             prob.ctrl.zero_grad()
@@ -230,8 +232,8 @@ def extra_block(device, B: int) -> dict:
         T = prob.ts.numel() - 1
         d, c, lh = spec["target"]["dim"], spec["net"]["channels"], spec["net"]["num_layers"] - 2
         tb = min(t_b[1:])
-        tf = 2 * (4 * d * c + 2 * lh * c * c) * B * T / (tb * 1e-3) / 1e12
-        out["train_step_" + name] = {"method": "kl", "steps": T, "forward_kernel_ms": min(t_f[1:]), "backward_kernel_ms": tb,
+        tf = 2 * (4 * d * c + 2 * lh * c * c) * bt * T / (tb * 1e-3) / 1e12
+        out["train_step_" + name + ("" if bt == B else f"_b{bt}")] = {"method": "kl", "batch": bt, "steps": T, "forward_kernel_ms": min(t_f[1:]), "backward_kernel_ms": tb,
                                      "backward_kernel": bwd_name, "backward_algorithmic_tflops": tf,
                                      "backward_frac": tf / PEAK_FP32_TFLOPS}
     return out

@@ -716,6 +716,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   const bool need_t = ctrl_kind == SDEH_CTRL_SCORE || ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET;
   const bool refc = REFC >= 0 ? REFC != 0 : (flags & SDEH_FLAG_REFERENCE_CTRL) && loss_kind == SDEH_LOSS_REFERENCE_SDE;
   const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+  // (32-trajectory groups: the row whose noise this lane helps to draw -- lanes 32..63 work for trajectory lane - 32)
+  const long long row_n = (long long)blockIdx.x * (rpg * n_groups) + group * rpg + (lane & 31);
+  const unsigned long long grow_n = (unsigned long long)(A.row_offset + (row_n < A.batch ? row_n : A.batch - 1));
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
   if (fsync) ws_flag_set(hand, 1);
   else ws_barrier();  // barrier A: x_0 published
@@ -790,6 +793,26 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       const float* __restrict__ np = noise + ((long long)i * A.batch + lrow) * d;
 #pragma unroll
       for (int j = 0; j < DP; ++j) xi[j] = np[PAD ? min(j, d - 1) : j];
+    } else if (A.half) {
+      // Groups of 32 trajectories leave lanes 32..63 of this wave idle: they draw the ODD Philox blocks of trajectory lane - 32, the
+      // lower lanes the even ones, and one v_permlane32_swap per value hands each half the other's (same counters, same values:
+      // bit-identical noise for half the Philox / Box-Muller instructions, the largest item of the V wave's step)
+      constexpr int NB = (DP + 3) / 4;
+      const int hh = lane >> 5;
+#pragma unroll
+      for (int jp = 0; jp < (NB + 1) / 2; ++jp) {
+        const int jb = 2 * jp + hh;
+        float n[4];
+        box_muller4(philox_block(A.seed, rng_off, grow_n, i, jb), n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = (!PAD || 4 * jb < d) ? n[q] : 0.0f;
+          auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+          if (8 * jp + q < DP) xi[8 * jp + q] = __uint_as_float(r[0]);          // block 2 jp: drawn by the lower lanes
+          if (8 * jp + 4 + q < DP) xi[8 * jp + 4 + q] = __uint_as_float(r[1]);  // block 2 jp + 1: drawn by the upper lanes
+        }
+        SDEH_FENCE();
+      }
     } else {
 #pragma unroll
       for (int jb = 0; jb < (DP + 3) / 4; ++jb) {

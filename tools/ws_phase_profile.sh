@@ -2,7 +2,7 @@
 # Cycle counts of the M and the V wave of one trajectory group of the wave-specialised kernel (headline variant): builds a
 # measurement copy of the library with -DSDEH_WS_PROFILE (s_memtime at the hand-off points; never part of the shipped build).
 #   bash tools/ws_phase_profile.sh          (build here; the .so travels to the GPU box under prof_tmp/)
-#   bash tools/ws_phase_profile.sh run      (on the GPU box)
+#   bash tools/ws_phase_profile.sh run [B]  (on the GPU box; B = 32768: the groups of 32 trajectories)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 if [ "${1:-build}" = "build" ]; then
@@ -14,5 +14,5 @@ if [ "${1:-build}" = "build" ]; then
   echo "built $ROOT/prof_tmp/libsdeh_wsprof.so"
 else
   cd $ROOT
-  SDEH_LIBRARY=$ROOT/prof_tmp/libsdeh_wsprof.so python tools/quick_time.py 12 2>&1 | grep -E "phases|kernel ms" | tail -3
+  SDEH_LIBRARY=$ROOT/prof_tmp/libsdeh_wsprof.so python tools/quick_time.py 12 ${2:-65536} 2>&1 | grep -E "phases|kernel ms" | tail -3
 fi

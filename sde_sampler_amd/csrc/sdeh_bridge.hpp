@@ -330,17 +330,19 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
   constexpr int rpw = HALF ? 32 : 64;
   // Coordinate split (small batches, exact divergence): the step is 2 network passes + d tangent recursions in ONE wave, and up to
   // 8192 trajectories there are fewer 32-row tiles than CUs.  With csplit = 4 the workgroup's four waves carry the same 32
-  // trajectories: each repeats the two base passes and the state update (identical results), takes the tangents of coordinates
-  // wave, wave + 4, ..., and the per-coordinate diagonal entries meet in LDS, where every wave sums them in coordinate order --
-  // the sum the single wave forms, bit for bit.  Wave 0 stores.
+  // trajectories: each repeats the inference network's base pass and the state update (identical results) and takes a share of the
+  // tangents; wave 0 alone evaluates the generative control (target score + network pass) and therefore takes its tangents last
+  // (coordinate jt belongs to wave (jt + 1) & 3).  The per-coordinate diagonal entries and the control meet in LDS, where every wave
+  // sums the former in coordinate order -- the sum the single wave forms, bit for bit.  Wave 0 stores.
   const int wave = tid >> 6;
-  const int csplit = (HALF && A.csplit > 1) ? A.csplit : 1;
+  const int csplit = (HALF && A.csplit > 1 && A.div_noise == nullptr && L2.n_hidden < kTanCache && !A.half) ? A.csplit : 1;  // (cached-tangent branch only)
   const long long wave_row0 = csplit > 1 ? (long long)blockIdx.x * rpw : (long long)blockIdx.x * (4 * rpw) + wave * rpw;
   const long long row = wave_row0 + lane;
   const bool live = lane < rpw && row < A.batch && (csplit == 1 || wave == 0);
   const long long lrow = (lane < rpw && row < A.batch) ? row : A.batch - 1;
   if (wave_row0 >= A.batch) return;  // whole wave (with csplit: whole workgroup) out of range
-  float* __restrict__ dj_lds = lds + L.lds_floats + L2.lds_floats + (A.lay.k_max > 0 ? A.lay.k_max : 0) * 256;  // [2][d][32]
+  float* __restrict__ dj_lds = lds + L.lds_floats + L2.lds_floats + (A.lay.k_max > 0 ? A.lay.k_max : 0) * 256;  // [2][2][d][32]: J_jj | u
+  const bool gen_here = csplit == 1 || wave == 0;  // this wave evaluates the generative control
 
   const int d = PAD ? A.d : DP;
   float x[DP];
@@ -370,10 +372,10 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
 
     // ---- generative control u -----------------------------------------------------------------------------------
     float tsc[DP], psc[DP];
-    if (need_t) target_score<DP>(tgt, ws, lds, L, 0, d, lg_lds, x, tsc);
+    if (need_t && gen_here) target_score<DP>(tgt, ws, lds, L, 0, d, lg_lds, x, tsc);
     if (need_p) dgauss_score<DP>(ws + L.dg[1], x, psc);
     float u[DP];
-    {
+    if (gen_here) {
       float sterm[DP];
       ctrl_score_term<DP>(ctrl_kind, A, L, ws, i, cf, sig, tsc, psc, sterm);
       SDEH_FENCE();
@@ -382,6 +384,12 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
       for (int j = 0; j < DP; ++j) {
         u[j] = clipf(u[j], A.clip_model) + sterm[j];
         if (PAD) u[j] = j < d ? u[j] : 0.0f;
+      }
+      if (csplit > 1) {  // for the other waves (read behind the step's barrier)
+        float* __restrict__ ub = dj_lds + ((i & 1) * 2 + 1) * d * 32;
+#pragma unroll
+        for (int j = 0; j < DP; ++j)
+          if ((!PAD || j < d) && lane < 32) ub[j * 32 + lane] = u[j];
       }
     }
     SDEH_FENCE();
@@ -409,8 +417,8 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
         f32x16 dc[kTanCache][C / 32];
         mlp_forward_dcache<DP, C>(lds2, L2, A.inf_act, ws2 + L2.emb + i * C, x, v, lane, dc);
         if (csplit > 1) {
-          float* __restrict__ dj = dj_lds + (i & 1) * d * 32;  // two buffers: one barrier per step orders writes and reads
-          for (int jt = wave; jt < d; jt += 4) {
+          float* __restrict__ dj = dj_lds + (i & 1) * 2 * d * 32;  // two buffers: one barrier per step orders writes and reads
+          for (int jt = (wave + 3) & 3; jt < d; jt += 4) {  // wave 1: 0, 4, ..; wave 2: 1, 5, ..; wave 3: 2, ..; wave 0: 3, 7, ..
             const float djj = mlp_tangent_cached<C>(lds2, L2, ws2 + L2.tan_in + jt * C, ws2 + L2.tan_out + jt * C, dc, lane);
             float vj = 0.0f;
 #pragma unroll
@@ -420,6 +428,11 @@ __global__ __launch_bounds__(256) void bridge_kernel(const float* __restrict__ w
           }
           ws_barrier();
           for (int jt = 0; jt < d; ++jt) div += dj[jt * 32 + (lane & 31)];
+          if (wave != 0) {
+            const float* __restrict__ ub = dj + d * 32;
+#pragma unroll
+            for (int j = 0; j < DP; ++j) u[j] = (!PAD || j < d) ? ub[(PAD ? min(j, d - 1) : j) * 32 + (lane & 31)] : 0.0f;
+          }
         } else
         for (int jt = 0; jt < d; ++jt) {
           const float djj = mlp_tangent_cached<C>(lds2, L2, ws2 + L2.tan_in + jt * C, ws2 + L2.tan_out + jt * C, dc, lane);
@@ -901,13 +914,13 @@ int launch_bridge(const TrajArgs& a, hipStream_t stream) {
   if (((a.batch <= 32 * 1024 || cached) && !(tiles && tiles[0] == '6')) || (tiles && tiles[0] == '3')) {
     TrajArgs b = a;
     b.half = tiles && tiles[0] == '3' && tiles[2] == 'g' ? 1 : 0;  // here: 1 = do not keep act' in registers
-    // coordinate split (kernel header): while the 32-row tiles are fewer than the CUs and there is more than one tangent to share.
+    // coordinate split (kernel header): while the 32-row tiles are fewer than the CUs.
     // SDEH_BRIDGE_SPLIT=1 | 4 forces it (read per call: tests compare the two).
     const char* split = getenv("SDEH_BRIDGE_SPLIT");
-    const size_t split_bytes = lds_bytes + (size_t)2 * a.d * 32 * sizeof(float);
+    const size_t split_bytes = lds_bytes + (size_t)4 * a.d * 32 * sizeof(float);  // [2 steps][J_jj | u][d][32]
     b.csplit = 1;
-    if (cached && !b.half && a.d >= 2 && split_bytes <= 160 * 1024 &&
-        (split != nullptr ? split[0] == '4' : a.batch <= 32 * 256))
+    if (cached && !b.half && split_bytes <= 160 * 1024 &&
+        (split != nullptr ? split[0] == '4' : (a.batch <= 32 * 256 || (a.batch <= 64 * 256 && a.d >= 10))))  // (two rounds pay from d = 10 on)
       b.csplit = 4;
     const unsigned grid = b.csplit > 1 ? (unsigned)((a.batch + 31) / 32) : (unsigned)((a.batch + 127) / 128);
     hipLaunchKernelGGL((bridge_kernel<DP, C, PAD, true>), dim3(grid), dim3(256), b.csplit > 1 ? split_bytes : lds_bytes, stream, a.ws,

@@ -136,14 +136,15 @@ def test_controlled_integrator_64_row_tiles_match_32_row_tiles():
     assert torch.equal(full, halves)
 
 
-@pytest.mark.parametrize("d,batch", [(2, 2048), (5, 777), (10, 2048), (33, 96)])
+@pytest.mark.parametrize("d,batch", [(1, 300), (2, 2048), (5, 777), (10, 2048), (33, 96)])
 def test_bridge_coordinate_split_is_bitwise_the_single_wave_result(d, batch):
     """Small batches, exact divergence: the four waves of a workgroup carry the same 32 trajectories and share the d tangent passes
     (csrc/sdeh_bridge.hpp, `csplit`); the diagonal entries are summed in coordinate order by every wave, so samples, rnd, the
     trajectory and the training gradients of both networks are bit for bit those of one wave per tile (SDEH_BRIDGE_SPLIT=1)."""
     import os
 
-    spec = dict(BRIDGE_SPEC, batch=batch, target=dict(kind="funnel", dim=d) if d >= 5 else dict(kind="gmm", dim=d, name="random7"),
+    target = dict(kind="funnel", dim=d) if d >= 5 else (dict(kind="gmm", dim=d, name="random7") if d > 1 else BRIDGE_SPEC["target"])
+    spec = dict(BRIDGE_SPEC, batch=batch, target=target,
                 prior=dict(kind="iso_gauss", dim=d))
     for part in ("ctrl", "inference_ctrl"):
         spec[part] = dict(spec[part], clip_model=0.5 if d == 5 else 10.0)  # d = 5: the clamp's mask on the diagonal is active

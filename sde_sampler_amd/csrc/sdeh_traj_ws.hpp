@@ -509,11 +509,12 @@ __device__ __forceinline__ void mfma_stage_one(const float* __restrict__ w, IN&&
 // owning output-channel tile mw of every layer (half the MFMAs and half the activations of the dependent chain per wave).  Each
 // layer's input is both tiles, so after activating its tile a wave parks it in `abuf` (double-buffered by layer parity), the
 // workgroup barrier makes both tiles visible, and the other tile is read back in the same (register, lane) arrangement.  The
-// k-steps run in the order of ws_mlp_half (tile 0's channels, then tile 1's), so the results are bit-identical to it.
+// k-steps of the hidden layers run in the order of ws_mlp_half (tile 0's channels, then tile 1's): their pre-activations are bit-identical
+// to it (the fused backward re-evaluates them); the output layer is the sum of two per-wave partial sums (see below).
 template <int DP, int C, int ACT, bool ZS>
 __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float* __restrict__ xbuf, float* __restrict__ abuf,
-                                            const WsLayout& L, const f32x16& emb_mine, int lane, int mw, int& parity,
-                                            const ZStore& Z) {
+                                            float* __restrict__ xbuf2, const WsLayout& L, const f32x16& emb_mine, int lane, int mw,
+                                            int& parity, const ZStore& Z) {
   static_assert(C == 64, "pair mode splits the two 32-channel tiles of a 64-channel network");
   constexpr int OT = 2, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
@@ -554,15 +555,22 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
     mine = nxt;
     if constexpr (ZS) ws_store_z(Z, l + 1, C, mw, 0, lane, mine);
   }
-  exchange();
-  if constexpr (OTD == 1) {  // d <= 32: one output tile, wave 0 computes it
-    if (mw == 0) {
-      f32x16 u = load16(lds + L.b_out + h * 16);
-      layer(lds + L.w_out + lane, std::integral_constant<int, 1>{}, u);
+  if constexpr (OTD == 1) {
+    // d <= 32, one output tile: no further exchange -- each wave contracts over ITS OWN 32 channels (16 MFMAs; wave 1 used to idle
+    // through wave 0's 32) and publishes the partial sum in a buffer of its own; the V wave adds the two (bias in wave 0's).
+    act_tile<ACT>(mine);
+    float* __restrict__ ob = mw == 0 ? xbuf : xbuf2;
+    f32x16 u;
+    if (mw == 0) u = load16(lds + L.b_out + h * 16);
+    else {
 #pragma unroll
-      for (int r = 0; r < R; ++r) xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j] = u[r];
+      for (int q = 0; q < 16; ++q) u[q] = 0.0f;
     }
-  } else {  // two output tiles: one each
+    mfma_stage_one<16, 1>(lds + L.w_out + lane + mw * (16 * 64), [&](int s) { return mine[s]; }, u);
+#pragma unroll
+    for (int r = 0; r < R; ++r) ob[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j] = u[r];
+  } else {  // two output tiles: one each, over all 64 channels (one more exchange; measured equal to partial sums at d = 50)
+    exchange();
     f32x16 u = load16(lds + L.b_out + (mw * 2 + h) * 16);
     layer(lds + L.w_out + mw * 64 + lane, std::integral_constant<int, OTD>{}, u);
 #pragma unroll
@@ -601,6 +609,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int i = tid; i < L.lds_floats / 4; i += (int)blockDim.x) dst[i] = src[i];
   }
   float* __restrict__ xbuf = lds + L.lds_floats + group * (XR * 64);
+  // pair mode: the second M wave's partial network output (behind the exchange buffer and the activation parking); zeroed once --
+  // the M waves write columns 0..31 only, the idle lanes of the V wave read the others
+  float* __restrict__ xbuf2 = xbuf + XR * 64 + 2 * 2 * 16 * 64;
+  if (pair)
+    for (int i = tid; i < XR * 64; i += (int)blockDim.x) xbuf2[i] = 0.0f;
   // hand-off counters of the group (behind the exchange buffers): [0] x published by V, [1] network output published by M
   int* hand = reinterpret_cast<int*>(lds + L.lds_floats + kWsGroups * (XR * 64)) + 2 * group;
   const bool fsync = A.flag_sync != 0 && !pair;
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         ZStore Z{nullptr, (long long)n_steps * A.batch, A.zt_out == nullptr ? 0 : (int)(A.batch - row0 < 32 ? A.batch - row0 : 32)};
         for (int i = 0; i < n_steps; ++i) {
           if constexpr (PLANES == 1) Z.base = A.zt_out + (long long)i * A.batch + row0;
-          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, (PLANES == 1)>(lds, xbuf, abuf, L, emb1, lane, mw, parity, Z););
+          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, (PLANES == 1)>(lds, xbuf, abuf, abuf + 2 * 2 * 16 * 64, L, emb1, lane, mw, parity, Z););
           ws_barrier();  // barrier B: network output published
           if (i + 1 < n_steps) emb1 = load16(ws + L.emb + (i + 1) * C + (mw * 2 + h) * 16);
           ws_barrier();  // barrier A: x_{i+1} published
@@ -728,9 +741,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
     const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
 
-    // pair mode: the M waves exchange activations at n_hidden + 1 workgroup barriers per step; this wave joins them, spaced
-    // through its own work so that it never arrives late (input layer ~0.4 us, then ~1.1 us per layer)
-    if (pair) ws_barrier();
+    // pair mode: the M waves exchange activations at n_hidden (d > 32: n_hidden + 1) workgroup barriers per step; this wave joins
+    // them, spaced through its own work so that it never arrives late (input layer ~0.4 us, then ~1.1 us per layer)
+    constexpr bool kPairSum = row_tiles(DP) == 1;  // the network output arrives as two partial sums (ws_mlp_pair)
+    const int n_join = L.n_hidden + (kPairSum ? 0 : 1);
+    if (pair && n_join >= 1) ws_barrier();
     // ---- score term of the control (needs x only; runs while the M wave evaluates the network) -----------
     float sterm[DP];
     if (ctrl_kind != SDEH_CTRL_CLIPPED) {
@@ -786,7 +801,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     }
     SDEH_FENCE();
 
-    if (pair && L.n_hidden >= 1) ws_barrier();
+    if (pair && n_join >= 2) ws_barrier();
     // ---- Gaussian draws (independent of the control) --------------------------------------------------------
     float xi[DP];
     if (noise != nullptr) {
@@ -828,7 +843,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     }
 
     if (pair)
-      for (int k = 2; k <= L.n_hidden; ++k) ws_barrier();
+      for (int k = 3; k <= n_join; ++k) ws_barrier();
     // exponential integrator (oc.py:428-443):  x <- x a_k + (b_k^2 s^2) u + (s b_k) xi
     // Euler-Maruyama (oc.py:213-219, 325-331): x <- x + (f x + sig u) dt + sig (xi sqrt(dt))
     const bool expo = loss_kind == SDEH_LOSS_EXPONENTIAL;
@@ -853,9 +868,16 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     WS_T(tv2);
     // ---- u = clip(nn) + score term; publish x_{i+1} first: the M wave is idle until barrier A ------------------------
     float u[DP];
+    if (pair && kPairSum) {  // the network output is the sum of the two M waves' partial sums (ws_mlp_pair); one branch, not one per coordinate
+#pragma unroll
+      for (int j = 0; j < DP; ++j) u[j] = xbuf[j * 64 + lane] + xbuf2[j * 64 + lane];
+    } else {
+#pragma unroll
+      for (int j = 0; j < DP; ++j) u[j] = xbuf[j * 64 + lane];
+    }
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
-      const float nn = xbuf[j * 64 + lane];
+      const float nn = u[j];
       if constexpr (PLANES == 1) {
         if (A.nn_out != nullptr && live && (!PAD || j < d)) A.nn_out[((long long)i * A.batch + lrow) * d + j] = nn;
       }
@@ -946,10 +968,11 @@ template <int DP>
 inline size_t ws_lds_bytes(const WsLayout& L) {
   return ((size_t)L.lds_floats + (size_t)kWsGroups * xrows<DP>() * 64 + 2 * kWsGroups) * sizeof(float);  // + the hand-off counters
 }
-// pair mode: one exchange buffer + the activation parking (2 parities x 2 tiles x 16 registers x 64 lanes)
+// pair mode: one exchange buffer + the activation parking (2 parities x 2 tiles x 16 registers x 64 lanes) + the second M wave's
+// partial network output
 template <int DP>
 inline size_t ws_pair_lds_bytes(const WsLayout& L) {
-  return ((size_t)L.lds_floats + (size_t)xrows<DP>() * 64 + 2 * 2 * 16 * 64) * sizeof(float);
+  return ((size_t)L.lds_floats + (size_t)2 * xrows<DP>() * 64 + 2 * 2 * 16 * 64) * sizeof(float);  // x / partial 0 | parking | partial 1
 }
 
 template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV>

@@ -579,6 +579,110 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
   }
 }
 
+// Quad mode (TrajArgs::half == 3; C = 64, d <= 32, activations without a kink): FOUR M waves serve one group of 32 trajectories.  Wave mw
+// owns output channels 16 mw .. 16 mw + 15 of every layer as two 16 x 16 accumulator tiles (v_mfma_f32_16x16x4_f32: trajectories 0..15 and
+// 16..31 -- two independent chains): a hidden layer is 2 x 16 instructions of 32 cycles per wave instead of the pair mode's 32 of 64.
+//   lane (n, kk) = (lane & 15, lane >> 4);  accumulator register q <-> row 4 kk + q of the tile, column n
+//   A operand: the packed weight image of the 32 x 32 x 2 kernels serves as it is -- instruction t takes the packed k-steps 2t and 2t + 1:
+//              lane (n, kk) reads entry (k-step 2t + (kk >> 1), lane half kk & 1) of its row, i.e. k = mdim(2t + (kk >> 1), kk & 1)
+//   B operand: a layer's input in natural channel order, plane[k][32 trajectories] in LDS (row stride 48: conflict-free reads); every wave
+//              writes its 16 channels, one barrier, every wave reads all 64 (double-buffered by layer parity)
+//   output layer: as in the pair mode with one tile -- each wave contracts over its OWN 16 channels straight from its registers (register q
+//              of lane (n, kk) is channel 16 mw + 4 kk + q: instruction q's four k) and publishes a partial sum; the V wave adds the four.
+// The pre-activations are not bit for bit those of the 32 x 32 x 2 kernels (another instruction), which is why networks with ReLU -- whose
+// fused backward re-evaluates them bitwise -- stay with the pair mode.
+constexpr int kQuadPRS = 48;
+typedef float f32x4q __attribute__((ext_vector_type(4)));
+#define SDEH_MFMA16Q(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int ACT>
+__device__ __forceinline__ void act_tile4(f32x4q& v) {
+  if constexpr (ACT == SDEH_ACT_GELU_ERF) {
+    const f2 a = act_gelu2(f2{v[0], v[1]}), b = act_gelu2(f2{v[2], v[3]});
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = act_ct<ACT>(v[q]);
+  }
+}
+
+template <int DP, int C, int ACT>
+__device__ __forceinline__ void ws_mlp_quad(const float* __restrict__ lds, const float* __restrict__ xbuf, float* __restrict__ planes,
+                                            float* __restrict__ pout, const WsLayout& L, const f32x4q& emb_mine, int lane, int mw,
+                                            int& parity) {
+  static_assert(C == 64 && DP <= 32, "quad mode: 64 channels as four 16-row tiles, one 32-coordinate output tile");
+  constexpr int OT = 2, R = mregs(DP), XR = xrows<DP>(), PRS = kQuadPRS;
+  const int n = lane & 15, kk = lane >> 4;
+  // this lane's entry of a packed k-step pair: k-step + (kk >> 1), lane half kk & 1, row 16 mw + n of the weight matrix
+  const int aoff = (kk >> 1) * OT * 64 + (mw >> 1) * 64 + 32 * (kk & 1) + 16 * (mw & 1) + n;
+  // ... and the channel that entry multiplies: mdim(2t + (kk >> 1), kk & 1) = mdim(2t, 0) + (kk >> 1) + 4 (kk & 1)
+  const int koff = (kk >> 1) + 4 * (kk & 1);
+  f32x4q acc[2] = {emb_mine, emb_mine};
+  {  // input layer: k runs over the coordinates, B from the exchange buffer [coordinate][64]
+    const float* __restrict__ w = lds + L.w_in + aoff;
+#pragma unroll
+    for (int t = 0; t < (R + 1) / 2; ++t) {
+      const bool in_range = 2 * t + (kk >> 1) < R;  // (an odd R: the pair's second k-step does not exist)
+      const float a = w[2 * t * OT * 64];
+      const int c = mdim(2 * t, 0) + koff;
+      const float b0 = in_range ? xbuf[c * 64 + n] : 0.0f, b1 = in_range ? xbuf[c * 64 + 16 + n] : 0.0f;
+      acc[0] = SDEH_MFMA16Q(a, b0, acc[0]);
+      acc[1] = SDEH_MFMA16Q(a, b1, acc[1]);
+    }
+  }
+  for (int l = 0; l < L.n_hidden; ++l) {
+    act_tile4<ACT>(acc[0]);
+    act_tile4<ACT>(acc[1]);
+    float* __restrict__ pl = planes + parity * 64 * PRS;
+    {
+      float* __restrict__ p = pl + (16 * mw + 4 * kk) * PRS + n;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { p[q * PRS] = acc[0][q]; p[q * PRS + 16] = acc[1][q]; }
+    }
+    ws_barrier();
+    parity ^= 1;
+    const f32x4q bias = *reinterpret_cast<const f32x4q*>(lds + L.b_hid + l * C + ((mw >> 1) * 2 + (kk & 1)) * 16 + 4 * (2 * (mw & 1) + (kk >> 1)));
+    acc[0] = bias;
+    acc[1] = bias;
+    const float* __restrict__ w = lds + L.w_hid + l * L.w_hid_stride + aoff;
+    const float* __restrict__ bp = pl + koff * PRS + n;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const float a = w[2 * t * OT * 64];
+      const float b0 = bp[mdim(2 * t, 0) * PRS], b1 = bp[mdim(2 * t, 0) * PRS + 16];
+      acc[0] = SDEH_MFMA16Q(a, b0, acc[0]);
+      acc[1] = SDEH_MFMA16Q(a, b1, acc[1]);
+    }
+  }
+  act_tile4<ACT>(acc[0]);
+  act_tile4<ACT>(acc[1]);
+  // output layer: partial sums over this wave's 16 channels; instruction q: lane (n, kk) holds channel 16 mw + 4 kk + q = packed k-step
+  // 16 (mw >> 1) + q + 4 (2 (mw & 1) + (kk >> 1)), lane half kk & 1
+#pragma unroll
+  for (int ct = 0; ct < (DP + 15) / 16; ++ct) {
+    f32x4q u[2];
+    if (mw == 0) {
+      u[0] = *reinterpret_cast<const f32x4q*>(lds + L.b_out + (kk & 1) * 16 + 4 * (2 * ct + (kk >> 1)));
+      u[1] = u[0];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[0][q] = u[1][q] = 0.0f;
+    }
+    const float* __restrict__ w = lds + L.w_out + (16 * (mw >> 1) + 4 * (2 * (mw & 1) + (kk >> 1))) * 64 + 32 * (kk & 1) + 16 * ct + n;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float a = w[q * 64];
+      u[0] = SDEH_MFMA16Q(a, acc[0][q], u[0]);
+      u[1] = SDEH_MFMA16Q(a, acc[1][q], u[1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 16 * ct + 4 * kk + q;
+      if (c < XR) { pout[c * 64 + n] = u[0][q]; pout[c * 64 + 16 + n] = u[1][q]; }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------------------------
@@ -598,8 +702,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n_groups = (int)(blockDim.x >> 7);
-  const bool pair = A.half == 2;  // one group, three waves: V, M(tile 0), M(tile 1)
+  const bool pair = A.half >= 2;  // one group of 32 trajectories per workgroup: V + two M waves (half == 2) or V + four (half == 3: quad)
+  const bool quad = A.half == 3;
+  const int n_groups = pair ? 1 : (int)(blockDim.x >> 7);
   const bool is_m = wave >= n_groups;
   const int group = pair ? 0 : (is_m ? wave - n_groups : wave);
 
@@ -611,9 +716,10 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   float* __restrict__ xbuf = lds + L.lds_floats + group * (XR * 64);
   // pair mode: the second M wave's partial network output (behind the exchange buffer and the activation parking); zeroed once --
   // the M waves write columns 0..31 only, the idle lanes of the V wave read the others
-  float* __restrict__ xbuf2 = xbuf + XR * 64 + 2 * 2 * 16 * 64;
+  // (quad mode: the exchange planes sit in between, and there are three such buffers)
+  float* __restrict__ xbuf2 = xbuf + XR * 64 + (quad ? 2 * 64 * kQuadPRS : 2 * 2 * 16 * 64);
   if (pair)
-    for (int i = tid; i < XR * 64; i += (int)blockDim.x) xbuf2[i] = 0.0f;
+    for (int i = tid; i < (quad ? 3 : 1) * XR * 64; i += (int)blockDim.x) xbuf2[i] = 0.0f;
   // hand-off counters of the group (behind the exchange buffers): [0] x published by V, [1] network output published by M
   int* hand = reinterpret_cast<int*>(lds + L.lds_floats + kWsGroups * (XR * 64)) + 2 * group;
   const bool fsync = A.flag_sync != 0 && !pair;
@@ -633,6 +739,25 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     __builtin_amdgcn_s_setprio(SDEH_MPRIO);
 #endif
     __syncthreads();  // LDS image staged
+    if constexpr (C == 64 && DP <= 32 && PLANES != 1) {
+      if (quad) {
+        const int mw = wave - 1;
+        const int kk = lane >> 4;
+        const int epos = ((mw >> 1) * 2 + (kk & 1)) * 16 + 4 * (2 * (mw & 1) + (kk >> 1));  // this lane's four channels in the M-order rows
+        float* __restrict__ planes = xbuf + XR * 64;
+        float* __restrict__ pout = mw == 0 ? xbuf : xbuf2 + (mw - 1) * XR * 64;
+        int parity = 0;
+        f32x4q emb1 = *reinterpret_cast<const f32x4q*>(ws + L.emb + epos);
+        ws_barrier();  // barrier A: x_0 published
+        for (int i = 0; i < n_steps; ++i) {
+          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_quad<DP, C, ACTC>(lds, xbuf, planes, pout, L, emb1, lane, mw, parity););
+          ws_barrier();  // barrier B: network output published
+          if (i + 1 < n_steps) emb1 = *reinterpret_cast<const f32x4q*>(ws + L.emb + (i + 1) * C + epos);
+          ws_barrier();  // barrier A: x_{i+1} published
+        }
+        return;
+      }
+    }
     if constexpr (C == 64) {
       if (pair) {
         const int mw = wave - 1;
@@ -868,7 +993,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     WS_T(tv2);
     // ---- u = clip(nn) + score term; publish x_{i+1} first: the M wave is idle until barrier A ------------------------
     float u[DP];
-    if (pair && kPairSum) {  // the network output is the sum of the two M waves' partial sums (ws_mlp_pair); one branch, not one per coordinate
+    if (quad) {  // the network output is the sum of the M waves' partial sums (ws_mlp_quad: four; ws_mlp_pair: two); one branch each
+#pragma unroll
+      for (int j = 0; j < DP; ++j)
+        u[j] = ((xbuf[j * 64 + lane] + xbuf2[j * 64 + lane]) + xbuf2[(XR + j) * 64 + lane]) + xbuf2[(2 * XR + j) * 64 + lane];
+    } else if (pair && kPairSum) {
 #pragma unroll
       for (int j = 0; j < DP; ++j) u[j] = xbuf[j * 64 + lane] + xbuf2[j * 64 + lane];
     } else {
@@ -974,6 +1103,11 @@ template <int DP>
 inline size_t ws_pair_lds_bytes(const WsLayout& L) {
   return ((size_t)L.lds_floats + (size_t)2 * xrows<DP>() * 64 + 2 * 2 * 16 * 64) * sizeof(float);  // x / partial 0 | parking | partial 1
 }
+// quad mode: x / partial 0 | two exchange planes [64][48] | partials 1..3
+template <int DP>
+inline size_t ws_quad_lds_bytes(const WsLayout& L) {
+  return ((size_t)L.lds_floats + (size_t)4 * xrows<DP>() * 64 + 2 * 64 * kQuadPRS) * sizeof(float);
+}
 
 template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV>
 int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
@@ -1008,7 +1142,16 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   if (pair_fits && a.batch <= 32 * 256) { groups = 1; half = 2; }
   if (force != nullptr && (force[0] == '2' || force[0] == '4')) { groups = force[0] - '0'; half = force[1] == 'h' ? 1 : 0; }
   if (force != nullptr && force[0] == 'p' && pair_fits) { groups = 1; half = 2; }
+  //   B <=  6 400 : quad mode -- FOUR M waves on 16-row tiles (v_mfma_f32_16x16x4_f32), five waves per group of 32: d <= 32, no plane
+  //                 stores, activations without a kink (ReLU: the fused backward re-evaluates the pair mode's pre-activations bitwise)
+  const bool quad_fits = C == 64 && DP <= 32 && planes != 1 && (ACT >= 0 ? ACT : a.act) != SDEH_ACT_RELU &&
+                         ws_quad_lds_bytes<DP>(a.lay) <= 160 * 1024;
+  const char* quad_env = getenv("SDEH_WS_QUAD");  // "0": never, "1": whenever it fits (tests); read per call
+  if (half == 2 && quad_fits && !(force != nullptr && force[0] == 'p') && (quad_env != nullptr ? quad_env[0] == '1' : a.batch <= 32 * 200))
+    half = 3;
+  if (quad_env != nullptr && quad_env[0] == '1' && quad_fits && force == nullptr) { groups = 1; half = 3; }
   if (half == 2 && ws_pair_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_pair_lds_bytes<DP>(a.lay);
+  if (half == 3 && ws_quad_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_quad_lds_bytes<DP>(a.lay);
   TrajArgs b = a;
   b.half = half;
   b.flag_sync = getenv("SDEH_WS_BARRIER") == nullptr ? 1 : 0;  // A/B aid (read per call): the workgroup-barrier hand-off
@@ -1016,13 +1159,13 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);
   if (planes == 1)
     hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 1>), dim3(grid),
-                       dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+                       dim3(half == 3 ? 320 : (half == 2 ? 192 : 128 * groups)), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   else if (planes == 2)
     hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 2>), dim3(grid),
-                       dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+                       dim3(half == 3 ? 320 : (half == 2 ? 192 : 128 * groups)), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   else
     hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 0>), dim3(grid),
-                       dim3(half == 2 ? 192 : 128 * groups), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+                       dim3(half == 3 ? 320 : (half == 2 ? 192 : 128 * groups)), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
 #ifdef SDEH_WS_PROFILE
   {
     (void)hipStreamSynchronize(stream);

@@ -23,6 +23,9 @@ def _grads(prob, x0, noise, planes: bool, tile: int | None = None, waves: int | 
     `waves`: 2 | 4 forces the wavefronts per 16-trajectory team (default: 4)."""
     if planes:
         os.environ["SDEH_BWD_PLANES"] = "1"
+    # both paths behind the SAME forward kernel: the plane path's forward stores pre-activations from the M waves, which the quad mode
+    # of small batches (four M waves on 16-row tiles, another MFMA shape and rounding) does not do
+    os.environ["SDEH_WS_QUAD"] = "0"
     if tile is not None:
         os.environ["SDEH_BWD_TILE"] = str(tile)
     if waves is not None:
@@ -35,6 +38,7 @@ def _grads(prob, x0, noise, planes: bool, tile: int | None = None, waves: int | 
         return val.item(), {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in prob.ctrl.named_parameters()}, name
     finally:
         os.environ.pop("SDEH_BWD_PLANES", None)
+        os.environ.pop("SDEH_WS_QUAD", None)
         os.environ.pop("SDEH_BWD_TILE", None)
         os.environ.pop("SDEH_BWD_WAVES", None)
 

@@ -167,3 +167,30 @@ def test_bridge_coordinate_split_is_bitwise_the_single_wave_result(d, batch):
     assert torch.equal(a[3], b[3])
     for ga, gb in zip(a[4], b[4]):
         assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("name", ["cfg1_dw_dis_lv", "cfg2_gmm2_dis_kl", "cfg4_funnel_dds_lv"])
+def test_quad_mode_agrees_with_pair_mode(name):
+    """Small batches, d <= 32: four M waves on 16-row tiles (v_mfma_f32_16x16x4_f32, csrc/sdeh_traj_ws.hpp ws_mlp_quad) against the pair
+    mode (two M waves, 32 x 32 x 2) on the same Philox stream: another instruction and another summation tree, so the agreement is that of
+    two fp32 evaluations of the same trajectory -- estimators to 1e-4, rows to the contract's median / max bars."""
+    import os
+
+    spec = problems.baseline_spec(name)
+    spec["batch"] = 1000
+    prob = _build(spec)
+    x = prob.prior.sample((1000,))
+    out = {}
+    for quad in ("0", "1"):
+        os.environ["SDEH_WS_QUAD"] = quad
+        try:
+            prob.loss.engine.calls = 5
+            res = prob.eval(x, compute_weights=True, return_traj=False)
+            out[quad] = (res.samples.clone(), res.log_norm_const_preds["log_norm_const_lb_ito"], res.log_norm_const_preds["log_norm_const_is"])
+        finally:
+            os.environ.pop("SDEH_WS_QUAD", None)
+    a, b = out["0"], out["1"]
+    assert not torch.equal(a[0], b[0])  # (the switch really selects another kernel path)
+    diff = (a[0] - b[0]).abs()
+    assert diff.median().item() <= 1e-4 and diff.max().item() <= 1e-2, (diff.median().item(), diff.max().item())
+    assert abs(a[1] - b[1]) <= 1e-4 and abs(a[2] - b[2]) <= 1e-3, (a[1:], b[1:])

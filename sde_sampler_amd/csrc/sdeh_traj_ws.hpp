@@ -1142,14 +1142,19 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   if (pair_fits && a.batch <= 32 * 256) { groups = 1; half = 2; }
   if (force != nullptr && (force[0] == '2' || force[0] == '4')) { groups = force[0] - '0'; half = force[1] == 'h' ? 1 : 0; }
   if (force != nullptr && force[0] == 'p' && pair_fits) { groups = 1; half = 2; }
-  //   B <=  6 400 : quad mode -- FOUR M waves on 16-row tiles (v_mfma_f32_16x16x4_f32), five waves per group of 32: d <= 32, no plane
+  //   B <=  8 192 (16 384 with a closed-form target) : quad mode -- FOUR M waves on 16-row tiles (v_mfma_f32_16x16x4_f32), five waves per group of 32: d <= 32, no plane
   //                 stores, activations without a kink (ReLU: the fused backward re-evaluates the pair mode's pre-activations bitwise)
   const bool quad_fits = C == 64 && DP <= 32 && planes != 1 && (ACT >= 0 ? ACT : a.act) != SDEH_ACT_RELU &&
                          ws_quad_lds_bytes<DP>(a.lay) <= 160 * 1024;
   const char* quad_env = getenv("SDEH_WS_QUAD");  // "0": never, "1": whenever it fits (tests); read per call
-  if (half == 2 && quad_fits && !(force != nullptr && force[0] == 'p') && (quad_env != nullptr ? quad_env[0] == '1' : a.batch <= 32 * 200))
+  // Measured (tools/quad_threshold_timing.py, us per step quad / otherwise): B = 8192: 2.9 / 4.1 (d = 1), 2.8 / 4.1 (d = 10), 5.4 / 5.9 (d = 2,
+  // 40-component mixture); B = 16 384 (two workgroups per CU): 5.5 / 7.0 for the closed-form targets, 10.5 / 7.3 for the mixture (its V
+  // waves then compete for the SIMDs); B = 24 576: 8.0 / 7.0.
+  const bool light_v = (TGT >= 0 ? TGT : a.target.kind) != SDEH_DENS_GMM;
+  if (quad_fits && force == nullptr && (quad_env != nullptr ? quad_env[0] == '1' : (a.batch <= 32 * 256 || (light_v && a.batch <= 64 * 256)))) {
+    groups = 1;
     half = 3;
-  if (quad_env != nullptr && quad_env[0] == '1' && quad_fits && force == nullptr) { groups = 1; half = 3; }
+  }
   if (half == 2 && ws_pair_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_pair_lds_bytes<DP>(a.lay);
   if (half == 3 && ws_quad_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_quad_lds_bytes<DP>(a.lay);
   TrajArgs b = a;

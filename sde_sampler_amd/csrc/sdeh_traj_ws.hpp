@@ -1113,7 +1113,9 @@ template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int AC
 int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   size_t lds_bytes = ws_lds_bytes<DP>(a.lay);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
-  const bool pair_fits = C == 64 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
+  // (pair / quad mode: at least one hidden layer -- its exchange barrier is what separates the M waves' reads of x from the write of the
+  // first partial network output into the same buffer)
+  const bool pair_fits = C == 64 && a.lay.n_hidden >= 1 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
   const int planes = (a.zt_out != nullptr && a.nn_out != nullptr) ? 1 : (a.sc_out != nullptr || a.tsc_out != nullptr || a.xs_cm != nullptr ? 2 : 0);
   static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
   bool& attr_set = attr_done[current_device_slot()];
@@ -1144,7 +1146,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   if (force != nullptr && force[0] == 'p' && pair_fits) { groups = 1; half = 2; }
   //   B <=  8 192 (16 384 with a closed-form target) : quad mode -- FOUR M waves on 16-row tiles (v_mfma_f32_16x16x4_f32), five waves per group of 32: d <= 32, no plane
   //                 stores, activations without a kink (ReLU: the fused backward re-evaluates the pair mode's pre-activations bitwise)
-  const bool quad_fits = C == 64 && DP <= 32 && planes != 1 && (ACT >= 0 ? ACT : a.act) != SDEH_ACT_RELU &&
+  const bool quad_fits = C == 64 && DP <= 32 && a.lay.n_hidden >= 1 && planes != 1 && (ACT >= 0 ? ACT : a.act) != SDEH_ACT_RELU &&
                          ws_quad_lds_bytes<DP>(a.lay) <= 160 * 1024;
   const char* quad_env = getenv("SDEH_WS_QUAD");  // "0": never, "1": whenever it fits (tests); read per call
   // Measured (tools/quad_threshold_timing.py, us per step quad / otherwise): B = 8192: 2.9 / 4.1 (d = 1), 2.8 / 4.1 (d = 10), 5.4 / 5.9 (d = 2,

@@ -416,3 +416,13 @@ def test_random_integration_matches_oracle(case):
     scale = max(1.0, float(ref.abs().max()))
     assert row_err.median().item() <= 1e-4 * scale, f"{tag}: median row error {row_err.median().item():.3e}"
     assert (row_err > 2e-3 * scale).float().mean().item() <= 0.25, f"{tag}: max row error {row_err.max().item():.3e}"
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_network_without_hidden_layers_matches_oracle(case):
+    """FourierMLP(num_layers=2) (models/mlp.py:99-103: no hidden layer at all): the small-batch modes that split a group's network over two
+    or four M waves rely on a hidden layer's exchange barrier, so such a network runs the one-M-wave form at every batch size."""
+    def hook(spec, rng):
+        spec["net"]["num_layers"] = 2
+        spec["net"]["activation"] = ["gelu", "silu", "relu", "gelu"][case]
+    check_eval_case(case, spec_hook=hook)

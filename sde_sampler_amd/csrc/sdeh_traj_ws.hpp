@@ -116,10 +116,16 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 //   SHARED with NV < DP: the tables cover only the first NV coordinates (SDEH_DENS_FLAG_NVARY: the others are identical in
 //            every component); those factor out as one Gaussian -- they cancel in the responsibilities and add
 //            (mu_0d - x_d)/sigma_d^2 to the score and -(x_d - mu_0d)^2/(2 sigma_d^2) to the log-density.
-template <int DP, bool SHARED, bool SCORE, int NV>
+// KS (groups of 32 trajectories, where lanes 32..63 of the V wave idle): the component chunks alternate between the lane halves --
+// the upper half evaluates the odd chunks for trajectory lane - 32 (it gets that trajectory's table coordinates through
+// v_permlane32_swap) and the two online-softmax states (m, z, P, Q) are merged at the end, in both halves alike.  Only where the tables
+// cover at most 8 coordinates (the exchange costs a swap per coordinate); the chunk order differs from the unsplit evaluation, so this is
+// for the small-batch modes whose results are not bit-identical to the large-batch ones anyway (pair / quad mode).
+template <int DP, bool SHARED, bool SCORE, int NV, bool KS = false>
 __device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const WsLayout& L, int K,
                                             const float (&x)[DP], float (&score)[DP]) {
   static_assert(NV == DP || (SHARED && NV % 4 == 0 && NV < DP), "NV: DP, or a multiple of 4 below DP (shared scale)");
+  if constexpr (KS && (SHARED ? NV : DP) > 8) return gmm_online<DP, SHARED, SCORE, NV, false>(lds, L, K, x, score);
   constexpr int CH = 8;
   constexpr int NP = (NV + 1) / 2;                           // coordinate pairs the tables cover
   constexpr int NQ = SHARED ? (NV + 3) / 4 : (DP + 1) / 2;  // float4 per table row
@@ -130,22 +136,40 @@ __device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const
   const float4* __restrict__ plg = reinterpret_cast<const float4*>(lds + L.gmm_lg);
   const float4* __restrict__ psc = reinterpret_cast<const float4*>(lds + L.gmm_sc);
   const float* __restrict__ vec = lds + L.gmm_vec;  // SHARED: 1/(sqrt2 s_d), 1/s_d^2, mu_0d/(sqrt2 s_d), mu_0d/s_d^2
+  // lower lane half's value in every lane (KS: the coordinates of the trajectory both halves work on)
+  auto lower = [](float v) {
+    if constexpr (KS) {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      return __uint_as_float(r[0]);
+    } else {
+      return v;
+    }
+  };
+  const int hh = KS ? (int)((threadIdx.x & 63) >> 5) : 0;
   f2 y[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    const float x0 = x[2 * p], x1 = 2 * p + 1 < DP ? x[2 * p + 1] : 0.0f;
+    const float x0 = lower(x[2 * p]), x1 = 2 * p + 1 < DP ? lower(x[2 * p + 1]) : 0.0f;
     y[p] = SHARED ? f2{x0 * vec[2 * p], x1 * vec[2 * p + 1]} : f2{x0, x1};
   }
   float m = -INFINITY, z = 0.0f;
   f2 P[NP], Q[SHARED ? 1 : NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) { P[p] = splat(0.0f); if (!SHARED) Q[p] = splat(0.0f); }
-  for (int c0 = 0; c0 < KR; c0 += CH) {
+  for (int cp = 0; cp < KR; cp += (KS ? 2 : 1) * CH) {
+    // KS: this half's chunk of the pair; the upper half's last chunk may not exist (an odd number of chunks): it re-reads the last
+    // one with logits -inf (weights zero)
+    const bool have = !KS || cp + hh * CH < KR;
+    const int c0 = KS ? (have ? cp + hh * CH : KR - CH) : cp;
     float l[CH];
     {  // the chunk's constants first: a read issued inside the stream would drain the prefetch queue (lgkmcnt(0))
       const float4 c_lo = *reinterpret_cast<const float4*>(pc + c0), c_hi = *reinterpret_cast<const float4*>(pc + c0 + 4);
       l[0] = c_lo.x; l[1] = c_lo.y; l[2] = c_lo.z; l[3] = c_lo.w;
       l[4] = c_hi.x; l[5] = c_hi.y; l[6] = c_hi.z; l[7] = c_hi.w;
+      if constexpr (KS) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) l[k] = have ? l[k] : -INFINITY;
+      }
     }
     SDEH_FENCE();
     f2 acc0 = splat(0.0f), acc1 = splat(0.0f);
@@ -178,7 +202,8 @@ __device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const
     float cm = l[0];
 #pragma unroll
     for (int k = 1; k < CH; ++k) cm = fmaxf(cm, l[k]);
-    const float mn = fmaxf(m, cm);
+    // (KS: a half without a chunk sees logits -inf only; the finite floor keeps exp(m - mn) = exp(-inf) = 0 instead of exp(NaN))
+    const float mn = KS ? fmaxf(fmaxf(m, cm), -3.0e38f) : fmaxf(m, cm);
     const float resc = __expf(m - mn);  // exp(-inf) = 0 on the first chunk
     m = mn;
     float e[CH];
@@ -206,6 +231,34 @@ __device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const
           }
         }
       });
+    }
+  }
+  if constexpr (KS) {  // merge the two halves' online-softmax states (both halves end up with the same totals)
+    auto both = [](float v, float& lo, float& hi) {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      lo = __uint_as_float(r[0]);
+      hi = __uint_as_float(r[1]);
+    };
+    float m0, m1, z0, z1;
+    both(m, m0, m1);
+    both(z, z0, z1);
+    const float mm = fmaxf(m0, m1);
+    const float s0 = __expf(m0 - mm), s1 = __expf(m1 - mm);  // (m1 = -inf when the upper half had no component: s1 = 0)
+    m = mm;
+    z = fmaf(z0, s0, z1 * s1);
+    if constexpr (SCORE) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        float a0, a1, b0, b1;
+        both(P[p].x, a0, a1);
+        both(P[p].y, b0, b1);
+        P[p] = f2{fmaf(a0, s0, a1 * s1), fmaf(b0, s0, b1 * s1)};
+        if constexpr (!SHARED) {
+          both(Q[p].x, a0, a1);
+          both(Q[p].y, b0, b1);
+          Q[p] = f2{fmaf(a0, s0, a1 * s1), fmaf(b0, s0, b1 * s1)};
+        }
+      }
     }
   }
   if constexpr (SCORE) {
@@ -249,13 +302,13 @@ __device__ __forceinline__ float ws_target_logp(const DensArgs& D, const float* 
   }
 }
 
-template <int DP, int NV>
+template <int DP, int NV, bool KS = false>
 __device__ __forceinline__ void ws_target_score(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
                                                 int gmmv, int dreal, const float (&x)[DP], float (&s)[DP]) {
   switch (D.kind) {
     case SDEH_DENS_GMM:
-      if (gmmv == 2) (void)gmm_online<DP, true, true, NV>(lds, L, D.n_comp, x, s);
-      else (void)gmm_online<DP, false, true, DP>(lds, L, D.n_comp, x, s);
+      if (gmmv == 2) (void)gmm_online<DP, true, true, NV, KS>(lds, L, D.n_comp, x, s);
+      else (void)gmm_online<DP, false, true, DP, KS>(lds, L, D.n_comp, x, s);
       break;
     case SDEH_DENS_DIAG_GAUSS: dgauss_score<DP>(ws + L.dg[0], x, s); break;
     case SDEH_DENS_MULTI_WELL: mwell_score<DP>(D, dreal, x, s); break;
@@ -875,7 +928,10 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     float sterm[DP];
     if (ctrl_kind != SDEH_CTRL_CLIPPED) {
       float tsc[DP], psc[DP];
-      if (need_t) ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, tsc);
+      if (need_t) {  // pair / quad mode: mixture components split over the two lane halves (gmm_online KS)
+        if (pair) ws_target_score<DP, (GNV > 0 ? GNV : DP), true>(tgt, ws, lds, L, gmmv, d, x, tsc);
+        else ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, tsc);
+      }
       if (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR) dgauss_score<DP>(ws + L.dg[1], x, psc);
       const float w = cf[CF_W];
       if (ctrl_kind == SDEH_CTRL_SCORE) {  // reparam.py:56-83

@@ -56,12 +56,28 @@ WORKLOADS = {
 }
 
 
+#: the translation-unit sources of the headline trajectory kernel: `profiles/pmc_headline.json` is stamped with their hash, and its
+#: counters (HBM traffic, executed instructions) are only reported while the kernel they were taken on is the kernel that runs
+HEADLINE_KERNEL_SOURCES = ("sdeh_traj_ws.hpp", "sdeh_variants.inc", "sdeh_traj_inst.hip", "sdeh_traj.hpp", "sdeh_common.hpp", "Makefile")
+
+
+def headline_kernel_sha() -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in HEADLINE_KERNEL_SOURCES:
+        h.update((ROOT / "sde_sampler_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def pmc_record():
-    """Per-launch PMC counters of the headline trajectory kernel from the committed rocprofv3 passes (tools/pmc_profile.sh)."""
+    """Per-launch PMC counters of the headline trajectory kernel from the committed rocprofv3 passes (tools/pmc_profile.sh ->
+    tools/pmc_headline_json.py), or None when they were taken on other kernel sources than the ones in this tree."""
     try:
-        return json.loads((ROOT / "profiles" / "pmc_headline.json").read_text())
+        rec = json.loads((ROOT / "profiles" / "pmc_headline.json").read_text())
     except (OSError, ValueError):
         return None
+    return rec if rec.get("kernel_sha") == headline_kernel_sha() else None
 
 
 def flops_per_traj_step(d: int, c: int, lh: int, k: int) -> float:
@@ -173,14 +189,22 @@ def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | No
                       f"of {chunk_one} ({s_one:.1f} s) -> {rate_one:.3e} trajectory-steps/s"}
 
 
-def timed_kernel_ms(prob, x0, n_warm: int = 3, n: int = 5) -> float:
-    for _ in range(n_warm):
+def timed_kernel_ms(prob, x0, n_warm: int = 10, n: int = 10, budget_s: float = 4.0) -> tuple[float, float, int]:
+    """(median, min, launches) of the trajectory kernel's duration: >= 10 untimed launches first (the first ~8 after idle run while
+    the clock ramps up), then >= 10 timed ones -- fewer only for kernels that take longer than budget_s / 10."""
+    t0 = time.perf_counter()
+    for i in range(n_warm):
         prob.eval(x0, compute_weights=False, return_traj=False)
-    ms = []
-    for _ in range(n):
+        torch.cuda.synchronize()
+        if i >= 1 and time.perf_counter() - t0 > budget_s:
+            break
+    ms, t0 = [], time.perf_counter()
+    for i in range(n):
         prob.eval(x0, compute_weights=False, return_traj=False)
         ms.append(prob.loss.engine.last_kernel_ms())
-    return sum(ms) / len(ms)
+        if i >= 2 and time.perf_counter() - t0 > budget_s:
+            break
+    return statistics.median(ms), min(ms), len(ms)
 
 
 def extra_block(device, B: int) -> dict:
@@ -199,13 +223,26 @@ def extra_block(device, B: int) -> dict:
             prob = problems.build(spec, device=device)
             prob.loss.engine.timing = True
             x0 = prob.prior.sample((B,))
-            ms = timed_kernel_ms(prob, x0)
+            ms, ms_min, n = timed_kernel_ms(prob, x0)
         finally:
             os.environ.pop("SDEH_GENERIC_ONLY", None)
         T = prob.ts.numel() - 1
         tf = algorithmic_flops(spec) * B * T / (ms * 1e-3) / 1e12
-        out["headline_generic_kernel" if generic else name] = {"kernel_ms": ms, "algorithmic_tflops": tf,
-                                                               "frac": tf / PEAK_FP32_TFLOPS}
+        out["headline_generic_kernel" if generic else name] = {"kernel_ms": ms, "kernel_ms_min": ms_min, "launches": n,
+                                                               "algorithmic_tflops": tf, "frac": tf / PEAK_FP32_TFLOPS,
+                                                               "kernel": prob.loss.engine.last_kernel_name()}
+    # the wide-network kernels (BASELINE configs[4]'s shape: C = 256, d = 196) at their workloads' own batch and T
+    for name in ("wide_pis_funnel196", "cfg5_like_bridge196"):
+        spec = problems.baseline_spec(name)
+        prob = problems.build(spec, device=device)
+        prob.loss.engine.timing = True
+        x0 = prob.prior.sample((spec["batch"],))
+        ms, ms_min, n = timed_kernel_ms(prob, x0, n_warm=2, n=3, budget_s=1.5)
+        T = prob.ts.numel() - 1
+        tf = algorithmic_flops(spec) * spec["batch"] * T / (ms * 1e-3) / 1e12
+        out[name] = {"batch": spec["batch"], "steps": T, "kernel_ms": ms, "kernel_ms_min": ms_min, "launches": n,
+                     "algorithmic_tflops": tf, "frac": tf / PEAK_FP32_TFLOPS, "kernel": prob.loss.engine.last_kernel_name()}
+        del prob, x0
     # One training step of BASELINE configs[1] (DIS, method kl, GMM d = 2, T = 100) and of configs[2]'s shape (PIS kl, GMM-40 d = 50,
     # T = 200) at this batch: kernel times of the training forward and of the fused backward (back-propagation through time + weight
     # gradients, csrc/sdeh_bwdf.hip), and the backward's rate -- 2 x (4dC + 2 Lh C^2) FLOPs per trajectory-step (adjoint chain +
@@ -348,8 +385,15 @@ def run(args, rank: int, world: int, local_rank: int):
                          f"(--same-device --backend gloo exercises the N > 1 path on one GPU)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # a process group exists whenever a launcher provided the rendezvous (WORLD_SIZE in the environment, also WORLD_SIZE=1) or
+    # --dist asks for it: the one-rank job then runs the very code an 8-rank job runs (RCCL init with device_id, the 8-float
+    # all-gather on the device tensor, barriers) -- tests/test_hip_rccl.py
+    use_dist = world > 1 or args.dist or os.environ.get("WORLD_SIZE") is not None
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
@@ -382,7 +426,7 @@ def run(args, rank: int, world: int, local_rank: int):
         return prob.eval(x0, compute_weights=False, return_traj=False)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -396,7 +440,7 @@ def run(args, rank: int, world: int, local_rank: int):
         kernel_ms.append(prob.loss.engine.last_kernel_ms())
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -404,7 +448,7 @@ def run(args, rank: int, world: int, local_rank: int):
     # quality: log Z from one weighted evaluation (in-kernel noise), global over all ranks
     full = prob.eval(x0, compute_weights=True, return_traj=False)
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -462,8 +506,10 @@ def run(args, rank: int, world: int, local_rank: int):
             out["log_z"].update(checked)
         if out["cpu_baseline"]["value"]:
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if use_dist:
+        out["config"]["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -487,6 +533,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the log_z / extra blocks of the headline line")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--dist", action="store_true",
+                    help="initialise the process group (RCCL) also for --gpus 1: a one-rank job that runs the multi-rank code path")
     ap.add_argument("--same-device", action="store_true",
                     help="testing aid: all ranks use cuda:0 (with --backend gloo) to exercise the N > 1 path on one GPU")
     args = ap.parse_args()

@@ -629,6 +629,13 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     // the one buffer a plan grows after creation: 32 group sums per trajectory of the network part of the divergence
     const size_t need = (size_t)bridge_wide_scratch_floats(batch);
     if (need > plan->scratch_floats) {
+      // (the one allocation a plan makes after creation: it synchronises the device, so it must not happen while the stream is
+      // being captured into a hipGraph -- run one launch at the largest batch before capturing)
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+        return fail(SDEH_ERR_CAPACITY, "simulate_fwd (wide bridge): the plan's divergence scratch (%zu floats) is smaller than this batch "
+                                       "needs (%zu) and cannot grow while the stream is capturing: launch once at this batch first",
+                    plan->scratch_floats, need);
       int prev = 0;
       (void)hipGetDevice(&prev);
       hipError_t e = hipSetDevice(plan->device);
@@ -879,6 +886,13 @@ int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProbl
   if (getenv("SDEH_BWD_PLANES") != nullptr) return 0;  // A/B aid: the plane-writing kernels (read per call)
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
   if (bptt && (pr->flags & SDEH_FLAG_INIT_LOGP)) return 0;
+  // The training forward of the fused path is the wave-specialised kernel.  A launch the single-wave kernel would serve (mixture
+  // tables beyond LDS, SDEH_LEGACY) keeps none of its planes: say so BEFORE the caller launches, instead of integrating twice.
+  if (getenv("SDEH_LEGACY") != nullptr) return 0;
+  if (pr->target.kind == SDEH_DENS_GMM && plan->variant != nullptr) {
+    const bool shared = pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE;
+    if (make_layout(plan->variant->dp, net.channels, net.n_hidden, 1, pr->target.n_components, 1, shared).gmm_lds == 0) return 0;
+  }
   return 1;
 }
 

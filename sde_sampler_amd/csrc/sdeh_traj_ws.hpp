@@ -48,7 +48,9 @@ __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0
 // order, so the data is visible before the counter), the consumer polls with s_sleep between the reads (it shares its SIMD with
 // the producer at G = 4: a sleeping wave issues nothing).
 __device__ __forceinline__ void ws_flag_set(int* flag, int value) {
-  asm volatile("" ::: "memory");
+  // the data stores of this wave have COMPLETED before the flag store is issued (lgkmcnt counts LDS operations): the ordering the
+  // consumer relies on is architectural, not a property of the LDS queue being in-order
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   *reinterpret_cast<volatile int*>(flag) = value;
   asm volatile("" ::: "memory");
 }

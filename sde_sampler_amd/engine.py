@@ -514,7 +514,7 @@ class TrajectoryEngine:
             noise_p = keep.ptr(noise, device, "noise")
         x_T = torch.empty((batch, dim), device=device, dtype=torch.float32)
         rnd = torch.empty((batch, 1), device=device, dtype=torch.float32)
-        xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32) if return_traj else None
+        xs = None  # row-major trajectory [T+1, B, d]: allocated by the branch that writes it (the fused training path keeps [T+1, d, B])
         k = pr.target.n_components if pr.target.kind == L.DENS_GMM else 0
         n_hidden = pr.base_model.n_hidden
         if pr.flags & L.FLAG_INFERENCE_CTRL:
@@ -532,7 +532,7 @@ class TrajectoryEngine:
                 raise ValueError(f"div_noise must be [{n_steps}, {batch}, {dim}], got {tuple(div_noise.shape)}")
             dn_p = keep.ptr(div_noise, device, "div_noise")
         if want_planes:  # training forward: keep what the backward kernels need
-            if xs is None or want_gp or div_noise is not None:
+            if not return_traj or want_gp or div_noise is not None:
                 raise ValueError("want_planes goes with return_traj=True and without the Bridge outputs")
             if lib.sdeh_ctrl_backward_fused_supported(plan.handle, C.byref(pr)):
                 # fused backward (csrc/sdeh_bwdf.hip): the combined score per step and the terminal target score, no [C, T*B] planes
@@ -553,6 +553,7 @@ class TrajectoryEngine:
                 if status == 0:
                     return x_T, rnd, xs_cm, ("fused", sc, tscore)
                 del xs_cm, sc, tscore  # integrated by a kernel that keeps no planes (mixture tables beyond LDS): once more, the plane way
+            xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
             zt = torch.empty((pr.base_model.n_hidden + 1, pr.base_model.channels, n_steps * batch), device=device, dtype=torch.float32)
             nn = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32)
             with torch.cuda.device(device):
@@ -562,6 +563,8 @@ class TrajectoryEngine:
             if status < 0:
                 L.check(status)
             return x_T, rnd, xs, ((zt, nn) if status == 0 else None)  # 1: served by a kernel that keeps no planes
+        if return_traj:
+            xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
         with torch.cuda.device(device):
             L.check(lib.sdeh_simulate_fwd_aux(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
                                               seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
@@ -625,10 +628,12 @@ def merge_stats(stats: torch.Tensor) -> torch.Tensor:
 
 def all_gather_stats(stats: torch.Tensor, group=None) -> torch.Tensor:
     """The single collective of an evaluation: all-gather 8 floats per rank (RCCL on GPU tensors, gloo on CPU
-    tensors), then merge on the host.  Without an initialised process group this is just the local merge."""
+    tensors), then merge on the host.  Without an initialised process group this is just the local merge.  With one, the
+    collective runs at EVERY world size (also 1): a single-rank job executes exactly the code an 8-rank job does
+    (tests/test_hip_rccl.py runs it over RCCL on one GPU and compares bitwise with the group-less path)."""
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return merge_stats(stats)
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo":  # CPU collectives (tests): move the 8 floats to the host first

@@ -63,6 +63,14 @@ def _world_size(group=None) -> int:
     return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
+def _dist_on() -> bool:
+    """True once torch.distributed is initialised -- at ANY world size: a one-rank process group takes the data-parallel code path
+    (collectives included), so that what runs on one GPU under RCCL is what runs on eight (tests/test_hip_rccl.py)."""
+    import torch.distributed as dist
+
+    return dist.is_available() and dist.is_initialized()
+
+
 def _all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     """SUM all-reduce of a few scalars (RCCL on the device for the nccl backend, through the host for gloo); returned on the CPU."""
     import torch.distributed as dist
@@ -96,7 +104,7 @@ class _MaskedMoment(torch.autograd.Function):
 
 class BaseOCLoss:
     #: set to a torch.distributed process group (or leave None for the default group); evaluation statistics are
-    #: merged across ranks whenever torch.distributed is initialised with world_size > 1
+    #: merged across ranks whenever torch.distributed is initialised (at any world size)
     process_group = None
 
     def __init__(self, generative_ctrl: Callable, sde=None, method: str = "kl", traj_per_sample: int = 1,
@@ -156,7 +164,7 @@ class BaseOCLoss:
             rnd = rnd.reshape(self.traj_per_sample, -1, 1)
             mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)
             filtered = self.traj_per_sample * (mask.numel() - mask.sum())
-            if world == 1:
+            if not _dist_on():
                 self.n_filtered += filtered.item()
                 return rnd[:, mask].var(dim=0).mean(), {"train/n_filtered_cumulative": self.n_filtered}
             per_sample = rnd[:, mask].var(dim=0)
@@ -165,7 +173,7 @@ class BaseOCLoss:
             loss = per_sample.sum() / tot[0].item()
         else:
             filtered = mask.numel() - mask.sum()
-            if world == 1:
+            if not _dist_on():
                 self.n_filtered += filtered.item()
                 loss = rnd[mask].var() if self.method == "lv" else rnd[mask].mean()
                 return loss, {"train/n_filtered_cumulative": self.n_filtered}
@@ -241,14 +249,22 @@ class BaseOCLoss:
         self.n_filtered = state_dict["n_filtered"]
         if self._n_filtered_dev is not None:
             self._n_filtered_dev.zero_()
-        # extension of the reference's {"n_filtered"} (losses/oc.py:133-137): a resumed run continues the noise stream
+        # extension of the reference's {"n_filtered"} (losses/oc.py:133-137): a resumed run continues the noise stream.  Under a
+        # replayed hipGraph the position is `calls` + the device counter (utils/graphs.py): both are saved and restored
         self.engine.calls = int(state_dict.get("rng_calls", self.engine.calls))
+        if self.rng_counter is not None:
+            self.rng_counter.fill_(int(state_dict.get("rng_counter", 0)))
+        else:  # no device counter in this object: fold the saved one into the call count (same Philox offset = calls + counter)
+            self.engine.calls += int(state_dict.get("rng_counter", 0))
 
     def state_dict(self) -> dict:
         on_device = 0 if self._n_filtered_dev is None else int(self._n_filtered_dev.item())
-        return {"n_filtered": self.n_filtered + on_device, "rng_calls": self.engine.calls}
+        counter = 0 if self.rng_counter is None else int(self.rng_counter.item())
+        return {"n_filtered": self.n_filtered + on_device, "rng_calls": self.engine.calls, "rng_counter": counter}
 
     def _row_offset(self, local_batch: int) -> int:
+        """Global index of this rank's first trajectory.  The default, rank * local batch, assumes EQUAL local batches on all
+        ranks (what the solvers' `eval_batch_size // world` split gives); set `row_offset` explicitly for ragged shards."""
         if self.row_offset is not None:
             return int(self.row_offset)
         import torch.distributed as dist

@@ -1,0 +1,152 @@
+"""Size-independent properties at BASELINE.json's FULL per-GPU sizes: every configuration the parity
+fixtures pin at oracle size is also run at the size it is quoted on --
+
+    configs[1]  GMM-40 d=2, DIS kl         B = 65 536, T = 100
+    configs[2]  GMM-40 d=50, PIS           B = 32 768 per GPU (262 144 / 8), T = 200      (groups of 32 trajectories)
+    configs[3]  funnel d=10, DDS lv        B = 32 768 per GPU (131 072 / 4), T = 401
+    wide        funnel d=196, C=256, PIS   B = 32 768, T = 200                            (traj_wide, CT = 2)
+    configs[4]  Bridge d=196, C=256        B = 4 096 per GPU (32 768 / 8), T = 200        (bridge_wide)
+
+-- through what does not depend on the size: determinism per (seed, call), bitwise invariance to how the batch is split over
+launches (two shards with row offsets) and over workgroup tilings, estimators == the statistics of the rows, and the fast mode's
+(in-kernel Philox) lower bound within 4 standard errors of the ORACLE run with torch noise on a few hundred rows."""
+import math
+import os
+from contextlib import contextmanager
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+#        spec name               B      oracle rows  kernel-name fragment
+CASES = [("cfg2_gmm2_dis_kl", 65536, 512, "traj_ws<2_0_dis_gmm>"),
+         ("cfg3_gmm50_pis_kl", 32768, 512, "traj_ws<50_0_pis_gmm4>"),
+         ("cfg4_funnel_dds_lv", 32768, 512, "traj_ws<10_0_dds_funnel>"),
+         ("wide_pis_funnel196", 32768, 512, "traj_wide<C=256,CT=2>"),
+         ("cfg5_like_bridge196", 4096, 48, "bridge_wide<C=256,split=2>")]
+
+
+@contextmanager
+def _env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+def _build(name, batch):
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec(name)
+    spec["batch"] = batch
+    torch.manual_seed(1)
+    prob = problems.build(spec)
+    inf = getattr(prob.loss, "inference_ctrl", None)
+    cpu = dict(params={k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()},
+               tt=dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+               if spec["target"]["kind"] == "gmm" else None,
+               params_inf={k: v.detach().clone() for k, v in inf.state_dict().items()} if inf is not None else None)
+    prob.to(DEV)
+    return spec, prob, cpu
+
+
+@pytest.mark.parametrize("name,batch,rows,kernel", CASES, ids=[c[0] for c in CASES])
+def test_fullsize_determinism_sharding_and_estimators(name, batch, rows, kernel):
+    spec, prob, _ = _build(name, batch)
+    eng = prob.loss.engine
+    torch.manual_seed(5)
+    x0 = prob.prior.sample((batch,))
+    eng.calls = 11
+    a = prob.eval(x0, compute_weights=True, return_traj=False)
+    assert eng.last_kernel_name() == kernel, eng.last_kernel_name()
+    assert torch.isfinite(a.samples).all() and torch.isfinite(a.weights).all()
+    eng.calls = 11
+    b = prob.eval(x0, compute_weights=True, return_traj=False)
+    assert torch.equal(a.samples, b.samples) and torch.equal(a.weights, b.weights)  # same (seed, call): bitwise
+    eng.calls = 12
+    c = prob.eval(x0, compute_weights=False, return_traj=False)
+    assert not torch.equal(a.samples, c.samples)  # the next call draws new noise
+    # two shards with row offsets == one launch (global-row Philox counters; groups of 64 and of 32 round identically)
+    cut = batch // 2 + 32 * 7
+    halves = []
+    for lo, hi in ((0, cut), (cut, batch)):
+        eng.calls, prob.loss.row_offset = 11, lo
+        halves.append(prob.eval(x0[lo:hi], compute_weights=False, return_traj=False))
+    prob.loss.row_offset = 0
+    assert torch.equal(torch.cat([h.samples for h in halves]), a.samples)
+    # estimators == statistics of the rows
+    with torch.no_grad():
+        eng.calls = 11
+        kw = dict(compute_ito_int=True)
+        if spec["loss"]["kind"] == "time_reversal":
+            kw["train"] = False
+        xT, rnd, _ = prob.loss.simulate(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, **kw)
+    assert torch.equal(xT, a.samples)
+    neg = -rnd.double().flatten()
+    lb = neg.mean().item()
+    assert abs(a.log_norm_const_preds["log_norm_const_lb_ito"] - lb) <= 1e-4 * max(1.0, abs(lb))
+    m = neg.max()
+    lz = ((neg - m).exp().mean().log() + m).item()
+    assert abs(a.log_norm_const_preds["log_norm_const_is"] - lz) <= 1e-4 * max(1.0, abs(lz))
+    assert abs(a.metrics["eval/lv_loss"] / rnd.double().var().item() - 1.0) < 1e-3
+    assert a.weights.max().item() == 1.0
+
+
+def test_fullsize_wide_tilings_are_bitwise_identical():
+    """wide_pis_funnel196 at B = 32 768, T = 200: 32- and 64-trajectory workgroups (CT = 1 / 2) run the same arithmetic per trajectory."""
+    spec, prob, _ = _build("wide_pis_funnel196", 32768)
+    x0 = prob.prior.sample((32768,))
+    out = {}
+    for ct in (1, 2):
+        with _env(SDEH_WIDE_CT=ct):
+            prob.loss.engine.calls = 4
+            out[ct] = prob.eval(x0, compute_weights=True, return_traj=False)
+            assert prob.loss.engine.last_kernel_name() == f"traj_wide<C=256,CT={ct}>"
+    assert torch.equal(out[1].samples, out[2].samples) and torch.equal(out[1].weights, out[2].weights)
+
+
+def test_fullsize_bridge_split_is_bitwise_identical():
+    """cfg5_like_bridge196 at configs[4]'s per-GPU batch (B = 4096, T = 200): 1, 2 or 8 workgroups per column tile add the same 32
+    coordinate-group sums in the same order."""
+    spec, prob, _ = _build("cfg5_like_bridge196", 4096)
+    torch.manual_seed(2)
+    x0 = prob.prior.sample((4096,))
+    out = {}
+    for split in (1, 2, 8):
+        with _env(SDEH_WIDE_SPLIT=split):
+            prob.loss.engine.calls = 4
+            out[split] = prob.eval(x0, compute_weights=True, return_traj=False)
+            assert prob.loss.engine.last_kernel_name() == f"bridge_wide<C=256,split={split}>"
+    for split in (2, 8):
+        assert torch.equal(out[1].samples, out[split].samples), split
+        assert torch.equal(out[1].weights, out[split].weights), split
+    assert torch.isfinite(out[1].weights).all()
+
+
+@pytest.mark.parametrize("name,batch,rows,kernel", CASES, ids=[c[0] for c in CASES])
+def test_fullsize_fast_mode_within_4se_of_the_oracle(name, batch, rows, kernel):
+    """In-kernel Philox noise at the full batch against the oracle (torch.randn noise) on `rows` trajectories of the same problem:
+    the lower bounds agree within 4 combined standard errors (the oracle's few hundred rows dominate the error bar)."""
+    from oracle import em_oracle as eo
+
+    spec, prob, cpu = _build(name, batch)
+    torch.manual_seed(21)
+    x0 = prob.prior.sample((batch,))
+    with torch.no_grad():
+        kw = dict(compute_ito_int=True)
+        if spec["loss"]["kind"] == "time_reversal":
+            kw["train"] = False
+        _, rnd, _ = prob.loss.simulate(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, **kw)
+    torch.set_num_threads(min(16, os.cpu_count() or 4))
+    oracle = eo.Problem(spec, cpu["params"], cpu["tt"], params_inf=cpu["params_inf"])
+    torch.manual_seed(22)
+    ref = oracle.eval(prob.ts.cpu().clone(), x0[:rows].cpu().clone(), None, compute_weights=True)
+    a, b = -rnd.double().cpu().flatten(), -ref["rnd"].double().flatten()
+    se = math.sqrt(a.var().item() / batch + b.var().item() / rows)
+    assert abs(a.mean().item() - b.mean().item()) <= 4 * se + 1e-3, (a.mean().item(), b.mean().item(), se)
+    assert 0.7 < (a.std() / b.std()).item() < 1.4, (a.std().item(), b.std().item())

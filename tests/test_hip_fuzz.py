@@ -331,7 +331,7 @@ def test_random_bridge_matches_oracle(case):
     out = prob.eval(x0.to(DEV), compute_weights=True, noise=noise.to(DEV))
     row_err = ((out.samples.cpu() - ref["samples"]).abs().amax(dim=1) - cond_rows).clamp_min(0.0)
     scale = max(1.0, float(ref["samples"].abs().max()))
-    assert row_err.median().item() <= 1e-4 * scale and (row_err > 2e-3 * scale).float().mean().item() <= 0.25, f"{tag}: x_T"
+    assert row_err.median().item() <= 1e-4 * scale and (row_err > 2e-3 * scale).float().mean().item() <= DRIFT_MAX, f"{tag}: x_T"
     got, want = out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"]
     assert _close(got, want, 2e-3 * max(1.0, abs(want)) + cond_lb), f"{tag}: lb_ito {got} vs {want}"
     val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
@@ -415,7 +415,7 @@ def test_random_integration_matches_oracle(case):
     row_err = ((xs.cpu() - ref).abs().amax(dim=(0, 2)) - cond_rows).clamp_min(0.0)
     scale = max(1.0, float(ref.abs().max()))
     assert row_err.median().item() <= 1e-4 * scale, f"{tag}: median row error {row_err.median().item():.3e}"
-    assert (row_err > 2e-3 * scale).float().mean().item() <= 0.25, f"{tag}: max row error {row_err.max().item():.3e}"
+    assert (row_err > 2e-3 * scale).float().mean().item() <= DRIFT_MAX, f"{tag}: max row error {row_err.max().item():.3e}"
 
 
 @pytest.mark.parametrize("case", [0, 1, 2, 3])

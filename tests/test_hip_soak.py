@@ -1,0 +1,129 @@
+"""Soak under load: every kernel family with hand-issued instructions (asm waits / loads / packed GELU / LDS
+hand-off counters) launched 20 times at a FIXED Philox offset while a second stream keeps the GPU busy with large GEMMs -- every
+launch must be bitwise the first one.  A missed hazard or an unconsumed prefetch shows up as a few stale rows in an occasional
+launch, and only when the timing around the kernel moves (tests/perf/soak_determinism.py is the long-running form)."""
+import os
+from contextlib import contextmanager
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_LAUNCHES = 20
+
+
+@contextmanager
+def _env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+class _Load:
+    """Saturating side stream: back-to-back 4096^3 fp32 GEMMs (all CUs, MFMA + HBM) enqueued ahead of the launches under test."""
+
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.a = torch.randn(4096, 4096, device=device)
+        self.b = torch.randn(4096, 4096, device=device)
+        self.c = torch.empty_like(self.a)
+
+    def push(self, n=3):
+        with torch.cuda.stream(self.stream):
+            for _ in range(n):
+                torch.mm(self.a, self.b, out=self.c)
+
+
+#            name                     batch   T     env                              expected kernel-name fragment
+EVAL_CASES = [
+    ("gmm50_pis_headline", 65536, 40, {}, "traj_ws<50_0_pis_gmm4>"),          # groups of 64
+    ("gmm50_pis_headline", 24576, 40, {}, "traj_ws<"),                         # groups of 32 (half)
+    ("gmm50_pis_headline", 6000, 40, {}, "traj_ws<"),                          # pair mode (d > 32)
+    ("cfg1_dw_dis_lv", 1024, 60, {}, "traj_ws<"),                              # quad mode
+    ("cfg2_gmm2_dis_kl", 6000, 60, {}, "traj_ws<"),                            # quad mode, mixture on both lane halves
+    ("cfg4_funnel_dds_lv", 32768, 60, {}, "traj_ws<"),
+    ("gmm50_pis_headline", 16384, 30, {"SDEH_GENERIC_ONLY": 1}, "traj_ws<50_0_g>"),
+    ("wide_pis_funnel196", 4096, 12, {"SDEH_WIDE_CT": 1}, "traj_wide<C=256,CT=1>"),
+    ("wide_pis_funnel196", 8320, 12, {"SDEH_WIDE_CT": 2}, "traj_wide<C=256,CT=2>"),
+    ("cfg5_like_bridge196", 512, 6, {"SDEH_WIDE_SPLIT": 1}, "bridge_wide<C=256,split=1>"),
+    ("cfg5_like_bridge196", 512, 6, {"SDEH_WIDE_SPLIT": 2}, "bridge_wide<C=256,split=2>"),
+    ("cfg5_like_bridge196", 256, 6, {"SDEH_WIDE_SPLIT": 8}, "bridge_wide<C=256,split=8>"),
+]
+
+
+@pytest.mark.parametrize("name,batch,steps,env,kernel", EVAL_CASES, ids=[f"{c[0]}-B{c[1]}-{'-'.join(f'{k}{v}' for k, v in c[3].items()) or 'default'}" for c in EVAL_CASES])
+def test_evaluation_kernels_are_bitwise_repeatable_under_load(name, batch, steps, env, kernel):
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec(name)
+    spec["batch"] = batch
+    spec["grid"]["steps"] = steps
+    prob = problems.build(spec, device="cuda:0")
+    torch.manual_seed(1)
+    x0 = prob.prior.sample((batch,))
+    eng = prob.loss.engine
+    load = _Load(x0.device)
+    ref = None
+    with _env(**env):
+        for i in range(N_LAUNCHES):
+            if i % 2 == 1:  # every other launch competes with the side stream (the others run alone: both timings are exercised)
+                load.push()
+            eng.calls = 7
+            r = prob.eval(x0, compute_weights=True, return_traj=False)
+            cur = (r.samples.clone(), r.weights.clone())
+            if ref is None:
+                ref = cur
+                assert kernel in eng.last_kernel_name(), eng.last_kernel_name()
+                assert torch.isfinite(cur[0]).all() and torch.isfinite(cur[1]).all()
+            else:
+                assert torch.equal(ref[0], cur[0]), f"launch {i}: {(ref[0] != cur[0]).any(dim=1).sum().item()} rows of x_T differ"
+                assert torch.equal(ref[1], cur[1]), f"launch {i}: {(ref[1] != cur[1]).sum().item()} weights differ"
+    torch.cuda.synchronize()
+
+
+TRAIN_CASES = [
+    ("cfg3_gmm50_pis_kl", 16384, 30, "kl", {}, "bwd_fused<"),      # tiles of 32, through time
+    ("cfg1_dw_dis_lv", 16384, 40, "lv", {}, "bwd_fused<"),         # tiles of 32, row-parallel
+    ("cfg2_gmm2_dis_kl", 2048, 40, "kl", {}, "bwd_fused16<"),      # tiles of 16, four waves
+    ("cfg3_gmm50_pis_kl", 2048, 30, "kl", {"SDEH_BWD_WAVES": 2}, "bwd_fused16<"),  # tiles of 16, two waves
+]
+
+
+@pytest.mark.parametrize("name,batch,steps,method,env,kernel", TRAIN_CASES, ids=[f"{c[0]}-B{c[1]}-{c[3]}-{'-'.join(f'{k}{v}' for k, v in c[4].items()) or 'default'}" for c in TRAIN_CASES])
+def test_fused_backward_is_bitwise_repeatable_under_load(name, batch, steps, method, env, kernel):
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec(name)
+    spec["batch"] = batch
+    spec["grid"]["steps"] = steps
+    spec["loss"]["method"] = method
+    prob = problems.build(spec, device="cuda:0")
+    torch.manual_seed(1)
+    x0 = prob.prior.sample((batch,))
+    eng = prob.loss.engine
+    load = _Load(x0.device)
+    ref = None
+    with _env(**env):
+        for i in range(N_LAUNCHES):
+            if i % 2 == 1:
+                load.push()
+            eng.calls = 3
+            prob.ctrl.zero_grad()
+            val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+            val.backward()
+            cur = torch.cat([p.grad.flatten() for p in prob.ctrl.parameters() if p.grad is not None] + [val.detach().reshape(1)])
+            if ref is None:
+                ref = cur.clone()
+                assert kernel in eng.last_kernel_name(), eng.last_kernel_name()
+                assert torch.isfinite(cur).all()
+            else:
+                assert torch.equal(ref, cur), f"step {i}: {(ref != cur).sum().item()} gradient entries differ"
+    torch.cuda.synchronize()

@@ -22,6 +22,16 @@ def _rows(name, got, ref, max_tol=1e-2, med_tol=1e-4):
     assert np.median(err) <= med_tol, f"{name}: median err {np.median(err):.3e}"
 
 
+#: share of rows allowed beyond the per-row bar after the conditioning probes (the narrow sweep's measured bound, tests/test_hip_fuzz.py)
+DRIFT_MAX = float(os.environ.get("SDEH_FUZZ_DRIFT_MAX", "0.05"))
+
+
+def _est_tol(want: float) -> float:
+    """|delta| <= 1e-4 absolute; an fp32 estimator of magnitude > 25 cannot be held to that (one ulp of 250 is 1.5e-5 and
+    the sum runs over T steps): 4e-6 relative there (the bar of tests/test_hip_contract.py)."""
+    return max(1e-4, 4e-6 * abs(want))
+
+
 class _ct:
     """forces the column tiles per workgroup (32 or 64 trajectories) of the wide kernels"""
 
@@ -57,12 +67,15 @@ def test_wide_eval_matches_reference_golden(path, ct):
     _rows("x_T", r1.samples.cpu().numpy(), fx["eval1/x_T"])
     _rows("rnd (ito)", rnd1.cpu().numpy(), fx["eval1/rnd"])
     _rows("rnd", rnd2.cpu().numpy(), fx["eval2/rnd"])
-    scale = max(1.0, float(np.abs(fx["eval1/rnd"]).max()))
+    # SURVEY 8d's bars, as in tests/test_hip_contract.py: estimators 1e-4 absolute (4e-6 relative beyond a magnitude of 25);
+    # eval/lv_loss, a variance that weights the rows the contract lets deviate, 1e-4 relative
     for key in ("log_norm_const_lb_ito", "log_norm_const_is"):
-        assert abs(r1.log_norm_const_preds[key] - float(fx["eval1/" + key])) <= 1e-4 * scale, key
-    assert abs(r2.log_norm_const_preds["log_norm_const_lb"] - float(fx["eval2/log_norm_const_lb"])) <= 1e-4 * scale
+        want = float(fx["eval1/" + key])
+        assert abs(r1.log_norm_const_preds[key] - want) <= _est_tol(want), (key, r1.log_norm_const_preds[key], want)
+    want = float(fx["eval2/log_norm_const_lb"])
+    assert abs(r2.log_norm_const_preds["log_norm_const_lb"] - want) <= _est_tol(want)
     lv = float(fx["eval1/lv_loss"])
-    assert abs(r1.metrics["eval/lv_loss"] - lv) <= 2e-3 * max(1.0, abs(lv))
+    assert abs(r1.metrics["eval/lv_loss"] - lv) <= 1e-4 * max(1.0, abs(lv)), (r1.metrics["eval/lv_loss"], lv)
     assert torch.equal(r1.samples, r2.samples)  # the Ito integral only enters rnd
     xs = r1.xs.cpu().numpy()
     assert xs.shape == (prob.ts.numel(), *fx["x0"].shape)
@@ -175,10 +188,10 @@ def test_wide_bridge_eval_matches_reference_golden(path, split):
     _rows("x_T", r1.samples.cpu().numpy(), fx["eval1/x_T"], max_tol=2e-3)
     # the divergence sums d Jacobian entries of magnitude O(1) per step, accumulated over T steps into rnd
     _rows("rnd", rnd.cpu().numpy(), fx["eval2/rnd"], max_tol=1e-3, med_tol=1e-4)
-    scale = max(1.0, float(np.abs(fx["eval1/rnd"]).max()))
-    assert abs(r1.log_norm_const_preds["log_norm_const_is"] - float(fx["eval1/log_norm_const_is"])) <= 1e-4 * scale
-    assert abs(r1.log_norm_const_preds["log_norm_const_lb_ito"] - float(fx["eval1/log_norm_const_lb_ito"])) <= 1e-4 * scale
-    assert abs(r2.log_norm_const_preds["log_norm_const_lb"] - float(fx["eval2/log_norm_const_lb"])) <= 1e-4 * scale
+    for res, key, ref_key in ((r1, "log_norm_const_is", "eval1/log_norm_const_is"), (r1, "log_norm_const_lb_ito", "eval1/log_norm_const_lb_ito"),
+                              (r2, "log_norm_const_lb", "eval2/log_norm_const_lb")):
+        want = float(fx[ref_key])
+        assert abs(res.log_norm_const_preds[key] - want) <= _est_tol(want), (key, res.log_norm_const_preds[key], want)
     assert xs.shape == (prob.ts.numel(), *x0.shape) and torch.equal(xs[-1], r1.samples)
 
 
@@ -308,6 +321,6 @@ def test_random_wide_bridge_matches_oracle(case):
     cond_lb = abs(ref_p["log_norm_const_lb_ito"] - ref["log_norm_const_lb_ito"]) if math.isfinite(ref_p["log_norm_const_lb_ito"]) else math.inf
     row_err = ((out.samples.cpu() - ref["samples"]).abs().amax(dim=1) - cond_rows).clamp_min(0.0)
     scale = max(1.0, float(ref["samples"].abs().max()))
-    assert row_err.median().item() <= 1e-4 * scale and (row_err > 2e-3 * scale).float().mean().item() <= 0.25, f"{tag}: x_T {row_err.max().item():.2e}"
+    assert row_err.median().item() <= 1e-4 * scale and (row_err > 2e-3 * scale).float().mean().item() <= DRIFT_MAX, f"{tag}: x_T {row_err.max().item():.2e}"
     got, want = out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"]
     assert _close(got, want, 2e-3 * max(1.0, abs(want)) + 2.0 * cond_lb), f"{tag}: lb_ito {got} vs {want}"

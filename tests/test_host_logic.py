@@ -166,7 +166,8 @@ def test_loss_contract():
     with pytest.raises(ValueError, match="single trajectory"):
         ReferenceSDELoss(generative_ctrl=None, method="lv_traj", traj_per_sample=1)
     loss = ExponentialIntegratorSDELoss(generative_ctrl=None, alpha=1.0, sigma=2.0, method="lv", max_rnd=1e8, unknown_kw=1)
-    assert loss.state_dict() == {"n_filtered": 0, "rng_calls": 0}  # reference keys + the position in the noise stream
+    # reference keys + the position in the noise stream (call count + the device counter of replayed hipGraphs)
+    assert loss.state_dict() == {"n_filtered": 0, "rng_calls": 0, "rng_counter": 0}
     loss.load_state_dict({"n_filtered": 7})  # a reference checkpoint (losses/oc.py:133-137) loads as is
     assert loss.n_filtered == 7 and (loss.alpha, loss.sigma) == (1.0, 2.0) and loss.engine.calls == 0
     loss.load_state_dict({"n_filtered": 7, "rng_calls": 12})

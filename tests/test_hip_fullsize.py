@@ -72,11 +72,14 @@ def test_fullsize_determinism_sharding_and_estimators(name, batch, rows, kernel)
     c = prob.eval(x0, compute_weights=False, return_traj=False)
     assert not torch.equal(a.samples, c.samples)  # the next call draws new noise
     # two shards with row offsets == one launch (global-row Philox counters; groups of 64 and of 32 round identically)
+    # (shards of <= 16 384 trajectories with d <= 32 would otherwise select the quad mode, whose 16-row MFMA shape rounds differently
+    # -- the bitwise statement holds between launches that run the same kernel mode)
     cut = batch // 2 + 32 * 7
     halves = []
-    for lo, hi in ((0, cut), (cut, batch)):
-        eng.calls, prob.loss.row_offset = 11, lo
-        halves.append(prob.eval(x0[lo:hi], compute_weights=False, return_traj=False))
+    with _env(SDEH_WS_QUAD=0):
+        for lo, hi in ((0, cut), (cut, batch)):
+            eng.calls, prob.loss.row_offset = 11, lo
+            halves.append(prob.eval(x0[lo:hi], compute_weights=False, return_traj=False))
     prob.loss.row_offset = 0
     assert torch.equal(torch.cat([h.samples for h in halves]), a.samples)
     # estimators == statistics of the rows

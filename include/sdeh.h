@@ -415,10 +415,12 @@ int32_t sdeh_sample_stats(const float* samples, int64_t batch, int32_t d, const 
  * sdeh_bridge_div_backward write -- what the reference's autograd accumulates into Linear.weight.grad / .bias.grad through its
  * T per-step backward calls (models/mlp.py:114-122 under losses/oc.py:232-256):
  *   part_w[k][i][j] = sum_{n in chunk k} D[i][n] * act(Z[j][n])      part_b[k][i] = sum_{n in chunk k} D[i][n]
- * D [m, N] (m <= 64: d loss / d pre-activation of the layer above), Z [c, N] (c <= 64: pre-activations of the layer below;
+ * D [m, N] (m <= 256: d loss / d pre-activation of the layer above), Z [c, N] (c <= 256: pre-activations of the layer below;
  * act = SDEH_ACT_IDENTITY when Z already holds the layer input).  chunk: rows per partial, a multiple of 8;
- * n_chunks = ceil(N / chunk);  part_w [n_chunks, 64, 64] and part_b [n_chunks, 64] (rows >= m, columns >= c are zero).
- * The caller sums the partials over k (deterministic: no atomics).  One pass over D and Z, activation applied on the fly.
+ * n_chunks = ceil(N / chunk);  part_w [n_chunks, mp, cp] and part_b [n_chunks, mp] with mp = 64 ceil(m / 64), cp = 64 ceil(c / 64)
+ * (64-channel networks: [n_chunks, 64, 64] / [n_chunks, 64]; rows >= m, columns >= c are zero).
+ * The caller sums the partials over k (deterministic: no atomics).  One pass over D and Z per [64, 64] block of the product,
+ * activation applied on the fly.
  */
 int32_t sdeh_weight_grad(const float* D, int32_t m, const float* Z, int32_t c, int64_t N, int32_t act, int64_t chunk,
                          float* part_w, float* part_b, void* stream);

@@ -32,6 +32,7 @@ long long time_embed_workspace_floats(const SdehTimeEmbed& te, int n_steps);
 int launch_sample_stats(const float* x, const float* w, const float* domain, long long B, int d, float* scratch, int nb,
                         float* out, hipStream_t st);
 int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used);           // sdeh_wide.hip
+int launch_wide_bwd(const BwdArgs& a, hipStream_t stream);                      // sdeh_wide_bwd.hip
 int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used, float* scratch);  // sdeh_wide.hip
 long long bridge_wide_scratch_floats(long long batch);                                           // sdeh_wide.hip
 
@@ -172,7 +173,9 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
 }
 
 // Workspace layout of a wide network (C in {128, 256}, d <= 256; sdeh_wide.hip): everything lives in global memory.
-static WsLayout make_wide_layout(int d, int c, int n_hidden, int t_max, int g, bool with_tan, int k_max = 0) {
+// with_bwd: also the transposed images of the training backward (sdeh_wide_bwd.hip): out_layer^T packed like an input layer
+// (k = coordinates), the hidden layers transposed, input_embed^T packed like an out layer (rows = coordinates)
+static WsLayout make_wide_layout(int d, int c, int n_hidden, int t_max, int g, bool with_tan, int k_max = 0, bool with_bwd = false) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.wide = 1;
@@ -189,10 +192,14 @@ static WsLayout make_wide_layout(int d, int c, int n_hidden, int t_max, int g, b
   L.b_out = o; o += L.otd * 32;
   L.wt_out = L.wt_hid = L.wt_in = -1;
   L.tan_in = L.tan_out = -1;
+  if (with_tan || with_bwd) { L.wt_hid = o; o += n_hidden * L.w_hid_stride; }
   if (with_tan) {
-    L.wt_hid = o; o += n_hidden * L.w_hid_stride;
     L.tan_in = o; o += d * c;
     L.tan_out = o; o += d * c;
+  }
+  if (with_bwd) {
+    L.wt_out = o; o += (L.dp8 / 8) * L.ot * 256;
+    L.wt_in = o; o += (c / 8) * L.otd * 256;
   }
   L.lds_floats = 0;
   L.coef = o; o += t_max * kCoefStride;
@@ -252,7 +259,7 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   if (wide) {
     if (desc->dim > 256) return fail(SDEH_ERR_UNSUPPORTED, "plan_create: dim=%d (the wide-network kernels cover d <= 256)", desc->dim);
     // two regions (generative + inference network of a Bridge), each with the tangent tables / transposed hidden layers
-    ws_floats = 2 * (size_t)make_wide_layout(desc->dim, desc->channels, desc->max_hidden, desc->max_steps, 32 * row_tiles(desc->dim), true, k_max).total + 64;
+    ws_floats = 2 * (size_t)make_wide_layout(desc->dim, desc->channels, desc->max_hidden, desc->max_steps, 32 * row_tiles(desc->dim), true, k_max, true).total + 64;
   } else {
     v = pick_variant(desc->dim);
     if (v == nullptr)
@@ -434,15 +441,18 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   if (k > plan->desc.max_components)
     return fail(SDEH_ERR_CAPACITY, "simulate_fwd: GMM with %d components > plan max %d", k, plan->desc.max_components);
 
-  if (plan->wide) {  // wide networks (sdeh_wide.hip): evaluation kernels; closed-form targets
-    if (backward || integrate)
-      return fail(SDEH_ERR_UNSUPPORTED, "networks with %d channels are evaluated by the wide-network kernels, which have no "
-                                        "backward pass / plain integrator (channels = 64 has)", net.channels);
+  if (plan->wide) {  // wide networks (sdeh_wide.hip, sdeh_wide_bwd.hip)
+    if (integrate)
+      return fail(SDEH_ERR_UNSUPPORTED, "networks with %d channels (or d > 64) have no plain integrator (channels = 64 with d <= 64 has)", net.channels);
+    if (backward && pr->target.kind == SDEH_DENS_GMM &&
+        (need_target_score || (!(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL) && (pr->flags & SDEH_FLAG_TERMINAL_TARGET))))
+      return fail(SDEH_ERR_UNSUPPORTED, "wide-network training: mixture targets are not built into the backward kernel (Gaussian, "
+                                        "double-well and funnel targets are)");
     if (need_target && pr->target.kind == SDEH_DENS_GMM && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
       return fail(SDEH_ERR_UNSUPPORTED, "wide Bridge kernel: mixture targets are not built in (Gaussian, double-well and funnel targets are)");
     if ((pr->flags & SDEH_FLAG_INFERENCE_CTRL) && net.channels < 128)
       return fail(SDEH_ERR_UNSUPPORTED, "Bridge with d > 64 needs channels = 128 or 256 (the wide Bridge kernel splits >= 4 row tiles over its waves)");
-    out->L = make_wide_layout(d, net.channels, net.n_hidden, n_steps, g, false, need_target && pr->target.kind == SDEH_DENS_GMM ? k : 0);
+    out->L = make_wide_layout(d, net.channels, net.n_hidden, n_steps, g, false, need_target && pr->target.kind == SDEH_DENS_GMM ? k : 0, backward);
     if ((size_t)out->L.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "simulate_fwd: workspace too small");
     out->v = nullptr; out->refc = refc; out->g = g; out->k = k;
     return SDEH_OK;
@@ -566,9 +576,13 @@ static void fill_traj_args(TrajArgs& A, const SdehProblem* pr, const float* x0, 
 static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0, int64_t batch,
                          const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, float* x_T, float* rnd, float* xs,
                          void* stream, const Checked& ck, float* gp, const float* div_noise, bool want_planes) {
-  if (want_planes || gp != nullptr || div_noise != nullptr)
-    return fail(SDEH_ERR_UNSUPPORTED, "wide-network kernels are evaluation-only: no training planes / Hutchinson probes "
-                                      "(train with channels = 64, or evaluate under torch.no_grad())");
+  // (training planes: the wide forward keeps none -- the caller's backward re-evaluates the network at the stored trajectory,
+  // sdeh_wide_bwd.hip; Hutchinson probes are a 64-channel feature)
+  (void)want_planes;
+  if (div_noise != nullptr)
+    return fail(SDEH_ERR_UNSUPPORTED, "wide-network Bridge: the Hutchinson divergence estimators are built for channels = 64 "
+                                      "(the exact divergence is built in)");
+  if (gp != nullptr && !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)) return fail(SDEH_ERR_INVALID, "simulate_fwd_aux: gp without an inference control");
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   const bool bridge = pr->flags & SDEH_FLAG_INFERENCE_CTRL;
@@ -848,6 +862,32 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
                                       "configuration the reference produces");
   if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && dgam == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward: dgam is null");
   const WsLayout& L = ck.L;
+  if (plan->wide) {  // channel-split chain kernel of sdeh_wide_bwd.hip (same planes; nn_in is not used: the wide forward keeps none)
+    hipStream_t stw = (hipStream_t)stream;
+    PrepArgs Pw;
+    Pw.ws = plan->ws; Pw.lay = L; Pw.prob = *pr; Pw.ts = ts; Pw.n_steps = n_steps;
+    Pw.ts_out = nullptr; Pw.n_out = 0; Pw.eps = 0.0f;
+    rc = launch_prep(Pw, stw);
+    if (rc != SDEH_OK) return fail(rc, "ctrl_backward (wide): prep kernel launch failed");
+    BwdArgs Aw;
+    memset(&Aw, 0, sizeof(Aw));
+    Aw.ws = plan->ws; Aw.lay = L; Aw.xs = xs; Aw.noise = noise; Aw.grad_rnd = grad_rnd; Aw.gextra = gextra;
+    Aw.cost_ctrl = cost_ctrl; Aw.lam_extra = lam_extra; Aw.dx = dx_out;
+    Aw.zt = zt; Aw.dt = dt; Aw.dout = dout; Aw.dgam = dgam; Aw.nn_in = nullptr;
+    Aw.batch = batch; Aw.row_offset = row_offset; Aw.n_steps = n_steps; Aw.d = pr->base_model.dim;
+    Aw.loss_kind = pr->loss_kind; Aw.ctrl_kind = pr->ctrl_kind; Aw.flags = pr->flags; Aw.act = pr->base_model.activation;
+    Aw.clip_model = pr->clip_model; Aw.clip_score = pr->clip_score; Aw.scale_score = pr->scale_score;
+    Aw.clip_target = pr->clip_target;
+    Aw.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
+    Aw.seed = seed; Aw.offset = offset; Aw.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
+    if (plan->timing) (void)hipEventRecord(plan->ev0, stw);
+    rc = launch_wide_bwd(Aw, stw);
+    if (plan->timing) { (void)hipEventRecord(plan->ev1, stw); plan->timed = true; }
+    snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_wide<C=%d,%s>", pr->base_model.channels, bptt ? "bptt" : "rows");
+    if (rc == SDEH_ERR_UNSUPPORTED)
+      return fail(rc, "ctrl_backward (wide): act' planes of %d layers at C=%d exceed 160 KiB of LDS", pr->base_model.n_hidden + 1, pr->base_model.channels);
+    return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward (wide): kernel launch failed");
+  }
   // The backward kernel reads mixture tables from LDS only.  It needs them for the control's target score and -- in
   // back-propagation through time -- for the terminal cost's d/dx_T; ClippedCtrl / LerpPriorCtrl in the row-parallel mode need neither.
   const bool ctrl_uses_target = pr->ctrl_kind != SDEH_CTRL_CLIPPED && pr->ctrl_kind != SDEH_CTRL_LERP_PRIOR;
@@ -1136,7 +1176,7 @@ int32_t sdeh_weight_grad(const float* D, int32_t m, const float* Z, int32_t c, i
                          float* part_w, float* part_b, void* stream) {
   if (D == nullptr || Z == nullptr || part_w == nullptr || part_b == nullptr || N < 1)
     return fail(SDEH_ERR_INVALID, "weight_grad: bad argument");
-  if (m < 1 || m > 64 || c < 1 || c > 64) return fail(SDEH_ERR_UNSUPPORTED, "weight_grad: m=%d c=%d (1..64)", m, c);
+  if (m < 1 || m > 256 || c < 1 || c > 256) return fail(SDEH_ERR_UNSUPPORTED, "weight_grad: m=%d c=%d (1..256)", m, c);
   if (chunk < 8 || (chunk & 7) != 0) return fail(SDEH_ERR_INVALID, "weight_grad: chunk=%lld must be a positive multiple of 8", (long long)chunk);
   const int rc = launch_weight_grad(D, m, Z, c, N, act, chunk, part_w, part_b, (hipStream_t)stream);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "weight_grad: launch failed (act=%d)", act);

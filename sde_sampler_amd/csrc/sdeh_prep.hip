@@ -192,6 +192,10 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
       if (L.wt_hid >= 0) pack(ws + L.wt_hid + l * L.w_hid_stride, net.hidden_w[l], C, C, C, OT, C / 8, true);
     }
     pack(ws + L.w_out, net.out_w, C, d, C, OTD, C / 8, false);            // out_layer.weight [d, C]
+    if (L.wt_out >= 0) {  // training backward: out_layer^T (rows = channels, k = coordinates), input_embed^T (rows = coordinates, k = channels)
+      pack(ws + L.wt_out, net.out_w, C, C, d, OT, L.dp8 / 8, true);
+      pack(ws + L.wt_in, net.input_w, d, d, C, OTD, C / 8, true);
+    }
     for (int c = gid; c < OTD * 32; c += stride) ws[L.b_out + morder(c)] = c < d ? net.out_b[c] : 0.0f;
     if (L.tan_in >= 0) {
       for (int e = gid; e < d * C; e += stride) {

@@ -6,7 +6,8 @@
 // contraction index is simply enumerated in the order the lanes hold it -- no LDS staging, no transposition.  The
 // activation is applied to Z on the fly (the host used to run one GELU kernel, one split-K bmm, one sum and one bias
 // reduction per layer over planes that reach 1.7 GB each at B = 65 536: 10 passes over HBM instead of one).
-// One wave = one chunk of n = one [64, 64] partial (+ [64] bias partial); the chunks are summed by the caller.
+// One wave = one chunk of n = one [64, 64] partial (+ [64] bias partial); the chunks are summed by the caller.  Layers of the wide
+// networks (m, c up to 256) are tiled into [64, 64] blocks over blockIdx.y / .z, each block streaming its own 64 + 64 rows.
 #include "sdeh_traj.hpp"
 
 namespace sdeh {
@@ -55,6 +56,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ D,
   if (ck >= n_chunks) return;
   const long long n_begin = ck * chunk;
   const long long n_end = n_begin + chunk < N ? n_begin + chunk : N;
+  // wide layers (m, c up to 256): the [m, c] product is tiled into [64, 64] blocks, one per (blockIdx.y, blockIdx.z); the partial of
+  // a chunk is the padded matrix [64 gridDim.y][64 gridDim.z] (64-channel networks: one block, the layout below is unchanged)
+  const int mb = blockIdx.y, cb = blockIdx.z;
+  const int ldw = 64 * (int)gridDim.z, mp = 64 * (int)gridDim.y;
+  D += (long long)mb * 64 * N;
+  Z += (long long)cb * 64 * N;
+  m = m - 64 * mb < 64 ? m - 64 * mb : 64;
+  c = c - 64 * cb < 64 ? c - 64 * cb : 64;
   const bool two_d = m > 32, two_z = c > 32;
   // float4 loads when every row start is 16-byte aligned (n_begin is a multiple of 8)
   const bool vec = (N & 3) == 0 && ((reinterpret_cast<unsigned long long>(D) | reinterpret_cast<unsigned long long>(Z)) & 15) == 0;
@@ -123,18 +132,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ D,
   }
 
   // partial [64][64]: accumulator q of lane (j, h) in tile (a, b) is element (32 a + rho(q, h), 32 b + j)
-  float* __restrict__ pw = part_w + ck * 4096;
+  float* __restrict__ pw = part_w + ck * ((long long)mp * ldw) + (long long)mb * 64 * ldw + cb * 64;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) pw[(32 * a + rho(q, h)) * 64 + 32 * b + j] = acc[a][b][q];
+      for (int q = 0; q < 16; ++q) pw[(32 * a + rho(q, h)) * ldw + 32 * b + j] = acc[a][b][q];
   bs0 += __shfl_xor(bs0, 32);
   bs1 += __shfl_xor(bs1, 32);
-  if (h == 0) {
-    part_b[ck * 64 + j] = bs0;
-    part_b[ck * 64 + 32 + j] = bs1;
+  if (h == 0 && cb == 0) {
+    part_b[ck * mp + mb * 64 + j] = bs0;
+    part_b[ck * mp + mb * 64 + 32 + j] = bs1;
   }
 }
 
@@ -180,7 +189,7 @@ int launch_partial_sums(const float* part, long long n_items, long long n_chunks
 int launch_weight_grad(const float* D, int m, const float* Z, int c, long long N, int act, long long chunk, float* part_w,
                        float* part_b, hipStream_t stream) {
   const long long n_chunks = (N + chunk - 1) / chunk;
-  const dim3 grid((unsigned)((n_chunks + 3) / 4));
+  const dim3 grid((unsigned)((n_chunks + 3) / 4), (unsigned)((m + 63) / 64), (unsigned)((c + 63) / 64));
   switch (act) {
     case SDEH_ACT_GELU_ERF:
       hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_GELU_ERF>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);

@@ -534,6 +534,15 @@ class TrajectoryEngine:
         if want_planes:  # training forward: keep what the backward kernels need
             if not return_traj or want_gp or div_noise is not None:
                 raise ValueError("want_planes goes with return_traj=True and without the Bridge outputs")
+            if pr.base_model.channels != 64 or dim > 64:
+                # wide networks (csrc/sdeh_wide_bwd.hip): the forward keeps the trajectory only; the backward re-evaluates the network
+                # on the matrix pipe at the stored states
+                xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
+                with torch.cuda.device(device):
+                    L.check(lib.sdeh_simulate_fwd_aux(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
+                                                      seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(), rnd.data_ptr(),
+                                                      xs.data_ptr(), None, None, stream))
+                return x_T, rnd, xs, None
             if lib.sdeh_ctrl_backward_fused_supported(plan.handle, C.byref(pr)):
                 # fused backward (csrc/sdeh_bwdf.hip): the combined score per step and the terminal target score, no [C, T*B] planes
                 # (coordinate-major planes: [.., d, B])

@@ -137,33 +137,50 @@ def _time_table_grads(ctrl, ts, d_emb, d_gam) -> dict[int, torch.Tensor]:
 def _wgrad_batch(items: list[tuple[torch.Tensor, torch.Tensor, int]]) -> list[tuple[torch.Tensor, torch.Tensor]]:
     """[(dmat @ act(z)^T [m, c], dmat.sum(1) [m]) for (dmat [m, N], z [c, N], act) in items], every product in ONE pass over its
     two coordinate-major planes (sdeh_weight_grad: activation on the fly, K-contiguous MFMA operands) and ONE reduction of all
-    the per-chunk partials at the end (sdeh_partial_sums).  All items share N."""
+    the per-chunk partials at the end (sdeh_partial_sums).  All items share N; m, c <= 256 (the products of the wide networks are
+    tiled into [64, 64] blocks by the kernel, partials padded to multiples of 64)."""
     N = items[0][0].shape[1]
     dev = items[0][0].device
-    # ~8192 partials (a few waves per SIMD hide the HBM latency); at least 128 rows per partial keeps the partial sums small
-    chunk = max(128, -(-N // 8192))
+    pad = lambda v: 64 * ((v + 63) // 64)
+    mp = max(pad(dm.shape[0]) for dm, _, _ in items)
+    cp = max(pad(z.shape[0]) for _, z, _ in items)
+    # ~8192 waves per product (a few per SIMD hide the HBM latency; one wave = one [64, 64] block of one chunk); at least 128 rows
+    # per partial keeps the partial sums small
+    blocks = (mp // 64) * (cp // 64)
+    chunk = max(128, -(-N // max(256, 8192 // blocks)))
     chunk = (chunk + 31) // 32 * 32
     n_chunks = -(-N // chunk)
-    part_w = torch.empty((len(items), n_chunks, 64, 64), device=dev, dtype=torch.float32)
-    part_b = torch.empty((len(items), n_chunks, 64), device=dev, dtype=torch.float32)
     lib = L.load()
     stream = torch.cuda.current_stream(dev).cuda_stream
     keep = []
+    out = []
+    # one partial buffer for the 64-channel case (every item [64, 64]: a single reduction launch); per-shape buffers otherwise
+    groups: dict[tuple[int, int], list[int]] = {}
+    for i, (dmat, z, _) in enumerate(items):
+        groups.setdefault((pad(dmat.shape[0]), pad(z.shape[0])), []).append(i)
+    results: list = [None] * len(items)
     with torch.cuda.device(dev):
-        for i, (dmat, z, act_id) in enumerate(items):
-            dmat, z = dmat.contiguous(), z.contiguous()
-            keep.append((dmat, z))
-            L.check(lib.sdeh_weight_grad(dmat.data_ptr(), dmat.shape[0], z.data_ptr(), z.shape[0], N, act_id, chunk,
-                                         part_w[i].data_ptr(), part_b[i].data_ptr(), stream))
-        # the sums over the chunks are done by the library too (deterministic two-pass kernel): torch's multi-block reduction is
-        # not safe to replay inside a hipGraph on this stack (see csrc/sdeh_wgrad.hip)
-        n = len(items)
-        w = torch.empty((n, 64, 64), device=dev, dtype=torch.float32)
-        b = torch.empty((n, 64), device=dev, dtype=torch.float32)
-        scratch = torch.empty(lib.sdeh_partial_sums_scratch_floats(n, n_chunks, 4096), device=dev, dtype=torch.float32)
-        L.check(lib.sdeh_partial_sums(part_w.data_ptr(), n, n_chunks, 4096, scratch.data_ptr(), w.data_ptr(), stream))
-        L.check(lib.sdeh_partial_sums(part_b.data_ptr(), n, n_chunks, 64, scratch.data_ptr(), b.data_ptr(), stream))
-    return [(w[i, :dmat.shape[0], :z.shape[0]], b[i, :dmat.shape[0]]) for i, (dmat, z, _) in enumerate(items)]
+        for (gm, gc), idxs in groups.items():
+            n = len(idxs)
+            part_w = torch.empty((n, n_chunks, gm, gc), device=dev, dtype=torch.float32)
+            part_b = torch.empty((n, n_chunks, gm), device=dev, dtype=torch.float32)
+            for slot, i in enumerate(idxs):
+                dmat, z, act_id = items[i]
+                dmat, z = dmat.contiguous(), z.contiguous()
+                keep.append((dmat, z))
+                L.check(lib.sdeh_weight_grad(dmat.data_ptr(), dmat.shape[0], z.data_ptr(), z.shape[0], N, act_id, chunk,
+                                             part_w[slot].data_ptr(), part_b[slot].data_ptr(), stream))
+            # the sums over the chunks are done by the library too (deterministic two-pass kernel): torch's multi-block reduction is
+            # not safe to replay inside a hipGraph on this stack (see csrc/sdeh_wgrad.hip)
+            w = torch.empty((n, gm, gc), device=dev, dtype=torch.float32)
+            b = torch.empty((n, gm), device=dev, dtype=torch.float32)
+            scratch = torch.empty(lib.sdeh_partial_sums_scratch_floats(n, n_chunks, gm * gc), device=dev, dtype=torch.float32)
+            L.check(lib.sdeh_partial_sums(part_w.data_ptr(), n, n_chunks, gm * gc, scratch.data_ptr(), w.data_ptr(), stream))
+            L.check(lib.sdeh_partial_sums(part_b.data_ptr(), n, n_chunks, gm, scratch.data_ptr(), b.data_ptr(), stream))
+            for slot, i in enumerate(idxs):
+                dmat, z, _ = items[i]
+                results[i] = (w[slot, :dmat.shape[0], :z.shape[0]], b[slot, :dmat.shape[0]])
+    return results
 
 
 def _wgrad(dmat: torch.Tensor, z: torch.Tensor, act_id: int) -> tuple[torch.Tensor, torch.Tensor]:
@@ -179,7 +196,7 @@ def _time_embed_grads(te, act_id: int, steps: torch.Tensor, table_grad: torch.Te
     keep = E._Keep()
     st = L.SdehTimeEmbed()
     E._fill_time_embed(te, st, keep, dev, "time embedding")
-    if not 1 <= st.n_hidden <= 4:
+    if not 1 <= st.n_hidden <= 4 or st.channels > 64:  # (the kernel stages a [C, 2C] layer in LDS: 64 channels)
         return None
     layers = list(E._sub(te, "hidden_layer"))
     out_layer, phase = E._sub(te, "out_layer"), E._sub(te, "timestep_phase")

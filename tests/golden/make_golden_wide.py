@@ -2,8 +2,10 @@
 """Golden vectors for the WIDE-network kernels (`wide_*.npz`): FourierMLP with 128 / 256 channels and state dimensions up to
 196 -- the shape of BASELINE.json configs[4] -- through the reference's three simulate() loops and its Bridge branch
 (losses/oc.py:156-230 incl. 189-202, 286-343, 400-457; models/mlp.py:85-122 with `channels` a free constructor argument).
-Produced by RUNNING THE REFERENCE; build container only (see make_golden.py for the conventions).  Evaluation passes only (the
-wide kernels are evaluation kernels): parameters, ts, x0, per-step noise -> x_T, rnd, estimators of both eval passes."""
+Produced by RUNNING THE REFERENCE; build container only (see make_golden.py for the conventions): parameters, ts, x0, per-step
+noise -> x_T, rnd, estimators of both eval passes, and (round 3) the training losses and PARAMETER GRADIENTS of the reference's
+autograd for methods kl and lv (`loss(...)` + `.backward()`, losses/oc.py:232-256; Bridges: both networks, exact divergence with
+create_graph=True, utils/autograd.py:14-22) -- the pins of the wide training backward (csrc/sdeh_wide_bwd.hip)."""
 from __future__ import annotations
 
 import json
@@ -20,6 +22,9 @@ import make_golden as mg  # noqa: E402
 from sde_sampler.losses.oc import TimeReversalLoss  # noqa: E402
 
 OUT = Path(__file__).resolve().parent
+#: gradient tensors above this size are stored as a strided sample of their flattened entries (+ their Euclidean norm): the two
+#: methods x two networks of a C = 256 Bridge would otherwise be 15 MB of incompressible floats per fixture
+GRAD_FULL_MAX, GRAD_STRIDE = 16384, 5
 ISO = lambda d, **kw: dict(kind="iso_gauss", dim=d, loc=0.0, scale=1.0, **kw)
 
 CASES = {
@@ -135,6 +140,30 @@ def _eval_passes(out, loss, ts, x0, state, terminal, second, train_kw):
         out["eval2/log_norm_const_lb"] = np.float64(res2.log_norm_const_preds["log_norm_const_lb"])
 
 
+def _train_passes(out, loss, mods, ts, x0, state, terminal, second):
+    """train_{kl,lv}/loss and the gradients of every parameter of `mods` = (("grad", generative), ("grad_inf", inference)...)."""
+    keep = loss.method
+    for method in ("kl", "lv"):
+        loss.method, loss.n_filtered = method, 0
+        for _, mod in mods:
+            mod.zero_grad()
+        torch.set_rng_state(state)
+        val, metrics = loss(ts, x0, terminal, second)
+        val.backward()
+        out[f"train_{method}/loss"] = np.float64(val.item())
+        out[f"train_{method}/n_filtered"] = np.int64(metrics["train/n_filtered_cumulative"])
+        for prefix, mod in mods:
+            for k, p in mod.named_parameters():
+                g = p.grad.detach().numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+                key = f"train_{method}/{prefix}/{k}"
+                if g.size > GRAD_FULL_MAX:  # the [256, 256] / [256, 512] / [196, 256] matrices: every GRAD_STRIDE-th entry + the norm
+                    out[key + "@stride"] = g.reshape(-1)[::GRAD_STRIDE].copy()
+                    out[key + "@norm"] = np.float64(np.linalg.norm(g.astype(np.float64)))
+                else:
+                    out[key] = g
+    loss.method, loss.n_filtered = keep, 0
+
+
 def run_case(name, case):
     target, prior, sde, ctrl, loss, second, ts = mg.reference_problem(case)
     x0, noise, state = mg.draw_inputs(case, prior, ts)
@@ -142,6 +171,7 @@ def run_case(name, case):
     out.update(ts=ts.numpy(), x0=x0.numpy(), noise=noise.numpy())
     train_kw = {"train": False} if case["loss"]["kind"] == "time_reversal" else {}
     _eval_passes(out, loss, ts, x0, state, target.unnorm_log_prob, second, train_kw)
+    _train_passes(out, loss, (("grad", ctrl),), ts, x0, state, target.unnorm_log_prob, second)
     if case["target"]["kind"] == "gmm":
         out["target/loc"], out["target/scale"] = target.loc.numpy(), target.scale.numpy()
         out["target/mixture_weights"] = target.mixture_weights.numpy()
@@ -166,6 +196,7 @@ def run_bridge_case(name, case):
     out.update({"param_inf/" + k: v.detach().numpy().copy() for k, v in inf.state_dict().items()})
     out.update(ts=ts.numpy(), x0=x0.numpy(), noise=noise.numpy())
     _eval_passes(out, loss, ts, x0, state, target.unnorm_log_prob, prior.log_prob, {"train": False})
+    _train_passes(out, loss, (("grad", ctrl), ("grad_inf", inf)), ts, x0, state, target.unnorm_log_prob, prior.log_prob)
     _finish(name, case, out, ts, x0)
 
 
@@ -174,7 +205,8 @@ def _finish(name, case, out, ts, x0):
     path = OUT / f"{name}.npz"
     np.savez_compressed(path, **out)
     print(f"{name:34s} B={case['B']:3d} T={len(ts)-1:3d} d={x0.shape[1]:3d} logZ_is={out['eval1/log_norm_const_is']:+.5f} "
-          f"lb={out['eval2/log_norm_const_lb']:+.5f} {path.stat().st_size/1024:.1f} KB")
+          f"lb={out['eval2/log_norm_const_lb']:+.5f} train_kl={out['train_kl/loss']:+.5f} train_lv={out['train_lv/loss']:+.5f} "
+          f"{path.stat().st_size/1024:.1f} KB")
 
 
 if __name__ == "__main__":

@@ -233,3 +233,45 @@ def test_wide_network_eval_passes_bit_exact(path):
     assert np.array_equal(r2["samples"].numpy(), fx["eval2/x_T"])
     assert np.array_equal(r2["rnd"].numpy(), fx["eval2/rnd"])
     assert r2["log_norm_const_lb"] == float(fx["eval2/log_norm_const_lb"])
+
+
+def golden_grad(fx, key):
+    """(reference gradient, is_strided): large tensors of the wide fixtures are stored as every GRAD_STRIDE-th flattened entry
+    (`key@stride`, tests/golden/make_golden_wide.py) together with their Euclidean norm (`key@norm`)."""
+    if key in fx.files:
+        return fx[key], None
+    return fx[key + "@stride"], float(fx[key + "@norm"])
+
+
+@pytest.mark.parametrize("method", ["kl", "lv"])
+@pytest.mark.parametrize("path", GOLDEN_WIDE, ids=lambda p: Path(p).stem)
+def test_wide_network_train_loss_and_grads_bit_exact(path, method):
+    """Round 3: the wide fixtures also carry the reference's training losses and parameter gradients (both networks of a Bridge,
+    exact divergence with create_graph=True) -- the oracle's autograd reproduces them bit for bit."""
+    torch.set_num_threads(4)
+    fx, prob, params, ts, x0, noise = load(path)
+    pinf = prob.inference_ctrl.p if prob.inference_ctrl is not None else {}
+    groups = (("grad", params), ("grad_inf", pinf))
+    for _, pd in groups:
+        for k, p in pd.items():
+            if p.is_floating_point() and not k.endswith("timestep_coeff"):
+                p.requires_grad_(True)
+    loss, n_filtered, _, _ = prob.train_loss(ts, x0, noise, method=method)
+    loss.backward()
+    assert loss.item() == float(fx[f"train_{method}/loss"])
+    assert n_filtered == int(fx[f"train_{method}/n_filtered"])
+    checked = 0
+    for prefix, pd in groups:
+        for k, p in pd.items():
+            key = f"train_{method}/{prefix}/{k}"
+            if key not in fx.files and key + "@stride" not in fx.files:
+                continue
+            ref, norm = golden_grad(fx, key)
+            g = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+            if norm is None:
+                assert np.array_equal(g, ref), key
+            else:
+                assert np.array_equal(g.reshape(-1)[::5], ref), key
+                assert np.linalg.norm(g.astype(np.float64)) == norm, key
+            checked += 1
+    assert checked >= 10

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SDEH_ABI_VERSION 3
+#define SDEH_ABI_VERSION 4
 #define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
 
 typedef enum {
@@ -176,8 +176,9 @@ typedef struct {
 
 typedef struct {
   int32_t dim;         /* d <= 64 with channels = 64: every entry point.  d <= 256 with channels = 128 / 256, and 64 < d <= 256 with
-                          channels = 64: the evaluation-only "wide" kernels (sdeh_simulate_fwd; a Bridge needs channels >= 128, a
-                          closed-form target and an inference network with <= 2 hidden layers) */
+                          channels = 64: the "wide" kernels -- sdeh_simulate_fwd[_aux], sdeh_ctrl_backward[_ex] + sdeh_weight_grad,
+                          sdeh_bridge_div_backward_wide (a Bridge needs channels >= 128, a closed-form target and an inference
+                          network with <= 2 hidden layers; training needs closed-form targets) */
   int32_t channels;    /* C: 64, 128 or 256 */
   int32_t max_hidden;  /* largest n_hidden of base_model */
   int32_t max_steps;   /* largest T = len(ts)-1 */
@@ -340,6 +341,29 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, con
                                  const float* xs, int64_t batch, const float* grad_rnd, const float* zt, float* tz,
                                  float* ta, float* td, float* d2, float* cj, float* dgam, float* dx_accum,
                                  const float* div_noise, void* stream);
+
+/*
+ * Bridge on WIDE networks (channels 128 / 256: conf/solver/bridge.yaml with the channels of BASELINE configs[4]): gradient of the
+ * divergence term  sum_n w_i sigma dt sum_j 1[|v_nn,j| <= clip_model] J_jj(x_n; theta_v)  w.r.t. the inference network -- what the
+ * reference's autograd does through the d backward passes per step of utils/autograd.py:14-22 (create_graph=True) under
+ * losses/oc.py:189-200.  The per-(row, coordinate) tangents cannot be written out at these sizes (the planes tz / ta / td of
+ * sdeh_bridge_div_backward would take d (Lh+1) C N floats), so the contraction is fused (csrc/sdeh_wide_bwd.hip): the gradient of one
+ * hidden layer stays in the accumulators of persistent workgroups for a whole launch; one launch per hidden layer.  Exact
+ * divergence only; inference networks with one or two hidden layers; the first-order terms go through sdeh_ctrl_backward_ex as for
+ * 64 channels (the trajectory kernels accept gp for wide plans).
+ *   zt   [(Lh+1), C, N]  in : pre-activations of the inference network, as sdeh_ctrl_backward_ex wrote them for the inference problem
+ *   d2   [(Lh+1), C, N]  out: adjoints of those pre-activations through the divergence (ADD to the dt planes of the first-order pass:
+ *                             the weight gradients of both are one sdeh_weight_grad contraction)
+ *   dgam [g, N]          out: d / d gamma(t) of the score part of the divergence (LerpPriorCtrl; NULL for ClippedCtrl)
+ *   out  (floats): d / d input_embed.weight TRANSPOSED [d, C] | d / d out_layer.weight [d, C] | d / d hidden_layer[0].weight [C, C] |
+ *                  (two hidden layers:) d / d hidden_layer[1].weight TRANSPOSED [C, C]   -- the tangent streams' direct contributions
+ *   scratch: sdeh_bridge_div_backward_wide_sizes floats (per-workgroup partials, summed deterministically: no atomics).
+ */
+int32_t sdeh_bridge_div_backward_wide_sizes(int32_t dim, int32_t channels, int32_t n_hidden, int32_t n_steps, int64_t batch,
+                                            int64_t* scratch_floats, int64_t* out_floats);
+int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
+                                      int64_t batch, const float* grad_rnd, const float* zt, float* d2, float* dgam, float* scratch,
+                                      int64_t scratch_floats, float* out, void* stream);
 
 /*
  * Batch reductions of BaseOCLoss.compute_results / compute_loss (losses/oc.py:72-123), as mergeable partial

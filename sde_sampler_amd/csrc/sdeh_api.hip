@@ -33,6 +33,8 @@ int launch_sample_stats(const float* x, const float* w, const float* domain, lon
                         float* out, hipStream_t st);
 int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used);           // sdeh_wide.hip
 int launch_wide_bwd(const BwdArgs& a, hipStream_t stream);                      // sdeh_wide_bwd.hip
+int launch_wide_div_bwd(const WideDivArgs& a, hipStream_t stream);              // sdeh_wide_bwd.hip
+int wide_div_grid(long long batch, int n_steps);                                // sdeh_wide_bwd.hip
 int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used, float* scratch);  // sdeh_wide.hip
 long long bridge_wide_scratch_floats(long long batch);                                           // sdeh_wide.hip
 
@@ -638,6 +640,7 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     A.ws2 = plan->ws + ck.L.total; A.lay2 = L2;
     A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
     A.inf_clip_model = inf.clip_model; A.inf_clip_score = inf.clip_score; A.inf_scale_score = inf.scale_score;
+    A.gp = gp;  // [T, B, d] or null: u + v per step (training: the inference network's upstream gradient)
   }
   if (bridge) {
     // the one buffer a plan grows after creation: 32 group sums per trajectory of the network part of the divergence
@@ -913,6 +916,101 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   rc = ck.v->fn_bwd(A, st);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward: kernel launch failed");
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Bridge on wide networks: gradient of the divergence term, fused (sdeh_wide_bwd.hip)
+// ---------------------------------------------------------------------------------------------------------
+static void wide_div_sizes(int d, int c, int n_hidden, int n_steps, long long batch, long long* grid, long long* xp, long long* cp,
+                           long long* sums, long long* out) {
+  const long long g = wide_div_grid(batch, n_steps);
+  *grid = g;
+  *xp = g * c * c;
+  *cp = g * d * c;
+  *sums = ((g + 31) / 32) * (long long)c * (c > d ? c : d);
+  *out = 2LL * d * c + (long long)n_hidden * c * c;
+}
+
+int32_t sdeh_bridge_div_backward_wide_sizes(int32_t dim, int32_t channels, int32_t n_hidden, int32_t n_steps, int64_t batch,
+                                            int64_t* scratch_floats, int64_t* out_floats) {
+  if (dim < 1 || (channels != 128 && channels != 256) || n_hidden < 1 || n_hidden > 2 || n_steps < 1 || batch < 1 ||
+      scratch_floats == nullptr || out_floats == nullptr)
+    return fail(SDEH_ERR_INVALID, "bridge_div_backward_wide_sizes: bad argument (channels 128 / 256, one or two hidden layers)");
+  long long g, xp, cp, sums, out;
+  wide_div_sizes(dim, channels, n_hidden, n_steps, batch, &g, &xp, &cp, &sums, &out);
+  *scratch_floats = 2 * xp + 3 * cp + sums;
+  *out_floats = out;
+  return SDEH_OK;
+}
+
+int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                      int64_t batch, const float* grad_rnd, const float* zt, float* d2, float* dgam, float* scratch,
+                                      int64_t scratch_floats, float* out, void* stream) {
+  if (plan == nullptr || pr == nullptr || ts == nullptr || xs == nullptr || grad_rnd == nullptr || zt == nullptr || d2 == nullptr ||
+      scratch == nullptr || out == nullptr)
+    return fail(SDEH_ERR_INVALID, "bridge_div_backward_wide: null argument");
+  if (!plan->wide || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL))
+    return fail(SDEH_ERR_INVALID, "bridge_div_backward_wide: needs a wide plan and a problem with an inference control");
+  Checked ck;
+  int rc = check_problem(plan, pr, ts, n_steps, batch, 0, false, &ck);
+  if (rc != SDEH_OK) return rc;
+  const SdehInferenceCtrl& inf = pr->inference;
+  const SdehFourierMLP& net2 = inf.base_model;
+  const int d = pr->base_model.dim, C = net2.channels;
+  if (C != pr->base_model.channels || (C != 128 && C != 256))
+    return fail(SDEH_ERR_UNSUPPORTED, "bridge_div_backward_wide: both networks need 128 or 256 channels");
+  if (net2.n_hidden < 1 || net2.n_hidden > 2)
+    return fail(SDEH_ERR_UNSUPPORTED, "bridge_div_backward_wide: built for inference networks with one or two hidden layers (got %d)", net2.n_hidden);
+  if (inf.ctrl_kind == SDEH_CTRL_LERP_PRIOR && dgam == nullptr) return fail(SDEH_ERR_INVALID, "bridge_div_backward_wide: dgam is null");
+  int g2 = 1;
+  if (inf.ctrl_kind == SDEH_CTRL_LERP_PRIOR && inf.score_model.n_hidden > 0) g2 = inf.score_model.dim_out == 1 ? 1 : 32 * row_tiles(d);
+  const WsLayout L2 = make_wide_layout(d, C, net2.n_hidden, n_steps, g2, true);
+  if ((size_t)ck.L.total + (size_t)L2.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "bridge_div_backward_wide: workspace too small");
+  long long grid, xp, cp, sums, n_out;
+  wide_div_sizes(d, C, net2.n_hidden, n_steps, batch, &grid, &xp, &cp, &sums, &n_out);
+  if (scratch_floats < 2 * xp + 3 * cp + sums)
+    return fail(SDEH_ERR_CAPACITY, "bridge_div_backward_wide: scratch too small (%lld < %lld floats)", (long long)scratch_floats, 2 * xp + 3 * cp + sums);
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = ck.L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
+  rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "bridge_div_backward_wide: prep kernel launch failed");
+  PrepArgs P2 = P;
+  P2.ws = plan->ws + ck.L.total; P2.lay = L2;
+  P2.prob.ctrl_kind = inf.ctrl_kind; P2.prob.clip_model = inf.clip_model; P2.prob.clip_score = inf.clip_score;
+  P2.prob.scale_score = inf.scale_score; P2.prob.base_model = inf.base_model; P2.prob.score_model = inf.score_model;
+  P2.prob.target.kind = P2.prob.prior.kind = P2.prob.second.kind = SDEH_DENS_NONE;
+  rc = launch_prep(P2, st);
+  if (rc != SDEH_OK) return fail(rc, "bridge_div_backward_wide: second prep kernel launch failed");
+  // scratch: [xpart side 1][xpart side 0][cpart side 1][cpart side 0][spart][sums]
+  float* xp1 = scratch; float* xp0 = xp1 + xp; float* cp1 = xp0 + xp; float* cp0 = cp1 + cp; float* sp0 = cp0 + cp; float* sm = sp0 + cp;
+  if (hipMemsetAsync(cp1, 0, (size_t)(3 * cp) * sizeof(float), st) != hipSuccess) return fail(SDEH_ERR_HIP, "bridge_div_backward_wide: memset failed");
+  WideDivArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = ck.L; A.ws2 = plan->ws + ck.L.total; A.lay2 = L2;
+  A.xs = xs; A.grad_rnd = grad_rnd; A.zt = zt; A.d2 = d2; A.dgam = dgam;
+  A.batch = batch; A.n_steps = n_steps; A.d = d; A.inf_kind = inf.ctrl_kind; A.act = net2.activation;
+  A.clip_model = inf.clip_model; A.clip_score = inf.clip_score; A.scale_score = inf.scale_score;
+  float* g_in = out; float* g_out = out + (long long)d * C; float* g_hid = g_out + (long long)d * C;
+  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  if (net2.n_hidden == 2) {  // side 1: d W_2^T, d W_out, adj z_2
+    A.side = 1; A.xpart = xp1; A.cpart = cp1; A.spart = nullptr;
+    rc = launch_wide_div_bwd(A, st);
+    if (rc == SDEH_OK) rc = launch_partial_sums(xp1, 1, grid, (long long)C * C, sm, g_hid + (long long)C * C, st);
+    if (rc == SDEH_OK) rc = launch_partial_sums(cp1, 1, grid, (long long)d * C, sm, g_out, st);
+  }
+  if (rc == SDEH_OK) {  // side 0: d W_1, d W_in^T, (one hidden layer: d W_out), adj z_1, adj z_0, d gamma
+    A.side = 0; A.xpart = xp0; A.cpart = cp0; A.spart = net2.n_hidden == 1 ? sp0 : nullptr;
+    rc = launch_wide_div_bwd(A, st);
+    if (rc == SDEH_OK) rc = launch_partial_sums(xp0, 1, grid, (long long)C * C, sm, g_hid, st);
+    if (rc == SDEH_OK) rc = launch_partial_sums(cp0, 1, grid, (long long)d * C, sm, g_in, st);
+    if (rc == SDEH_OK && net2.n_hidden == 1) rc = launch_partial_sums(sp0, 1, grid, (long long)d * C, sm, g_out, st);
+  }
+  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bridge_div_bwd_wide<C=%d>", C);
+  if (rc == SDEH_ERR_UNSUPPORTED) return fail(rc, "bridge_div_backward_wide: planes of %d layers at C=%d exceed 160 KiB of LDS", net2.n_hidden + 2, C);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "bridge_div_backward_wide: kernel launch failed");
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -146,6 +146,25 @@ struct BridgeBwdArgs {
   float clip_model, clip_score, scale_score;
 };
 
+// sdeh_bridge_div_backward_wide (sdeh_wide_bwd.hip): the divergence term's gradient on wide networks, fused
+struct WideDivArgs {
+  const float* ws;    // region 1: per-step coefficients, prior table
+  WsLayout lay;
+  const float* ws2;   // region 2: the inference network (packed + transposed weights, tangent tables, gamma, biases)
+  WsLayout lay2;
+  const float* xs;        // [T+1, B, d]
+  const float* grad_rnd;  // [B]
+  const float* zt;        // [(Lh+1), C, N] pre-activations of the inference network (sdeh_ctrl_backward_ex wrote them)
+  float* d2;              // [(Lh+1), C, N] adjoints of the base pre-activations through the divergence (side 1 writes plane Lh, side 0 the rest)
+  float* dgam;            // [g, N] (side 0)
+  float* xpart;           // [grid][C][C] partial of dX
+  float* cpart;           // [grid][d][C] partial of d L / d col_q  (zeroed by the caller)
+  float* spart;           // [grid][d][C] partial of d L / d W_out (Lh = 1 only, side 0; zeroed by the caller)
+  long long batch;
+  int n_steps, d, inf_kind, act, side;
+  float clip_model, clip_score, scale_score;
+};
+
 struct BwdArgs {
   const float* ws;
   WsLayout lay;

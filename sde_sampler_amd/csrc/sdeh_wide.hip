@@ -806,6 +806,12 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
         for (int q = 0; q < 16; ++q)
           if (coord(q) < d) xp[(q & 3) + 8 * (q >> 2)] = x[q];
       }
+      if (A.gp != nullptr && live && lead) {  // training: u + v of this step (the inference network's upstream gradient)
+        float* __restrict__ gq = A.gp + ((long long)i * A.batch + lrow) * d + cb;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (coord(q) < d) gq[(q & 3) + 8 * (q >> 2)] = u[q] + v[q];
+      }
       SDEH_FENCE();
     };
     if (nto > 0) vtile(xr[0][0], nu[0][0], nv[0][0], w);

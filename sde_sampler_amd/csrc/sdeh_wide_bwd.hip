@@ -520,4 +520,402 @@ int launch_wide_bwd(const BwdArgs& a, hipStream_t stream) {
   return SDEH_ERR_UNSUPPORTED;
 }
 
+
+// =========================================================================================================
+// Gradient of the Bridge's divergence term on wide networks (losses/oc.py:189-200 with utils/autograd.py:14-22, create_graph=True):
+//     L_div = sum over rows n = (t, i) of  c_n sum_j m_nj J_jj(x_n; theta_v),   c_n = w_i sigma(t) dt,  m_nj = 1[|v_nn,j| <= clip_model]
+// for an inference network with Lh = 1 or 2 hidden layers.  With D_l = act'(z_l), P_j = D_0 . W_in[:, j], R_j = D_Lh . W_out[j, :]:
+//     Lh = 2:  F_j = W_1 P_j,  G_j = W_2^T R_j,  J_jj = G_j^T D_1 F_j          Lh = 1:  F_j = W_1 P_j,  G_j = R_j := W_out[j, :]
+// The per-(row, coordinate) operands (F, G, their adjoints: C floats each, 657 GB per plane at configs[4]'s size) can never be
+// written out, so the contraction is fused: the [C, C] gradient of ONE hidden layer stays in the accumulators of a persistent
+// workgroup for the whole launch (all 256 AGPRs of its four waves at C = 256 -- which is why the two hidden layers take two
+// launches, `side` 0 / 1).  One launch, per (step, tile of 32 trajectories) and coordinate j, all four waves on the same j:
+//     S_j  = X_s Q_s                 (side 0: G_j = W_2^T R_j;  side 1: F_j = W_1 P_j)            one [C, C] product, wave w: row tiles {w, w + 4}
+//     O_j  = X Q_j                   (side 0 only: F_j, for d L / d D_1 = sum_j c_j F_j G_j)
+//     dS_j = c_j D_1 . S_j           -> LDS plane [C][32]
+//     dX  += dS_j Q_j^T              (contraction over the 32 trajectories: both operands are planes read transposed; side 0: dW_1,
+//                                     side 1: dW_2^T)
+//     dQ_j = X^T dS_j                -> d L / d D_q += dQ_j . col_q[j],   d L / d col_q[j] += sum_traj dQ_j . D_q
+// (col_q[j] = column j of W_in for side 0, row j of W_out for side 1).  Seven [C, C] products per (row, coordinate) in total against
+// the forward's two.  After the coordinates of an item the adjoints of the base pre-activations (how z_l enters through act') close
+// the chain: adj z_l = act''(z_l) dD_l + act'(z_l) W_{l+1}^T adj z_{l+1}, written as planes d2 [(Lh+1), C, N] -- the weight gradients
+// they imply are the same contraction as the first-order ones (sdeh_weight_grad adds them to the planes of sdeh_ctrl_backward_ex).
+// =========================================================================================================
+constexpr int kDivRS = 36;  // row stride of the planes: conflict-free transposed ds_read_b128 (4 x odd), as in sdeh_bwdf.hip
+
+
+// B-order index of channel ch inside the tangent tables (WsLayout: idx = (ch / 8) * 8 + (ch & 1) * 4 + ((ch & 7) >> 1))
+__device__ __forceinline__ int wdiv_bidx(int ch) { return (ch & ~7) + (ch & 1) * 4 + ((ch & 7) >> 1); }
+
+// acc[k] = sum over NS4 k-groups of  Wp[tile tiles[k]][:] . (plane[:, traj] * col[:])   (col == nullptr: the plane alone)
+//   wgrp: packed layer (k-groups of OT tiles);  pl: plane + h * kDivRS + j;  col: B-order vector + 4 h
+template <int NT>
+__device__ __forceinline__ void wdiv_pass(const float* __restrict__ wgrp, int OT, const int (&tiles)[NT], int NS4, unsigned lane_off,
+                                          const float* __restrict__ pl, const float* __restrict__ col, f32x16 (&acc)[NT]) {
+  f32x4 a[2][NT];
+  const int grp_floats = OT * 256;
+  auto issue = [&](int S, f32x4 (&av)[NT]) {
+    const float* base = wgrp + (long long)(S < NS4 ? S : NS4 - 1) * grp_floats;
+#pragma unroll
+    for (int k = 0; k < NT; ++k) wide_gload(av[k], lane_off + (unsigned)(tiles[k] * 1024), base);
+  };
+#pragma unroll
+  for (int k = 0; k < NT; ++k)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
+  issue(0, a[0]);
+  float b[2][4];
+  auto loadB = [&](int S, float (&bv)[4]) {
+    const int Sc = S < NS4 ? S : NS4 - 1;
+    const float* __restrict__ dp = pl + (8 * Sc) * kDivRS;
+    bv[0] = dp[0]; bv[1] = dp[2 * kDivRS]; bv[2] = dp[4 * kDivRS]; bv[3] = dp[6 * kDivRS];
+    if (col != nullptr) {
+      const float4 cv = *reinterpret_cast<const float4*>(col + 8 * Sc);
+      bv[0] *= cv.x; bv[1] *= cv.y; bv[2] *= cv.z; bv[3] *= cv.w;
+    }
+  };
+  loadB(0, b[0]);
+  for (int S = 0; S < NS4; S += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      issue(S + u + 1, a[(u + 1) % 2]);
+      loadB(S + u + 1, b[(u + 1) % 2]);
+      wide_vmwait<NT, NT>(a[u]);  // all but the NT newest loads have landed
+      SDEH_FENCE();
+      if (S + u < NS4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int k = 0; k < NT; ++k) acc[k] = SDEH_MFMA(a[u][k][e], b[u][e], acc[k]);
+      }
+      SDEH_FENCE();
+    }
+  }
+  wide_vmwait<0, NT>(a[0]);  // drain the clamped re-reads issued by the last iterations
+  wide_vmwait<0, NT>(a[1]);
+}
+
+template <int OTW>  // C = 128 OTW
+__global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivArgs A, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int OT = 4 * OTW, C = 128 * OTW, RS = kDivRS;
+  const WsLayout& L = A.lay;
+  const WsLayout& L2 = A.lay2;
+  const float* __restrict__ ws = A.ws;
+  const float* __restrict__ ws2 = A.ws2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, j = lane & 31;
+  const int d = A.d, OTD = L2.otd, Lh = L2.n_hidden, T = A.n_steps, side = A.side, act = A.act;
+  const long long B = A.batch, N = (long long)T * B;
+  const bool direct = Lh == 1;  // G_j = W_out[j, :] itself: no S product, no second side
+
+  float* __restrict__ Dp = lds;                               // act'(z_l), l = 0 .. Lh: [Lh + 1][C][RS]
+  float* __restrict__ dS = Dp + (Lh + 1) * C * RS;             // dS_j / scratch plane [C][RS] (rows of coordinates during the mask pass: 32 OTD <= C)
+  float* __restrict__ cols = dS + C * RS;                      // [2 buffers][2][C]: col_s, col_q of the coordinate at hand (B order)
+  unsigned* __restrict__ maskw = reinterpret_cast<unsigned*>(cols + 4 * C);  // [8 coordinate tiles][32 trajectories] clip-mask bits
+  float* __restrict__ slots = reinterpret_cast<float*>(maskw + 8 * 32);       // [4][32]
+  float* __restrict__ ptab = slots + 4 * 32;                   // prior table (mu, 1/sigma^2) [2 dp]
+
+  for (int i = tid; i < 2 * L.dp; i += 256) ptab[i] = ws[L.dg[1] + i];
+  int tiles[OTW];
+#pragma unroll
+  for (int k = 0; k < OTW; ++k) tiles[k] = w + 4 * k;
+  const unsigned lane_off = (unsigned)(lane * 16);
+  const int nto = (OTD > w ? 1 : 0) + (OTD > w + 4 ? 1 : 0);
+  const bool vec4 = (d & 3) == 0;
+  // images: S = X_s Q_s, O = X Q, dQ = X^T dS
+  const float* __restrict__ img_s = side == 0 ? ws2 + L2.wt_hid + L2.w_hid_stride : ws2 + L2.w_hid;   // W_2^T | W_1
+  const float* __restrict__ img_o = ws2 + L2.w_hid;                                                      // W_1 (side 0: O = F)
+  const float* __restrict__ img_b = side == 0 ? ws2 + L2.wt_hid : ws2 + L2.w_hid + L2.w_hid_stride;     // W_1^T | W_2
+  const float* __restrict__ tab_s = side == 0 ? ws2 + L2.tan_out : ws2 + L2.tan_in;                      // col_s[j]: row j of W_out | column j of W_in
+  const float* __restrict__ tab_q = side == 0 ? ws2 + L2.tan_in : ws2 + L2.tan_out;
+  float* __restrict__ Ds = Dp + (side == 0 ? Lh : 0) * C * RS;   // D of the S product's B operand (D_Lh | D_0)
+  float* __restrict__ Dq = Dp + (side == 0 ? 0 : Lh) * C * RS;   // D_q (D_0 | D_Lh)
+  float* __restrict__ D1 = Dp + (Lh == 2 ? 1 : (side == 0 ? 1 : 0)) * C * RS;  // the middle derivative (Lh = 1: D_1 is also D_Lh)
+
+  f32x16 acc[OTW][OT];  // dX: row tiles {w, w + 4} x all column tiles
+#pragma unroll
+  for (int k = 0; k < OTW; ++k)
+#pragma unroll
+    for (int bt = 0; bt < OT; ++bt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[k][bt][q] = 0.0f;
+
+  float* __restrict__ cpart = A.cpart + (long long)blockIdx.x * d * C;
+  float* __restrict__ spart = A.spart != nullptr ? A.spart + (long long)blockIdx.x * d * C : nullptr;
+  auto bidx = [&](int ot, int q) { return (4 * ot + (q >> 2)) * 8 + (q & 1) * 4 + ((q >> 1) & 1) + 2 * h; };  // B order of channel 32 ot + rho(q, h)
+
+  const long long n_items = (long long)n_tiles * T;
+  __syncthreads();
+  for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int t = (int)(item / n_tiles), tile = (int)(item % n_tiles);
+    const long long row0 = (long long)tile * 32, r = row0 + j;
+    const bool live = r < B;
+    const long long lrow = live ? r : B - 1;
+    const long long n = (long long)t * B + lrow;
+    cfp cf = as_const(ws + L.coef + t * kCoefStride);
+    const float sig = cf[CF_SIGMA], dt = cf[CF_DT], wl = cf[CF_W];
+    const float crow = live ? A.grad_rnd[lrow] * sig * dt : 0.0f;  // c_n
+
+    // ---- act'(z_l) planes; act(z_Lh) -> scratch plane (the out layer's input) -------------------------------------------------
+    SDEH_ACT_SWITCH(act, ACT,
+      for (int l = 0; l <= Lh; ++l) {
+        _Pragma("unroll") for (int k = 0; k < OTW; ++k) {
+          f32x16 z;
+          _Pragma("unroll") for (int q = 0; q < 16; ++q) z[q] = live ? A.zt[((long long)l * C + 32 * tiles[k] + rho(q, h)) * N + n] : 0.0f;
+          _Pragma("unroll") for (int q = 0; q < 16; ++q) Dp[(l * C + 32 * tiles[k] + rho(q, h)) * RS + j] = act_grad(z[q], ACT);
+          if (l == Lh) {
+            act_tile<ACT>(z);
+            _Pragma("unroll") for (int q = 0; q < 16; ++q) dS[(32 * tiles[k] + rho(q, h)) * RS + j] = z[q];
+          }
+        }
+      });
+    if (tid < 8 * 32) maskw[tid] = 0u;
+    wide_barrier();
+    // ---- v_nn = W_out a_Lh + b_out -> clip-mask bits m_nj (torch.clamp's backward: 1 on [-m, m]) ------------------------------------
+    {
+      f32x16 vnn[2][1];
+      unsigned vo[2];
+      vo[0] = (unsigned)((w * 64 + lane) * 16);
+      vo[1] = nto > 1 ? (unsigned)(((w + 4) * 64 + lane) * 16) : vo[0];
+      const float* __restrict__ wl_out = ws2 + L2.w_out;
+      if (nto == 2) {
+        WidePre<2> pre;
+        wide_prefetch<2>(pre, wl_out, OTD * 256, C / 8, vo);
+        wide_layer<2, 1>(pre, wl_out, OTD * 256, C / 8, vo, dS + h * RS + j, RS, vnn);
+      } else {
+        WidePre<1> pre;
+        unsigned v1[1] = {nto == 1 ? vo[0] : (unsigned)(((w % OTD) * 64 + lane) * 16)};
+        wide_prefetch<1>(pre, wl_out, OTD * 256, C / 8, v1);
+        f32x16 o1[1][1];
+        wide_layer<1, 1>(pre, wl_out, OTD * 256, C / 8, v1, dS + h * RS + j, RS, o1);
+        vnn[0][0] = o1[0][0];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < nto) {
+          const f32x16 bo = load16(ws2 + L2.b_hid + Lh * C + ((w + 4 * k) * 2 + h) * 16);
+          unsigned bits = 0u;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float v = vnn[k][0][q] + bo[q];
+            if (v >= -A.clip_model && v <= A.clip_model) bits |= 1u << (4 * h + (q & 3) + 8 * (q >> 2));
+          }
+          atomicOr(&maskw[(w + 4 * k) * 32 + j], bits);
+        }
+    }
+    // ---- score part of the divergence: only gamma(t) carries parameters (side 0) ---------------------------------------------
+    if (side == 0 && A.inf_kind == SDEH_CTRL_LERP_PRIOR) {
+      const float w1 = 1.0f - wl;
+      float s = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < nto) {
+          const int cb = 32 * (w + 4 * k) + 4 * h;
+          const f32x16 x = wide_row16(A.xs + n * d, cb, d, vec4);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int cc = cb + (q & 3) + 8 * (q >> 2);
+            const float mu = ptab[2 * cc], iv = ptab[2 * cc + 1];
+            const float sc = w1 * (mu - x[q]) * iv;
+            const bool inside = sc >= -A.clip_score && sc <= A.clip_score;
+            const float gj = (inside && cc < d) ? crow * sig * A.scale_score * -(w1 * iv) : 0.0f;
+            s += gj;
+            if (L2.g != 1 && cc < d && live) A.dgam[(long long)cc * N + n] = gj;
+          }
+        }
+      s = half_sum(s);
+      if (h == 0) slots[w * 32 + j] = s;
+    }
+    // the first coordinate's columns
+    if (tid < C / 4) {
+      *reinterpret_cast<float4*>(cols + tid * 4) = *reinterpret_cast<const float4*>(tab_s + tid * 4);
+      *reinterpret_cast<float4*>(cols + C + tid * 4) = *reinterpret_cast<const float4*>(tab_q + tid * 4);
+    }
+    wide_barrier();
+    if (side == 0 && A.inf_kind == SDEH_CTRL_LERP_PRIOR && L2.g == 1 && w == 0 && h == 0 && live)
+      A.dgam[n] = ((slots[j] + slots[32 + j]) + slots[64 + j]) + slots[96 + j];
+
+    // ---- the coordinates --------------------------------------------------------------------------------------------------
+    f32x16 dDq[OTW], dD1[OTW];
+#pragma unroll
+    for (int k = 0; k < OTW; ++k)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dDq[k][q] = dD1[k][q] = 0.0f;
+    for (int jc = 0; jc < d; ++jc) {
+      const float* __restrict__ cs = cols + (jc & 1) * 2 * C;  // col_s (B order)
+      const float* __restrict__ cq = cs + C;                    // col_q
+      if (jc + 1 < d && tid < C / 4) {  // stage the next coordinate's columns into the other buffer (visible behind barrier A)
+        float* __restrict__ nx = cols + ((jc + 1) & 1) * 2 * C;
+        *reinterpret_cast<float4*>(nx + tid * 4) = *reinterpret_cast<const float4*>(tab_s + (long long)(jc + 1) * C + tid * 4);
+        *reinterpret_cast<float4*>(nx + C + tid * 4) = *reinterpret_cast<const float4*>(tab_q + (long long)(jc + 1) * C + tid * 4);
+      }
+      const float cj = ((maskw[(jc >> 5) * 32 + j] >> (jc & 31)) & 1u) ? crow : 0.0f;
+      f32x16 S[OTW], O[OTW];
+      if (!direct) wdiv_pass<OTW>(img_s, OT, tiles, C / 8, lane_off, Ds + h * RS + j, cs + 4 * h, S);
+      if (side == 0) wdiv_pass<OTW>(img_o, OT, tiles, C / 8, lane_off, Dq + h * RS + j, cq + 4 * h, O);
+#pragma unroll
+      for (int k = 0; k < OTW; ++k) {
+        float sred[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ch = 32 * tiles[k] + rho(q, h);
+          const float d1 = D1[ch * RS + j];
+          const float sv = direct ? cs[bidx(tiles[k], q)] : S[k][q];
+          if (side == 0) dD1[k][q] = fmaf(cj * O[k][q], sv, dD1[k][q]);
+          dS[ch * RS + j] = cj * d1 * sv;
+          if (direct) sred[q] = cj * d1 * O[k][q];  // Lh = 1: d L / d W_out[j, ch] = sum_traj c_j D_1 F_j
+        }
+        if (direct) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float v = sum_xor16(sum_row16(sred[q]));
+            if (j == 0) spart[(long long)jc * C + 32 * tiles[k] + rho(q, h)] += v;
+          }
+        }
+      }
+      wide_barrier();  // A: dS_j complete (and the next coordinate's columns staged)
+      // dX += dS_j Q_j^T over the 32 trajectories: lane (m, kk) reads rows transposed, trajectories 8 u + 4 kk .. + 3
+      {
+        float4 av[OTW][4];
+#pragma unroll
+        for (int k = 0; k < OTW; ++k)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) av[k][u] = *reinterpret_cast<const float4*>(dS + (32 * tiles[k] + j) * RS + 8 * u + 4 * h);
+#pragma unroll
+        for (int bt = 0; bt < OT; ++bt) {
+          const float cqv = cq[wdiv_bidx(32 * bt + j)];
+          float4 bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float4 t4 = *reinterpret_cast<const float4*>(Dq + (32 * bt + j) * RS + 8 * u + 4 * h);
+            bv[u] = float4{t4.x * cqv, t4.y * cqv, t4.z * cqv, t4.w * cqv};
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < OTW; ++k) {
+              acc[k][bt] = SDEH_MFMA(av[k][u].x, bv[u].x, acc[k][bt]);
+              acc[k][bt] = SDEH_MFMA(av[k][u].y, bv[u].y, acc[k][bt]);
+              acc[k][bt] = SDEH_MFMA(av[k][u].z, bv[u].z, acc[k][bt]);
+              acc[k][bt] = SDEH_MFMA(av[k][u].w, bv[u].w, acc[k][bt]);
+            }
+        }
+      }
+      // dQ_j = X^T dS_j;  d L / d D_q,  d L / d col_q[j]
+      {
+        f32x16 dQ[OTW];
+        wdiv_pass<OTW>(img_b, OT, tiles, C / 8, lane_off, dS + h * RS + j, nullptr, dQ);
+#pragma unroll
+        for (int k = 0; k < OTW; ++k)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int ch = 32 * tiles[k] + rho(q, h);
+            dDq[k][q] = fmaf(dQ[k][q], cq[bidx(tiles[k], q)], dDq[k][q]);
+            const float v = sum_xor16(sum_row16(dQ[k][q] * Dq[ch * RS + j]));
+            if (j == 0) cpart[(long long)jc * C + ch] += v;
+          }
+      }
+      wide_barrier();  // B: everyone is through dS_j
+    }
+
+    // ---- adjoints of the base pre-activations ------------------------------------------------------------------------------------
+    //   side 1: adj z_Lh = act''(z_Lh) dD_Lh.   side 0: adj z_1 = act''(z_1) dD_1 + act'(z_1) W_2^T adj z_2 (Lh = 2), then
+    //   adj z_0 = act''(z_0) dD_0 + act'(z_0) W_1^T adj z_1
+    auto load_z = [&](int l, int k) {
+      f32x16 z;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) z[q] = live ? A.zt[((long long)l * C + 32 * tiles[k] + rho(q, h)) * N + n] : 0.0f;
+      return z;
+    };
+    if (side == 1) {
+#pragma unroll
+      for (int k = 0; k < OTW; ++k) {
+        const f32x16 z = load_z(Lh, k);
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (live) A.d2[((long long)Lh * C + 32 * tiles[k] + rho(q, h)) * N + n] = act_grad2(z[q], act) * dDq[k][q];
+      }
+    } else {
+      f32x16 adj[OTW];
+      if (Lh == 2) {  // adj z_2 from the side-1 launch -> plane; adj a_1 = W_2^T adj z_2
+#pragma unroll
+        for (int k = 0; k < OTW; ++k)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int ch = 32 * tiles[k] + rho(q, h);
+            dS[ch * RS + j] = live ? A.d2[((long long)2 * C + ch) * N + n] : 0.0f;
+          }
+        wide_barrier();
+        wdiv_pass<OTW>(ws2 + L2.wt_hid + L2.w_hid_stride, OT, tiles, C / 8, lane_off, dS + h * RS + j, nullptr, adj);
+        wide_barrier();
+      }
+      // adj z_1
+#pragma unroll
+      for (int k = 0; k < OTW; ++k) {
+        const f32x16 z = load_z(1, k);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ch = 32 * tiles[k] + rho(q, h);
+          float v = act_grad2(z[q], act) * dD1[k][q];
+          if (Lh == 2) v = fmaf(Dp[(C + ch) * RS + j], adj[k][q], v);
+          if (live) A.d2[((long long)C + ch) * N + n] = v;
+          dS[ch * RS + j] = v;
+        }
+      }
+      wide_barrier();
+      wdiv_pass<OTW>(ws2 + L2.wt_hid, OT, tiles, C / 8, lane_off, dS + h * RS + j, nullptr, adj);  // adj a_0 = W_1^T adj z_1
+#pragma unroll
+      for (int k = 0; k < OTW; ++k) {
+        const f32x16 z = load_z(0, k);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int ch = 32 * tiles[k] + rho(q, h);
+          const float v = fmaf(Dp[ch * RS + j], adj[k][q], act_grad2(z[q], act) * dDq[k][q]);
+          if (live) A.d2[(long long)ch * N + n] = v;
+        }
+      }
+    }
+    wide_barrier();  // planes free for the next item
+  }
+
+  // ---- this workgroup's partial of dX ---------------------------------------------------------------------------------------------
+  float* __restrict__ xp = A.xpart + (long long)blockIdx.x * C * C;
+#pragma unroll
+  for (int k = 0; k < OTW; ++k)
+#pragma unroll
+    for (int bt = 0; bt < OT; ++bt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) xp[(32 * tiles[k] + rho(q, h)) * C + 32 * bt + j] = acc[k][bt][q];
+}
+
+inline size_t wide_div_lds_bytes(const WsLayout& L, const WsLayout& L2) {
+  return ((size_t)(L2.n_hidden + 2) * L2.c * kDivRS + 4 * L2.c + 8 * 32 + 4 * 32 + 2 * L.dp) * sizeof(float);
+}
+
+int wide_div_grid(long long batch, int n_steps) {
+  const long long items = ((batch + 31) / 32) * n_steps;
+  return (int)(items < 256 ? items : 256);  // persistent: one workgroup per CU (the [C, C] accumulators live for the whole launch)
+}
+
+// side 1 first (it leaves adj z_Lh in d2), then side 0.  Lh = 1: side 0 only.
+int launch_wide_div_bwd(const WideDivArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = wide_div_lds_bytes(a.lay, a.lay2);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  const int otw = a.lay2.c / 128;
+  const void* fn = otw == 2 ? reinterpret_cast<const void*>(&wide_bridge_div_bwd_kernel<2>) : reinterpret_cast<const void*>(&wide_bridge_div_bwd_kernel<1>);
+  static bool attr_done[kMaxDevices][2] = {};
+  bool& attr_set = attr_done[current_device_slot()][otw - 1];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  const int n_tiles = (int)((a.batch + 31) / 32);
+  const int grid = wide_div_grid(a.batch, a.n_steps);
+  if (otw == 2) hipLaunchKernelGGL((wide_bridge_div_bwd_kernel<2>), dim3(grid), dim3(256), lds_bytes, stream, a, n_tiles);
+  else hipLaunchKernelGGL((wide_bridge_div_bwd_kernel<1>), dim3(grid), dim3(256), lds_bytes, stream, a, n_tiles);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
 }  // namespace sdeh

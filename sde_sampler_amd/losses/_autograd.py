@@ -348,6 +348,12 @@ class _BridgeFn(torch.autograd.Function):
         pr_b = eng.build_problem(device=dev, keep=keep_b, **st["problem_kwargs"])
         Cn, Lh = pr_b.inference.base_model.channels, pr_b.inference.base_model.n_hidden
         g = dgam.shape[0]
+        if Cn != 64 or d > 64:  # wide networks: the fused divergence backward (csrc/sdeh_wide_bwd.hip)
+            if not lv:
+                raise L.SdehUnsupported(-2, "wide-network Bridge: training is built for the log-variance methods (conf/solver/bridge.yaml: "
+                                            "loss time_reversal_lv); method='kl' needs the divergence term's d/dx, which is not built in")
+            grads.update(_wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam))
+            return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
         eps = st.get("div_noise")
         if eps is not None:
             eps = eps.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -367,6 +373,41 @@ class _BridgeFn(torch.autograd.Function):
             grads = generative(cost_ctrl=gp, lam_extra=dx)
         grads.update(_weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, td=td, ta=ta, cj=cj, dgam=dgam2, eps=eps)))
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
+
+
+def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam) -> dict[int, torch.Tensor]:
+    """Gradients of the inference network of a wide Bridge: first-order planes (zt, dt, dout, dgam from sdeh_ctrl_backward_ex) + the
+    divergence term through sdeh_bridge_div_backward_wide (adjoint planes d2 of the base pre-activations, the tangent streams' direct
+    weight gradients, d / d gamma of the score part)."""
+    dev = xs.device
+    T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+    N = T * B
+    base = inf.base_model
+    Cn, Lh = base.channels, len(base.hidden_layer)
+    lib = L.load()
+    n_scratch, n_out = C.c_int64(), C.c_int64()
+    L.check(lib.sdeh_bridge_div_backward_wide_sizes(d, Cn, Lh, T, B, C.byref(n_scratch), C.byref(n_out)))
+    scratch = torch.empty(n_scratch.value, device=dev, dtype=torch.float32)
+    out = torch.empty(n_out.value, device=dev, dtype=torch.float32)
+    d2 = torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
+    dgam2 = torch.zeros_like(dgam)
+    plan = eng._plan(dev, d, Cn, max(Lh, pr_b.base_model.n_hidden), T, 0)
+    with torch.cuda.device(dev):
+        L.check(lib.sdeh_bridge_div_backward_wide(
+            plan.handle, C.byref(pr_b), keep_b.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B, w.data_ptr(), zt.data_ptr(),
+            d2.data_ptr(), dgam2.data_ptr(), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream))
+    grads = _weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, dgam=dgam2))
+    with torch.no_grad():
+        g_in = out[:d * Cn].view(d, Cn)
+        g_out = out[d * Cn:2 * d * Cn].view(d, Cn)
+        g_hid = out[2 * d * Cn:].view(Lh, Cn, Cn)
+        grads[id(base.input_embed.weight)] = grads[id(base.input_embed.weight)] + g_in.t()
+        grads[id(base.out_layer.weight)] = grads[id(base.out_layer.weight)] + g_out
+        grads[id(base.hidden_layer[0].weight)] = grads[id(base.hidden_layer[0].weight)] + g_hid[0]
+        if Lh == 2:
+            grads[id(base.hidden_layer[1].weight)] = grads[id(base.hidden_layer[1].weight)] + g_hid[1].t()
+    return grads
 
 
 def _leaves(loss, params):

@@ -96,3 +96,40 @@ def test_wide_training_with_a_mixture_target_fails_loudly():
     val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
     with pytest.raises(SdehUnsupported, match="mixture"):
         val.backward()
+
+
+def _bridge(path):
+    from sde_sampler_amd import problems
+
+    fx, meta, params, tt = load_fixture(path)
+    prob = problems.build(meta, params, tt, device=DEV, params_inf=inference_params(fx))
+    return fx, meta, prob
+
+
+@pytest.mark.parametrize("path", GOLDEN_WIDE_BRIDGE, ids=lambda p: Path(p).stem)
+def test_wide_bridge_training_gradients_match_reference(path):
+    """conf/solver/bridge.yaml's loss (time_reversal_lv) on wide networks: loss value and the parameter gradients of BOTH networks
+    against the reference's autograd (exact divergence with create_graph=True: d backward passes per step, differentiated again)."""
+    fx, meta, prob = _bridge(path)
+    prob.loss.method = "lv"
+    inf = prob.loss.inference_ctrl
+    x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
+    val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
+    ref = float(fx["train_lv/loss"])
+    assert abs(val.item() - ref) <= 2e-4 * max(1.0, abs(ref)), (val.item(), ref)
+    val.backward()
+    assert prob.loss.engine.last_kernel_name() == f"bridge_div_bwd_wide<C={meta['net']['channels']}>"
+    worst_u = _check_grads(fx, "lv", "grad", prob.ctrl)
+    worst_v = _check_grads(fx, "lv", "grad_inf", inf)
+    print(f"{Path(path).stem} lv: worst relative gradient error generative {worst_u[0]:.2e} ({worst_u[1]}), inference {worst_v[0]:.2e} ({worst_v[1]})")
+
+
+def test_wide_bridge_training_with_kl_fails_loudly():
+    from sde_sampler_amd import SdehUnsupported
+
+    fx, meta, prob = _bridge(GOLDEN_WIDE_BRIDGE[0])
+    prob.loss.method = "kl"
+    x0 = torch.from_numpy(fx["x0"]).to(DEV)
+    val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+    with pytest.raises(SdehUnsupported, match="log-variance"):
+        val.backward()

@@ -541,6 +541,18 @@ int launch_wide_bwd(const BwdArgs& a, hipStream_t stream) {
 // the chain: adj z_l = act''(z_l) dD_l + act'(z_l) W_{l+1}^T adj z_{l+1}, written as planes d2 [(Lh+1), C, N] -- the weight gradients
 // they imply are the same contraction as the first-order ones (sdeh_weight_grad adds them to the planes of sdeh_ctrl_backward_ex).
 // =========================================================================================================
+// -DSDEH_WDIV_PROFILE: per-phase cycle counts of one wave (block 0, wave 0) of the divergence backward -- a measurement build, never
+// shipped (tools/wdiv_phase_profile.sh).  0 S pass, 1 O pass, 2 elementwise + dS store, 3 barrier A, 4 dX, 5 dQ pass, 6 dQ elementwise,
+// 7 barrier B + tables, 8 coordinates counted, 9 item prologue, 10 item epilogue, 11 items
+#ifdef SDEH_WDIV_PROFILE
+__device__ unsigned long long wdiv_prof[16];
+#define WDIV_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define WDIV_ADD(k, t0, t1) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&wdiv_prof[k], (t1) - (t0)); } while (0)
+#else
+#define WDIV_T(var) do {} while (0)
+#define WDIV_ADD(k, t0, t1) do {} while (0)
+#endif
+
 constexpr int kDivRS = 36;  // row stride of the planes: conflict-free transposed ds_read_b128 (4 x odd), as in sdeh_bwdf.hip
 
 
@@ -548,25 +560,31 @@ constexpr int kDivRS = 36;  // row stride of the planes: conflict-free transpose
 __device__ __forceinline__ int wdiv_bidx(int ch) { return (ch & ~7) + (ch & 1) * 4 + ((ch & 7) >> 1); }
 
 // acc[k] = sum over NS4 k-groups of  Wp[tile tiles[k]][:] . (plane[:, traj] * col[:])   (col == nullptr: the plane alone)
-//   wgrp: packed layer (k-groups of OT tiles);  pl: plane + h * kDivRS + j;  col: B-order vector + 4 h
+//   wgrp: packed layer (k-groups of OT tiles);  pl: plane + h * kDivRS + j;  col: B-order vector + 4 h;  NS4 a multiple of 4
+// The A operands stream from L2 through a ring of four k-groups, three groups (>= 1536 cycles of this wave's MFMAs) ahead of their
+// use: with one wave per SIMD nothing else hides the L2 latency (a ring of two measured 3x the MFMA time of the whole kernel).
+constexpr int kDivPD = 3;
 template <int NT>
 __device__ __forceinline__ void wdiv_pass(const float* __restrict__ wgrp, int OT, const int (&tiles)[NT], int NS4, unsigned lane_off,
                                           const float* __restrict__ pl, const float* __restrict__ col, f32x16 (&acc)[NT]) {
-  f32x4 a[2][NT];
+  constexpr int U = kDivPD + 1;
+  f32x4 a[U][NT];
   const int grp_floats = OT * 256;
-  auto issue = [&](int S, f32x4 (&av)[NT]) {
-    const float* base = wgrp + (long long)(S < NS4 ? S : NS4 - 1) * grp_floats;
+  unsigned voff[NT];
 #pragma unroll
-    for (int k = 0; k < NT; ++k) wide_gload(av[k], lane_off + (unsigned)(tiles[k] * 1024), base);
-  };
+  for (int k = 0; k < NT; ++k) voff[k] = lane_off + (unsigned)(tiles[k] * 1024);
 #pragma unroll
   for (int k = 0; k < NT; ++k)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
-  issue(0, a[0]);
+  const int last = NS4 - 1;
+#pragma unroll
+  for (int g = 0; g < kDivPD; ++g)
+#pragma unroll
+    for (int k = 0; k < NT; ++k) wide_gload(a[g][k], voff[k], wgrp + (long long)(g < last ? g : last) * grp_floats);
   float b[2][4];
   auto loadB = [&](int S, float (&bv)[4]) {
-    const int Sc = S < NS4 ? S : NS4 - 1;
+    const int Sc = S < last ? S : last;
     const float* __restrict__ dp = pl + (8 * Sc) * kDivRS;
     bv[0] = dp[0]; bv[1] = dp[2 * kDivRS]; bv[2] = dp[4 * kDivRS]; bv[3] = dp[6 * kDivRS];
     if (col != nullptr) {
@@ -575,27 +593,37 @@ __device__ __forceinline__ void wdiv_pass(const float* __restrict__ wgrp, int OT
     }
   };
   loadB(0, b[0]);
-  for (int S = 0; S < NS4; S += 2) {
+  const float* __restrict__ wnext = wgrp + (long long)(kDivPD < last ? kDivPD : last) * grp_floats;  // group S + kDivPD of the stream
+  for (int S = 0; S < NS4; S += U) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      issue(S + u + 1, a[(u + 1) % 2]);
-      loadB(S + u + 1, b[(u + 1) % 2]);
-      wide_vmwait<NT, NT>(a[u]);  // all but the NT newest loads have landed
+    for (int u = 0; u < U; ++u) {
+      wide_vmwait<(kDivPD - 1) * NT, NT>(a[u]);  // everything older than the kDivPD - 1 newest groups has landed
       SDEH_FENCE();
-      if (S + u < NS4) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+      for (int e = 0; e < 2; ++e)
 #pragma unroll
-          for (int k = 0; k < NT; ++k) acc[k] = SDEH_MFMA(a[u][k][e], b[u][e], acc[k]);
-      }
+        for (int k = 0; k < NT; ++k) acc[k] = SDEH_MFMA(a[u][k][e], b[u % 2][e], acc[k]);
+      SDEH_FENCE();
+#pragma unroll
+      for (int k = 0; k < NT; ++k) wide_gload(a[(u + kDivPD) % U][k], voff[k], wnext);
+      wnext = S + u + kDivPD < last ? wnext + grp_floats : wnext;
+      loadB(S + u + 1, b[(u + 1) % 2]);
+      SDEH_FENCE();
+#pragma unroll
+      for (int e = 2; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) acc[k] = SDEH_MFMA(a[u][k][e], b[u % 2][e], acc[k]);
       SDEH_FENCE();
     }
   }
-  wide_vmwait<0, NT>(a[0]);  // drain the clamped re-reads issued by the last iterations
-  wide_vmwait<0, NT>(a[1]);
+  // the clamped re-reads requested by the last iterations have no consumer: they must land before their registers are reused
+#pragma unroll
+  for (int u = 0; u < U; ++u) wide_vmwait<0, NT>(a[u]);
 }
 
-template <int OTW>  // C = 128 OTW
+// LH2: two hidden layers (else one: G_j = W_out[j, :] itself -- no S product, no second side);  SIDE: which hidden layer's gradient
+// this launch accumulates (compile-time, so that the per-element loops carry no wave-uniform branches)
+template <int OTW, bool LH2, int SIDE>  // C = 128 OTW
 __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivArgs A, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int OT = 4 * OTW, C = 128 * OTW, RS = kDivRS;
@@ -606,16 +634,20 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, j = lane & 31;
-  const int d = A.d, OTD = L2.otd, Lh = L2.n_hidden, T = A.n_steps, side = A.side, act = A.act;
+  constexpr int Lh = LH2 ? 2 : 1, side = SIDE;
+  const int d = A.d, OTD = L2.otd, T = A.n_steps, act = A.act;
   const long long B = A.batch, N = (long long)T * B;
-  const bool direct = Lh == 1;  // G_j = W_out[j, :] itself: no S product, no second side
+  constexpr bool direct = !LH2;
+  static_assert(LH2 || SIDE == 0, "one hidden layer: a single launch");
 
   float* __restrict__ Dp = lds;                               // act'(z_l), l = 0 .. Lh: [Lh + 1][C][RS]
   float* __restrict__ dS = Dp + (Lh + 1) * C * RS;             // dS_j / scratch plane [C][RS] (rows of coordinates during the mask pass: 32 OTD <= C)
   float* __restrict__ cols = dS + C * RS;                      // [2 buffers][2][C]: col_s, col_q of the coordinate at hand (B order)
   unsigned* __restrict__ maskw = reinterpret_cast<unsigned*>(cols + 4 * C);  // [8 coordinate tiles][32 trajectories] clip-mask bits
   float* __restrict__ slots = reinterpret_cast<float*>(maskw + 8 * 32);       // [4][32]
-  float* __restrict__ ptab = slots + 4 * 32;                   // prior table (mu, 1/sigma^2) [2 dp]
+  float* __restrict__ stg = slots + 4 * 32;                    // [2][C]: the coordinate's d L / d col_q (and d L / d W_out row, Lh = 1) before
+                                                               // they are added to the workgroup's partial tables, coalesced
+  float* __restrict__ ptab = stg + 2 * C;                      // prior table (mu, 1/sigma^2) [2 dp]
 
   for (int i = tid; i < 2 * L.dp; i += 256) ptab[i] = ws[L.dg[1] + i];
   int tiles[OTW];
@@ -657,6 +689,7 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
     cfp cf = as_const(ws + L.coef + t * kCoefStride);
     const float sig = cf[CF_SIGMA], dt = cf[CF_DT], wl = cf[CF_W];
     const float crow = live ? A.grad_rnd[lrow] * sig * dt : 0.0f;  // c_n
+    WDIV_T(ti0);
 
     // ---- act'(z_l) planes; act(z_Lh) -> scratch plane (the out layer's input) -------------------------------------------------
     SDEH_ACT_SWITCH(act, ACT,
@@ -743,7 +776,10 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
     for (int k = 0; k < OTW; ++k)
 #pragma unroll
       for (int q = 0; q < 16; ++q) dDq[k][q] = dD1[k][q] = 0.0f;
+    WDIV_T(ti1);
+    WDIV_ADD(9, ti0, ti1);
     for (int jc = 0; jc < d; ++jc) {
+      WDIV_T(tc0);
       const float* __restrict__ cs = cols + (jc & 1) * 2 * C;  // col_s (B order)
       const float* __restrict__ cq = cs + C;                    // col_q
       if (jc + 1 < d && tid < C / 4) {  // stage the next coordinate's columns into the other buffer (visible behind barrier A)
@@ -751,31 +787,54 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
         *reinterpret_cast<float4*>(nx + tid * 4) = *reinterpret_cast<const float4*>(tab_s + (long long)(jc + 1) * C + tid * 4);
         *reinterpret_cast<float4*>(nx + C + tid * 4) = *reinterpret_cast<const float4*>(tab_q + (long long)(jc + 1) * C + tid * 4);
       }
+      // this coordinate's rows of the partial tables: requested now, added to behind barrier B (one coalesced read-modify-write per
+      // thread instead of 32 dependent scattered ones per wave)
+      float old_c = 0.0f, old_s = 0.0f;
+      if (tid < C) {
+        old_c = cpart[(long long)jc * C + tid];
+        if constexpr (direct) old_s = spart[(long long)jc * C + tid];
+      }
       const float cj = ((maskw[(jc >> 5) * 32 + j] >> (jc & 31)) & 1u) ? crow : 0.0f;
       f32x16 S[OTW], O[OTW];
-      if (!direct) wdiv_pass<OTW>(img_s, OT, tiles, C / 8, lane_off, Ds + h * RS + j, cs + 4 * h, S);
-      if (side == 0) wdiv_pass<OTW>(img_o, OT, tiles, C / 8, lane_off, Dq + h * RS + j, cq + 4 * h, O);
+      if constexpr (!direct) wdiv_pass<OTW>(img_s, OT, tiles, C / 8, lane_off, Ds + h * RS + j, cs + 4 * h, S);
+      SDEH_FENCE();
+      WDIV_T(tc1);
+      if constexpr (side == 0) wdiv_pass<OTW>(img_o, OT, tiles, C / 8, lane_off, Dq + h * RS + j, cq + 4 * h, O);
+      SDEH_FENCE();
+      WDIV_T(tc2);
+      // Element (k, q) of this lane = channel 32 (w + 4 k) + rrow(q) + 4 h: every LDS address below is ONE per-lane base plus a
+      // compile-time offset (the DS instructions' immediate).  The bases are made opaque per coordinate: hipcc otherwise precomputes
+      // one address register per element and array -- ~600 loop invariants that live in scratch and come back one dependent
+      // scratch_load at a time (measured: 40 k cycles per coordinate for this block, 2.4 x its matrix work).
+      int e_rs = (32 * w + 4 * h) * RS + j, e_b = 32 * w + 2 * h, e_ch = 32 * w + 4 * h;
+      asm volatile("" : "+v"(e_rs), "+v"(e_b), "+v"(e_ch));
+      {
+        const float* __restrict__ d1e = D1 + e_rs;
+        float* __restrict__ dse = dS + e_rs;
+        const float* __restrict__ cse = cs + e_b;
+        float* __restrict__ stge = stg + C + e_ch;
 #pragma unroll
-      for (int k = 0; k < OTW; ++k) {
-        float sred[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const int ch = 32 * tiles[k] + rho(q, h);
-          const float d1 = D1[ch * RS + j];
-          const float sv = direct ? cs[bidx(tiles[k], q)] : S[k][q];
-          if (side == 0) dD1[k][q] = fmaf(cj * O[k][q], sv, dD1[k][q]);
-          dS[ch * RS + j] = cj * d1 * sv;
-          if (direct) sred[q] = cj * d1 * O[k][q];  // Lh = 1: d L / d W_out[j, ch] = sum_traj c_j D_1 F_j
-        }
-        if (direct) {
+        for (int k = 0; k < OTW; ++k)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const float v = sum_xor16(sum_row16(sred[q]));
-            if (j == 0) spart[(long long)jc * C + 32 * tiles[k] + rho(q, h)] += v;
+            constexpr int dummy = 0; (void)dummy;
+            const int orow = (128 * k + (q & 3) + 8 * (q >> 2)) * RS;
+            const int ob = 128 * k + (q >> 2) * 8 + (q & 1) * 4 + ((q >> 1) & 1);
+            const float d1 = d1e[orow];
+            float sv;
+            if constexpr (direct) sv = cse[ob];
+            else sv = S[k][q];
+            if constexpr (side == 0) dD1[k][q] = fmaf(cj * O[k][q], sv, dD1[k][q]);
+            dse[orow] = cj * d1 * sv;
+            if constexpr (direct) {  // one hidden layer: d L / d W_out[j, ch] = sum_traj c_j D_1 F_j
+              const float v = sum_xor16(sum_row16(cj * d1 * O[k][q]));
+              if (j == 0) stge[128 * k + (q & 3) + 8 * (q >> 2)] = v;
+            }
           }
-        }
       }
+      WDIV_T(tc3);
       wide_barrier();  // A: dS_j complete (and the next coordinate's columns staged)
+      WDIV_T(tc4);
       // dX += dS_j Q_j^T over the 32 trajectories: lane (m, kk) reads rows transposed, trajectories 8 u + 4 kk .. + 3
       {
         float4 av[OTW][4];
@@ -785,6 +844,7 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
           for (int u = 0; u < 4; ++u) av[k][u] = *reinterpret_cast<const float4*>(dS + (32 * tiles[k] + j) * RS + 8 * u + 4 * h);
 #pragma unroll
         for (int bt = 0; bt < OT; ++bt) {
+          SDEH_FENCE();  // one column tile's operands at a time (hoisted, the eight tiles' reads are 128 live registers)
           const float cqv = cq[wdiv_bidx(32 * bt + j)];
           float4 bv[4];
 #pragma unroll
@@ -804,25 +864,46 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
         }
       }
       // dQ_j = X^T dS_j;  d L / d D_q,  d L / d col_q[j]
+      WDIV_T(tc5);
       {
         f32x16 dQ[OTW];
+        SDEH_FENCE();
         wdiv_pass<OTW>(img_b, OT, tiles, C / 8, lane_off, dS + h * RS + j, nullptr, dQ);
+        SDEH_FENCE();
+        WDIV_T(tc6);
+        WDIV_ADD(5, tc5, tc6);
+        int f_rs = (32 * w + 4 * h) * RS + j, f_b = 32 * w + 2 * h, f_ch = 32 * w + 4 * h;
+        asm volatile("" : "+v"(f_rs), "+v"(f_b), "+v"(f_ch));
+        const float* __restrict__ dqe = Dq + f_rs;
+        const float* __restrict__ cqe = cq + f_b;
+        float* __restrict__ stgq = stg + f_ch;
 #pragma unroll
         for (int k = 0; k < OTW; ++k)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const int ch = 32 * tiles[k] + rho(q, h);
-            dDq[k][q] = fmaf(dQ[k][q], cq[bidx(tiles[k], q)], dDq[k][q]);
-            const float v = sum_xor16(sum_row16(dQ[k][q] * Dq[ch * RS + j]));
-            if (j == 0) cpart[(long long)jc * C + ch] += v;
+            if ((q & 3) == 0) SDEH_FENCE();
+            const int orow = (128 * k + (q & 3) + 8 * (q >> 2)) * RS;
+            const int ob = 128 * k + (q >> 2) * 8 + (q & 1) * 4 + ((q >> 1) & 1);
+            dDq[k][q] = fmaf(dQ[k][q], cqe[ob], dDq[k][q]);
+            const float v = sum_xor16(sum_row16(dQ[k][q] * dqe[orow]));
+            if (j == 0) stgq[128 * k + (q & 3) + 8 * (q >> 2)] = v;
           }
       }
-      wide_barrier();  // B: everyone is through dS_j
+      WDIV_T(tc7);
+      wide_barrier();  // B: everyone is through dS_j; the staged sums are complete
+      if (tid < C) {
+        cpart[(long long)jc * C + tid] = old_c + stg[tid];
+        if constexpr (direct) spart[(long long)jc * C + tid] = old_s + stg[C + tid];
+      }
+      WDIV_T(tc8);
+      WDIV_ADD(0, tc0, tc1); WDIV_ADD(1, tc1, tc2); WDIV_ADD(2, tc2, tc3); WDIV_ADD(3, tc3, tc4); WDIV_ADD(4, tc4, tc5);
+      WDIV_ADD(6, tc5, tc7); WDIV_ADD(7, tc7, tc8); WDIV_ADD(8, 0ull, 1ull);
     }
 
     // ---- adjoints of the base pre-activations ------------------------------------------------------------------------------------
     //   side 1: adj z_Lh = act''(z_Lh) dD_Lh.   side 0: adj z_1 = act''(z_1) dD_1 + act'(z_1) W_2^T adj z_2 (Lh = 2), then
     //   adj z_0 = act''(z_0) dD_0 + act'(z_0) W_1^T adj z_1
+    WDIV_T(te0);
     auto load_z = [&](int l, int k) {
       f32x16 z;
 #pragma unroll
@@ -878,6 +959,8 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
       }
     }
     wide_barrier();  // planes free for the next item
+    WDIV_T(te1);
+    WDIV_ADD(10, te0, te1); WDIV_ADD(11, 0ull, 1ull);
   }
 
   // ---- this workgroup's partial of dX ---------------------------------------------------------------------------------------------
@@ -891,7 +974,7 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
 }
 
 inline size_t wide_div_lds_bytes(const WsLayout& L, const WsLayout& L2) {
-  return ((size_t)(L2.n_hidden + 2) * L2.c * kDivRS + 4 * L2.c + 8 * 32 + 4 * 32 + 2 * L.dp) * sizeof(float);
+  return ((size_t)(L2.n_hidden + 2) * L2.c * kDivRS + 6 * L2.c + 8 * 32 + 4 * 32 + 2 * L.dp) * sizeof(float);
 }
 
 int wide_div_grid(long long batch, int n_steps) {
@@ -900,21 +983,52 @@ int wide_div_grid(long long batch, int n_steps) {
 }
 
 // side 1 first (it leaves adj z_Lh in d2), then side 0.  Lh = 1: side 0 only.
+#ifdef SDEH_WDIV_PROFILE
+static void wdiv_prof_dump(hipStream_t stream, int side) {
+  (void)hipStreamSynchronize(stream);
+  unsigned long long v[16];
+  (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(wdiv_prof), sizeof(v));
+  const double n = v[8] ? (double)v[8] : 1.0, ni = v[11] ? (double)v[11] : 1.0;
+  fprintf(stderr, "wdiv side %d (cycles per coordinate of block 0 / wave 0, %llu coordinates): S %.0f | O %.0f | elementwise %.0f | barrier A %.0f | "
+          "dX %.0f | dQ pass %.0f | dQ pass + elementwise %.0f | barrier B + tables %.0f || per item (%llu): prologue %.0f epilogue %.0f\n",
+          side, v[8], v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5] / n, v[6] / n, v[7] / n, v[11], v[9] / ni, v[10] / ni);
+  unsigned long long z[16] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(wdiv_prof), z, sizeof(z));
+}
+#endif
+
 int launch_wide_div_bwd(const WideDivArgs& a, hipStream_t stream) {
+#ifdef SDEH_WDIV_PROFILE
+  struct Dump { hipStream_t s; int side; ~Dump() { wdiv_prof_dump(s, side); } } dump{stream, a.side};
+#endif
   const size_t lds_bytes = wide_div_lds_bytes(a.lay, a.lay2);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
-  const int otw = a.lay2.c / 128;
-  const void* fn = otw == 2 ? reinterpret_cast<const void*>(&wide_bridge_div_bwd_kernel<2>) : reinterpret_cast<const void*>(&wide_bridge_div_bwd_kernel<1>);
-  static bool attr_done[kMaxDevices][2] = {};
-  bool& attr_set = attr_done[current_device_slot()][otw - 1];
-  if (!attr_set) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return SDEH_ERR_HIP;
-    attr_set = true;
-  }
+  const int otw = a.lay2.c / 128, lh = a.lay2.n_hidden;
+  if ((otw != 1 && otw != 2) || (lh != 1 && lh != 2) || (lh == 1 && a.side != 0)) return SDEH_ERR_UNSUPPORTED;
   const int n_tiles = (int)((a.batch + 31) / 32);
   const int grid = wide_div_grid(a.batch, a.n_steps);
-  if (otw == 2) hipLaunchKernelGGL((wide_bridge_div_bwd_kernel<2>), dim3(grid), dim3(256), lds_bytes, stream, a, n_tiles);
-  else hipLaunchKernelGGL((wide_bridge_div_bwd_kernel<1>), dim3(grid), dim3(256), lds_bytes, stream, a, n_tiles);
+  const int variant = (otw - 1) * 3 + (lh == 1 ? 2 : a.side);
+  static bool attr_done[kMaxDevices][6] = {};
+  bool& attr_set = attr_done[current_device_slot()][variant];
+#define SDEH_WDIV_LAUNCH(OTW_, LH2_, SIDE_)                                                                                        \
+  do {                                                                                                                             \
+    if (!attr_set) {                                                                                                               \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wide_bridge_div_bwd_kernel<OTW_, LH2_, SIDE_>),                       \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)                               \
+        return SDEH_ERR_HIP;                                                                                                       \
+      attr_set = true;                                                                                                             \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((wide_bridge_div_bwd_kernel<OTW_, LH2_, SIDE_>), dim3(grid), dim3(256), lds_bytes, stream, a, n_tiles);     \
+  } while (0)
+  switch (variant) {
+    case 0: SDEH_WDIV_LAUNCH(1, true, 0); break;
+    case 1: SDEH_WDIV_LAUNCH(1, true, 1); break;
+    case 2: SDEH_WDIV_LAUNCH(1, false, 0); break;
+    case 3: SDEH_WDIV_LAUNCH(2, true, 0); break;
+    case 4: SDEH_WDIV_LAUNCH(2, true, 1); break;
+    default: SDEH_WDIV_LAUNCH(2, false, 0); break;
+  }
+#undef SDEH_WDIV_LAUNCH
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

@@ -205,9 +205,12 @@ def _time_embed_grads(te, act_id: int, steps: torch.Tensor, table_grad: torch.Te
     work = torch.empty(lib.sdeh_time_embed_workspace_floats(C.byref(st), steps.numel()), device=dev, dtype=torch.float32)
     table_grad = table_grad.contiguous().float()
     with torch.cuda.device(dev):
-        L.check(lib.sdeh_time_embed_backward(C.byref(st), act_id, keep.ptr(steps, dev, "ts"), steps.numel(), table_grad.data_ptr(),
-                                             float("inf") if clip is None else float(clip), work.data_ptr(), flat.data_ptr(),
-                                             torch.cuda.current_stream(dev).cuda_stream))
+        status = lib.sdeh_time_embed_backward(C.byref(st), act_id, keep.ptr(steps, dev, "ts"), steps.numel(), table_grad.data_ptr(),
+                                              float("inf") if clip is None else float(clip), work.data_ptr(), flat.data_ptr(),
+                                              torch.cuda.current_stream(dev).cuda_stream)
+    if status == -2:  # a shape the kernel does not stage in LDS (e.g. a per-coordinate gamma(t) with dim_out > 64): autograd on the table
+        return None
+    L.check(status)
     # flat layout (include/sdeh.h): phase | (weight, bias) per hidden layer | out_layer weight, bias
     out: dict[int, torch.Tensor] = {}
     pos = 0

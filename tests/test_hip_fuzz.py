@@ -184,9 +184,10 @@ def test_random_training_gradients_match_oracle(case):
     check_training_case(case)
 
 
-def check_training_case(case, num_layers=None, expect_kernel=None):
+def check_training_case(case, num_layers=None, expect_kernel=None, spec_hook=None):
     """One random training problem against the oracle's autograd.  `num_layers`: force the network depth (4 = the depth the fused
-    backward kernel is compiled for); `expect_kernel`: prefix the backward kernel's name must have."""
+    backward kernel is compiled for); `expect_kernel`: prefix the backward kernel's name must have; `spec_hook(spec, rng)`: reshape
+    the random problem (the wide-network sweep of tests/test_hip_wide_train.py)."""
     from sde_sampler_amd import problems
 
     rng = np.random.default_rng(5000 + case)
@@ -197,6 +198,8 @@ def check_training_case(case, num_layers=None, expect_kernel=None):
     spec["loss"]["method"] = method
     spec["loss"]["max_rnd"] = 1e8 if method == "lv" else None
     spec["batch"] = int(rng.choice([33, 64, 100]))  # at least two rows for the variance
+    if spec_hook is not None:
+        spec_hook(spec, rng)
     prob = problems.build(spec)
     params = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in prob.ctrl.state_dict().items()}
     tt = None
@@ -231,7 +234,7 @@ def check_training_case(case, num_layers=None, expect_kernel=None):
         if expect_kernel is not None and not kernel.startswith("traj_legacy"):  # (legacy forward: mixture tables beyond LDS, plane path)
             assert kernel.startswith(expect_kernel), kernel
     except SdehUnsupported as exc:  # a documented limit, e.g. a wide mixture next to the transposed weights in LDS
-        if "do not fit in LDS" in str(exc):
+        if "do not fit in LDS" in str(exc) or "wide-network training: mixture targets" in str(exc):
             pytest.skip(str(exc)[:120])
         raise
     tag = f"case {case}: {method} {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"

@@ -133,3 +133,71 @@ def test_wide_bridge_training_with_kl_fails_loudly():
     val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
     with pytest.raises(SdehUnsupported, match="log-variance"):
         val.backward()
+
+
+def _widen_train(spec, rng):
+    from tests.test_hip_wide import _widen
+
+    _widen(spec, rng)
+    spec["batch"] = int(rng.choice([33, 40, 64, 100]))  # at least two rows for the variance
+
+
+@pytest.mark.parametrize("case", range(24 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))
+def test_random_wide_training_gradients_match_oracle(case):
+    """Seeded random training problems (loss x method x control x SDE x target x clip activity x depth x ragged batch) on WIDE networks:
+    loss value and every parameter gradient against the oracle's autograd on identical noise, with the conditioning-aware criteria of
+    tests/test_hip_fuzz.py (mixture targets are a documented limit of the wide backward and are skipped)."""
+    from tests.test_hip_fuzz import check_training_case
+
+    check_training_case(11000 + case, spec_hook=_widen_train, expect_kernel="bwd_wide")
+
+
+@pytest.mark.parametrize("case", range(8 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))
+def test_random_wide_bridge_training_matches_oracle(case):
+    """Random Bridges on wide networks, method lv: loss and the gradients of BOTH networks against the oracle's autograd through the
+    exact divergence (d backward passes per step, create_graph=True)."""
+    import math
+
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
+    from tests.test_hip_fuzz import _close, _grad_tol
+    from tests.test_hip_wide import _random_wide_bridge_spec
+
+    rng = np.random.default_rng(13000 + case)
+    spec = _random_wide_bridge_spec(rng)
+    if spec["inference_net"]["num_layers"] == 2:  # no hidden layer: the divergence gradient is built for one or two
+        spec["inference_net"]["num_layers"] = 3
+    spec["loss"].update(method="lv", max_rnd=1e8)
+    spec["batch"] = int(rng.choice([33, 40]))
+    prob = problems.build(spec)
+    inf = prob.loss.inference_ctrl
+    leaf = lambda sd: {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    params, params_inf = leaf(prob.ctrl.state_dict()), leaf(inf.state_dict())
+    oracle = eo.Problem(spec, params, None, params_inf=params_inf)
+    ts = prob.ts.clone()
+    B, d, T = spec["batch"], spec["target"]["dim"], ts.numel() - 1
+    torch.manual_seed(case)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(T, B, d)
+    torch.set_num_threads(4)
+    ref_loss, _, _, _ = oracle.train_loss(ts, x0.clone(), noise, method="lv")
+    if not math.isfinite(ref_loss.item()) or abs(ref_loss.item()) > 1e12:
+        pytest.skip("a random configuration that blows up in the reference itself")
+    ref_loss.backward()
+    prob.to(DEV)
+    val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
+    val.backward()
+    tag = (f"case {case}: wide bridge lv {spec['ctrl']['kind']} + {spec['inference_ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T} "
+           f"{spec['net']} inf {spec['inference_net']}")
+    assert prob.loss.engine.last_kernel_name().startswith("bridge_div_bwd_wide"), tag
+    assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item()))), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    for mod, ref, net in ((prob.ctrl, params, spec["net"]), (inf, params_inf, spec["inference_net"])):
+        gmax = max((torch.nan_to_num(p.grad).abs().max().item() for p in ref.values() if p.grad is not None), default=0.0)
+        for k, p in mod.named_parameters():
+            g_ref = ref[k].grad
+            if g_ref is None or not torch.isfinite(g_ref).all():
+                continue
+            g = p.grad.cpu() if p.grad is not None else torch.zeros_like(g_ref)
+            denom = max(g_ref.abs().max().item(), 1e-4 * gmax, 1e-12)
+            err = (g - g_ref).abs().max().item() / denom
+            assert err <= _grad_tol(net, k), f"{tag}: grad {k} rel err {err:.2e}"

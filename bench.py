@@ -53,7 +53,16 @@ WORKLOADS = {
                           "one training step per bench step"),
     "train_gmm50_pis_kl": ("cfg3_gmm50_pis_kl", "trajectory-steps/sec of one optimisation step (forward + backward + Adam), PIS kl, GMM-40 d=50",
                            "BASELINE configs[2]'s shape: GMM-40 d=50, basic_pis, loss.method=kl, T=200, one training step per bench step"),
+    # training on the wide networks (csrc/sdeh_wide_bwd.hip): configs[4]'s shape as the reference trains it (conf/solver/bridge.yaml:
+    # two FourierMLP C=256, loss time_reversal_lv, exact divergence) at its per-GPU batch, and a plain PIS-style network of that width
+    "train_cfg5_like": ("cfg5_like_bridge196", "trajectory-steps/sec of one optimisation step (forward + backward + Adam), Bridge lv, d=196 C=256",
+                        "BASELINE configs[4]'s shape: Bridge (LerpTargetCtrl + LerpPriorCtrl, exact divergence) on a funnel d=196 in place "
+                        "of the NICE flow, two FourierMLP C=256 L=4 GELU, loss.method=lv, T=200, batch 4096 per GPU (32 768 / 8)"),
+    "train_wide_pis_lv": ("wide_pis_funnel196", "trajectory-steps/sec of one optimisation step (forward + backward + Adam), PIS lv, d=196 C=256",
+                          "funnel d=196, basic_pis-style, FourierMLP C=256 L=4 GELU, loss.method=lv, T=200, batch 8192"),
 }
+#: default batch / loss method of the wide training workloads (the others: 65 536 and the spec's method)
+TRAIN_DEFAULTS = {"train_cfg5_like": (4096, "lv"), "train_wide_pis_lv": (8192, "lv")}
 
 
 #: the translation-unit sources of the headline trajectory kernel: `profiles/pmc_headline.json` is stamped with their hash, and its
@@ -116,14 +125,20 @@ def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | No
     params, tt, params_inf = prob_cpu_state
     if train_method is not None:  # the training workloads: the oracle's loss + autograd backward on a bounded sample
         threads = min(8, physical_cores())
-        leaves = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in params.items()}
-        oracle = eo.Problem(spec, leaves, tt)
+        leaf = lambda sd: {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+        leaves = leaf(params)
+        leaves_inf = leaf(params_inf) if params_inf is not None else None
+        oracle = eo.Problem(spec, leaves, tt, params_inf=leaves_inf)
         ts = oracle.grid()
-        T, d, rows, rates = ts.numel() - 1, spec["target"]["dim"], 256, []
+        bridge = bool(spec.get("inference_ctrl"))
+        if bridge:  # d backward passes per step, differentiated again: the first 4 intervals of the grid, 32 rows
+            ts = ts[:5]
+        wide = spec["net"]["channels"] > 64
+        T, d, rows, rates = ts.numel() - 1, spec["target"]["dim"], (32 if bridge else (64 if wide else 256)), []
         torch.set_num_threads(threads)
         for _ in range(4):
             x0c = torch.zeros(rows, d) if spec["prior"]["kind"] == "delta" else torch.randn(rows, d)
-            for v in leaves.values():
+            for v in list(leaves.values()) + (list(leaves_inf.values()) if leaves_inf else []):
                 v.grad = None
             t0 = time.perf_counter()
             l_ref, _, _, _ = oracle.train_loss(ts, x0c, None, method=train_method)
@@ -310,29 +325,36 @@ def log_z_block(spec, device, B: int, rank: int, world: int) -> dict | None:
 
 
 def run_train(args, device):
-    """Training workloads (single GPU): a bench step = loss(...) forward, backward (fused kernel), Adam.  Roofline: the backward
-    kernel, 2 x (4dC + 2 Lh C^2) algorithmic FLOPs per trajectory-step; cpu_baseline: the oracle's loss + autograd backward on a
-    bounded sample."""
+    """Training workloads (single GPU): a bench step = loss(...) forward, backward, Adam.  Roofline: the dominant backward kernel
+    (the fused backward for 64 channels; the chain kernel or the Bridge's divergence backward for the wide networks) with its
+    algorithmic FLOPs; `backward_ms` = the whole backward between HIP events on the launch stream.  cpu_baseline: the oracle's loss +
+    autograd backward on a bounded sample."""
     from sde_sampler_amd import problems
 
     spec_name, metric, description = WORKLOADS[args.workload]
     spec = problems.baseline_spec(spec_name)
-    spec["batch"] = args.batch or 65536
+    batch_default, method_default = TRAIN_DEFAULTS.get(args.workload, (65536, None))
+    spec["batch"] = args.batch or batch_default
+    if method_default is not None:
+        spec["loss"]["method"] = method_default
     if args.em_steps:
         spec["grid"]["steps"] = args.em_steps
     prob = problems.build(spec)
+    inf = getattr(prob.loss, "inference_ctrl", None)
     params_cpu = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
+    params_inf_cpu = {k: v.detach().clone() for k, v in inf.state_dict().items()} if inf is not None else None
     tt = (dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
           if spec["target"]["kind"] == "gmm" else None)
     prob.to(device)
     B, T, d = spec["batch"], prob.ts.numel() - 1, spec["target"]["dim"]
     c, lh = spec["net"]["channels"], spec["net"]["num_layers"] - 2
     method = spec["loss"]["method"]
-    opt = torch.optim.Adam(prob.ctrl.parameters(), lr=1e-4)
+    trainable = list(prob.ctrl.parameters()) + (list(inf.parameters()) if inf is not None else [])
+    opt = torch.optim.Adam(trainable, lr=1e-4)
     eng = prob.loss.engine
     eng.timing = True
     torch.manual_seed(1)
-    fwd_ms, bwd_ms = [], []
+    fwd_ms, bwd_ms, bwd_total_ms = [], [], []
 
     def step(record):
         x0 = prob.prior.sample((B,))
@@ -340,9 +362,14 @@ def run_train(args, device):
         loss, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
         if record:
             fwd_ms.append(eng.last_kernel_ms())  # (waits for the forward kernel: the reference's step synchronises on loss.item() too)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         loss.backward()
         if record:
+            e1.record()
             bwd_ms.append(eng.last_kernel_ms())
+            e1.synchronize()
+            bwd_total_ms.append(e0.elapsed_time(e1))
         opt.step()
         return loss
 
@@ -354,22 +381,43 @@ def run_train(args, device):
         loss = step(True)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    k_ms = sum(bwd_ms) / len(bwd_ms)
-    flops_b = 2 * (4 * d * c + 2 * lh * c * c)
-    achieved = flops_b * B * T / (k_ms * 1e-3) / 1e12
+    k_ms = statistics.median(bwd_ms)
+    kernel = eng.last_kernel_name()
+    f_net = 4 * d * c + 2 * lh * c * c
+    if kernel.startswith("bridge_div_bwd_wide"):
+        ci, lhi = spec.get("inference_net", spec["net"])["channels"], spec.get("inference_net", spec["net"])["num_layers"] - 2
+        n_prod = 4 if lhi == 2 else 2  # [C, C] products per (row, coordinate) the gradient itself needs (two weight-gradient
+        flops_k = n_prod * 2 * d * ci * ci  # accumulations + two adjoint products); the kernel also recomputes F_j, G_j (+ F_j once more)
+        flops_exec = (7 if lhi == 2 else 3) * 2 * d * ci * ci
+        flops_total = 2 * f_net + 2 * (4 * d * ci + 2 * lhi * ci * ci) + flops_k
+        note = ("dominant kernel = the Bridge's divergence backward (csrc/sdeh_wide_bwd.hip, two launches: one hidden layer's [C, C] "
+                "gradient resident per launch); algorithmic FLOPs per trajectory-step: d x 4 products of 2 C^2 (weight-gradient "
+                "accumulations of both hidden layers + the two adjoint products); executed: 7 products (F_j, G_j recomputed, F_j twice)")
+    elif kernel.startswith("bwd_wide"):
+        flops_k, flops_exec, flops_total = f_net, 2 * f_net, 2 * f_net
+        note = ("dominant kernel = the wide chain kernel (csrc/sdeh_wide_bwd.hip): algorithmic FLOPs = the adjoint chain (4dC + 2 Lh C^2); it "
+                "also re-evaluates the network (executed: twice that); the weight gradients are sdeh_weight_grad's (counted in "
+                "`backward_algorithmic_tflops` over the whole backward)")
+    else:
+        flops_k = flops_exec = flops_total = 2 * f_net
+        note = ("dominant kernel = the fused backward (csrc/sdeh_bwdf.hip); algorithmic FLOPs: adjoint chain + weight "
+                "gradients = 2 x (4dC + 2 Lh C^2); the kernel also re-evaluates the network (a third on top, not counted)")
+    achieved = flops_k * B * T / (k_ms * 1e-3) / 1e12
+    b_ms = statistics.median(bwd_total_ms)
     out = {"metric": metric, "value": B * T * args.steps / elapsed, "unit": "trajectory-steps/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"{args.workload}: {description}", "batch_per_gpu": B, "global_batch": B, "em_steps": T, "dim": d,
                       "channels": c, "method": method, "noise": "in-kernel Philox4x32-10 + Box-Muller (replayed by the backward)"},
            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
-                        "traffic": None, "kernel": eng.last_kernel_name(), "kernel_ms": k_ms, "forward_kernel_ms": sum(fwd_ms) / len(fwd_ms),
-                        "flops_per_traj_step": flops_b,
-                        "note": "dominant kernel = the fused backward (csrc/sdeh_bwdf.hip); algorithmic FLOPs: adjoint chain + weight "
-                                "gradients = 2 x (4dC + 2 Lh C^2); the kernel also re-evaluates the network (a third on top, not counted)"},
+                        "traffic": None, "kernel": kernel, "kernel_ms": k_ms, "forward_kernel_ms": statistics.median(fwd_ms),
+                        "flops_per_traj_step": flops_k, "executed_tflops": flops_exec * B * T / (k_ms * 1e-3) / 1e12,
+                        "frac_executed": flops_exec * B * T / (k_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                        "backward_ms": b_ms, "backward_algorithmic_tflops": flops_total * B * T / (b_ms * 1e-3) / 1e12,
+                        "backward_frac": flops_total * B * T / (b_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "note": note},
            "final_loss": float(loss)}
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(spec, (params_cpu, tt, None), train_method=method)
+        out["cpu_baseline"] = cpu_baseline(spec, (params_cpu, tt, params_inf_cpu), train_method=method)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
 
@@ -538,12 +586,12 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="testing aid: all ranks use cuda:0 (with --backend gloo) to exercise the N > 1 path on one GPU")
     args = ap.parse_args()
-    heavy = args.workload in ("wide_pis_funnel196", "cfg5_like_bridge196")
+    heavy = args.workload in ("wide_pis_funnel196", "cfg5_like_bridge196", "train_cfg5_like")
     train = args.workload.startswith("train_")
     if args.steps is None:
-        args.steps = 5 if heavy else (100 if train else 1000)
+        args.steps = (3 if args.workload == "train_cfg5_like" else 5) if heavy else ((20 if args.workload == "train_wide_pis_lv" else 100) if train else 1000)
     if args.warmup is None:
-        args.warmup = 2 if heavy else (5 if train else 20)
+        args.warmup = (1 if args.workload == "train_cfg5_like" else 2) if heavy else (5 if train else 20)
     if train:
         if args.gpus != 1 or os.environ.get("WORLD_SIZE") not in (None, "1"):
             raise SystemExit("the training workloads are single-GPU measurements (data-parallel training: tests/test_distributed_gloo.py)")

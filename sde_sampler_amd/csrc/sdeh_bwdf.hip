@@ -264,13 +264,29 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   };
   auto item_live = [&](int t_i, int tile_i) { return BPTT ? tile_i < n_tiles : t_i < T; };
   // x of the step that comes next -- also across items: in the row-parallel mode an item is a single step
-  auto load_x = [&](int t, int tile_i) {
+  // 16 coordinates (cb + rrow(q)) of column `col` of a coordinate-major plane [d][B] whose start is WAVE-UNIFORM: one scalar base +
+  // a 32-bit byte offset per element (global_load saddr form), the lane's part of it made opaque per call.  Written with 64-bit
+  // element addresses (plane[(cb + rrow(q)) * B + col]) hipcc keeps one loop-invariant address PAIR per element and plane alive
+  // across the step loop -- they spill, and come back as ~35 dependent scratch reloads per step, each behind its own vmcnt(0).
+  // Coordinates >= d read a valid element (clamped) and are zeroed by a select: no branches.
+  const unsigned Bu = (unsigned)B;
+  auto load_cm16 = [&](const float* __restrict__ plane_u, unsigned col) {
     f32x16 v;
-    const long long rw = (long long)tile_i * 32 + j;
-    const float* __restrict__ plane = A.xs + (long long)t * d * B + (rw < B ? rw : B - 1);
+    unsigned lane_off = ((unsigned)(cb < d ? cb : 0) * Bu + col) * 4u;
+    asm volatile("" : "+v"(lane_off));
+    const char* __restrict__ pb = reinterpret_cast<const char*>(plane_u);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cb + rrow(q) < d ? plane[(long long)(cb + rrow(q)) * B] : 0.0f;
+    for (int q = 0; q < 16; ++q) {
+      const bool ok = cb + rrow(q) < d;
+      const unsigned off = ok ? lane_off + (unsigned)rrow(q) * Bu * 4u : lane_off;
+      const float val = *reinterpret_cast<const float*>(pb + off);
+      v[q] = ok ? val : 0.0f;
+    }
     return v;
+  };
+  auto load_x = [&](int t, int tile_i) {
+    const long long rw = (long long)tile_i * 32 + j;
+    return load_cm16(A.xs + (long long)t * d * B, (unsigned)(rw < B ? rw : B - 1));
   };
   auto clamp_item = [&](int& t_io, int& tile_io) {  // a team without an item shadows the last one (and contributes zeros)
     if (!item_live(t_io, tile_io)) { t_io = BPTT ? T - 1 : T - 1; tile_io = n_tiles - 1; }
@@ -297,10 +313,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
     const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
 
     auto load16c = [&](const float* __restrict__ plane) {  // 16 coordinates of the own tile from a coordinate-major [d][B] plane
-      f32x16 v;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v[q] = cb + rrow(q) < d ? plane[(long long)(cb + rrow(q)) * B + lrow] : 0.0f;
-      return v;
+      return load_cm16(plane, (unsigned)lrow);
     };
     auto load16r = [&](const float* __restrict__ rowp) {  // ... from a row of a [.., d] tensor (the caller's noise)
       f32x16 v;

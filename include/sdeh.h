@@ -355,6 +355,8 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, con
  *   d2   [(Lh+1), C, N]  out: adjoints of those pre-activations through the divergence (ADD to the dt planes of the first-order pass:
  *                             the weight gradients of both are one sdeh_weight_grad contraction)
  *   dgam [g, N]          out: d / d gamma(t) of the score part of the divergence (LerpPriorCtrl; NULL for ClippedCtrl)
+ *   dx_accum [T, B, d]   in/out or NULL: method "kl" / "kl_ito" -- the divergence term's share of d loss / d x_t (W_in^T adj z_0) is
+ *                             ADDED to the plane sdeh_ctrl_backward_ex wrote as dx_out (it becomes lam_extra of the generative BPTT)
  *   out  (floats): d / d input_embed.weight TRANSPOSED [d, C] | d / d out_layer.weight [d, C] | d / d hidden_layer[0].weight [C, C] |
  *                  (two hidden layers:) d / d hidden_layer[1].weight TRANSPOSED [C, C]   -- the tangent streams' direct contributions
  *   scratch: sdeh_bridge_div_backward_wide_sizes floats (per-workgroup partials, summed deterministically: no atomics).
@@ -362,8 +364,8 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, con
 int32_t sdeh_bridge_div_backward_wide_sizes(int32_t dim, int32_t channels, int32_t n_hidden, int32_t n_steps, int64_t batch,
                                             int64_t* scratch_floats, int64_t* out_floats);
 int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
-                                      int64_t batch, const float* grad_rnd, const float* zt, float* d2, float* dgam, float* scratch,
-                                      int64_t scratch_floats, float* out, void* stream);
+                                      int64_t batch, const float* grad_rnd, const float* zt, float* d2, float* dgam, float* dx_accum,
+                                      float* scratch, int64_t scratch_floats, float* out, void* stream);
 
 /*
  * Batch reductions of BaseOCLoss.compute_results / compute_loss (losses/oc.py:72-123), as mergeable partial

@@ -944,8 +944,8 @@ int32_t sdeh_bridge_div_backward_wide_sizes(int32_t dim, int32_t channels, int32
 }
 
 int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
-                                      int64_t batch, const float* grad_rnd, const float* zt, float* d2, float* dgam, float* scratch,
-                                      int64_t scratch_floats, float* out, void* stream) {
+                                      int64_t batch, const float* grad_rnd, const float* zt, float* d2, float* dgam, float* dx_accum,
+                                      float* scratch, int64_t scratch_floats, float* out, void* stream) {
   if (plan == nullptr || pr == nullptr || ts == nullptr || xs == nullptr || grad_rnd == nullptr || zt == nullptr || d2 == nullptr ||
       scratch == nullptr || out == nullptr)
     return fail(SDEH_ERR_INVALID, "bridge_div_backward_wide: null argument");
@@ -964,7 +964,7 @@ int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, con
   if (inf.ctrl_kind == SDEH_CTRL_LERP_PRIOR && dgam == nullptr) return fail(SDEH_ERR_INVALID, "bridge_div_backward_wide: dgam is null");
   int g2 = 1;
   if (inf.ctrl_kind == SDEH_CTRL_LERP_PRIOR && inf.score_model.n_hidden > 0) g2 = inf.score_model.dim_out == 1 ? 1 : 32 * row_tiles(d);
-  const WsLayout L2 = make_wide_layout(d, C, net2.n_hidden, n_steps, g2, true);
+  const WsLayout L2 = make_wide_layout(d, C, net2.n_hidden, n_steps, g2, true, 0, true);  // + the transposed images (input_embed^T: d/dx)
   if ((size_t)ck.L.total + (size_t)L2.total > plan->ws_floats) return fail(SDEH_ERR_CAPACITY, "bridge_div_backward_wide: workspace too small");
   long long grid, xp, cp, sums, n_out;
   wide_div_sizes(d, C, net2.n_hidden, n_steps, batch, &grid, &xp, &cp, &sums, &n_out);
@@ -989,7 +989,7 @@ int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, con
   WideDivArgs A;
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = ck.L; A.ws2 = plan->ws + ck.L.total; A.lay2 = L2;
-  A.xs = xs; A.grad_rnd = grad_rnd; A.zt = zt; A.d2 = d2; A.dgam = dgam;
+  A.xs = xs; A.grad_rnd = grad_rnd; A.zt = zt; A.d2 = d2; A.dgam = dgam; A.dx = dx_accum;
   A.batch = batch; A.n_steps = n_steps; A.d = d; A.inf_kind = inf.ctrl_kind; A.act = net2.activation;
   A.clip_model = inf.clip_model; A.clip_score = inf.clip_score; A.scale_score = inf.scale_score;
   float* g_in = out; float* g_out = out + (long long)d * C; float* g_hid = g_out + (long long)d * C;

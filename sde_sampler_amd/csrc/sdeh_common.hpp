@@ -157,6 +157,7 @@ struct WideDivArgs {
   const float* zt;        // [(Lh+1), C, N] pre-activations of the inference network (sdeh_ctrl_backward_ex wrote them)
   float* d2;              // [(Lh+1), C, N] adjoints of the base pre-activations through the divergence (side 1 writes plane Lh, side 0 the rest)
   float* dgam;            // [g, N] (side 0)
+  float* dx;              // [T, B, d] or null: d loss / d x_t, the divergence term's share ADDED (side 0; method kl)
   float* xpart;           // [grid][C][C] partial of dX
   float* cpart;           // [grid][d][C] partial of d L / d col_q  (zeroed by the caller)
   float* spart;           // [grid][d][C] partial of d L / d W_out (Lh = 1 only, side 0; zeroed by the caller)

@@ -101,20 +101,20 @@ __device__ __forceinline__ void wide_bwd_delta_store(const f32x16 (&acc)[OTW][1]
 
 // out[k] = W[coordinate tiles {w, w + 4}][:] . plane   (an out-layer-shaped product: w_out or input_embed^T), nto tiles of this wave
 __device__ __forceinline__ void wide_bwd_coord_layer(const float* __restrict__ wl, int otd, int NS4, int w, int lane, int nto,
-                                                     const float* __restrict__ actl, f32x16 (&out)[2][1]) {
+                                                     const float* __restrict__ actl, f32x16 (&out)[2][1], int rs = 32) {
   unsigned vo[2];
   vo[0] = (unsigned)((w * 64 + lane) * 16);
   vo[1] = nto > 1 ? (unsigned)(((w + 4) * 64 + lane) * 16) : vo[0];
   if (nto == 2) {
     WidePre<2> pre;
     wide_prefetch<2>(pre, wl, otd * 256, NS4, vo);
-    wide_layer<2, 1>(pre, wl, otd * 256, NS4, vo, actl, 32, out);
+    wide_layer<2, 1>(pre, wl, otd * 256, NS4, vo, actl, rs, out);
   } else {  // one tile, or none (the wave runs the same stream on tile w % otd and drops the result: no control flow around asm loads)
     WidePre<1> pre;
     unsigned v1[1] = {nto == 1 ? vo[0] : (unsigned)(((w % otd) * 64 + lane) * 16)};
     wide_prefetch<1>(pre, wl, otd * 256, NS4, v1);
     f32x16 o1[1][1];
-    wide_layer<1, 1>(pre, wl, otd * 256, NS4, v1, actl, 32, o1);
+    wide_layer<1, 1>(pre, wl, otd * 256, NS4, v1, actl, rs, o1);
     out[0][0] = o1[0][0];
   }
 }
@@ -910,6 +910,7 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
       for (int q = 0; q < 16; ++q) z[q] = live ? A.zt[((long long)l * C + 32 * tiles[k] + rho(q, h)) * N + n] : 0.0f;
       return z;
     };
+    float* __restrict__ dS2 = Dp + Lh * C * RS;  // act'(z_Lh) is no longer needed: adj z_0 goes here (the dS plane is still being read)
     if (side == 1) {
 #pragma unroll
       for (int k = 0; k < OTW; ++k) {
@@ -955,7 +956,21 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
           const int ch = 32 * tiles[k] + rho(q, h);
           const float v = fmaf(Dp[ch * RS + j], adj[k][q], act_grad2(z[q], act) * dDq[k][q]);
           if (live) A.d2[(long long)ch * N + n] = v;
+          if (A.dx != nullptr) dS2[ch * RS + j] = v;
         }
+      }
+      if (A.dx != nullptr) {  // back-propagation through time (method kl): the divergence term's share of d loss / d x_t = W_in^T adj z_0
+        wide_barrier();       // (the mask and the score part carry no d/dx: clamp / clip indicators are constants of the graph)
+        f32x16 dxa[2][1];
+        wide_bwd_coord_layer(ws2 + L2.wt_in, OTD, C / 8, w, lane, nto, dS2 + h * RS + j, dxa, RS);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+          if (k < nto && live) {
+            float* __restrict__ xp = A.dx + n * d + 32 * (w + 4 * k) + 4 * h;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              if (32 * (w + 4 * k) + 4 * h + (q & 3) + 8 * (q >> 2) < d) xp[(q & 3) + 8 * (q >> 2)] += dxa[k][0][q];
+          }
       }
     }
     wide_barrier();  // planes free for the next item

@@ -352,10 +352,12 @@ class _BridgeFn(torch.autograd.Function):
         Cn, Lh = pr_b.inference.base_model.channels, pr_b.inference.base_model.n_hidden
         g = dgam.shape[0]
         if Cn != 64 or d > 64:  # wide networks: the fused divergence backward (csrc/sdeh_wide_bwd.hip)
-            if not lv:
-                raise L.SdehUnsupported(-2, "wide-network Bridge: training is built for the log-variance methods (conf/solver/bridge.yaml: "
-                                            "loss time_reversal_lv); method='kl' needs the divergence term's d/dx, which is not built in")
-            grads.update(_wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam))
+            if st.get("div_noise") is not None:
+                raise L.SdehUnsupported(-2, "wide-network Bridge: the Hutchinson divergence estimators are built for channels = 64")
+            inf_grads = _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam, dx)
+            if not lv:  # generative network: back-propagation through time with the cost on u + v and the inference network's d loss / d x_t
+                grads = generative(cost_ctrl=gp, lam_extra=dx)
+            grads.update(inf_grads)
             return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
         eps = st.get("div_noise")
         if eps is not None:
@@ -378,7 +380,7 @@ class _BridgeFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
 
-def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam) -> dict[int, torch.Tensor]:
+def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam, dx=None) -> dict[int, torch.Tensor]:
     """Gradients of the inference network of a wide Bridge: first-order planes (zt, dt, dout, dgam from sdeh_ctrl_backward_ex) + the
     divergence term through sdeh_bridge_div_backward_wide (adjoint planes d2 of the base pre-activations, the tangent streams' direct
     weight gradients, d / d gamma of the score part)."""
@@ -398,8 +400,8 @@ def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout
     with torch.cuda.device(dev):
         L.check(lib.sdeh_bridge_div_backward_wide(
             plan.handle, C.byref(pr_b), keep_b.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B, w.data_ptr(), zt.data_ptr(),
-            d2.data_ptr(), dgam2.data_ptr(), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
-            torch.cuda.current_stream(dev).cuda_stream))
+            d2.data_ptr(), dgam2.data_ptr(), None if dx is None else dx.data_ptr(), scratch.data_ptr(), scratch.numel(),
+            out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
     grads = _weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, dgam=dgam2))
     with torch.no_grad():
         g_in = out[:d * Cn].view(d, Cn)

@@ -866,6 +866,9 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
   if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && dgam == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward: dgam is null");
   const WsLayout& L = ck.L;
   if (plan->wide) {  // channel-split chain kernel of sdeh_wide_bwd.hip (same planes; nn_in is not used: the wide forward keeps none)
+    if ((long long)n_steps * batch >= (1LL << 25))
+      return fail(SDEH_ERR_CAPACITY, "ctrl_backward (wide): n_steps * batch = %lld rows: the plane columns are addressed with 32-bit byte "
+                                     "offsets per row tile (< 2^25 rows per call; split the batch)", (long long)n_steps * batch);
     hipStream_t stw = (hipStream_t)stream;
     PrepArgs Pw;
     Pw.ws = plan->ws; Pw.lay = L; Pw.prob = *pr; Pw.ts = ts; Pw.n_steps = n_steps;

@@ -48,19 +48,40 @@ __device__ __forceinline__ f32x16 wide_row16(const float* __restrict__ rowp, int
   return v;
 }
 
+// Column n of rows 32 tile + rho(q, h) of a coordinate-major plane [C][N]: a WAVE-UNIFORM base per (plane, row tile) + a 32-bit byte
+// offset per element, (rho(q, h) N + n) 4 < 2^32 (N < 3.3e7 rows), the lane's part made opaque per call -- hipcc otherwise keeps one
+// 64-bit address per element and plane as a loop invariant of the step loop (they spill and return as dependent scratch reloads:
+// sdeh_bwdf.hip has the measurement).
+struct WidePlaneCol {
+  char* base;        // plane + 32 tile N floats (uniform)
+  unsigned lane;     // (4 h N + n) 4
+  unsigned nbytes;   // 4 N (uniform)
+  __device__ __forceinline__ float* at(int q) const { return reinterpret_cast<float*>(base + (lane + (unsigned)((q & 3) + 8 * (q >> 2)) * nbytes)); }
+};
+__device__ __forceinline__ WidePlaneCol wide_plane_col(float* plane_u, int tile, long long N, long long n, int h) {
+  WidePlaneCol c;
+  c.base = reinterpret_cast<char*>(plane_u + (long long)32 * tile * N);
+  c.nbytes = (unsigned)N * 4u;
+  c.lane = ((unsigned)(4 * h) * (unsigned)N + (unsigned)n) * 4u;
+  asm volatile("" : "+v"(c.lane));
+  return c;
+}
+
 // this wave's tiles of a layer: z = acc + bias -> HBM plane zt_l [C][N] (column n), act'(z) -> LDS plane dpl [C][32], act(z) -> LDS
 // plane out [rows][32]
 template <int OTW>
 __device__ __forceinline__ void wide_bwd_act_store(f32x16 (&acc)[OTW][1], const f32x16 (&bias)[OTW], int act, float* __restrict__ outl,
-                                                   float* __restrict__ dpl, float* __restrict__ zt_col, long long N, bool store, int t0,
-                                                   int h) {
+                                                   float* __restrict__ dpl, float* __restrict__ zt_l, long long N, long long n, bool store,
+                                                   int t0, int h) {
   SDEH_ACT_SWITCH(act, ACT,
     _Pragma("unroll") for (int k = 0; k < OTW; ++k) {
       f32x16 z = acc[k][0] + bias[k];
-      _Pragma("unroll") for (int q = 0; q < 16; ++q) {
-        const int ch = 32 * (t0 + 4 * k) + rho(q, h);
-        if (store) zt_col[(long long)ch * N] = z[q];
-        if (dpl != nullptr) dpl[ch * 32] = act_grad(z[q], ACT);
+      const WidePlaneCol col = wide_plane_col(zt_l, t0 + 4 * k, N, n, h);
+      if (store) {
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) *col.at(q) = z[q];
+      }
+      if (dpl != nullptr) {
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) dpl[(32 * (t0 + 4 * k) + rho(q, h)) * 32] = act_grad(z[q], ACT);
       }
       act_tile<ACT>(z);
       _Pragma("unroll") for (int q = 0; q < 16; ++q) outl[(32 * (t0 + 4 * k) + rho(q, h)) * 32] = z[q];
@@ -71,28 +92,39 @@ __device__ __forceinline__ void wide_bwd_act_store(f32x16 (&acc)[OTW][1], const 
 // dpl == nullptr (networks whose act' planes do not fit LDS: (n_hidden + 1) C 128 B > ~120 KiB): act'(z_l) is recomputed from the
 // pre-activation this lane wrote to zt_l a moment ago (an L2 hit)
 template <int OTW>
-__device__ __forceinline__ void wide_bwd_delta_store(const f32x16 (&acc)[OTW][1], const float* __restrict__ dpl, const float* __restrict__ zt_col,
-                                                     int act, float* __restrict__ outl, float* __restrict__ dt_col, long long N,
+__device__ __forceinline__ void wide_bwd_delta_store(const f32x16 (&acc)[OTW][1], const float* __restrict__ dpl, float* __restrict__ zt_l,
+                                                     int act, float* __restrict__ outl, float* __restrict__ dt_l, long long N, long long n,
                                                      bool store, int t0, int h) {
   if (dpl != nullptr) {
 #pragma unroll
-    for (int k = 0; k < OTW; ++k)
+    for (int k = 0; k < OTW; ++k) {
+      const WidePlaneCol col = wide_plane_col(dt_l, t0 + 4 * k, N, n, h);
+      f32x16 v;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int ch = 32 * (t0 + 4 * k) + rho(q, h);
-        const float v = acc[k][0][q] * dpl[ch * 32];
-        if (store) dt_col[(long long)ch * N] = v;
-        outl[ch * 32] = v;
+        v[q] = acc[k][0][q] * dpl[ch * 32];
+        outl[ch * 32] = v[q];
       }
+      if (store) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) *col.at(q) = v[q];
+      }
+    }
   } else {
     SDEH_ACT_SWITCH(act, ACT,
       _Pragma("unroll") for (int k = 0; k < OTW; ++k) {
+        const WidePlaneCol zc = wide_plane_col(zt_l, t0 + 4 * k, N, n, h);
+        const WidePlaneCol col = wide_plane_col(dt_l, t0 + 4 * k, N, n, h);
         f32x16 z;
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) z[q] = store ? zt_col[(long long)(32 * (t0 + 4 * k) + rho(q, h)) * N] : 0.0f;
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) z[q] = 0.0f;
+        if (store) {
+          _Pragma("unroll") for (int q = 0; q < 16; ++q) z[q] = *zc.at(q);
+        }
         _Pragma("unroll") for (int q = 0; q < 16; ++q) {
           const int ch = 32 * (t0 + 4 * k) + rho(q, h);
           const float v = acc[k][0][q] * act_grad(z[q], ACT);
-          if (store) dt_col[(long long)ch * N] = v;
+          if (store) *col.at(q) = v;
           outl[ch * 32] = v;
         }
       });
@@ -286,7 +318,7 @@ __global__ __launch_bounds__(256) void wide_bwd_kernel(const BwdArgs A, int n_ti
 #pragma unroll
         for (int k = 0; k < OTW; ++k) bias[k] = l == 0 ? emb[k] : load16(bias_g + (l - 1) * C + ((wh + 4 * k) * 2 + h) * 16);
         wide_barrier();  // everyone has read the plane that is about to be overwritten
-        if (has) wide_bwd_act_store<OTW>(acc, bias, act, pl + j, dlds ? dplanes + l * C * RS + j : nullptr, A.zt + (long long)l * C * N + n, N, live, wh, h);
+        if (has) wide_bwd_act_store<OTW>(acc, bias, act, pl + j, dlds ? dplanes + l * C * RS + j : nullptr, A.zt + (long long)l * C * N, N, n, live, wh, h);
         wide_barrier();
         if (l == Lh) break;
         wide_layer<OTW, 1>(pre_h, ws + L.w_hid + l * L.w_hid_stride, OT * 256, C / 8, voff, pl + h * RS + j, RS, acc);
@@ -400,8 +432,8 @@ __global__ __launch_bounds__(256) void wide_bwd_kernel(const BwdArgs A, int n_ti
         WidePre<OTW> pre_h;
         if (k > 0) wide_prefetch<OTW>(pre_h, ws + L.wt_hid + (k - 1) * L.w_hid_stride, OT * 256, C / 8, voff);
         wide_barrier();  // everyone has read the plane that is about to be overwritten
-        if (has) wide_bwd_delta_store<OTW>(acc, dlds ? dplanes + k * C * RS + j : nullptr, A.zt + (long long)k * C * N + n, act, pl + j,
-                                           A.dt + (long long)k * C * N + n, N, live, wh, h);
+        if (has) wide_bwd_delta_store<OTW>(acc, dlds ? dplanes + k * C * RS + j : nullptr, A.zt + (long long)k * C * N, act, pl + j,
+                                           A.dt + (long long)k * C * N, N, n, live, wh, h);
         wide_barrier();
         if (k == 0) break;
         wide_layer<OTW, 1>(pre_h, ws + L.wt_hid + (k - 1) * L.w_hid_stride, OT * 256, C / 8, voff, pl + h * RS + j, RS, acc);

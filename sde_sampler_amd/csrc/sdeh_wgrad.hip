@@ -50,16 +50,21 @@ __device__ __forceinline__ void wg_load(WgTile& t, const float* __restrict__ row
 template <int ACT>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ D, int m, const float* __restrict__ Z, int c,
                                                     long long N, long long chunk, long long n_chunks,
-                                                    float* __restrict__ part_w, float* __restrict__ part_b) {
+                                                    float* __restrict__ part_w, float* __restrict__ part_b, int mp_blocks, int cp_blocks) {
   const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-  const long long ck = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
+  // 64-channel networks (one [64, 64] block): the four waves of a workgroup take four chunks.  Wide layers (m, c up to 256): the
+  // [m, c] product is tiled into [64, 64] blocks and the four waves take a 2 x 2 arrangement of blocks of the SAME chunk -- two waves
+  // share each row of D and of Z, which then comes from the CU's L1 instead of L2 for the second one.  The partial of a chunk is the
+  // padded matrix [mp][ldw] (multiples of 64; 64-channel networks: [64][64], unchanged).
+  const bool blocked = mp_blocks > 1 || cp_blocks > 1;
+  const long long ck = blocked ? (long long)blockIdx.x : (long long)blockIdx.x * 4 + wv;
   if (ck >= n_chunks) return;
+  const int mb = blocked ? 2 * (int)blockIdx.y + (wv >> 1) : 0, cb = blocked ? 2 * (int)blockIdx.z + (wv & 1) : 0;
+  if (mb >= mp_blocks || cb >= cp_blocks) return;
   const long long n_begin = ck * chunk;
   const long long n_end = n_begin + chunk < N ? n_begin + chunk : N;
-  // wide layers (m, c up to 256): the [m, c] product is tiled into [64, 64] blocks, one per (blockIdx.y, blockIdx.z); the partial of
-  // a chunk is the padded matrix [64 gridDim.y][64 gridDim.z] (64-channel networks: one block, the layout below is unchanged)
-  const int mb = blockIdx.y, cb = blockIdx.z;
-  const int ldw = 64 * (int)gridDim.z, mp = 64 * (int)gridDim.y;
+  const int ldw = 64 * cp_blocks, mp = 64 * mp_blocks;
   D += (long long)mb * 64 * N;
   Z += (long long)cb * 64 * N;
   m = m - 64 * mb < 64 ? m - 64 * mb : 64;
@@ -189,19 +194,22 @@ int launch_partial_sums(const float* part, long long n_items, long long n_chunks
 int launch_weight_grad(const float* D, int m, const float* Z, int c, long long N, int act, long long chunk, float* part_w,
                        float* part_b, hipStream_t stream) {
   const long long n_chunks = (N + chunk - 1) / chunk;
-  const dim3 grid((unsigned)((n_chunks + 3) / 4), (unsigned)((m + 63) / 64), (unsigned)((c + 63) / 64));
+  const int mpb = (m + 63) / 64, cpb = (c + 63) / 64;
+  const bool blocked = mpb > 1 || cpb > 1;
+  const dim3 grid(blocked ? (unsigned)n_chunks : (unsigned)((n_chunks + 3) / 4), blocked ? (unsigned)((mpb + 1) / 2) : 1u,
+                  blocked ? (unsigned)((cpb + 1) / 2) : 1u);
   switch (act) {
     case SDEH_ACT_GELU_ERF:
-      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_GELU_ERF>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);
+      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_GELU_ERF>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b, mpb, cpb);
       break;
     case SDEH_ACT_SILU:
-      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_SILU>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);
+      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_SILU>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b, mpb, cpb);
       break;
     case SDEH_ACT_RELU:
-      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_RELU>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);
+      hipLaunchKernelGGL(wgrad_kernel<SDEH_ACT_RELU>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b, mpb, cpb);
       break;
     case kActIdentity:
-      hipLaunchKernelGGL(wgrad_kernel<kActIdentity>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b);
+      hipLaunchKernelGGL(wgrad_kernel<kActIdentity>, grid, dim3(256), 0, stream, D, m, Z, c, N, chunk, n_chunks, part_w, part_b, mpb, cpb);
       break;
     default:
       return SDEH_ERR_INVALID;

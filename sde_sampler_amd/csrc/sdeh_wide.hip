@@ -353,16 +353,16 @@ int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used) {
   const char* force = getenv("SDEH_WIDE_CT");  // testing aid: "1" | "2" (read per call)
   // (128 trajectories per workgroup -- CT = 4, one plane -- would quarter the operand loads per MFMA, but the state and the network
   // output of 128 trajectories do not fit the wave's registers next to the elementwise phase: it spills and measures 36.7 ms against
-  // 29.6 ms for CT = 2 at B = 32 768; it stays available through SDEH_WIDE_CT=4 for experiments)
+  // 29.6 ms for CT = 2 at B = 32 768; those instantiations -- 770-1154 spilled registers -- were removed in round 3)
   int ct = a.batch > 32 * 256 ? 2 : 1;
-  if (force != nullptr && (force[0] == '1' || force[0] == '2' || force[0] == '4')) ct = force[0] - '0';
+  if (force != nullptr && (force[0] == '1' || force[0] == '2')) ct = force[0] - '0';
   const int K = a.target.kind == SDEH_DENS_GMM ? a.target.n_comp : 0;
   if (K > 0) ct = 1;  // mixture targets: tables, partial logits and responsibilities take the LDS of the second column tile
   if (ct_used != nullptr) *ct_used = ct;
   const int otw = a.lay.c == 64 ? 1 : a.lay.c / 128;  // C = 64 (d > 64): one tile per wave, two waves with hidden tiles
   if (K > 0) return otw == 2 ? launch_wide_t<2, 1, true>(a, stream) : launch_wide_t<1, 1, true>(a, stream);
-  if (otw == 2) return ct == 4 ? launch_wide_t<2, 4>(a, stream) : (ct == 2 ? launch_wide_t<2, 2>(a, stream) : launch_wide_t<2, 1>(a, stream));
-  if (otw == 1) return ct == 4 ? launch_wide_t<1, 4>(a, stream) : (ct == 2 ? launch_wide_t<1, 2>(a, stream) : launch_wide_t<1, 1>(a, stream));
+  if (otw == 2) return ct == 2 ? launch_wide_t<2, 2>(a, stream) : launch_wide_t<2, 1>(a, stream);
+  if (otw == 1) return ct == 2 ? launch_wide_t<1, 2>(a, stream) : launch_wide_t<1, 1>(a, stream);
   return SDEH_ERR_UNSUPPORTED;
 }
 

@@ -14,8 +14,9 @@ def _run(dmat, z, act, chunk):
     m, N = dmat.shape
     c = z.shape[0]
     n_chunks = -(-N // chunk)
-    pw = torch.full((n_chunks, 64, 64), float("nan"), device=DEV)
-    pb = torch.full((n_chunks, 64), float("nan"), device=DEV)
+    mp, cp = 64 * ((m + 63) // 64), 64 * ((c + 63) // 64)  # partials are padded to multiples of 64 (wide layers: [64, 64] blocks)
+    pw = torch.full((n_chunks, mp, cp), float("nan"), device=DEV)
+    pb = torch.full((n_chunks, mp), float("nan"), device=DEV)
     L.check(L.load().sdeh_weight_grad(dmat.data_ptr(), m, z.data_ptr(), c, N, act, chunk, pw.data_ptr(), pb.data_ptr(),
                                       torch.cuda.current_stream().cuda_stream))
     return pw, pb
@@ -26,7 +27,10 @@ ACTS = {L.ACT_GELU_ERF: torch.nn.functional.gelu, L.ACT_SILU: torch.nn.functiona
 
 
 @pytest.mark.parametrize("m,c,N,chunk", [(64, 64, 4096, 128), (64, 64, 5000, 256), (1, 64, 777, 64), (50, 64, 2049, 8),
-                                         (64, 2, 1003, 128), (33, 17, 130, 128), (10, 64, 100 * 257, 1024)])
+                                         (64, 2, 1003, 128), (33, 17, 130, 128), (10, 64, 100 * 257, 1024),
+                                         # layers of the wide networks (round 3): blocked over [64, 64] tiles, 2 x 2 per workgroup
+                                         (256, 256, 3000, 512), (196, 256, 1111, 128), (256, 196, 2050, 256), (128, 70, 777, 64),
+                                         (65, 129, 300, 32)])
 @pytest.mark.parametrize("act", sorted(ACTS))
 def test_weight_grad_matches_float64(m, c, N, chunk, act):
     torch.manual_seed(m * 1000 + c + N)
@@ -59,7 +63,7 @@ def test_weight_grad_unaligned_views_and_errors():
     assert (pw.sum(0).double() - ref).abs().max() < 1e-3
     lib = L.load()
     args = (dmat.data_ptr(), 64, z.data_ptr(), 64, 1001, 0, 128, pw.data_ptr(), pb.data_ptr(), None)
-    for bad in [dict(chunk=12), dict(m=65), dict(c=0), dict(act=7)]:
+    for bad in [dict(chunk=12), dict(m=257), dict(c=0), dict(act=7)]:
         a = list(args)
         if "chunk" in bad: a[6] = bad["chunk"]
         if "m" in bad: a[1] = bad["m"]

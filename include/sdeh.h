@@ -280,6 +280,8 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* problem, const flo
  *   lam_extra [T,B,d] or NULL (BPTT): added to d loss / d x_t          dx_out [T,B,d] or NULL (row-parallel): written
  *   nn_in     [T,B,d] or NULL: the raw network outputs written by sdeh_simulate_fwd_train; with it `zt` is an INPUT (the forward
  *             launch's pre-activation planes) and the kernel does not re-evaluate the network
+ *   xt_out    [d, N] or NULL (plans for channels 128 / 256 or d > 64 only): x_t coordinate-major, written next to the planes -- the
+ *             operand of input_embed.weight's gradient in the layout sdeh_weight_grad reads (ABI v4)
  *
  * sdeh_simulate_fwd_train == sdeh_simulate_fwd for a training step (xs required) that also keeps what the backward needs:
  *   zt [(Lh+1), C, n_steps*batch]  pre-activations of every layer, coordinate-major (n = step * batch + row)
@@ -336,7 +338,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* problem, const 
                               const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, const float* grad_rnd, const float* gextra, const float* cost_ctrl,
                               const float* lam_extra, float* dx_out, float* zt, float* dt, float* dout, float* dgam,
-                              const float* nn_in, void* stream);
+                              const float* nn_in, float* xt_out, void* stream);
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                                  const float* xs, int64_t batch, const float* grad_rnd, const float* zt, float* tz,
                                  float* ta, float* td, float* d2, float* cj, float* dgam, float* dx_accum,

@@ -792,7 +792,7 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
                            int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                            const float* grad_rnd, float* zt, float* dt, float* dout, float* dgam, void* stream) {
   return sdeh_ctrl_backward_ex(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, nullptr, nullptr,
-                               nullptr, nullptr, zt, dt, dout, dgam, nullptr, stream);
+                               nullptr, nullptr, zt, dt, dout, dgam, nullptr, nullptr, stream);
 }
 
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
@@ -849,7 +849,8 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const fl
 int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                               int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                               const float* grad_rnd, const float* gextra, const float* cost_ctrl, const float* lam_extra,
-                              float* dx_out, float* zt, float* dt, float* dout, float* dgam, const float* nn_in, void* stream) {
+                              float* dx_out, float* zt, float* dt, float* dout, float* dgam, const float* nn_in, float* xt_out,
+                              void* stream) {
   if (xs == nullptr || grad_rnd == nullptr || zt == nullptr || dt == nullptr || dout == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward: null argument");
   Checked ck;
@@ -865,6 +866,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
                                       "configuration the reference produces");
   if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && dgam == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward: dgam is null");
   const WsLayout& L = ck.L;
+  if (xt_out != nullptr && !plan->wide) return fail(SDEH_ERR_INVALID, "ctrl_backward_ex: xt_out belongs to the wide-network kernels");
   if (plan->wide) {  // channel-split chain kernel of sdeh_wide_bwd.hip (same planes; nn_in is not used: the wide forward keeps none)
     if ((long long)n_steps * batch >= (1LL << 25))
       return fail(SDEH_ERR_CAPACITY, "ctrl_backward (wide): n_steps * batch = %lld rows: the plane columns are addressed with 32-bit byte "
@@ -879,7 +881,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
     memset(&Aw, 0, sizeof(Aw));
     Aw.ws = plan->ws; Aw.lay = L; Aw.xs = xs; Aw.noise = noise; Aw.grad_rnd = grad_rnd; Aw.gextra = gextra;
     Aw.cost_ctrl = cost_ctrl; Aw.lam_extra = lam_extra; Aw.dx = dx_out;
-    Aw.zt = zt; Aw.dt = dt; Aw.dout = dout; Aw.dgam = dgam; Aw.nn_in = nullptr;
+    Aw.zt = zt; Aw.dt = dt; Aw.dout = dout; Aw.dgam = dgam; Aw.nn_in = nullptr; Aw.xt_out = xt_out;
     Aw.batch = batch; Aw.row_offset = row_offset; Aw.n_steps = n_steps; Aw.d = pr->base_model.dim;
     Aw.loss_kind = pr->loss_kind; Aw.ctrl_kind = pr->ctrl_kind; Aw.flags = pr->flags; Aw.act = pr->base_model.activation;
     Aw.clip_model = pr->clip_model; Aw.clip_score = pr->clip_score; Aw.scale_score = pr->scale_score;

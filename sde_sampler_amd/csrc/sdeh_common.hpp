@@ -188,6 +188,7 @@ struct BwdArgs {
   unsigned long long seed, offset;
   const unsigned long long* rng_dev;
   const float* nn_in;  // [T, B, d] or null: with it, `zt` already holds the forward launch's pre-activations and is only read
+  float* xt_out;       // [d, N] or null (wide plans): x_t coordinate-major, written next to the planes
 };
 
 // sdeh_ctrl_backward_fused (sdeh_bwdf.hip): back-propagation + weight gradients in one kernel

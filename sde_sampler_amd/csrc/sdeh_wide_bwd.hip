@@ -294,6 +294,16 @@ __global__ __launch_bounds__(256) void wide_bwd_kernel(const BwdArgs A, int n_ti
 
     // ======================================================================================= forward (re-evaluation at x_t)
     load_x(t);
+    if (A.xt_out != nullptr && live) {  // x_t coordinate-major [d][N]: the input layer's weight-gradient operand (a strided transpose
+#pragma unroll                          // of the row-major trajectory costs the framework 5.8 ms per 1.3 GB)
+      for (int k = 0; k < 2; ++k)
+        if (k < nto) {
+          const WidePlaneCol col = wide_plane_col(A.xt_out, w + 4 * k, N, n, h);
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (32 * (w + 4 * k) + rho(q, h) < d) *col.at(q) = xr[k][0][q];
+        }
+    }
     wide_publish<1>(cx, pl, xr, nto);
     wide_barrier();
     float fs = 0.0f, fx0 = 0.0f, fiv = 0.0f;

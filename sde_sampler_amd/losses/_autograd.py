@@ -39,6 +39,8 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
     dt = torch.empty_like(zt)
     dout = torch.empty((d, N), device=dev, dtype=torch.float32)
     dgam = torch.zeros((max(g, 1), N), device=dev, dtype=torch.float32)
+    # wide networks: the chain kernel also leaves x_t coordinate-major (the operand of input_embed.weight's gradient)
+    xt = torch.empty((d, N), device=dev, dtype=torch.float32) if (Cn != 64 or d > 64) else None
     plan = engine._plan(dev, d, Cn, Lh, T, pr.target.n_components if pr.target.kind == L.DENS_GMM else 0)
     noise = st["noise"]
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -48,8 +50,8 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
             plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
             None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
             w.data_ptr(), ptr(gextra), ptr(cost_ctrl), ptr(lam_extra), ptr(dx_out), zt.data_ptr(), dt.data_ptr(),
-            dout.data_ptr(), dgam.data_ptr(), ptr(nn_in), stream))
-    return zt, dt, dout, dgam
+            dout.data_ptr(), dgam.data_ptr(), ptr(nn_in), ptr(xt), stream))
+    return (zt, dt, dout, dgam) if xt is None else (zt, dt, dout, dgam, xt)
 
 
 def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torch.Tensor]:
@@ -221,7 +223,7 @@ def _time_embed_grads(te, act_id: int, steps: torch.Tensor, table_grad: torch.Te
     return out
 
 
-def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, torch.Tensor]:
+def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, xt=None, extra=None) -> dict[int, torch.Tensor]:
     """Parameter gradients of one control from the coordinate-major planes (sdeh_weight_grad over N; autograd on the [T, .]
     tables of the two time-only sub-networks).  `extra`: additive second-order contributions of the Bridge divergence term."""
     base = ctrl.base_model
@@ -236,7 +238,7 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, extra=None) -> dict[int, tor
         # every product of this control goes into one batch: (parameter, wants_bias, planes...); products of the same parameter add
         w_in, w_out = base.input_embed.weight, base.out_layer.weight
         jobs: list[tuple[torch.nn.Parameter, torch.nn.Parameter | None, torch.Tensor, torch.Tensor, int]] = []
-        Xt = xs[:T].reshape(N, d).t().contiguous()  # [d, N]
+        Xt = xt if xt is not None else xs[:T].reshape(N, d).t().contiguous()  # [d, N]
         d0 = dt[0] + extra["d2"][0] if "d2" in extra else dt[0]
         jobs.append((w_in, None, d0, Xt, L.ACT_IDENTITY))
         d_emb = d0.reshape(Cn, T, B).sum(dim=2).t().contiguous()  # [T, C]: gradient of the time embedding table
@@ -345,7 +347,8 @@ class _BridgeFn(torch.autograd.Function):
         v_flags = (kw["flags"] | L.FLAG_CHANGE_SDE_CTRL) & ~(L.FLAG_TERMINAL_TARGET | L.FLAG_INIT_LOGP | L.FLAG_TERMINAL_SECOND)
         kw_v = dict(kw, generative_ctrl=inf, terminal_target=None, second=None, clip_target=None, flags=v_flags)
         pr_v = eng.build_problem(device=dev, keep=keep_v, **kw_v)
-        zt, dt, dout, dgam = _ctrl_backward(eng, pr_v, keep_v, ts, xs, w, st, gextra=gp, dx_out=dx)
+        zt, dt, dout, dgam, *xt_v = _ctrl_backward(eng, pr_v, keep_v, ts, xs, w, st, gextra=gp, dx_out=dx)
+        xt_v = xt_v[0] if xt_v else None
         # inference network, divergence term
         keep_b = E._Keep()
         pr_b = eng.build_problem(device=dev, keep=keep_b, **st["problem_kwargs"])
@@ -354,7 +357,7 @@ class _BridgeFn(torch.autograd.Function):
         if Cn != 64 or d > 64:  # wide networks: the fused divergence backward (csrc/sdeh_wide_bwd.hip)
             if st.get("div_noise") is not None:
                 raise L.SdehUnsupported(-2, "wide-network Bridge: the Hutchinson divergence estimators are built for channels = 64")
-            inf_grads = _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam, dx)
+            inf_grads = _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam, dx, xt_v)
             if not lv:  # generative network: back-propagation through time with the cost on u + v and the inference network's d loss / d x_t
                 grads = generative(cost_ctrl=gp, lam_extra=dx)
             grads.update(inf_grads)
@@ -380,7 +383,7 @@ class _BridgeFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
 
-def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam, dx=None) -> dict[int, torch.Tensor]:
+def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam, dx=None, xt=None) -> dict[int, torch.Tensor]:
     """Gradients of the inference network of a wide Bridge: first-order planes (zt, dt, dout, dgam from sdeh_ctrl_backward_ex) + the
     divergence term through sdeh_bridge_div_backward_wide (adjoint planes d2 of the base pre-activations, the tangent streams' direct
     weight gradients, d / d gamma of the score part)."""
@@ -402,7 +405,7 @@ def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout
             plan.handle, C.byref(pr_b), keep_b.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B, w.data_ptr(), zt.data_ptr(),
             d2.data_ptr(), dgam2.data_ptr(), None if dx is None else dx.data_ptr(), scratch.data_ptr(), scratch.numel(),
             out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
-    grads = _weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, dgam=dgam2))
+    grads = _weight_grads(inf, ts, xs, zt, dt, dout, dgam, xt=xt, extra=dict(d2=d2, dgam=dgam2))
     with torch.no_grad():
         g_in = out[:d * Cn].view(d, Cn)
         g_out = out[d * Cn:2 * d * Cn].view(d, Cn)

@@ -282,6 +282,11 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* problem, const flo
  *             launch's pre-activation planes) and the kernel does not re-evaluate the network
  *   xt_out    [d, N] or NULL (plans for channels 128 / 256 or d > 64 only): x_t coordinate-major, written next to the planes -- the
  *             operand of input_embed.weight's gradient in the layout sdeh_weight_grad reads (ABI v4)
+ *   sc_in [T,B,d], tscore_in [B,d] or NULL (wide plans with a MIXTURE target only): the planes sdeh_simulate_fwd_train2 wrote -- the
+ *             wide backward evaluates no mixture (sc_in whenever the control has a target-score term, tscore_in for methods kl / kl_ito
+ *             with SDEH_FLAG_TERMINAL_TARGET).  On a wide plan sdeh_simulate_fwd_train2 keeps everything ROW-major: xs [n_steps+1, batch,
+ *             d], sc [n_steps, batch, d], tscore [batch, d] (sc / tscore written for mixture targets only; closed-form targets are
+ *             re-evaluated by the backward kernel).
  *
  * sdeh_simulate_fwd_train == sdeh_simulate_fwd for a training step (xs required) that also keeps what the backward needs:
  *   zt [(Lh+1), C, n_steps*batch]  pre-activations of every layer, coordinate-major (n = step * batch + row)
@@ -338,7 +343,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* problem, const 
                               const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, const float* grad_rnd, const float* gextra, const float* cost_ctrl,
                               const float* lam_extra, float* dx_out, float* zt, float* dt, float* dout, float* dgam,
-                              const float* nn_in, float* xt_out, void* stream);
+                              const float* nn_in, float* xt_out, const float* sc_in, const float* tscore_in, void* stream);
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                                  const float* xs, int64_t batch, const float* grad_rnd, const float* zt, float* tz,
                                  float* ta, float* td, float* d2, float* cj, float* dgam, float* dx_accum,

@@ -129,7 +129,7 @@ PROTOTYPES = {
     "sdeh_ctrl_backward_fused": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64,
                                              C.c_uint64, C.c_int64, fp, fp, fp, fp, C.c_int64, fp, C.c_void_p]),
     "sdeh_ctrl_backward_ex": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64,
-                                          C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_void_p]),
+                                          C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_bridge_div_backward": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, fp, fp, fp,
                                              fp, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_bridge_div_backward_wide_sizes": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_int64),

@@ -446,10 +446,6 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   if (plan->wide) {  // wide networks (sdeh_wide.hip, sdeh_wide_bwd.hip)
     if (integrate)
       return fail(SDEH_ERR_UNSUPPORTED, "networks with %d channels (or d > 64) have no plain integrator (channels = 64 with d <= 64 has)", net.channels);
-    if (backward && pr->target.kind == SDEH_DENS_GMM &&
-        (need_target_score || (!(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL) && (pr->flags & SDEH_FLAG_TERMINAL_TARGET))))
-      return fail(SDEH_ERR_UNSUPPORTED, "wide-network training: mixture targets are not built into the backward kernel (Gaussian, "
-                                        "double-well and funnel targets are)");
     if (need_target && pr->target.kind == SDEH_DENS_GMM && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
       return fail(SDEH_ERR_UNSUPPORTED, "wide Bridge kernel: mixture targets are not built in (Gaussian, double-well and funnel targets are)");
     if ((pr->flags & SDEH_FLAG_INFERENCE_CTRL) && net.channels < 128)
@@ -577,10 +573,12 @@ static void fill_traj_args(TrajArgs& A, const SdehProblem* pr, const float* x0, 
 // Wide networks (C = 128 / 256, d <= 256): the channel-split kernels of sdeh_wide.hip, with or without an inference control.
 static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0, int64_t batch,
                          const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, float* x_T, float* rnd, float* xs,
-                         void* stream, const Checked& ck, float* gp, const float* div_noise, bool want_planes) {
-  // (training planes: the wide forward keeps none -- the caller's backward re-evaluates the network at the stored trajectory,
-  // sdeh_wide_bwd.hip; Hutchinson probes are a 64-channel feature)
-  (void)want_planes;
+                         void* stream, const Checked& ck, float* gp, const float* div_noise, float* sc_out, float* tsc_out) {
+  // (training: the wide forward keeps no network planes -- the caller's backward re-evaluates the network at the stored trajectory,
+  // sdeh_wide_bwd.hip; what it keeps for a MIXTURE target is the score entering the control, sc_out [T, B, d], and the terminal target
+  // score, tsc_out [B, d] (sdeh_simulate_fwd_train2 on a wide plan); Hutchinson probes are a 64-channel feature)
+  if ((sc_out != nullptr || tsc_out != nullptr) && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train2 (wide): the Bridge forward keeps no score planes");
   if (div_noise != nullptr)
     return fail(SDEH_ERR_UNSUPPORTED, "wide-network Bridge: the Hutchinson divergence estimators are built for channels = 64 "
                                       "(the exact divergence is built in)");
@@ -597,6 +595,7 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   TrajArgs A{};
   fill_traj_args(A, pr, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, n_steps);
   A.ws = plan->ws; A.lay = ck.L;
+  A.sc_out = sc_out; A.tsc_out = tsc_out;  // (only the mixture instantiations write them)
   if (bridge) {
     const SdehInferenceCtrl& inf = pr->inference;
     const SdehFourierMLP& net2 = inf.base_model;
@@ -694,9 +693,15 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   if (rc != SDEH_OK) return rc;
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
-  if (plan->wide)
-    return simulate_wide(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise,
-                         zt_out != nullptr || nn_out != nullptr || sc_out != nullptr || tsc_out != nullptr || xs_cm != nullptr);
+  if (plan->wide) {
+    // sdeh_simulate_fwd_train2 on a wide plan: `xs_cm` is the ROW-major trajectory [T+1, B, d] (the wide backward reads rows), sc /
+    // tscore row-major as well and written for mixture targets only; sdeh_simulate_fwd_train's network planes are not produced
+    const bool gmm = pr->target.kind == SDEH_DENS_GMM;
+    rc = simulate_wide(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs != nullptr ? xs : xs_cm, stream, ck,
+                       gp, div_noise, gmm ? sc_out : nullptr, gmm ? tsc_out : nullptr);
+    if (rc == SDEH_OK && planes_written != nullptr) *planes_written = xs_cm != nullptr;
+    return rc;
+  }
   if (pr->flags & SDEH_FLAG_INFERENCE_CTRL)
     return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise);
   const WsLayout& L = ck.L;
@@ -779,7 +784,7 @@ int32_t sdeh_simulate_fwd_train2(SdehPlan* plan, const SdehProblem* pr, const fl
   if (xs == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd_train2: xs (the coordinate-major trajectory plane) is required");
   if (pr != nullptr && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
     return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train2: the Bridge forward keeps no planes (use sdeh_simulate_fwd_aux)");
-  if (pr != nullptr && pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr)
+  if (pr != nullptr && pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr && !(plan != nullptr && plan->wide))
     return fail(SDEH_ERR_INVALID, "simulate_fwd_train2: sc is required for controls with a score term");
   bool written = false;
   const int rc = simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, nullptr, nullptr, nullptr,
@@ -792,7 +797,7 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
                            int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                            const float* grad_rnd, float* zt, float* dt, float* dout, float* dgam, void* stream) {
   return sdeh_ctrl_backward_ex(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, nullptr, nullptr,
-                               nullptr, nullptr, zt, dt, dout, dgam, nullptr, nullptr, stream);
+                               nullptr, nullptr, zt, dt, dout, dgam, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
@@ -850,7 +855,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
                               int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                               const float* grad_rnd, const float* gextra, const float* cost_ctrl, const float* lam_extra,
                               float* dx_out, float* zt, float* dt, float* dout, float* dgam, const float* nn_in, float* xt_out,
-                              void* stream) {
+                              const float* sc_in, const float* tscore_in, void* stream) {
   if (xs == nullptr || grad_rnd == nullptr || zt == nullptr || dt == nullptr || dout == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward: null argument");
   Checked ck;
@@ -866,8 +871,15 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
                                       "configuration the reference produces");
   if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && dgam == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward: dgam is null");
   const WsLayout& L = ck.L;
-  if (xt_out != nullptr && !plan->wide) return fail(SDEH_ERR_INVALID, "ctrl_backward_ex: xt_out belongs to the wide-network kernels");
+  if ((xt_out != nullptr || sc_in != nullptr || tscore_in != nullptr) && !plan->wide)
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_ex: xt_out / sc_in / tscore_in belong to the wide-network kernels");
   if (plan->wide) {  // channel-split chain kernel of sdeh_wide_bwd.hip (same planes; nn_in is not used: the wide forward keeps none)
+    if (pr->target.kind == SDEH_DENS_GMM) {  // the chain kernel evaluates no mixture: the forward launch's planes stand in
+      const bool ctrl_t = pr->ctrl_kind == SDEH_CTRL_SCORE || pr->ctrl_kind == SDEH_CTRL_LERP || pr->ctrl_kind == SDEH_CTRL_LERP_TARGET;
+      if ((ctrl_t && sc_in == nullptr) || (bptt && (pr->flags & SDEH_FLAG_TERMINAL_TARGET) && tscore_in == nullptr))
+        return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward (wide): a mixture target needs the planes of sdeh_simulate_fwd_train2 (sc_in: the score "
+                                          "entering the control; tscore_in for methods kl / kl_ito) -- the wide backward evaluates no mixture");
+    }
     if ((long long)n_steps * batch >= (1LL << 25))
       return fail(SDEH_ERR_CAPACITY, "ctrl_backward (wide): n_steps * batch = %lld rows: the plane columns are addressed with 32-bit byte "
                                      "offsets per row tile (< 2^25 rows per call; split the batch)", (long long)n_steps * batch);
@@ -882,6 +894,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
     Aw.ws = plan->ws; Aw.lay = L; Aw.xs = xs; Aw.noise = noise; Aw.grad_rnd = grad_rnd; Aw.gextra = gextra;
     Aw.cost_ctrl = cost_ctrl; Aw.lam_extra = lam_extra; Aw.dx = dx_out;
     Aw.zt = zt; Aw.dt = dt; Aw.dout = dout; Aw.dgam = dgam; Aw.nn_in = nullptr; Aw.xt_out = xt_out;
+    Aw.sc_in = pr->target.kind == SDEH_DENS_GMM ? sc_in : nullptr; Aw.tscore_in = pr->target.kind == SDEH_DENS_GMM ? tscore_in : nullptr;
     Aw.batch = batch; Aw.row_offset = row_offset; Aw.n_steps = n_steps; Aw.d = pr->base_model.dim;
     Aw.loss_kind = pr->loss_kind; Aw.ctrl_kind = pr->ctrl_kind; Aw.flags = pr->flags; Aw.act = pr->base_model.activation;
     Aw.clip_model = pr->clip_model; Aw.clip_score = pr->clip_score; Aw.scale_score = pr->scale_score;

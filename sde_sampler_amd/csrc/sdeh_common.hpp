@@ -189,6 +189,8 @@ struct BwdArgs {
   const unsigned long long* rng_dev;
   const float* nn_in;  // [T, B, d] or null: with it, `zt` already holds the forward launch's pre-activations and is only read
   float* xt_out;       // [d, N] or null (wide plans): x_t coordinate-major, written next to the planes
+  const float* sc_in;      // [T, B, d] or null (wide plans, mixture targets): the score entering the control, from the forward launch
+  const float* tscore_in;  // [B, d] or null (wide plans, mixture targets, BPTT): 1[|log rho(x_T)| <= clip_target] target.score(x_T)
 };
 
 // sdeh_ctrl_backward_fused (sdeh_bwdf.hip): back-propagation + weight gradients in one kernel

@@ -190,7 +190,22 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
       const int cb = 32 * t + 4 * hv;  // register q <-> coordinate cb + (q & 3) + 8 (q >> 2)
       auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
       float sterm[16], psc[16];
-      wide_score_term16<GMM>(sq, cx, x, cb, c, fs[c], fx0[c], fiv[c], ws + L.gam + i * L.g, sterm, psc);
+      if constexpr (GMM) {
+        // training forward on a mixture target (sdeh_simulate_fwd_train2 on a wide plan): keep the combined score entering the control,
+        // row-major [T, B, d] -- the backward (sdeh_wide_bwd.hip) evaluates no mixture
+        float scr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) scr[q] = 0.0f;
+        wide_score_term16<GMM>(sq, cx, x, cb, c, fs[c], fx0[c], fiv[c], ws + L.gam + i * L.g, sterm, psc, A.sc_out != nullptr ? scr : nullptr);
+        if (A.sc_out != nullptr && live[c]) {
+          float* __restrict__ sp = A.sc_out + ((long long)i * A.batch + lrow[c]) * d + cb;
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (coord(q) < d) sp[(q & 3) + 8 * (q >> 2)] = scr[q];
+        }
+      } else {
+        wide_score_term16<GMM>(sq, cx, x, cb, c, fs[c], fx0[c], fiv[c], ws + L.gam + i * L.g, sterm, psc);
+      }
       SDEH_FENCE();
       // ---- Gaussian draws: register group g4 = coordinates cb + 8 g4 .. + 3 = Philox block (cb + 8 g4) / 4 ------------------------
       float n[16];
@@ -320,6 +335,31 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
         const int cc = 32 * (w + 4 * k) + rho(q, h);
         if (k < nto && cc < d && live[c]) A.xT[lrow[c] * d + cc] = xr[k][c][q];
       }
+  if constexpr (GMM) {
+    // training forward (method kl): 1[|log rho(x_T)| <= clip_target] target.score(x_T), row-major [B, d] -- d (terminal cost) / d x_T,
+    // negated (the responsibilities of x_T were normalised behind the last publish; visible since the barrier above)
+    if (A.tsc_out != nullptr && tgt.kind == SDEH_DENS_GMM) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < nto) {
+#pragma unroll
+          for (int c = 0; c < CT; ++c) {
+            const int cb = 32 * (w + 4 * k) + 4 * h, col = 32 * c + j;
+            float sc[16];
+            wide_gmm_score16(cx, gm, xr[k][c], cb, col, sc);
+            const float lp = gm.lse[col] + tgt.lnc;
+            const float keep = fabsf(lp) <= A.clip_target ? 1.0f : 0.0f;
+            if (live[c]) {
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                const int cc = cb + (q & 3) + 8 * (q >> 2);
+                if (cc < d) A.tsc_out[lrow[c] * d + cc] = keep * sc[q];
+              }
+            }
+          }
+        }
+    }
+  }
 }
 
 inline size_t wide_lds_bytes(const WsLayout& L, int ct, int n_planes, int K) {

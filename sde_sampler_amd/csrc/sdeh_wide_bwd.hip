@@ -275,8 +275,10 @@ __global__ __launch_bounds__(256) void wide_bwd_kernel(const BwdArgs A, int n_ti
             const float2 pp = *reinterpret_cast<const float2*>(cx.tab2 + 2 * cc);
             v = wi * (pp.x - xr[k][0][q]) * pp.y;
           }
-          if (flags & SDEH_FLAG_TERMINAL_TARGET)
-            v = fmaf(-wi * keep, wide_target_score(tgt, cx.tab0, cc, d, xr[k][0][q], fs, fx0, fiv), v);
+          if (flags & SDEH_FLAG_TERMINAL_TARGET) {
+            if (A.tscore_in != nullptr) v = fmaf(-wi, (cc < d ? A.tscore_in[lrow * d + cc] : 0.0f), v);  // (the clip indicator is in the plane)
+            else v = fmaf(-wi * keep, wide_target_score(tgt, cx.tab0, cc, d, xr[k][0][q], fs, fx0, fiv), v);
+          }
           lam[k][q] = cc < d ? v : 0.0f;
         }
       }
@@ -357,7 +359,19 @@ __global__ __launch_bounds__(256) void wide_bwd_kernel(const BwdArgs A, int n_ti
         float sc[16], psc[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) sc[q] = psc[q] = 0.0f;
-        if (has_score || need_p) wide_score_mix16(sq, cx, x, cb, 0, fs, fx0, fiv, sc, psc);
+        if (A.sc_in != nullptr) {  // mixture target: the forward launch's score plane stands in (no mixture is evaluated here)
+          const f32x16 sv = wide_row16(A.sc_in + n * d, cb, d, vec4);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) sc[q] = sv[q];
+          if (need_p) {  // the prior score alone (the reference control of EulerDDS)
+            WideScore sp = sq;
+            sp.ctrl_kind = SDEH_CTRL_CLIPPED;
+            float dummy[16];
+            wide_score_mix16(sp, cx, x, cb, 0, fs, fx0, fiv, dummy, psc);
+          }
+        } else if (has_score || need_p) {
+          wide_score_mix16(sq, cx, x, cb, 0, fs, fx0, fiv, sc, psc);
+        }
         SDEH_FENCE();
         float xi[16];
         if (ito) {

@@ -502,10 +502,14 @@ __device__ __forceinline__ void wide_score_mix16(const WideScore& S, const WideC
 template <bool GMM = false>
 __device__ __forceinline__ void wide_score_term16(const WideScore& S, const WideCtx& cx, const f32x16& x, int cb, int c, float fs,
                                                   float fx0, float fiv, const float* __restrict__ gam_row, float (&sterm)[16],
-                                                  float (&psc)[16]) {
+                                                  float (&psc)[16], float* __restrict__ sc_raw = nullptr) {
   auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
   float sc[16];
   wide_score_mix16<GMM>(S, cx, x, cb, c, fs, fx0, fiv, sc, psc);
+  if (sc_raw != nullptr && S.ctrl_kind != SDEH_CTRL_CLIPPED) {  // training forward on a mixture target: the score before clip / gamma
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sc_raw[q] = sc[q];
+  }
   if (S.ctrl_kind != SDEH_CTRL_CLIPPED) {
     if (S.g == 1) {
 #pragma unroll

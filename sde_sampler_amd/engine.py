@@ -538,6 +538,21 @@ class TrajectoryEngine:
                 # wide networks (csrc/sdeh_wide_bwd.hip): the forward keeps the trajectory only; the backward re-evaluates the network
                 # on the matrix pipe at the stored states
                 xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
+                if pr.target.kind == L.DENS_GMM:
+                    # mixture target: the backward evaluates no mixture -- the forward keeps the score entering the control and (kl) the
+                    # terminal target score, row-major (sdeh_simulate_fwd_train2 on a wide plan)
+                    need_sc = pr.ctrl_kind in (L.CTRL_SCORE, L.CTRL_LERP, L.CTRL_LERP_TARGET)
+                    bptt = not (pr.flags & L.FLAG_CHANGE_SDE_CTRL)
+                    sc = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32) if need_sc else None
+                    tscore = (torch.empty((batch, dim), device=device, dtype=torch.float32)
+                              if bptt and (pr.flags & L.FLAG_TERMINAL_TARGET) else None)
+                    with torch.cuda.device(device):
+                        status = lib.sdeh_simulate_fwd_train2(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
+                                                              seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
+                                                              rnd.data_ptr(), xs.data_ptr(), None if sc is None else sc.data_ptr(),
+                                                              None if tscore is None else tscore.data_ptr(), stream)
+                    L.check(status if status < 0 else 0)
+                    return x_T, rnd, xs, ("wide", sc, tscore)
                 with torch.cuda.device(device):
                     L.check(lib.sdeh_simulate_fwd_aux(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
                                                       seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(), rnd.data_ptr(),

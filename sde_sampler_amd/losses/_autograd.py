@@ -27,7 +27,8 @@ def _ctrl_parameters(ctrl) -> list[torch.nn.Parameter]:
     return [p for p in ctrl.parameters() if p.requires_grad]
 
 
-def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None, lam_extra=None, dx_out=None, planes=None):
+def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None, lam_extra=None, dx_out=None, planes=None,
+                   sc_in=None, tscore_in=None):
     """Runs sdeh_ctrl_backward_ex for the control in the problem's generative slots; returns the planes.  `planes` = (zt, nn) kept
     by the training forward (sdeh_simulate_fwd_train): the kernel then reads them instead of re-evaluating the network."""
     dev = xs.device
@@ -50,7 +51,7 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
             plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
             None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
             w.data_ptr(), ptr(gextra), ptr(cost_ctrl), ptr(lam_extra), ptr(dx_out), zt.data_ptr(), dt.data_ptr(),
-            dout.data_ptr(), dgam.data_ptr(), ptr(nn_in), ptr(xt), stream))
+            dout.data_ptr(), dgam.data_ptr(), ptr(nn_in), ptr(xt), ptr(sc_in), ptr(tscore_in), stream))
     return (zt, dt, dout, dgam) if xt is None else (zt, dt, dout, dgam, xt)
 
 
@@ -303,6 +304,9 @@ class _TrajectoryFn(torch.autograd.Function):
         kept = st.get("planes")
         if kept is not None and kept[0] == "fused":
             grads = _fused_backward(loss, pr, keep, ts, xs, w, st, kept[1], kept[2])
+        elif kept is not None and kept[0] == "wide":  # wide network on a mixture target: the forward launch's score planes
+            planes = _ctrl_backward(loss.engine, pr, keep, ts, xs, w, st, sc_in=kept[1], tscore_in=kept[2])
+            grads = _weight_grads(loss.generative_ctrl, ts, xs, *planes)
         else:
             planes = _ctrl_backward(loss.engine, pr, keep, ts, xs, w, st, planes=kept)
             grads = _weight_grads(loss.generative_ctrl, ts, xs, *planes)

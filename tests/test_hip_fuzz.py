@@ -234,7 +234,7 @@ def check_training_case(case, num_layers=None, expect_kernel=None, spec_hook=Non
         if expect_kernel is not None and not kernel.startswith("traj_legacy"):  # (legacy forward: mixture tables beyond LDS, plane path)
             assert kernel.startswith(expect_kernel), kernel
     except SdehUnsupported as exc:  # a documented limit, e.g. a wide mixture next to the transposed weights in LDS
-        if "do not fit in LDS" in str(exc) or "wide-network training: mixture targets" in str(exc):
+        if "do not fit in LDS" in str(exc):
             pytest.skip(str(exc)[:120])
         raise
     tag = f"case {case}: {method} {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"

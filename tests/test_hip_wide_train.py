@@ -138,7 +138,10 @@ def test_random_wide_training_gradients_match_oracle(case):
     tests/test_hip_fuzz.py (mixture targets are a documented limit of the wide backward and are skipped)."""
     from tests.test_hip_fuzz import check_training_case
 
-    check_training_case(11000 + case, spec_hook=_widen_train, expect_kernel="bwd_wide")
+    # (ReLU networks: twice the kink allowance of the 64-channel sweep -- 128 / 256 units per layer and d up to 250 inputs put more
+    # pre-activations within rounding of zero; case 132: one flipped unit of the input layer = 5.6e-2 of input_embed.weight's gradient,
+    # float64 on the oracle's side of the kink)
+    check_training_case(11000 + case, spec_hook=_widen_train, expect_kernel="bwd_wide", relu_tol_scale=2.0)
 
 
 @pytest.mark.parametrize("case", range(8 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))

@@ -288,6 +288,46 @@ def extra_block(device, B: int) -> dict:
         out["train_step_" + name + ("" if bt == B else f"_b{bt}")] = {"method": "kl", "batch": bt, "steps": T, "forward_kernel_ms": min(t_f[1:]), "backward_kernel_ms": tb,
                                      "backward_kernel": bwd_name, "backward_algorithmic_tflops": tf,
                                      "backward_frac": tf / PEAK_FP32_TFLOPS}
+    # Training on the wide networks (csrc/sdeh_wide_bwd.hip; `--workload train_cfg5_like | train_wide_pis_lv` are the full-size runs):
+    # configs[4]'s shape -- Bridge lv, two C = 256 networks, exact divergence, B = 4096 per GPU -- at T = 20 of its 200 steps (the
+    # kernels' time per step does not depend on T), and a plain PIS-style network of that width at B = 8192, T = 200
+    for name, bt, steps in (("cfg5_like_bridge196", 4096, 20), ("wide_pis_funnel196", 8192, 200)):
+        spec = problems.baseline_spec(name)
+        spec["batch"], spec["grid"]["steps"], spec["loss"]["method"] = bt, steps, "lv"
+        prob = problems.build(spec, device=device)
+        eng = prob.loss.engine
+        eng.timing = True
+        inf = getattr(prob.loss, "inference_ctrl", None)
+        x0 = prob.prior.sample((bt,))
+        t_f, t_k, t_b = [], [], []
+        for rep in range(3):
+            for m in (prob.ctrl, inf):
+                if m is not None:
+                    m.zero_grad()
+            val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+            torch.cuda.synchronize()
+            t_f.append(eng.last_kernel_ms())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            val.backward()
+            e1.record()
+            e1.synchronize()
+            t_k.append(eng.last_kernel_ms())
+            t_b.append(e0.elapsed_time(e1))
+            kname = eng.last_kernel_name()
+        d, c, lh = spec["target"]["dim"], spec["net"]["channels"], spec["net"]["num_layers"] - 2
+        f_net = 4 * d * c + 2 * lh * c * c
+        bridge = inf is not None
+        f_dom, f_exec = (8 * d * c * c, 14 * d * c * c) if bridge else (f_net, 2 * f_net)
+        f_bwd = (4 * f_net + 8 * d * c * c) if bridge else 2 * f_net
+        rows = bt * steps
+        out["train_step_wide_" + name] = {
+            "method": "lv", "batch": bt, "steps": steps, "forward_kernel_ms": min(t_f[1:]), "backward_ms": min(t_b[1:]),
+            "dominant_kernel": kname, "dominant_kernel_ms": min(t_k[1:]),
+            "dominant_frac_algorithmic": f_dom * rows / (min(t_k[1:]) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+            "dominant_frac_executed": f_exec * rows / (min(t_k[1:]) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+            "backward_frac_algorithmic": f_bwd * rows / (min(t_b[1:]) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+        del prob, x0
     return out
 
 

@@ -265,3 +265,15 @@ def test_sinkhorn_argument_checks_mirror_the_reference():
         sk.compute(x, torch.zeros(5, 2), w_x=torch.ones(4) / 4)  # only one weight vector
     with pytest.raises(RuntimeError, match="no CPU path"):
         sk.compute(x, torch.zeros(5, 2))
+
+
+def test_committed_pmc_record_belongs_to_the_headline_kernel_in_this_tree():
+    """profiles/pmc_headline.json is stamped with the hash of the headline trajectory kernel's sources (bench.py:
+    HEADLINE_KERNEL_SOURCES); bench.py reports `roofline.traffic` / `executed_tflops` only while the stamp matches.  A change to
+    those sources needs a new PMC pass (tools/pmc_profile.sh) or -- when the kernel's code did not change -- a re-stamp
+    (tools/pmc_headline_json.py on the kept summary)."""
+    import bench
+
+    rec = bench.pmc_record()
+    assert rec is not None, "profiles/pmc_headline.json is stale: kernel_sha != bench.headline_kernel_sha()"
+    assert rec["kernel_sha"] == bench.headline_kernel_sha() and rec["FETCH_SIZE_KiB"] > 0 and rec["SQ_INSTS_MFMA"] > 0

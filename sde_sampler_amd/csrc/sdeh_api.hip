@@ -1003,7 +1003,6 @@ int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, con
   if (rc != SDEH_OK) return fail(rc, "bridge_div_backward_wide: second prep kernel launch failed");
   // scratch: [xpart side 1][xpart side 0][cpart side 1][cpart side 0][spart][sums]
   float* xp1 = scratch; float* xp0 = xp1 + xp; float* cp1 = xp0 + xp; float* cp0 = cp1 + cp; float* sp0 = cp0 + cp; float* sm = sp0 + cp;
-  if (hipMemsetAsync(cp1, 0, (size_t)(3 * cp) * sizeof(float), st) != hipSuccess) return fail(SDEH_ERR_HIP, "bridge_div_backward_wide: memset failed");
   WideDivArgs A;
   memset(&A, 0, sizeof(A));
   A.ws = plan->ws; A.lay = ck.L; A.ws2 = plan->ws + ck.L.total; A.lay2 = L2;

@@ -159,8 +159,8 @@ struct WideDivArgs {
   float* dgam;            // [g, N] (side 0)
   float* dx;              // [T, B, d] or null: d loss / d x_t, the divergence term's share ADDED (side 0; method kl)
   float* xpart;           // [grid][C][C] partial of dX
-  float* cpart;           // [grid][d][C] partial of d L / d col_q  (zeroed by the caller)
-  float* spart;           // [grid][d][C] partial of d L / d W_out (Lh = 1 only, side 0; zeroed by the caller)
+  float* cpart;           // [grid][d][C] partial of d L / d col_q  (zeroed by the kernel)
+  float* spart;           // [grid][d][C] partial of d L / d W_out (Lh = 1 only, side 0; zeroed by the kernel)
   long long batch;
   int n_steps, d, inf_kind, act, side;
   float clip_model, clip_score, scale_score;

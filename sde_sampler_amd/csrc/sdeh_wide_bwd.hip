@@ -734,6 +734,13 @@ __global__ __launch_bounds__(256) void wide_bridge_div_bwd_kernel(const WideDivA
   float* __restrict__ spart = A.spart != nullptr ? A.spart + (long long)blockIdx.x * d * C : nullptr;
   auto bidx = [&](int ot, int q) { return (4 * ot + (q >> 2)) * 8 + (q & 1) * 4 + ((q >> 1) & 1) + 2 * h; };  // B order of channel 32 ot + rho(q, h)
 
+  // this workgroup's partial tables start at zero (written here, not by a memset node: inside a replayed hipGraph a captured
+  // hipMemsetAsync in front of these launches was not reliably re-executed on this stack -- the tables kept accumulating from the
+  // second replay on, tests/test_hip_graphs.py)
+  for (int i = tid; i < d * C; i += 256) {
+    cpart[i] = 0.0f;
+    if (spart != nullptr) spart[i] = 0.0f;
+  }
   const long long n_items = (long long)n_tiles * T;
   __syncthreads();
   for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {

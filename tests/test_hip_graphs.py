@@ -42,6 +42,10 @@ def _build(seed=0, method="lv"):
                     ctrl=dict(kind="lerp_target", **lerp), inference_ctrl=dict(kind="lerp_prior", **lerp),
                     net=dict(channels=64, num_layers=4, activation="gelu"),
                     loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=50))
+    elif method.startswith("wide"):  # wide networks (csrc/sdeh_wide_bwd.hip): "wide_lv" / "wide_kl" plain, "wide_bridge" configs[4]'s shape
+        spec = problems.baseline_spec("cfg5_like_bridge196" if method == "wide_bridge" else "wide_pis_funnel196")
+        spec["grid"]["steps"] = 6 if method == "wide_bridge" else 12
+        spec["loss"]["method"] = "kl" if method == "wide_kl" else "lv"
     else:
         spec = problems.baseline_spec("cfg1_dw_dis_lv")
         spec["loss"]["method"] = method
@@ -158,7 +162,8 @@ def test_graphed_step_skips_non_finite_updates_on_device():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("method,batch", [("lv", 2048), ("kl", 2048), ("bridge", 2048), ("lv", 65536), ("kl", 40000), ("bridge", 16384)])
+@pytest.mark.parametrize("method,batch", [("lv", 2048), ("kl", 2048), ("bridge", 2048), ("lv", 65536), ("kl", 40000), ("bridge", 16384),
+                                          ("wide_lv", 2048), ("wide_kl", 1000), ("wide_bridge", 256)])
 def test_replayed_gradients_equal_eager_gradients(method, batch):
     """Every parameter gradient of forward + backward replayed from a hipGraph (three replays) against the eager launch at the
     same Philox offset.  Guards against ordering / buffer-reuse hazards of captured steps (a multi-block framework reduction

@@ -1,3 +1,4 @@
+"""Diagnostic: fills the caching allocator with NaN / 1e30 / -3 before a wide training step and compares every gradient bitwise with a clean run -- an uninitialised read of a work buffer shows up as a difference (python tests/perf/poison_uninitialised_reads.py [wide_bridge|wide_lv|wide_kl] [batch])."""
 import sys, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import test_hip_graphs as G

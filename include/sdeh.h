@@ -301,6 +301,13 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* problem, const 
                               const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, float* x_T, float* rnd, float* xs, float* gp, const float* div_noise,
                               void* stream);
+/* sdeh_simulate_fwd_aux that also keeps, on a WIDE plan with a MIXTURE target, what sdeh_ctrl_backward_ex reads for the generative
+ * control of a Bridge (row-major, either may be NULL): sc [n_steps, batch, d] the score entering the generative control,
+ * tscore [batch, d] = 1[|target.unnorm_log_prob(x_T)| <= clip_target] target.score(x_T).  Other targets: nothing is written. */
+int32_t sdeh_simulate_fwd_aux2(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
+                               const float* x0, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                               int64_t row_offset, float* x_T, float* rnd, float* xs, float* gp, const float* div_noise,
+                               float* sc, float* tscore, void* stream);
 
 /*
  * Fused training backward (csrc/sdeh_bwdf.hip): what `loss.backward()` does in the reference (solver/base.py:407 through the

@@ -119,6 +119,8 @@ PROTOTYPES = {
                                        C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_simulate_fwd_aux": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
                                           C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_simulate_fwd_aux2": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
+                                           C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_simulate_fwd_train": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,
                                             C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_void_p]),
     "sdeh_simulate_fwd_train2": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp,

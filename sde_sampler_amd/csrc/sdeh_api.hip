@@ -446,8 +446,6 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   if (plan->wide) {  // wide networks (sdeh_wide.hip, sdeh_wide_bwd.hip)
     if (integrate)
       return fail(SDEH_ERR_UNSUPPORTED, "networks with %d channels (or d > 64) have no plain integrator (channels = 64 with d <= 64 has)", net.channels);
-    if (need_target && pr->target.kind == SDEH_DENS_GMM && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
-      return fail(SDEH_ERR_UNSUPPORTED, "wide Bridge kernel: mixture targets are not built in (Gaussian, double-well and funnel targets are)");
     if ((pr->flags & SDEH_FLAG_INFERENCE_CTRL) && net.channels < 128)
       return fail(SDEH_ERR_UNSUPPORTED, "Bridge with d > 64 needs channels = 128 or 256 (the wide Bridge kernel splits >= 4 row tiles over its waves)");
     out->L = make_wide_layout(d, net.channels, net.n_hidden, n_steps, g, false, need_target && pr->target.kind == SDEH_DENS_GMM ? k : 0, backward);
@@ -576,9 +574,8 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
                          void* stream, const Checked& ck, float* gp, const float* div_noise, float* sc_out, float* tsc_out) {
   // (training: the wide forward keeps no network planes -- the caller's backward re-evaluates the network at the stored trajectory,
   // sdeh_wide_bwd.hip; what it keeps for a MIXTURE target is the score entering the control, sc_out [T, B, d], and the terminal target
-  // score, tsc_out [B, d] (sdeh_simulate_fwd_train2 on a wide plan); Hutchinson probes are a 64-channel feature)
-  if ((sc_out != nullptr || tsc_out != nullptr) && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
-    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train2 (wide): the Bridge forward keeps no score planes");
+  // score, tsc_out [B, d] (sdeh_simulate_fwd_train2 on a wide plan; Bridges: sdeh_simulate_fwd_aux2); Hutchinson probes are a
+  // 64-channel feature)
   if (div_noise != nullptr)
     return fail(SDEH_ERR_UNSUPPORTED, "wide-network Bridge: the Hutchinson divergence estimators are built for channels = 64 "
                                       "(the exact divergence is built in)");
@@ -763,6 +760,17 @@ int32_t sdeh_simulate_fwd_aux(SdehPlan* plan, const SdehProblem* pr, const float
                               float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, void* stream) {
   return simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, gp, div_noise, nullptr,
                        nullptr, nullptr, stream);
+}
+
+int32_t sdeh_simulate_fwd_aux2(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                               int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                               float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, float* sc, float* tscore,
+                               void* stream) {
+  if ((sc != nullptr || tscore != nullptr) && (plan == nullptr || !plan->wide))
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_aux2: sc / tscore are written by the wide-network kernels only (64-channel Bridges: the "
+                                  "backward kernels evaluate the mixture themselves)");
+  return simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, gp, div_noise, nullptr,
+                       nullptr, nullptr, stream, sc, tscore);
 }
 
 int32_t sdeh_simulate_fwd_train(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,

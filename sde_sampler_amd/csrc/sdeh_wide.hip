@@ -535,7 +535,10 @@ __device__ __forceinline__ void wide_tangent_pass2(const float* __restrict__ wgr
   wide_vmwait<0, 2>(a[0]);  // drain the clamped re-read issued by the last iteration
 }
 
-template <int OTW>  // C = 128 OTW
+// GMM: mixture targets (distr/gauss.py:66-140) compiled in.  The divergence leaves no LDS for mixture tables at C = 256, so they are
+// read from the workspace (L2: K d floats per trajectory and step next to the d C^2 of the divergence), and the partial logits /
+// responsibilities take the act' planes' place between the divergence and the next step's inference pass.
+template <int OTW, bool GMM>  // C = 128 OTW
 __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int split, float* __restrict__ divparts) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int CT = 1, RS = 32, OT = 4 * OTW, C = 128 * OTW;
@@ -572,6 +575,13 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
   const float* bias_v = ws2 + L2.b_hid;  // inference network
   for (int i = tid; i < 4 * 8 * RS; i += 256) divacc[i] = 0.0f;
   cx.bias = bias_u;
+  WideGmm gm{};
+  if constexpr (GMM) {
+    gm.K = A.target.kind == SDEH_DENS_GMM ? A.target.n_comp : 0;
+    gm.d4 = L.gmm_row;
+    gm.mu = ws + L.gmm_lg; gm.a = ws + L.gmm_sc; gm.ck = ws + L.gmm_c;
+    gm.part = dplanes; gm.resp = dplanes + 4 * gm.K * RS; gm.lse = gm.resp + gm.K * RS;
+  }
 
   const int nto = (OTD > w ? 1 : 0) + (OTD > w + 4 ? 1 : 0);
   const long long row0 = (long long)tile * RS;
@@ -796,14 +806,36 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
     WideScore sq;
     sq.ctrl_kind = ctrl_kind; sq.g = L.g; sq.need_t = need_t; sq.need_p = need_p; sq.tgt = tgt; sq.wl = wl;
     sq.mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;
-    sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = as_const(ws + L.gam + i * L.g)[0]; sq.d = d; sq.gmm = nullptr;
+    sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = as_const(ws + L.gam + i * L.g)[0]; sq.d = d; sq.gmm = &gm;
+    if constexpr (GMM) {
+      if (need_t && tgt.kind == SDEH_DENS_GMM) {  // responsibilities of x_i (the act' planes are free: every wave is through its coordinates)
+        wide_barrier();
+        wide_gmm_partials<CT>(cx, gm, xr, nto);
+        wide_barrier();
+        if (w == 0) wide_gmm_normalise<CT>(cx, gm);
+        wide_barrier();
+      }
+    }
     const float g20 = as_const(ws2 + L2.gam + i * L2.g)[0];
     float costl = 0.0f, itol = 0.0f, divs = 0.0f;
     auto vtile = [&](f32x16& x, const f32x16& nuv, const f32x16& nvv, int t) {
       const int cb = 32 * t + 4 * hv;
       auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
       float sterm[16], psc[16];
-      wide_score_term16(sq, cx, x, cb, 0, fs, fx0, fiv, ws + L.gam + i * L.g, sterm, psc);
+      if constexpr (GMM) {  // training forward: the combined score entering the control, row-major [T, B, d] (as traj_wide_kernel)
+        float scr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) scr[q] = 0.0f;
+        wide_score_term16<GMM>(sq, cx, x, cb, 0, fs, fx0, fiv, ws + L.gam + i * L.g, sterm, psc, A.sc_out != nullptr ? scr : nullptr);
+        if (A.sc_out != nullptr && live && lead) {
+          float* __restrict__ sp = A.sc_out + ((long long)i * A.batch + lrow) * d + cb;
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (coord(q) < d) sp[(q & 3) + 8 * (q >> 2)] = scr[q];
+        }
+      } else {
+        wide_score_term16(sq, cx, x, cb, 0, fs, fx0, fiv, ws + L.gam + i * L.g, sterm, psc);
+      }
       SDEH_FENCE();
       float n[16];
       wide_noise16(A.noise != nullptr ? A.noise + ((long long)i * A.batch + lrow) * d : nullptr, vec4, cb, d, A.seed, rng_off, grow, i, n);
@@ -884,6 +916,13 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
   if (flags & SDEH_FLAG_TERMINAL_TARGET) {
     if (tgt.kind == SDEH_DENS_DIAG_GAUSS) wide_gauss_quad<CT>(cx, cx.tab0, xr, nto, WSL_LOGP_B);
     else if (tgt.kind == SDEH_DENS_MULTI_WELL) wide_mwell_sum<CT>(cx, tgt, xr, nto, WSL_LOGP_B);
+    if constexpr (GMM) {
+      if (tgt.kind == SDEH_DENS_GMM) {  // log-density (and responsibilities) of x_T
+        wide_gmm_partials<CT>(cx, gm, xr, nto);
+        __syncthreads();
+        if (w == 0) wide_gmm_normalise<CT>(cx, gm);
+      }
+    }
   }
   __syncthreads();
   if (w == 0 && h == 0) {
@@ -897,10 +936,33 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
         const float first = -0.5f * __logf(6.283185307179586f * tgt.p0) - 0.5f * x0v * x0v / tgt.p0;
         const float other = -(float)(d - 1) * (x0v + 1.8378770664093453f) * 0.5f - 0.5f * sqs * __expf(-x0v);
         lp = first + other + tgt.lnc;
+      } else if (GMM && tgt.kind == SDEH_DENS_GMM) {
+        lp = gm.lse[j] + tgt.lnc;
       }
       rr -= clipf(lp, A.clip_target);
     }
     if (live) A.rnd[row0 + j] = rr;
+  }
+  if constexpr (GMM) {
+    // training forward (method kl): 1[|log rho(x_T)| <= clip_target] target.score(x_T), row-major [B, d]
+    if (A.tsc_out != nullptr && tgt.kind == SDEH_DENS_GMM && (flags & SDEH_FLAG_TERMINAL_TARGET)) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+        if (k < nto) {
+          const int cb = 32 * (w + 4 * k) + 4 * h;
+          float sc[16];
+          wide_gmm_score16(cx, gm, xr[k][0], cb, j, sc);
+          const float lp = gm.lse[j] + tgt.lnc;
+          const float keep = fabsf(lp) <= A.clip_target ? 1.0f : 0.0f;
+          if (live) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const int cc = cb + (q & 3) + 8 * (q >> 2);
+              if (cc < d) A.tsc_out[lrow * d + cc] = keep * sc[q];
+            }
+          }
+        }
+    }
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k)
@@ -921,27 +983,30 @@ __global__ void bridge_wide_finish(float* __restrict__ rnd, const float* __restr
   rnd[row] += s;
 }
 
-inline size_t bridge_wide_lds_bytes(const WsLayout& L, const WsLayout& L2) {
+inline size_t bridge_wide_lds_bytes(const WsLayout& L, const WsLayout& L2, int K) {
   const int rows = L.c > 32 * L.otd ? L.c : 32 * L.otd;
-  return ((size_t)rows * 32 + (size_t)(L2.n_hidden + 1) * L.c * 32 + kWideSlots * 4 * 32 + 4 * 8 * 32 + 4 * 4 * L.c + 3 * (2 * L.dp + 4)) * sizeof(float);
+  size_t dpl = (size_t)(L2.n_hidden + 1) * L.c * 32;
+  const size_t gmm = K > 0 ? (size_t)5 * K * 32 + 32 : 0;  // partial logits + responsibilities + logsumexp share the act' planes
+  if (gmm > dpl) dpl = gmm;
+  return ((size_t)rows * 32 + dpl + kWideSlots * 4 * 32 + 4 * 8 * 32 + 4 * 4 * L.c + 3 * (2 * L.dp + 4)) * sizeof(float);
 }
 
 long long bridge_wide_scratch_floats(long long batch) { return ((batch + 31) / 32) * kDivGroups * 32; }
 
-template <int OTW>
+template <int OTW, bool GMM>
 static int launch_bridge_wide_t(const TrajArgs& a, hipStream_t stream, int split, float* scratch) {
-  const size_t lds_bytes = bridge_wide_lds_bytes(a.lay, a.lay2);
+  const size_t lds_bytes = bridge_wide_lds_bytes(a.lay, a.lay2, GMM ? a.target.n_comp : 0);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_wide_kernel<OTW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bridge_wide_kernel<OTW, GMM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
   const long long tiles = (a.batch + 31) / 32;
-  hipLaunchKernelGGL((bridge_wide_kernel<OTW>), dim3((unsigned)(tiles * split)), dim3(256), lds_bytes, stream, a, split, scratch);
+  hipLaunchKernelGGL((bridge_wide_kernel<OTW, GMM>), dim3((unsigned)(tiles * split)), dim3(256), lds_bytes, stream, a, split, scratch);
   hipLaunchKernelGGL(bridge_wide_finish, dim3((unsigned)((a.batch + 255) / 256)), dim3(256), 0, stream, a.rnd, scratch, a.batch);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
@@ -955,8 +1020,13 @@ int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used, f
   if (force != nullptr && (force[0] == '1' || force[0] == '2' || force[0] == '4' || force[0] == '8')) split = force[0] - '0';
   if (split_used != nullptr) *split_used = split;
   const int otw = a.lay.c / 128;
-  if (otw == 2) return launch_bridge_wide_t<2>(a, stream, split, scratch);
-  if (otw == 1) return launch_bridge_wide_t<1>(a, stream, split, scratch);
+  if (a.target.kind == SDEH_DENS_GMM && a.target.n_comp > 0) {
+    if (otw == 2) return launch_bridge_wide_t<2, true>(a, stream, split, scratch);
+    if (otw == 1) return launch_bridge_wide_t<1, true>(a, stream, split, scratch);
+    return SDEH_ERR_UNSUPPORTED;
+  }
+  if (otw == 2) return launch_bridge_wide_t<2, false>(a, stream, split, scratch);
+  if (otw == 1) return launch_bridge_wide_t<1, false>(a, stream, split, scratch);
   return SDEH_ERR_UNSUPPORTED;
 }
 

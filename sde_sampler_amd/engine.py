@@ -489,7 +489,8 @@ class TrajectoryEngine:
             return_traj: bool, keep: _Keep, row_offset: int = 0, seed: int | None = None, want_gp: bool = False,
             div_noise: torch.Tensor | None = None, want_planes: bool = False):
         """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None); with `want_gp`
-        (Bridge training) additionally the plane u + v [T,B,d] as a fourth element; with `want_planes` (training without an
+        (Bridge training) additionally the plane u + v [T,B,d] as a fourth element and, fifth, (sc [T,B,d] | None, tscore [B,d] | None)
+        -- the score planes a wide Bridge on a mixture target keeps for its generative network's backward; with `want_planes` (training without an
         inference control) a fourth element: ("fused", sc [T,d,B] | None, tscore [d,B] | None) when the fused backward takes the
         problem (xs is then the coordinate-major [T+1,d,B] plane), else (zt [(Lh+1),C,T*B], nn [T,B,d]); None when the launch kept nothing."""
         if not x.is_cuda:
@@ -589,13 +590,23 @@ class TrajectoryEngine:
             return x_T, rnd, xs, ((zt, nn) if status == 0 else None)  # 1: served by a kernel that keeps no planes
         if return_traj:
             xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
+        sc = tscore = None
+        if want_gp and pr.target.kind == L.DENS_GMM and (pr.base_model.channels != 64 or dim > 64):
+            # training forward of a wide Bridge on a mixture target: the backward of the generative network evaluates no mixture -- keep
+            # the score entering it and (kl) the terminal target score, as the plain wide training forward does
+            if pr.ctrl_kind in (L.CTRL_SCORE, L.CTRL_LERP, L.CTRL_LERP_TARGET):
+                sc = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32)
+            if not (pr.flags & L.FLAG_CHANGE_SDE_CTRL) and (pr.flags & L.FLAG_TERMINAL_TARGET):
+                tscore = torch.empty((batch, dim), device=device, dtype=torch.float32)
         with torch.cuda.device(device):
-            L.check(lib.sdeh_simulate_fwd_aux(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
-                                              seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
-                                              rnd.data_ptr(), None if xs is None else xs.data_ptr(),
-                                              None if gp is None else gp.data_ptr(), dn_p, stream))
+            L.check(lib.sdeh_simulate_fwd_aux2(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
+                                               seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
+                                               rnd.data_ptr(), None if xs is None else xs.data_ptr(),
+                                               None if gp is None else gp.data_ptr(), dn_p,
+                                               None if sc is None else sc.data_ptr(),
+                                               None if tscore is None else tscore.data_ptr(), stream))
         if want_gp:
-            return x_T, rnd, xs, gp
+            return x_T, rnd, xs, gp, (sc, tscore)
         return x_T, rnd, xs
 
     # ------------------------------------------------------------------------------------------------------

@@ -338,10 +338,13 @@ class _BridgeFn(torch.autograd.Function):
         lv = bool(kw["flags"] & L.FLAG_CHANGE_SDE_CTRL)
         eng = loss.engine
 
+        sc_u, tscore_u = st.get("score_planes") or (None, None)  # wide Bridge on a mixture target (engine.run)
+
         def generative(**extra):  # lv: d rnd / d u = dB (the cost's u-derivative vanishes identically); kl: BPTT
             keep = E._Keep()
             pr_u = eng.build_problem(device=dev, keep=keep, **kw)
-            return _weight_grads(loss.generative_ctrl, ts, xs, *_ctrl_backward(eng, pr_u, keep, ts, xs, w, st, **extra))
+            return _weight_grads(loss.generative_ctrl, ts, xs,
+                                 *_ctrl_backward(eng, pr_u, keep, ts, xs, w, st, sc_in=sc_u, tscore_in=tscore_u, **extra))
 
         grads = generative() if lv else None
         # inference network, first order: d rnd / d v = (u + v) dt (+ dB with the Ito term); v does not drive the SDE, so this is
@@ -403,7 +406,7 @@ def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout
     out = torch.empty(n_out.value, device=dev, dtype=torch.float32)
     d2 = torch.empty((Lh + 1, Cn, N), device=dev, dtype=torch.float32)
     dgam2 = torch.zeros_like(dgam)
-    plan = eng._plan(dev, d, Cn, max(Lh, pr_b.base_model.n_hidden), T, 0)
+    plan = eng._plan(dev, d, Cn, max(Lh, pr_b.base_model.n_hidden), T, pr_b.target.n_components if pr_b.target.kind == L.DENS_GMM else 0)
     with torch.cuda.device(dev):
         L.check(lib.sdeh_bridge_div_backward_wide(
             plan.handle, C.byref(pr_b), keep_b.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B, w.data_ptr(), zt.data_ptr(),

@@ -322,6 +322,8 @@ class BaseOCLoss:
                              row_offset=row_offset, div_noise=div_noise)
                 if want_planes:
                     state["planes"] = out[3]  # (zt, nn) of the forward launch, or None
+                if want_gp:
+                    state["score_planes"] = out[4]  # (sc, tscore): wide Bridge on a mixture target, else (None, None)
                 return (x_T, rnd, xs, out[3], state) if want_gp else (x_T, rnd, xs, state)
             return x_T, rnd, xs
 

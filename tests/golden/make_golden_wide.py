@@ -117,6 +117,26 @@ BRIDGE_CASES = {
         net=dict(channels=128, num_layers=4, activation="gelu"),
         loss=dict(kind="time_reversal", method="kl", max_rnd=None),
         grid=dict(start=0.0, end=1.0, steps=8, rescale_t=None)),
+    # Bridges on MIXTURE targets (distr/gauss.py:66-140): the benchmark's 40-mode mixture, d = 50, with 128-channel networks
+    # (basic_bridge.yaml's controls, VP, lv) ...
+    "widebridge_gmm50_c128": dict(
+        B=24, seed=73, target=dict(kind="gmm", dim=50, name="fab50"), prior=ISO(50),
+        sde=dict(kind="vp", beta_min=0.1, beta_max=6.0, scale=1.0, terminal_t=1.0),
+        ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        inference_ctrl=dict(kind="lerp_prior", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        net=dict(channels=128, num_layers=4, activation="gelu"),
+        loss=dict(kind="time_reversal", method="lv", max_rnd=1e8),
+        grid=dict(start=0.0, end=1.0, steps=8, rescale_t=None)),
+    # ... and general scales / weights (7 components) at d = 72, C = 256: LerpCtrl generative (prior and target score), ClippedCtrl
+    # inference control on a 3-layer network, ScaledBM, kl
+    "widebridge_gmm72_c256": dict(
+        B=20, seed=79, target=dict(kind="gmm", dim=72, name="random7"), prior=ISO(72),
+        sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+        ctrl=dict(kind="lerp", clip_model=1e4, clip_score=1e4, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        inference_ctrl=dict(kind="clipped", clip_model=1e4),
+        net=dict(channels=256, num_layers=4, activation="gelu"), inference_net=dict(channels=256, num_layers=3, activation="silu"),
+        loss=dict(kind="time_reversal", method="kl", max_rnd=None),
+        grid=dict(start=0.0, end=1.0, steps=6, rescale_t=None)),
 }
 
 
@@ -197,6 +217,9 @@ def run_bridge_case(name, case):
     out.update(ts=ts.numpy(), x0=x0.numpy(), noise=noise.numpy())
     _eval_passes(out, loss, ts, x0, state, target.unnorm_log_prob, prior.log_prob, {"train": False})
     _train_passes(out, loss, (("grad", ctrl), ("grad_inf", inf)), ts, x0, state, target.unnorm_log_prob, prior.log_prob)
+    if case["target"]["kind"] == "gmm":
+        out["target/loc"], out["target/scale"] = target.loc.numpy(), target.scale.numpy()
+        out["target/mixture_weights"] = target.mixture_weights.numpy()
     _finish(name, case, out, ts, x0)
 
 

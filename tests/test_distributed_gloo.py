@@ -83,7 +83,7 @@ def _dp_worker(rank, world, port, q):
         share, metrics = loss_obj.compute_loss(rnd)
         share.backward()
         all_reduce_gradients([theta])
-        out[method] = (share.item(), metrics["train/loss_global"], theta.grad.clone(), loss_obj.n_filtered)
+        out[method] = (share.item(), metrics["train/loss_global"], theta.grad.tolist(), loss_obj.n_filtered)  # (plain lists: a tensor in the queue is an fd the parent must fetch while this process lives)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -131,5 +131,5 @@ def test_two_rank_training_loss_is_the_global_batch_loss():
         assert sum(shares) == pytest.approx(ref.item(), rel=1e-5)
         for r in range(world):
             assert results[r][method][1] == pytest.approx(ref.item(), rel=1e-5)
-            assert torch.allclose(results[r][method][2], theta.grad, rtol=1e-4, atol=1e-6), method
+            assert torch.allclose(torch.tensor(results[r][method][2]), theta.grad, rtol=1e-4, atol=1e-6), method
             assert results[r][method][3] == (2 if method == "lv_traj" else 1)

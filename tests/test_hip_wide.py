@@ -127,8 +127,8 @@ def test_wide_fast_mode_agrees_with_oracle_statistics():
     assert 0.8 < float(g.std() / o.std()) < 1.25
 
 
-def test_wide_mixture_agrees_with_the_narrow_kernels_and_wide_bridge_on_a_mixture_is_refused():
-    from sde_sampler_amd import SdehUnsupported, problems
+def test_wide_mixture_agrees_with_the_narrow_kernels_and_wide_bridge_runs_on_a_mixture():
+    from sde_sampler_amd import problems
 
     # (training through the wide kernels: tests/test_hip_wide_train.py)
     # the headline mixture (GMM-40 d=50) through a 128-channel network runs in the wide kernel ...
@@ -137,15 +137,24 @@ def test_wide_mixture_agrees_with_the_narrow_kernels_and_wide_bridge_on_a_mixtur
     gm = problems.build(spec, device=DEV)
     out = gm.eval(gm.prior.sample((300,)))
     assert gm.loss.engine.last_kernel_name() == "traj_wide<C=128,CT=1>" and torch.isfinite(out.samples).all()
-    # ... a Bridge on a mixture with wide networks is refused
+    # ... and so does a Bridge on a mixture with wide networks (parity: the widebridge_gmm* fixtures below); whatever the number of
+    # workgroups sharing a column tile, bit for bit
     lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
     bspec = dict(batch=64, target=dict(kind="gmm", dim=2, name="fab"), prior=dict(kind="iso_gauss", dim=2),
                  sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0), ctrl=dict(kind="lerp_target", **lerp),
                  inference_ctrl=dict(kind="lerp_prior", **lerp), net=dict(channels=128, num_layers=4, activation="gelu"),
                  loss=dict(kind="time_reversal", method="kl"), grid=dict(start=0.0, end=1.0, steps=8))
     br = problems.build(bspec, device=DEV)
-    with pytest.raises(SdehUnsupported, match="mixture"):
-        br.eval(br.prior.sample((64,)))
+    x0 = br.prior.sample((70,))
+    outs = []
+    for n in (1, 8):
+        with _split(n):
+            br.loss.engine.calls = 0
+            res = br.eval(x0)
+            assert br.loss.engine.last_kernel_name().startswith("bridge_wide<C=128")
+            outs.append((res.samples.clone(), res.weights.clone()))
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -249,15 +258,19 @@ def test_random_wide_problem_matches_oracle(case):
     check_eval_case(3000 + case, spec_hook=_widen, expect_kernel="traj_wide")
 
 
-def _random_wide_bridge_spec(rng):
+def _random_wide_bridge_spec(rng, mixture=False):
+    """mixture=False: closed-form targets (the seeds of the first sweeps); True: the same draw with a mixture target put in its place."""
     from tests.test_hip_fuzz import random_spec
 
     while True:
         spec = random_spec(rng)
-        if spec["loss"]["kind"] == "time_reversal" and spec["target"]["kind"] != "gmm":  # (the wide Bridge takes closed-form targets)
+        if spec["loss"]["kind"] == "time_reversal" and spec["target"]["kind"] != "gmm":
             break
     c = int(rng.choice([128, 256]))
     d = int(rng.choice([33, 44, 70, 100, 150, 196]))
+    if mixture:
+        d = int(rng.choice([33, 50, 70, 100]))
+        spec["target"] = dict(kind="gmm", dim=d, name="fab50" if d == 50 else "random7")
     for part in ("target", "prior"):
         if spec[part] is not None and "dim" in spec[part]:
             spec[part]["dim"] = d
@@ -282,10 +295,14 @@ def _random_wide_bridge_spec(rng):
     return spec
 
 
-@pytest.mark.parametrize("case", range(12 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))
-def test_random_wide_bridge_matches_oracle(case):
+_BRIDGE_SWEEP = ([(c, False) for c in range(12 * int(os.environ.get("SDEH_FUZZ_SCALE", "1")))] +
+                 [(c, True) for c in range(500, 500 + 6 * int(os.environ.get("SDEH_FUZZ_SCALE", "1")))])
+
+
+@pytest.mark.parametrize("case,mixture", _BRIDGE_SWEEP, ids=lambda v: str(v))
+def test_random_wide_bridge_matches_oracle(case, mixture):
     """Random Bridges (TimeReversalLoss with an inference control, exact divergence) on wide networks: x_T rows and the estimators
-    against the oracle (d backward passes per step through the inference network) on identical noise."""
+    against the oracle (d backward passes per step through the inference network) on identical noise.  Cases 500+: mixture targets."""
     import math
 
     from oracle import em_oracle as eo
@@ -293,12 +310,15 @@ def test_random_wide_bridge_matches_oracle(case):
     from tests.test_hip_fuzz import _close, _perturbed
 
     rng = np.random.default_rng(7000 + case)
-    spec = _random_wide_bridge_spec(rng)
+    spec = _random_wide_bridge_spec(rng, mixture)
     prob = problems.build(spec)
     inf = prob.loss.inference_ctrl
     params = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
     params_inf = {k: v.detach().clone() for k, v in inf.state_dict().items()}
-    oracle = eo.Problem(spec, params, None, params_inf)
+    tt = None
+    if spec["target"]["kind"] == "gmm":
+        tt = dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+    oracle = eo.Problem(spec, params, tt, params_inf)
     ts = prob.ts.clone()
     B, d, T = spec["batch"], spec["target"]["dim"], ts.numel() - 1
     torch.manual_seed(case)

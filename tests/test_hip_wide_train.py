@@ -144,10 +144,15 @@ def test_random_wide_training_gradients_match_oracle(case):
     check_training_case(11000 + case, spec_hook=_widen_train, expect_kernel="bwd_wide", relu_tol_scale=2.0)
 
 
-@pytest.mark.parametrize("case", range(8 * int(os.environ.get("SDEH_FUZZ_SCALE", "1"))))
-def test_random_wide_bridge_training_matches_oracle(case):
+_BRIDGE_TRAIN_SWEEP = ([(c, False) for c in range(8 * int(os.environ.get("SDEH_FUZZ_SCALE", "1")))] +
+                       [(c, True) for c in range(500, 500 + 4 * int(os.environ.get("SDEH_FUZZ_SCALE", "1")))])
+
+
+@pytest.mark.parametrize("case,mixture", _BRIDGE_TRAIN_SWEEP, ids=lambda v: str(v))
+def test_random_wide_bridge_training_matches_oracle(case, mixture):
     """Random Bridges on wide networks, methods lv and kl: loss and the gradients of BOTH networks against the oracle's autograd through the
-    exact divergence (d backward passes per step, create_graph=True)."""
+    exact divergence (d backward passes per step, create_graph=True).  Cases 500+: mixture targets (the generative network's backward
+    takes their scores from the forward launch's planes)."""
     import math
 
     from oracle import em_oracle as eo
@@ -156,7 +161,7 @@ def test_random_wide_bridge_training_matches_oracle(case):
     from tests.test_hip_wide import _random_wide_bridge_spec
 
     rng = np.random.default_rng(13000 + case)
-    spec = _random_wide_bridge_spec(rng)
+    spec = _random_wide_bridge_spec(rng, mixture)
     if spec["inference_net"]["num_layers"] == 2:  # no hidden layer: the divergence gradient is built for one or two
         spec["inference_net"]["num_layers"] = 3
     method = str(rng.choice(["lv", "kl"]))
@@ -166,7 +171,10 @@ def test_random_wide_bridge_training_matches_oracle(case):
     inf = prob.loss.inference_ctrl
     leaf = lambda sd: {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
     params, params_inf = leaf(prob.ctrl.state_dict()), leaf(inf.state_dict())
-    oracle = eo.Problem(spec, params, None, params_inf=params_inf)
+    tt = None
+    if spec["target"]["kind"] == "gmm":
+        tt = dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+    oracle = eo.Problem(spec, params, tt, params_inf=params_inf)
     ts = prob.ts.clone()
     B, d, T = spec["batch"], spec["target"]["dim"], ts.numel() - 1
     torch.manual_seed(case)

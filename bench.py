@@ -228,12 +228,14 @@ def extra_block(device, B: int) -> dict:
     from sde_sampler_amd import problems
 
     out = {}
-    for name in ("gmm50_dense_shared", "gmm50_dense_general", "gmm50_pis_headline"):
+    # (headline_generic_kernel: run-time switches for loss / control / target / activation, mixture tables over the four coordinates the
+    # reference's padded mixtures differ in -- variant "50_0_g4"; ..._full_tables: the plain generic variant, tables over all 50)
+    for name, gen in (("gmm50_dense_shared", None), ("gmm50_dense_general", None), ("gmm50_pis_headline", "1"), ("gmm50_pis_headline", "2")):
         spec = problems.baseline_spec(name)
         spec["batch"] = B
-        generic = name == "gmm50_pis_headline"
+        generic = gen is not None
         if generic:
-            os.environ["SDEH_GENERIC_ONLY"] = "1"
+            os.environ["SDEH_GENERIC_ONLY"] = gen
         try:
             prob = problems.build(spec, device=device)
             prob.loss.engine.timing = True
@@ -243,7 +245,7 @@ def extra_block(device, B: int) -> dict:
             os.environ.pop("SDEH_GENERIC_ONLY", None)
         T = prob.ts.numel() - 1
         tf = algorithmic_flops(spec) * B * T / (ms * 1e-3) / 1e12
-        out["headline_generic_kernel" if generic else name] = {"kernel_ms": ms, "kernel_ms_min": ms_min, "launches": n,
+        out[("headline_generic_kernel" if gen == "1" else "headline_generic_kernel_full_tables") if generic else name] = {"kernel_ms": ms, "kernel_ms_min": ms_min, "launches": n,
                                                                "algorithmic_tflops": tf, "frac": tf / PEAK_FP32_TFLOPS,
                                                                "kernel": prob.loss.engine.last_kernel_name()}
     # the wide-network kernels (BASELINE configs[4]'s shape: C = 256, d = 196) at their workloads' own batch and T

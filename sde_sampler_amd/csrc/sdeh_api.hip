@@ -91,18 +91,24 @@ static const Variant* pick_variant(int d) {
   return best;
 }
 
-// specialised variant whose compile-time choices all match the problem, if any
+// specialised variant (of the plan's dimension class) whose compile-time choices all match the problem, if any
 // gmm: 0 = no LDS tables possible, 1 = general, 2 = shared scale; nvary: varying-prefix length promised by the caller (-1 none)
-static const Variant* pick_specialised(int d, int loss, int ctrl, int tgt, int gmm, int act, int refc, int nvary) {
+// generic_only: only variants that fix nothing but the table form (tags "g<n>": run-time switches for everything else)
+static const Variant* pick_specialised(const Variant* cls, int loss, int ctrl, int tgt, int gmm, int act, int refc, int nvary, bool generic_only) {
   const Variant* best = nullptr;
+  int best_fixed = -1;
   for (const Variant& v : kVariants) {
-    if (is_generic(v) || v.pad || v.dp != d) continue;
+    if (is_generic(v) || v.pad != cls->pad || v.dp != cls->dp) continue;
     if (!((v.loss < 0 || v.loss == loss) && (v.ctrl < 0 || v.ctrl == ctrl) && (v.tgt < 0 || v.tgt == tgt) &&
           (v.gmm < 0 || v.gmm == gmm) && (v.act < 0 || v.act == act) && (v.refc < 0 || v.refc == refc)))
       continue;
+    const int fixed = (v.loss >= 0) + (v.ctrl >= 0) + (v.tgt >= 0) + (v.gmm >= 0) + (v.act >= 0) + (v.refc >= 0);
+    if (generic_only && fixed > 0) continue;
     if (v.gnv > 0 && !(gmm == 2 && nvary >= 0 && nvary <= v.gnv)) continue;
-    // prefer the variant whose mixture tables cover the fewest coordinates
-    if (best == nullptr || (v.gnv > 0 && (best->gnv <= 0 || v.gnv < best->gnv))) best = &v;
+    // prefer the variant whose mixture tables cover the fewest coordinates, then the one with the most compile-time choices
+    const bool fewer = v.gnv > 0 && (best == nullptr || best->gnv <= 0 || v.gnv < best->gnv);
+    const bool same = best != nullptr && ((v.gnv > 0) == (best->gnv > 0)) && (v.gnv <= 0 || v.gnv == best->gnv);
+    if (best == nullptr || fewer || (same && fixed > best_fixed)) { best = &v; best_fixed = fixed; }
   }
   return best;
 }
@@ -134,14 +140,15 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   L.gmm_row = 2 * ((dp + 1) & ~1);
   const int k_rows = (k_max + 7) & ~7;  // table rows padded to a multiple of 8 (padding rows: logit -inf)
   L.gmm_rows = k_rows;
-  const int gmm_floats = 2 * k_rows * L.gmm_row + align4(k_rows);
+  // shared-scale tables: one word per (k,d), rows of 4*ceil(dp/4) floats (gmm_nv > 0: of the first gmm_nv coordinates only), then the
+  // per-coordinate vectors; general tables: (mu, a) pairs
+  const int rs_full = 4 * ((dp + 3) / 4);
+  const int rs = gmm_nv > 0 ? gmm_nv : rs_full;
+  const int gmm_floats = shared_scale ? 2 * k_rows * rs + 4 * rs_full + align4(k_rows) : 2 * k_rows * L.gmm_row + align4(k_rows);
   // LDS budget of the wave-specialised kernel: image + four [coordinate][64] exchange buffers within 160 KiB
   const size_t xbuf_floats = with_bwd ? 0 : (size_t)4 * (mdim(mregs(dp) - 1, 1) + 1) * 64;
   L.gmm_lds = (k_max > 0 && !gmm_global && ((size_t)(o + gmm_floats) + xbuf_floats) * sizeof(float) <= 160 * 1024) ? 1 : 0;
   if (L.gmm_lds && shared_scale) {
-    // shared-scale tables: one word per (k,d), rows of 4*ceil(dp/4) floats, then the two per-coordinate vectors
-    const int rs_full = 4 * ((dp + 3) / 4);
-    const int rs = gmm_nv > 0 ? gmm_nv : rs_full;
     L.gmm_lds = 2;
     L.gmm_row = rs;
     L.gmm_lg = o; o += k_rows * rs;
@@ -457,13 +464,24 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   const bool shared = pr->target.kind == SDEH_DENS_GMM && (pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE);
   const int nvary = shared ? SDEH_DENS_FLAG_GET_NVARY(pr->target.flags) : -1;
   const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
-  const bool no_spec = getenv("SDEH_GENERIC_ONLY") != nullptr;  // testing / measurement aid: force the generic variants (read per call)
+  // testing / measurement aid: only the variants with run-time switches for loss / control / target / activation (read per call);
+  // SDEH_GENERIC_ONLY=2 also rules out the ones with reduced mixture tables ("g4")
+  const char* gen_only = getenv("SDEH_GENERIC_ONLY");
+  const bool no_spec = gen_only != nullptr;
   // which GMM table form would the layout give?  (0: tables do not fit LDS, 1: general, 2: shared scale)
   // the integrator runs on the single-wave code path of the generic variant (mixture tables in LDS when they fit)
   WsLayout L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, 0, backward);
-  const Variant* sv = (no_spec || backward || integrate) ? nullptr
-                              : pick_specialised(d, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds,
-                                                 net.activation, refc ? 1 : 0, nvary);
+  const Variant* sv = (backward || integrate) ? nullptr
+                              : pick_specialised(v, pr->loss_kind, pr->ctrl_kind, pr->target.kind, L.gmm_lds,
+                                                 net.activation, refc ? 1 : 0, nvary, no_spec);
+  if (sv == nullptr && !(backward || integrate) && shared && nvary >= 0 && L.gmm_lds == 0 && !force_legacy) {
+    // full tables beyond LDS (d near 64, many components): tables over the varying prefix may still fit
+    const Variant* rv = pick_specialised(v, pr->loss_kind, pr->ctrl_kind, pr->target.kind, 2, net.activation, refc ? 1 : 0, nvary, no_spec);
+    if (rv != nullptr && rv->gnv > 0 &&
+        make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, rv->gnv).gmm_lds == 2)
+      sv = rv;
+  }
+  if (gen_only != nullptr && gen_only[0] == '2') sv = nullptr;
   if (sv != nullptr && sv->dp == v->dp) {
     v = sv;
     if (v->gnv > 0) L = make_layout(v->dp, net.channels, net.n_hidden, n_steps, k, g, shared, force_legacy, v->gnv);

@@ -50,7 +50,8 @@ EVAL_CASES = [
     ("cfg1_dw_dis_lv", 1024, 60, {}, "traj_ws<"),                              # quad mode
     ("cfg2_gmm2_dis_kl", 6000, 60, {}, "traj_ws<"),                            # quad mode, mixture on both lane halves
     ("cfg4_funnel_dds_lv", 32768, 60, {}, "traj_ws<"),
-    ("gmm50_pis_headline", 16384, 30, {"SDEH_GENERIC_ONLY": 1}, "traj_ws<50_0_g>"),
+    ("gmm50_pis_headline", 16384, 30, {"SDEH_GENERIC_ONLY": 2}, "traj_ws<50_0_g>"),
+    ("gmm50_pis_headline", 16384, 30, {"SDEH_GENERIC_ONLY": 1}, "traj_ws<50_0_g4>"),  # run-time switches, tables over 4 coordinates
     ("wide_pis_funnel196", 4096, 12, {"SDEH_WIDE_CT": 1}, "traj_wide<C=256,CT=1>"),
     ("wide_pis_funnel196", 8320, 12, {"SDEH_WIDE_CT": 2}, "traj_wide<C=256,CT=2>"),
     ("cfg5_like_bridge196", 512, 6, {"SDEH_WIDE_SPLIT": 1}, "bridge_wide<C=256,split=1>"),

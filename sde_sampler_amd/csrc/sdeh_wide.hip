@@ -559,7 +559,12 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
   cx.wave = w; cx.lane = lane; cx.j = j; cx.h = h;
   cx.planes = lds; cx.plane_floats = rows * RS;
   float* dplanes = lds + rows * RS;                       // act'(z_l) of the inference network, l = 0 .. Lh: [Lh + 1][C][32]
-  cx.scr = dplanes + (L2.n_hidden + 1) * C * RS;          // [kWideSlots][4][32]
+  int dpl_floats = (L2.n_hidden + 1) * C * RS;
+  if constexpr (GMM) {  // the mixture's partial logits / responsibilities / logsumexp share this region (bridge_wide_lds_bytes)
+    const int gmm_floats = A.target.kind == SDEH_DENS_GMM ? 5 * A.target.n_comp * RS + RS : 0;
+    dpl_floats = gmm_floats > dpl_floats ? gmm_floats : dpl_floats;
+  }
+  cx.scr = dplanes + dpl_floats;                          // [kWideSlots][4][32]
   float* divacc = cx.scr + kWideSlots * 4 * RS;           // [4 waves][8 groups][32]: sigma dt mask J_jj accumulated over the steps
   float* cols = divacc + 4 * 8 * RS;                      // [4 waves][2 coordinates][2][C]: column j of W_in / row j of W_out of the coordinates at hand
   float* tabs = cols + 4 * 4 * C;

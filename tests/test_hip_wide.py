@@ -157,6 +157,37 @@ def test_wide_mixture_agrees_with_the_narrow_kernels_and_wide_bridge_runs_on_a_m
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_wide_bridge_mixture_scratch_larger_than_the_derivative_planes():
+    """40 components with an inference network WITHOUT hidden layers (num_layers = 2) at C = 128: the mixture's logits / responsibilities
+    (5 K + 1 rows of 32) need more LDS than the one act' plane they share a region with -- the region is sized for the larger of the
+    two.  Against the oracle on identical noise."""
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
+
+    lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
+    spec = dict(batch=40, target=dict(kind="gmm", dim=50, name="fab50"), prior=dict(kind="iso_gauss", dim=50),
+                sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0), ctrl=dict(kind="lerp_target", **lerp),
+                inference_ctrl=dict(kind="lerp_prior", **lerp), net=dict(channels=128, num_layers=4, activation="gelu"),
+                inference_net=dict(channels=128, num_layers=2, activation="gelu"),
+                loss=dict(kind="time_reversal", method="kl"), grid=dict(start=0.0, end=1.0, steps=5))
+    prob = problems.build(spec)
+    inf = prob.loss.inference_ctrl
+    params = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
+    params_inf = {k: v.detach().clone() for k, v in inf.state_dict().items()}
+    tt = dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+    torch.manual_seed(2)
+    x0 = prob.prior.sample((40,))
+    noise = torch.randn(5, 40, 50)
+    ref = eo.Problem(spec, params, tt, params_inf).eval(prob.ts.clone(), x0.clone(), noise, compute_weights=True)
+    prob.to(DEV)
+    out = prob.eval(x0.to(DEV), compute_weights=True, noise=noise.to(DEV))
+    assert prob.loss.engine.last_kernel_name().startswith("bridge_wide<C=128")
+    assert (out.samples.cpu() - ref["samples"]).abs().max().item() <= 2e-4 * max(1.0, float(ref["samples"].abs().max()))
+    for name in ("log_norm_const_lb_ito", "log_norm_const_is"):
+        got, want = out.log_norm_const_preds[name], ref[name]
+        assert abs(got - want) <= _est_tol(want), f"{name}: {got} vs {want}"
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Bridge on wide networks (bridge_wide_kernel): exact divergence of the inference control, configs[4] geometry
 # ---------------------------------------------------------------------------------------------------------------------------

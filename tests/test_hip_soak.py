@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-N_LAUNCHES = 20
+N_LAUNCHES = int(os.environ.get("SDEH_SOAK_LAUNCHES", "20"))  # SDEH_SOAK_LAUNCHES=500: an occasional long soak
 
 
 @contextmanager

@@ -42,6 +42,12 @@ def _build(seed=0, method="lv"):
                     ctrl=dict(kind="lerp_target", **lerp), inference_ctrl=dict(kind="lerp_prior", **lerp),
                     net=dict(channels=64, num_layers=4, activation="gelu"),
                     loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=50))
+    elif method == "wide_bridge_gmm":  # wide Bridge on the benchmark's mixture, kl: the forward launch keeps both score planes
+        lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
+        spec = dict(batch=256, target=dict(kind="gmm", dim=50, name="fab50"), prior=dict(kind="iso_gauss", dim=50),
+                    sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0), ctrl=dict(kind="lerp_target", **lerp),
+                    inference_ctrl=dict(kind="lerp_prior", **lerp), net=dict(channels=128, num_layers=4, activation="gelu"),
+                    loss=dict(kind="time_reversal", method="kl"), grid=dict(start=0.0, end=1.0, steps=6))
     elif method.startswith("wide"):  # wide networks (csrc/sdeh_wide_bwd.hip): "wide_lv" / "wide_kl" plain, "wide_bridge" configs[4]'s shape
         spec = problems.baseline_spec("cfg5_like_bridge196" if method == "wide_bridge" else "wide_pis_funnel196")
         spec["grid"]["steps"] = 6 if method == "wide_bridge" else 12
@@ -163,7 +169,7 @@ def test_graphed_step_skips_non_finite_updates_on_device():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("method,batch", [("lv", 2048), ("kl", 2048), ("bridge", 2048), ("lv", 65536), ("kl", 40000), ("bridge", 16384),
-                                          ("wide_lv", 2048), ("wide_kl", 1000), ("wide_bridge", 256)])
+                                          ("wide_lv", 2048), ("wide_kl", 1000), ("wide_bridge", 256), ("wide_bridge_gmm", 200)])
 def test_replayed_gradients_equal_eager_gradients(method, batch):
     """Every parameter gradient of forward + backward replayed from a hipGraph (three replays) against the eager launch at the
     same Philox offset.  Guards against ordering / buffer-reuse hazards of captured steps (a multi-block framework reduction

@@ -112,6 +112,7 @@ struct TrajArgs {
   float* gp;  // [T, B, d] or null: u + v per step (needed by the backward pass of the inference network)
   int flag_sync;  // wave-specialised kernel: pair-level LDS counters instead of workgroup barriers for the V <-> M hand-off
   int half;   // wave-specialised kernel: a group is 32 trajectories (one MFMA column tile) instead of 64 -- small batches
+  int vout;   // wave-specialised kernel, d <= 4: the out layer runs on the V wave's vector pipe (the M wave publishes its last activations)
   int csplit; // Bridge kernel: waves of a workgroup that carry the SAME 32 trajectories and split the coordinates' tangent passes (1 | 4)
   const float* div_noise;  // [T, B, d] or null: Hutchinson probe vectors (training with div_estimator); null = exact divergence
   // training forward (sdeh_simulate_fwd_train): what the backward kernels would otherwise recompute

@@ -446,9 +446,20 @@ __device__ __forceinline__ void mfma_stage(const float* __restrict__ w, IN&& in,
   }
 }
 
+// Small state dimensions (d <= 4): the out layer is a 32-row matrix tile around d live rows -- 64 (32) MFMAs per step and group for
+// 2 x 64 useful weights at d = 2.  With `abuf` != nullptr the M wave stops after the last hidden layer and publishes its activated
+// outputs [channel][trajectory] instead; the V wave forms the d dot products on the vector pipe (d x 64 FMAs per trajectory).
+template <int C>
+__device__ __forceinline__ void ws_publish_act(float* __restrict__ abuf, const f32x16 (&a)[C / 32], int col, int h) {
+#pragma unroll
+  for (int ot = 0; ot < C / 32; ++ot)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) abuf[(32 * ot + rho(q, h)) * 64 + col] = a[ot][q];
+}
+
 template <int DP, int C, bool ZS>
 __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
-                                       int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z) {
+                                       int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z, float* __restrict__ abuf = nullptr) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
   f32x16 curA[OT], curB[OT], nxtA[OT], nxtB[OT];
@@ -483,6 +494,15 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
 #pragma unroll
     for (int ot = 0; ot < OT; ++ot) { if constexpr (ZS) ws_store_z(Z, l + 1, C, ot, 1, lane, nxtB[ot]); curA[ot] = nxtA[ot]; curB[ot] = nxtB[ot]; }
   }
+  if constexpr (DP <= 4) {
+    if (abuf != nullptr) {  // out layer on the V wave: activate tile B (tile A is) and publish both
+      SDEH_ACT_SWITCH(act, ACTC,
+        _Pragma("unroll") for (int ot = 0; ot < OT; ++ot) act_tile<ACTC>(curB[ot]););
+      ws_publish_act<C>(abuf, curA, j, h);
+      ws_publish_act<C>(abuf, curB, j + 32, h);
+      return;
+    }
+  }
   {  // out_layer(act(e)); the A tile's result is published while the B tile's MFMAs run
     f32x16 uA[OTD], uB[OTD];
 #pragma unroll
@@ -505,7 +525,7 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
 // dependent layers is half as long (the launch is latency-bound: a handful of wavefronts on 1024 SIMDs).
 template <int DP, int C, bool ZS>
 __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
-                                            int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z) {
+                                            int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z, float* __restrict__ abuf = nullptr) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
   f32x16 cur[OT], nxt[OT], none[1];
@@ -534,6 +554,12 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
     for (int ot = 0; ot < OT; ++ot) { cur[ot] = nxt[ot]; if constexpr (ZS) ws_store_z(Z, l + 1, C, ot, 0, lane, cur[ot]); }
   }
   activate_all();
+  if constexpr (DP <= 4) {
+    if (abuf != nullptr) {  // out layer on the V wave
+      ws_publish_act<C>(abuf, cur, j, h);
+      return;
+    }
+  }
   f32x16 u[OTD];
 #pragma unroll
   for (int t = 0; t < OTD; ++t) u[t] = load16(lds + L.b_out + (t * 2 + h) * 16);
@@ -778,6 +804,11 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   // hand-off counters of the group (behind the exchange buffers): [0] x published by V, [1] network output published by M
   int* hand = reinterpret_cast<int*>(lds + L.lds_floats + kWsGroups * (XR * 64)) + 2 * group;
   const bool fsync = A.flag_sync != 0 && !pair;
+  // d <= 4 (launcher: TrajArgs::vout): [64 channels][64 trajectories] per group behind the counters -- the M wave's last activations
+  float* __restrict__ abuf = nullptr;
+  if constexpr (DP <= 4 && C == 64) {
+    if (A.vout && !pair) abuf = lds + L.lds_floats + kWsGroups * (XR * 64) + 2 * kWsGroups + group * (64 * 64);
+  }
   if (fsync && tid < 2 * kWsGroups) reinterpret_cast<int*>(lds + L.lds_floats + kWsGroups * (XR * 64))[tid] = 0;
 
   const int ctrl_kind = CTRL >= 0 ? CTRL : A.ctrl_kind, loss_kind = LOSS >= 0 ? LOSS : A.loss_kind;
@@ -852,8 +883,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       // generic variants (ACT < 0): the activation id becomes a compile-time constant of three copies of the network --
       // selecting it per element costs a scalar branch per element pair inside the MFMA stages (1.5x on the whole kernel)
       SDEH_ACT_SWITCH(act, ACTC,
-        if (A.half) ws_mlp_half<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z);
-        else ws_mlp<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z););
+        if (A.half) ws_mlp_half<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z, abuf);
+        else ws_mlp<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z, abuf););
       if (fsync) ws_flag_set(hand + 1, i + 1);
       else ws_barrier();  // barrier B: network output published
       WS_T(tm1);
@@ -889,6 +920,10 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   // exchange buffer: coordinates >= DP that M-layout registers can address stay zero for the whole launch
 #pragma unroll
   for (int j = 0; j < XR; ++j) xbuf[j * 64 + lane] = j < DP ? x[j] : 0.0f;
+  if constexpr (DP <= 4) {
+    if (abuf != nullptr)  // groups of 32: the M wave writes columns 0..31 only, this wave's idle lanes read the others
+      for (int c = 0; c < 64; ++c) abuf[c * 64 + lane] = 0.0f;
+  }
   __syncthreads();  // LDS image staged
 
   float rnd = 0.0f;
@@ -1058,6 +1093,29 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     } else if (pair && kPairSum) {
 #pragma unroll
       for (int j = 0; j < DP; ++j) u[j] = xbuf[j * 64 + lane] + xbuf2[j * 64 + lane];
+    } else if (DP <= 4 && abuf != nullptr) {
+      if constexpr (DP <= 4) {
+        // out_layer(act(e)) on the vector pipe: rows 0..3 of the packed out layer are one broadcast ds_read_b128 per channel (k-step s,
+        // lane half hh of the packed image <-> channel mdim(s, hh)); two chains per output
+        int woff = L.w_out;
+        asm volatile("" : "+v"(woff));  // one base, immediate offsets: nothing per channel to hoist out of the step loop
+        const float* __restrict__ ab = abuf + lane;
+        float acc[2][DP];
+#pragma unroll
+        for (int j = 0; j < DP; ++j) { acc[0][j] = lds[L.b_out + j]; acc[1][j] = 0.0f; }
+#pragma unroll
+        for (int s = 0; s < C / 2; ++s)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const float4 wv = *reinterpret_cast<const float4*>(lds + woff + s * 64 + hh * 32);
+            const float av = ab[mdim(s, hh) * 64];
+            const float wr[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+            for (int j = 0; j < DP; ++j) acc[hh][j] = fmaf(wr[j], av, acc[hh][j]);
+          }
+#pragma unroll
+        for (int j = 0; j < DP; ++j) u[j] = acc[0][j] + acc[1][j];
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < DP; ++j) u[j] = xbuf[j * 64 + lane];
@@ -1155,6 +1213,11 @@ template <int DP>
 inline size_t ws_lds_bytes(const WsLayout& L) {
   return ((size_t)L.lds_floats + (size_t)kWsGroups * xrows<DP>() * 64 + 2 * kWsGroups) * sizeof(float);  // + the hand-off counters
 }
+// d <= 4 with the out layer on the V wave: + the activation planes [groups][64][64]
+template <int DP>
+inline size_t ws_vout_lds_bytes(const WsLayout& L) {
+  return ws_lds_bytes<DP>(L) + (size_t)kWsGroups * 64 * 64 * sizeof(float);
+}
 // pair mode: one exchange buffer + the activation parking (2 parities x 2 tiles x 16 registers x 64 lanes) + the second M wave's
 // partial network output
 template <int DP>
@@ -1219,6 +1282,15 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   if (half == 3 && ws_quad_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_quad_lds_bytes<DP>(a.lay);
   TrajArgs b = a;
   b.half = half;
+  // d <= 4, groups of 64 / 32 trajectories: the out layer on the V wave's vector pipe when the activation planes fit (SDEH_WS_VOUT=0: never)
+  b.vout = 0;
+  if (DP <= 4 && C == 64 && half <= 1 && ws_vout_lds_bytes<DP>(a.lay) <= 160 * 1024) {
+    const char* vo = getenv("SDEH_WS_VOUT");  // A/B aid, read per call
+    if (vo == nullptr || vo[0] != '0') {
+      b.vout = 1;
+      if (ws_vout_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_vout_lds_bytes<DP>(a.lay);
+    }
+  }
   b.flag_sync = getenv("SDEH_WS_BARRIER") == nullptr ? 1 : 0;  // A/B aid (read per call): the workgroup-barrier hand-off
   const int rows = (half ? 32 : 64) * groups;
   const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);

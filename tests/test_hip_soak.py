@@ -50,6 +50,8 @@ EVAL_CASES = [
     ("cfg1_dw_dis_lv", 1024, 60, {}, "traj_ws<"),                              # quad mode
     ("cfg2_gmm2_dis_kl", 6000, 60, {}, "traj_ws<"),                            # quad mode, mixture on both lane halves
     ("cfg4_funnel_dds_lv", 32768, 60, {}, "traj_ws<"),
+    ("cfg2_gmm2_dis_kl", 65536, 60, {}, "traj_ws<2_0_dis_gmm>"),              # groups of 64, out layer on the V wave (d <= 4)
+    ("cfg2_gmm2_dis_kl", 20000, 60, {"SDEH_WS_VOUT": 0}, "traj_ws<2_0_dis_gmm>"),  # ... and on the matrix pipe
     ("gmm50_pis_headline", 16384, 30, {"SDEH_GENERIC_ONLY": 2}, "traj_ws<50_0_g>"),
     ("gmm50_pis_headline", 16384, 30, {"SDEH_GENERIC_ONLY": 1}, "traj_ws<50_0_g4>"),  # run-time switches, tables over 4 coordinates
     ("wide_pis_funnel196", 4096, 12, {"SDEH_WIDE_CT": 1}, "traj_wide<C=256,CT=1>"),

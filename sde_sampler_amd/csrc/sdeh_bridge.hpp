@@ -907,7 +907,7 @@ int launch_bridge(const TrajArgs& a, hipStream_t stream) {
   }
   // 32 trajectories per wave (HALF) while that still leaves a SIMD per wave: the step is a chain of dependent network passes, so
   // small batches are latency-bound and halving the MFMA chain is worth more than filling the lanes
-  static const char* tiles = getenv("SDEH_BRIDGE_TILES");  // testing aid: "64" = 64-row tiles, "32g" = 32-row, generic tangents
+  const char* tiles = getenv("SDEH_BRIDGE_TILES");  // testing aid, read per call: "64" = 64-row tiles, "32g" = 32-row, generic tangents
   // exact divergence with act' kept in registers (32-row tiles only): fewer MFMA passes per row than the 64-row tiles at
   // every batch size (d = 2: 6.6 vs 8.0 ms at B = 65 536; d = 10: 13.4 vs 33.3 ms)
   const bool cached = a.div_noise == nullptr && a.lay2.n_hidden < kTanCache;

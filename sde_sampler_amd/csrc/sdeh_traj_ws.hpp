@@ -1259,7 +1259,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   //                 default batch sizes (train 512 / 2048, eval 6000) live here and are latency-bound: 14.5 -> 7.1 us per step
   //   B <=  8 192 : pair mode -- one group of 32 per workgroup served by a V wave and TWO M waves (one output-channel tile each),
   //                 three waves on three SIMDs of a CU: 7.1 -> ~5 us per step
-  static const char* force = getenv("SDEH_WS_GROUPS");  // testing aid: "2" | "4" | "2h" | "4h" | "p" (pair)
+  const char* force = getenv("SDEH_WS_GROUPS");  // testing aid, read per call like the other switches: "2" | "4" | "2h" | "4h" | "p" (pair)
   int groups = a.batch <= 2 * 32 * 256 ? 2 : kWsGroups;
   int half = a.batch <= 4 * 32 * 256 ? 1 : 0;
   if (pair_fits && a.batch <= 32 * 256) { groups = 1; half = 2; }

@@ -93,7 +93,7 @@ torch.save(dict(xT=xT.cpu(), rnd=rnd.cpu()), {out!r})
 
 def test_bridge_exact_divergence_tilings_agree(tmp_path):
     """Exact divergence: 32-row tiles with act' kept in registers (the default), 32-row and 64-row tiles with the generic
-    base + tangent passes (SDEH_BRIDGE_TILES, read once per process -> one subprocess per setting)."""
+    base + tangent passes (SDEH_BRIDGE_TILES; one subprocess per setting)."""
     import os
     import subprocess
     import sys

@@ -3,7 +3,7 @@ OUT=gpurun_out/r03u
 mkdir -p $OUT
 ROOT=$(pwd)
 bash tools/pmc_profile.sh $OUT/pmc_headline > $OUT/pmc.log 2>&1
-python tools/pmc_headline_json.py $OUT/pmc_headline/summary.txt $OUT/r03_pmc_headline.txt > /dev/null; cp profiles/pmc_headline.json $OUT/pmc_headline.json
+python tools/pmc_headline_json.py $OUT/pmc_headline/summary.txt profiles/r03_pmc_headline.txt > /dev/null; cp profiles/pmc_headline.json profiles/r03_pmc_headline.txt $OUT/
 (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_headline -- python $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra > $ROOT/$OUT/prof_headline.log 2>&1)
 DB=$(find $OUT/prof_headline -name "*.db" | head -1)
 python tools/rocprof_summary.py $DB > $OUT/kernel_stats_headline.txt

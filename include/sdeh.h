@@ -28,6 +28,8 @@
 extern "C" {
 #endif
 
+/* v4 (round 3): sdeh_ctrl_backward_ex gained xt_out / sc_in / tscore_in; wide-network training entry points
+ * (sdeh_bridge_div_backward_wide[_sizes]); sdeh_simulate_fwd_aux2. */
 #define SDEH_ABI_VERSION 4
 #define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
 

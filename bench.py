@@ -124,7 +124,6 @@ def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | No
 
     params, tt, params_inf = prob_cpu_state
     if train_method is not None:  # the training workloads: the oracle's loss + autograd backward on a bounded sample
-        threads = min(8, physical_cores())
         leaf = lambda sd: {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
         leaves = leaf(params)
         leaves_inf = leaf(params_inf) if params_inf is not None else None
@@ -134,19 +133,26 @@ def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | No
         if bridge:  # d backward passes per step, differentiated again: the first 4 intervals of the grid, 32 rows
             ts = ts[:5]
         wide = spec["net"]["channels"] > 64
-        T, d, rows, rates = ts.numel() - 1, spec["target"]["dim"], (32 if bridge else (64 if wide else 256)), []
-        torch.set_num_threads(threads)
-        for _ in range(4):
-            x0c = torch.zeros(rows, d) if spec["prior"]["kind"] == "delta" else torch.randn(rows, d)
-            for v in list(leaves.values()) + (list(leaves_inf.values()) if leaves_inf else []):
-                v.grad = None
-            t0 = time.perf_counter()
-            l_ref, _, _, _ = oracle.train_loss(ts, x0c, None, method=train_method)
-            l_ref.backward()
-            rates.append(rows * T / (time.perf_counter() - t0))
-        return {"value": statistics.median(rates[1:]), "unit": "trajectory-steps/s", "cores": threads, "kind": "port",
+        T, d, rows = ts.numel() - 1, spec["target"]["dim"], (32 if bridge else (64 if wide else 256))
+        # thread counts swept like the evaluation leg's (one thread is often the fastest setting for these small per-step tensors)
+        by_threads = {}
+        for threads in sorted({1, min(8, physical_cores()), min(32, physical_cores())}):
+            torch.set_num_threads(threads)
+            rates = []
+            for _ in range(4):
+                x0c = torch.zeros(rows, d) if spec["prior"]["kind"] == "delta" else torch.randn(rows, d)
+                for v in list(leaves.values()) + (list(leaves_inf.values()) if leaves_inf else []):
+                    v.grad = None
+                t0 = time.perf_counter()
+                l_ref, _, _, _ = oracle.train_loss(ts, x0c, None, method=train_method)
+                l_ref.backward()
+                rates.append(rows * T / (time.perf_counter() - t0))
+            by_threads[threads] = statistics.median(rates[1:])
+        best = max(by_threads, key=by_threads.get)
+        return {"value": by_threads[best], "unit": "trajectory-steps/s", "cores": best, "kind": "port",
+                "by_threads": {str(k): v for k, v in by_threads.items()},
                 "sample": f"oracle/em_oracle.py train_loss + autograd backward (no optimizer step), {rows} trajectories x T={T}, "
-                          f"median of 3 after 1 warm-up, {threads} torch threads"}
+                          f"median of 3 after 1 warm-up per thread count {sorted(by_threads)}; `value` = the best ({best} threads)"}
     oracle = eo.Problem(spec, params, tt, params_inf=params_inf)
     ts = oracle.grid()
     bridge = bool(spec.get("inference_ctrl"))

@@ -49,6 +49,36 @@ __device__ __forceinline__ float act_grad(float v, int act) {
   return v > 0.0f ? 1.0f : 0.0f;
 }
 
+// GELU and its derivative of an element pair from ONE evaluation of the tail Phi(-|v|) (the fused backward kernels: act and act' are
+// half of their vector work).  `a` is act_gelu2(v) bit for bit (the same instructions: the re-evaluated activations stay the forward
+// kernel's); act' = Phi(v) + v phi(v) takes Phi from that tail instead of act_grad's own degree-9 fit: |error| <= 2.4e-6 (the
+// degree-6 fit is tuned for t * tail, its tail alone is off by that much at 0) against 1.4e-7 -- two orders inside the gradients'
+// parity bar (2e-4 of each tensor's scale), for 7 instead of 17 instructions per element.  -DSDEH_NO_JOINT_GELU: the separate forms.
+__device__ __forceinline__ void act_gelu2_both(f2 v, f2& a, f2& g) {
+#if defined(SDEH_NO_JOINT_GELU) || defined(SDEH_NO_PK_GELU)
+  a = act_gelu2(v);
+  g = f2{act_grad(v.x, SDEH_ACT_GELU_ERF), act_grad(v.y, SDEH_ACT_GELU_ERF)};
+#else
+  const f2 t = f2{__builtin_amdgcn_fmed3f(fabsf(v.x), 0.0f, 6.0f), __builtin_amdgcn_fmed3f(fabsf(v.y), 0.0f, 6.0f)};
+  f2 q = pk_fma_sc(splat(3.3092907814e-05f), t, splat_bits(-7.6922050644e-04f));
+  q = pk_fma_sc(q, t, splat_bits(8.0807191412e-03f));
+  q = pk_fma_sc(q, t, splat_bits(-5.3412108121e-02f));
+  q = pk_fma_sc(q, t, splat_bits(-4.5877097054e-01f));
+  q = pk_fma_sc(q, t, splat_bits(-1.1512017029e+00f));
+  q = pk_fma_sc(q, t, splat_bits(-9.9999306093e-01f));
+  const f2 e = f2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};  // Phi(-|v|)
+  f2 relu;  // (see act_gelu2 for the extra input t)
+  asm("v_max_f32 %0, 0, %1" : "=v"(relu.x) : "v"(v.x), "v"(t.x));
+  asm("v_max_f32 %0, 0, %1" : "=v"(relu.y) : "v"(v.y), "v"(t.y));
+  a = pk_fma(-t, e, relu);
+  const f2 v2 = v * v;
+  const f2 phi = f2{0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * v2.x),
+                    0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * v2.y)};
+  const f2 Phi = f2{v.x < 0.0f ? e.x : 1.0f - e.x, v.y < 0.0f ? e.y : 1.0f - e.y};
+  g = pk_fma(v, phi, Phi);
+#endif
+}
+
 // second derivative of the activation (Bridge: the divergence's dependence on the base pre-activations)
 __device__ __forceinline__ float act_grad2(float v, int act) {
   if (act == SDEH_ACT_GELU_ERF)  // (Phi + v phi)' = phi (2 - v^2)

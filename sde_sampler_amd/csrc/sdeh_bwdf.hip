@@ -161,10 +161,20 @@ __device__ __forceinline__ void dw_acc(const float* __restrict__ dplane, int R, 
 // act(z) and act'(z) of one tile
 template <int ACT>
 __device__ __forceinline__ void act_both(const f32x16& z, f32x16& a, f32x16& g) {
+  if constexpr (ACT == SDEH_ACT_GELU_ERF) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) g[q] = act_grad(z[q], ACT);
-  a = z;
-  act_tile<ACT>(a);
+    for (int q = 0; q < 16; q += 2) {
+      f2 av, gv;
+      act_gelu2_both(f2{z[q], z[q + 1]}, av, gv);
+      a[q] = av.x; a[q + 1] = av.y;
+      g[q] = gv.x; g[q + 1] = gv.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[q] = act_grad(z[q], ACT);
+    a = z;
+    act_tile<ACT>(a);
+  }
 }
 
 // accumulator tile -> natural [rows][ld] matrix block (row tile R, column tile Cc): coalesced over the lanes

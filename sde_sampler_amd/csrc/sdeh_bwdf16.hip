@@ -170,21 +170,18 @@ __device__ __forceinline__ void dw_acc(const float* __restrict__ dplane, int dro
 template <int ACT, int MT>
 __device__ __forceinline__ void act_both(const Vt<MT>& z, Vt<MT>& a, Vt<MT>& gr) {
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) gr.m[m][q] = act_grad(z.m[m][q], ACT);
-#pragma unroll
   for (int m = 0; m < MT; ++m) {
     if constexpr (ACT == SDEH_ACT_GELU_ERF) {
 #pragma unroll
       for (int q = 0; q < 4; q += 2) {
-        const f2 v = act_gelu2(f2{z.m[m][q], z.m[m][q + 1]});
-        a.m[m][q] = v.x;
-        a.m[m][q + 1] = v.y;
+        f2 av, gv;
+        act_gelu2_both(f2{z.m[m][q], z.m[m][q + 1]}, av, gv);
+        a.m[m][q] = av.x; a.m[m][q + 1] = av.y;
+        gr.m[m][q] = gv.x; gr.m[m][q + 1] = gv.y;
       }
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a.m[m][q] = act_ct<ACT>(z.m[m][q]);
+      for (int q = 0; q < 4; ++q) { gr.m[m][q] = act_grad(z.m[m][q], ACT); a.m[m][q] = act_ct<ACT>(z.m[m][q]); }
     }
   }
 }

@@ -79,6 +79,24 @@ __device__ __forceinline__ void act_gelu2_both(f2 v, f2& a, f2& g) {
 #endif
 }
 
+// act(z) in place and act'(z) of one accumulator tile (training backward kernels: joint evaluation for the GELU)
+template <int ACT>
+__device__ __forceinline__ void act_both_tile(f32x16& z, f32x16& g) {
+  if constexpr (ACT == SDEH_ACT_GELU_ERF) {
+#pragma unroll
+    for (int q = 0; q < 16; q += 2) {
+      f2 av, gv;
+      act_gelu2_both(f2{z[q], z[q + 1]}, av, gv);
+      z[q] = av.x; z[q + 1] = av.y;
+      g[q] = gv.x; g[q + 1] = gv.y;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[q] = act_grad(z[q], ACT);
+    act_tile<ACT>(z);
+  }
+}
+
 // second derivative of the activation (Bridge: the divergence's dependence on the base pre-activations)
 __device__ __forceinline__ float act_grad2(float v, int act) {
   if (act == SDEH_ACT_GELU_ERF)  // (Phi + v phi)' = phi (2 - v^2)

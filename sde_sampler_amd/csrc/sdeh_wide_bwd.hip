@@ -81,9 +81,12 @@ __device__ __forceinline__ void wide_bwd_act_store(f32x16 (&acc)[OTW][1], const 
         _Pragma("unroll") for (int q = 0; q < 16; ++q) *col.at(q) = z[q];
       }
       if (dpl != nullptr) {
-        _Pragma("unroll") for (int q = 0; q < 16; ++q) dpl[(32 * (t0 + 4 * k) + rho(q, h)) * 32] = act_grad(z[q], ACT);
+        f32x16 g;
+        act_both_tile<ACT>(z, g);
+        _Pragma("unroll") for (int q = 0; q < 16; ++q) dpl[(32 * (t0 + 4 * k) + rho(q, h)) * 32] = g[q];
+      } else {
+        act_tile<ACT>(z);
       }
-      act_tile<ACT>(z);
       _Pragma("unroll") for (int q = 0; q < 16; ++q) outl[(32 * (t0 + 4 * k) + rho(q, h)) * 32] = z[q];
     });
 }

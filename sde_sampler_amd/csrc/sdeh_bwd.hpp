@@ -79,6 +79,15 @@ __device__ __forceinline__ void act_gelu2_both(f2 v, f2& a, f2& g) {
 #endif
 }
 
+// SiLU and its derivative from one exponential: act stays act_silu bit for bit (v / (1 + e^-v), IEEE division); the sigmoid for
+// act' = s (1 + v (1 - s)) is v_rcp_f32 of the same denominator (1 ulp) instead of a second exponential and division.
+__device__ __forceinline__ void act_silu_both(float v, float& a, float& g) {
+  const float den = 1.0f + __expf(-v);
+  a = v / den;
+  const float sg = __builtin_amdgcn_rcpf(den);
+  g = sg * fmaf(v, 1.0f - sg, 1.0f);
+}
+
 // act(z) in place and act'(z) of one accumulator tile (training backward kernels: joint evaluation for the GELU)
 template <int ACT>
 __device__ __forceinline__ void act_both_tile(f32x16& z, f32x16& g) {
@@ -90,6 +99,9 @@ __device__ __forceinline__ void act_both_tile(f32x16& z, f32x16& g) {
       z[q] = av.x; z[q + 1] = av.y;
       g[q] = gv.x; g[q + 1] = gv.y;
     }
+  } else if constexpr (ACT == SDEH_ACT_SILU) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { float av, gv; act_silu_both(z[q], av, gv); z[q] = av; g[q] = gv; }
   } else {
 #pragma unroll
     for (int q = 0; q < 16; ++q) g[q] = act_grad(z[q], ACT);

@@ -169,6 +169,9 @@ __device__ __forceinline__ void act_both(const f32x16& z, f32x16& a, f32x16& g) 
       a[q] = av.x; a[q + 1] = av.y;
       g[q] = gv.x; g[q + 1] = gv.y;
     }
+  } else if constexpr (ACT == SDEH_ACT_SILU) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { float av, gv; act_silu_both(z[q], av, gv); a[q] = av; g[q] = gv; }
   } else {
 #pragma unroll
     for (int q = 0; q < 16; ++q) g[q] = act_grad(z[q], ACT);

@@ -179,6 +179,9 @@ __device__ __forceinline__ void act_both(const Vt<MT>& z, Vt<MT>& a, Vt<MT>& gr)
         a.m[m][q] = av.x; a.m[m][q + 1] = av.y;
         gr.m[m][q] = gv.x; gr.m[m][q + 1] = gv.y;
       }
+    } else if constexpr (ACT == SDEH_ACT_SILU) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { float av, gv; act_silu_both(z.m[m][q], av, gv); a.m[m][q] = av; gr.m[m][q] = gv; }
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { gr.m[m][q] = act_grad(z.m[m][q], ACT); a.m[m][q] = act_ct<ACT>(z.m[m][q]); }

@@ -1151,12 +1151,17 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   A.n_tiles = (int)((batch + tile - 1) / tile);
-  A.n_slots = tile == 16 ? bwdf16_slots(batch) : bwdf_slots(batch, n_steps, bptt);
+  // tiles of 32: trajectory-split teams (sdeh_bwdf2.hip; at most as many partial records as the channel-split kernel, whose sizes
+  // the scratch was checked against) unless the network has three hidden layers; SDEH_BWD_V1=1 keeps the channel-split kernel (A/B)
+  static const bool force_v1 = getenv("SDEH_BWD_V1") != nullptr;
+  const bool v2 = tile == 32 && !force_v1 && bwdf2_fits(d, net.n_hidden) && (d <= 32 || getenv("SDEH_BWD_V2") != nullptr);
+  A.n_slots = tile == 16 ? bwdf16_slots(batch) : (v2 ? bwdf2_slots(batch, n_steps, bptt) : bwdf_slots(batch, n_steps, bptt));
   A.wsize = bwdf_wsize(d, net.n_hidden);
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
-  rc = tile == 16 ? launch_bwdf16(A, st) : launch_bwdf(A, st);
+  rc = tile == 16 ? launch_bwdf16(A, st) : (v2 ? launch_bwdf2(A, st) : launch_bwdf(A, st));
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
-  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused%s<%s,tiles=%d>", tile == 16 ? "16" : "", bptt ? "bptt" : "rows", d <= 32 ? 1 : 2);
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused%s<%s,tiles=%d%s>", tile == 16 ? "16" : "", bptt ? "bptt" : "rows", d <= 32 ? 1 : 2,
+           tile == 16 ? "" : (v2 ? ",traj-split" : ",chan-split"));
   if (rc != SDEH_OK) return fail(rc, "ctrl_backward_fused: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   // deterministic sums over the teams / tiles
   float* s1 = sums;

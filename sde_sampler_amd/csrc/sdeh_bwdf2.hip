@@ -1,0 +1,701 @@
+// Fused training backward, trajectory-split teams (round 4).  Same contract, inputs, outputs and partial-
+// gradient records as sdeh_bwdf.hip (the reference's loss.backward() through losses/oc.py:176-222 / 301-334 / 416-446 and
+// models/mlp.py:114-122, solver/base.py:399-407); what changes is who owns what:
+//
+//   * sdeh_bwdf.hip splits a team's two waves by CHANNEL tile: every layer's input is both waves' output, so the chain of a step
+//     (re-evaluation + adjoint) crosses eight workgroup barriers, each followed by an LDS round trip, with one wave per SIMD and
+//     nothing to fill the gaps; with d <= 32 both waves mirror the out layer and the input gradient (64 of 296 MFMAs per step).
+//   * here a wave owns 32 trajectories and ALL 64 channels.  The accumulator layout of v_mfma_f32_32x32x2_f32 is also its B-operand
+//     layout (sdeh_common.hpp), so a layer's activated accumulators feed the next layer's MFMAs straight from registers: the chain
+//     of a step -- forward and transposed -- touches LDS only for the weights and crosses NO barrier.  Two row tiles per layer are
+//     two independent accumulator chains (no dependent-issue gap), operands are requested one k-group ahead.
+//   * the weight gradients contract over trajectories, i.e. need both operands transposed (lane = row): a wave publishes delta_k and
+//     a_k of its 32 trajectories to its own two LDS planes, and the team's two waves each take ONE ROW TILE of every gradient over the
+//     team's 64 trajectories (half the accumulators per wave: 6-8 tiles, the same record as sdeh_bwdf.hip).  Two barriers per product,
+//     both off the critical path of the arithmetic: the operands of a product are loaded into registers between them, and the
+//     product's 64 MFMAs are then issued INTERLEAVED with the chain's next transposed layer (four independent accumulators).
+//   * no mirror work; the funnel's per-trajectory sums and d loss / d gamma(t) need no cross-wave exchange (a wave has all coordinates).
+//   * with two coordinate tiles and two hidden layers the pre-activations are kept instead of (act, act'): act / act' are evaluated
+//     again in the backward stage that needs them (~2 k cycles per step) -- the price of holding 64 channels x 3 layers x 32
+//     trajectories next to eight gradient tiles in one wave's registers.
+//
+// Per step and SIMD: 528 (d <= 8) .. 752 (d = 50) matrix instructions for 32 trajectories against 2 x 296 (2 x 392) in sdeh_bwdf.hip.
+// One to two hidden layers; three keep sdeh_bwdf.hip.
+#include "sdeh_bwdf.hpp"
+#ifdef SDEH_BWDF_PROFILE
+#include <cstdio>
+#endif
+
+namespace sdeh {
+
+#ifdef SDEH_BWDF_PROFILE
+__device__ unsigned long long bwdf2_prof[16];
+#define BW2_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define BW2_ADD(k, t0, t1) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&bwdf2_prof[k], (t1) - (t0)); } while (0)
+#else
+#define BW2_T(var) do {} while (0)
+#define BW2_ADD(k, t0, t1) do {} while (0)
+#endif
+
+namespace bwdf2 {
+using namespace bwdf;
+
+// operands of one chunk (8 trajectories: 4 k-steps) of a weight-gradient product; chunk 4 w + c lives in the planes of the team's wave w
+struct DwChunk {
+  float4 dv, a0, a1;
+};
+
+// lane (i, h): delta row 32 R + i, a rows 32 c0 + i (and 32 (c0 + 1) + i), trajectories 8 c + 4 h .. + 3 of wave w's tile
+template <bool TWO>
+__device__ __forceinline__ void dw_load(const float* __restrict__ team_planes, int R, int c0, int i, int h, int k, DwChunk& o) {
+  const float* __restrict__ Dp = team_planes + (k >> 2) * 2 * PLANE;
+  const float* __restrict__ Ap = Dp + PLANE;
+  o.dv = plane_getT(Dp, R, i, h, k & 3);
+  o.a0 = plane_getT(Ap, c0, i, h, k & 3);
+  if constexpr (TWO) o.a1 = plane_getT(Ap, c0 + 1, i, h, k & 3);
+}
+
+__device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
+
+// one chunk of a product (4 or 8 matrix instructions)
+template <bool TWO>
+__device__ __forceinline__ void dw_chunk(const DwChunk& o, f32x16& acc0, f32x16& acc1) {
+  acc0 = SDEH_MFMA(o.dv.x, o.a0.x, acc0);
+  if constexpr (TWO) acc1 = SDEH_MFMA(o.dv.x, o.a1.x, acc1);
+  acc0 = SDEH_MFMA(o.dv.y, o.a0.y, acc0);
+  if constexpr (TWO) acc1 = SDEH_MFMA(o.dv.y, o.a1.y, acc1);
+  acc0 = SDEH_MFMA(o.dv.z, o.a0.z, acc0);
+  if constexpr (TWO) acc1 = SDEH_MFMA(o.dv.z, o.a1.z, acc1);
+  acc0 = SDEH_MFMA(o.dv.w, o.a0.w, acc0);
+  if constexpr (TWO) acc1 = SDEH_MFMA(o.dv.w, o.a1.w, acc1);
+}
+
+// Forward layer from registers:  o[R] += sum_{s < ng} sum_e W[32 R + i][8 s + 4 h + e] * b[s >> 2][4 (s & 3) + e]   (R < NR)
+// wrow = &W[i * ld + 4 h]; the second row tile is 32 ld floats further.  One accumulator per row tile, k order (s, e) as in
+// sdeh_bwdf.hip's mm_rows and the forward kernel: the pre-activations are the forward launch's bit for bit.
+template <int NG, int NB, int NR>
+__device__ __forceinline__ void fwd_rows(const float* __restrict__ wrow, int ld, const f32x16 (&b)[NB], int ng, f32x16 (&o)[NR]) {
+  float4 w[2][NR];
+#pragma unroll
+  for (int R = 0; R < NR; ++R) w[0][R] = *reinterpret_cast<const float4*>(wrow + 32 * R * ld);
+#pragma unroll
+  for (int s = 0; s < NG; ++s) {
+    if (s < ng) {
+      if (s + 1 < NG && s + 1 < ng) {
+#pragma unroll
+        for (int R = 0; R < NR; ++R) w[(s + 1) & 1][R] = *reinterpret_cast<const float4*>(wrow + 32 * R * ld + 8 * (s + 1));
+      }
+      const f32x16& bt = b[s >> 2];
+      const int q0 = 4 * (s & 3);
+#pragma unroll
+      for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(w[s & 1][R].x, bt[q0], o[R]);
+#pragma unroll
+      for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(w[s & 1][R].y, bt[q0 + 1], o[R]);
+#pragma unroll
+      for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(w[s & 1][R].z, bt[q0 + 2], o[R]);
+#pragma unroll
+      for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(w[s & 1][R].w, bt[q0 + 3], o[R]);
+      SDEH_FENCE();
+    }
+  }
+}
+
+// One backward stage, entered behind the barrier that made the team's (delta_k, a_k) planes visible: the transposed layer from registers
+//     o[R] = sum_{s < ng} sum_e W[(8 s + 4 h + e) * LD + 32 R + i] * b[s >> 2][4 (s & 3) + e]        (R < NR; wcol = &W[4 h * LD + i])
+// issued interleaved with the eight chunks of the weight-gradient product  acc0 (, acc1) += delta[row tile R] a[tile c0 (, c0 + 1)]^T
+// over the team's 64 trajectories (operands one chunk ahead through a ring: 24 registers instead of a whole product's 96).
+// dsum[w] += this lane's delta values of wave w's trajectories (bias gradients, d loss / d emb[t]).  Ends with the barrier behind
+// which the planes may be overwritten.
+template <int NGC, int LD, int NR, int NB, bool TWO>
+__device__ __forceinline__ void stage_cols(const float* __restrict__ wcol, const f32x16 (&b)[NB], int ng, f32x16 (&o)[NR],
+                                           const float* __restrict__ team_planes, int Rd, int c0, int i, int h,
+                                           f32x16& acc0, f32x16& acc1, float (&dsum)[2]) {
+#pragma unroll
+  for (int R = 0; R < NR; ++R)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o[R][q] = 0.0f;
+  float wc[2][4][NR];
+  DwChunk ck[2];
+  dw_load<TWO>(team_planes, Rd, c0, i, h, 0, ck[0]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int R = 0; R < NR; ++R) wc[0][e][R] = wcol[e * LD + 32 * R];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const bool chain = s < NGC && s < ng;
+    if (s + 1 < 8) dw_load<TWO>(team_planes, Rd, c0, i, h, s + 1, ck[(s + 1) & 1]);
+    if (s + 1 < NGC && s + 1 < ng) {
+      const float* __restrict__ p = wcol + 8 * (s + 1) * LD;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int R = 0; R < NR; ++R) wc[(s + 1) & 1][e][R] = p[e * LD + 32 * R];
+    }
+    if (chain) {
+      const f32x16& bt = b[(s >> 2) < NB ? (s >> 2) : 0];
+      const int q0 = 4 * (s & 3);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(wc[s & 1][e][R], bt[q0 + e], o[R]);
+    }
+    dsum[s >> 2] += sum4(ck[s & 1].dv);
+    dw_chunk<TWO>(ck[s & 1], acc0, acc1);
+    SDEH_FENCE();
+  }
+  ws_barrier();
+}
+
+}  // namespace bwdf2
+
+template <int OTD, bool BPTT, int LH, bool RECOMP>
+__global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
+  using namespace bwdf2;
+  constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
+  constexpr int NDW = OTD + 2 * LH + (OTD == 2 ? 2 : 1);  // weight-gradient tiles of a wave: input_embed, hidden, out_layer
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* __restrict__ Win = lds;
+  float* __restrict__ Whid = Win + 64 * RSI;
+  float* __restrict__ Wout = Whid + LH * 64 * RSW;
+  float* __restrict__ bh = Wout + DPP * RSW;
+  float* __restrict__ bo = bh + LH * 64;
+  float* __restrict__ tabs = bo + 64;
+  const WsLayout& L = A.lay;
+  const float* __restrict__ ws = A.ws;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 1, r = wave & 1;
+  const int j = lane & 31, h = lane >> 5;
+  float* __restrict__ team_planes = tabs + TABS + team * 4 * PLANE;  // wave (team, w): D at w * 2 PLANE, A behind it
+  float* __restrict__ Dme = team_planes + r * 2 * PLANE;
+  float* __restrict__ Ame = Dme + PLANE;
+  const int d = A.d, T = A.n_steps;
+  const long long B = A.batch;
+
+  // ---- stage the parameters (natural layouts, zero padding) and the Gaussian tables ----------------------------------------
+  for (int idx = tid; idx < 64 * RSI; idx += 256) {
+    const int row = idx / RSI, col = idx - row * RSI;
+    Win[idx] = col < d ? A.w_in[row * d + col] : 0.0f;
+  }
+  for (int idx = tid; idx < LH * 64 * RSW; idx += 256) {
+    const int l = idx / (64 * RSW), rem = idx - l * 64 * RSW, row = rem / RSW, col = rem - row * RSW;
+    Whid[idx] = col < 64 ? A.w_hid[l][row * 64 + col] : 0.0f;
+  }
+  for (int idx = tid; idx < DPP * RSW; idx += 256) {
+    const int row = idx / RSW, col = idx - row * RSW;
+    Wout[idx] = (row < d && col < 64) ? A.w_out[row * 64 + col] : 0.0f;
+  }
+  if (tid < LH * 64) bh[tid] = A.b_hid[tid >> 6][tid & 63];
+  if (tid < 64) bo[tid] = tid < d ? A.b_out[tid] : 0.0f;
+  for (int idx = tid; idx < TABS; idx += 256) {  // tabs[(2 k + c) * 64 + coordinate]: c = 0 mean, 1 inverse variance; k = prior, second, target
+    const int k = idx / 128, c = (idx >> 6) & 1, cj = idx & 63;
+    const int which = k == 0 ? 1 : (k == 1 ? 2 : 0);
+    tabs[idx] = cj < d && cj < L.dp ? ws[L.dg[which] + 2 * cj + c] : 0.0f;
+  }
+  for (int idx = tid; idx < 2 * 4 * PLANE; idx += 256) tabs[TABS + idx] = 0.0f;  // never-written rows / trajectories must not hold NaNs
+  __syncthreads();
+
+  const int act = A.act, ctrl_kind = A.ctrl_kind, flags = A.flags;
+  const bool has_score = ctrl_kind != SDEH_CTRL_CLIPPED;
+  const bool refc = (flags & SDEH_FLAG_REFERENCE_CTRL) && A.loss_kind == SDEH_LOSS_REFERENCE_SDE;
+  const bool expo = A.loss_kind == SDEH_LOSS_EXPONENTIAL;
+  const bool ito = (flags & SDEH_FLAG_ITO) != 0;
+  const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
+
+  // weight-gradient accumulators (as in sdeh_bwdf.hip): [0, OTD) input_embed: row tile r x coordinate tiles; hidden layer l: row
+  // tile r x 2; out_layer: OTD == 2: coordinate tile r x 2 channel tiles; OTD == 1: coordinate tile 0 x channel tile r
+  f32x16 dw[NDW];
+#pragma unroll
+  for (int k = 0; k < NDW; ++k)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dw[k][q] = 0.0f;
+  float bs_hid[LH], bs_out = 0.0f;
+#pragma unroll
+  for (int l = 0; l < LH; ++l) bs_hid[l] = 0.0f;
+
+  // Items: pairs of 32-trajectory tiles (through time) or (step, pair), step-major (row-parallel); team team_g takes item team_g,
+  // team_g + n_teams, ...; wave r of the team owns tile 2 pair + r (an odd tile count leaves the last pair's second wave shadowing
+  // the last tile with zero weights).
+  const int n_tiles = A.n_tiles, n_pairs = (n_tiles + 1) >> 1;
+  const int n_teams = (int)gridDim.x * 2, team_g = (int)blockIdx.x * 2 + team;
+  const long long n_items = BPTT ? (long long)n_pairs : (long long)n_pairs * T;
+  const long long n_rounds = (n_items + n_teams - 1) / n_teams;
+  const int d_t = BPTT ? 0 : n_teams / n_pairs, d_pair = BPTT ? n_teams : n_teams % n_pairs;
+  int it_t = BPTT ? T - 1 : team_g / n_pairs, it_pair = BPTT ? team_g : team_g % n_pairs;  // the current item
+  auto advance = [&](int& t_io, int& pair_io) {
+    pair_io += d_pair;
+    if constexpr (!BPTT) {
+      t_io += d_t;
+      if (pair_io >= n_pairs) { pair_io -= n_pairs; t_io += 1; }
+    }
+  };
+  auto item_live = [&](int t_i, int pair_i) { return BPTT ? pair_i < n_pairs : t_i < T; };
+  auto clamp_item = [&](int& t_io, int& pair_io) {  // a team without an item shadows the last one (and contributes zeros)
+    if (!item_live(t_io, pair_io)) { t_io = T - 1; pair_io = n_pairs - 1; }
+  };
+  auto tile_of = [&](int pair_i) { const int tl = 2 * pair_i + r; return tl < n_tiles ? tl : n_tiles - 1; };
+
+  // 16 coordinates (32 ct + 4 h + rrow(q)) of column `col` of a coordinate-major plane [d][B] with a WAVE-UNIFORM start: one scalar
+  // base + a 32-bit byte offset per element, the lane's part opaque per call (sdeh_bwdf.hip: 64-bit element addresses become loop
+  // invariants that spill); coordinates >= d read a valid element and are zeroed by a select.
+  const unsigned Bu = (unsigned)B;
+  auto load_cm16 = [&](const float* __restrict__ plane_u, unsigned col, int ct) {
+    f32x16 v;
+    const int cb = 32 * ct + 4 * h;
+    unsigned lane_off = ((unsigned)(cb < d ? cb : 0) * Bu + col) * 4u;
+    asm volatile("" : "+v"(lane_off));
+    const char* __restrict__ pb = reinterpret_cast<const char*>(plane_u);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const bool ok = cb + rrow(q) < d;
+      const unsigned off = ok ? lane_off + (unsigned)rrow(q) * Bu * 4u : lane_off;
+      const float val = *reinterpret_cast<const float*>(pb + off);
+      v[q] = ok ? val : 0.0f;
+    }
+    return v;
+  };
+  auto load_x = [&](int t, int tile_i, f32x16 (&xo)[OTD]) {
+    const long long rw = (long long)tile_i * 32 + j;
+    const unsigned col = (unsigned)(rw < B ? rw : B - 1);
+#pragma unroll
+    for (int ct = 0; ct < OTD; ++ct) xo[ct] = load_cm16(A.xs + (long long)t * d * B, col, ct);
+  };
+  auto load_emb = [&](int t, f32x16 (&eo)[2]) {  // timestep_embed(t) + input bias, accumulator order: the FIRST addend of the input layer
+#pragma unroll
+    for (int R = 0; R < 2; ++R) eo[R] = load16(ws + L.emb + t * C + (R * 2 + h) * 16);
+  };
+
+  f32x16 xnext[OTD], embnext[2];
+  {
+    int t0 = it_t, p0 = it_pair;
+    clamp_item(t0, p0);
+    load_x(t0, tile_of(p0), xnext);
+    load_emb(t0, embnext);
+  }
+  for (long long round = 0; round < n_rounds; ++round) {
+    const bool live_item = item_live(it_t, it_pair);
+    int cur_t = it_t, cur_pair = it_pair;
+    clamp_item(cur_t, cur_pair);
+    const bool live_tile = live_item && 2 * cur_pair + r < n_tiles;
+    const long long tile = tile_of(cur_pair);
+    const long long row = tile * 32 + j;
+    const bool live = live_tile && row < B;
+    const long long lrow = row < B ? row : B - 1;
+    const float wi = live ? A.grad_rnd[lrow] : 0.0f;
+    const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+
+    f32x16 lam[OTD];
+#pragma unroll
+    for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) lam[ct][q] = 0.0f;
+    if constexpr (BPTT) {  // lambda_T = w_i d(terminal costs)/dx_T  (losses/oc.py:225,337,449-450)
+#pragma unroll
+      for (int ct = 0; ct < OTD; ++ct) {
+        const int cb = 32 * ct + 4 * h;
+        if (flags & SDEH_FLAG_TERMINAL_SECOND) {
+          const f32x16 xT = load_cm16(A.xs + (long long)T * d * B, (unsigned)lrow, ct);
+          const f32x16 smu = rows16(tabs + 2 * 64 + cb), sis = rows16(tabs + 3 * 64 + cb);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) lam[ct][q] = wi * (smu[q] - xT[q]) * sis[q];
+        }
+        if ((flags & SDEH_FLAG_TERMINAL_TARGET) && A.tscore != nullptr) {
+          const f32x16 st = load_cm16(A.tscore, (unsigned)lrow, ct);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) lam[ct][q] = fmaf(-wi, st[q], lam[ct][q]);
+        }
+      }
+    }
+    const int t_first = cur_t;
+    const int t_last = BPTT ? 0 : t_first;
+    advance(it_t, it_pair);  // from here on: the team's NEXT item
+
+    for (int t = t_first; t >= t_last; --t) {
+      BW2_T(tp0);
+      f32x16 x[OTD], embv[2];
+#pragma unroll
+      for (int ct = 0; ct < OTD; ++ct) x[ct] = xnext[ct];
+      embv[0] = embnext[0]; embv[1] = embnext[1];
+      // the step's other inputs: requested first, consumed after the forward pass
+      f32x16 scv[OTD];
+      if (has_score) {
+#pragma unroll
+        for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm16(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
+      }
+      const float gam0 = has_score ? ws[L.gam + t * L.g] : 0.0f;  // gamma(t) (its first entry)
+      cfp cf = as_const(ws + L.coef + t * kCoefStride);
+      const float sig = cf[CF_SIGMA], wl = cf[CF_W];
+      const float c_i = expo ? cf[CF_SBK] : cf[CF_SQDT];
+      const float cdt = expo ? cf[CF_B2S2] : cf[CF_DT];
+      const float c_u = expo ? cf[CF_B2S2] : sig * cf[CF_DT];
+      const float c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], cf[CF_DT], 1.0f);
+
+      // ======================================================================================= forward (re-evaluation at x_t)
+      // keep[k]: RECOMP ? Z_k : act'(Z_k)  (k = 0 .. LH);   akeep[k] = a_{k+1} = act(Z_k)  (k < LH; not with RECOMP)
+      f32x16 keep[LH + 1][2];
+      f32x16 akeep[RECOMP ? 1 : LH][2];
+      f32x16 cur[2];
+      {
+        f32x16 z[2] = {embv[0], embv[1]};
+        fwd_rows<4 * OTD, OTD, 2>(Win + j * RSI + 4 * h, RSI, x, A.n_kg, z);
+        BW2_T(tpa);
+        BW2_ADD(9, tp0, tpa);
+        if constexpr (RECOMP) {
+          keep[0][0] = z[0]; keep[0][1] = z[1];
+          SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(z[0]); act_tile<ACT>(z[1]););
+          cur[0] = z[0]; cur[1] = z[1];
+        } else {
+          SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[0][0]); act_both<ACT>(z[1], cur[1], keep[0][1]););
+          akeep[0][0] = cur[0]; akeep[0][1] = cur[1];
+        }
+        BW2_T(tpb);
+        BW2_ADD(10, tpa, tpb);
+      }
+      BW2_T(tpc);
+#pragma unroll
+      for (int l = 0; l < LH; ++l) {  // hidden layer l: Z_{l+1} = W_l a_{l+1} + b_l;  a_{l+2} = act(Z_{l+1})
+        f32x16 z[2] = {rows16(bh + l * 64 + 4 * h), rows16(bh + l * 64 + 32 + 4 * h)};
+        fwd_rows<8, 2, 2>(Whid + l * 64 * RSW + j * RSW + 4 * h, RSW, cur, 8, z);
+        if constexpr (RECOMP) {
+          keep[l + 1][0] = z[0]; keep[l + 1][1] = z[1];
+          SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(z[0]); act_tile<ACT>(z[1]););
+          cur[0] = z[0]; cur[1] = z[1];
+        } else {
+          SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[l + 1][0]); act_both<ACT>(z[1], cur[1], keep[l + 1][1]););
+          if (l + 1 < LH) { akeep[l + 1 < LH ? l + 1 : 0][0] = cur[0]; akeep[l + 1 < LH ? l + 1 : 0][1] = cur[1]; }
+        }
+      }
+      BW2_T(tpd);
+      BW2_ADD(11, tpc, tpd);
+      // a_{LH+1} goes to the A plane at once (free since the previous product's second barrier); the out layer reads the registers
+      plane_put(Ame, 0, j, h, cur[0]);
+      plane_put(Ame, 1, j, h, cur[1]);
+      f32x16 nn[OTD];
+#pragma unroll
+      for (int ct = 0; ct < OTD; ++ct) nn[ct] = rows16(bo + 32 * ct + 4 * h);
+      fwd_rows<8, 2, OTD>(Wout + j * RSW + 4 * h, RSW, cur, 8, nn);
+      BW2_T(tp1);
+      BW2_ADD(12, tpd, tp1);
+
+      // ======================================================================================= upstream gradient of the control
+      // (and, through time, everything of the adjoint update that does not need W_in^T delta_0)
+      f32x16 dout[OTD];
+      {
+        float gsum = 0.0f;
+        const float mult = (ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig) * A.scale_score;
+        const float coef_t = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET ? wl : 0.0f);
+        const float coef_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR ? 1.0f - wl : 0.0f;
+        // score terms the reference detaches (reparam.py:58,134,169,188) or obtains by autograd without a graph carry no Jacobian
+        const float jac_t = (!has_score || (flags & (SDEH_FLAG_DETACH_SCORE | SDEH_FLAG_TARGET_SCORE_CONST))) ? 0.0f : coef_t;
+        const float jac_p = (!has_score || (flags & SDEH_FLAG_DETACH_SCORE)) ? 0.0f : coef_p;
+        f32x16 cvec[OTD], Gc[OTD];
+#pragma unroll
+        for (int ct = 0; ct < OTD; ++ct) {
+          const int cb = 32 * ct + 4 * h;
+          f32x16 xi;
+          if (ito) {
+            float n[16];
+            if (A.noise != nullptr) {
+              const float* __restrict__ rowp = A.noise + ((long long)t * B + lrow) * d;
+#pragma unroll
+              for (int q = 0; q < 16; ++q) n[q] = cb + rrow(q) < d ? rowp[cb + rrow(q)] : 0.0f;
+            } else {
+#pragma unroll
+              for (int g4 = 0; g4 < 4; ++g4) {
+                float n4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (cb + 8 * g4 < d) box_muller4(philox_block(A.seed, rng_off, grow, t, (cb + 8 * g4) >> 2), n4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n[4 * g4 + e] = n4[e];
+                SDEH_FENCE();
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xi[q] = cb + rrow(q) < d ? n[q] : 0.0f;
+          }
+          f32x16 rr;  // reference control sigma * prior.score(x) (solver/oc.py:305-306)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) rr[q] = 0.0f;
+          if (BPTT && refc) {
+            const f32x16 pmu = rows16(tabs + 0 * 64 + cb), pis = rows16(tabs + 1 * 64 + cb);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rr[q] = sig * (pmu[q] - x[ct][q]) * pis[q];
+          }
+          f32x16 gcoord;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            float mfac = 0.0f, csc = 0.0f, keep_s = 0.0f;
+            if (has_score) {
+              const float gam = A.g == 1 ? gam0 : ws[L.gam + t * L.g + min(cb + rrow(q), L.g - 1)];
+              mfac = mult * gam;
+              csc = clipf(scv[ct][q], A.clip_score);
+              keep_s = fabsf(scv[ct][q]) <= A.clip_score ? 1.0f : 0.0f;
+            }
+            float gc = ito ? wi * c_i * xi[q] : 0.0f;
+            if constexpr (BPTT) {
+              const float u = clipf(nn[ct][q], A.clip_model) + mfac * csc;
+              gc = wi * fmaf(u - rr[q], cdt, ito ? c_i * xi[q] : 0.0f);
+            }
+            const float gq = BPTT ? fmaf(c_u, lam[ct][q], gc) : gc;
+            Gc[ct][q] = gc;
+            const float gg = gq * mult * csc;
+            gcoord[q] = gg;
+            gsum += gg;
+            cvec[ct][q] = keep_s * mfac * gq;
+            dout[ct][q] = fabsf(nn[ct][q]) <= A.clip_model ? gq : 0.0f;
+          }
+          if (has_score && live_tile && A.g != 1) {  // d loss / d gamma(t) per coordinate: over the 32 trajectories of this lane half
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float v = sum_xor16(sum_row16(gcoord[q]));
+              if (j == 0) A.gpart[(tile * T + t) * A.gw + cb + rrow(q)] = v;
+            }
+          }
+        }
+        if (has_score && live_tile && A.g == 1) {  // summed over the tile's trajectories and all coordinates
+          gsum = sum_wave(gsum);
+          if (lane < 2) A.gpart[(tile * T + t) * A.gw + lane] = lane == 0 ? gsum : 0.0f;
+        }
+        if constexpr (BPTT) {
+          // ===================================================================================== adjoint update, first part
+          //   lambda_t = c_x lambda_{t+1} + (d score term / d x)^T G + direct cost terms  [+ W_in^T delta_0 at the end of the step]
+          f32x16 vt[OTD];
+#pragma unroll
+          for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) vt[ct][q] = 0.0f;
+          if (jac_t != 0.0f) {  // closed-form target scores are differentiated through x
+            if (A.target.kind == SDEH_DENS_DIAG_GAUSS) {
+#pragma unroll
+              for (int ct = 0; ct < OTD; ++ct) {
+                const f32x16 tis = rows16(tabs + 5 * 64 + 32 * ct + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) vt[ct][q] = -tis[q] * cvec[ct][q];
+              }
+            } else if (A.target.kind == SDEH_DENS_MULTI_WELL) {
+#pragma unroll
+              for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                  const float y = x[ct][q] - A.target.p1;
+                  vt[ct][q] = (32 * ct + 4 * h + rrow(q) < A.target.n_comp ? -4.0f * (3.0f * y * y - A.target.p0) : -1.0f) * cvec[ct][q];
+                }
+            } else if (A.target.kind == SDEH_DENS_FUNNEL) {
+              // s_0 = -x0/var - (d-1)/2 + e^{-x0} sum x_j^2 / 2,  s_j = -x_j e^{-x0}   (coordinate 0 = register 0 of the h = 0 half of
+              // coordinate tile 0); the sums run over all coordinates: registers, tiles and the two lane halves of this wave
+              const float x0 = __shfl(x[0][0], j), c0 = __shfl(cvec[0][0], j);
+              float sq = 0.0f, cx = 0.0f;
+#pragma unroll
+              for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                  const bool first = q == 0 && h == 0 && ct == 0;
+                  sq = fmaf(first ? 0.0f : x[ct][q], x[ct][q], sq);
+                  cx = fmaf(first ? 0.0f : cvec[ct][q], x[ct][q], cx);
+                }
+              sq = sum_xor32(sq);
+              cx = sum_xor32(cx);
+              const float iv = __expf(-x0);
+#pragma unroll
+              for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) vt[ct][q] = iv * (c0 * x[ct][q] - cvec[ct][q]);
+              if (h == 0) vt[0][0] = c0 * (-1.0f / A.target.p0 - 0.5f * iv * sq) + iv * cx;
+            }
+          }
+#pragma unroll
+          for (int ct = 0; ct < OTD; ++ct) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) lam[ct][q] = fmaf(jac_t, vt[ct][q], c_x * lam[ct][q]);
+            if (jac_p != 0.0f || refc) {
+              const f32x16 pis = rows16(tabs + 1 * 64 + 32 * ct + 4 * h);
+#pragma unroll
+              for (int q = 0; q < 16; ++q) {
+                float v = fmaf(-jac_p * pis[q], cvec[ct][q], lam[ct][q]);  // Gaussian prior: J = -1/sigma^2
+                if (refc) v = fmaf(sig * pis[q], Gc[ct][q], v);             // cost depends on x through sigma * prior.score(x)
+                lam[ct][q] = v;
+              }
+            }
+          }
+        }
+      }
+      BW2_T(tp2);
+
+      // ======================================================================================= backward + weight gradients
+      // each product: publish (delta_k, a_k), barrier, operands -> registers, barrier (planes free again), then the product's matrix
+      // instructions interleaved with the chain's next transposed layer
+#pragma unroll
+      for (int ct = 0; ct < OTD; ++ct) plane_put(Dme, ct, j, h, dout[ct]);
+      ws_barrier();
+      f32x16 dl[2];
+      {
+        float ds[2] = {0.0f, 0.0f};
+        if constexpr (OTD == 2)
+          stage_cols<8, RSW, 2, 2, true>(Wout + 4 * h * RSW + j, dout, A.n_kg, dl, team_planes, r, 0, j, h, dw[OTD + 2 * LH], dw[NDW - 1], ds);
+        else
+          stage_cols<4, RSW, 2, 1, false>(Wout + 4 * h * RSW + j, dout, A.n_kg, dl, team_planes, 0, r, j, h, dw[OTD + 2 * LH], dw[OTD + 2 * LH], ds);
+        bs_out += ds[0] + ds[1];
+      }
+      BW2_T(tp3);
+#pragma unroll
+      for (int l = LH - 1; l >= -1; --l) {
+        BW2_T(tq0);
+        // dl = d loss / d a_{l+2};  delta = dl . act'(Z_{l+1});  publish with a_{l+1} (l = -1: x)
+        if constexpr (RECOMP) {
+          // act'(Z_{l+1}) and a_{l+1} = act(Z_l) are evaluated again here instead of living in registers since the forward pass
+          f32x16 gz[2];
+          SDEH_ACT_SWITCH(act, ACT, {
+            f32x16 tmp;
+            act_both<ACT>(keep[l + 1][0], tmp, gz[0]);
+            act_both<ACT>(keep[l + 1][1], tmp, gz[1]);
+          });
+#pragma unroll
+          for (int q = 0; q < 16; ++q) { dl[0][q] *= gz[0][q]; dl[1][q] *= gz[1][q]; }
+          if (l >= 0) {
+            f32x16 ak[2] = {keep[l >= 0 ? l : 0][0], keep[l >= 0 ? l : 0][1]};
+            SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(ak[0]); act_tile<ACT>(ak[1]););
+            plane_put(Ame, 0, j, h, ak[0]);
+            plane_put(Ame, 1, j, h, ak[1]);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) { dl[0][q] *= keep[l + 1][0][q]; dl[1][q] *= keep[l + 1][1][q]; }
+          if (l >= 0) {
+            plane_put(Ame, 0, j, h, akeep[l >= 0 ? l : 0][0]);
+            plane_put(Ame, 1, j, h, akeep[l >= 0 ? l : 0][1]);
+          }
+        }
+        if (l < 0) {
+#pragma unroll
+          for (int ct = 0; ct < OTD; ++ct) plane_put(Ame, ct, j, h, x[ct]);
+        }
+        plane_put(Dme, 0, j, h, dl[0]);
+        plane_put(Dme, 1, j, h, dl[1]);
+        BW2_T(tq1);
+        ws_barrier();
+        BW2_T(tq2);
+        BW2_ADD(13, tq0, tq1); BW2_ADD(14, tq1, tq2);
+        float ds[2] = {0.0f, 0.0f};
+        if (l >= 0) {
+          f32x16 dn[2];
+          stage_cols<8, RSW, 2, 2, true>(Whid + (l >= 0 ? l : 0) * 64 * RSW + 4 * h * RSW + j, dl, 8, dn, team_planes, r, 0, j, h,
+                                         dw[OTD + 2 * (l >= 0 ? l : 0)], dw[OTD + 2 * (l >= 0 ? l : 0) + 1], ds);
+          bs_hid[l >= 0 ? l : 0] += ds[0] + ds[1];
+          dl[0] = dn[0]; dl[1] = dn[1];
+        } else {
+          // the next step's (or item's) x and time embedding: requested in front of the step's last block of matrix instructions
+          if (t > t_last) {
+            load_x(t - 1, (int)tile, xnext);
+            load_emb(t - 1, embnext);
+          } else if (round + 1 < n_rounds) {
+            int tn = it_t, pn = it_pair;
+            clamp_item(tn, pn);
+            load_x(tn, tile_of(pn), xnext);
+            load_emb(tn, embnext);
+          }
+          f32x16 dx[OTD];
+          stage_cols<(BPTT ? 8 : 0), RSI, OTD, 2, (OTD == 2)>(Win + 4 * h * RSI + j, dl, 8, dx, team_planes, r, 0, j, h, dw[0], dw[OTD - 1], ds);
+          // d loss / d (time embedding + input bias)[t][32 r + i] per tile of the pair (ds[w]: wave w's trajectories)
+          const float e0 = sum_xor32(ds[0]), e1 = sum_xor32(ds[1]);
+          if (live_item && h == 0) {
+            const long long tl0 = 2 * (long long)cur_pair;
+            A.epart[(tl0 * T + t) * 64 + 32 * r + j] = e0;
+            if (tl0 + 1 < n_tiles) A.epart[((tl0 + 1) * T + t) * 64 + 32 * r + j] = e1;
+          }
+          if constexpr (BPTT) {
+#pragma unroll
+            for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+              for (int q = 0; q < 16; ++q) lam[ct][q] += dx[ct][q];
+          }
+        }
+      }
+      BW2_T(tp4);
+      BW2_ADD(0, tp0, tp1); BW2_ADD(1, tp1, tp2); BW2_ADD(2, tp2, tp3); BW2_ADD(3, tp3, tp4); BW2_ADD(7, tp0, tp4); BW2_ADD(8, 0ull, 1ull);
+    }
+  }
+
+  // ---- the team's partial gradients ---------------------------------------------------------------------------------------
+  float* __restrict__ rec = A.wpart + (long long)team_g * A.wsize;
+#pragma unroll
+  for (int k = 0; k < OTD; ++k) store_tile(rec, DPP, r, k, j, h, dw[k]);
+#pragma unroll
+  for (int l = 0; l < LH; ++l) {
+    store_tile(rec + off_whid<OTD>() + l * 4096, 64, r, 0, j, h, dw[OTD + 2 * l]);
+    store_tile(rec + off_whid<OTD>() + l * 4096, 64, r, 1, j, h, dw[OTD + 2 * l + 1]);
+    float b = bs_hid[l];
+    b += __shfl_xor(b, 32);
+    if (h == 0) rec[off_bhid<OTD, LH>() + l * 64 + 32 * r + j] = b;
+  }
+  {
+    float b = bs_out;
+    b += __shfl_xor(b, 32);
+    if constexpr (OTD == 2) {
+      store_tile(rec + off_wout<OTD, LH>(), 64, r, 0, j, h, dw[OTD + 2 * LH]);
+      store_tile(rec + off_wout<OTD, LH>(), 64, r, 1, j, h, dw[OTD + 2 * LH + 1]);
+      if (h == 0) rec[off_bout<OTD, LH>() + 32 * r + j] = b;
+    } else {
+      store_tile(rec + off_wout<OTD, LH>(), 64, 0, r, j, h, dw[OTD + 2 * LH]);
+      if (h == 0 && r == 0) rec[off_bout<OTD, LH>() + j] = b;
+    }
+  }
+}
+
+template <int OTD, bool BPTT, int LH>
+static int launch_bwdf2_t(const BwdfArgs& a, hipStream_t stream) {
+  constexpr bool RECOMP = OTD == 2 && LH == 2;
+  const size_t lds_bytes = (size_t)bwdf::lds_floats<OTD, LH>() * sizeof(float);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  static bool attr_done[kMaxDevices] = {};
+  bool& attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, BPTT, LH, RECOMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bwdf2_kernel<OTD, BPTT, LH, RECOMP>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+bool bwdf2_fits(int d, int n_hidden) { return n_hidden >= 1 && n_hidden <= 2 && bwdf_fits(d, n_hidden); }
+
+// teams (of two 32-trajectory tiles) the launch uses: two per workgroup, one workgroup per CU
+int bwdf2_slots(long long batch, int n_steps, bool bptt) {
+  const long long tiles = (batch + 31) / 32, pairs = (tiles + 1) / 2;
+  const long long items = bptt ? pairs : pairs * n_steps;
+  const long long wgs = (items + 1) / 2;
+  return 2 * (int)(wgs < 256 ? wgs : 256);
+}
+
+#ifdef SDEH_BWDF_PROFILE
+static void bwdf2_prof_dump(hipStream_t stream) {
+  (void)hipStreamSynchronize(stream);
+  unsigned long long v[16];
+  (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(bwdf2_prof), sizeof(v));
+  const double n = v[8] ? (double)v[8] : 1.0;
+  fprintf(stderr, "bwdf2 phases (cycles per step of block 0 / wave 0, %llu steps): forward %.0f | elementwise %.0f | out stage %.0f | "
+          "hidden + in stages %.0f | step %.0f || forward: in mm %.0f, in act %.0f, hidden %.0f, publish + out mm %.0f || stages: act' + publish %.0f, "
+          "barrier %.0f\n", v[8], v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[7] / n, v[9] / n, v[10] / n, v[11] / n, v[12] / n, v[13] / n, v[14] / n);
+  unsigned long long z[16] = {};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(bwdf2_prof), z, sizeof(z));
+}
+#endif
+
+int launch_bwdf2(const BwdfArgs& a, hipStream_t stream) {
+#ifdef SDEH_BWDF_PROFILE
+  struct Dump { hipStream_t s; ~Dump() { bwdf2_prof_dump(s); } } dump{stream};
+#endif
+  const bool bptt = !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  if (a.n_hidden == 1) {
+    if (a.d <= 32) return bptt ? launch_bwdf2_t<1, true, 1>(a, stream) : launch_bwdf2_t<1, false, 1>(a, stream);
+    return bptt ? launch_bwdf2_t<2, true, 1>(a, stream) : launch_bwdf2_t<2, false, 1>(a, stream);
+  }
+  if (a.n_hidden == 2) {
+    if (a.d <= 32) return bptt ? launch_bwdf2_t<1, true, 2>(a, stream) : launch_bwdf2_t<1, false, 2>(a, stream);
+    return bptt ? launch_bwdf2_t<2, true, 2>(a, stream) : launch_bwdf2_t<2, false, 2>(a, stream);
+  }
+  return SDEH_ERR_UNSUPPORTED;
+}
+
+}  // namespace sdeh

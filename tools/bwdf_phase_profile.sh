@@ -8,8 +8,10 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 if [ "${1:-build}" = "build" ]; then
   mkdir -p $ROOT/prof_tmp
   cd $ROOT/sde_sampler_amd/csrc
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fno-slp-vectorize --offload-arch=gfx950 -Wno-comment -DSDEH_BWDF_PROFILE -c sdeh_bwdf.hip -o /tmp/bwdf_prof.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v sdeh_bwdf.o) /tmp/bwdf_prof.o -o $ROOT/prof_tmp/libsdeh_prof.so
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fno-slp-vectorize --offload-arch=gfx950 -Wno-comment -DSDEH_BWDF_PROFILE -c sdeh_bwdf.hip -o /tmp/bwdf_prof.o &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fno-slp-vectorize --offload-arch=gfx950 -Wno-comment -DSDEH_BWDF_PROFILE -c sdeh_bwdf2.hip -o /tmp/bwdf2_prof.o
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v "sdeh_bwdf.o\|sdeh_bwdf2.o") /tmp/bwdf_prof.o /tmp/bwdf2_prof.o -o $ROOT/prof_tmp/libsdeh_prof.so
   echo "built $ROOT/prof_tmp/libsdeh_prof.so"
 else
   cd $ROOT

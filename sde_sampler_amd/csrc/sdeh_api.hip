@@ -1154,7 +1154,11 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   // tiles of 32: trajectory-split teams (sdeh_bwdf2.hip; at most as many partial records as the channel-split kernel, whose sizes
   // the scratch was checked against) unless the network has three hidden layers; SDEH_BWD_V1=1 keeps the channel-split kernel (A/B)
   static const bool force_v1 = getenv("SDEH_BWD_V1") != nullptr;
-  const bool v2 = tile == 32 && !force_v1 && bwdf2_fits(d, net.n_hidden) && (d <= 32 || getenv("SDEH_BWD_V2") != nullptr);
+  static const bool force_v2 = getenv("SDEH_BWD_V2") != nullptr;
+  // (two coordinate tiles through time: the trajectory-split kernel still spills there and loses to the channel-split one -- 22 vs
+  // 15 ms at d = 50, B = 65 536; its funnel Jacobian would couple the two tiles)
+  const bool v2 = tile == 32 && !force_v1 && bwdf2_fits(d, net.n_hidden) &&
+                  (d <= 32 || (!bptt) || (force_v2 && pr->target.kind != SDEH_DENS_FUNNEL));
   A.n_slots = tile == 16 ? bwdf16_slots(batch) : (v2 ? bwdf2_slots(batch, n_steps, bptt) : bwdf_slots(batch, n_steps, bptt));
   A.wsize = bwdf_wsize(d, net.n_hidden);
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);

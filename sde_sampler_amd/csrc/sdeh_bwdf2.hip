@@ -42,32 +42,37 @@ using namespace bwdf;
 
 // operands of one chunk (8 trajectories: 4 k-steps) of a weight-gradient product; chunk 4 w + c lives in the planes of the team's wave w
 struct DwChunk {
-  float4 dv, a0, a1;
+  float4 dv, a0;
 };
 
-// lane (i, h): delta row 32 R + i, a rows 32 c0 + i (and 32 (c0 + 1) + i), trajectories 8 c + 4 h .. + 3 of wave w's tile
-template <bool TWO>
-__device__ __forceinline__ void dw_load(const float* __restrict__ team_planes, int R, int c0, int i, int h, int k, DwChunk& o) {
-  const float* __restrict__ Dp = team_planes + (k >> 2) * 2 * PLANE;
-  const float* __restrict__ Ap = Dp + PLANE;
+// lane (i, h): delta row 32 R + i, a row 32 c0 + i, trajectories 8 c + 4 h .. + 3 of one wave's tile (wplanes: that wave's D plane, A behind it)
+__device__ __forceinline__ void dw_load(const float* __restrict__ planes, int R, int c0, int i, int h, int k, DwChunk& o) {
+  const float* __restrict__ Dp = planes + (k >> 2) * 2 * PLANE;
   o.dv = plane_getT(Dp, R, i, h, k & 3);
-  o.a0 = plane_getT(Ap, c0, i, h, k & 3);
-  if constexpr (TWO) o.a1 = plane_getT(Ap, c0 + 1, i, h, k & 3);
+  o.a0 = plane_getT(Dp + PLANE, c0, i, h, k & 3);
+}
+
+// the first NQ registers of an accumulator-layout tile -> plane [row][trajectory]
+template <int NQ>
+__device__ __forceinline__ void plane_put_n(float* __restrict__ plane, int tile, int j, int h, const f32x16& v) {
+  float* __restrict__ p = plane + (32 * tile + 4 * h) * RS + j;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) p[rrow(q) * RS] = v[q];
+}
+// the value of lane j (lower half) in both halves
+__device__ __forceinline__ float bcast_lo(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]);
 }
 
 __device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
 
-// one chunk of a product (4 or 8 matrix instructions)
-template <bool TWO>
-__device__ __forceinline__ void dw_chunk(const DwChunk& o, f32x16& acc0, f32x16& acc1) {
-  acc0 = SDEH_MFMA(o.dv.x, o.a0.x, acc0);
-  if constexpr (TWO) acc1 = SDEH_MFMA(o.dv.x, o.a1.x, acc1);
-  acc0 = SDEH_MFMA(o.dv.y, o.a0.y, acc0);
-  if constexpr (TWO) acc1 = SDEH_MFMA(o.dv.y, o.a1.y, acc1);
-  acc0 = SDEH_MFMA(o.dv.z, o.a0.z, acc0);
-  if constexpr (TWO) acc1 = SDEH_MFMA(o.dv.z, o.a1.z, acc1);
-  acc0 = SDEH_MFMA(o.dv.w, o.a0.w, acc0);
-  if constexpr (TWO) acc1 = SDEH_MFMA(o.dv.w, o.a1.w, acc1);
+// one chunk of a product (4 matrix instructions)
+__device__ __forceinline__ void dw_chunk(const DwChunk& o, f32x16& acc) {
+  acc = SDEH_MFMA(o.dv.x, o.a0.x, acc);
+  acc = SDEH_MFMA(o.dv.y, o.a0.y, acc);
+  acc = SDEH_MFMA(o.dv.z, o.a0.z, acc);
+  acc = SDEH_MFMA(o.dv.w, o.a0.w, acc);
 }
 
 // Forward layer from registers:  o[R] += sum_{s < ng} sum_e W[32 R + i][8 s + 4 h + e] * b[s >> 2][4 (s & 3) + e]   (R < NR)
@@ -102,21 +107,22 @@ __device__ __forceinline__ void fwd_rows(const float* __restrict__ wrow, int ld,
 
 // One backward stage, entered behind the barrier that made the team's (delta_k, a_k) planes visible: the transposed layer from registers
 //     o[R] = sum_{s < ng} sum_e W[(8 s + 4 h + e) * LD + 32 R + i] * b[s >> 2][4 (s & 3) + e]        (R < NR; wcol = &W[4 h * LD + i])
-// issued interleaved with the eight chunks of the weight-gradient product  acc0 (, acc1) += delta[row tile R] a[tile c0 (, c0 + 1)]^T
-// over the team's 64 trajectories (operands one chunk ahead through a ring: 24 registers instead of a whole product's 96).
-// dsum[w] += this lane's delta values of wave w's trajectories (bias gradients, d loss / d emb[t]).  Ends with the barrier behind
-// which the planes may be overwritten.
-template <int NGC, int LD, int NR, int NB, bool TWO>
+// issued interleaved with the chunks of ONE tile of the weight-gradient product  acc += delta[row tile Rd] a[tile c0]^T  over the
+// trajectories of NCH / 4 waves (planes: the first of them; operands one chunk ahead through a ring).  dsum[w] += this lane's delta
+// values of wave w's trajectories (bias gradients, d loss / d emb[t]).  Ends with the barrier behind which the planes may be overwritten.
+template <int NGC, int LD, int NR, int NB, int NCH>
 __device__ __forceinline__ void stage_cols(const float* __restrict__ wcol, const f32x16 (&b)[NB], int ng, f32x16 (&o)[NR],
-                                           const float* __restrict__ team_planes, int Rd, int c0, int i, int h,
-                                           f32x16& acc0, f32x16& acc1, float (&dsum)[2]) {
+                                           const float* __restrict__ planes, int Rd, int c0, int i, int h,
+                                           f32x16& acc, float (&dsum)[NCH / 4]) {
+  constexpr int CPI = NCH / 8;  // chunks per iteration
 #pragma unroll
   for (int R = 0; R < NR; ++R)
 #pragma unroll
     for (int q = 0; q < 16; ++q) o[R][q] = 0.0f;
   float wc[2][4][NR];
-  DwChunk ck[2];
-  dw_load<TWO>(team_planes, Rd, c0, i, h, 0, ck[0]);
+  DwChunk ck[2][CPI];
+#pragma unroll
+  for (int c = 0; c < CPI; ++c) dw_load(planes, Rd, c0, i, h, c, ck[0][c]);
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -124,7 +130,10 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ wcol, const
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const bool chain = s < NGC && s < ng;
-    if (s + 1 < 8) dw_load<TWO>(team_planes, Rd, c0, i, h, s + 1, ck[(s + 1) & 1]);
+    if (s + 1 < 8) {
+#pragma unroll
+      for (int c = 0; c < CPI; ++c) dw_load(planes, Rd, c0, i, h, CPI * (s + 1) + c, ck[(s + 1) & 1][c]);
+    }
     if (s + 1 < NGC && s + 1 < ng) {
       const float* __restrict__ p = wcol + 8 * (s + 1) * LD;
 #pragma unroll
@@ -140,8 +149,11 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ wcol, const
 #pragma unroll
         for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(wc[s & 1][e][R], bt[q0 + e], o[R]);
     }
-    dsum[s >> 2] += sum4(ck[s & 1].dv);
-    dw_chunk<TWO>(ck[s & 1], acc0, acc1);
+#pragma unroll
+    for (int c = 0; c < CPI; ++c) {
+      dsum[(CPI * s + c) >> 2] += sum4(ck[s & 1][c].dv);
+      dw_chunk(ck[s & 1][c], acc);
+    }
     SDEH_FENCE();
   }
   ws_barrier();
@@ -149,11 +161,20 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ wcol, const
 
 }  // namespace bwdf2
 
-template <int OTD, bool BPTT, int LH, bool RECOMP>
+// NQ: accumulator registers of a coordinate tile that can hold live coordinates (d <= 8: 4, d <= 16: 8, else 16; two coordinate tiles: 16):
+// loads, the elementwise phase and the publishes of x / delta_out loop over those only.  VIO (d <= 4): the input layer, the out layer
+// and their transposes run on the vector pipe (2 x 64 weights per coordinate: 32 FMAs per lane and coordinate instead of 8 + 32 + 8 +
+// 32 matrix instructions on tiles that are 7/8 padding); their weight gradients stay on the matrix pipe (off the chain).
+template <int OTD, bool BPTT, int LH, bool RECOMP, int NQ, bool VIO>
 __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   using namespace bwdf2;
+  static_assert(OTD == 1 || NQ == 16, "two coordinate tiles: all registers live");
+  static_assert(!VIO || (OTD == 1 && NQ == 4), "vector-pipe in / out layers: d <= 4");
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
-  constexpr int NDW = OTD + 2 * LH + (OTD == 2 ? 2 : 1);  // weight-gradient tiles of a wave: input_embed, hidden, out_layer
+  constexpr int NGI = OTD == 2 ? 8 : NQ / 4;              // k-groups of the coordinates
+  // two coordinate tiles: x_t is read again where it is needed behind the input layer (the Jacobians of the closed-form scores, the
+  // operand of input_embed.weight's gradient) instead of occupying 32 registers for the whole step
+  constexpr bool XRELOAD = OTD == 2 && BPTT;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* __restrict__ Win = lds;
   float* __restrict__ Whid = Win + 64 * RSI;
@@ -161,15 +182,20 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   float* __restrict__ bh = Wout + DPP * RSW;
   float* __restrict__ bo = bh + LH * 64;
   float* __restrict__ tabs = bo + 64;
+  float* __restrict__ planes = tabs + TABS;
+  float* __restrict__ vio_in = planes + 2 * 4 * PLANE;  // [4][64]: column i of input_embed.weight in accumulator order (VIO)
+  float* __restrict__ vio_out = vio_in + 256;           // [4][64]: row i of out_layer.weight in accumulator order
   const WsLayout& L = A.lay;
   const float* __restrict__ ws = A.ws;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int team = wave >> 1, r = wave & 1;
   const int j = lane & 31, h = lane >> 5;
-  float* __restrict__ team_planes = tabs + TABS + team * 4 * PLANE;  // wave (team, w): D at w * 2 PLANE, A behind it
-  float* __restrict__ Dme = team_planes + r * 2 * PLANE;
+  float* __restrict__ Dme = planes + wave * 2 * PLANE;  // wave w: D plane at w * 2 PLANE, A plane behind it
   float* __restrict__ Ame = Dme + PLANE;
+  // this wave's tile of every weight gradient: hidden layers and (two coordinate tiles) input_embed / out_layer: tile (wR, wC) of the
+  // 2 x 2 over all four waves' trajectories; one coordinate tile: input_embed row tile wC / out_layer channel tile wC over the
+  // trajectories of the wave pair wR (the two pairs' sums meet in LDS at the end)
+  const int wR = wave >> 1, wC = wave & 1;
   const int d = A.d, T = A.n_steps;
   const long long B = A.batch;
 
@@ -193,32 +219,41 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     const int which = k == 0 ? 1 : (k == 1 ? 2 : 0);
     tabs[idx] = cj < d && cj < L.dp ? ws[L.dg[which] + 2 * cj + c] : 0.0f;
   }
-  for (int idx = tid; idx < 2 * 4 * PLANE; idx += 256) tabs[TABS + idx] = 0.0f;  // never-written rows / trajectories must not hold NaNs
+  for (int idx = tid; idx < 2 * 4 * PLANE; idx += 256) planes[idx] = 0.0f;  // never-written rows / trajectories must not hold NaNs
+  if constexpr (VIO) {
+    const int i = tid >> 6, m = tid & 63, ch = 32 * (m >> 5) + rrow(m & 15) + 4 * ((m >> 4) & 1);  // m = (R * 2 + h) * 16 + q
+    vio_in[tid] = i < d ? A.w_in[ch * d + i] : 0.0f;
+    vio_out[tid] = i < d ? A.w_out[i * 64 + ch] : 0.0f;
+  }
   __syncthreads();
 
+#ifdef SDEH_BWDF2_ACT
+  const int act = SDEH_BWDF2_ACT, ctrl_kind = A.ctrl_kind, flags = A.flags;
+#else
   const int act = A.act, ctrl_kind = A.ctrl_kind, flags = A.flags;
+#endif
   const bool has_score = ctrl_kind != SDEH_CTRL_CLIPPED;
   const bool refc = (flags & SDEH_FLAG_REFERENCE_CTRL) && A.loss_kind == SDEH_LOSS_REFERENCE_SDE;
   const bool expo = A.loss_kind == SDEH_LOSS_EXPONENTIAL;
   const bool ito = (flags & SDEH_FLAG_ITO) != 0;
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
 
-  // weight-gradient accumulators (as in sdeh_bwdf.hip): [0, OTD) input_embed: row tile r x coordinate tiles; hidden layer l: row
-  // tile r x 2; out_layer: OTD == 2: coordinate tile r x 2 channel tiles; OTD == 1: coordinate tile 0 x channel tile r
-  f32x16 dw[NDW];
+  f32x16 dw_in, dw_out, dw_hid[LH];
 #pragma unroll
-  for (int k = 0; k < NDW; ++k)
+  for (int q = 0; q < 16; ++q) { dw_in[q] = 0.0f; dw_out[q] = 0.0f; }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) dw[k][q] = 0.0f;
+  for (int l = 0; l < LH; ++l)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dw_hid[l][q] = 0.0f;
   float bs_hid[LH], bs_out = 0.0f;
 #pragma unroll
   for (int l = 0; l < LH; ++l) bs_hid[l] = 0.0f;
 
-  // Items: pairs of 32-trajectory tiles (through time) or (step, pair), step-major (row-parallel); team team_g takes item team_g,
-  // team_g + n_teams, ...; wave r of the team owns tile 2 pair + r (an odd tile count leaves the last pair's second wave shadowing
-  // the last tile with zero weights).
-  const int n_tiles = A.n_tiles, n_pairs = (n_tiles + 1) >> 1;
-  const int n_teams = (int)gridDim.x * 2, team_g = (int)blockIdx.x * 2 + team;
+  // Items: quads of 32-trajectory tiles (through time) or (step, quad), step-major (row-parallel); the workgroup is one team and takes
+  // item blockIdx, blockIdx + gridDim, ...; wave w owns tile 4 quad + w (a tile count that is no multiple of four leaves the last
+  // quad's spare waves shadowing the last tile with zero weights).
+  const int n_tiles = A.n_tiles, n_pairs = (n_tiles + 3) >> 2;
+  const int n_teams = (int)gridDim.x, team_g = (int)blockIdx.x;
   const long long n_items = BPTT ? (long long)n_pairs : (long long)n_pairs * T;
   const long long n_rounds = (n_items + n_teams - 1) / n_teams;
   const int d_t = BPTT ? 0 : n_teams / n_pairs, d_pair = BPTT ? n_teams : n_teams % n_pairs;
@@ -234,24 +269,36 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   auto clamp_item = [&](int& t_io, int& pair_io) {  // a team without an item shadows the last one (and contributes zeros)
     if (!item_live(t_io, pair_io)) { t_io = T - 1; pair_io = n_pairs - 1; }
   };
-  auto tile_of = [&](int pair_i) { const int tl = 2 * pair_i + r; return tl < n_tiles ? tl : n_tiles - 1; };
+  auto tile_of = [&](int pair_i) { const int tl = 4 * pair_i + wave; return tl < n_tiles ? tl : n_tiles - 1; };
 
-  // 16 coordinates (32 ct + 4 h + rrow(q)) of column `col` of a coordinate-major plane [d][B] with a WAVE-UNIFORM start: one scalar
+  // NQ coordinates (32 ct + 4 h + rrow(q)) of column `col` of a coordinate-major plane [d][B] with a WAVE-UNIFORM start: one scalar
   // base + a 32-bit byte offset per element, the lane's part opaque per call (sdeh_bwdf.hip: 64-bit element addresses become loop
-  // invariants that spill); coordinates >= d read a valid element and are zeroed by a select.
+  // invariants that spill); coordinates >= d read a valid element and are zeroed by a select.  Registers >= NQ: zero.
+  // The element offsets are formed on the vector pipe from an opaque copy of the row stride: as scalar expressions each of the 16
+  // rows of every plane gets its own 64-bit scalar base, a few hundred scalar registers in all -- they spill to vector-register lanes,
+  // and every use costs a v_readlane plus the wait states behind it (966 + 553 instructions in the step loop of the d = 50 kernel).
   const unsigned Bu = (unsigned)B;
-  auto load_cm16 = [&](const float* __restrict__ plane_u, unsigned col, int ct) {
+  auto load_cm = [&](const float* __restrict__ plane_u, unsigned col, int ct) {
     f32x16 v;
     const int cb = 32 * ct + 4 * h;
     unsigned lane_off = ((unsigned)(cb < d ? cb : 0) * Bu + col) * 4u;
-    asm volatile("" : "+v"(lane_off));
+    unsigned s1 = Bu * 4u;
+    asm volatile("" : "+v"(lane_off), "+v"(s1));
+    const unsigned s2 = s1 + s1, s3 = s2 + s1, s8 = s1 << 3;
     const char* __restrict__ pb = reinterpret_cast<const char*>(plane_u);
+    unsigned bg = lane_off;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const bool ok = cb + rrow(q) < d;
-      const unsigned off = ok ? lane_off + (unsigned)rrow(q) * Bu * 4u : lane_off;
-      const float val = *reinterpret_cast<const float*>(pb + off);
-      v[q] = ok ? val : 0.0f;
+      if (q < NQ) {
+        const bool ok = cb + rrow(q) < d;
+        const unsigned oq = (q & 3) == 0 ? bg : ((q & 3) == 1 ? bg + s1 : ((q & 3) == 2 ? bg + s2 : bg + s3));
+        const unsigned off = ok ? oq : lane_off;
+        const float val = *reinterpret_cast<const float*>(pb + off);
+        v[q] = ok ? val : 0.0f;
+        if ((q & 3) == 3) bg += s8;
+      } else {
+        v[q] = 0.0f;
+      }
     }
     return v;
   };
@@ -259,25 +306,41 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     const long long rw = (long long)tile_i * 32 + j;
     const unsigned col = (unsigned)(rw < B ? rw : B - 1);
 #pragma unroll
-    for (int ct = 0; ct < OTD; ++ct) xo[ct] = load_cm16(A.xs + (long long)t * d * B, col, ct);
+    for (int ct = 0; ct < OTD; ++ct) xo[ct] = load_cm(A.xs + (long long)t * d * B, col, ct);
   };
   auto load_emb = [&](int t, f32x16 (&eo)[2]) {  // timestep_embed(t) + input bias, accumulator order: the FIRST addend of the input layer
 #pragma unroll
     for (int R = 0; R < 2; ++R) eo[R] = load16(ws + L.emb + t * C + (R * 2 + h) * 16);
   };
+  // the per-step scalars travel with x: fetched in front of the previous step's last block of matrix instructions (scalar loads share
+  // the LDS counter: requested at the top of a step they hold up the first weight read)
+  struct StepCoef { float sig, wl, c_i, cdt, c_u, c_x, gam0; };
+  auto load_coef = [&](int t) {
+    StepCoef c;
+    cfp cf = as_const(ws + L.coef + t * kCoefStride);
+    c.sig = cf[CF_SIGMA]; c.wl = cf[CF_W];
+    c.c_i = expo ? cf[CF_SBK] : cf[CF_SQDT];
+    c.cdt = expo ? cf[CF_B2S2] : cf[CF_DT];
+    c.c_u = expo ? cf[CF_B2S2] : c.sig * cf[CF_DT];
+    c.c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], cf[CF_DT], 1.0f);
+    c.gam0 = has_score ? as_const(ws + L.gam + t * L.g)[0] : 0.0f;  // gamma(t) (its first entry)
+    return c;
+  };
 
   f32x16 xnext[OTD], embnext[2];
+  StepCoef cnext;
   {
     int t0 = it_t, p0 = it_pair;
     clamp_item(t0, p0);
     load_x(t0, tile_of(p0), xnext);
     load_emb(t0, embnext);
+    cnext = load_coef(t0);
   }
   for (long long round = 0; round < n_rounds; ++round) {
     const bool live_item = item_live(it_t, it_pair);
     int cur_t = it_t, cur_pair = it_pair;
     clamp_item(cur_t, cur_pair);
-    const bool live_tile = live_item && 2 * cur_pair + r < n_tiles;
+    const bool live_tile = live_item && 4 * cur_pair + wave < n_tiles;
     const long long tile = tile_of(cur_pair);
     const long long row = tile * 32 + j;
     const bool live = live_tile && row < B;
@@ -295,15 +358,15 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       for (int ct = 0; ct < OTD; ++ct) {
         const int cb = 32 * ct + 4 * h;
         if (flags & SDEH_FLAG_TERMINAL_SECOND) {
-          const f32x16 xT = load_cm16(A.xs + (long long)T * d * B, (unsigned)lrow, ct);
+          const f32x16 xT = load_cm(A.xs + (long long)T * d * B, (unsigned)lrow, ct);
           const f32x16 smu = rows16(tabs + 2 * 64 + cb), sis = rows16(tabs + 3 * 64 + cb);
 #pragma unroll
-          for (int q = 0; q < 16; ++q) lam[ct][q] = wi * (smu[q] - xT[q]) * sis[q];
+          for (int q = 0; q < NQ; ++q) lam[ct][q] = wi * (smu[q] - xT[q]) * sis[q];
         }
         if ((flags & SDEH_FLAG_TERMINAL_TARGET) && A.tscore != nullptr) {
-          const f32x16 st = load_cm16(A.tscore, (unsigned)lrow, ct);
+          const f32x16 st = load_cm(A.tscore, (unsigned)lrow, ct);
 #pragma unroll
-          for (int q = 0; q < 16; ++q) lam[ct][q] = fmaf(-wi, st[q], lam[ct][q]);
+          for (int q = 0; q < NQ; ++q) lam[ct][q] = fmaf(-wi, st[q], lam[ct][q]);
         }
       }
     }
@@ -313,23 +376,24 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
 
     for (int t = t_first; t >= t_last; --t) {
       BW2_T(tp0);
+      // The read-only LDS tables through bases the compiler cannot see through: their loads are invariants of the step loop (no store
+      // aliases the restrict-qualified tables), and hoisted out of it they occupy -- and spill -- hundreds of registers.
+      int opq = 0;
+      asm volatile("" : "+v"(opq));
+      const float* __restrict__ Win_s = Win + opq;
+      const float* __restrict__ Whid_s = Whid + opq;
+      const float* __restrict__ Wout_s = Wout + opq;
+      const float* __restrict__ bh_s = bh + opq;
+      const float* __restrict__ bo_s = bo + opq;
+      const float* __restrict__ tabs_s = tabs + opq;
+      const float* __restrict__ vin_s = vio_in + opq;
+      const float* __restrict__ vout_s = vio_out + opq;
       f32x16 x[OTD], embv[2];
 #pragma unroll
       for (int ct = 0; ct < OTD; ++ct) x[ct] = xnext[ct];
       embv[0] = embnext[0]; embv[1] = embnext[1];
-      // the step's other inputs: requested first, consumed after the forward pass
-      f32x16 scv[OTD];
-      if (has_score) {
-#pragma unroll
-        for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm16(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
-      }
-      const float gam0 = has_score ? ws[L.gam + t * L.g] : 0.0f;  // gamma(t) (its first entry)
-      cfp cf = as_const(ws + L.coef + t * kCoefStride);
-      const float sig = cf[CF_SIGMA], wl = cf[CF_W];
-      const float c_i = expo ? cf[CF_SBK] : cf[CF_SQDT];
-      const float cdt = expo ? cf[CF_B2S2] : cf[CF_DT];
-      const float c_u = expo ? cf[CF_B2S2] : sig * cf[CF_DT];
-      const float c_x = expo ? cf[CF_ALPHAK] : fmaf(cf[CF_DRIFT], cf[CF_DT], 1.0f);
+      const StepCoef cs = cnext;
+      const float sig = cs.sig, wl = cs.wl, c_i = cs.c_i, cdt = cs.cdt, c_u = cs.c_u, c_x = cs.c_x, gam0 = cs.gam0;
 
       // ======================================================================================= forward (re-evaluation at x_t)
       // keep[k]: RECOMP ? Z_k : act'(Z_k)  (k = 0 .. LH);   akeep[k] = a_{k+1} = act(Z_k)  (k < LH; not with RECOMP)
@@ -338,43 +402,94 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       f32x16 cur[2];
       {
         f32x16 z[2] = {embv[0], embv[1]};
-        fwd_rows<4 * OTD, OTD, 2>(Win + j * RSI + 4 * h, RSI, x, A.n_kg, z);
+        if constexpr (VIO) {
+          // emb + sum_i W_in[:, i] x_i in coordinate order: the fmaf chain the matrix instructions of the forward launch evaluate
+          // (their other k values meet zero weights)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < d) {
+              const float xb = bcast_lo(x[0][i]);
+              const f32x16 w0 = load16(vin_s + i * 64 + h * 16), w1 = load16(vin_s + i * 64 + 32 + h * 16);
+#pragma unroll
+              for (int q = 0; q < 16; ++q) { z[0][q] = fmaf(w0[q], xb, z[0][q]); z[1][q] = fmaf(w1[q], xb, z[1][q]); }
+            }
+          }
+        } else {
+          fwd_rows<NGI, OTD, 2>(Win_s + j * RSI + 4 * h, RSI, x, NGI, z);  // all k-groups of the tile class: no branch around matrix instructions
+        }
+        SDEH_FENCE();
         BW2_T(tpa);
         BW2_ADD(9, tp0, tpa);
         if constexpr (RECOMP) {
           keep[0][0] = z[0]; keep[0][1] = z[1];
-          SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(z[0]); act_tile<ACT>(z[1]););
+          SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(z[0]); SDEH_FENCE(); act_tile<ACT>(z[1]););
+          SDEH_FENCE();
           cur[0] = z[0]; cur[1] = z[1];
         } else {
-          SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[0][0]); act_both<ACT>(z[1], cur[1], keep[0][1]););
+          SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[0][0]); SDEH_FENCE(); act_both<ACT>(z[1], cur[1], keep[0][1]););
+          SDEH_FENCE();
           akeep[0][0] = cur[0]; akeep[0][1] = cur[1];
         }
+        SDEH_FENCE();
         BW2_T(tpb);
         BW2_ADD(10, tpa, tpb);
       }
       BW2_T(tpc);
 #pragma unroll
       for (int l = 0; l < LH; ++l) {  // hidden layer l: Z_{l+1} = W_l a_{l+1} + b_l;  a_{l+2} = act(Z_{l+1})
-        f32x16 z[2] = {rows16(bh + l * 64 + 4 * h), rows16(bh + l * 64 + 32 + 4 * h)};
-        fwd_rows<8, 2, 2>(Whid + l * 64 * RSW + j * RSW + 4 * h, RSW, cur, 8, z);
+        f32x16 z[2] = {rows16(bh_s + l * 64 + 4 * h), rows16(bh_s + l * 64 + 32 + 4 * h)};
+        fwd_rows<8, 2, 2>(Whid_s + l * 64 * RSW + j * RSW + 4 * h, RSW, cur, 8, z);
+        SDEH_FENCE();
         if constexpr (RECOMP) {
           keep[l + 1][0] = z[0]; keep[l + 1][1] = z[1];
-          SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(z[0]); act_tile<ACT>(z[1]););
+          SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(z[0]); SDEH_FENCE(); act_tile<ACT>(z[1]););
+          SDEH_FENCE();
           cur[0] = z[0]; cur[1] = z[1];
         } else {
-          SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[l + 1][0]); act_both<ACT>(z[1], cur[1], keep[l + 1][1]););
+          SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[l + 1][0]); SDEH_FENCE(); act_both<ACT>(z[1], cur[1], keep[l + 1][1]););
+          SDEH_FENCE();
           if (l + 1 < LH) { akeep[l + 1 < LH ? l + 1 : 0][0] = cur[0]; akeep[l + 1 < LH ? l + 1 : 0][1] = cur[1]; }
         }
       }
       BW2_T(tpd);
       BW2_ADD(11, tpc, tpd);
+      SDEH_FENCE();
+      // the score entering the control: requested in front of the out layer, consumed behind it
+      f32x16 scv[OTD];
+#pragma unroll
+      for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) scv[ct][q] = 0.0f;
+      if (has_score) {
+#pragma unroll
+        for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
+      }
+      SDEH_FENCE();
       // a_{LH+1} goes to the A plane at once (free since the previous product's second barrier); the out layer reads the registers
       plane_put(Ame, 0, j, h, cur[0]);
       plane_put(Ame, 1, j, h, cur[1]);
+      SDEH_FENCE();
       f32x16 nn[OTD];
+      if constexpr (VIO) {
 #pragma unroll
-      for (int ct = 0; ct < OTD; ++ct) nn[ct] = rows16(bo + 32 * ct + 4 * h);
-      fwd_rows<8, 2, OTD>(Wout + j * RSW + 4 * h, RSW, cur, 8, nn);
+        for (int q = 0; q < 16; ++q) nn[0][q] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < d) {
+            const f32x16 w0 = load16(vout_s + i * 64 + h * 16), w1 = load16(vout_s + i * 64 + 32 + h * 16);
+            float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { p0 = fmaf(w0[q], cur[0][q], p0); p1 = fmaf(w1[q], cur[1][q], p1); }
+            const float tot = sum_xor32(p0 + p1) + bo_s[i];
+            nn[0][i] = h == 0 ? tot : 0.0f;  // coordinates 4 .. 7 (the h = 1 half) stay exactly zero
+          }
+        }
+      } else {
+#pragma unroll
+        for (int ct = 0; ct < OTD; ++ct) nn[ct] = rows16(bo_s + 32 * ct + 4 * h);
+        fwd_rows<8, 2, OTD>(Wout_s + j * RSW + 4 * h, RSW, cur, 8, nn);
+      }
+      SDEH_FENCE();
       BW2_T(tp1);
       BW2_ADD(12, tpd, tp1);
 
@@ -389,20 +504,36 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         // score terms the reference detaches (reparam.py:58,134,169,188) or obtains by autograd without a graph carry no Jacobian
         const float jac_t = (!has_score || (flags & (SDEH_FLAG_DETACH_SCORE | SDEH_FLAG_TARGET_SCORE_CONST))) ? 0.0f : coef_t;
         const float jac_p = (!has_score || (flags & SDEH_FLAG_DETACH_SCORE)) ? 0.0f : coef_p;
-        f32x16 cvec[OTD], Gc[OTD];
+        // one coordinate tile at a time, the adjoint's update included: nothing but dout and lambda of a tile outlives its turn (the
+        // funnel's Jacobian couples all coordinates: one tile only -- launch_bwdf2 leaves funnels with d > 32 to sdeh_bwdf.hip)
 #pragma unroll
         for (int ct = 0; ct < OTD; ++ct) {
+          SDEH_FENCE();
           const int cb = 32 * ct + 4 * h;
+          f32x16 cvec, Gc;
+          f32x16 xe;  // x_t of this tile, where the adjoint needs it
+          if constexpr (XRELOAD) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xe[q] = 0.0f;
+            if (BPTT && (refc || (jac_t != 0.0f && A.target.kind == SDEH_DENS_MULTI_WELL)))
+              xe = load_cm(A.xs + (long long)t * d * B, (unsigned)lrow, ct);
+          } else {
+            xe = x[ct];
+          }
+#pragma unroll
+          for (int q = 0; q < 16; ++q) dout[ct][q] = 0.0f;
           f32x16 xi;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) xi[q] = 0.0f;
           if (ito) {
             float n[16];
             if (A.noise != nullptr) {
               const float* __restrict__ rowp = A.noise + ((long long)t * B + lrow) * d;
 #pragma unroll
-              for (int q = 0; q < 16; ++q) n[q] = cb + rrow(q) < d ? rowp[cb + rrow(q)] : 0.0f;
+              for (int q = 0; q < NQ; ++q) n[q] = cb + rrow(q) < d ? rowp[cb + rrow(q)] : 0.0f;
             } else {
 #pragma unroll
-              for (int g4 = 0; g4 < 4; ++g4) {
+              for (int g4 = 0; g4 < NQ / 4; ++g4) {
                 float n4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (cb + 8 * g4 < d) box_muller4(philox_block(A.seed, rng_off, grow, t, (cb + 8 * g4) >> 2), n4);
 #pragma unroll
@@ -411,44 +542,112 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
               }
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) xi[q] = cb + rrow(q) < d ? n[q] : 0.0f;
+            for (int q = 0; q < NQ; ++q) xi[q] = cb + rrow(q) < d ? n[q] : 0.0f;
           }
+          SDEH_FENCE();
           f32x16 rr;  // reference control sigma * prior.score(x) (solver/oc.py:305-306)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) rr[q] = 0.0f;
+          for (int q = 0; q < NQ; ++q) rr[q] = 0.0f;
           if (BPTT && refc) {
-            const f32x16 pmu = rows16(tabs + 0 * 64 + cb), pis = rows16(tabs + 1 * 64 + cb);
+            const f32x16 pmu = rows16(tabs_s + 0 * 64 + cb), pis = rows16(tabs_s + 1 * 64 + cb);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rr[q] = sig * (pmu[q] - x[ct][q]) * pis[q];
+            for (int q = 0; q < NQ; ++q) rr[q] = sig * (pmu[q] - xe[q]) * pis[q];
           }
+          SDEH_FENCE();
+          // the wave-uniform switches (has_score, ito, per-coordinate gamma) are folded into operands OUTSIDE the element loop: a uniform
+          // condition evaluated per element becomes a scalar branch per element, and the accumulators that live across it get copied
+          f32x16 mfv;  // mult * gamma(t)[coordinate]; zero without a score term (scv is zero then as well)
+          if (!has_score) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mfv[q] = 0.0f;
+          } else if (A.g == 1) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mfv[q] = mult * gam0;
+          } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) mfv[q] = mult * ws[L.gam + t * L.g + min(cb + rrow(q), L.g - 1)];
+          }
+          SDEH_FENCE();
+          const float c_ie = ito ? c_i : 0.0f;  // (xi is zero without the Ito term)
           f32x16 gcoord;
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            float mfac = 0.0f, csc = 0.0f, keep_s = 0.0f;
-            if (has_score) {
-              const float gam = A.g == 1 ? gam0 : ws[L.gam + t * L.g + min(cb + rrow(q), L.g - 1)];
-              mfac = mult * gam;
-              csc = clipf(scv[ct][q], A.clip_score);
-              keep_s = fabsf(scv[ct][q]) <= A.clip_score ? 1.0f : 0.0f;
-            }
-            float gc = ito ? wi * c_i * xi[q] : 0.0f;
+          for (int q = 0; q < NQ; ++q) {
+            const float mfac = mfv[q];
+            const float csc = clipf(scv[ct][q], A.clip_score);
+            const float keep_s = fabsf(scv[ct][q]) <= A.clip_score ? 1.0f : 0.0f;
+            float gc = wi * c_ie * xi[q];
             if constexpr (BPTT) {
               const float u = clipf(nn[ct][q], A.clip_model) + mfac * csc;
-              gc = wi * fmaf(u - rr[q], cdt, ito ? c_i * xi[q] : 0.0f);
+              gc = wi * fmaf(u - rr[q], cdt, c_ie * xi[q]);
             }
             const float gq = BPTT ? fmaf(c_u, lam[ct][q], gc) : gc;
-            Gc[ct][q] = gc;
+            Gc[q] = gc;
             const float gg = gq * mult * csc;
             gcoord[q] = gg;
             gsum += gg;
-            cvec[ct][q] = keep_s * mfac * gq;
+            cvec[q] = keep_s * mfac * gq;
             dout[ct][q] = fabsf(nn[ct][q]) <= A.clip_model ? gq : 0.0f;
+            if ((q & 3) == 3) SDEH_FENCE();
           }
+          SDEH_FENCE();
           if (has_score && live_tile && A.g != 1) {  // d loss / d gamma(t) per coordinate: over the 32 trajectories of this lane half
+            float mine = 0.0f;  // lane j < NQ keeps register j's sum: one store per lane half instead of a branch per register
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < NQ; ++q) {
               const float v = sum_xor16(sum_row16(gcoord[q]));
-              if (j == 0) A.gpart[(tile * T + t) * A.gw + cb + rrow(q)] = v;
+              mine = j == q ? v : mine;
+            }
+            if (j < NQ) A.gpart[(tile * T + t) * A.gw + cb + (j & 3) + 8 * (j >> 2)] = mine;
+          }
+          SDEH_FENCE();
+          if constexpr (BPTT) {
+            // ===================================================================================== adjoint update, first part
+            //   lambda_t = c_x lambda_{t+1} + (d score term / d x)^T G + direct cost terms  [+ W_in^T delta_0 at the end of the step]
+            f32x16 vt;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) vt[q] = 0.0f;
+            if (jac_t != 0.0f) {  // closed-form target scores are differentiated through x
+              if (A.target.kind == SDEH_DENS_DIAG_GAUSS) {
+                const f32x16 tis = rows16(tabs_s + 5 * 64 + cb);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) vt[q] = -tis[q] * cvec[q];
+              } else if (A.target.kind == SDEH_DENS_MULTI_WELL) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                  const float y = xe[q] - A.target.p1;
+                  vt[q] = (cb + rrow(q) < A.target.n_comp ? -4.0f * (3.0f * y * y - A.target.p0) : -1.0f) * cvec[q];
+                }
+              } else if (OTD == 1 && A.target.kind == SDEH_DENS_FUNNEL) {
+                // s_0 = -x0/var - (d-1)/2 + e^{-x0} sum x_j^2 / 2,  s_j = -x_j e^{-x0}   (coordinate 0 = register 0 of the h = 0 half);
+                // the sums run over all coordinates: registers and the two lane halves of this wave
+                const float x0 = bcast_lo(x[0][0]), c0 = bcast_lo(cvec[0]);
+                float sq = 0.0f, cx = 0.0f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                  const bool first = q == 0 && h == 0;
+                  sq = fmaf(first ? 0.0f : x[0][q], x[0][q], sq);
+                  cx = fmaf(first ? 0.0f : cvec[q], x[0][q], cx);
+                }
+                sq = sum_xor32(sq);
+                cx = sum_xor32(cx);
+                const float iv = __expf(-x0);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) vt[q] = iv * (c0 * x[0][q] - cvec[q]);
+                if (h == 0) vt[0] = c0 * (-1.0f / A.target.p0 - 0.5f * iv * sq) + iv * cx;
+              }
+            }
+            SDEH_FENCE();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) lam[ct][q] = fmaf(jac_t, vt[q], c_x * lam[ct][q]);
+            SDEH_FENCE();
+            if (jac_p != 0.0f || refc) {
+              const f32x16 pis = rows16(tabs_s + 1 * 64 + cb);
+              const float sig_r = refc ? sig : 0.0f;
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) {
+                const float v = fmaf(-jac_p * pis[q], cvec[q], lam[ct][q]);  // Gaussian prior: J = -1/sigma^2
+                lam[ct][q] = fmaf(sig_r * pis[q], Gc[q], v);                // cost depends on x through sigma * prior.score(x)
+              }
             }
           }
         }
@@ -456,87 +655,45 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
           gsum = sum_wave(gsum);
           if (lane < 2) A.gpart[(tile * T + t) * A.gw + lane] = lane == 0 ? gsum : 0.0f;
         }
-        if constexpr (BPTT) {
-          // ===================================================================================== adjoint update, first part
-          //   lambda_t = c_x lambda_{t+1} + (d score term / d x)^T G + direct cost terms  [+ W_in^T delta_0 at the end of the step]
-          f32x16 vt[OTD];
-#pragma unroll
-          for (int ct = 0; ct < OTD; ++ct)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) vt[ct][q] = 0.0f;
-          if (jac_t != 0.0f) {  // closed-form target scores are differentiated through x
-            if (A.target.kind == SDEH_DENS_DIAG_GAUSS) {
-#pragma unroll
-              for (int ct = 0; ct < OTD; ++ct) {
-                const f32x16 tis = rows16(tabs + 5 * 64 + 32 * ct + 4 * h);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) vt[ct][q] = -tis[q] * cvec[ct][q];
-              }
-            } else if (A.target.kind == SDEH_DENS_MULTI_WELL) {
-#pragma unroll
-              for (int ct = 0; ct < OTD; ++ct)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                  const float y = x[ct][q] - A.target.p1;
-                  vt[ct][q] = (32 * ct + 4 * h + rrow(q) < A.target.n_comp ? -4.0f * (3.0f * y * y - A.target.p0) : -1.0f) * cvec[ct][q];
-                }
-            } else if (A.target.kind == SDEH_DENS_FUNNEL) {
-              // s_0 = -x0/var - (d-1)/2 + e^{-x0} sum x_j^2 / 2,  s_j = -x_j e^{-x0}   (coordinate 0 = register 0 of the h = 0 half of
-              // coordinate tile 0); the sums run over all coordinates: registers, tiles and the two lane halves of this wave
-              const float x0 = __shfl(x[0][0], j), c0 = __shfl(cvec[0][0], j);
-              float sq = 0.0f, cx = 0.0f;
-#pragma unroll
-              for (int ct = 0; ct < OTD; ++ct)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                  const bool first = q == 0 && h == 0 && ct == 0;
-                  sq = fmaf(first ? 0.0f : x[ct][q], x[ct][q], sq);
-                  cx = fmaf(first ? 0.0f : cvec[ct][q], x[ct][q], cx);
-                }
-              sq = sum_xor32(sq);
-              cx = sum_xor32(cx);
-              const float iv = __expf(-x0);
-#pragma unroll
-              for (int ct = 0; ct < OTD; ++ct)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) vt[ct][q] = iv * (c0 * x[ct][q] - cvec[ct][q]);
-              if (h == 0) vt[0][0] = c0 * (-1.0f / A.target.p0 - 0.5f * iv * sq) + iv * cx;
-            }
-          }
-#pragma unroll
-          for (int ct = 0; ct < OTD; ++ct) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) lam[ct][q] = fmaf(jac_t, vt[ct][q], c_x * lam[ct][q]);
-            if (jac_p != 0.0f || refc) {
-              const f32x16 pis = rows16(tabs + 1 * 64 + 32 * ct + 4 * h);
-#pragma unroll
-              for (int q = 0; q < 16; ++q) {
-                float v = fmaf(-jac_p * pis[q], cvec[ct][q], lam[ct][q]);  // Gaussian prior: J = -1/sigma^2
-                if (refc) v = fmaf(sig * pis[q], Gc[ct][q], v);             // cost depends on x through sigma * prior.score(x)
-                lam[ct][q] = v;
-              }
-            }
-          }
-        }
       }
+      SDEH_FENCE();
       BW2_T(tp2);
 
       // ======================================================================================= backward + weight gradients
-      // each product: publish (delta_k, a_k), barrier, operands -> registers, barrier (planes free again), then the product's matrix
-      // instructions interleaved with the chain's next transposed layer
+      // each product: publish (delta_k, a_k), barrier; then its matrix instructions -- operands a chunk ahead through a register ring
+      // -- interleaved with the chain's next transposed layer; a barrier behind them frees the planes
 #pragma unroll
-      for (int ct = 0; ct < OTD; ++ct) plane_put(Dme, ct, j, h, dout[ct]);
+      for (int ct = 0; ct < OTD; ++ct) plane_put_n<NQ>(Dme, ct, j, h, dout[ct]);
       ws_barrier();
       f32x16 dl[2];
-      {
+      if constexpr (OTD == 2) {
+        float ds[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        stage_cols<8, RSW, 2, 2, 16>(Wout_s + 4 * h * RSW + j, dout, 8, dl, planes, wR, wC, j, h, dw_out, ds);
+        bs_out += (ds[0] + ds[1]) + (ds[2] + ds[3]);
+      } else {
         float ds[2] = {0.0f, 0.0f};
-        if constexpr (OTD == 2)
-          stage_cols<8, RSW, 2, 2, true>(Wout + 4 * h * RSW + j, dout, A.n_kg, dl, team_planes, r, 0, j, h, dw[OTD + 2 * LH], dw[NDW - 1], ds);
-        else
-          stage_cols<4, RSW, 2, 1, false>(Wout + 4 * h * RSW + j, dout, A.n_kg, dl, team_planes, 0, r, j, h, dw[OTD + 2 * LH], dw[OTD + 2 * LH], ds);
+        const float* __restrict__ pp = planes + wR * 4 * PLANE;  // the pair's planes
+        if constexpr (VIO) {
+          f32x16 none[1];
+          stage_cols<0, RSW, 1, 1, 8>(Wout_s, dout, 0, none, pp, 0, wC, j, h, dw_out, ds);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) { dl[0][q] = 0.0f; dl[1][q] = 0.0f; }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (i < d) {
+              const float gb = bcast_lo(dout[0][i]);
+              const f32x16 w0 = load16(vout_s + i * 64 + h * 16), w1 = load16(vout_s + i * 64 + 32 + h * 16);
+#pragma unroll
+              for (int q = 0; q < 16; ++q) { dl[0][q] = fmaf(w0[q], gb, dl[0][q]); dl[1][q] = fmaf(w1[q], gb, dl[1][q]); }
+            }
+          }
+        } else {
+          stage_cols<NGI, RSW, 2, 1, 8>(Wout_s + 4 * h * RSW + j, dout, NGI, dl, pp, 0, wC, j, h, dw_out, ds);
+        }
         bs_out += ds[0] + ds[1];
       }
       BW2_T(tp3);
+      f32x16 xpub[OTD];
 #pragma unroll
       for (int l = LH - 1; l >= -1; --l) {
         BW2_T(tq0);
@@ -547,15 +704,21 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
           SDEH_ACT_SWITCH(act, ACT, {
             f32x16 tmp;
             act_both<ACT>(keep[l + 1][0], tmp, gz[0]);
+            SDEH_FENCE();
             act_both<ACT>(keep[l + 1][1], tmp, gz[1]);
           });
+          SDEH_FENCE();
 #pragma unroll
           for (int q = 0; q < 16; ++q) { dl[0][q] *= gz[0][q]; dl[1][q] *= gz[1][q]; }
+          SDEH_FENCE();
           if (l >= 0) {
-            f32x16 ak[2] = {keep[l >= 0 ? l : 0][0], keep[l >= 0 ? l : 0][1]};
-            SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(ak[0]); act_tile<ACT>(ak[1]););
-            plane_put(Ame, 0, j, h, ak[0]);
-            plane_put(Ame, 1, j, h, ak[1]);
+#pragma unroll
+            for (int R = 0; R < 2; ++R) {
+              f32x16 ak = keep[l >= 0 ? l : 0][R];
+              SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(ak););
+              plane_put(Ame, R, j, h, ak);
+              SDEH_FENCE();
+            }
           }
         } else {
 #pragma unroll
@@ -565,48 +728,88 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             plane_put(Ame, 1, j, h, akeep[l >= 0 ? l : 0][1]);
           }
         }
+        if constexpr (XRELOAD) {
+          if (l == 0) {  // requested in front of the last hidden stage's matrix instructions
+#pragma unroll
+            for (int ct = 0; ct < OTD; ++ct) xpub[ct] = load_cm(A.xs + (long long)t * d * B, (unsigned)lrow, ct);
+          }
+        }
         if (l < 0) {
 #pragma unroll
-          for (int ct = 0; ct < OTD; ++ct) plane_put(Ame, ct, j, h, x[ct]);
+          for (int ct = 0; ct < OTD; ++ct) plane_put_n<NQ>(Ame, ct, j, h, XRELOAD ? xpub[ct] : x[ct]);
         }
+        SDEH_FENCE();
         plane_put(Dme, 0, j, h, dl[0]);
         plane_put(Dme, 1, j, h, dl[1]);
+        SDEH_FENCE();
         BW2_T(tq1);
         ws_barrier();
         BW2_T(tq2);
         BW2_ADD(13, tq0, tq1); BW2_ADD(14, tq1, tq2);
-        float ds[2] = {0.0f, 0.0f};
         if (l >= 0) {
+          float ds[4] = {0.0f, 0.0f, 0.0f, 0.0f};
           f32x16 dn[2];
-          stage_cols<8, RSW, 2, 2, true>(Whid + (l >= 0 ? l : 0) * 64 * RSW + 4 * h * RSW + j, dl, 8, dn, team_planes, r, 0, j, h,
-                                         dw[OTD + 2 * (l >= 0 ? l : 0)], dw[OTD + 2 * (l >= 0 ? l : 0) + 1], ds);
-          bs_hid[l >= 0 ? l : 0] += ds[0] + ds[1];
+          stage_cols<8, RSW, 2, 2, 16>(Whid_s + (l >= 0 ? l : 0) * 64 * RSW + 4 * h * RSW + j, dl, 8, dn, planes, wR, wC, j, h,
+                                       dw_hid[l >= 0 ? l : 0], ds);
+          bs_hid[l >= 0 ? l : 0] += (ds[0] + ds[1]) + (ds[2] + ds[3]);
           dl[0] = dn[0]; dl[1] = dn[1];
         } else {
-          // the next step's (or item's) x and time embedding: requested in front of the step's last block of matrix instructions
+          // the next step's (or item's) x, time embedding and scalars: requested in front of the step's last block of matrix instructions
           if (t > t_last) {
             load_x(t - 1, (int)tile, xnext);
             load_emb(t - 1, embnext);
+            cnext = load_coef(t - 1);
           } else if (round + 1 < n_rounds) {
             int tn = it_t, pn = it_pair;
             clamp_item(tn, pn);
             load_x(tn, tile_of(pn), xnext);
             load_emb(tn, embnext);
+            cnext = load_coef(tn);
           }
           f32x16 dx[OTD];
-          stage_cols<(BPTT ? 8 : 0), RSI, OTD, 2, (OTD == 2)>(Win + 4 * h * RSI + j, dl, 8, dx, team_planes, r, 0, j, h, dw[0], dw[OTD - 1], ds);
-          // d loss / d (time embedding + input bias)[t][32 r + i] per tile of the pair (ds[w]: wave w's trajectories)
-          const float e0 = sum_xor32(ds[0]), e1 = sum_xor32(ds[1]);
-          if (live_item && h == 0) {
-            const long long tl0 = 2 * (long long)cur_pair;
-            A.epart[(tl0 * T + t) * 64 + 32 * r + j] = e0;
-            if (tl0 + 1 < n_tiles) A.epart[((tl0 + 1) * T + t) * 64 + 32 * r + j] = e1;
+          // d loss / d (time embedding + input bias)[t][row] per tile: the delta row sums of each wave's trajectories
+          if constexpr (OTD == 2) {
+            float ds[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            stage_cols<(BPTT ? 8 : 0), RSI, 2, 2, 16>(Win_s + 4 * h * RSI + j, dl, 8, dx, planes, wR, wC, j, h, dw_in, ds);
+            if (live_item && wC == 0) {
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const float e = sum_xor32(ds[w]);
+                const long long tl = 4 * (long long)cur_pair + w;
+                if (h == 0 && tl < n_tiles) A.epart[(tl * T + t) * 64 + 32 * wR + j] = e;
+              }
+            }
+          } else {
+            float ds[2] = {0.0f, 0.0f};
+            stage_cols<((BPTT && !VIO) ? NGI == 0 ? 0 : 8 : 0), RSI, 1, 2, 8>(Win_s + 4 * h * RSI + j, dl, 8, dx, planes + wR * 4 * PLANE, wC, 0, j, h, dw_in, ds);
+            if (live_item) {
+#pragma unroll
+              for (int w = 0; w < 2; ++w) {
+                const float e = sum_xor32(ds[w]);
+                const long long tl = 4 * (long long)cur_pair + 2 * wR + w;
+                if (h == 0 && tl < n_tiles) A.epart[(tl * T + t) * 64 + 32 * wC + j] = e;
+              }
+            }
           }
           if constexpr (BPTT) {
+            if constexpr (VIO) {
 #pragma unroll
-            for (int ct = 0; ct < OTD; ++ct)
+              for (int i = 0; i < 4; ++i) {
+                if (i < d) {
+                  const f32x16 w0 = load16(vin_s + i * 64 + h * 16), w1 = load16(vin_s + i * 64 + 32 + h * 16);
+                  float p0 = 0.0f, p1 = 0.0f;
 #pragma unroll
-              for (int q = 0; q < 16; ++q) lam[ct][q] += dx[ct][q];
+                  for (int q = 0; q < 16; ++q) { p0 = fmaf(w0[q], dl[0][q], p0); p1 = fmaf(w1[q], dl[1][q], p1); }
+                  const float tot = sum_xor32(p0 + p1);
+                  lam[0][i] += h == 0 ? tot : 0.0f;
+                }
+              }
+            } else {
+#pragma unroll
+              for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) lam[ct][q] += dx[ct][q];
+            }
           }
         }
       }
@@ -615,57 +818,82 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     }
   }
 
-  // ---- the team's partial gradients ---------------------------------------------------------------------------------------
+  // ---- the team's partial gradients (the record of sdeh_bwdf.hip) -----------------------------------------------------------
   float* __restrict__ rec = A.wpart + (long long)team_g * A.wsize;
 #pragma unroll
-  for (int k = 0; k < OTD; ++k) store_tile(rec, DPP, r, k, j, h, dw[k]);
-#pragma unroll
   for (int l = 0; l < LH; ++l) {
-    store_tile(rec + off_whid<OTD>() + l * 4096, 64, r, 0, j, h, dw[OTD + 2 * l]);
-    store_tile(rec + off_whid<OTD>() + l * 4096, 64, r, 1, j, h, dw[OTD + 2 * l + 1]);
+    store_tile(rec + off_whid<OTD>() + l * 4096, 64, wR, wC, j, h, dw_hid[l]);
     float b = bs_hid[l];
     b += __shfl_xor(b, 32);
-    if (h == 0) rec[off_bhid<OTD, LH>() + l * 64 + 32 * r + j] = b;
+    if (h == 0 && wC == 0) rec[off_bhid<OTD, LH>() + l * 64 + 32 * wR + j] = b;
   }
-  {
+  if constexpr (OTD == 2) {
+    store_tile(rec, DPP, wR, wC, j, h, dw_in);
+    store_tile(rec + off_wout<OTD, LH>(), 64, wR, wC, j, h, dw_out);
     float b = bs_out;
     b += __shfl_xor(b, 32);
-    if constexpr (OTD == 2) {
-      store_tile(rec + off_wout<OTD, LH>(), 64, r, 0, j, h, dw[OTD + 2 * LH]);
-      store_tile(rec + off_wout<OTD, LH>(), 64, r, 1, j, h, dw[OTD + 2 * LH + 1]);
-      if (h == 0) rec[off_bout<OTD, LH>() + 32 * r + j] = b;
-    } else {
-      store_tile(rec + off_wout<OTD, LH>(), 64, 0, r, j, h, dw[OTD + 2 * LH]);
-      if (h == 0 && r == 0) rec[off_bout<OTD, LH>() + j] = b;
+    if (h == 0 && wC == 0) rec[off_bout<OTD, LH>() + 32 * wR + j] = b;
+  } else {
+    // input_embed row tile wC / out_layer channel tile wC: the second wave pair hands its sums to the first through the (now idle) planes
+    ws_barrier();
+    float* __restrict__ xch = planes + wC * 2 * PLANE;  // 2 x 16 x 64 + 64 floats per tile index: inside two planes
+    if (wR == 1) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { xch[q * 64 + lane] = dw_in[q]; xch[1024 + q * 64 + lane] = dw_out[q]; }
+      xch[2048 + lane] = bs_out;
+    }
+    ws_barrier();
+    if (wR == 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { dw_in[q] += xch[q * 64 + lane]; dw_out[q] += xch[1024 + q * 64 + lane]; }
+      float b = bs_out + xch[2048 + lane];
+      b += __shfl_xor(b, 32);
+      store_tile(rec, DPP, wC, 0, j, h, dw_in);
+      store_tile(rec + off_wout<OTD, LH>(), 64, 0, wC, j, h, dw_out);
+      if (h == 0 && wC == 0) rec[off_bout<OTD, LH>() + j] = b;
     }
   }
 }
 
-template <int OTD, bool BPTT, int LH>
-static int launch_bwdf2_t(const BwdfArgs& a, hipStream_t stream) {
-  constexpr bool RECOMP = OTD == 2 && LH == 2;
-  const size_t lds_bytes = (size_t)bwdf::lds_floats<OTD, LH>() * sizeof(float);
+template <int OTD, bool BPTT, int LH, int NQ, bool VIO>
+static int launch_bwdf2_q(const BwdfArgs& a, hipStream_t stream) {
+  constexpr bool RECOMP = false;  // (kept act, act-prime: with four-wave teams they fit; the re-evaluating form spills more)
+  const size_t lds_bytes = (size_t)(bwdf::lds_floats<OTD, LH>() + 512) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, BPTT, LH, RECOMP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, BPTT, LH, RECOMP, NQ, VIO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwdf2_kernel<OTD, BPTT, LH, RECOMP>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((bwdf2_kernel<OTD, BPTT, LH, RECOMP, NQ, VIO>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
-bool bwdf2_fits(int d, int n_hidden) { return n_hidden >= 1 && n_hidden <= 2 && bwdf_fits(d, n_hidden); }
+template <int OTD, bool BPTT, int LH>
+static int launch_bwdf2_t(const BwdfArgs& a, hipStream_t stream) {
+  if constexpr (OTD == 2) {
+    return launch_bwdf2_q<2, BPTT, LH, 16, false>(a, stream);
+  } else if constexpr (LH == 2) {  // the shipped depth: specialised by the number of live coordinates
+    static const bool no_vio = getenv("SDEH_BWD_NO_VIO") != nullptr;  // A/B aid (read once)
+    if (a.d <= 4 && !no_vio) return launch_bwdf2_q<1, BPTT, LH, 4, true>(a, stream);
+    if (a.d <= 8) return launch_bwdf2_q<1, BPTT, LH, 4, false>(a, stream);
+    if (a.d <= 16) return launch_bwdf2_q<1, BPTT, LH, 8, false>(a, stream);
+    return launch_bwdf2_q<1, BPTT, LH, 16, false>(a, stream);
+  } else {
+    return launch_bwdf2_q<1, BPTT, LH, 16, false>(a, stream);
+  }
+}
 
-// teams (of two 32-trajectory tiles) the launch uses: two per workgroup, one workgroup per CU
+bool bwdf2_fits(int d, int n_hidden) { return n_hidden >= 1 && n_hidden <= 2 && bwdf_fits(d, n_hidden); }  // (+ launch_bwdf2's own refusals)
+
+// teams (of four 32-trajectory tiles: one workgroup, one per CU) the launch uses
 int bwdf2_slots(long long batch, int n_steps, bool bptt) {
-  const long long tiles = (batch + 31) / 32, pairs = (tiles + 1) / 2;
-  const long long items = bptt ? pairs : pairs * n_steps;
-  const long long wgs = (items + 1) / 2;
-  return 2 * (int)(wgs < 256 ? wgs : 256);
+  const long long tiles = (batch + 31) / 32, quads = (tiles + 3) / 4;
+  const long long items = bptt ? quads : quads * n_steps;
+  return (int)(items < 256 ? items : 256);
 }
 
 #ifdef SDEH_BWDF_PROFILE
@@ -687,6 +915,7 @@ int launch_bwdf2(const BwdfArgs& a, hipStream_t stream) {
   struct Dump { hipStream_t s; ~Dump() { bwdf2_prof_dump(s); } } dump{stream};
 #endif
   const bool bptt = !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  if (a.d > 32 && bptt && a.target.kind == SDEH_DENS_FUNNEL) return SDEH_ERR_UNSUPPORTED;  // its Jacobian couples the two coordinate tiles
   if (a.n_hidden == 1) {
     if (a.d <= 32) return bptt ? launch_bwdf2_t<1, true, 1>(a, stream) : launch_bwdf2_t<1, false, 1>(a, stream);
     return bptt ? launch_bwdf2_t<2, true, 1>(a, stream) : launch_bwdf2_t<2, false, 1>(a, stream);

@@ -102,6 +102,9 @@ class _MaskedMoment(torch.autograd.Function):
         return torch.where(mask, per_row * grad_out, torch.zeros_like(rnd)), None, None, None
 
 
+_GRAPH_COUNTER_START = 1 << 40  # = utils.graphs.COUNTER_START (first value of a captured step's device-resident Philox counter)
+
+
 class BaseOCLoss:
     #: set to a torch.distributed process group (or leave None for the default group); evaluation statistics are
     #: merged across ranks whenever torch.distributed is initialised (at any world size)
@@ -249,18 +252,29 @@ class BaseOCLoss:
         self.n_filtered = state_dict["n_filtered"]
         if self._n_filtered_dev is not None:
             self._n_filtered_dev.zero_()
-        # extension of the reference's {"n_filtered"} (losses/oc.py:133-137): a resumed run continues the noise stream.  Under a
-        # replayed hipGraph the position is `calls` + the device counter (utils/graphs.py): both are saved and restored
+        # extension of the reference's {"n_filtered"} (losses/oc.py:133-137): a resumed run continues the noise stream.  The Philox
+        # offset of a launch is (stream_id << 40) + calls + *rng_counter; under a replayed hipGraph the device counter starts at
+        # utils.graphs.COUNTER_START (apart from every eager offset) and advances by one per replay.  What is saved is the number of
+        # REPLAYS, so that a checkpoint moves between eager and graphed runs without wiping COUNTER_START (replays would reuse eager
+        # offsets) or carrying 2^40 into the stream-id bits of `calls`:
+        #   graphed -> graphed: counter = COUNTER_START + replays        eager -> graphed: counter left where the capture put it
+        #   graphed -> eager:   calls += replays                         checkpoints without the keys: nothing is touched
         self.engine.calls = int(state_dict.get("rng_calls", self.engine.calls))
-        if self.rng_counter is not None:
-            self.rng_counter.fill_(int(state_dict.get("rng_counter", 0)))
-        else:  # no device counter in this object: fold the saved one into the call count (same Philox offset = calls + counter)
-            self.engine.calls += int(state_dict.get("rng_counter", 0))
+        replays = state_dict.get("rng_replays")
+        if replays is None and int(state_dict.get("rng_counter", 0)) >= _GRAPH_COUNTER_START:  # checkpoints of the first format
+            replays = int(state_dict["rng_counter"]) - _GRAPH_COUNTER_START
+        if replays is not None:
+            if self.rng_counter is not None:
+                self.rng_counter.fill_(_GRAPH_COUNTER_START + int(replays))
+            else:
+                self.engine.calls += int(replays)
 
     def state_dict(self) -> dict:
         on_device = 0 if self._n_filtered_dev is None else int(self._n_filtered_dev.item())
         counter = 0 if self.rng_counter is None else int(self.rng_counter.item())
-        return {"n_filtered": self.n_filtered + on_device, "rng_calls": self.engine.calls, "rng_counter": counter}
+        replays = counter - _GRAPH_COUNTER_START if counter >= _GRAPH_COUNTER_START else 0
+        return {"n_filtered": self.n_filtered + on_device, "rng_calls": self.engine.calls, "rng_counter": counter,
+                "rng_replays": replays}
 
     def _row_offset(self, local_batch: int) -> int:
         """Global index of this rank's first trajectory.  The default, rank * local batch, assumes EQUAL local batches on all

@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import em_oracle as eo
+from tests.helpers import hatch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -130,6 +131,7 @@ def check_eval_case(case, spec_hook=None, expect_kernel=None):
         ref = oracle.eval(ts, x0.clone(), noise, compute_weights=weights, return_traj=True)
         probes = [oracle.eval(ts, *_perturbed(x0, noise, eps), compute_weights=weights, return_traj=True) for eps in _PERTS]
     except ValueError as exc:  # torch.distributions' support check on non-finite states: the configuration blows up in the reference
+        hatch("eval:reference_rejects_configuration", f"case {case}")
         pytest.skip(f"random configuration rejected by the reference's own distribution checks: {str(exc)[:80]}")
     cond_rows = torch.stack([torch.nan_to_num((q["xs"] - ref["xs"]).abs().amax(dim=(0, 2)), nan=math.inf) for q in probes]).amax(dim=0)
 
@@ -156,7 +158,9 @@ def check_eval_case(case, spec_hook=None, expect_kernel=None):
         more = [oracle.eval(ts, *_perturbed(x0, noise, eps), compute_weights=weights, return_traj=True) for eps in _MORE_PERTS]
         cond_all = torch.maximum(cond_rows, torch.stack([torch.nan_to_num((q["xs"] - ref["xs"]).abs().amax(dim=(0, 2)), nan=math.inf)
                                                           for q in more]).amax(dim=0))
+        hatch("eval:bulk_reprobed", tag)
         if cond_all.median().item() > 1e-3 * scale:
+            hatch("eval:chaotic_reference_skip", tag)
             pytest.skip(f"{tag}: chaotic in the reference itself (median response {cond_all.median().item():.2e} to 1e-6 probes, scale {scale:.1f})")
         row_err = (raw_err - cond_all).clamp_min(0.0)
     assert row_err.median().item() <= 1e-4 * scale, f"{tag}: median row error {row_err.median().item():.3e} (scale {scale:.2f})"
@@ -171,6 +175,7 @@ def check_eval_case(case, spec_hook=None, expect_kernel=None):
 
     drifted, n_chaotic = drift(cond_rows)
     if drifted > DRIFT_MAX:  # three probes under-estimate the conditioning of a discontinuous (clamped) map: look again with eight more
+        hatch("eval:drift_reprobed", tag)
         more = [oracle.eval(ts, *_perturbed(x0, noise, eps), compute_weights=weights, return_traj=True) for eps in _MORE_PERTS]
         cond_more = torch.stack([torch.nan_to_num((q["xs"] - ref["xs"]).abs().amax(dim=(0, 2)), nan=math.inf) for q in more]).amax(dim=0)
         drifted, n_chaotic = drift(torch.maximum(cond_rows, cond_more))
@@ -178,6 +183,8 @@ def check_eval_case(case, spec_hook=None, expect_kernel=None):
         with open(os.environ["SDEH_FUZZ_REPORT"], "a") as fh:
             fh.write(f"{case} B={B} T={T} d={d} median={row_err.median().item() / scale:.3e} max={row_err.max().item() / scale:.3e} "
                      f"drifted={drifted:.4f} chaotic_rows={n_chaotic}\n")
+    if drifted > 0.0:
+        hatch("eval:rows_beyond_bar_within_allowance", f"{tag}: {drifted:.4f}")
     assert drifted <= DRIFT_MAX, f"{tag}: {drifted:.0%} of the rows differ by more than {2e-3 * scale:.1e}"
     assert (out.xs[0].cpu() == ref["xs"][0]).all()  # the initial state is passed through
     key = "log_norm_const_lb_ito" if weights else "log_norm_const_lb"
@@ -185,6 +192,7 @@ def check_eval_case(case, spec_hook=None, expect_kernel=None):
     if math.isfinite(want) and abs(want) > 1e8:
         # quartic wells far from the origin: costs of 1e9 .. 1e14 whose rows answer a 1e-6 probe with changes of 1e8 -- the
         # reference's trajectories have exploded (finite by luck); rows were compared above, the estimator only in magnitude
+        hatch("eval:exploded_reference_estimator", tag)
         assert (not math.isfinite(got)) or abs(got) > 1e6, f"{tag}: {key} {got} vs {want}"
         return
     cond = cond_of(key)
@@ -231,6 +239,7 @@ def check_training_case(case, num_layers=None, expect_kernel=None, spec_hook=Non
     try:
         ref_loss, _, _, _ = oracle.train_loss(ts, x0.clone(), noise, method=method)
     except ValueError as exc:  # torch.distributions' support check on non-finite states: the configuration blows up in the reference
+        hatch("train:reference_rejects_configuration", f"case {case}")
         pytest.skip(f"random configuration rejected by the reference's own distribution checks: {str(exc)[:80]}")
     ref_loss.backward()
     # conditioning probe: loss and gradients of the reference at inputs moved by 1e-6
@@ -258,19 +267,23 @@ def check_training_case(case, num_layers=None, expect_kernel=None, spec_hook=Non
             assert kernel.startswith(expect_kernel), kernel
     except SdehUnsupported as exc:  # a documented limit, e.g. a wide mixture next to the transposed weights in LDS
         if "do not fit in LDS" in str(exc):
+            hatch("train:lds_table_limit_skip", f"case {case}")
             pytest.skip(str(exc)[:120])
         raise
     tag = f"case {case}: {method} {spec['loss']['kind']} / {spec['ctrl']['kind']} / {spec['target']['kind']} d={d} B={B} T={T}"
-    if math.isfinite(ref_loss.item()) and abs(ref_loss.item()) > 1e8:  # the reference's own trajectories have exploded (finite by luck)
-        assert not math.isfinite(val.item()) or abs(val.item()) > 1e6, f"{tag}: loss {val.item()} vs {ref_loss.item()}"
-        return
+    if math.isfinite(ref_loss.item()) and abs(ref_loss.item()) > 1e8:
+        # Large losses are compared like any other (relative bar + the reference's own response to the probes; the float64 oracle
+        # arbitrates the gradients below) -- unless the reference is not comparable with ITSELF: a loss beyond 1e15, or one that a
+        # one-in-a-million probe moves by more than 5 % (its trajectories have exploded and are finite by luck).  Then only the
+        # magnitude is checked.  (the shortcut used to take every loss above 1e8.)
+        if abs(ref_loss.item()) > 1e15 or not cond_loss <= 0.05 * abs(ref_loss.item()):
+            hatch("train:exploded_reference_loss", tag)
+            assert not math.isfinite(val.item()) or abs(val.item()) > 1e-2 * abs(ref_loss.item()), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+            return
+        hatch("train:large_loss_compared_relatively", tag)
     assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item())) + cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
     if not math.isfinite(ref_loss.item()):
-        return
-    if abs(ref_loss.item()) > 1e9:
-        # trajectories at magnitudes where the fp32 reference's own gradients are off by per cents against float64 (case 11081 of the
-        # wide sweep: loss 1.1e11, the library 100 x closer to float64 than the oracle -- tests/perf/fuzz_wide_train_dbg.py): the loss
-        # value above is what can be compared
+        hatch("train:nonfinite_reference_loss", tag)
         return
     gmax = max((torch.nan_to_num(p.grad).abs().max().item() for p in params.values() if p.grad is not None), default=0.0)
     g64 = None
@@ -282,9 +295,11 @@ def check_training_case(case, num_layers=None, expect_kernel=None, spec_hook=Non
         # relative to the tensor's own scale, with a floor at 1e-4 of the largest gradient of the network (tiny gradients of
         # e.g. a clamped gamma carry only rounding noise)
         if not torch.isfinite(g_ref).all():
+            hatch("train:nonfinite_reference_gradient", f"{tag}: {k}")
             continue  # the reference's own gradient is not finite for this random configuration
         denom = max(g_ref.abs().max().item(), 1e-4 * gmax, 1e-12)
         if cond_grad.get(k, 0.0) > 0.5 * denom:
+            hatch("train:gradient_ill_conditioned_in_reference", f"{tag}: {k}")
             continue  # a 1e-6 change of the inputs moves the reference's own gradient by more than half of its size: nothing to compare
         err = max((g - g_ref).abs().max().item() - cond_grad.get(k, 0.0), 0.0) / denom
         tol = _grad_tol(spec["net"], k) * (relu_tol_scale if spec["net"].get("activation") == "relu" else 1.0)
@@ -293,6 +308,7 @@ def check_training_case(case, num_layers=None, expect_kernel=None, spec_hook=Non
             # rounding that the +-1e-6 input probes do not show -- case 11224 of the wide sweep: library 12 x closer to float64.)  The
             # float64 run of the oracle decides: the library must be within the bar of float64, or at least as close to it as the
             # fp32 oracle is.
+            hatch("train:float64_arbitration", f"{tag}: {k} {err:.2e}")
             if g64 is None:
                 g64 = _float64_grads(spec, params, tt, ts, x0, noise, method)
             if g64 is not None and g64.get(k) is not None:
@@ -374,6 +390,7 @@ def test_random_bridge_matches_oracle(case):
     torch.set_num_threads(4)
     ref = oracle.eval(ts, x0.clone(), noise, compute_weights=True)
     if not math.isfinite(ref["log_norm_const_lb_ito"]):  # a random configuration that blows up in the reference itself
+        hatch("bridge:nonfinite_reference", f"case {case}")
         prob.to(DEV)
         out = prob.eval(x0.to(DEV), compute_weights=True, noise=noise.to(DEV))
         assert not math.isfinite(out.log_norm_const_preds["log_norm_const_lb_ito"])
@@ -400,11 +417,13 @@ def test_random_bridge_matches_oracle(case):
     assert _close(got, want, 2e-3 * max(1.0, abs(want)) + cond_lb), f"{tag}: lb_ito {got} vs {want}"
     val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
     val.backward()
-    if math.isfinite(ref_loss.item()) and abs(ref_loss.item()) > 1e8:  # the reference's own trajectories have exploded (finite by luck)
-        assert not math.isfinite(val.item()) or abs(val.item()) > 1e6, f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    if math.isfinite(ref_loss.item()) and abs(ref_loss.item()) > 1e8 and (abs(ref_loss.item()) > 1e15 or not cond_loss <= 0.05 * abs(ref_loss.item())):
+        hatch("bridge:exploded_reference_loss", tag)  # (not comparable with itself: see check_training_case)
+        assert not math.isfinite(val.item()) or abs(val.item()) > 1e-2 * abs(ref_loss.item()), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
         return
     assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item())) + cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
     if not math.isfinite(ref_loss.item()):
+        hatch("bridge:nonfinite_reference_loss", tag)
         return
     for mod, pd, pd_p in ((prob.ctrl, params, params_p), (inf, params_inf, params_inf_p)):
         gmax = max((torch.nan_to_num(p.grad).abs().max().item() for p in pd.values() if p.grad is not None), default=0.0)

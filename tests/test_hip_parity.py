@@ -14,11 +14,15 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN, close, hip_problem, load_fixture
+from tests.helpers import GOLDEN, close, hip_problem, load_fixture, measured
 
 pytestmark = pytest.mark.gpu
 
 ROW_MAX, ROW_MEDIAN, ROW_RTOL = 1e-2, 1e-4, 1e-4
+# Training parity bars: the loss at SURVEY 8d's estimator bar, 1e-4 relative (was 2e-3); parameter gradients at 2 x
+# the worst error measured over all fixtures, methods and tensors (gpurun_out/parity_measured.txt of the round's GPU run; was 2e-4)
+LOSS_BAR = 1e-4
+GRAD_BAR = 1e-4
 
 
 def _row_check(name, got, ref):
@@ -93,7 +97,8 @@ def test_rnd_rows_match_oracle(path):
             _row_check(f"train rnd({method})", rnd.cpu().numpy(), rnd_o.detach().numpy())
             val, met = prob.loss(*args, noise=noise.cuda())
             ref = float(fx[f"train_{method}/loss"])
-            assert abs(val.item() - ref) <= 2e-3 * max(1.0, abs(ref)), (method, val.item(), ref)
+            measured(f"train loss {Path(path).stem} {method}", abs(val.item() - ref) / max(1.0, abs(ref)), LOSS_BAR)
+            assert abs(val.item() - ref) <= LOSS_BAR * max(1.0, abs(ref)), (method, val.item(), ref)
             assert met["train/n_filtered_cumulative"] >= int(fx[f"train_{method}/n_filtered"])
 
 
@@ -124,7 +129,7 @@ def test_training_gradients_match_reference(path, method):
     prob.ctrl.zero_grad()
     val, met = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
     ref_val = float(fx[f"train_{method}/loss"])
-    assert abs(val.item() - ref_val) <= 2e-3 * max(1.0, abs(ref_val))
+    assert abs(val.item() - ref_val) <= LOSS_BAR * max(1.0, abs(ref_val))
     val.backward()
     checked = 0
     for name, p in prob.ctrl.named_parameters():
@@ -132,7 +137,8 @@ def test_training_gradients_match_reference(path, method):
         got = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros_like(ref)
         scale = max(np.abs(ref).max(), 1e-6)
         err = np.abs(got - ref).max()
-        assert err <= 2e-4 * scale + 1e-7, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+        measured(f"grad {Path(path).stem} {method} {name}", err / scale, GRAD_BAR)
+        assert err <= GRAD_BAR * scale + 1e-7, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
         checked += 1
     assert checked >= 10
 
@@ -329,10 +335,12 @@ def test_kl_ito_and_lv_traj_training_match_reference(path):
         val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob,
                            noise=torch.from_numpy(noise).cuda())
         ref_val = float(fx[f"train_{method}/loss"])
-        assert abs(val.item() - ref_val) <= 2e-3 * max(1.0, abs(ref_val)), (method, val.item(), ref_val)
+        measured(f"train loss {Path(path).stem} {method}", abs(val.item() - ref_val) / max(1.0, abs(ref_val)), LOSS_BAR)
+        assert abs(val.item() - ref_val) <= LOSS_BAR * max(1.0, abs(ref_val)), (method, val.item(), ref_val)
         val.backward()
         for name, p in prob.ctrl.named_parameters():
             ref = fx[f"train_{method}/grad/{name}"]
             scale = max(np.abs(ref).max(), 1e-6)
             err = np.abs(p.grad.cpu().numpy() - ref).max()
-            assert err <= 2e-4 * scale + 1e-7, f"{method} {name}: max err {err:.3e} vs scale {scale:.3e}"
+            measured(f"grad {Path(path).stem} {method} {name}", err / scale, GRAD_BAR)
+            assert err <= GRAD_BAR * scale + 1e-7, f"{method} {name}: max err {err:.3e} vs scale {scale:.3e}"

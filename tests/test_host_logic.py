@@ -167,11 +167,28 @@ def test_loss_contract():
         ReferenceSDELoss(generative_ctrl=None, method="lv_traj", traj_per_sample=1)
     loss = ExponentialIntegratorSDELoss(generative_ctrl=None, alpha=1.0, sigma=2.0, method="lv", max_rnd=1e8, unknown_kw=1)
     # reference keys + the position in the noise stream (call count + the device counter of replayed hipGraphs)
-    assert loss.state_dict() == {"n_filtered": 0, "rng_calls": 0, "rng_counter": 0}
+    assert loss.state_dict() == {"n_filtered": 0, "rng_calls": 0, "rng_counter": 0, "rng_replays": 0}
     loss.load_state_dict({"n_filtered": 7})  # a reference checkpoint (losses/oc.py:133-137) loads as is
     assert loss.n_filtered == 7 and (loss.alpha, loss.sigma) == (1.0, 2.0) and loss.engine.calls == 0
     loss.load_state_dict({"n_filtered": 7, "rng_calls": 12})
     assert loss.engine.calls == 12 and loss.engine.offset() == 12
+    # resuming across eager <-> graphed runs: a graphed loss carries a device counter that starts at COUNTER_START
+    from sde_sampler_amd.utils.graphs import COUNTER_START
+    graphed = ExponentialIntegratorSDELoss(generative_ctrl=None, alpha=1.0, sigma=2.0, method="lv")
+    graphed.rng_counter = torch.full((1,), COUNTER_START + 5, dtype=torch.int64)
+    sd = graphed.state_dict()
+    assert sd["rng_counter"] == COUNTER_START + 5 and sd["rng_replays"] == 5
+    graphed.load_state_dict({"n_filtered": 0})  # a checkpoint without the keys (any earlier one) leaves the counter alone
+    assert int(graphed.rng_counter) == COUNTER_START + 5
+    graphed.load_state_dict({"n_filtered": 0, "rng_calls": 12, "rng_counter": 0, "rng_replays": 0})  # eager -> graphed: COUNTER_START survives
+    assert int(graphed.rng_counter) == COUNTER_START and graphed.engine.calls == 12
+    graphed.load_state_dict(sd)  # graphed -> graphed
+    assert int(graphed.rng_counter) == COUNTER_START + 5
+    eager = ExponentialIntegratorSDELoss(generative_ctrl=None, alpha=1.0, sigma=2.0, method="lv")
+    eager.load_state_dict(dict(sd, rng_calls=3))  # graphed -> eager: only the replay count joins the calls, no carry into the stream id
+    assert eager.engine.calls == 8 and eager.engine.offset() == 8
+    eager.load_state_dict({"n_filtered": 0, "rng_calls": 3, "rng_counter": COUNTER_START + 2})  # the first format of these checkpoints
+    assert eager.engine.calls == 5
     from sde_sampler_amd.eq.integrator import EulerIntegrator
     assert EulerIntegrator().engine.offset() == 1 << 40  # its own Philox stream
     rnd = torch.tensor([[1.0], [float("nan")], [2e9], [3.0]])

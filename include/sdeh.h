@@ -30,7 +30,7 @@ extern "C" {
 
 /* v4 (round 3): sdeh_ctrl_backward_ex gained xt_out / sc_in / tscore_in; wide-network training entry points
  * (sdeh_bridge_div_backward_wide[_sizes]); sdeh_simulate_fwd_aux2. */
-#define SDEH_ABI_VERSION 4
+#define SDEH_ABI_VERSION 5
 #define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
 
 typedef enum {
@@ -178,14 +178,18 @@ typedef struct {
 
 typedef struct {
   int32_t dim;         /* d <= 64 with channels = 64: every entry point.  d <= 256 with channels = 128 / 256, and 64 < d <= 256 with
-                          channels = 64: the "wide" kernels -- sdeh_simulate_fwd[_aux], sdeh_ctrl_backward[_ex] + sdeh_weight_grad,
-                          sdeh_bridge_div_backward_wide (a Bridge needs channels >= 128, a closed-form target and an inference
-                          network with <= 2 hidden layers; training needs closed-form targets) */
+                          channels = 64: the "wide" kernels -- sdeh_simulate_fwd[_aux / _train2], sdeh_ctrl_backward[_ex] +
+                          sdeh_weight_grad (every loss method, closed-form AND mixture targets; the score planes a mixture's backward
+                          needs come from sdeh_simulate_fwd_train2), sdeh_bridge_div_backward_wide (a Bridge needs channels >= 128
+                          and an inference network with 1 or 2 hidden layers; exact divergence only) */
   int32_t channels;    /* C: 64, 128 or 256 */
   int32_t max_hidden;  /* largest n_hidden of base_model */
   int32_t max_steps;   /* largest T = len(ts)-1 */
   int32_t max_components; /* largest GMM K (0 if unused) */
   int32_t device;      /* HIP device ordinal */
+  int64_t max_batch;   /* ABI v5.  Largest batch of a wide Bridge launch (its divergence needs 32 partial sums per trajectory of plan-
+                          owned scratch): reserved by sdeh_plan_create.  0 = none: call sdeh_plan_reserve before the first launch.
+                          No stream-ordered entry point allocates. */
 } SdehPlanDesc;
 
 typedef struct SdehPlan SdehPlan;
@@ -199,6 +203,20 @@ const char* sdeh_last_error(void);
  * Replaces: nothing in the reference (loss objects are plain Python, losses/oc.py:13-48). */
 int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** plan);
 void sdeh_plan_destroy(SdehPlan* plan);
+/* ABI v5.  Grows the plan's batch-dependent scratch (wide Bridge: desc.max_batch) to `max_batch` trajectories.  Synchronises the
+ * device (hipFree / hipMalloc): call it outside stream captures; sdeh_simulate_fwd* never allocates and answers SDEH_ERR_CAPACITY when
+ * the reservation is too small. */
+int32_t sdeh_plan_reserve(SdehPlan* plan, int64_t max_batch);
+/* ABI v5.  Kernel-mode options of a plan (which compiled variant / tiling serves a launch; several of them round differently, see
+ * INTEGRATION.md): `value` NULL or "" = automatic choice.  sdeh_plan_create takes the environment variables of the same names as the
+ * initial values (a test override, read ONCE there); nothing on the launch path reads the environment.  Names:
+ *   SDEH_LEGACY (single-wave trajectory kernel)      SDEH_GENERIC_ONLY ("1" | "2": run-time switched variants only)
+ *   SDEH_WS_GROUPS ("2" | "4" | "2h" | "4h" | "p")    SDEH_WS_QUAD ("0" | "1")      SDEH_WS_VOUT ("0")      SDEH_WS_BARRIER
+ *   SDEH_BWD_PLANES (plane-writing backward)         SDEH_BWD_TILE ("16" | "32")   SDEH_BWD_WAVES ("2" | "4")
+ *   SDEH_BWD_V1 / SDEH_BWD_V2 (channel- / trajectory-split fused backward)        SDEH_BWD_NO_VIO
+ *   SDEH_BRIDGE_TILES ("64" | "32g")   SDEH_BRIDGE_SPLIT ("1" | "4")   SDEH_WIDE_CT ("1" | "2")   SDEH_WIDE_SPLIT ("1" | "2" | "4" | "8")
+ * Unknown names: SDEH_ERR_INVALID. */
+int32_t sdeh_plan_set_option(SdehPlan* plan, const char* name, const char* value);
 
 /* Measurement hooks (reference analogue: the wall-clock `eval/sample_time`, solver/oc.py:88-97).  When enabled,
  * every sdeh_simulate_fwd records HIP events immediately before and after the TRAJECTORY kernel on the stream

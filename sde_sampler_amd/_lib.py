@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-SDEH_ABI_VERSION = 4
+SDEH_ABI_VERSION = 5
 SDEH_MAX_HIDDEN = 8
 SDEH_REDUCE_SCRATCH = 8192
 
@@ -84,7 +84,7 @@ class SdehProblem(C.Structure):
 class SdehPlanDesc(C.Structure):
     _fields_ = [
         ("dim", C.c_int32), ("channels", C.c_int32), ("max_hidden", C.c_int32), ("max_steps", C.c_int32),
-        ("max_components", C.c_int32), ("device", C.c_int32),
+        ("max_components", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int64),
     ]
 
 
@@ -104,12 +104,21 @@ class SdehUnsupported(SdehError, NotImplementedError):
     """The configuration is valid in the reference but not built into the HIP engine."""
 
 
+# kernel-mode options of a plan (include/sdeh.h: sdeh_plan_set_option); the environment variables of the same names are the test
+# override -- the binding copies them into the plan before a launch whenever they changed, the library itself never reads them on
+# the launch path
+PLAN_OPTIONS = ("SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES",
+                "SDEH_BWD_TILE", "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT",
+                "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT")
+
 # every symbol include/sdeh.h declares, with its prototype
 PROTOTYPES = {
     "sdeh_abi_version": (C.c_int32, []),
     "sdeh_last_error": (C.c_char_p, []),
     "sdeh_plan_create": (C.c_int32, [C.POINTER(SdehPlanDesc), C.POINTER(C.c_void_p)]),
     "sdeh_plan_destroy": (None, [C.c_void_p]),
+    "sdeh_plan_reserve": (C.c_int32, [C.c_void_p, C.c_int64]),
+    "sdeh_plan_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "sdeh_plan_set_timing": (C.c_int32, [C.c_void_p, C.c_int32]),
     "sdeh_plan_last_kernel_ms": (C.c_int32, [C.c_void_p, C.POINTER(C.c_float)]),
     "sdeh_plan_last_kernel_name": (C.c_char_p, [C.c_void_p]),

@@ -233,7 +233,7 @@ struct SdehPlan {
   SdehPlanDesc desc;
   int device;
   const Variant* variant;  // narrow networks (C = 64, d <= 64); null for wide plans
-  bool wide;               // C in {128, 256}, d <= 256: the channel-split kernels of sdeh_wide.hip (evaluation only)
+  bool wide;               // C in {128, 256}, d <= 256: the channel-split kernels of sdeh_wide.hip / sdeh_wide_bwd.hip
   float* ws;          // workspace
   size_t ws_floats;
   float* scratch;     // wide Bridge only: per-(column tile, coordinate group) divergence sums (grown on first use at a larger batch)
@@ -242,7 +242,25 @@ struct SdehPlan {
   bool timed;
   hipEvent_t ev0, ev1;
   char last_kernel[96];
+  PlanOptions opts;  // kernel-mode options (sdeh_plan_set_option)
 };
+
+// options of the plan whose entry point runs on this thread
+static thread_local const PlanOptions* tl_opts = nullptr;
+const char* sdeh::plan_opt(OptKey key) { return tl_opts != nullptr && tl_opts->v[key][0] != 0 ? tl_opts->v[key] : nullptr; }
+struct OptScope {
+  const PlanOptions* prev;
+  explicit OptScope(const SdehPlan* plan) : prev(tl_opts) { tl_opts = plan != nullptr ? &plan->opts : nullptr; }
+  ~OptScope() { tl_opts = prev; }
+};
+static const char* const kOptNames[OPT_COUNT] = {
+    "SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES", "SDEH_BWD_TILE",
+    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT"};
+static void opt_store(PlanOptions& o, int key, const char* value) {
+  memset(o.v[key], 0, sizeof(o.v[key]));
+  if (value != nullptr) strncpy(o.v[key], value, sizeof(o.v[key]) - 1);
+}
+static int reserve_scratch(SdehPlan* plan, size_t need);
 static constexpr int kRedBlocks = SDEH_REDUCE_SCRATCH / 8;
 
 extern "C" {
@@ -299,6 +317,7 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   p->timing = p->timed = false;
   p->ev0 = p->ev1 = nullptr;
   p->last_kernel[0] = 0;
+  for (int k = 0; k < OPT_COUNT; ++k) opt_store(p->opts, k, getenv(kOptNames[k]));  // the environment is a test override, read ONCE here
   int prev = 0;
   hipError_t e = hipGetDevice(&prev);
   if (e == hipSuccess) e = hipSetDevice(desc->device);
@@ -311,8 +330,44 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
     delete p;
     return rc;
   }
+  if (wide && desc->max_batch > 0) {
+    const int rc = reserve_scratch(p, (size_t)bridge_wide_scratch_floats(desc->max_batch));
+    if (rc != SDEH_OK) { (void)hipFree(p->ws); delete p; return rc; }
+  }
   *out = p;
   return SDEH_OK;
+}
+
+// (re)allocates the wide Bridge's divergence scratch: 32 partial sums per trajectory.  Synchronises the device.
+static int reserve_scratch(SdehPlan* plan, size_t need) {
+  if (need <= plan->scratch_floats) return SDEH_OK;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  hipError_t e = hipSetDevice(plan->device);
+  if (e == hipSuccess && plan->scratch != nullptr) e = hipFree(plan->scratch);
+  plan->scratch = nullptr;
+  plan->scratch_floats = 0;
+  if (e == hipSuccess) e = hipMalloc((void**)&plan->scratch, need * sizeof(float));
+  (void)hipSetDevice(prev);
+  if (e != hipSuccess) return fail(SDEH_ERR_HIP, "plan_reserve: scratch allocation failed: %s", hipGetErrorString(e));
+  plan->scratch_floats = need;
+  return SDEH_OK;
+}
+
+int32_t sdeh_plan_reserve(SdehPlan* plan, int64_t max_batch) {
+  if (plan == nullptr || max_batch < 0) return fail(SDEH_ERR_INVALID, "plan_reserve: bad argument");
+  if (!plan->wide || max_batch == 0) return SDEH_OK;  // (only the wide Bridge has batch-dependent scratch)
+  return reserve_scratch(plan, (size_t)bridge_wide_scratch_floats(max_batch));
+}
+
+int32_t sdeh_plan_set_option(SdehPlan* plan, const char* name, const char* value) {
+  if (plan == nullptr || name == nullptr) return fail(SDEH_ERR_INVALID, "plan_set_option: null argument");
+  for (int k = 0; k < OPT_COUNT; ++k)
+    if (strcmp(name, kOptNames[k]) == 0) {
+      opt_store(plan->opts, k, value);
+      return SDEH_OK;
+    }
+  return fail(SDEH_ERR_INVALID, "plan_set_option: unknown option %s", name);
 }
 
 int32_t sdeh_plan_set_timing(SdehPlan* plan, int32_t enable) {
@@ -463,10 +518,10 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   const Variant* v = plan->variant;
   const bool shared = pr->target.kind == SDEH_DENS_GMM && (pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE);
   const int nvary = shared ? SDEH_DENS_FLAG_GET_NVARY(pr->target.flags) : -1;
-  const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;  // A/B aid: single-wave kernel, global tables
-  // testing / measurement aid: only the variants with run-time switches for loss / control / target / activation (read per call);
+  const bool force_legacy = plan_opt(OPT_LEGACY) != nullptr;  // A/B aid: single-wave kernel, global tables
+  // testing / measurement aid: only the variants with run-time switches for loss / control / target / activation (a plan option);
   // SDEH_GENERIC_ONLY=2 also rules out the ones with reduced mixture tables ("g4")
-  const char* gen_only = getenv("SDEH_GENERIC_ONLY");
+  const char* gen_only = plan_opt(OPT_GENERIC_ONLY);
   const bool no_spec = gen_only != nullptr;
   // which GMM table form would the layout give?  (0: tables do not fit LDS, 1: general, 2: shared scale)
   // the integrator runs on the single-wave code path of the generic variant (mixture tables in LDS when they fit)
@@ -657,26 +712,12 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     A.gp = gp;  // [T, B, d] or null: u + v per step (training: the inference network's upstream gradient)
   }
   if (bridge) {
-    // the one buffer a plan grows after creation: 32 group sums per trajectory of the network part of the divergence
+    // 32 group sums per trajectory of the network part of the divergence: reserved by sdeh_plan_create / sdeh_plan_reserve
     const size_t need = (size_t)bridge_wide_scratch_floats(batch);
-    if (need > plan->scratch_floats) {
-      // (the one allocation a plan makes after creation: it synchronises the device, so it must not happen while the stream is
-      // being captured into a hipGraph -- run one launch at the largest batch before capturing)
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-        return fail(SDEH_ERR_CAPACITY, "simulate_fwd (wide bridge): the plan's divergence scratch (%zu floats) is smaller than this batch "
-                                       "needs (%zu) and cannot grow while the stream is capturing: launch once at this batch first",
-                    plan->scratch_floats, need);
-      int prev = 0;
-      (void)hipGetDevice(&prev);
-      hipError_t e = hipSetDevice(plan->device);
-      if (e == hipSuccess && plan->scratch != nullptr) e = hipFree(plan->scratch);
-      plan->scratch = nullptr; plan->scratch_floats = 0;
-      if (e == hipSuccess) e = hipMalloc((void**)&plan->scratch, need * sizeof(float));
-      (void)hipSetDevice(prev);
-      if (e != hipSuccess) return fail(SDEH_ERR_HIP, "simulate_fwd (wide bridge): scratch allocation failed: %s", hipGetErrorString(e));
-      plan->scratch_floats = need;
-    }
+    if (need > plan->scratch_floats)
+      return fail(SDEH_ERR_CAPACITY, "simulate_fwd (wide bridge): the plan's divergence scratch (%zu floats) is smaller than this batch needs "
+                                     "(%zu): SdehPlanDesc.max_batch / sdeh_plan_reserve (no stream-ordered call allocates)",
+                  plan->scratch_floats, need);
   }
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
   int detail = 0;
@@ -699,6 +740,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                          float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, float* zt_out, float* nn_out,
                          bool* planes_written, void* stream, float* sc_out = nullptr, float* tsc_out = nullptr, float* xs_cm = nullptr) {
+  OptScope opt_scope(plan);
   if (planes_written != nullptr) *planes_written = false;
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
   if ((gp != nullptr || div_noise != nullptr) && (pr == nullptr || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)))
@@ -721,7 +763,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise);
   const WsLayout& L = ck.L;
   const Variant* v = ck.v;
-  const bool force_legacy = getenv("SDEH_LEGACY") != nullptr;
+  const bool force_legacy = plan_opt(OPT_LEGACY) != nullptr;
 
   hipStream_t st = (hipStream_t)stream;
   PrepArgs P;
@@ -829,11 +871,12 @@ int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* t
 int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                                  int64_t batch, const float* grad_rnd, const float* zt, float* tz, float* ta, float* td,
                                  float* d2, float* cj, float* dgam, float* dx_accum, const float* div_noise, void* stream) {
+  OptScope opt_scope(plan);
   if (plan == nullptr || pr == nullptr || ts == nullptr || xs == nullptr || grad_rnd == nullptr || zt == nullptr || tz == nullptr ||
       ta == nullptr || td == nullptr || d2 == nullptr || cj == nullptr)
     return fail(SDEH_ERR_INVALID, "bridge_div_backward: null argument");
   if (!(pr->flags & SDEH_FLAG_INFERENCE_CTRL)) return fail(SDEH_ERR_INVALID, "bridge_div_backward: the problem has no inference control");
-  if (plan->wide) return fail(SDEH_ERR_UNSUPPORTED, "bridge_div_backward: wide-network plans are evaluation-only");
+  if (plan->wide) return fail(SDEH_ERR_UNSUPPORTED, "bridge_div_backward: wide-network plans take sdeh_bridge_div_backward_wide");
   if (batch < 1 || n_steps < 1 || n_steps > plan->desc.max_steps) return fail(SDEH_ERR_INVALID, "bridge_div_backward: batch=%lld n_steps=%d", (long long)batch, n_steps);
   const SdehInferenceCtrl& inf = pr->inference;
   const SdehFourierMLP& net2 = inf.base_model;
@@ -882,6 +925,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
                               const float* grad_rnd, const float* gextra, const float* cost_ctrl, const float* lam_extra,
                               float* dx_out, float* zt, float* dt, float* dout, float* dgam, const float* nn_in, float* xt_out,
                               const float* sc_in, const float* tscore_in, void* stream) {
+  OptScope opt_scope(plan);
   if (xs == nullptr || grad_rnd == nullptr || zt == nullptr || dt == nullptr || dout == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward: null argument");
   Checked ck;
@@ -990,6 +1034,7 @@ int32_t sdeh_bridge_div_backward_wide_sizes(int32_t dim, int32_t channels, int32
 int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                                       int64_t batch, const float* grad_rnd, const float* zt, float* d2, float* dgam, float* dx_accum,
                                       float* scratch, int64_t scratch_floats, float* out, void* stream) {
+  OptScope opt_scope(plan);
   if (plan == nullptr || pr == nullptr || ts == nullptr || xs == nullptr || grad_rnd == nullptr || zt == nullptr || d2 == nullptr ||
       scratch == nullptr || out == nullptr)
     return fail(SDEH_ERR_INVALID, "bridge_div_backward_wide: null argument");
@@ -1060,16 +1105,17 @@ int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, con
 // Fused training backward (sdeh_bwdf.hip)
 // ---------------------------------------------------------------------------------------------------------
 int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProblem* pr) {
+  OptScope opt_scope(plan);
   if (plan == nullptr || pr == nullptr || plan->wide) return 0;
   const SdehFourierMLP& net = pr->base_model;
   if (net.channels != 64 || !bwdf_fits(net.dim, net.n_hidden)) return 0;
   if (pr->flags & (SDEH_FLAG_INFERENCE_CTRL | SDEH_FLAG_INFERENCE_SDE)) return 0;
-  if (getenv("SDEH_BWD_PLANES") != nullptr) return 0;  // A/B aid: the plane-writing kernels (read per call)
+  if (plan_opt(OPT_BWD_PLANES) != nullptr) return 0;  // A/B aid: the plane-writing kernels (a plan option)
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
   if (bptt && (pr->flags & SDEH_FLAG_INIT_LOGP)) return 0;
   // The training forward of the fused path is the wave-specialised kernel.  A launch the single-wave kernel would serve (mixture
   // tables beyond LDS, SDEH_LEGACY) keeps none of its planes: say so BEFORE the caller launches, instead of integrating twice.
-  if (getenv("SDEH_LEGACY") != nullptr) return 0;
+  if (plan_opt(OPT_LEGACY) != nullptr) return 0;
   if (pr->target.kind == SDEH_DENS_GMM && plan->variant != nullptr) {
     const bool shared = pr->target.flags & SDEH_DENS_FLAG_SHARED_SCALE;
     if (make_layout(plan->variant->dp, net.channels, net.n_hidden, 1, pr->target.n_components, 1, shared).gmm_lds == 0) return 0;
@@ -1097,8 +1143,9 @@ int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_
   bwdf_sizes(dim, n_hidden, n_steps, batch, gamma_dim == 1 ? 1 : 64, bptt != 0, 32, &w, &e, &g, &s, &o);
   *scratch_floats = w + e + g + s;
   *out_floats = o;
-  // the activation decides between the two tilings as well (sdeh_bwdf16.hip) and is not an argument here: room for either
-  if (bwdf_tile(batch, bptt != 0, SDEH_ACT_GELU_ERF) == 16) {
+  // the activation and the plan's SDEH_BWD_TILE option decide between the two tilings as well (sdeh_bwdf16.hip) and are not arguments
+  // here: room for either wherever the 16-trajectory kernel can be asked for (through time, up to 65 536 trajectories)
+  if (bptt != 0 && batch <= 65536) {
     bwdf_sizes(dim, n_hidden, n_steps, batch, gamma_dim == 1 ? 1 : 64, true, 16, &w, &e, &g, &s, &o);
     if (w + e + g + s > *scratch_floats) *scratch_floats = w + e + g + s;
   }
@@ -1109,6 +1156,7 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
                                  int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                                  const float* grad_rnd, const float* sc, const float* tscore, float* scratch,
                                  int64_t scratch_floats, float* out, void* stream) {
+  OptScope opt_scope(plan);
   if (xs == nullptr || grad_rnd == nullptr || scratch == nullptr || out == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: null argument");
   Checked ck;
@@ -1118,6 +1166,10 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
     return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward_fused: compiled for channels = 64, one to three hidden layers, "
                                       "d <= 64, no inference control (sdeh_ctrl_backward_ex + sdeh_weight_grad take the rest)");
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  // the kernels address the coordinate-major planes [d][B] with 32-bit byte offsets (sdeh_bwdf.hip: load_cm16)
+  if ((long long)(pr->base_model.dim <= 32 ? 32 : 64) * batch * 4 >= (1ll << 32))
+    return fail(SDEH_ERR_CAPACITY, "ctrl_backward_fused: %lld trajectories: the coordinate-major planes are addressed with 32-bit byte offsets "
+                                   "(64 * batch * 4 < 2^32); sdeh_ctrl_backward_ex + sdeh_weight_grad take larger batches", (long long)batch);
   if (pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr) return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: sc is null");
   if (bptt && (pr->flags & SDEH_FLAG_TERMINAL_TARGET) && tscore == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: tscore is null (back-propagation through time with a terminal target cost)");
@@ -1152,9 +1204,8 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   A.n_tiles = (int)((batch + tile - 1) / tile);
   // tiles of 32: trajectory-split teams (sdeh_bwdf2.hip; at most as many partial records as the channel-split kernel, whose sizes
-  // the scratch was checked against) unless the network has three hidden layers; SDEH_BWD_V1=1 keeps the channel-split kernel (A/B)
-  static const bool force_v1 = getenv("SDEH_BWD_V1") != nullptr;
-  static const bool force_v2 = getenv("SDEH_BWD_V2") != nullptr;
+  // the scratch was checked against) unless the network has three hidden layers; plan option SDEH_BWD_V1 keeps the channel-split kernel (A/B)
+  const bool force_v1 = plan_opt(OPT_BWD_V1) != nullptr, force_v2 = plan_opt(OPT_BWD_V2) != nullptr;
   // (two coordinate tiles through time: the trajectory-split kernel still spills there and loses to the channel-split one -- 22 vs
   // 15 ms at d = 50, B = 65 536; its funnel Jacobian would couple the two tiles)
   const bool v2 = tile == 32 && !force_v1 && bwdf2_fits(d, net.n_hidden) &&
@@ -1182,6 +1233,7 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, cons
                        const float* ts_out, int32_t n_out, float eps, const float* x_init, int64_t batch,
                        const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, float* xs_out,
                        void* stream) {
+  OptScope opt_scope(plan);
   if (plan == nullptr || pr == nullptr || timesteps == nullptr || ts_out == nullptr || x_init == nullptr || xs_out == nullptr)
     return fail(SDEH_ERR_INVALID, "integrate: null argument");
   if (kind != SDEH_INT_LANGEVIN && kind != SDEH_INT_CONTROLLED) return fail(SDEH_ERR_INVALID, "integrate: kind %d", kind);

@@ -907,7 +907,7 @@ int launch_bridge(const TrajArgs& a, hipStream_t stream) {
   }
   // 32 trajectories per wave (HALF) while that still leaves a SIMD per wave: the step is a chain of dependent network passes, so
   // small batches are latency-bound and halving the MFMA chain is worth more than filling the lanes
-  const char* tiles = getenv("SDEH_BRIDGE_TILES");  // testing aid, read per call: "64" = 64-row tiles, "32g" = 32-row, generic tangents
+  const char* tiles = plan_opt(OPT_BRIDGE_TILES);  // testing aid, a plan option: "64" = 64-row tiles, "32g" = 32-row, generic tangents
   // exact divergence with act' kept in registers (32-row tiles only): fewer MFMA passes per row than the 64-row tiles at
   // every batch size (d = 2: 6.6 vs 8.0 ms at B = 65 536; d = 10: 13.4 vs 33.3 ms)
   const bool cached = a.div_noise == nullptr && a.lay2.n_hidden < kTanCache;
@@ -915,8 +915,8 @@ int launch_bridge(const TrajArgs& a, hipStream_t stream) {
     TrajArgs b = a;
     b.half = tiles && tiles[0] == '3' && tiles[2] == 'g' ? 1 : 0;  // here: 1 = do not keep act' in registers
     // coordinate split (kernel header): while the 32-row tiles are fewer than the CUs.
-    // SDEH_BRIDGE_SPLIT=1 | 4 forces it (read per call: tests compare the two).
-    const char* split = getenv("SDEH_BRIDGE_SPLIT");
+    // SDEH_BRIDGE_SPLIT=1 | 4 forces it (a plan option: tests compare the two).
+    const char* split = plan_opt(OPT_BRIDGE_SPLIT);
     const size_t split_bytes = lds_bytes + (size_t)4 * a.d * 32 * sizeof(float);  // [2 steps][J_jj | u][d][32]
     b.csplit = 1;
     if (cached && !b.half && split_bytes <= 160 * 1024 &&

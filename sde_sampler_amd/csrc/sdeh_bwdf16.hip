@@ -666,7 +666,7 @@ static int launch_bwdf16_l(const BwdfArgs& a, hipStream_t stream) {
 // the 32-trajectory kernel fills the chip as well and needs fewer instructions per trajectory.  SDEH_BWD_TILE=16 | 32 forces either.
 int bwdf_tile(long long batch, bool bptt, int act) {
   if (!bptt || act == SDEH_ACT_RELU) return 32;
-  const char* force = getenv("SDEH_BWD_TILE");  // (read per call: tests switch it)
+  const char* force = plan_opt(OPT_BWD_TILE);  // (a plan option: tests switch it)
   if (force != nullptr && force[0] == '1') return 16;
   if (force != nullptr && force[0] == '3') return 32;
   return batch < 16384 ? 16 : 32;
@@ -682,7 +682,7 @@ int bwdf16_slots(long long batch) {
 // wave has a SIMD of its own), and still 0.89 against 0.99 ms at 8192, where two workgroups of four share a CU -- two waves per SIMD
 // (252-288 registers each) fill each other's LDS round trips.  SDEH_BWD_WAVES=2 keeps the two-wave teams reachable (tests).
 int bwdf16_waves(long long batch) {
-  const char* force = getenv("SDEH_BWD_WAVES");
+  const char* force = plan_opt(OPT_BWD_WAVES);
   if (force != nullptr && (force[0] == '2' || force[0] == '4')) return force[0] - '0';
   (void)batch;
   return 4;

@@ -877,7 +877,7 @@ static int launch_bwdf2_t(const BwdfArgs& a, hipStream_t stream) {
   if constexpr (OTD == 2) {
     return launch_bwdf2_q<2, BPTT, LH, 16, false>(a, stream);
   } else if constexpr (LH == 2) {  // the shipped depth: specialised by the number of live coordinates
-    static const bool no_vio = getenv("SDEH_BWD_NO_VIO") != nullptr;  // A/B aid (read once)
+    const bool no_vio = plan_opt(OPT_BWD_NO_VIO) != nullptr;  // A/B aid (plan option)
     if (a.d <= 4 && !no_vio) return launch_bwdf2_q<1, BPTT, LH, 4, true>(a, stream);
     if (a.d <= 8) return launch_bwdf2_q<1, BPTT, LH, 4, false>(a, stream);
     if (a.d <= 16) return launch_bwdf2_q<1, BPTT, LH, 8, false>(a, stream);

@@ -290,6 +290,18 @@ struct SinkArgs {
   float inv_eps;
 };
 
+// Kernel-mode options of the plan whose entry point is executing on this thread (include/sdeh.h: sdeh_plan_set_option).  The launchers
+// ask plan_opt(key) where they used to call getenv: nullptr = automatic, else the value string.  Nothing on the launch path reads the
+// environment (sdeh_plan_create copies it once).
+enum OptKey {
+  OPT_LEGACY, OPT_GENERIC_ONLY, OPT_WS_GROUPS, OPT_WS_QUAD, OPT_WS_VOUT, OPT_WS_BARRIER, OPT_BWD_PLANES, OPT_BWD_TILE, OPT_BWD_WAVES,
+  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_COUNT
+};
+struct PlanOptions {
+  char v[OPT_COUNT][8];
+};
+const char* plan_opt(OptKey key);
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device setting: the launchers remember it per device ordinal
 constexpr int kMaxDevices = 64;
 inline int current_device_slot() {

@@ -1259,7 +1259,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   //                 default batch sizes (train 512 / 2048, eval 6000) live here and are latency-bound: 14.5 -> 7.1 us per step
   //   B <=  8 192 : pair mode -- one group of 32 per workgroup served by a V wave and TWO M waves (one output-channel tile each),
   //                 three waves on three SIMDs of a CU: 7.1 -> ~5 us per step
-  const char* force = getenv("SDEH_WS_GROUPS");  // testing aid, read per call like the other switches: "2" | "4" | "2h" | "4h" | "p" (pair)
+  const char* force = plan_opt(OPT_WS_GROUPS);  // testing aid, a plan option like the other switches: "2" | "4" | "2h" | "4h" | "p" (pair)
   int groups = a.batch <= 2 * 32 * 256 ? 2 : kWsGroups;
   int half = a.batch <= 4 * 32 * 256 ? 1 : 0;
   if (pair_fits && a.batch <= 32 * 256) { groups = 1; half = 2; }
@@ -1269,7 +1269,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   //                 stores, activations without a kink (ReLU: the fused backward re-evaluates the pair mode's pre-activations bitwise)
   const bool quad_fits = C == 64 && DP <= 32 && a.lay.n_hidden >= 1 && planes != 1 && (ACT >= 0 ? ACT : a.act) != SDEH_ACT_RELU &&
                          ws_quad_lds_bytes<DP>(a.lay) <= 160 * 1024;
-  const char* quad_env = getenv("SDEH_WS_QUAD");  // "0": never, "1": whenever it fits (tests); read per call
+  const char* quad_env = plan_opt(OPT_WS_QUAD);  // "0": never, "1": whenever it fits (tests); a plan option
   // Measured (tools/quad_threshold_timing.py, us per step quad / otherwise): B = 8192: 2.9 / 4.1 (d = 1), 2.8 / 4.1 (d = 10), 5.4 / 5.9 (d = 2,
   // 40-component mixture); B = 16 384 (two workgroups per CU): 5.5 / 7.0 for the closed-form targets, 10.5 / 7.3 for the mixture (its V
   // waves then compete for the SIMDs); B = 24 576: 8.0 / 7.0.
@@ -1285,13 +1285,13 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   // d <= 4, groups of 64 / 32 trajectories: the out layer on the V wave's vector pipe when the activation planes fit (SDEH_WS_VOUT=0: never)
   b.vout = 0;
   if (DP <= 4 && C == 64 && half <= 1 && ws_vout_lds_bytes<DP>(a.lay) <= 160 * 1024) {
-    const char* vo = getenv("SDEH_WS_VOUT");  // A/B aid, read per call
+    const char* vo = plan_opt(OPT_WS_VOUT);  // A/B aid, a plan option
     if (vo == nullptr || vo[0] != '0') {
       b.vout = 1;
       if (ws_vout_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_vout_lds_bytes<DP>(a.lay);
     }
   }
-  b.flag_sync = getenv("SDEH_WS_BARRIER") == nullptr ? 1 : 0;  // A/B aid (read per call): the workgroup-barrier hand-off
+  b.flag_sync = plan_opt(OPT_WS_BARRIER) == nullptr ? 1 : 0;  // A/B aid (a plan option): the workgroup-barrier hand-off
   const int rows = (half ? 32 : 64) * groups;
   const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);
   if (planes == 1)

@@ -390,7 +390,7 @@ static int launch_wide_t(const TrajArgs& a, hipStream_t stream) {
 // Column tiles per workgroup: 64 trajectories (CT = 2) halve the weight traffic per trajectory and the barriers per MFMA, but
 // a launch needs >= 256 workgroups to use every CU: below 16 384 trajectories the 32-trajectory form fills more CUs.
 int launch_wide(const TrajArgs& a, hipStream_t stream, int* ct_used) {
-  const char* force = getenv("SDEH_WIDE_CT");  // testing aid: "1" | "2" (read per call)
+  const char* force = plan_opt(OPT_WIDE_CT);  // testing aid: "1" | "2" (a plan option)
   // (128 trajectories per workgroup -- CT = 4, one plane -- would quarter the operand loads per MFMA, but the state and the network
   // output of 128 trajectories do not fit the wave's registers next to the elementwise phase: it spills and measures 36.7 ms against
   // 29.6 ms for CT = 2 at B = 32 768; those instantiations -- 770-1154 spilled registers -- were removed in round 3)
@@ -1018,7 +1018,7 @@ static int launch_bridge_wide_t(const TrajArgs& a, hipStream_t stream, int split
 
 // split: workgroups per column tile of 32 trajectories (1, 2, 4, 8): enough of them to occupy the 256 CUs
 int launch_bridge_wide(const TrajArgs& a, hipStream_t stream, int* split_used, float* scratch) {
-  const char* force = getenv("SDEH_WIDE_SPLIT");  // testing aid: "1" | "2" | "4" | "8"
+  const char* force = plan_opt(OPT_WIDE_SPLIT);  // testing aid: "1" | "2" | "4" | "8"
   const long long tiles = (a.batch + 31) / 32;
   int split = 1;
   while (split < 8 && tiles * split < 256) split *= 2;

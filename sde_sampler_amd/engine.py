@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Callable
 
 import torch
@@ -235,6 +236,27 @@ class _Plan:
     def __init__(self, lib, desc: L.SdehPlanDesc):
         self.lib, self.handle = lib, C.c_void_p()
         L.check(lib.sdeh_plan_create(C.byref(desc), C.byref(self.handle)))
+        self.reserved = int(desc.max_batch)
+        self.options = {name: os.environ.get(name) for name in L.PLAN_OPTIONS}  # what sdeh_plan_create read
+
+    def sync_options(self, overrides: dict | None = None) -> None:
+        """Kernel-mode options: `overrides` (engine.options) over the environment (the tests' switch), pushed to the plan when they
+        differ from what it holds.  The library reads no environment variable on the launch path."""
+        env = os.environ
+        for name in L.PLAN_OPTIONS:
+            want = overrides.get(name) if overrides and name in overrides else env.get(name)
+            if want != self.options[name]:
+                L.check(self.lib.sdeh_plan_set_option(self.handle, name.encode(), None if want is None else str(want).encode()))
+                self.options[name] = want
+
+    def reserve(self, batch: int) -> None:
+        """Batch-dependent plan scratch (wide Bridge): grown HERE, outside the stream-ordered calls (it synchronises the device)."""
+        if batch > self.reserved:
+            if torch.cuda.is_current_stream_capturing():
+                raise L.SdehError(-4, f"the plan's scratch covers {self.reserved} trajectories and cannot grow to {batch} while the "
+                                      "stream is capturing: launch once at this batch first")
+            L.check(self.lib.sdeh_plan_reserve(self.handle, int(batch)))
+            self.reserved = int(batch)
 
     def __del__(self):
         try:
@@ -256,6 +278,9 @@ class TrajectoryEngine:
         #: give further loss objects of one process their own id.
         self.stream_id = 0
         self.timing = False  # record HIP events around the trajectory kernel (bench.py)
+        #: kernel-mode options of this engine's plans ({name in _lib.PLAN_OPTIONS: value or None}); take precedence over the
+        #: environment variables of the same names
+        self.options: dict = {}
         self._last_plan = None
 
     # ------------------------------------------------------------------------------------------------------
@@ -270,8 +295,12 @@ class TrajectoryEngine:
                                   max_components=cap[2], device=device.index)
             plan = _Plan(L.load(), desc)
             plan.cap = cap
+            plan.timing = False
             self._plans[key] = plan
-        L.check(plan.lib.sdeh_plan_set_timing(plan.handle, 1 if self.timing else 0))
+        if plan.timing != self.timing:
+            L.check(plan.lib.sdeh_plan_set_timing(plan.handle, 1 if self.timing else 0))
+            plan.timing = self.timing
+        plan.sync_options(self.options)
         self._last_plan = plan
         return plan
 
@@ -521,6 +550,8 @@ class TrajectoryEngine:
         if pr.flags & L.FLAG_INFERENCE_CTRL:
             n_hidden = max(n_hidden, pr.inference.base_model.n_hidden)
         plan = self._plan(device, dim, pr.base_model.channels, n_hidden, n_steps, k)
+        if (pr.flags & L.FLAG_INFERENCE_CTRL) and (pr.base_model.channels != 64 or dim > 64):
+            plan.reserve(batch)  # the wide Bridge's divergence scratch (no stream-ordered call of the library allocates)
         if seed is None:
             seed = torch.initial_seed()
         offset = self.offset()
@@ -559,7 +590,8 @@ class TrajectoryEngine:
                                                       seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(), rnd.data_ptr(),
                                                       xs.data_ptr(), None, None, stream))
                 return x_T, rnd, xs, None
-            if lib.sdeh_ctrl_backward_fused_supported(plan.handle, C.byref(pr)):
+            # (the fused backward addresses its [d][B] planes with 32-bit byte offsets: beyond 2^24 trajectories the plane path)
+            if 64 * batch * 4 < 2 ** 32 and lib.sdeh_ctrl_backward_fused_supported(plan.handle, C.byref(pr)):
                 # fused backward (csrc/sdeh_bwdf.hip): the combined score per step and the terminal target score, no [C, T*B] planes
                 # (coordinate-major planes: [.., d, B])
                 xs_cm = torch.empty((n_steps + 1, dim, batch), device=device, dtype=torch.float32)

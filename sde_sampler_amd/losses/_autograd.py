@@ -399,6 +399,9 @@ def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout
     N = T * B
     base = inf.base_model
     Cn, Lh = base.channels, len(base.hidden_layer)
+    if Lh not in (1, 2):  # (the C side refuses as well; say it before anything is allocated)
+        raise L.SdehUnsupported(-2, f"wide-network Bridge: the divergence backward is built for inference networks with one or two "
+                                    f"hidden layers (num_layers 3 or 4), got {Lh}")
     lib = L.load()
     n_scratch, n_out = C.c_int64(), C.c_int64()
     L.check(lib.sdeh_bridge_div_backward_wide_sizes(d, Cn, Lh, T, B, C.byref(n_scratch), C.byref(n_out)))

@@ -15,9 +15,10 @@ ReferenceSDELoss 281-391, ExponentialIntegratorSDELoss 394-505), selected by poi
 Training: `loss(...)` back-propagates through the fused kernels for every method (losses/_autograd.py +
 `sdeh_ctrl_backward`): row-parallel for "lv" / "lv_traj" (detached SDE control), back-propagation through time with the
 adjoint kept in registers for "kl" / "kl_ito"; the Bridge (`inference_ctrl`, exact or Hutchinson divergence) trains through
-`sdeh_ctrl_backward_ex` + `sdeh_bridge_div_backward`.  Not built in (raises `SdehUnsupported`, never falls back):
-`sde_ctrl_noise` / `sde_ctrl_dropout` (dead code in the reference) and training of the wide-network
-(channels > 64) kernels, which are evaluation-only.
+`sdeh_ctrl_backward_ex` + `sdeh_bridge_div_backward`; wide networks (channels 128 / 256, or 64 with d > 64) train through the
+kernels of `csrc/sdeh_wide_bwd.hip` (every method, closed-form and mixture targets, the Bridge with the exact divergence).  Not
+built in (raises `SdehUnsupported`, never falls back): `sde_ctrl_noise` / `sde_ctrl_dropout` (dead code in the reference,
+DESIGN.md section 7) and the Hutchinson divergence estimators on wide networks.
 """
 from __future__ import annotations
 

@@ -135,7 +135,7 @@ def _widen_train(spec, rng):
 def test_random_wide_training_gradients_match_oracle(case):
     """Seeded random training problems (loss x method x control x SDE x target x clip activity x depth x ragged batch) on WIDE networks:
     loss value and every parameter gradient against the oracle's autograd on identical noise, with the conditioning-aware criteria of
-    tests/test_hip_fuzz.py (mixture targets are a documented limit of the wide backward and are skipped)."""
+    tests/test_hip_fuzz.py (mixture targets included: their score planes come from the forward launch, sdeh_simulate_fwd_train2)."""
     from tests.test_hip_fuzz import check_training_case
 
     # (ReLU networks: twice the kink allowance of the 64-channel sweep -- 128 / 256 units per layer and d up to 250 inputs put more

@@ -521,6 +521,21 @@ def run(args, rank: int, world: int, local_rank: int):
     def step():
         return prob.eval(x0, compute_weights=False, return_traj=False)
 
+    # One step = one `loss.eval` (coefficient tables + trajectory kernel + estimator reduction + the 8-float copy its Results need).
+    # Without a process group the call is replayed as one hipGraph: the eager call's ~0.1 ms of host work between two launches
+    # (describing the problem, four ctypes launches, allocations) is no part of the path being measured.  With a
+    # group the estimator merge crosses the ranks through the host (one all-gather): eager.
+    graphed = not use_dist and not args.eager
+    if graphed:
+        from sde_sampler_amd.utils.graphs import GraphedEval
+
+        for _ in range(3):
+            step()
+        replay = GraphedEval(lambda x: prob.eval(x, compute_weights=False, return_traj=False), [prob.loss], x0)
+
+        def step():  # noqa: F811
+            return replay()
+
     def fence():
         if use_dist:
             dist.barrier()
@@ -581,7 +596,8 @@ def run(args, rank: int, world: int, local_rank: int):
         "config": {"workload": f"{args.workload}: {description}",
                    "batch_per_gpu": B, "global_batch": world * B, "em_steps": T, "dim": d,
                    "channels": spec["net"]["channels"],
-                   "noise": "in-kernel Philox4x32-10 + Box-Muller", "parallelism": f"batch-sharded x{world}"},
+                   "noise": "in-kernel Philox4x32-10 + Box-Muller", "parallelism": f"batch-sharded x{world}",
+                   "step": "loss.eval replayed as one hipGraph (utils.graphs.GraphedEval)" if graphed else "eager loss.eval"},
         "roofline": roofline,
         "log_z_untrained_control": {"log_norm_const_is": full.log_norm_const_preds["log_norm_const_is"],
                                     "log_norm_const_lb_ito": full.log_norm_const_preds["log_norm_const_lb_ito"],
@@ -626,6 +642,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the workload's)")
     ap.add_argument("--em-steps", type=int, default=None, help="Euler-Maruyama steps T (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true",
+                    help="one eager loss.eval per step (default at N = 1 without a process group: the same call replayed as one hipGraph, "
+                         "sde_sampler_amd.utils.graphs.GraphedEval -- identical kernels and results, no per-call Python in between)")
     ap.add_argument("--no-extra", action="store_true", help="skip the log_z / extra blocks of the headline line")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")

@@ -230,16 +230,29 @@ class BaseOCLoss:
         """log Z estimators from the per-trajectory `rnd` via one device reduction (+ one 8-float all-gather when
         running data-parallel).  The values are those of the reference formulas (neg_rnd.mean(), log mean exp,
         rnd.var()) over the GLOBAL batch; `samples` / `weights` stay rank-local shards."""
-        stats = E.all_gather_stats(E.estimator_stats(rnd), group=group)
+        local = E.estimator_stats(rnd)
+        if E._deferred is not None:
+            # utils.graphs.GraphedEval is capturing: leave the device half (reduction, importance weights against the LOCAL maximum --
+            # there is no process group in a captured evaluation) in the graph and the host half (`finish_results`) to the replay
+            weights = E.importance_weights(rnd, local[3:4]) if compute_weights else None
+            E._deferred.update(stats=local, weights=weights, compute_weights=compute_weights, ts=ts, samples=samples, xs=xs)
+            return None
+        stats = E.all_gather_stats(local, group=group)
+        weights = None
+        if compute_weights:
+            m = torch.as_tensor(float(stats[3]), dtype=torch.float32, device=rnd.device)
+            weights = E.importance_weights(rnd, m)
+        return BaseOCLoss.finish_results(stats, weights, compute_weights, ts, samples, xs)
+
+    @staticmethod
+    def finish_results(stats: torch.Tensor, weights, compute_weights: bool, ts, samples, xs) -> Results:
+        """The host half of compute_results: estimators from the merged statistics."""
         est = E.estimators_from_stats(stats)
         metrics = {}
         if compute_weights:
-            m = torch.as_tensor(est["log_weight_max"], dtype=torch.float32, device=rnd.device)
-            weights = E.importance_weights(rnd, m)
             preds = {"log_norm_const_lb_ito": est["mean_neg_rnd"], "log_norm_const_is": est["log_norm_const_is"]}
             metrics["eval/lv_loss"] = est["var_rnd"]
         else:
-            weights = None
             preds = {"log_norm_const_lb": est["mean_neg_rnd"]}
         return Results(samples=samples, weights=weights, log_norm_const_preds=preds, ts=ts, xs=xs, metrics=metrics)
 

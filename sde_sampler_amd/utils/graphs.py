@@ -35,7 +35,7 @@ from typing import Callable, Iterable
 
 import torch
 
-__all__ = ["GraphedTrainStep"]
+__all__ = ["GraphedTrainStep", "GraphedEval"]
 
 #: first value of the device counter: far above anything `engine.calls` reaches, so that replays and eager launches of the
 #: same seed never share a Philox offset
@@ -156,3 +156,71 @@ class GraphedTrainStep:
         self.graph.replay()
         self.replays += 1
         return self.loss
+
+
+class GraphedEval:
+    """One evaluation (`loss.eval(ts, x, ...)`: coefficient tables, trajectory kernel, estimator reduction, importance weights) as ONE
+    graph launch plus the 8-float device->host copy its `Results` need.
+
+    At the reference's evaluation sizes the host side of an eager `loss.eval` -- describing the problem, four ctypes launches, the
+    output allocations -- costs as much as the kernels (B = 1024, T = 100: 0.28 ms of kernels, ~0.1 ms of host work before the
+    first launch); replayed, the call is a copy of `x` into the captured input, one launch and the synchronising copy that the
+    reference's `.item()`s are as well.
+
+    eval_fn   (x) -> Results: calls `loss.eval(ts, x, ...)` of ONE of `losses` (e.g. `problems.Problem.eval`); must not synchronise
+              otherwise and must not run data-parallel (no process group: the estimator merge across ranks goes through the host)
+    losses    the loss objects involved (they get the device-resident Philox counter, as under GraphedTrainStep; pass `counter=` to
+              share one with a captured training step)
+    x         example input [B, d]; calls take inputs of this shape
+
+    The tensors inside the returned `Results` (samples, weights, xs) are the graph's static outputs: the next call overwrites them."""
+
+    def __init__(self, eval_fn: Callable, losses: Iterable, x: torch.Tensor, *, warmup: int = 2, counter: torch.Tensor | None = None):
+        import torch.distributed as dist
+
+        from sde_sampler_amd import engine as E
+
+        if not x.is_cuda:
+            raise RuntimeError("GraphedEval needs a GPU (hipGraph capture)")
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("GraphedEval: data-parallel evaluations merge their estimators through the host; evaluate eagerly")
+        self.device = x.device
+        self.losses = list(losses)
+        self._eval_fn = eval_fn
+        self.x = x.detach().clone()
+        self.counter = counter if counter is not None else next(
+            (lo.rng_counter for lo in self.losses if lo.rng_counter is not None), None)
+        if self.counter is None:
+            self.counter = torch.full((1,), COUNTER_START, dtype=torch.int64, device=self.device)
+        for lo in self.losses:
+            lo.rng_counter = self.counter
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(max(int(warmup), 1)):
+                eval_fn(self.x)
+                self.counter.add_(1)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self.graph = torch.cuda.CUDAGraph()
+        self._parts: dict = {}
+        E._deferred = self._parts
+        try:
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                if eval_fn(self.x) is not None:
+                    raise RuntimeError("GraphedEval: eval_fn did not go through BaseOCLoss.compute_results")
+                self.counter.add_(1)
+        finally:
+            E._deferred = None
+        self.replays = 0
+
+    def __call__(self, x: torch.Tensor | None = None):
+        from sde_sampler_amd import engine as E
+        from sde_sampler_amd.losses.oc import BaseOCLoss
+
+        if x is not None and x is not self.x:
+            self.x.copy_(x)
+        self.graph.replay()
+        self.replays += 1
+        p = self._parts
+        return BaseOCLoss.finish_results(E.merge_stats(p["stats"]), p["weights"], p["compute_weights"], p["ts"], p["samples"], p["xs"])

@@ -322,3 +322,43 @@ def test_random_problem_replayed_gradients_equal_eager(case):
             scale = float(g.abs().max()) + 1e-12
             err = float((p.grad - g).abs().max())
             assert err <= 1e-5 * scale, (rep, method, spec["loss"]["kind"], spec["ctrl"]["kind"], spec["target"]["kind"], name, err, scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,weights", [("gmm50_pis_headline", False), ("cfg2_gmm2_dis_kl", True), ("cfg4_funnel_dds_lv", True)])
+def test_graphed_eval_equals_eager_eval(name, weights):
+    """utils.graphs.GraphedEval: the replayed evaluation (one launch + the 8-float copy) returns bit for bit what the eager
+    `loss.eval` returns at the same Philox offset -- samples, importance weights and every estimator -- draws fresh noise per replay,
+    and takes new inputs through its static buffer."""
+    from sde_sampler_amd.utils.graphs import GraphedEval
+
+    spec = problems.baseline_spec(name)
+    spec["batch"] = 4096
+    prob = problems.build(spec, device="cuda:0")
+    torch.manual_seed(5)
+    x0 = prob.prior.sample((4096,))
+    eng = prob.loss.engine
+    calls0 = eng.calls
+    ge = GraphedEval(lambda x: prob.eval(x, compute_weights=weights, return_traj=False), [prob.loss], x0, warmup=1)
+    assert eng.calls == calls0 + 2  # one warm-up launch + the captured one
+    c = int(ge.counter)
+    res = ge(x0)
+    samples, w = res.samples.clone(), None if res.weights is None else res.weights.clone()
+    assert int(ge.counter) == c + 1
+    res2 = ge()  # fresh noise
+    assert not torch.equal(res2.samples, samples)
+    # the eager launch at the captured offset (calls0 + 1) and the counter value of the first replay
+    eng.calls = calls0 + 1
+    ge.counter.fill_(c)
+    ref = prob.eval(x0, compute_weights=weights, return_traj=False)
+    assert torch.equal(ref.samples, samples)
+    assert ref.log_norm_const_preds == res.log_norm_const_preds and ref.metrics == res.metrics
+    if weights:
+        assert torch.equal(ref.weights, w)
+    x1 = prob.prior.sample((4096,))
+    ge.counter.fill_(c)
+    res3 = ge(x1)
+    eng.calls = calls0 + 1
+    ge.counter.fill_(c)
+    ref3 = prob.eval(x1, compute_weights=weights, return_traj=False)
+    assert torch.equal(ref3.samples, res3.samples) and ref3.log_norm_const_preds == res3.log_norm_const_preds

@@ -294,3 +294,39 @@ def test_committed_pmc_record_belongs_to_the_headline_kernel_in_this_tree():
     rec = bench.pmc_record()
     assert rec is not None, "profiles/pmc_headline.json is stale: kernel_sha != bench.headline_kernel_sha()"
     assert rec["kernel_sha"] == bench.headline_kernel_sha() and rec["FETCH_SIZE_KiB"] > 0 and rec["SQ_INSTS_MFMA"] > 0
+
+
+def test_problem_description_cache_follows_the_objects():
+    """engine.build_problem caches the filled SdehProblem per (objects, flags) and revalidates it with a fingerprint of what it
+    read: a replaced parameter tensor (EMA swap), a mutated clip value (MultiStepParams) and a rewritten coefficient tensor must all
+    show up in the next description; in-place parameter updates keep the pointers (the kernels read the current values)."""
+    from sde_sampler_amd import engine as E
+    from sde_sampler_amd import problems
+
+    prob = problems.build(problems.baseline_spec("gmm50_pis_headline"))
+    eng = prob.loss.engine
+    n_described = []
+    describe = eng._describe
+    eng._describe = lambda **kw: (n_described.append(1), describe(**kw))[1]
+    kw = dict(loss_kind=prob.loss._LOSS_KIND, generative_ctrl=prob.ctrl, sde=prob.sde, flags=0, device=torch.device("cpu"),
+              terminal_target=prob.target, reference_prior=prob.loss._reference_prior() if hasattr(prob.loss, "_reference_prior") else None)
+    a = eng.build_problem(keep=E._Keep(), **kw)
+    keep = E._Keep()
+    b = eng.build_problem(keep=keep, **kw)
+    assert len(n_described) == 1 and bytes(a) == bytes(b) and a is not b and len(keep) > 10  # a hit: a copy, the tensors kept alive
+    b.clip_model = 123.0  # the copy is the caller's
+    assert eng.build_problem(keep=E._Keep(), **kw).clip_model == a.clip_model
+    w = prob.ctrl.base_model.out_layer.weight
+    with torch.no_grad():
+        w.mul_(1.5)  # an optimizer step: same storage
+    assert eng.build_problem(keep=E._Keep(), **kw).base_model.out_w == a.base_model.out_w and len(n_described) == 1
+    w.data = w.data.clone()  # an EMA swap: new storage
+    c = eng.build_problem(keep=E._Keep(), **kw)
+    assert len(n_described) == 2 and c.base_model.out_w == w.data_ptr() != a.base_model.out_w
+    prob.ctrl.clip_model = 7.5  # MultiStepParams mutates the clip values
+    assert eng.build_problem(keep=E._Keep(), **kw).clip_model == 7.5 and len(n_described) == 3
+    assert eng.build_problem(keep=E._Keep(), **dict(kw, flags=4)).flags & 4 and len(n_described) == 4  # other flags: another entry
+    with torch.no_grad():
+        prob.target.loc[0, 0] += 1.0  # values of a table the description depends on (mixture structure): version bump
+    eng.build_problem(keep=E._Keep(), **kw)
+    assert len(n_described) == 5

@@ -57,6 +57,26 @@ def main():
               + (f", trajectory kernel {sum(k_ms) / n:.4f} ms" if timing else ""))
         for label, v in acc.items():
             print(f"    {label:60s} {v / n * 1e6:8.1f} us per call")
+    # the same call replayed as one graph (utils.graphs.GraphedEval)
+    from sde_sampler_amd.utils.graphs import GraphedEval
+
+    eng.timing = False
+    ge = GraphedEval(lambda x: prob.eval(x, compute_weights=False, return_traj=False), [prob.loss], x0)
+    for _ in range(20):
+        ge()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        ge()
+    torch.cuda.synchronize()
+    print(f"{name} B={spec['batch']} replayed as one hipGraph (GraphedEval): {(time.perf_counter() - t0) / 300 * 1e3:.4f} ms per call")
+    eng.timing = True
+    try:
+        ge2 = GraphedEval(lambda x: prob.eval(x, compute_weights=False, return_traj=False), [prob.loss], x0)
+        ge2(); ge2()
+        print(f"    kernel events inside the graph: last_kernel_ms = {eng.last_kernel_ms():.4f}")
+    except Exception as exc:  # noqa: BLE001
+        print(f"    kernel events inside the graph: {type(exc).__name__}: {str(exc)[:200]}")
 
 
 if __name__ == "__main__":

@@ -370,7 +370,7 @@ def log_z_block(spec, device, B: int, rank: int, world: int) -> dict | None:
            "abs_log_z_error": abs(est["log_norm_const_is"] - 0.0),
            "modes_covered": int((share >= 0.5 / share.numel()).sum()), "n_modes": int(share.numel()),
            "note": "PIS on this target collapses onto few of the 40 modes (log Z_is -> log(covered / 40) = -3.69 for one): the oracle "
-                   "trained on the same schedule on the CPU takes the same course (profiles/r04_train_reference_cpu.txt)"}
+                   "trained on the same schedule on the CPU takes the same course (profiles/r04_train_reference_cpu.txt, tests/perf/train_reference_cpu.py)"}
     # parity mode on a sub-batch (identical x0 and noise): the GPU half here, the CPU half inside the cpu_baseline leg
     Bs, T, d = 4096, prob.ts.numel() - 1, spec["target"]["dim"]
     torch.manual_seed(11)

@@ -83,6 +83,20 @@ def _all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
     return t.cpu()
 
 
+def _all_reduce_on_device(t: torch.Tensor, group=None) -> torch.Tensor:
+    """SUM all-reduce of a few doubles that STAY on their device: no `.item()`, no host copy for the nccl (= RCCL) backend -- an
+    ordinary stream-ordered operation, capturable into a hipGraph.  (gloo reduces host tensors: CUDA inputs take a detour there.)"""
+    import torch.distributed as dist
+
+    t = t.detach().to(torch.float64).clone()
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        return host.to(t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 class _MaskedMoment(torch.autograd.Function):
     """mean (kl) or unbiased variance (lv) of the kept rows of rnd [B, 1] from the statistics vector of
     engine.estimator_stats (n, sum(-rnd), M2, ...); the gradient is elementwise: 1/n, or 2 (rnd_i - mean) / (n - 1), zero on
@@ -101,6 +115,29 @@ class _MaskedMoment(torch.autograd.Function):
         rnd, mask, n, mean = ctx.saved_tensors
         per_row = 2.0 * (rnd - mean) / (n - 1.0) if ctx.lv else (1.0 / n).expand_as(rnd)
         return torch.where(mask, per_row * grad_out, torch.zeros_like(rnd)), None, None, None
+
+
+class _SharedMoment(torch.autograd.Function):
+    """This rank's additive share of the GLOBAL batch's mean (kl) or unbiased variance (lv) of the kept rows, from the local
+    statistics (n_l, mean_l, M2_l about the local mean) and the global (n, mean) that ONE device-side all-reduce delivered:
+        kl:  n_l mean_l / n            lv:  (M2_l + n_l (mean_l - mean)^2) / (n - 1)      (Chan: the local M2 moved to the global mean)
+    -- no second pass over the rows.  Gradient per kept row: 1 / n, or 2 (rnd_i - mean) / (n - 1): with the global mean taken as a
+    constant these are exact, the omitted term is proportional to sum_i (rnd_i - mean) = 0 over the global batch."""
+
+    @staticmethod
+    def forward(ctx, rnd, mask, n_l, mean_l, m2_l, n, mean, lv: bool):
+        # (the per-row gradient in the rows' own precision from the rounded global moments: at world size 1 the operations -- and the
+        # results, bit for bit -- of _MaskedMoment)
+        ctx.save_for_backward(rnd, mask, n.to(rnd.dtype), mean.to(rnd.dtype))
+        ctx.lv = lv
+        share = (m2_l + n_l * (mean_l - mean) ** 2) / (n - 1.0) if lv else n_l * mean_l / n
+        return share.to(rnd.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rnd, mask, n, mean = ctx.saved_tensors
+        per_row = (2.0 * (rnd - mean) / (n - 1.0) if ctx.lv else (1.0 / n).expand_as(rnd)).to(rnd.dtype)
+        return torch.where(mask, per_row * grad_out, torch.zeros_like(rnd)), None, None, None, None, None, None, None
 
 
 _GRAPH_COUNTER_START = 1 << 40  # = utils.graphs.COUNTER_START (first value of a captured step's device-resident Philox counter)
@@ -140,6 +177,9 @@ class BaseOCLoss:
         #: filtered-sample count kept on the device) so that a whole training step can be captured (utils/graphs.py)
         self.graph_safe = False
         self._n_filtered_dev: torch.Tensor | None = None
+        #: data-parallel runs: also report the loss of the GLOBAL batch as `train/loss_global` (an extra all-reduce and a host
+        #: synchronisation per step; the shares returned by `compute_loss` sum to it)
+        self.report_global_loss = False
 
     # -- filtering / loss value (reference 50-92) ------------------------------------------------------------
     def filter(self, rnd: torch.Tensor, samples: torch.Tensor | None = None) -> torch.Tensor:
@@ -161,8 +201,6 @@ class BaseOCLoss:
         assert mask.shape == rnd.shape
         world = _world_size(self.process_group)
         if self.graph_safe:
-            if world != 1:
-                raise L.SdehUnsupported(-2, "graph_safe losses are single-process (the data-parallel shares go through the host)")
             return self._compute_loss_on_device(rnd, mask)
         if self.method == "lv_traj":
             rnd = rnd.reshape(self.traj_per_sample, -1, 1)
@@ -187,41 +225,55 @@ class BaseOCLoss:
             n_glob, mean_glob = tot[0].item(), tot[1].item() / tot[0].item()
             self.n_filtered += int(tot[2].item())
             loss = ((kept - mean_glob) ** 2).sum() / (n_glob - 1) if self.method == "lv" else kept.sum() / n_glob
-        glob = _all_reduce_sum(loss.detach().double().reshape(1), self.process_group)
-        return loss, {"train/n_filtered_cumulative": self.n_filtered, "train/loss_global": glob.item()}
+        metrics = {"train/n_filtered_cumulative": self.n_filtered}
+        if self.report_global_loss:  # one more all-reduce + a host round trip: off the hot path unless asked for
+            metrics["train/loss_global"] = _all_reduce_sum(loss.detach().double().reshape(1), self.process_group).item()
+        return loss, metrics
 
     def _compute_loss_on_device(self, rnd: torch.Tensor, mask: torch.Tensor) -> tuple[torch.Tensor, dict]:
         """compute_loss without a host round trip: same estimators (losses/oc.py:72-92) as masked reductions.  Rows the filter
-        drops contribute exactly zero value and zero gradient, as `rnd[mask]` does."""
+        drops contribute exactly zero value and zero gradient, as `rnd[mask]` does.  Data-parallel (a process group exists, at any
+        world size): ONE device-side all-reduce of [n, sum rnd, n_filtered] (3 doubles; RCCL on the device tensor, capturable as a
+        graph node) gives the global count and mean, the rank's share of the global loss follows from its local statistics
+        (`_SharedMoment`) -- no second collective, no `.item()`."""
         zero = torch.zeros((), device=rnd.device, dtype=rnd.dtype)
-        if rnd.is_cuda and rnd.dtype == torch.float32 and self.method != "lv_traj":
-            # Sums through the library's own two-pass reduction (sdeh_reduce_estimators), elementwise ops otherwise: a captured
-            # step must not contain the framework's multi-block reductions (utils/graphs.py, tests/perf/rocm_graph_two_reductions.py)
-            stats = E.estimator_stats(torch.where(mask, rnd.detach(), torch.full_like(rnd, math.nan)), max_rnd=math.inf)  # +inf: keep finite rows
-            loss = _MaskedMoment.apply(rnd, mask, stats, self.method == "lv")
-            if self._n_filtered_dev is None:
-                self._n_filtered_dev = torch.zeros((), device=rnd.device, dtype=torch.int64)
-            self._n_filtered_dev += stats[6].to(torch.int64)
-            return loss, {"train/n_filtered_cumulative": self._n_filtered_dev}
-        if self.method == "lv_traj":
-            rnd = rnd.reshape(self.traj_per_sample, -1, 1)
-            mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)
-            kept = mask.sum()
-            filtered = self.traj_per_sample * (mask.numel() - kept)
-            clean = torch.where(mask.expand_as(rnd), rnd, zero)
-            loss = torch.where(mask, clean.var(dim=0), zero).sum() / kept
-        else:
-            kept = mask.sum()
-            filtered = mask.numel() - kept
-            mean = torch.where(mask, rnd, zero).sum() / kept
-            if self.method == "lv":
-                loss = (torch.where(mask, rnd - mean, zero) ** 2).sum() / (kept - 1)
-            else:
-                loss = mean
+        dp = _dist_on()
         if self._n_filtered_dev is None:
             self._n_filtered_dev = torch.zeros((), device=rnd.device, dtype=torch.int64)
+        if self.method != "lv_traj":
+            if rnd.is_cuda and rnd.dtype == torch.float32:
+                # Sums through the library's own two-pass reduction (sdeh_reduce_estimators), elementwise ops otherwise: a captured
+                # step must not contain the framework's multi-block reductions (utils/graphs.py, tests/perf/rocm_graph_two_reductions.py)
+                stats = E.estimator_stats(torch.where(mask, rnd.detach(), torch.full_like(rnd, math.nan)), max_rnd=math.inf)  # +inf: keep finite rows
+                if not dp:
+                    self._n_filtered_dev += stats[6].to(torch.int64)
+                    return _MaskedMoment.apply(rnd, mask, stats, self.method == "lv"), {"train/n_filtered_cumulative": self._n_filtered_dev}
+                n_l, s_l, m2_l, nf_l = stats[0].double(), -stats[1].double(), stats[2].double(), stats[6].double()
+            else:
+                kept = mask.sum()
+                n_l, nf_l = kept.double(), (mask.numel() - kept).double()
+                s_l = torch.where(mask, rnd.detach(), zero).double().sum()
+                m2_l = (torch.where(mask, rnd.detach().double() - s_l / n_l, zero.double()) ** 2).sum()
+                if not dp:
+                    mean = torch.where(mask, rnd, zero).sum() / kept
+                    loss = (torch.where(mask, rnd - mean, zero) ** 2).sum() / (kept - 1) if self.method == "lv" else mean
+                    self._n_filtered_dev += (mask.numel() - kept)
+                    return loss, {"train/n_filtered_cumulative": self._n_filtered_dev}
+            glob = _all_reduce_on_device(torch.stack([n_l, s_l, nf_l]), self.process_group)
+            self._n_filtered_dev += glob[2].to(torch.int64)
+            loss = _SharedMoment.apply(rnd, mask, n_l, s_l / n_l, m2_l, glob[0], glob[1] / glob[0], self.method == "lv")
+            return loss, {"train/n_filtered_cumulative": self._n_filtered_dev}
+        rnd = rnd.reshape(self.traj_per_sample, -1, 1)
+        mask = mask.reshape(self.traj_per_sample, -1, 1).all(dim=0)
+        kept = mask.sum()
+        filtered = self.traj_per_sample * (mask.numel() - kept)
+        clean = torch.where(mask.expand_as(rnd), rnd, zero)
+        total = torch.where(mask, clean.var(dim=0), zero).sum()
+        if dp:  # the samples of a trajectory group live on one rank: the shares are sums of per-sample variances over the global count
+            glob = _all_reduce_on_device(torch.stack([kept.double(), filtered.double()]), self.process_group)
+            kept, filtered = glob[0].to(rnd.dtype), glob[1].to(torch.int64)
         self._n_filtered_dev += filtered
-        return loss, {"train/n_filtered_cumulative": self._n_filtered_dev}
+        return total / kept, {"train/n_filtered_cumulative": self._n_filtered_dev}
 
     # -- evaluation statistics (reference 94-123) ---------------------------------------------------------------
     @staticmethod

@@ -2,7 +2,7 @@
 """The CPU side of tools/train_reference_schedule.py: the oracle (oracle/em_oracle.py, bit-exact against the reference on the golden
 fixtures) trains the same problem on the same schedule -- basic_pis / kl, Adam lr 1e-3, batch 512, T = 100 -- for as many steps as
 the budget allows and reports the same quantities, so that the HIP run's quality can be read against the reference's own course
-(the full 10 000 steps take ~3 h of CPU).    python tools/train_reference_cpu.py [--steps 600] [--threads 8]"""
+(the full 10 000 steps take ~3 h of CPU).    python tests/perf/train_reference_cpu.py [--steps 600] [--threads 8]"""
 import argparse
 import json
 import math
@@ -10,7 +10,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from oracle import em_oracle as eo

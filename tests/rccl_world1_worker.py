@@ -49,10 +49,53 @@ def run_all(tag: str) -> dict:
     return out
 
 
+def run_graphed(tag: str) -> dict:
+    """A whole optimisation step -- forward, fused backward, the gradient all-reduce, Adam -- captured into ONE hipGraph and replayed
+    (utils.graphs.GraphedTrainStep), with and without a process group; and the same step eagerly under
+    torch.cuda.set_sync_debug_mode("error"): a host synchronisation anywhere in a data-parallel step raises."""
+    from sde_sampler_amd.utils.graphs import GraphedTrainStep
+
+    out = {}
+    dev = torch.device("cuda", 0)
+    for name, method in (("cfg1_dw_dis_lv", "lv"), ("cfg2_gmm2_dis_kl", "kl")):
+        spec = problems.baseline_spec(name)
+        spec["batch"] = 2048
+        spec["loss"]["method"] = method
+        torch.manual_seed(1)
+        prob = problems.build(spec, device=dev)
+        params = list(prob.ctrl.parameters())
+        opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+        torch.manual_seed(5)
+
+        def loss_fn():
+            x = prob.prior.sample((2048,))
+            return prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
+
+        step = GraphedTrainStep(loss_fn, [prob.loss], opt, after_backward=lambda: all_reduce_gradients(params), warmup=2, guard=True)
+        losses = [float(step()) for _ in range(3)]
+        # an eager step of the same kind must not synchronise either
+        torch.cuda.synchronize()
+        torch.cuda.set_sync_debug_mode("error")
+        try:
+            opt.zero_grad(set_to_none=True)
+            val = loss_fn()
+            val.backward()
+            all_reduce_gradients(params)
+            opt.step()
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+        torch.cuda.synchronize()
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        out[f"{name}/graphed"] = {"losses_hex": [v.hex() for v in losses], "params_sum_hex": float(flat.double().sum()).hex(),
+                                  "params_abs_hex": float(flat.double().abs().sum()).hex(), "skipped": int(step.n_skipped)}
+    return out
+
+
 def main():
     assert torch.cuda.is_available()
     torch.cuda.set_device(0)
     ref = run_all("no group")
+    ref.update(run_graphed("no group"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
     os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
@@ -73,6 +116,10 @@ def main():
 
     dist.all_gather_into_tensor, dist.all_reduce = counted_ag, counted_ar
     got = run_all("nccl world 1")
+    n_eager = dict(calls)
+    got.update(run_graphed("nccl world 1"))
+    calls["graphed_all_reduce"] = calls["all_reduce"] - n_eager["all_reduce"]
+    calls["all_reduce"] = n_eager["all_reduce"]
     dist.barrier()
     torch.cuda.synchronize()
     dist.all_gather_into_tensor, dist.all_reduce = ag, ar

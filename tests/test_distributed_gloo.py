@@ -80,10 +80,26 @@ def _dp_worker(rank, world, port, q):
             f = torch.cat([f[: n // 2], f[: n // 2] * 1.1 + 0.05])
         rnd = (f @ theta).reshape(-1, 1) + 30.0 + (rank == 1) * (torch.arange(f.shape[0]).reshape(-1, 1) == 5) * 1e6  # one filtered row
         theta.grad = None
+        loss_obj.report_global_loss = True  # (an extra all-reduce: off by default)
         share, metrics = loss_obj.compute_loss(rnd)
         share.backward()
         all_reduce_gradients([theta])
         out[method] = (share.item(), metrics["train/loss_global"], theta.grad.tolist(), loss_obj.n_filtered)  # (plain lists: a tensor in the queue is an fd the parent must fetch while this process lives)
+        # the capture-safe form of the same loss (graph_safe: masked reductions, ONE device-side all-reduce, no .item()): same share,
+        # same gradient, the filtered count kept in a tensor
+        safe = BaseOCLoss(generative_ctrl=None, method=method, max_rnd=1e3, traj_per_sample=2 if method == "lv_traj" else 1)
+        safe.graph_safe = True
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(tuple(t.shape)), real(t, *a, **k))[1]
+        theta.grad = None
+        rnd2 = (f @ theta).reshape(-1, 1) + 30.0 + (rank == 1) * (torch.arange(f.shape[0]).reshape(-1, 1) == 5) * 1e6
+        share2, metrics2 = safe.compute_loss(rnd2)
+        share2.backward()
+        dist.all_reduce = real
+        assert len(calls) == 1 and "train/loss_global" not in metrics2, calls  # one collective on the loss path
+        all_reduce_gradients([theta])
+        out[method + "/graph_safe"] = (share2.item(), None, theta.grad.tolist(), int(metrics2["train/n_filtered_cumulative"]))
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -133,3 +149,10 @@ def test_two_rank_training_loss_is_the_global_batch_loss():
             assert results[r][method][1] == pytest.approx(ref.item(), rel=1e-5)
             assert torch.allclose(torch.tensor(results[r][method][2]), theta.grad, rtol=1e-4, atol=1e-6), method
             assert results[r][method][3] == (2 if method == "lv_traj" else 1)
+        # the capture-safe loss: the same shares (to fp32 rounding of another summation order), gradient and filtered count
+        safe = [results[r][method + "/graph_safe"] for r in range(world)]
+        assert sum(v[0] for v in safe) == pytest.approx(ref.item(), rel=1e-5)
+        for r in range(world):
+            assert safe[r][0] == pytest.approx(shares[r], rel=1e-4, abs=1e-6), (method, r)
+            assert torch.allclose(torch.tensor(safe[r][2]), theta.grad, rtol=1e-4, atol=1e-6), method
+            assert safe[r][3] == (2 if method == "lv_traj" else 1)

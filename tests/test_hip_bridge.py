@@ -136,3 +136,39 @@ def test_bridge_hutchinson_training_matches_reference(path, est):
     # without given probes the loss draws its own (device RNG) and still trains
     val2, _ = loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
     assert torch.isfinite(val2)
+
+
+@pytest.mark.parametrize("method,replay", [("lv", False), ("kl", False), ("lv", True)])
+@pytest.mark.parametrize("path", GOLDEN_BRIDGE[1:], ids=lambda p: Path(p).stem)
+def test_bridge_backward_in_batch_slices_equals_one_pass(path, method, replay, monkeypatch):
+    """The 64-channel Bridge backward slices the batch when its per-(row, coordinate) planes exceed the memory budget
+    (losses/_autograd.py::_BridgeFn.backward; conf/solver/bridge.yaml's shape needs 126 GB of them in one pass): the gradients of the
+    slices add up to the one-pass gradients, with the supplied noise and with the Philox draws replayed at the slices' global rows."""
+    fx, meta, prob = _build(path)
+    x0 = torch.from_numpy(fx["x0"]).to(DEV)
+    noise = None if replay else torch.from_numpy(fx["noise"]).to(DEV)
+    if replay:  # in-kernel noise: any batch -- five slices, the last one ragged
+        x0 = torch.cat([x0, 0.5 * x0, -x0])[:150].contiguous()
+    loss = prob.loss
+    loss.method, loss.max_rnd = method, (1e8 if method == "lv" else None)
+    params = list(prob.ctrl.parameters()) + list(loss.inference_ctrl.parameters())
+    out = []
+    for budget in (None, "1"):  # "1" byte: as many slices as the rounding to 32 trajectories allows
+        if budget is None:
+            monkeypatch.delenv("SDEH_BRIDGE_PLANE_BYTES", raising=False)
+        else:
+            monkeypatch.setenv("SDEH_BRIDGE_PLANE_BYTES", budget)
+        for p in params:
+            p.grad = None
+        loss.engine.calls = 7  # the same Philox offset for both passes
+        val, _ = loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
+        val.backward()
+        out.append((val.item(), [None if p.grad is None else p.grad.clone() for p in params]))
+    assert x0.shape[0] > 32, "the fixture must give more than one slice"
+    assert out[0][0] == out[1][0]
+    gmax = max(g.abs().max().item() for g in out[0][1] if g is not None)
+    for a, b in zip(out[0][1], out[1][1]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            err = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-3 * gmax)
+            assert err <= 2e-5, err  # another summation order over the trajectories, nothing else

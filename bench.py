@@ -532,20 +532,12 @@ def run(args, rank: int, world: int, local_rank: int):
     def step():
         return prob.eval(x0, compute_weights=False, return_traj=False)
 
-    # One step = one `loss.eval` (coefficient tables + trajectory kernel + estimator reduction + the 8-float copy its Results need).
-    # Without a process group the call is replayed as one hipGraph: the eager call's ~0.1 ms of host work between two launches
-    # (describing the problem, four ctypes launches, allocations) is no part of the path being measured.  With a
-    # group the estimator merge crosses the ranks through the host (one all-gather): eager.
-    graphed = not use_dist and not args.eager
-    if graphed:
-        from sde_sampler_amd.utils.graphs import GraphedEval
-
-        for _ in range(3):
-            step()
-        replay = GraphedEval(lambda x: prob.eval(x, compute_weights=False, return_traj=False), [prob.loss], x0)
-
-        def step():  # noqa: F811
-            return replay()
+    # One step = one eager `loss.eval` (coefficient tables + trajectory kernel + estimator reduction + the 8-float copy its Results
+    # need), the trajectory kernel bracketed by HIP events on its stream in every step of the timed region (the roofline's duration).
+    # --graphed replays the same call as one hipGraph (utils.graphs.GraphedEval: identical kernels and results, ~50 us less host work
+    # per step) -- events recorded by graph nodes read 0.3 ms too long on this stack, so that mode is reported in `graphed_step`
+    # next to the eager line (measured behind the timed region) and is not what `value` / `roofline` are taken from.
+    graphed = False
 
     def fence():
         if use_dist:
@@ -566,6 +558,27 @@ def run(args, rank: int, world: int, local_rank: int):
         t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
+
+    # the same step replayed as one hipGraph (N = 1 without a process group: the estimator merge across ranks goes through the host)
+    graphed_step = None
+    if not use_dist and not args.no_graphed:
+        from sde_sampler_amd.utils.graphs import GraphedEval
+
+        prob.loss.engine.timing = False
+        replay = GraphedEval(lambda x: prob.eval(x, compute_weights=False, return_traj=False), [prob.loss], x0)
+        n_rep = max(args.steps, 20)
+        for _ in range(10):
+            replay()
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(n_rep):
+            replay()
+        torch.cuda.synchronize()
+        tg = (time.perf_counter() - tg) / n_rep
+        graphed_step = {"ms_per_step": 1e3 * tg, "value": B * T / tg, "steps": n_rep,
+                        "what": "the bench step replayed as one hipGraph (sde_sampler_amd.utils.graphs.GraphedEval): one launch + the 8-float copy"}
+        prob.loss.rng_counter = None  # back to by-value Philox offsets for the evaluations below
+        prob.loss.engine.timing = True
 
     # quality: log Z from one weighted evaluation (in-kernel noise), global over all ranks
     full = prob.eval(x0, compute_weights=True, return_traj=False)
@@ -618,6 +631,8 @@ def run(args, rank: int, world: int, local_rank: int):
     }
     print("[bench] gpu leg done: " + json.dumps({k: out[k] for k in ("value", "ms_per_step", "roofline")}),
           file=sys.stderr, flush=True)
+    if graphed_step is not None:
+        out["graphed_step"] = graphed_step
     if world == 1 and headline and not args.no_extra:
         out["log_z"] = log_z_block(spec, device, B, rank, world)
         out["extra"] = extra_block(device, B)
@@ -653,9 +668,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="trajectories per GPU (default: the workload's)")
     ap.add_argument("--em-steps", type=int, default=None, help="Euler-Maruyama steps T (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true",
-                    help="one eager loss.eval per step (default at N = 1 without a process group: the same call replayed as one hipGraph, "
-                         "sde_sampler_amd.utils.graphs.GraphedEval -- identical kernels and results, no per-call Python in between)")
+    ap.add_argument("--eager", action="store_true", help="(the default; kept for scripts) one eager loss.eval per step")
+    ap.add_argument("--no-graphed", action="store_true", help="skip the `graphed_step` measurement (the step replayed as one hipGraph)")
     ap.add_argument("--no-extra", action="store_true", help="skip the log_z / extra blocks of the headline line")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")

@@ -1208,7 +1208,12 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   const bool force_v1 = plan_opt(OPT_BWD_V1) != nullptr, force_v2 = plan_opt(OPT_BWD_V2) != nullptr;
   // (two coordinate tiles through time: the trajectory-split kernel still spills there and loses to the channel-split one -- 22 vs
   // 15 ms at d = 50, B = 65 536; its funnel Jacobian would couple the two tiles)
-  const bool v2 = tile == 32 && !force_v1 && bwdf2_fits(d, net.n_hidden) &&
+  // Through time an item is a whole tile: the channel-split kernel gives every 32 trajectories two SIMDs and fills the chip with 512
+  // tiles in one round (1.5 ms at d = 2, T = 100), the trajectory-split one gives them one SIMD and needs 1024 (2.2 ms for up to 1024
+  // tiles against the channel-split kernel's two rounds = 3.1 ms): the latter from 513 tiles on.  Row-parallel launches always have
+  // items to spare.
+  const bool enough = !bptt || A.n_tiles > 512 || force_v2;
+  const bool v2 = tile == 32 && !force_v1 && enough && bwdf2_fits(d, net.n_hidden) &&
                   (d <= 32 || (!bptt) || (force_v2 && pr->target.kind != SDEH_DENS_FUNNEL));
   A.n_slots = tile == 16 ? bwdf16_slots(batch) : (v2 ? bwdf2_slots(batch, n_steps, bptt) : bwdf_slots(batch, n_steps, bptt));
   A.wsize = bwdf_wsize(d, net.n_hidden);

@@ -58,8 +58,7 @@ def test_bench_under_a_launcher_with_one_rank_uses_rccl():
     assert launched["config"]["process_group"] == {"backend": "nccl", "world_size": 1}
     plain = _run([sys.executable, str(ROOT / "bench.py"), "--eager", *common])
     assert "process_group" not in plain["config"] and plain["config"]["step"] == "eager loss.eval"
-    replayed = _run([sys.executable, str(ROOT / "bench.py"), *common])  # the default at N = 1: the step replayed as one hipGraph
-    assert "hipGraph" in replayed["config"]["step"] and replayed["value"] > 0
+    assert plain["graphed_step"]["value"] > 0.9 * plain["value"]  # the same step replayed as one hipGraph, measured behind the timed region
     assert launched["log_z_untrained_control"] == plain["log_z_untrained_control"]  # same seeds, same Philox counters: bitwise
     flagged = _run([sys.executable, str(ROOT / "bench.py"), "--dist", *common])
     assert flagged["config"]["process_group"]["backend"] == "nccl"

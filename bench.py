@@ -565,6 +565,7 @@ def run(args, rank: int, world: int, local_rank: int):
         from sde_sampler_amd.utils.graphs import GraphedEval
 
         prob.loss.engine.timing = False
+        calls_before = prob.loss.engine.calls  # (the evaluations below keep the Philox offsets of a run without this block)
         replay = GraphedEval(lambda x: prob.eval(x, compute_weights=False, return_traj=False), [prob.loss], x0)
         n_rep = max(args.steps, 20)
         for _ in range(10):
@@ -578,6 +579,7 @@ def run(args, rank: int, world: int, local_rank: int):
         graphed_step = {"ms_per_step": 1e3 * tg, "value": B * T / tg, "steps": n_rep,
                         "what": "the bench step replayed as one hipGraph (sde_sampler_amd.utils.graphs.GraphedEval): one launch + the 8-float copy"}
         prob.loss.rng_counter = None  # back to by-value Philox offsets for the evaluations below
+        prob.loss.engine.calls = calls_before
         prob.loss.engine.timing = True
 
     # quality: log Z from one weighted evaluation (in-kernel noise), global over all ranks

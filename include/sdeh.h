@@ -213,7 +213,8 @@ int32_t sdeh_plan_reserve(SdehPlan* plan, int64_t max_batch);
  *   SDEH_LEGACY (single-wave trajectory kernel)      SDEH_GENERIC_ONLY ("1" | "2": run-time switched variants only)
  *   SDEH_WS_GROUPS ("2" | "4" | "2h" | "4h" | "p")    SDEH_WS_QUAD ("0" | "1")      SDEH_WS_VOUT ("0")      SDEH_WS_BARRIER
  *   SDEH_BWD_PLANES (plane-writing backward)         SDEH_BWD_TILE ("16" | "32")   SDEH_BWD_WAVES ("2" | "4")
- *   SDEH_BWD_V1 / SDEH_BWD_V2 (channel- / trajectory-split fused backward)        SDEH_BWD_NO_VIO
+ *   SDEH_BWD_V1 / SDEH_BWD_V2 (channel- / trajectory-split fused backward)        SDEH_BWD_NO_VIO      SDEH_BWD_SCAN ("0" | "1": the
+ *   scan form of back-propagation through time, d <= 4)
  *   SDEH_BRIDGE_TILES ("64" | "32g")   SDEH_BRIDGE_SPLIT ("1" | "4")   SDEH_WIDE_CT ("1" | "2")   SDEH_WIDE_SPLIT ("1" | "2" | "4" | "8")
  * Unknown names: SDEH_ERR_INVALID. */
 int32_t sdeh_plan_set_option(SdehPlan* plan, const char* name, const char* value);

@@ -255,7 +255,7 @@ struct OptScope {
 };
 static const char* const kOptNames[OPT_COUNT] = {
     "SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES", "SDEH_BWD_TILE",
-    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT"};
+    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT"};
 static void opt_store(PlanOptions& o, int key, const char* value) {
   memset(o.v[key], 0, sizeof(o.v[key]));
   if (value != nullptr) strncpy(o.v[key], value, sizeof(o.v[key]) - 1);
@@ -1149,6 +1149,12 @@ int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_
     bwdf_sizes(dim, n_hidden, n_steps, batch, gamma_dim == 1 ? 1 : 64, true, 16, &w, &e, &g, &s, &o);
     if (w + e + g + s > *scratch_floats) *scratch_floats = w + e + g + s;
   }
+  // the scan form of back-propagation through time (d <= 4): a row-parallel launch's partial records + the planes nn, J, G
+  if (bptt != 0 && bwdf2_scan_fits(dim, n_hidden) && batch <= 65536) {
+    bwdf_sizes(dim, n_hidden, n_steps, batch, gamma_dim == 1 ? 1 : 64, false, 32, &w, &e, &g, &s, &o);
+    const long long planes = (long long)n_steps * batch * (dim * dim + 2 * dim);
+    if (w + e + g + s + planes > *scratch_floats) *scratch_floats = w + e + g + s + planes;
+  }
   return SDEH_OK;
 }
 
@@ -1177,10 +1183,19 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   long long n_w, n_e, n_g, n_s, n_o;
-  const int tile = bwdf_tile(batch, bptt, net.activation);  // 16: small batches through time (sdeh_bwdf16.hip)
-  bwdf_sizes(d, net.n_hidden, n_steps, batch, L.g == 1 ? 1 : 64, bptt, tile, &n_w, &n_e, &n_g, &n_s, &n_o);
-  if (scratch_floats < n_w + n_e + n_g + n_s) return fail(SDEH_ERR_CAPACITY, "ctrl_backward_fused: scratch too small (%lld < %lld floats)",
-                                                          (long long)scratch_floats, n_w + n_e + n_g + n_s);
+  int tile = bwdf_tile(batch, bptt, net.activation);  // 16: small batches through time (sdeh_bwdf16.hip)
+  // Through time with d <= 4 below the batch that fills the chip with whole-tile items: the SCAN form (sdeh_bwdf2.hip) -- two
+  // row-parallel network passes around a recursion on d numbers per trajectory instead of one dependent chain through the network per
+  // step.  Plan option SDEH_BWD_SCAN: "0" never, "1" at every batch.
+  const char* scan_opt = plan_opt(OPT_BWD_SCAN);
+  const bool scan = bptt && bwdf2_scan_fits(d, net.n_hidden) && plan_opt(OPT_BWD_V1) == nullptr && plan_opt(OPT_BWD_TILE) == nullptr &&
+                    (scan_opt != nullptr ? scan_opt[0] == '1' : batch <= 3072) && batch <= 65536;  // (measured, d = 2, T = 100: 0.20 / 0.41 / 0.65 ms at 512 / 2048 / 4096 against 0.59 / 0.59 / 0.60)
+  if (scan) tile = 32;
+  bwdf_sizes(d, net.n_hidden, n_steps, batch, L.g == 1 ? 1 : 64, bptt && !scan, tile, &n_w, &n_e, &n_g, &n_s, &n_o);
+  const long long n_planes = scan ? (long long)n_steps * batch * (d * d + 2 * d) : 0;
+  if (scratch_floats < n_w + n_e + n_g + n_s + n_planes)
+    return fail(SDEH_ERR_CAPACITY, "ctrl_backward_fused: scratch too small (%lld < %lld floats)", (long long)scratch_floats,
+                n_w + n_e + n_g + n_s + n_planes);
   hipStream_t st = (hipStream_t)stream;
   PrepArgs P;
   P.ws = plan->ws; P.lay = L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
@@ -1218,10 +1233,27 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   A.n_slots = tile == 16 ? bwdf16_slots(batch) : (v2 ? bwdf2_slots(batch, n_steps, bptt) : bwdf_slots(batch, n_steps, bptt));
   A.wsize = bwdf_wsize(d, net.n_hidden);
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
-  rc = tile == 16 ? launch_bwdf16(A, st) : (v2 ? launch_bwdf2(A, st) : launch_bwdf(A, st));
+  if (scan) {
+    // nn [T, d, B] | J [T, d, d, B] | G [T, d, B] behind the partial records
+    float* planes = sums + n_s;
+    A.nn_out = planes;
+    A.jac_out = planes + (long long)n_steps * batch * d;
+    A.gq_out = A.jac_out + (long long)n_steps * batch * d * d;
+    A.n_slots = bwdf2_slots(batch, n_steps, false);
+    rc = launch_bwdf2_jac(A, st);
+    if (rc == SDEH_OK) rc = launch_bwdf2_scan(A, st);
+    if (rc == SDEH_OK) {
+      BwdfArgs R = A;  // the row-parallel backward (the lv form) with the scan's upstream gradient
+      R.flags |= SDEH_FLAG_CHANGE_SDE_CTRL;
+      R.gq_in = A.gq_out;
+      rc = launch_bwdf2(R, st);
+    }
+  } else {
+    rc = tile == 16 ? launch_bwdf16(A, st) : (v2 ? launch_bwdf2(A, st) : launch_bwdf(A, st));
+  }
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
-  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused%s<%s,tiles=%d%s>", tile == 16 ? "16" : "", bptt ? "bptt" : "rows", d <= 32 ? 1 : 2,
-           tile == 16 ? "" : (v2 ? ",traj-split" : ",chan-split"));
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused%s<%s,tiles=%d%s>", tile == 16 ? "16" : "", scan ? "bptt-scan" : (bptt ? "bptt" : "rows"),
+           d <= 32 ? 1 : 2, tile == 16 ? "" : (v2 || scan ? ",traj-split" : ",chan-split"));
   if (rc != SDEH_OK) return fail(rc, "ctrl_backward_fused: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   // deterministic sums over the teams / tiles
   float* s1 = sums;

@@ -159,16 +159,48 @@ __device__ __forceinline__ void stage_cols(const float* __restrict__ wcol, const
   ws_barrier();
 }
 
+// the transposed layer alone (no weight-gradient product next to it):  o[R] = sum_s sum_e W[(8 s + 4 h + e) * LD + 32 R + i] * b[s >> 2][4 (s & 3) + e]
+template <int LD>
+__device__ __forceinline__ void chain_cols(const float* __restrict__ wcol, const f32x16 (&b)[2], f32x16 (&o)[2]) {
+#pragma unroll
+  for (int R = 0; R < 2; ++R)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) o[R][q] = 0.0f;
+  float wc[2][4][2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int R = 0; R < 2; ++R) wc[0][e][R] = wcol[e * LD + 32 * R];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    if (s + 1 < 8) {
+      const float* __restrict__ p = wcol + 8 * (s + 1) * LD;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int R = 0; R < 2; ++R) wc[(s + 1) & 1][e][R] = p[e * LD + 32 * R];
+    }
+    const f32x16& bt = b[s >> 2];
+    const int q0 = 4 * (s & 3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int R = 0; R < 2; ++R) o[R] = SDEH_MFMA(wc[s & 1][e][R], bt[q0 + e], o[R]);
+    SDEH_FENCE();
+  }
+}
+
 }  // namespace bwdf2
 
 // NQ: accumulator registers of a coordinate tile that can hold live coordinates (d <= 8: 4, d <= 16: 8, else 16; two coordinate tiles: 16):
 // loads, the elementwise phase and the publishes of x / delta_out loop over those only.  VIO (d <= 4): the input layer, the out layer
 // and their transposes run on the vector pipe (2 x 64 weights per coordinate: 32 FMAs per lane and coordinate instead of 8 + 32 + 8 +
 // 32 matrix instructions on tiles that are 7/8 padding); their weight gradients stay on the matrix pipe (off the chain).
-template <int OTD, bool BPTT, int LH, bool RECOMP, int NQ, bool VIO>
+template <int OTD, bool BPTT, int LH, bool RECOMP, int NQ, bool VIO, bool JAC = false>
 __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   using namespace bwdf2;
   static_assert(OTD == 1 || NQ == 16, "two coordinate tiles: all registers live");
+  static_assert(!JAC || (VIO && !BPTT), "the Jacobian pass is row-parallel, d <= 4");
   static_assert(!VIO || (OTD == 1 && NQ == 4), "vector-pipe in / out layers: d <= 4");
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
   constexpr int NGI = OTD == 2 ? 8 : NQ / 4;              // k-groups of the coordinates
@@ -492,6 +524,54 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       SDEH_FENCE();
       BW2_T(tp1);
       BW2_ADD(12, tpd, tp1);
+      if constexpr (JAC) {
+        // ===================================================================================== Jacobian pass (scan form of BPTT)
+        // the raw network output and d nn_k / d x_i of this (step, trajectory): d reverse passes seeded with the unit vectors, no
+        // weight gradients, no planes, no barrier.  (The clamp's mask and the score terms are applied by the scan kernel.)
+        if (t > t_last) {
+          load_x(t - 1, (int)tile, xnext);
+          load_emb(t - 1, embnext);
+          cnext = load_coef(t - 1);
+        } else if (round + 1 < n_rounds) {
+          int tn = it_t, pn = it_pair;
+          clamp_item(tn, pn);
+          load_x(tn, tile_of(pn), xnext);
+          load_emb(tn, embnext);
+          cnext = load_coef(tn);
+        }
+        const bool wr = live && h == 0;
+        float* __restrict__ nno = A.nn_out + (long long)t * d * B + lrow;
+        float* __restrict__ jo = A.jac_out + (long long)t * d * d * B + lrow;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k < d) {
+            if (wr) nno[(long long)k * B] = nn[0][k];
+            f32x16 dj[2] = {load16(vout_s + k * 64 + h * 16), load16(vout_s + k * 64 + 32 + h * 16)};  // row k of out_layer.weight
+#pragma unroll
+            for (int l = LH; l >= 0; --l) {
+#pragma unroll
+              for (int q = 0; q < 16; ++q) { dj[0][q] *= keep[l][0][q]; dj[1][q] *= keep[l][1][q]; }
+              if (l > 0) {
+                f32x16 dn[2];
+                chain_cols<RSW>(Whid_s + (l - 1) * 64 * RSW + 4 * h * RSW + j, dj, dn);
+                dj[0] = dn[0]; dj[1] = dn[1];
+              }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (i < d) {
+                const f32x16 w0 = load16(vin_s + i * 64 + h * 16), w1 = load16(vin_s + i * 64 + 32 + h * 16);
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { p0 = fmaf(w0[q], dj[0][q], p0); p1 = fmaf(w1[q], dj[1][q], p1); }
+                const float tot = sum_xor32(p0 + p1);
+                if (wr) jo[((long long)k * d + i) * B] = tot;
+              }
+            }
+          }
+        }
+        continue;
+      }
 
       // ======================================================================================= upstream gradient of the control
       // (and, through time, everything of the adjoint update that does not need W_in^T delta_0)
@@ -569,6 +649,18 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
           }
           SDEH_FENCE();
           const float c_ie = ito ? c_i : 0.0f;  // (xi is zero without the Ito term)
+          // scan form of back-propagation through time: the upstream gradient of the control comes from the scan kernel
+          const bool use_gq = !BPTT && A.gq_in != nullptr;
+          f32x16 gql;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) gql[q] = 0.0f;
+          if (use_gq) {
+            gql = load_cm(A.gq_in + (long long)t * d * B, (unsigned)lrow, ct);
+            if (!live) {  // lanes beyond the batch shadow its last row: they must contribute nothing (w_i = 0 does that for w_i dB)
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) gql[q] = 0.0f;
+            }
+          }
           f32x16 gcoord;
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
@@ -580,7 +672,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
               const float u = clipf(nn[ct][q], A.clip_model) + mfac * csc;
               gc = wi * fmaf(u - rr[q], cdt, c_ie * xi[q]);
             }
-            const float gq = BPTT ? fmaf(c_u, lam[ct][q], gc) : gc;
+            const float gq = BPTT ? fmaf(c_u, lam[ct][q], gc) : (use_gq ? gql[q] : gc);
             Gc[q] = gc;
             const float gg = gq * mult * csc;
             gcoord[q] = gg;
@@ -853,6 +945,217 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       if (h == 0 && wC == 0) rec[off_bout<OTD, LH>() + j] = b;
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Back-propagation through time as a scan (d <= 4; VERDICT r03 next-step 1, the small-batch half).  Through time the adjoint obeys
+//     G_t = c_u lambda_{t+1} + gc_t,      lambda_t = c_x lambda_{t+1} + J_t^T (m_t . G_t) + (score / cost terms linear in G_t, gc_t)
+// with J_t = d nn / d x at (t, trajectory) and m_t the clamp's mask: the only thing that is sequential is a recursion on d numbers per
+// trajectory.  The fused kernels walk it with the whole network in the loop -- at the reference's training batches (512 .. 2048) that is
+// one dependent chain of ~6 us per step on a few dozen wavefronts.  Here the network work is ROW-PARALLEL twice (bwdf2_kernel<.., JAC>:
+// nn and the d x d Jacobian of every (step, trajectory); afterwards the lv form of the backward with the upstream gradient given), and
+// this kernel does the recursion: lane = trajectory, everything of a step in ~60 vector instructions, the next step's operands in flight.
+// The elementwise semantics (what is constant, what is differentiated: losses/oc.py:204-225, 319-337, 418-450; models/reparam.py) are
+// those of bwdf2_kernel's elementwise phase, statement for statement.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int D>  // the dimension at compile time: exact loops, no predicated loads (a branch per load breaks the prefetch ring)
+__global__ __launch_bounds__(64) void bwdf2_scan_kernel(const BwdfArgs A) {
+  const WsLayout& L = A.lay;
+  const float* __restrict__ ws = A.ws;
+  constexpr int d = D;
+  const int T = A.n_steps;
+  const long long B = A.batch;
+  const long long row = (long long)blockIdx.x * 64 + threadIdx.x;
+  const bool live = row < B;
+  const long long lrow = live ? row : B - 1;
+  const float wi = live ? A.grad_rnd[lrow] : 0.0f;
+  const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
+  const int ctrl_kind = A.ctrl_kind, flags = A.flags;
+  const bool has_score = ctrl_kind != SDEH_CTRL_CLIPPED;
+  const bool refc = (flags & SDEH_FLAG_REFERENCE_CTRL) && A.loss_kind == SDEH_LOSS_REFERENCE_SDE;
+  const bool expo = A.loss_kind == SDEH_LOSS_EXPONENTIAL;
+  const bool ito = (flags & SDEH_FLAG_ITO) != 0;
+  const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
+  // Gaussian tables: (mean, inverse variance) of prior [1], second [2], target [0]
+  float pmu[D], pis[D], tis[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const bool in = i < d && i < L.dp;
+    pmu[i] = in ? ws[L.dg[1] + 2 * i] : 0.0f;
+    pis[i] = in ? ws[L.dg[1] + 2 * i + 1] : 0.0f;
+    tis[i] = in ? ws[L.dg[0] + 2 * i + 1] : 0.0f;
+  }
+  float lam[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) lam[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {  // lambda_T = w_i d(terminal costs)/dx_T
+    if (i < d) {
+      if (flags & SDEH_FLAG_TERMINAL_SECOND) {
+        const float smu = ws[L.dg[2] + 2 * i], sis = ws[L.dg[2] + 2 * i + 1];
+        lam[i] = wi * (smu - A.xs[((long long)T * d + i) * B + lrow]) * sis;
+      }
+      if ((flags & SDEH_FLAG_TERMINAL_TARGET) && A.tscore != nullptr) lam[i] = fmaf(-wi, A.tscore[(long long)i * B + lrow], lam[i]);
+    }
+  }
+  // (the per-step scalars travel with the row as VECTOR loads through an opaque zero offset: scalar loads return out of order, a
+  // wait for one is a wait for all of them -- requested at the top of a step they cost their full latency, 1.7 us per step)
+  struct Row { float x[D], sc[D], nn[D], J[D * D], cf[8], gam[D]; };
+  int vz = 0;
+  asm volatile("" : "+v"(vz));
+  const float* __restrict__ scp = has_score ? A.sc : A.xs;
+  auto load_row = [&](int t) {
+    Row r;
+    {
+      const float* __restrict__ cp = ws + L.coef + t * kCoefStride + vz;
+      r.cf[0] = cp[CF_SIGMA]; r.cf[1] = cp[CF_W]; r.cf[2] = cp[CF_SBK]; r.cf[3] = cp[CF_SQDT];
+      r.cf[4] = cp[CF_B2S2]; r.cf[5] = cp[CF_DT]; r.cf[6] = cp[CF_ALPHAK]; r.cf[7] = cp[CF_DRIFT];
+      const float* __restrict__ gp = ws + L.gam + t * L.g + vz;
+#pragma unroll
+      for (int i = 0; i < D; ++i) r.gam[i] = has_score ? gp[A.g == 1 ? 0 : min(i, L.g - 1)] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const bool in = i < d;
+      const long long o = ((long long)t * d + (in ? i : 0)) * B + lrow;
+      r.x[i] = in ? A.xs[o] : 0.0f;
+      const float scl = scp[o];  // (unconditional: a valid plane stands in when there is no score term)
+      r.sc[i] = has_score ? scl : 0.0f;
+      r.nn[i] = in ? A.nn_out[o] : 0.0f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) r.J[D * k + i] = in && k < d ? A.jac_out[(((long long)t * d + k) * d + i) * B + lrow] : 0.0f;
+    }
+    return r;
+  };
+  // the operands of a step do not depend on the recursion: four steps of them in flight (a step is ~60 instructions, a load ~1.5 us)
+  constexpr int DEPTH = 4;
+  Row ring[DEPTH];
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u) ring[u] = load_row(T - 1 - u >= 0 ? T - 1 - u : 0);
+  for (int t0 = T - 1; t0 >= 0; t0 -= DEPTH) {
+#pragma unroll
+   for (int u = 0; u < DEPTH; ++u) {
+    const int t = t0 - u;
+    if (t < 0) break;
+    const Row r = ring[u];
+    ring[u] = load_row(t - DEPTH >= 0 ? t - DEPTH : 0);
+    const float sig = r.cf[0], wl = r.cf[1];
+    const float c_i = expo ? r.cf[2] : r.cf[3];
+    const float cdt = expo ? r.cf[4] : r.cf[5];
+    const float c_u = expo ? r.cf[4] : sig * r.cf[5];
+    const float c_x = expo ? r.cf[6] : fmaf(r.cf[7], r.cf[5], 1.0f);
+    const float mult = (ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig) * A.scale_score;
+    const float coef_t = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_TARGET ? wl : 0.0f);
+    const float coef_p = ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR ? 1.0f - wl : 0.0f;
+    const float jac_t = (!has_score || (flags & (SDEH_FLAG_DETACH_SCORE | SDEH_FLAG_TARGET_SCORE_CONST))) ? 0.0f : coef_t;
+    const float jac_p = (!has_score || (flags & SDEH_FLAG_DETACH_SCORE)) ? 0.0f : coef_p;
+    float xi[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) xi[i] = 0.0f;
+    if (ito) {
+      if (A.noise != nullptr) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) xi[i] = i < d ? A.noise[((long long)t * B + lrow) * d + i] : 0.0f;
+      } else {
+        float n4[4];
+        box_muller4(philox_block(A.seed, rng_off, grow, t, 0), n4);
+#pragma unroll
+        for (int i = 0; i < D; ++i) xi[i] = i < d ? n4[i] : 0.0f;
+      }
+    }
+    const float c_ie = ito ? c_i : 0.0f;
+    float dout[D], cvec[D], Gc[D], gqv[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float mfac = 0.0f;
+      if (has_score) mfac = mult * r.gam[i];
+      const float csc = clipf(r.sc[i], A.clip_score);
+      const float keep_s = fabsf(r.sc[i]) <= A.clip_score ? 1.0f : 0.0f;
+      const float rr = refc ? sig * (pmu[i] - r.x[i]) * pis[i] : 0.0f;  // reference control sigma * prior.score(x)
+      const float u = clipf(r.nn[i], A.clip_model) + mfac * csc;
+      const float gc = i < d ? wi * fmaf(u - rr, cdt, c_ie * xi[i]) : 0.0f;
+      const float gq = fmaf(c_u, lam[i], gc);
+      Gc[i] = gc;
+      cvec[i] = keep_s * mfac * gq;
+      dout[i] = fabsf(r.nn[i]) <= A.clip_model ? gq : 0.0f;
+      gqv[i] = gq;
+    }
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) A.gq_out[((long long)t * d + i) * B + lrow] = gqv[i];
+    }
+    float vt[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) vt[i] = 0.0f;
+    if (jac_t != 0.0f) {  // closed-form target scores are differentiated through x
+      if (A.target.kind == SDEH_DENS_DIAG_GAUSS) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) vt[i] = -tis[i] * cvec[i];
+      } else if (A.target.kind == SDEH_DENS_MULTI_WELL) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          const float y = r.x[i] - A.target.p1;
+          vt[i] = (i < A.target.n_comp ? -4.0f * (3.0f * y * y - A.target.p0) : -1.0f) * cvec[i];
+        }
+      } else if (A.target.kind == SDEH_DENS_FUNNEL) {
+        float sq = 0.0f, cx = 0.0f;
+#pragma unroll
+        for (int i = 1; i < D; ++i) { sq = fmaf(r.x[i], r.x[i], sq); cx = fmaf(cvec[i], r.x[i], cx); }
+        const float iv = __expf(-r.x[0]), c0 = cvec[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) vt[i] = iv * (c0 * r.x[i] - cvec[i]);
+        vt[0] = c0 * (-1.0f / A.target.p0 - 0.5f * iv * sq) + iv * cx;
+      }
+    }
+    const float sig_r = refc ? sig : 0.0f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float v = fmaf(jac_t, vt[i], c_x * lam[i]);
+      if (jac_p != 0.0f || refc) {
+        v = fmaf(-jac_p * pis[i], cvec[i], v);  // Gaussian prior: J = -1/sigma^2
+        v = fmaf(sig_r * pis[i], Gc[i], v);     // cost depends on x through sigma * prior.score(x)
+      }
+      float dx = 0.0f;  // W_in^T delta_0 = J^T (clamp mask . G)
+#pragma unroll
+      for (int k = 0; k < D; ++k) dx = fmaf(r.J[D * k + i], dout[k], dx);
+      lam[i] = i < d ? v + dx : 0.0f;
+    }
+   }
+  }
+}
+
+int launch_bwdf2_scan(const BwdfArgs& a, hipStream_t stream) {
+  const dim3 grid((unsigned)((a.batch + 63) / 64));
+  switch (a.d) {
+    case 1: hipLaunchKernelGGL(bwdf2_scan_kernel<1>, grid, dim3(64), 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(bwdf2_scan_kernel<2>, grid, dim3(64), 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(bwdf2_scan_kernel<3>, grid, dim3(64), 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(bwdf2_scan_kernel<4>, grid, dim3(64), 0, stream, a); break;
+    default: return SDEH_ERR_UNSUPPORTED;
+  }
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+bool bwdf2_scan_fits(int d, int n_hidden) { return d >= 1 && d <= 4 && n_hidden == 2 && bwdf_fits(d, n_hidden); }
+
+template <int LH>
+static int launch_bwdf2_jac_t(const BwdfArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = (size_t)(bwdf::lds_floats<1, LH>() + 512) * sizeof(float);
+  static bool attr_done[kMaxDevices] = {};
+  bool& attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<1, false, LH, false, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bwdf2_kernel<1, false, LH, false, 4, true, true>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+int launch_bwdf2_jac(const BwdfArgs& a, hipStream_t stream) {
+  if (!bwdf2_scan_fits(a.d, a.n_hidden) || a.nn_out == nullptr || a.jac_out == nullptr) return SDEH_ERR_UNSUPPORTED;
+  return launch_bwdf2_jac_t<2>(a, stream);
 }
 
 template <int OTD, bool BPTT, int LH, int NQ, bool VIO>

@@ -220,6 +220,13 @@ struct BwdfArgs {
   const unsigned long long* rng_dev;
   int n_tiles, n_slots, wsize;
   int n_hidden;           // 1 .. 3
+  // back-propagation through time as a SCAN (sdeh_bwdf2.hip, d <= 4): a row-parallel pass stores the raw network output and its
+  // d x d Jacobian per (step, trajectory), a scan over the steps forms the upstream gradient of the control, a row-parallel pass
+  // (the lv form of the backward) turns it into parameter gradients
+  float* nn_out;          // [T, d, B] or null
+  float* jac_out;         // [T, d, d, B] or null: d nn_k / d x_i at [t][k][i][row]
+  float* gq_out;          // [T, d, B] (scan kernel): d loss / d u_t
+  const float* gq_in;     // [T, d, B] or null (row-parallel kernel): use this upstream gradient instead of w_i dB
 };
 int launch_bwdf(const BwdfArgs& a, hipStream_t stream);
 int bwdf_wsize(int d, int n_hidden);                       // floats of one team's partial-gradient record
@@ -232,7 +239,10 @@ int bwdf16_slots(long long batch);
 // the same backward with trajectory-split teams (sdeh_bwdf2.hip): a wave owns 32 trajectories and all channels, no barrier in the chain
 int launch_bwdf2(const BwdfArgs& a, hipStream_t stream);
 bool bwdf2_fits(int d, int n_hidden);                        // one or two hidden layers
-int bwdf2_slots(long long batch, int n_steps, bool bptt);  // teams of two 32-trajectory tiles
+int bwdf2_slots(long long batch, int n_steps, bool bptt);  // teams of four 32-trajectory tiles
+int launch_bwdf2_jac(const BwdfArgs& a, hipStream_t stream);   // row-parallel: nn_out, jac_out (d <= 4, two hidden layers)
+int launch_bwdf2_scan(const BwdfArgs& a, hipStream_t stream);  // the adjoint recursion over the steps: gq_out
+bool bwdf2_scan_fits(int d, int n_hidden);
 
 // effective Philox offset of a launch: by-value part + the optional device-resident counter (hipGraph replays)
 __device__ __forceinline__ unsigned long long philox_offset(unsigned long long offset, const unsigned long long* dev) {
@@ -295,7 +305,7 @@ struct SinkArgs {
 // environment (sdeh_plan_create copies it once).
 enum OptKey {
   OPT_LEGACY, OPT_GENERIC_ONLY, OPT_WS_GROUPS, OPT_WS_QUAD, OPT_WS_VOUT, OPT_WS_BARRIER, OPT_BWD_PLANES, OPT_BWD_TILE, OPT_BWD_WAVES,
-  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_COUNT
+  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BWD_SCAN, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_COUNT
 };
 struct PlanOptions {
   char v[OPT_COUNT][8];

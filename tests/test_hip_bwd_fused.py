@@ -134,8 +134,10 @@ def test_fused_backward_equals_plane_backward_on_random_problems(case, tol=2e-4)
     if name1.startswith("traj_legacy"):  # mixture tables beyond LDS: the forward keeps no planes, the plane path serves
         pytest.skip(f"{tag}: forward served by {name1}")
     assert name1.startswith("bwd_fused"), f"{tag}: {name1}"
-    if method.startswith("kl") and tile is None and spec["net"].get("activation", "gelu") != "relu":
+    if method.startswith("kl") and tile is None and spec["net"].get("activation", "gelu") != "relu" and not (d <= 4 and spec["net"]["num_layers"] == 4):
         assert name1.startswith("bwd_fused16<bptt"), f"{tag}: {name1}"
+    if method.startswith("kl") and tile is None and d <= 4 and spec["net"]["num_layers"] == 4:  # the scan form (sdeh_bwdf2.hip)
+        assert name1.startswith("bwd_fused<bptt-scan"), f"{tag}: {name1}"
     assert not name2.startswith("bwd_fused"), f"{tag}: {name2}"
     assert v1 == v2 or (np.isnan(v1) and np.isnan(v2)), f"{tag}: loss {v1} vs {v2}"
     if not np.isfinite(v1):

@@ -95,7 +95,8 @@ def test_evaluation_kernels_are_bitwise_repeatable_under_load(name, batch, steps
 TRAIN_CASES = [
     ("cfg3_gmm50_pis_kl", 16384, 30, "kl", {}, "bwd_fused<"),      # tiles of 32, through time
     ("cfg1_dw_dis_lv", 16384, 40, "lv", {}, "bwd_fused<"),         # tiles of 32, row-parallel
-    ("cfg2_gmm2_dis_kl", 2048, 40, "kl", {}, "bwd_fused16<"),      # tiles of 16, four waves
+    ("cfg2_gmm2_dis_kl", 2048, 40, "kl", {}, "bwd_fused<bptt-scan"),                 # the scan form: Jacobian pass, scan, row-parallel pass
+    ("cfg2_gmm2_dis_kl", 2048, 40, "kl", {"SDEH_BWD_SCAN": 0}, "bwd_fused16<"),      # tiles of 16, four waves
     ("cfg3_gmm50_pis_kl", 2048, 30, "kl", {"SDEH_BWD_WAVES": 2}, "bwd_fused16<"),  # tiles of 16, two waves
 ]
 

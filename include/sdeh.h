@@ -377,6 +377,25 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, con
                                  float* ta, float* td, float* d2, float* cj, float* dgam, float* dx_accum,
                                  const float* div_noise, void* stream);
 
+/* 64-channel Bridge, FUSED (ABI v5; csrc/sdeh_bridgef.hip + the row-parallel kernel of csrc/sdeh_bwdf2.hip): every gradient of the
+ * INFERENCE network -- the first-order terms d rnd / d v = (u + v) dt + dB (losses/oc.py:189-202) and the divergence term
+ * sigma div_x v dt differentiated once more (utils/autograd.py:14-21 with create_graph=True) -- in three launches, without the
+ * per-coordinate planes of sdeh_ctrl_backward_ex + sdeh_bridge_div_backward (3 (Lh + 1) C floats per row and coordinate).
+ *   problem:   the inference control as the control of a plain problem (ClippedCtrl / LerpPriorCtrl; SDEH_FLAG_CHANGE_SDE_CTRL set, no
+ *              SDEH_FLAG_INFERENCE_*: v does not drive the SDE, every term is row-parallel), two hidden layers of 64 channels, d <= 64
+ *   xs        [n_steps + 1, d, batch]  the trajectory, COORDINATE-MAJOR
+ *   cost_ctrl [n_steps, d, batch]      u + v entering the running cost (what sdeh_simulate_fwd_aux returns, coordinate-major)
+ *   noise / seed / offset / row_offset: as in the forward launch; grad_rnd [batch] = d loss / d rnd_i
+ *   scratch:  sdeh_bridge_backward_fused_sizes floats (per-team partial records, three [64, n_steps * batch] planes)
+ *   out:      the record of sdeh_ctrl_backward_fused (n_hidden = 2), then the divergence term's DIRECT weight gradients, to be added:
+ *             hidden_layer[0..1].weight [2][64, 64] | input_embed.weight^T [P, 64] | out_layer.weight [P, 64]     (P = 32 ceil(d / 32))
+ * Deterministic (per-wave sequential sums; fixed-order partial sums). */
+int32_t sdeh_bridge_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_steps, int64_t batch, int32_t gamma_dim,
+                                         int64_t* scratch_floats, int64_t* out_floats);
+int32_t sdeh_bridge_backward_fused(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
+                                   int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                   const float* grad_rnd, const float* cost_ctrl, float* scratch, int64_t scratch_floats, float* out,
+                                   void* stream);
 /*
  * Bridge on WIDE networks (channels 128 / 256: conf/solver/bridge.yaml with the channels of BASELINE configs[4]): gradient of the
  * divergence term  sum_n w_i sigma dt sum_j 1[|v_nn,j| <= clip_model] J_jj(x_n; theta_v)  w.r.t. the inference network -- what the

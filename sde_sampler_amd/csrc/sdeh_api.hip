@@ -1266,6 +1266,110 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward_fused: partial sums failed");
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Bridge, 64 channels: every gradient of the INFERENCE network in three launches, no per-coordinate planes (sdeh_bridgef.hip)
+// ---------------------------------------------------------------------------------------------------------
+static void bridgef_sizes(int d, int n_steps, long long batch, int g, long long* fused, long long* planes, long long* hid, long long* io,
+                          long long* sums, long long* out) {
+  long long w, e, gp, s, o;
+  bwdf_sizes(d, 2, n_steps, batch, g, false, 32, &w, &e, &gp, &s, &o);
+  const long long slots = bwdf2_slots(batch, n_steps, false), dpp = d <= 32 ? 32 : 64;
+  *fused = w + e + gp + s;
+  *planes = 3LL * 64 * n_steps * batch;
+  *hid = slots * 2 * 4096;
+  *io = slots * 4 * 2 * dpp * 64;
+  *sums = ((slots + 31) / 32) * 2 * 4096 + ((slots * 4 + 31) / 32) * 2 * dpp * 64;
+  *out = o + 2 * 4096 + 2 * dpp * 64;
+}
+
+int32_t sdeh_bridge_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_steps, int64_t batch, int32_t gamma_dim,
+                                         int64_t* scratch_floats, int64_t* out_floats) {
+  if (!bridge_divf_fits(dim, n_hidden) || !bwdf2_fits(dim, n_hidden) || n_steps < 1 || batch < 1 || gamma_dim < 1 || scratch_floats == nullptr ||
+      out_floats == nullptr)
+    return fail(SDEH_ERR_UNSUPPORTED, "bridge_backward_fused_sizes: compiled for d <= 64 and two hidden layers of 64 channels");
+  long long f, p, hd, io, sm, o;
+  bridgef_sizes(dim, n_steps, batch, gamma_dim == 1 ? 1 : 64, &f, &p, &hd, &io, &sm, &o);
+  *scratch_floats = f + p + hd + io + sm;
+  *out_floats = o;
+  return SDEH_OK;
+}
+
+int32_t sdeh_bridge_backward_fused(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                   int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                   const float* grad_rnd, const float* cost_ctrl, float* scratch, int64_t scratch_floats, float* out,
+                                   void* stream) {
+  OptScope opt_scope(plan);
+  if (xs == nullptr || grad_rnd == nullptr || cost_ctrl == nullptr || scratch == nullptr || out == nullptr)
+    return fail(SDEH_ERR_INVALID, "bridge_backward_fused: null argument");
+  Checked ck;
+  int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, false, &ck);
+  if (rc != SDEH_OK) return rc;
+  const SdehFourierMLP& net = pr->base_model;
+  const int d = net.dim;
+  if (plan->wide || net.channels != 64 || !bridge_divf_fits(d, net.n_hidden) || !bwdf2_fits(d, net.n_hidden) ||
+      (pr->flags & (SDEH_FLAG_INFERENCE_CTRL | SDEH_FLAG_INFERENCE_SDE)) || !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL) ||
+      (pr->ctrl_kind != SDEH_CTRL_CLIPPED && pr->ctrl_kind != SDEH_CTRL_LERP_PRIOR))
+    return fail(SDEH_ERR_UNSUPPORTED, "bridge_backward_fused: the inference control as a plain row-parallel problem (ClippedCtrl / LerpPriorCtrl, "
+                                      "64 channels, two hidden layers, d <= 64); sdeh_ctrl_backward_ex + sdeh_bridge_div_backward take the rest");
+  // 32-bit byte offsets: the coordinate-major planes [d][B] per step, the S planes [64][T B] per layer
+  if ((long long)(d <= 32 ? 32 : 64) * batch * 4 >= (1ll << 32) || 64LL * n_steps * batch * 4 >= (1ll << 32))
+    return fail(SDEH_ERR_CAPACITY, "bridge_backward_fused: %lld x %d rows: the planes are addressed with 32-bit byte offsets", (long long)batch, n_steps);
+  const WsLayout& L = ck.L;
+  long long n_f, n_p, n_h, n_io, n_sm, n_o;
+  bridgef_sizes(d, n_steps, batch, L.g == 1 ? 1 : 64, &n_f, &n_p, &n_h, &n_io, &n_sm, &n_o);
+  if (scratch_floats < n_f + n_p + n_h + n_io + n_sm)
+    return fail(SDEH_ERR_CAPACITY, "bridge_backward_fused: scratch too small (%lld < %lld floats)", (long long)scratch_floats, n_f + n_p + n_h + n_io + n_sm);
+  long long n_w, n_e, n_g, n_s, n_o1;
+  bwdf_sizes(d, 2, n_steps, batch, L.g == 1 ? 1 : 64, false, 32, &n_w, &n_e, &n_g, &n_s, &n_o1);
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
+  rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "bridge_backward_fused: prep kernel launch failed");
+  BwdfArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = L;
+  A.w_in = net.input_w; A.w_out = net.out_w; A.b_out = net.out_b;
+  for (int l = 0; l < net.n_hidden; ++l) { A.w_hid[l] = net.hidden_w[l]; A.b_hid[l] = net.hidden_b[l]; }
+  A.n_hidden = net.n_hidden;
+  A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.gextra = cost_ctrl;
+  A.wpart = scratch; A.epart = scratch + n_w; A.gpart = scratch + n_w + n_e;
+  float* sums = scratch + n_w + n_e + n_g;
+  float* planes = scratch + n_f;
+  A.s_out = planes; A.s_in = planes;
+  A.div_hid = planes + n_p; A.div_io = A.div_hid + n_h;
+  float* sums2 = A.div_io + n_io;
+  A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d; A.n_kg = (d + 7) / 8;
+  A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = net.activation;
+  A.g = L.g; A.gw = L.g == 1 ? 2 : 64;
+  A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
+  A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
+  A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
+  A.n_tiles = (int)((batch + 31) / 32);
+  A.n_slots = bwdf2_slots(batch, n_steps, false);
+  A.wsize = bwdf_wsize(d, net.n_hidden);
+  const long long dpp = d <= 32 ? 32 : 64;
+  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  rc = launch_divf_zero(A.div_io, n_io, st);
+  if (rc == SDEH_OK) rc = launch_bridge_divf(A, st);
+  if (rc == SDEH_OK) rc = launch_bwdf2_bridge(A, st);
+  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bridge_bwd_fused<tiles=%d>", d <= 32 ? 1 : 2);
+  if (rc != SDEH_OK) return fail(rc, "bridge_backward_fused: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  float* s1 = sums;
+  float* s2 = s1 + ((A.n_slots + 31) / 32) * (long long)A.wsize;
+  rc = launch_partial_sums(A.wpart, 1, A.n_slots, A.wsize, s1, out, st);
+  if (rc == SDEH_OK) rc = launch_partial_sums(A.epart, 1, A.n_tiles, (long long)n_steps * 64, s2, out + A.wsize, st);
+  if (rc == SDEH_OK && pr->ctrl_kind != SDEH_CTRL_CLIPPED)
+    rc = launch_partial_sums(A.gpart, 1, A.n_tiles, (long long)n_steps * A.gw, s2 + ((A.n_tiles + 31) / 32) * (long long)n_steps * 64,
+                             out + A.wsize + (long long)n_steps * 64, st);
+  float* o2 = out + n_o1;
+  if (rc == SDEH_OK) rc = launch_partial_sums(A.div_hid, 1, A.n_slots, 2 * 4096, sums2, o2, st);
+  if (rc == SDEH_OK) rc = launch_partial_sums(A.div_io, 1, (long long)A.n_slots * 4, 2 * dpp * 64, sums2 + ((A.n_slots + 31) / 32) * 2 * 4096, o2 + 2 * 4096, st);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "bridge_backward_fused: partial sums failed");
+}
+
 int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, const float* timesteps, int32_t n_steps,
                        const float* ts_out, int32_t n_out, float eps, const float* x_init, int64_t batch,
                        const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, float* xs_out,

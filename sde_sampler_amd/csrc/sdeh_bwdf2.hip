@@ -21,7 +21,7 @@
 //
 // Per step and SIMD: 528 (d <= 8) .. 752 (d = 50) matrix instructions for 32 trajectories against 2 x 296 (2 x 392) in sdeh_bwdf.hip.
 // One to two hidden layers; three keep sdeh_bwdf.hip.
-#include "sdeh_bwdf.hpp"
+#include "sdeh_bwdf2.hpp"
 #ifdef SDEH_BWDF_PROFILE
 #include <cstdio>
 #endif
@@ -37,171 +37,20 @@ __device__ unsigned long long bwdf2_prof[16];
 #define BW2_ADD(k, t0, t1) do {} while (0)
 #endif
 
-namespace bwdf2 {
-using namespace bwdf;
-
-// operands of one chunk (8 trajectories: 4 k-steps) of a weight-gradient product; chunk 4 w + c lives in the planes of the team's wave w
-struct DwChunk {
-  float4 dv, a0;
-};
-
-// lane (i, h): delta row 32 R + i, a row 32 c0 + i, trajectories 8 c + 4 h .. + 3 of one wave's tile (wplanes: that wave's D plane, A behind it)
-__device__ __forceinline__ void dw_load(const float* __restrict__ planes, int R, int c0, int i, int h, int k, DwChunk& o) {
-  const float* __restrict__ Dp = planes + (k >> 2) * 2 * PLANE;
-  o.dv = plane_getT(Dp, R, i, h, k & 3);
-  o.a0 = plane_getT(Dp + PLANE, c0, i, h, k & 3);
-}
-
-// the first NQ registers of an accumulator-layout tile -> plane [row][trajectory]
-template <int NQ>
-__device__ __forceinline__ void plane_put_n(float* __restrict__ plane, int tile, int j, int h, const f32x16& v) {
-  float* __restrict__ p = plane + (32 * tile + 4 * h) * RS + j;
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) p[rrow(q) * RS] = v[q];
-}
-// the value of lane j (lower half) in both halves
-__device__ __forceinline__ float bcast_lo(float v) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]);
-}
-
-__device__ __forceinline__ float sum4(const float4& v) { return (v.x + v.y) + (v.z + v.w); }
-
-// one chunk of a product (4 matrix instructions)
-__device__ __forceinline__ void dw_chunk(const DwChunk& o, f32x16& acc) {
-  acc = SDEH_MFMA(o.dv.x, o.a0.x, acc);
-  acc = SDEH_MFMA(o.dv.y, o.a0.y, acc);
-  acc = SDEH_MFMA(o.dv.z, o.a0.z, acc);
-  acc = SDEH_MFMA(o.dv.w, o.a0.w, acc);
-}
-
-// Forward layer from registers:  o[R] += sum_{s < ng} sum_e W[32 R + i][8 s + 4 h + e] * b[s >> 2][4 (s & 3) + e]   (R < NR)
-// wrow = &W[i * ld + 4 h]; the second row tile is 32 ld floats further.  One accumulator per row tile, k order (s, e) as in
-// sdeh_bwdf.hip's mm_rows and the forward kernel: the pre-activations are the forward launch's bit for bit.
-template <int NG, int NB, int NR>
-__device__ __forceinline__ void fwd_rows(const float* __restrict__ wrow, int ld, const f32x16 (&b)[NB], int ng, f32x16 (&o)[NR]) {
-  float4 w[2][NR];
-#pragma unroll
-  for (int R = 0; R < NR; ++R) w[0][R] = *reinterpret_cast<const float4*>(wrow + 32 * R * ld);
-#pragma unroll
-  for (int s = 0; s < NG; ++s) {
-    if (s < ng) {
-      if (s + 1 < NG && s + 1 < ng) {
-#pragma unroll
-        for (int R = 0; R < NR; ++R) w[(s + 1) & 1][R] = *reinterpret_cast<const float4*>(wrow + 32 * R * ld + 8 * (s + 1));
-      }
-      const f32x16& bt = b[s >> 2];
-      const int q0 = 4 * (s & 3);
-#pragma unroll
-      for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(w[s & 1][R].x, bt[q0], o[R]);
-#pragma unroll
-      for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(w[s & 1][R].y, bt[q0 + 1], o[R]);
-#pragma unroll
-      for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(w[s & 1][R].z, bt[q0 + 2], o[R]);
-#pragma unroll
-      for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(w[s & 1][R].w, bt[q0 + 3], o[R]);
-      SDEH_FENCE();
-    }
-  }
-}
-
-// One backward stage, entered behind the barrier that made the team's (delta_k, a_k) planes visible: the transposed layer from registers
-//     o[R] = sum_{s < ng} sum_e W[(8 s + 4 h + e) * LD + 32 R + i] * b[s >> 2][4 (s & 3) + e]        (R < NR; wcol = &W[4 h * LD + i])
-// issued interleaved with the chunks of ONE tile of the weight-gradient product  acc += delta[row tile Rd] a[tile c0]^T  over the
-// trajectories of NCH / 4 waves (planes: the first of them; operands one chunk ahead through a ring).  dsum[w] += this lane's delta
-// values of wave w's trajectories (bias gradients, d loss / d emb[t]).  Ends with the barrier behind which the planes may be overwritten.
-template <int NGC, int LD, int NR, int NB, int NCH>
-__device__ __forceinline__ void stage_cols(const float* __restrict__ wcol, const f32x16 (&b)[NB], int ng, f32x16 (&o)[NR],
-                                           const float* __restrict__ planes, int Rd, int c0, int i, int h,
-                                           f32x16& acc, float (&dsum)[NCH / 4]) {
-  constexpr int CPI = NCH / 8;  // chunks per iteration
-#pragma unroll
-  for (int R = 0; R < NR; ++R)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) o[R][q] = 0.0f;
-  float wc[2][4][NR];
-  DwChunk ck[2][CPI];
-#pragma unroll
-  for (int c = 0; c < CPI; ++c) dw_load(planes, Rd, c0, i, h, c, ck[0][c]);
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int R = 0; R < NR; ++R) wc[0][e][R] = wcol[e * LD + 32 * R];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const bool chain = s < NGC && s < ng;
-    if (s + 1 < 8) {
-#pragma unroll
-      for (int c = 0; c < CPI; ++c) dw_load(planes, Rd, c0, i, h, CPI * (s + 1) + c, ck[(s + 1) & 1][c]);
-    }
-    if (s + 1 < NGC && s + 1 < ng) {
-      const float* __restrict__ p = wcol + 8 * (s + 1) * LD;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int R = 0; R < NR; ++R) wc[(s + 1) & 1][e][R] = p[e * LD + 32 * R];
-    }
-    if (chain) {
-      const f32x16& bt = b[(s >> 2) < NB ? (s >> 2) : 0];
-      const int q0 = 4 * (s & 3);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int R = 0; R < NR; ++R) o[R] = SDEH_MFMA(wc[s & 1][e][R], bt[q0 + e], o[R]);
-    }
-#pragma unroll
-    for (int c = 0; c < CPI; ++c) {
-      dsum[(CPI * s + c) >> 2] += sum4(ck[s & 1][c].dv);
-      dw_chunk(ck[s & 1][c], acc);
-    }
-    SDEH_FENCE();
-  }
-  ws_barrier();
-}
-
-// the transposed layer alone (no weight-gradient product next to it):  o[R] = sum_s sum_e W[(8 s + 4 h + e) * LD + 32 R + i] * b[s >> 2][4 (s & 3) + e]
-template <int LD>
-__device__ __forceinline__ void chain_cols(const float* __restrict__ wcol, const f32x16 (&b)[2], f32x16 (&o)[2]) {
-#pragma unroll
-  for (int R = 0; R < 2; ++R)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) o[R][q] = 0.0f;
-  float wc[2][4][2];
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int R = 0; R < 2; ++R) wc[0][e][R] = wcol[e * LD + 32 * R];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    if (s + 1 < 8) {
-      const float* __restrict__ p = wcol + 8 * (s + 1) * LD;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int R = 0; R < 2; ++R) wc[(s + 1) & 1][e][R] = p[e * LD + 32 * R];
-    }
-    const f32x16& bt = b[s >> 2];
-    const int q0 = 4 * (s & 3);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int R = 0; R < 2; ++R) o[R] = SDEH_MFMA(wc[s & 1][e][R], bt[q0 + e], o[R]);
-    SDEH_FENCE();
-  }
-}
-
-}  // namespace bwdf2
 
 // NQ: accumulator registers of a coordinate tile that can hold live coordinates (d <= 8: 4, d <= 16: 8, else 16; two coordinate tiles: 16):
 // loads, the elementwise phase and the publishes of x / delta_out loop over those only.  VIO (d <= 4): the input layer, the out layer
 // and their transposes run on the vector pipe (2 x 64 weights per coordinate: 32 FMAs per lane and coordinate instead of 8 + 32 + 8 +
 // 32 matrix instructions on tiles that are 7/8 padding); their weight gradients stay on the matrix pipe (off the chain).
-template <int OTD, bool BPTT, int LH, bool RECOMP, int NQ, bool VIO, bool JAC = false>
+// BR (Bridge, inference network; row-parallel): the cost's u + v enters the upstream gradient (gextra), the LerpPrior score is evaluated
+// here (the Bridge forward keeps no score plane), the divergence term adds its gamma(t) part and S_k (sdeh_bridgef.hip) at every layer.
+template <int OTD, bool BPTT, int LH, bool RECOMP, int NQ, bool VIO, bool JAC = false, bool BR = false>
 __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   using namespace bwdf2;
   static_assert(OTD == 1 || NQ == 16, "two coordinate tiles: all registers live");
   static_assert(!JAC || (VIO && !BPTT), "the Jacobian pass is row-parallel, d <= 4");
   static_assert(!VIO || (OTD == 1 && NQ == 4), "vector-pipe in / out layers: d <= 4");
+  static_assert(!BR || (!BPTT && !JAC && !RECOMP), "the Bridge form is row-parallel");
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
   constexpr int NGI = OTD == 2 ? 8 : NQ / 4;              // k-groups of the coordinates
   // two coordinate tiles: x_t is read again where it is needed behind the input layer (the Jacobians of the closed-form scores, the
@@ -492,7 +341,16 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       for (int ct = 0; ct < OTD; ++ct)
 #pragma unroll
         for (int q = 0; q < 16; ++q) scv[ct][q] = 0.0f;
-      if (has_score) {
+      if constexpr (BR) {
+        if (has_score) {  // LerpPriorCtrl: (1 - t / T) prior.score(x), closed form (models/reparam.py:160-189)
+#pragma unroll
+          for (int ct = 0; ct < OTD; ++ct) {
+            const f32x16 pmu = rows16(tabs_s + 0 * 64 + 32 * ct + 4 * h), pis = rows16(tabs_s + 1 * 64 + 32 * ct + 4 * h);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) scv[ct][q] = (1.0f - wl) * ((pmu[q] - x[ct][q]) * pis[q]);
+          }
+        }
+      } else if (has_score) {
 #pragma unroll
         for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
       }
@@ -661,6 +519,18 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
               for (int q = 0; q < NQ; ++q) gql[q] = 0.0f;
             }
           }
+          f32x16 gex, dsv;  // Bridge: u + v of the running cost; d (sigma dt div) / d gamma per coordinate (the score part of the divergence)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) { gex[q] = 0.0f; dsv[q] = 0.0f; }
+          if constexpr (BR) {
+            gex = load_cm(A.gextra + (long long)t * d * B, (unsigned)lrow, ct);
+            if (ctrl_kind == SDEH_CTRL_LERP_PRIOR) {
+              const f32x16 pis = rows16(tabs_s + 1 * 64 + cb);
+              const float cdiv = -(wi * sig * cdt) * mult * (1.0f - wl);
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) dsv[q] = cdiv * pis[q];
+            }
+          }
           f32x16 gcoord;
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
@@ -668,13 +538,15 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             const float csc = clipf(scv[ct][q], A.clip_score);
             const float keep_s = fabsf(scv[ct][q]) <= A.clip_score ? 1.0f : 0.0f;
             float gc = wi * c_ie * xi[q];
+            if constexpr (BR) gc = fmaf(wi * cdt, gex[q], gc);
             if constexpr (BPTT) {
               const float u = clipf(nn[ct][q], A.clip_model) + mfac * csc;
               gc = wi * fmaf(u - rr[q], cdt, c_ie * xi[q]);
             }
             const float gq = BPTT ? fmaf(c_u, lam[ct][q], gc) : (use_gq ? gql[q] : gc);
             Gc[q] = gc;
-            const float gg = gq * mult * csc;
+            float gg = gq * mult * csc;
+            if constexpr (BR) gg = fmaf(keep_s, dsv[q], gg);
             gcoord[q] = gg;
             gsum += gg;
             cvec[q] = keep_s * mfac * gq;
@@ -754,6 +626,24 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       // ======================================================================================= backward + weight gradients
       // each product: publish (delta_k, a_k), barrier; then its matrix instructions -- operands a chunk ahead through a register ring
       // -- interleaved with the chain's next transposed layer; a barrier behind them frees the planes
+      // Bridge: S_k of the divergence term (sdeh_bridgef.hip), plane [k][64][T B]; requested a stage ahead of its use.  Rows beyond the
+      // batch shadow its last row and must contribute nothing.
+      f32x16 sv[BR ? 2 : 1];
+      auto load_s = [&](int k) {
+        if constexpr (BR) {
+          const float* __restrict__ base = A.s_in + (long long)k * 64 * ((long long)B * T);
+          unsigned ns = Bu * (unsigned)T, off = (unsigned)(4 * h) * ns + (unsigned)t * Bu + (unsigned)lrow;
+          asm volatile("" : "+v"(ns), "+v"(off));
+#pragma unroll
+          for (int R = 0; R < 2; ++R)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+              const float v = base[off + (unsigned)(32 * R + rrow(q)) * ns];
+              sv[R][q] = live ? v : 0.0f;
+            }
+        }
+      };
+      load_s(LH);
 #pragma unroll
       for (int ct = 0; ct < OTD; ++ct) plane_put_n<NQ>(Dme, ct, j, h, dout[ct]);
       ws_barrier();
@@ -813,8 +703,14 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             }
           }
         } else {
+          if constexpr (BR) {  // adj(Z_k) = act'(Z_k) . d loss / d a_{k+1} + S_k
 #pragma unroll
-          for (int q = 0; q < 16; ++q) { dl[0][q] *= keep[l + 1][0][q]; dl[1][q] *= keep[l + 1][1][q]; }
+            for (int q = 0; q < 16; ++q) { dl[0][q] = fmaf(dl[0][q], keep[l + 1][0][q], sv[0][q]); dl[1][q] = fmaf(dl[1][q], keep[l + 1][1][q], sv[1][q]); }
+            if (l >= 0) load_s(l);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { dl[0][q] *= keep[l + 1][0][q]; dl[1][q] *= keep[l + 1][1][q]; }
+          }
           if (l >= 0) {
             plane_put(Ame, 0, j, h, akeep[l >= 0 ? l : 0][0]);
             plane_put(Ame, 1, j, h, akeep[l >= 0 ? l : 0][1]);
@@ -1188,6 +1084,32 @@ static int launch_bwdf2_t(const BwdfArgs& a, hipStream_t stream) {
   } else {
     return launch_bwdf2_q<1, BPTT, LH, 16, false>(a, stream);
   }
+}
+
+template <int OTD, int NQ, bool VIO>
+static int launch_bwdf2_br(const BwdfArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = (size_t)(bwdf::lds_floats<OTD, 2>() + 512) * sizeof(float);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  static bool attr_done[kMaxDevices] = {};
+  bool& attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, false, 2, false, NQ, VIO, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bwdf2_kernel<OTD, false, 2, false, NQ, VIO, false, true>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+// the inference network of a Bridge (row-parallel; two hidden layers): first-order terms + the base chain of the divergence term
+int launch_bwdf2_bridge(const BwdfArgs& a, hipStream_t stream) {
+  if (a.n_hidden != 2 || a.d > 64 || a.gextra == nullptr || a.s_in == nullptr || !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL)) return SDEH_ERR_UNSUPPORTED;
+  if (a.d <= 4) return launch_bwdf2_br<1, 4, true>(a, stream);
+  if (a.d <= 8) return launch_bwdf2_br<1, 4, false>(a, stream);
+  if (a.d <= 16) return launch_bwdf2_br<1, 8, false>(a, stream);
+  if (a.d <= 32) return launch_bwdf2_br<1, 16, false>(a, stream);
+  return launch_bwdf2_br<2, 16, false>(a, stream);
 }
 
 bool bwdf2_fits(int d, int n_hidden) { return n_hidden >= 1 && n_hidden <= 2 && bwdf_fits(d, n_hidden); }  // (+ launch_bwdf2's own refusals)

@@ -227,7 +227,18 @@ struct BwdfArgs {
   float* jac_out;         // [T, d, d, B] or null: d nn_k / d x_i at [t][k][i][row]
   float* gq_out;          // [T, d, B] (scan kernel): d loss / d u_t
   const float* gq_in;     // [T, d, B] or null (row-parallel kernel): use this upstream gradient instead of w_i dB
+  // Bridge, inference network (sdeh_bridgef.hip + the row-parallel kernel of sdeh_bwdf2.hip): the running cost's u + v and the
+  // divergence term  w_i sigma dt sum_j 1[|nn_j| <= clip_model] J_jj
+  const float* gextra;    // [T, d, B] or null: u + v (d rnd / d v = (u + v) dt + dB)
+  float* s_out;           // [3, 64, T * B] (divergence kernel): act''(Z_k) . d loss / d act'(Z_k), the term the base chain adds at layer k
+  const float* s_in;      // the same planes, read by the row-parallel kernel
+  float* div_hid;         // [n_slots][2][64][64]: the divergence term's direct gradient of the two hidden weights, per team
+  float* div_io;          // [n_slots * 4][2][32 OTD][64] (zeroed by the caller): per wave, columns of input_embed.weight | rows of out_layer.weight
 };
+int launch_bridge_divf(const BwdfArgs& a, hipStream_t stream);  // divergence term of a 64-channel Bridge, two hidden layers (sdeh_bridgef.hip)
+bool bridge_divf_fits(int d, int n_hidden);
+int launch_divf_zero(float* p, long long n, hipStream_t stream);
+int launch_bwdf2_bridge(const BwdfArgs& a, hipStream_t stream);  // the row-parallel backward with gextra / s_in / the in-kernel prior score
 int launch_bwdf(const BwdfArgs& a, hipStream_t stream);
 int bwdf_wsize(int d, int n_hidden);                       // floats of one team's partial-gradient record
 bool bwdf_fits(int d, int n_hidden);                        // compiled for this shape and its LDS image fits

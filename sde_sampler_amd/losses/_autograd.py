@@ -80,6 +80,13 @@ def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torc
             None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
             w.data_ptr(), ptr(sc), ptr(tscore), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
             torch.cuda.current_stream(dev).cuda_stream))
+    return _fused_record_grads(ctrl, ts, out, d, T, Lh, g, score_model)
+
+
+def _fused_record_grads(ctrl, ts, out, d, T, Lh, g, score_model, div: bool = False) -> dict[int, torch.Tensor]:
+    """{id(parameter): gradient} from the `out` record of sdeh_ctrl_backward_fused (include/sdeh.h); `div`: followed by the direct
+    weight gradients of a Bridge's divergence term (sdeh_bridge_backward_fused), which are added."""
+    base = ctrl.base_model
     P, gw = 32 * ((d + 31) // 32), (2 if g == 1 else 64)
     grads: dict[int, torch.Tensor] = {}
     pos = 0
@@ -102,8 +109,53 @@ def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torc
         d_gam = take(T * gw, T, gw)
         grads[id(base.input_embed.bias)] = d_emb.sum(dim=0)
         d_gam = d_gam.sum(dim=1, keepdim=True) if g == 1 else d_gam[:, :d].contiguous()
+        if div:
+            dv_hid = take(Lh * 4096, Lh, 64, 64)
+            dv_in = take(P * 64, P, 64)[:d]
+            dv_out = take(P * 64, P, 64)[:d]
+            for k, lin in enumerate(base.hidden_layer):
+                grads[id(lin.weight)] = grads[id(lin.weight)] + dv_hid[k]
+            grads[id(base.input_embed.weight)] = grads[id(base.input_embed.weight)] + dv_in.t()
+            grads[id(base.out_layer.weight)] = grads[id(base.out_layer.weight)] + dv_out
     grads.update(_time_table_grads(ctrl, ts, d_emb, d_gam if score_model is not None else None))
     return grads
+
+
+def _bridge_fused_ok(eng, inf_model, d, T, B, st) -> bool:
+    """Does the fused inference-network backward (sdeh_bridge_backward_fused) serve this Bridge?  64 channels, two hidden layers, the
+    exact divergence, planes within 32-bit byte offsets; plan option / environment SDEH_BWD_PLANES keeps the plane-writing kernels."""
+    return (inf_model.channels == 64 and d <= 64 and len(inf_model.hidden_layer) == 2 and st.get("div_noise") is None
+            and not (eng.options.get("SDEH_BWD_PLANES") or os.environ.get("SDEH_BWD_PLANES")) and 64 * T * B * 4 < 2 ** 32)
+
+
+def _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st) -> dict[int, torch.Tensor] | None:
+    """Every gradient of a 64-channel Bridge's inference network from sdeh_bridge_backward_fused (csrc/sdeh_bridgef.hip: no
+    per-coordinate planes), or None where that path is not compiled (then: sdeh_ctrl_backward_ex + sdeh_bridge_div_backward)."""
+    base = inf.base_model
+    dev = xs.device
+    T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+    Lh = len(base.hidden_layer)
+    if not _bridge_fused_ok(eng, base, d, T, B, st) or not (pr_v.flags & L.FLAG_CHANGE_SDE_CTRL) \
+            or pr_v.ctrl_kind not in (L.CTRL_CLIPPED, L.CTRL_LERP_PRIOR):
+        return None
+    score_model = getattr(inf, "score_model", None) if pr_v.ctrl_kind != L.CTRL_CLIPPED else None
+    g = 1 if score_model is None else score_model.out_layer.out_features
+    lib = L.load()
+    n_scratch, n_out = C.c_int64(), C.c_int64()
+    L.check(lib.sdeh_bridge_backward_fused_sizes(d, Lh, T, B, g, C.byref(n_scratch), C.byref(n_out)))
+    xs_cm = xs.permute(0, 2, 1).contiguous()   # [T + 1, d, B]: the kernels move whole cache lines of consecutive trajectories
+    gp_cm = gp.permute(0, 2, 1).contiguous()   # [T, d, B]
+    scratch = torch.empty(n_scratch.value, device=dev, dtype=torch.float32)
+    out = torch.empty(n_out.value, device=dev, dtype=torch.float32)
+    plan = eng._plan(dev, d, base.channels, Lh, T, 0)
+    noise = st["noise"]
+    with torch.cuda.device(dev):
+        L.check(lib.sdeh_bridge_backward_fused(
+            plan.handle, C.byref(pr_v), keep_v.ptr(ts.reshape(-1), dev, "ts"), T, xs_cm.data_ptr(), B,
+            None if noise is None else keep_v.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
+            w.data_ptr(), gp_cm.data_ptr(), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream))
+    return _fused_record_grads(inf, ts, out, d, T, Lh, g, score_model, div=True)
 
 
 def _time_table_grads(ctrl, ts, d_emb, d_gam) -> dict[int, torch.Tensor]:
@@ -340,9 +392,12 @@ class _BridgeFn(torch.autograd.Function):
         inf_model = st["problem_kwargs"]["inference_ctrl"].base_model
         Cn, Lh = inf_model.channels, len(inf_model.hidden_layer)
         n_slices = 1
+        lv = bool(st["problem_kwargs"]["flags"] & L.FLAG_CHANGE_SDE_CTRL)
         if Cn == 64 and d <= 64 and not torch.cuda.is_current_stream_capturing():
             dd = 1 if st.get("div_noise") is not None else d
             per_traj = 4.0 * T * (3 * dd * (Lh + 1) * Cn + 6 * (Lh + 1) * Cn + 6 * d)
+            if lv and _bridge_fused_ok(loss.engine, inf_model, d, T, B, st):  # fused: three [64, T B] planes + the generative network's
+                per_traj = 4.0 * T * (3 * Cn + 6 * (Lh + 1) * Cn + 8 * d)
             budget = float(os.environ.get("SDEH_BRIDGE_PLANE_BYTES", 0)) or 0.5 * torch.cuda.mem_get_info(xs.device)[0]
             n_slices = max(1, -(-int(per_traj * B) // max(int(budget), 1)))
         if n_slices == 1:
@@ -390,6 +445,11 @@ class _BridgeFn(torch.autograd.Function):
         v_flags = (kw["flags"] | L.FLAG_CHANGE_SDE_CTRL) & ~(L.FLAG_TERMINAL_TARGET | L.FLAG_INIT_LOGP | L.FLAG_TERMINAL_SECOND)
         kw_v = dict(kw, generative_ctrl=inf, terminal_target=None, second=None, clip_target=None, flags=v_flags)
         pr_v = eng.build_problem(device=dev, keep=keep_v, **kw_v)
+        if lv:  # 64 channels, two hidden layers, exact divergence: fused, nothing per coordinate leaves the chip
+            inf_grads = _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st)
+            if inf_grads is not None:
+                grads.update(inf_grads)
+                return grads
         zt, dt, dout, dgam, *xt_v = _ctrl_backward(eng, pr_v, keep_v, ts, xs, w, st, gextra=gp, dx_out=dx)
         xt_v = xt_v[0] if xt_v else None
         # inference network, divergence term

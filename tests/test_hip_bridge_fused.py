@@ -1,0 +1,70 @@
+"""The fused backward of a 64-channel Bridge's inference network (csrc/sdeh_bridgef.hip + the Bridge form of csrc/sdeh_bwdf2.hip's
+row-parallel kernel; reference losses/oc.py:189-202, utils/autograd.py:14-21) against the plane-writing kernels it replaces
+(sdeh_ctrl_backward_ex + sdeh_bridge_div_backward + sdeh_weight_grad, pinned to the reference's autograd by tests/test_hip_bridge.py):
+every parameter gradient of both networks on the same Philox draws, at shapes the goldens do not reach (ragged batches over several
+teams, d in every tile class, active clamps)."""
+import pytest
+import torch
+
+from tests.helpers import measured
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+NET = dict(channels=64, num_layers=4, activation="gelu")
+
+CASES = [
+    # name, target, d, batch, steps, inference kind, clip_model
+    ("gmm_d2", dict(kind="gmm", dim=2, name="fab"), 2, 200, 12, "lerp_prior", 10.0),
+    ("dw_d1_clipped", dict(kind="double_well", dim=1, separation=2.0, shift=1.0), 1, 77, 9, "clipped", 10.0),
+    ("mw_d5_clamps", dict(kind="multi_well", dim=5, n_double_wells=5, separation=2.0, shift=0.0), 5, 333, 7, "lerp_prior", 0.05),
+    ("funnel_d10", dict(kind="funnel", dim=10), 10, 1100, 6, "lerp_prior", 10.0),
+    ("gauss_d20", dict(kind="iso_gauss", dim=20, loc=1.0, scale=0.5), 20, 96, 5, "lerp_prior", 10.0),
+    ("gauss_d50", dict(kind="iso_gauss", dim=50, loc=1.0, scale=0.5), 50, 150, 4, "lerp_prior", 10.0),
+]
+
+
+def _grads(spec, x0_seed, planes, monkeypatch):
+    from sde_sampler_amd import problems
+
+    if planes:
+        monkeypatch.setenv("SDEH_BWD_PLANES", "1")
+    else:
+        monkeypatch.delenv("SDEH_BWD_PLANES", raising=False)
+    torch.manual_seed(11)
+    prob = problems.build(spec, device=DEV)
+    torch.manual_seed(x0_seed)
+    x0 = prob.prior.sample((spec["batch"],))
+    params = list(prob.ctrl.named_parameters()) + [("inf." + k, p) for k, p in prob.loss.inference_ctrl.named_parameters()]
+    prob.loss.engine.calls = 3
+    val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+    val.backward()
+    return val.item(), {k: (None if p.grad is None else p.grad.clone()) for k, p in params}, prob.loss.engine.last_kernel_name()
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_fused_bridge_backward_equals_the_plane_kernels(case, monkeypatch):
+    name, tspec, d, B, T, ikind, clip = case
+    ictrl = dict(kind=ikind, clip_model=clip)
+    if ikind == "lerp_prior":
+        ictrl.update(clip_score=10.0, scale_score=1.0, gamma_dim=(d if name == "mw_d5_clamps" else 1), gamma_bias=1.0)
+    spec = dict(batch=B, target=tspec, prior=dict(kind="iso_gauss", dim=d), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+                ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                inference_ctrl=ictrl, net=NET, loss=dict(kind="time_reversal", method="lv", max_rnd=1e8),
+                grid=dict(start=0.0, end=1.0, steps=T))
+    v_f, g_f, kern = _grads(spec, 5, False, monkeypatch)
+    v_p, g_p, _ = _grads(spec, 5, True, monkeypatch)
+    assert v_f == v_p  # the same forward launch
+    assert kern.startswith("bridge_bwd_fused"), kern
+    worst = 0.0
+    for k in g_p:
+        assert (g_f[k] is None) == (g_p[k] is None), k
+        if g_p[k] is None:
+            continue
+        scale = g_p[k].abs().max().item()
+        if scale == 0.0:
+            assert g_f[k].abs().max().item() <= 1e-7, k
+            continue
+        err = (g_f[k] - g_p[k]).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err <= 5e-5, (k, err)
+    measured(f"bridge_fused_vs_planes/{name}", worst, 5e-5)

@@ -390,6 +390,21 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, con
  *   out:      the record of sdeh_ctrl_backward_fused (n_hidden = 2), then the divergence term's DIRECT weight gradients, to be added:
  *             hidden_layer[0..1].weight [2][64, 64] | input_embed.weight^T [P, 64] | out_layer.weight [P, 64]     (P = 32 ceil(d / 32))
  * Deterministic (per-wave sequential sums; fixed-order partial sums). */
+/* The FORWARD half of the same split (ABI v5).  The SDE of a Bridge is driven by the generative control alone (losses/oc.py:176-217),
+ * so a training forward is (1) the plain problem -- the Bridge's problem without its inference control -- through
+ * sdeh_simulate_fwd_train2u == sdeh_simulate_fwd_train2 that also keeps u [n_steps, d, batch], the control driving the SDE, and
+ * (2) sdeh_bridge_inference_fwd: for every (step, trajectory) independently what the inference control adds to rnd,
+ *     drnd_i = sum_t [ sigma div_x v dt + (u . v + |v|^2 / 2) dt + v . dB ]            (dB only with SDEH_FLAG_ITO; exact divergence)
+ * and cost_ctrl = u + v [n_steps, d, batch] for sdeh_bridge_backward_fused.  rnd of the Bridge = rnd of (1) + drnd (another summation
+ * order than the step-sequential sdeh_simulate_fwd_aux: equal to fp32 rounding).  Same problem conventions as
+ * sdeh_bridge_backward_fused; scratch: sdeh_bridge_inference_fwd_scratch_floats. */
+int32_t sdeh_simulate_fwd_train2u(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* x0,
+                                  int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                  float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, void* stream);
+int64_t sdeh_bridge_inference_fwd_scratch_floats(int32_t n_steps, int64_t batch);
+int32_t sdeh_bridge_inference_fwd(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
+                                  int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, const float* u,
+                                  float* drnd, float* cost_ctrl, float* scratch, int64_t scratch_floats, void* stream);
 int32_t sdeh_bridge_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_steps, int64_t batch, int32_t gamma_dim,
                                          int64_t* scratch_floats, int64_t* out_floats);
 int32_t sdeh_bridge_backward_fused(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,

@@ -147,6 +147,11 @@ PROTOTYPES = {
                                                         C.POINTER(C.c_int64)]),
     "sdeh_bridge_div_backward_wide": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, fp, fp, fp, fp, fp,
                                                   C.c_int64, fp, C.c_void_p]),
+    "sdeh_simulate_fwd_train2u": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64, C.c_uint64,
+                                              C.c_int64, fp, fp, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_bridge_inference_fwd_scratch_floats": (C.c_int64, [C.c_int32, C.c_int64]),
+    "sdeh_bridge_inference_fwd": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64, C.c_uint64,
+                                              C.c_int64, fp, fp, fp, fp, C.c_int64, C.c_void_p]),
     "sdeh_bridge_backward_fused_sizes": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.POINTER(C.c_int64),
                                                      C.POINTER(C.c_int64)]),
     "sdeh_bridge_backward_fused": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64, C.c_uint64,

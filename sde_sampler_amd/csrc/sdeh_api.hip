@@ -739,7 +739,8 @@ int32_t sdeh_simulate_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts
 static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                          float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, float* zt_out, float* nn_out,
-                         bool* planes_written, void* stream, float* sc_out = nullptr, float* tsc_out = nullptr, float* xs_cm = nullptr) {
+                         bool* planes_written, void* stream, float* sc_out = nullptr, float* tsc_out = nullptr, float* xs_cm = nullptr,
+                         float* u_out = nullptr) {
   OptScope opt_scope(plan);
   if (planes_written != nullptr) *planes_written = false;
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
@@ -798,13 +799,13 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);
   } else {
     A.zt_out = zt_out; A.nn_out = nn_out;  // only the wave-specialised kernel writes the training planes
-    A.sc_out = sc_out; A.tsc_out = tsc_out; A.xs_cm = xs_cm;
+    A.sc_out = sc_out; A.tsc_out = tsc_out; A.xs_cm = xs_cm; A.u_out = u_out;
     rc = v->fn(A, st);
     if (rc == SDEH_OK && planes_written != nullptr)
       *planes_written = (zt_out != nullptr && nn_out != nullptr) || xs_cm != nullptr;
     // image + exchange buffers beyond 160 KiB (deep networks): the single-wave kernel needs less LDS
     if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) {
-      A.zt_out = nullptr; A.nn_out = nullptr; A.sc_out = nullptr; A.tsc_out = nullptr; A.xs_cm = nullptr;
+      A.zt_out = nullptr; A.nn_out = nullptr; A.sc_out = nullptr; A.tsc_out = nullptr; A.xs_cm = nullptr; A.u_out = nullptr;
       if (planes_written != nullptr) *planes_written = false;
       rc = plan->variant->fn_legacy(A, st);
       snprintf(plan->last_kernel, sizeof(plan->last_kernel), "traj_legacy<%s>", plan->variant->name);
@@ -859,6 +860,22 @@ int32_t sdeh_simulate_fwd_train2(SdehPlan* plan, const SdehProblem* pr, const fl
                                nullptr, nullptr, &written, stream, sc, tscore, xs);
   if (rc != SDEH_OK) return rc;
   return written ? SDEH_OK : 1;  // 1: integrated by a kernel that writes none of the planes
+}
+
+int32_t sdeh_simulate_fwd_train2u(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                                  int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                  float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, void* stream) {
+  if (xs == nullptr || u == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd_train2u: xs and u (coordinate-major planes) are required");
+  if (pr != nullptr && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train2u: the problem WITHOUT its inference control (sdeh_bridge_inference_fwd adds its terms)");
+  if (plan != nullptr && plan->wide) return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train2u: 64-channel plans");
+  if (pr != nullptr && pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_train2u: sc is required for controls with a score term");
+  bool written = false;
+  const int rc = simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, &written, stream, sc, tscore, xs, u);
+  if (rc != SDEH_OK) return rc;
+  return written ? SDEH_OK : 1;
 }
 
 int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
@@ -1280,6 +1297,58 @@ static void bridgef_sizes(int d, int n_steps, long long batch, int g, long long*
   *io = slots * 4 * 2 * dpp * 64;
   *sums = ((slots + 31) / 32) * 2 * 4096 + ((slots * 4 + 31) / 32) * 2 * dpp * 64;
   *out = o + 2 * 4096 + 2 * dpp * 64;
+}
+
+int64_t sdeh_bridge_inference_fwd_scratch_floats(int32_t n_steps, int64_t batch) {
+  if (n_steps < 1 || batch < 1) return 0;
+  return (int64_t)n_steps * batch + (int64_t)((n_steps + 31) / 32) * batch;
+}
+
+int32_t sdeh_bridge_inference_fwd(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                  int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, const float* u,
+                                  float* drnd, float* cost_ctrl, float* scratch, int64_t scratch_floats, void* stream) {
+  OptScope opt_scope(plan);
+  if (xs == nullptr || u == nullptr || drnd == nullptr || cost_ctrl == nullptr || scratch == nullptr)
+    return fail(SDEH_ERR_INVALID, "bridge_inference_fwd: null argument");
+  Checked ck;
+  int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, false, &ck);
+  if (rc != SDEH_OK) return rc;
+  const SdehFourierMLP& net = pr->base_model;
+  const int d = net.dim;
+  if (plan->wide || net.channels != 64 || !bridge_divf_fits(d, net.n_hidden) || (pr->flags & (SDEH_FLAG_INFERENCE_CTRL | SDEH_FLAG_INFERENCE_SDE)) ||
+      (pr->ctrl_kind != SDEH_CTRL_CLIPPED && pr->ctrl_kind != SDEH_CTRL_LERP_PRIOR))
+    return fail(SDEH_ERR_UNSUPPORTED, "bridge_inference_fwd: the inference control as the control of a plain problem (ClippedCtrl / LerpPriorCtrl, "
+                                      "64 channels, two hidden layers, d <= 64)");
+  if ((long long)(d <= 32 ? 32 : 64) * batch * 4 >= (1ll << 32))
+    return fail(SDEH_ERR_CAPACITY, "bridge_inference_fwd: %lld trajectories: the planes are addressed with 32-bit byte offsets", (long long)batch);
+  if (scratch_floats < sdeh_bridge_inference_fwd_scratch_floats(n_steps, batch)) return fail(SDEH_ERR_CAPACITY, "bridge_inference_fwd: scratch too small");
+  const WsLayout& L = ck.L;
+  hipStream_t st = (hipStream_t)stream;
+  PrepArgs P;
+  P.ws = plan->ws; P.lay = L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
+  P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
+  rc = launch_prep(P, st);
+  if (rc != SDEH_OK) return fail(rc, "bridge_inference_fwd: prep kernel launch failed");
+  BwdfArgs A;
+  memset(&A, 0, sizeof(A));
+  A.ws = plan->ws; A.lay = L;
+  A.w_in = net.input_w; A.w_out = net.out_w; A.b_out = net.out_b;
+  for (int l = 0; l < net.n_hidden; ++l) { A.w_hid[l] = net.hidden_w[l]; A.b_hid[l] = net.hidden_b[l]; }
+  A.n_hidden = net.n_hidden;
+  A.xs = xs; A.noise = noise; A.u_in = u; A.gp_out = cost_ctrl; A.drnd_out = scratch;
+  A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d;
+  A.loss_kind = pr->loss_kind; A.ctrl_kind = pr->ctrl_kind; A.flags = pr->flags; A.act = net.activation;
+  A.g = L.g; A.gw = L.g == 1 ? 2 : 64;
+  A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
+  A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
+  A.n_tiles = (int)((batch + 31) / 32);
+  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  rc = launch_bridge_rowsf(A, st);
+  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bridge_rows_fwd<tiles=%d>", d <= 32 ? 1 : 2);
+  if (rc != SDEH_OK) return fail(rc, "bridge_inference_fwd: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+  rc = launch_partial_sums(scratch, 1, n_steps, batch, scratch + (long long)n_steps * batch, drnd, st);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "bridge_inference_fwd: partial sums failed");
 }
 
 int32_t sdeh_bridge_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_steps, int64_t batch, int32_t gamma_dim,

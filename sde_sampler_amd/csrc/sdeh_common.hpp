@@ -122,6 +122,7 @@ struct TrajArgs {
   // (coordinate-major planes: consecutive trajectories at consecutive addresses -- coalesced for both kernels)
   float* xs_cm;   // [T+1, d, B] or null: the trajectory
   float* sc_out;  // [T, d, B] or null: combined score entering the control, before clip_score and gamma(t)
+  float* u_out;   // [T, d, B] or null: the control u_t driving the SDE (Bridge training: the inference pass is row-parallel given x_t, u_t)
   float* tsc_out; // [d, B] or null: 1[|log rho(x_T)| <= clip_target] * target.score(x_T)  (d terminal target cost / d x_T, negated)
 };
 
@@ -230,6 +231,9 @@ struct BwdfArgs {
   // Bridge, inference network (sdeh_bridgef.hip + the row-parallel kernel of sdeh_bwdf2.hip): the running cost's u + v and the
   // divergence term  w_i sigma dt sum_j 1[|nn_j| <= clip_model] J_jj
   const float* gextra;    // [T, d, B] or null: u + v (d rnd / d v = (u + v) dt + dB)
+  const float* u_in;      // [T, d, B] (bridge_rowsf_kernel): the generative control of the forward launch
+  float* gp_out;          // [T, d, B] (bridge_rowsf_kernel): u + v
+  float* drnd_out;        // [T, B]    (bridge_rowsf_kernel): what the inference control adds to rnd at step t
   float* s_out;           // [3, 64, T * B] (divergence kernel): act''(Z_k) . d loss / d act'(Z_k), the term the base chain adds at layer k
   const float* s_in;      // the same planes, read by the row-parallel kernel
   float* div_hid;         // [n_slots][2][64][64]: the divergence term's direct gradient of the two hidden weights, per team
@@ -238,6 +242,7 @@ struct BwdfArgs {
 int launch_bridge_divf(const BwdfArgs& a, hipStream_t stream);  // divergence term of a 64-channel Bridge, two hidden layers (sdeh_bridgef.hip)
 bool bridge_divf_fits(int d, int n_hidden);
 int launch_divf_zero(float* p, long long n, hipStream_t stream);
+int launch_bridge_rowsf(const BwdfArgs& a, hipStream_t stream);  // v, div_x v and their share of rnd for every (step, trajectory), row-parallel
 int launch_bwdf2_bridge(const BwdfArgs& a, hipStream_t stream);  // the row-parallel backward with gextra / s_in / the in-kernel prior score
 int launch_bwdf(const BwdfArgs& a, hipStream_t stream);
 int bwdf_wsize(int d, int n_hidden);                       // floats of one team's partial-gradient record

@@ -1132,6 +1132,14 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       if (PAD) x[j] = j < d ? x[j] : 0.0f;
       xbuf[j * 64 + lane] = x[j];
     }
+    if constexpr (PLANES == 2) {  // Bridge training: the inference pass (sdeh_bridgef.hip) is row-parallel given x_t and u_t
+      if (A.u_out != nullptr && live) {
+        float* __restrict__ up = A.u_out + (long long)i * d * A.batch + lrow;
+#pragma unroll
+        for (int j = 0; j < DP; ++j)
+          if (!PAD || j < d) up[(long long)j * A.batch] = u[j];
+      }
+    }
     if (fsync) ws_flag_set(hand, i + 2);
     else ws_barrier();  // barrier A: x_{i+1} published
     WS_T(tv3);

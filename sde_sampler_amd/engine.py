@@ -613,7 +613,7 @@ class TrajectoryEngine:
     # ------------------------------------------------------------------------------------------------------
     def run(self, pr: L.SdehProblem, ts: torch.Tensor, x: torch.Tensor, *, noise: torch.Tensor | None,
             return_traj: bool, keep: _Keep, row_offset: int = 0, seed: int | None = None, want_gp: bool = False,
-            div_noise: torch.Tensor | None = None, want_planes: bool = False):
+            div_noise: torch.Tensor | None = None, want_planes: bool = False, want_u: bool = False):
         """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None); with `want_gp`
         (Bridge training) additionally the plane u + v [T,B,d] as a fourth element and, fifth, (sc [T,B,d] | None, tscore [B,d] | None)
         -- the score planes a wide Bridge on a mixture target keeps for its generative network's backward; with `want_planes` (training without an
@@ -697,15 +697,25 @@ class TrajectoryEngine:
                 bptt = not (pr.flags & L.FLAG_CHANGE_SDE_CTRL)
                 tscore = (torch.empty((dim, batch), device=device, dtype=torch.float32)
                           if bptt and (pr.flags & L.FLAG_TERMINAL_TARGET) else None)
+                # want_u (split Bridge training, losses/_autograd.py): also the control driving the SDE, [T, d, B]
+                u_cm = torch.empty((n_steps, dim, batch), device=device, dtype=torch.float32) if want_u else None
                 with torch.cuda.device(device):
-                    status = lib.sdeh_simulate_fwd_train2(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
-                                                          seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
-                                                          rnd.data_ptr(), xs_cm.data_ptr(), None if sc is None else sc.data_ptr(),
-                                                          None if tscore is None else tscore.data_ptr(), stream)
+                    if want_u:
+                        status = lib.sdeh_simulate_fwd_train2u(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
+                                                               seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
+                                                               rnd.data_ptr(), xs_cm.data_ptr(), None if sc is None else sc.data_ptr(),
+                                                               None if tscore is None else tscore.data_ptr(), u_cm.data_ptr(), stream)
+                    else:
+                        status = lib.sdeh_simulate_fwd_train2(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
+                                                              seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
+                                                              rnd.data_ptr(), xs_cm.data_ptr(), None if sc is None else sc.data_ptr(),
+                                                              None if tscore is None else tscore.data_ptr(), stream)
                 if status < 0:
                     L.check(status)
                 if status == 0:
-                    return x_T, rnd, xs_cm, ("fused", sc, tscore)
+                    return x_T, rnd, xs_cm, (("fused", sc, tscore, u_cm) if want_u else ("fused", sc, tscore))
+                if want_u:
+                    raise RuntimeError("sdeh_simulate_fwd_train2u kept no planes although sdeh_ctrl_backward_fused_supported said it would")
                 del xs_cm, sc, tscore  # integrated by a kernel that keeps no planes (mixture tables beyond LDS): once more, the plane way
             xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
             zt = torch.empty((pr.base_model.n_hidden + 1, pr.base_model.channels, n_steps * batch), device=device, dtype=torch.float32)

@@ -128,12 +128,12 @@ def _bridge_fused_ok(eng, inf_model, d, T, B, st) -> bool:
             and not (eng.options.get("SDEH_BWD_PLANES") or os.environ.get("SDEH_BWD_PLANES")) and 64 * T * B * 4 < 2 ** 32)
 
 
-def _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st) -> dict[int, torch.Tensor] | None:
+def _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st, cm: bool = False) -> dict[int, torch.Tensor] | None:
     """Every gradient of a 64-channel Bridge's inference network from sdeh_bridge_backward_fused (csrc/sdeh_bridgef.hip: no
     per-coordinate planes), or None where that path is not compiled (then: sdeh_ctrl_backward_ex + sdeh_bridge_div_backward)."""
     base = inf.base_model
     dev = xs.device
-    T, B, d = xs.shape[0] - 1, xs.shape[1], xs.shape[2]
+    T, B, d = (xs.shape[0] - 1, xs.shape[2], xs.shape[1]) if cm else (xs.shape[0] - 1, xs.shape[1], xs.shape[2])  # cm: [T + 1, d, B] planes
     Lh = len(base.hidden_layer)
     if not _bridge_fused_ok(eng, base, d, T, B, st) or not (pr_v.flags & L.FLAG_CHANGE_SDE_CTRL) \
             or pr_v.ctrl_kind not in (L.CTRL_CLIPPED, L.CTRL_LERP_PRIOR):
@@ -143,8 +143,8 @@ def _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st) -> dict[i
     lib = L.load()
     n_scratch, n_out = C.c_int64(), C.c_int64()
     L.check(lib.sdeh_bridge_backward_fused_sizes(d, Lh, T, B, g, C.byref(n_scratch), C.byref(n_out)))
-    xs_cm = xs.permute(0, 2, 1).contiguous()   # [T + 1, d, B]: the kernels move whole cache lines of consecutive trajectories
-    gp_cm = gp.permute(0, 2, 1).contiguous()   # [T, d, B]
+    xs_cm = xs if cm else xs.permute(0, 2, 1).contiguous()   # [T + 1, d, B]: the kernels move whole cache lines of consecutive trajectories
+    gp_cm = gp if cm else gp.permute(0, 2, 1).contiguous()   # [T, d, B]
     scratch = torch.empty(n_scratch.value, device=dev, dtype=torch.float32)
     out = torch.empty(n_out.value, device=dev, dtype=torch.float32)
     plan = eng._plan(dev, d, base.channels, Lh, T, 0)
@@ -550,9 +550,98 @@ def simulate_with_grad(loss, launch, ts, x):
     return x_T, rnd, None
 
 
-def simulate_bridge_with_grad(loss, launch, ts, x, inference_ctrl):
+def _inference_problem(eng, kw: dict, dev):
+    """The inference control of a Bridge as the control of a plain row-parallel problem (it does not drive the SDE): (pr_v, keep_v, inf)."""
+    kw = dict(kw)
+    inf = kw.pop("inference_ctrl")
+    keep_v = E._Keep()
+    v_flags = (kw["flags"] | L.FLAG_CHANGE_SDE_CTRL) & ~(L.FLAG_TERMINAL_TARGET | L.FLAG_INIT_LOGP | L.FLAG_TERMINAL_SECOND)
+    kw_v = dict(kw, generative_ctrl=inf, terminal_target=None, second=None, clip_target=None, flags=v_flags)
+    return eng.build_problem(device=dev, keep=keep_v, **kw_v), keep_v, inf
+
+
+class _BridgeSplitFn(torch.autograd.Function):
+    """Bridge training, method lv, 64 channels, the exact divergence (conf/solver/bridge.yaml): the SDE is driven by the generative control
+    alone (losses/oc.py:176-217), so the forward is the PLAIN launch (sdeh_simulate_fwd_train2u: the wave-specialised kernel, keeping the
+    fused backward's planes and u_t) + one row-parallel pass over every (step, trajectory) for the inference control's terms
+    (sdeh_bridge_inference_fwd), instead of one wave walking the steps with d tangent passes in its loop; the backward is
+    sdeh_ctrl_backward_fused for the generative network and sdeh_bridge_backward_fused for the inference network.  No transposes, no
+    per-coordinate planes."""
+
+    @staticmethod
+    def forward(ctx, loss, launch, ts, x, *params):
+        x_T, rnd_u, xs_cm, state = launch(return_traj=True, want_state=True, want_planes=True, split=True)
+        _, sc, tscore, u_cm = state["planes"]
+        eng, dev = loss.engine, x.device
+        T, d, B = xs_cm.shape[0] - 1, xs_cm.shape[1], xs_cm.shape[2]
+        pr_v, keep_v, inf = _inference_problem(eng, state["problem_kwargs"], dev)
+        lib = L.load()
+        drnd = torch.empty((B, 1), device=dev, dtype=torch.float32)
+        gp_cm = torch.empty((T, d, B), device=dev, dtype=torch.float32)
+        scratch = torch.empty(lib.sdeh_bridge_inference_fwd_scratch_floats(T, B), device=dev, dtype=torch.float32)
+        plan = eng._plan(dev, d, 64, len(inf.base_model.hidden_layer), T, 0)
+        noise = state["noise"]
+        with torch.cuda.device(dev):
+            L.check(lib.sdeh_bridge_inference_fwd(
+                plan.handle, C.byref(pr_v), keep_v.ptr(ts.reshape(-1), dev, "ts"), T, xs_cm.data_ptr(), B,
+                None if noise is None else keep_v.ptr(noise, dev, "noise"), state["seed"], state["offset"], state["row_offset"],
+                u_cm.data_ptr(), drnd.data_ptr(), gp_cm.data_ptr(), scratch.data_ptr(), scratch.numel(),
+                torch.cuda.current_stream(dev).cuda_stream))
+        ctx.loss, ctx.state, ctx.kept = loss, state, (sc, tscore)
+        ctx.save_for_backward(ts, xs_cm, gp_cm)
+        ctx.mark_non_differentiable(x_T)
+        return x_T, rnd_u + drnd
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, _grad_xT, grad_rnd):
+        ts, xs_cm, gp_cm = ctx.saved_tensors
+        loss, st = ctx.loss, ctx.state
+        sc, tscore = ctx.kept
+        eng, dev = loss.engine, xs_cm.device
+        w = grad_rnd.reshape(-1).contiguous().float()
+        kw = dict(st["problem_kwargs"])
+        kw.pop("inference_ctrl")
+        keep = E._Keep()
+        pr_u = eng.build_problem(device=dev, keep=keep, **kw)
+        grads = _fused_backward(loss, pr_u, keep, ts, xs_cm, w, st, sc, tscore)
+        pr_v, keep_v, inf = _inference_problem(eng, st["problem_kwargs"], dev)
+        inf_grads = _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs_cm, gp_cm, w, st, cm=True)
+        if inf_grads is None:
+            raise RuntimeError("split Bridge backward: sdeh_bridge_backward_fused refused a problem its forward half accepted")
+        grads.update(inf_grads)
+        return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
+
+
+def _bridge_split_ok(loss, ts, x, inference_ctrl, flags: int, div_noise) -> bool:
+    """Does the split path serve this Bridge training call?  lv, exact divergence, both networks of 64 channels, the inference network with
+    two hidden layers, the generative problem one the fused backward takes (checked on the plain problem itself by the caller)."""
+    if not (flags & L.FLAG_CHANGE_SDE_CTRL) or div_noise is not None or os.environ.get("SDEH_BRIDGE_SEQ"):  # (A/B aid: the step-sequential forward)
+        return False
+    gen, inf_model = loss.generative_ctrl.base_model, inference_ctrl.base_model
+    T, (B, d) = ts.numel() - 1, x.shape
+    return (gen.channels == 64 and 64 * B * 4 < 2 ** 32
+            and _bridge_fused_ok(loss.engine, inf_model, d, T, B, dict(div_noise=div_noise)))
+
+
+def simulate_bridge_with_grad(loss, launch, ts, x, inference_ctrl, flags: int = 0, div_noise=None, problem_kwargs: dict | None = None):
     """Bridge counterpart: `rnd` is attached to the parameters of both networks."""
     params = _ctrl_parameters(loss.generative_ctrl) + _ctrl_parameters(inference_ctrl)
+    if problem_kwargs is not None and _bridge_split_ok(loss, ts, x, inference_ctrl, flags, div_noise):
+        eng = loss.engine
+        keep = E._Keep()
+        pr_u = eng.build_problem(device=x.device, keep=keep, **dict(problem_kwargs, inference_ctrl=None))
+        T, d = ts.numel() - 1, x.shape[1]
+        k = pr_u.target.n_components if pr_u.target.kind == L.DENS_GMM else 0
+        plan = eng._plan(x.device, d, 64, pr_u.base_model.n_hidden, T, k)
+        if L.load().sdeh_ctrl_backward_fused_supported(plan.handle, C.byref(pr_u)):
+            def wrapped_split(**kwargs):
+                x_T, rnd, xs, state = launch(**kwargs)
+                state["params"] = params
+                return x_T, rnd, xs, state
+
+            x_T, rnd = _BridgeSplitFn.apply(loss, wrapped_split, ts, x, *_leaves(loss, params))
+            return x_T, rnd, None
 
     def wrapped(return_traj, want_state, want_gp):
         x_T, rnd, xs, gp, state = launch(return_traj=return_traj, want_state=want_state, want_gp=want_gp)

@@ -378,15 +378,17 @@ class BaseOCLoss:
                               reference_prior=reference_prior, alpha=alpha, sigma=sigma, inference_ctrl=inference_ctrl,
                               rng_counter=self.rng_counter)
 
-        def run(return_traj: bool, want_state: bool = False, want_gp: bool = False, want_planes: bool = False):
+        def run(return_traj: bool, want_state: bool = False, want_gp: bool = False, want_planes: bool = False, split: bool = False):
+            # split (Bridge training, losses/_autograd.py::_BridgeSplitFn): the problem WITHOUT its inference control -- whose terms are
+            # row-parallel given the trajectory and the control -- keeping the fused backward's planes and u_t
             keep = E._Keep()
-            pr = self.engine.build_problem(device=x.device, keep=keep, **problem_kwargs)
+            pr = self.engine.build_problem(device=x.device, keep=keep, **(dict(problem_kwargs, inference_ctrl=None) if split else problem_kwargs))
             row_offset = self._row_offset(x.shape[0])
             offset = self.engine.offset()
             seed = torch.initial_seed()
             out = self.engine.run(pr, ts, x, noise=noise, return_traj=return_traj, keep=keep,
-                                  row_offset=row_offset, seed=seed, want_gp=want_gp, div_noise=div_noise,
-                                  want_planes=want_planes)
+                                  row_offset=row_offset, seed=seed, want_gp=want_gp, div_noise=None if split else div_noise,
+                                  want_planes=want_planes, want_u=split)
             x_T, rnd, xs = out[:3]
             # user-supplied callables the engine does not recognise are evaluated as given (device tensors in/out)
             if second is None and second_log_prob is not None:
@@ -417,7 +419,8 @@ class BaseOCLoss:
                                             "of built-in distributions (they are differentiated inside the kernel)")
             from sde_sampler_amd.losses._autograd import simulate_bridge_with_grad
 
-            x_T, rnd, _ = simulate_bridge_with_grad(self, run, ts, x, inference_ctrl)
+            x_T, rnd, _ = simulate_bridge_with_grad(self, run, ts, x, inference_ctrl, flags=flags, div_noise=div_noise,
+                                                    problem_kwargs=problem_kwargs)
             return x_T, rnd, None
         if needs_graph:
             if not (flags & L.FLAG_CHANGE_SDE_CTRL) and (target is None or (second is None and second_log_prob is not None)):

@@ -406,7 +406,10 @@ class TrajectoryEngine:
             keep.extend(ent[2])
             return L.SdehProblem.from_buffer_copy(ent[1])
         own = _Keep()
-        pr = self._describe(device=device, keep=own, **kw)
+        # (no graph: a converted copy of a parameter made with grad enabled would carry a grad_fn, keep that parameter's AccumulateGrad node
+        # -- bound to the stream of THIS call -- alive in the cache, and break a later hipGraph capture of the backward)
+        with torch.no_grad():
+            pr = self._describe(device=device, keep=own, **kw)
         keep.extend(own)
         if fp is not None and not own.converted:
             try:
@@ -663,6 +666,8 @@ class TrajectoryEngine:
         if want_planes:  # training forward: keep what the backward kernels need
             if not return_traj or want_gp or div_noise is not None:
                 raise ValueError("want_planes goes with return_traj=True and without the Bridge outputs")
+            if want_u and (pr.base_model.channels != 64 or dim > 64 or 64 * batch * 4 >= 2 ** 32):
+                raise ValueError("want_u: 64-channel networks, d <= 64, planes within 32-bit byte offsets")
             if pr.base_model.channels != 64 or dim > 64:
                 # wide networks (csrc/sdeh_wide_bwd.hip): the forward keeps the trajectory only; the backward re-evaluates the network
                 # on the matrix pipe at the stored states
@@ -688,7 +693,7 @@ class TrajectoryEngine:
                                                       xs.data_ptr(), None, None, stream))
                 return x_T, rnd, xs, None
             # (the fused backward addresses its [d][B] planes with 32-bit byte offsets: beyond 2^24 trajectories the plane path)
-            if 64 * batch * 4 < 2 ** 32 and lib.sdeh_ctrl_backward_fused_supported(plan.handle, C.byref(pr)):
+            if 64 * batch * 4 < 2 ** 32 and (want_u or lib.sdeh_ctrl_backward_fused_supported(plan.handle, C.byref(pr))):
                 # fused backward (csrc/sdeh_bwdf.hip): the combined score per step and the terminal target score, no [C, T*B] planes
                 # (coordinate-major planes: [.., d, B])
                 xs_cm = torch.empty((n_steps + 1, dim, batch), device=device, dtype=torch.float32)
@@ -714,8 +719,8 @@ class TrajectoryEngine:
                     L.check(status)
                 if status == 0:
                     return x_T, rnd, xs_cm, (("fused", sc, tscore, u_cm) if want_u else ("fused", sc, tscore))
-                if want_u:
-                    raise RuntimeError("sdeh_simulate_fwd_train2u kept no planes although sdeh_ctrl_backward_fused_supported said it would")
+                if want_u:  # served by a kernel that keeps no planes (mixture tables beyond LDS, SDEH_LEGACY): the caller falls back
+                    return x_T, rnd, None, None
                 del xs_cm, sc, tscore  # integrated by a kernel that keeps no planes (mixture tables beyond LDS): once more, the plane way
             xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
             zt = torch.empty((pr.base_model.n_hidden + 1, pr.base_model.channels, n_steps * batch), device=device, dtype=torch.float32)

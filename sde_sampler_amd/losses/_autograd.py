@@ -560,6 +560,48 @@ def _inference_problem(eng, kw: dict, dev):
     return eng.build_problem(device=dev, keep=keep_v, **kw_v), keep_v, inf
 
 
+def _bridge_split_forward(loss, launch, ts, x):
+    """(x_T, rnd, xs [T + 1, d, B], u + v [T, d, B], state) of a 64-channel Bridge from the plain launch + the row-parallel inference pass
+    (sdeh_simulate_fwd_train2u, sdeh_bridge_inference_fwd), or None when the plain launch was served by a kernel that keeps no planes."""
+    x_T, rnd_u, xs_cm, state = launch(return_traj=True, want_state=True, want_planes=True, split=True)
+    if xs_cm is None:
+        return None
+    u_cm = state["planes"][3]
+    eng, dev = loss.engine, x.device
+    T, d, B = xs_cm.shape[0] - 1, xs_cm.shape[1], xs_cm.shape[2]
+    pr_v, keep_v, inf = _inference_problem(eng, state["problem_kwargs"], dev)
+    lib = L.load()
+    drnd = torch.empty((B, 1), device=dev, dtype=torch.float32)
+    gp_cm = torch.empty((T, d, B), device=dev, dtype=torch.float32)
+    scratch = torch.empty(lib.sdeh_bridge_inference_fwd_scratch_floats(T, B), device=dev, dtype=torch.float32)
+    plan = eng._plan(dev, d, 64, len(inf.base_model.hidden_layer), T, 0)
+    noise = state["noise"]
+    with torch.cuda.device(dev):
+        L.check(lib.sdeh_bridge_inference_fwd(
+            plan.handle, C.byref(pr_v), keep_v.ptr(ts.reshape(-1), dev, "ts"), T, xs_cm.data_ptr(), B,
+            None if noise is None else keep_v.ptr(noise, dev, "noise"), state["seed"], state["offset"], state["row_offset"],
+            u_cm.data_ptr(), drnd.data_ptr(), gp_cm.data_ptr(), scratch.data_ptr(), scratch.numel(),
+            torch.cuda.current_stream(dev).cuda_stream))
+    return x_T, rnd_u + drnd, xs_cm, gp_cm, state
+
+
+def simulate_bridge_split(loss, launch, ts, x, inference_ctrl, return_traj: bool):
+    """Bridge WITHOUT a graph (evaluation, torch.no_grad()): (x_T, rnd, xs [T + 1, B, d] | None) through the same split, or None where it
+    does not apply (then the step-sequential kernel of csrc/sdeh_bridge.hpp)."""
+    gen, inf_model = loss.generative_ctrl.base_model, inference_ctrl.base_model
+    B, d = x.shape
+    if (os.environ.get("SDEH_BRIDGE_SEQ") or gen.channels != 64 or inf_model.channels != 64 or d > 64 or len(inf_model.hidden_layer) != 2
+            or 64 * B * 4 >= 2 ** 32):
+        return None
+    calls = loss.engine.calls
+    out = _bridge_split_forward(loss, launch, ts, x)
+    if out is None:
+        loss.engine.calls = calls  # the fall-back launch draws the same noise
+        return None
+    x_T, rnd, xs_cm, _, _ = out
+    return x_T, rnd, (xs_cm.permute(0, 2, 1).contiguous() if return_traj else None)
+
+
 class _BridgeSplitFn(torch.autograd.Function):
     """Bridge training, method lv, 64 channels, the exact divergence (conf/solver/bridge.yaml): the SDE is driven by the generative control
     alone (losses/oc.py:176-217), so the forward is the PLAIN launch (sdeh_simulate_fwd_train2u: the wave-specialised kernel, keeping the
@@ -570,27 +612,14 @@ class _BridgeSplitFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, loss, launch, ts, x, *params):
-        x_T, rnd_u, xs_cm, state = launch(return_traj=True, want_state=True, want_planes=True, split=True)
-        _, sc, tscore, u_cm = state["planes"]
-        eng, dev = loss.engine, x.device
-        T, d, B = xs_cm.shape[0] - 1, xs_cm.shape[1], xs_cm.shape[2]
-        pr_v, keep_v, inf = _inference_problem(eng, state["problem_kwargs"], dev)
-        lib = L.load()
-        drnd = torch.empty((B, 1), device=dev, dtype=torch.float32)
-        gp_cm = torch.empty((T, d, B), device=dev, dtype=torch.float32)
-        scratch = torch.empty(lib.sdeh_bridge_inference_fwd_scratch_floats(T, B), device=dev, dtype=torch.float32)
-        plan = eng._plan(dev, d, 64, len(inf.base_model.hidden_layer), T, 0)
-        noise = state["noise"]
-        with torch.cuda.device(dev):
-            L.check(lib.sdeh_bridge_inference_fwd(
-                plan.handle, C.byref(pr_v), keep_v.ptr(ts.reshape(-1), dev, "ts"), T, xs_cm.data_ptr(), B,
-                None if noise is None else keep_v.ptr(noise, dev, "noise"), state["seed"], state["offset"], state["row_offset"],
-                u_cm.data_ptr(), drnd.data_ptr(), gp_cm.data_ptr(), scratch.data_ptr(), scratch.numel(),
-                torch.cuda.current_stream(dev).cuda_stream))
-        ctx.loss, ctx.state, ctx.kept = loss, state, (sc, tscore)
+        out = _bridge_split_forward(loss, launch, ts, x)
+        if out is None:
+            raise RuntimeError("sdeh_simulate_fwd_train2u kept no planes although sdeh_ctrl_backward_fused_supported said it would")
+        x_T, rnd, xs_cm, gp_cm, state = out
+        ctx.loss, ctx.state, ctx.kept = loss, state, state["planes"][1:3]
         ctx.save_for_backward(ts, xs_cm, gp_cm)
         ctx.mark_non_differentiable(x_T)
-        return x_T, rnd_u + drnd
+        return x_T, rnd
 
     @staticmethod
     @torch.autograd.function.once_differentiable

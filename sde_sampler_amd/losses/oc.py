@@ -23,6 +23,7 @@ DESIGN.md section 7) and the Hutchinson divergence estimators on wide networks.
 from __future__ import annotations
 
 import logging
+import os
 import math
 from typing import Callable
 
@@ -433,6 +434,12 @@ class BaseOCLoss:
 
             x_T, rnd, _ = simulate_with_grad(self, run, ts, x)
             return x_T, rnd, None
+        if inference_ctrl is not None and div_noise is None:  # no graph: the same split (plain launch + row-parallel inference pass)
+            from sde_sampler_amd.losses._autograd import simulate_bridge_split
+
+            out = simulate_bridge_split(self, run, ts, x, inference_ctrl, return_traj)
+            if out is not None:
+                return out
         return run(return_traj)
 
     def _train_call(self, ts, x, simulate_kwargs: dict):

@@ -77,3 +77,40 @@ def test_fused_bridge_backward_equals_the_plane_kernels(case, monkeypatch):
             worst = max(worst, err)
             assert err <= 5e-5, (mode, k, err)
         measured(f"bridge_{mode}_vs_planes/{name}", worst, 5e-5)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[5]], ids=lambda c: c[0])
+def test_split_bridge_evaluation_equals_the_step_sequential_kernel(case, monkeypatch):
+    """Without a graph (loss.eval, torch.no_grad()): the plain launch + the row-parallel inference pass against csrc/sdeh_bridge.hpp's kernel
+    on the same Philox draws -- samples and trajectory bit for bit (the same generative launch arithmetic), rnd to fp32 rounding of
+    another summation order."""
+    from sde_sampler_amd import problems
+
+    name, tspec, d, B, T, ikind, clip = case
+    ictrl = dict(kind=ikind, clip_model=clip, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
+    spec = dict(batch=B, target=tspec, prior=dict(kind="iso_gauss", dim=d), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+                ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                inference_ctrl=ictrl, net=NET, loss=dict(kind="time_reversal", method="lv", max_rnd=1e8),
+                grid=dict(start=0.0, end=1.0, steps=T))
+    torch.manual_seed(11)
+    prob = problems.build(spec, device=DEV)
+    x0 = prob.prior.sample((B,))
+    out = {}
+    for mode in ("split", "seq"):
+        if mode == "seq":
+            monkeypatch.setenv("SDEH_BRIDGE_SEQ", "1")
+        else:
+            monkeypatch.delenv("SDEH_BRIDGE_SEQ", raising=False)
+        prob.loss.engine.calls = 9
+        with torch.no_grad():
+            x_T, rnd, xs = prob.loss.simulate(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, train=False,
+                                              compute_ito_int=True, return_traj=True)
+        out[mode] = (x_T.clone(), rnd.clone(), xs.clone(), prob.loss.engine.last_kernel_name())
+    assert out["split"][3].startswith("bridge_rows_fwd") and out["seq"][3].startswith("bridge<"), (out["split"][3], out["seq"][3])
+    diff_x = (out["split"][0] - out["seq"][0]).abs().max().item()
+    assert diff_x <= 1e-4, diff_x  # (two kernels, two summation orders inside the network)
+    assert (out["split"][2] - out["seq"][2]).abs().max().item() <= 1e-4
+    scale = out["seq"][1].abs().clamp(min=1.0)
+    err = ((out["split"][1] - out["seq"][1]).abs() / scale).max().item()
+    measured(f"bridge_split_eval_rnd/{name}", err, 1e-4)
+    assert err <= 1e-4, err

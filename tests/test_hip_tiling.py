@@ -102,7 +102,7 @@ def test_bridge_exact_divergence_tilings_agree(tmp_path):
     results = {}
     for mode in ("", "32g", "64"):
         out = str(tmp_path / f"tiles_{mode or 'default'}.pt")
-        env = dict(os.environ, SDEH_BRIDGE_TILES=mode)
+        env = dict(os.environ, SDEH_BRIDGE_TILES=mode, SDEH_BRIDGE_SEQ="1")  # the step-sequential kernel (the default forward is the split of losses/_autograd.py)
         if not mode:
             env.pop("SDEH_BRIDGE_TILES")
         subprocess.run([sys.executable, "-c", _TILES_SCRIPT.format(root=root, spec=dict(BRIDGE_SPEC, batch=4096), out=out)],
@@ -153,6 +153,7 @@ def test_bridge_coordinate_split_is_bitwise_the_single_wave_result(d, batch):
     out = {}
     for split in ("1", "4"):
         os.environ["SDEH_BRIDGE_SPLIT"] = split
+        os.environ["SDEH_BRIDGE_SEQ"] = "1"  # the step-sequential kernel this test is about (default: plain launch + row-parallel pass)
         try:
             prob.loss.engine.calls = 11
             res = prob.eval(x, compute_weights=True, return_traj=True)
@@ -160,6 +161,7 @@ def test_bridge_coordinate_split_is_bitwise_the_single_wave_result(d, batch):
             out[split] = (res.samples.clone(), res.weights.clone(), res.xs.clone(), value, grads)
         finally:
             os.environ.pop("SDEH_BRIDGE_SPLIT", None)
+            os.environ.pop("SDEH_BRIDGE_SEQ", None)
     a, b = out["1"], out["4"]
     assert torch.isfinite(a[0]).all()
     for k in range(3):

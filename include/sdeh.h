@@ -367,6 +367,11 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* problem, con
                                  const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                                  int64_t row_offset, const float* grad_rnd, const float* sc, const float* tscore,
                                  float* scratch, int64_t scratch_floats, float* out, void* stream);
+int32_t sdeh_ctrl_backward_fused_ex(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
+                                    const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                                    int64_t row_offset, const float* grad_rnd, const float* sc, const float* tscore,
+                                    const float* cost_ctrl, const float* lam_extra, float* scratch, int64_t scratch_floats,
+                                    float* out, void* stream);
 int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps,
                               const float* xs, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
                               int64_t row_offset, const float* grad_rnd, const float* gextra, const float* cost_ctrl,
@@ -386,6 +391,9 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, con
  *   xs        [n_steps + 1, d, batch]  the trajectory, COORDINATE-MAJOR
  *   cost_ctrl [n_steps, d, batch]      u + v entering the running cost (what sdeh_simulate_fwd_aux returns, coordinate-major)
  *   noise / seed / offset / row_offset: as in the forward launch; grad_rnd [batch] = d loss / d rnd_i
+ *   dx_out    [n_steps, d, batch] or NULL: d loss / d x_t of the inference control's terms (W_in^T adj(Z_0) + its score term's Jacobian).
+ *             Method kl: the generative network's back-propagation through time adds it to its adjoint at every step and takes its running
+ *             cost on u + v -- sdeh_ctrl_backward_fused_ex(..., cost_ctrl, lam_extra = dx_out, ...), == sdeh_ctrl_backward_fused otherwise.
  *   scratch:  sdeh_bridge_backward_fused_sizes floats (per-team partial records, three [64, n_steps * batch] planes)
  *   out:      the record of sdeh_ctrl_backward_fused (n_hidden = 2), then the divergence term's DIRECT weight gradients, to be added:
  *             hidden_layer[0..1].weight [2][64, 64] | input_embed.weight^T [P, 64] | out_layer.weight [P, 64]     (P = 32 ceil(d / 32))
@@ -409,8 +417,8 @@ int32_t sdeh_bridge_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t 
                                          int64_t* scratch_floats, int64_t* out_floats);
 int32_t sdeh_bridge_backward_fused(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
                                    int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                                   const float* grad_rnd, const float* cost_ctrl, float* scratch, int64_t scratch_floats, float* out,
-                                   void* stream);
+                                   const float* grad_rnd, const float* cost_ctrl, float* dx_out, float* scratch, int64_t scratch_floats,
+                                   float* out, void* stream);
 /*
  * Bridge on WIDE networks (channels 128 / 256: conf/solver/bridge.yaml with the channels of BASELINE configs[4]): gradient of the
  * divergence term  sum_n w_i sigma dt sum_j 1[|v_nn,j| <= clip_model] J_jj(x_n; theta_v)  w.r.t. the inference network -- what the

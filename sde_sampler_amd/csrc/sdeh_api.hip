@@ -1175,10 +1175,10 @@ int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_
   return SDEH_OK;
 }
 
-int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
-                                 int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                                 const float* grad_rnd, const float* sc, const float* tscore, float* scratch,
-                                 int64_t scratch_floats, float* out, void* stream) {
+static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                    int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                    const float* grad_rnd, const float* sc, const float* tscore, const float* cost_ctrl, const float* lam_extra,
+                                    float* scratch, int64_t scratch_floats, float* out, void* stream) {
   OptScope opt_scope(plan);
   if (xs == nullptr || grad_rnd == nullptr || scratch == nullptr || out == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: null argument");
@@ -1189,6 +1189,12 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
     return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward_fused: compiled for channels = 64, one to three hidden layers, "
                                       "d <= 64, no inference control (sdeh_ctrl_backward_ex + sdeh_weight_grad take the rest)");
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  if ((cost_ctrl != nullptr) != (lam_extra != nullptr))
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_fused_ex: cost_ctrl and lam_extra come together (a Bridge's generative network, method kl)");
+  if (cost_ctrl != nullptr && pr->base_model.n_hidden != 2)
+    return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward_fused_ex: cost_ctrl / lam_extra are compiled for two hidden layers");
+  if ((cost_ctrl != nullptr || lam_extra != nullptr) && !bptt)
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_fused_ex: cost_ctrl / lam_extra belong to back-propagation through time (methods kl / kl_ito)");
   // the kernels address the coordinate-major planes [d][B] with 32-bit byte offsets (sdeh_bwdf.hip: load_cm16)
   if ((long long)(pr->base_model.dim <= 32 ? 32 : 64) * batch * 4 >= (1ll << 32))
     return fail(SDEH_ERR_CAPACITY, "ctrl_backward_fused: %lld trajectories: the coordinate-major planes are addressed with 32-bit byte offsets "
@@ -1226,6 +1232,7 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
   for (int l = 0; l < net.n_hidden; ++l) { A.w_hid[l] = net.hidden_w[l]; A.b_hid[l] = net.hidden_b[l]; }
   A.n_hidden = net.n_hidden;
   A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.sc = sc; A.tscore = tscore;
+  A.cost_in = cost_ctrl; A.lam_in = lam_extra;
   A.wpart = scratch; A.epart = scratch + n_w; A.gpart = scratch + n_w + n_e;
   float* sums = scratch + n_w + n_e + n_g;
   A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d; A.n_kg = (d + 7) / 8;
@@ -1281,6 +1288,22 @@ int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const fl
     rc = launch_partial_sums(A.gpart, 1, A.n_tiles, (long long)n_steps * A.gw, s2 + ((A.n_tiles + 31) / 32) * (long long)n_steps * 64,
                              out + A.wsize + (long long)n_steps * 64, st);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward_fused: partial sums failed");
+}
+
+int32_t sdeh_ctrl_backward_fused(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                 int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                 const float* grad_rnd, const float* sc, const float* tscore, float* scratch,
+                                 int64_t scratch_floats, float* out, void* stream) {
+  return ctrl_backward_fused_impl(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, sc, tscore, nullptr, nullptr,
+                                  scratch, scratch_floats, out, stream);
+}
+
+int32_t sdeh_ctrl_backward_fused_ex(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                    int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                    const float* grad_rnd, const float* sc, const float* tscore, const float* cost_ctrl,
+                                    const float* lam_extra, float* scratch, int64_t scratch_floats, float* out, void* stream) {
+  return ctrl_backward_fused_impl(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, sc, tscore, cost_ctrl, lam_extra,
+                                  scratch, scratch_floats, out, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1365,8 +1388,8 @@ int32_t sdeh_bridge_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t 
 
 int32_t sdeh_bridge_backward_fused(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                                    int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                                   const float* grad_rnd, const float* cost_ctrl, float* scratch, int64_t scratch_floats, float* out,
-                                   void* stream) {
+                                   const float* grad_rnd, const float* cost_ctrl, float* dx_out, float* scratch, int64_t scratch_floats,
+                                   float* out, void* stream) {
   OptScope opt_scope(plan);
   if (xs == nullptr || grad_rnd == nullptr || cost_ctrl == nullptr || scratch == nullptr || out == nullptr)
     return fail(SDEH_ERR_INVALID, "bridge_backward_fused: null argument");
@@ -1402,7 +1425,7 @@ int32_t sdeh_bridge_backward_fused(SdehPlan* plan, const SdehProblem* pr, const 
   A.w_in = net.input_w; A.w_out = net.out_w; A.b_out = net.out_b;
   for (int l = 0; l < net.n_hidden; ++l) { A.w_hid[l] = net.hidden_w[l]; A.b_hid[l] = net.hidden_b[l]; }
   A.n_hidden = net.n_hidden;
-  A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.gextra = cost_ctrl;
+  A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.gextra = cost_ctrl; A.dx_out = dx_out;
   A.wpart = scratch; A.epart = scratch + n_w; A.gpart = scratch + n_w + n_e;
   float* sums = scratch + n_w + n_e + n_g;
   float* planes = scratch + n_f;

@@ -50,7 +50,8 @@ __device__ unsigned long long bwdf_prof[16];
 
 
 
-template <int OTD, bool BPTT, int LH>
+// KLB (through time, a Bridge's generative network with method kl): the running cost on the plane cost_in = u + v, lam_in added to the adjoint
+template <int OTD, bool BPTT, int LH, bool KLB = false>
 __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   using namespace bwdf;
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
@@ -304,6 +305,12 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
 #pragma unroll
           for (int q = 0; q < 16; ++q) rr[q] = sig * (pmu[q] - x[q]) * pis[q];
         }
+        // Bridge, method kl: the control entering the running cost is u + v (a plane; loaded where it is used: nothing to hold across the
+        // forward pass in the launches without one)
+        f32x16 cin;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) cin[q] = 0.0f;
+        if constexpr (KLB) cin = load16c(A.cost_in + (long long)t * d * B);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           float mfac = 0.0f, csc = 0.0f, keep_s = 0.0f;
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
           float gc = ito ? wi * c_i * xi[q] : 0.0f;
           if constexpr (BPTT) {
             const float u = clipf(nn[q], A.clip_model) + mfac * csc;
-            gc = wi * fmaf(u - rr[q], cdt, ito ? c_i * xi[q] : 0.0f);
+            gc = wi * fmaf(KLB ? cin[q] : u - rr[q], cdt, ito ? c_i * xi[q] : 0.0f);
           }
           const float gq = BPTT ? fmaf(c_u, lam[q], gc) : gc;
           Gc[q] = gc;
@@ -432,6 +439,11 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) lam[q] = fmaf(jac_t, vt[q], fmaf(c_x, lam[q], dx[q]));
+        if constexpr (KLB) {  // Bridge, method kl: the inference terms' d loss / d x_t
+          const f32x16 lin = load16c(A.lam_in + (long long)t * d * B);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) lam[q] += live ? lin[q] : 0.0f;  // (lanes beyond the batch shadow its last row: nothing from them)
+        }
         if (jac_p != 0.0f || refc) {
           const f32x16 pis = rows16(tabs + 1 * 64 + cb);
 #pragma unroll
@@ -475,19 +487,23 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   }
 }
 
-template <int OTD, bool BPTT, int LH>
+template <int OTD, bool BPTT, int LH, bool KLB = false>
 static int launch_bwdf_t(const BwdfArgs& a, hipStream_t stream) {
+  if constexpr (BPTT && LH == 2 && !KLB) {
+    if (a.cost_in != nullptr && a.lam_in != nullptr) return launch_bwdf_t<OTD, BPTT, LH, true>(a, stream);
+  }
+  if (!KLB && (a.cost_in != nullptr || a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;  // (two hidden layers, both planes)
   const size_t lds_bytes = (size_t)bwdf::lds_floats<OTD, LH>() * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf_kernel<OTD, BPTT, LH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf_kernel<OTD, BPTT, LH, KLB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwdf_kernel<OTD, BPTT, LH>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((bwdf_kernel<OTD, BPTT, LH, KLB>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

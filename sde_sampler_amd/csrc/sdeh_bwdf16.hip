@@ -206,7 +206,8 @@ __device__ __forceinline__ Vt<MT> mul_t(const Vt<MT>& a, const Vt<MT>& b) {
 
 }  // namespace bwdf16
 
-template <int OTD, int LH, int NW>
+// KLB (a Bridge's generative network with method kl): the running cost on the plane cost_in = u + v, lam_in added to the adjoint
+template <int OTD, int LH, int NW, bool KLB = false>
 __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
   using namespace bwdf16;
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
@@ -441,6 +442,9 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) rr.m[m][q] = sig * (pmu.m[m][q] - x.m[m][q]) * pis.m[m][q];
         }
+        // Bridge, method kl: the control entering the running cost is u + v (a plane, loaded where it is used)
+        V cin = zero_t<MT>();
+        if constexpr (KLB) cin = load8c(A.cost_in + (long long)t * d * B);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
               keep_s = fabsf(s) <= A.clip_score ? 1.0f : 0.0f;
             }
             const float u = clipf(nv, A.clip_model) + mfac * csc;
-            const float gc = wi * fmaf(u - rr.m[m][q], cdt, ito ? c_i * xi.m[m][q] : 0.0f);
+            const float gc = wi * fmaf(KLB ? cin.m[m][q] : u - rr.m[m][q], cdt, ito ? c_i * xi.m[m][q] : 0.0f);
             const float gq = fmaf(c_u, lam.m[m][q], gc);
             Gc.m[m][q] = gc;
             G.m[m][q] = gq;
@@ -589,6 +593,13 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) lam.m[m][q] = fmaf(jac_t, vt.m[m][q], fmaf(c_x, lam.m[m][q], dx.m[m][q]));
+        if constexpr (KLB) {  // Bridge, method kl: the inference terms' d loss / d x_t
+          const V lin = load8c(A.lam_in + (long long)t * d * B);
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lam.m[m][q] += live ? lin.m[m][q] : 0.0f;  // (lanes beyond the batch shadow its last row: nothing from them)
+        }
       if (jac_p != 0.0f || refc) {
         const V pis = rows_t<MT>(tabs + 1 * 64 + cb);
 #pragma unroll
@@ -634,19 +645,23 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
   }
 }
 
-template <int OTD, int LH, int NW>
+template <int OTD, int LH, int NW, bool KLB = false>
 static int launch_bwdf16_t(const BwdfArgs& a, hipStream_t stream) {
+  if constexpr (LH == 2 && NW == 4 && !KLB) {
+    if (a.cost_in != nullptr && a.lam_in != nullptr) return launch_bwdf16_t<OTD, LH, NW, true>(a, stream);
+  }
+  if (!KLB && (a.cost_in != nullptr || a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;  // (two hidden layers, four-wave teams, both planes)
   const size_t lds_bytes = (size_t)bwdf16::lds_floats<OTD, LH>() * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf16_kernel<OTD, LH, NW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf16_kernel<OTD, LH, NW, KLB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwdf16_kernel<OTD, LH, NW>), dim3((unsigned)a.n_slots), dim3(64 * NW), lds_bytes, stream, a);
+  hipLaunchKernelGGL((bwdf16_kernel<OTD, LH, NW, KLB>), dim3((unsigned)a.n_slots), dim3(64 * NW), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

@@ -44,13 +44,18 @@ __device__ unsigned long long bwdf2_prof[16];
 // 32 matrix instructions on tiles that are 7/8 padding); their weight gradients stay on the matrix pipe (off the chain).
 // BR (Bridge, inference network; row-parallel): the cost's u + v enters the upstream gradient (gextra), the LerpPrior score is evaluated
 // here (the Bridge forward keeps no score plane), the divergence term adds its gamma(t) part and S_k (sdeh_bridgef.hip) at every layer.
-template <int OTD, bool BPTT, int LH, bool RECOMP, int NQ, bool VIO, bool JAC = false, bool BR = false>
+// BR = 2: also d loss / d x_t of the inference network's terms (W_in^T adj(Z_0) + the score term's Jacobian) as a plane [T, d, B]: with method kl the
+// generative network's back-propagation through time adds it to its adjoint at every step.
+// KLB (through time, a Bridge's generative network with method kl): the running cost on the plane cost_in = u + v, lam_in added to the adjoint.
+template <int OTD, bool BPTT, int LH, bool RECOMP, int NQ, bool VIO, bool JAC = false, int BR = 0, bool KLB = false>
 __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   using namespace bwdf2;
   static_assert(OTD == 1 || NQ == 16, "two coordinate tiles: all registers live");
   static_assert(!JAC || (VIO && !BPTT), "the Jacobian pass is row-parallel, d <= 4");
   static_assert(!VIO || (OTD == 1 && NQ == 4), "vector-pipe in / out layers: d <= 4");
   static_assert(!BR || (!BPTT && !JAC && !RECOMP), "the Bridge form is row-parallel");
+  static_assert(!KLB || BPTT, "cost_in / lam_in belong to back-propagation through time");
+  constexpr bool WDX = BPTT || BR == 2;  // the chain goes on through the input layer: W_in^T delta_0
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
   constexpr int NGI = OTD == 2 ? 8 : NQ / 4;              // k-groups of the coordinates
   // two coordinate tiles: x_t is read again where it is needed behind the input layer (the Jacobians of the closed-form scores, the
@@ -531,6 +536,18 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
               for (int q = 0; q < NQ; ++q) dsv[q] = cdiv * pis[q];
             }
           }
+          // Bridge, method kl (through time): the control entering the running cost is u + v (a plane); the inference network's d loss / d x_t
+          f32x16 cin, lin;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) { cin[q] = 0.0f; lin[q] = 0.0f; }
+          if constexpr (KLB) {
+            cin = load_cm(A.cost_in + (long long)t * d * B, (unsigned)lrow, ct);
+            lin = load_cm(A.lam_in + (long long)t * d * B, (unsigned)lrow, ct);
+            if (!live) {  // lanes beyond the batch shadow its last row: nothing from them
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) lin[q] = 0.0f;
+            }
+          }
           f32x16 gcoord;
 #pragma unroll
           for (int q = 0; q < NQ; ++q) {
@@ -541,7 +558,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             if constexpr (BR) gc = fmaf(wi * cdt, gex[q], gc);
             if constexpr (BPTT) {
               const float u = clipf(nn[ct][q], A.clip_model) + mfac * csc;
-              gc = wi * fmaf(u - rr[q], cdt, c_ie * xi[q]);
+              gc = wi * fmaf(KLB ? cin[q] : u - rr[q], cdt, c_ie * xi[q]);
             }
             const float gq = BPTT ? fmaf(c_u, lam[ct][q], gc) : (use_gq ? gql[q] : gc);
             Gc[q] = gc;
@@ -564,6 +581,13 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             if (j < NQ) A.gpart[(tile * T + t) * A.gw + cb + (j & 3) + 8 * (j >> 2)] = mine;
           }
           SDEH_FENCE();
+          if constexpr (BR == 2) {  // d (v's score term) / d x_t: the Gaussian prior's J = -1 / sigma^2 through the clamp (lam is zero at the item's start)
+            if (jac_p != 0.0f) {
+              const f32x16 pis = rows16(tabs_s + 1 * 64 + cb);
+#pragma unroll
+              for (int q = 0; q < NQ; ++q) lam[ct][q] = -jac_p * pis[q] * cvec[q];
+            }
+          }
           if constexpr (BPTT) {
             // ===================================================================================== adjoint update, first part
             //   lambda_t = c_x lambda_{t+1} + (d score term / d x)^T G + direct cost terms  [+ W_in^T delta_0 at the end of the step]
@@ -602,7 +626,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             }
             SDEH_FENCE();
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) lam[ct][q] = fmaf(jac_t, vt[q], c_x * lam[ct][q]);
+            for (int q = 0; q < NQ; ++q) lam[ct][q] = KLB ? fmaf(jac_t, vt[q], fmaf(c_x, lam[ct][q], lin[q])) : fmaf(jac_t, vt[q], c_x * lam[ct][q]);
             SDEH_FENCE();
             if (jac_p != 0.0f || refc) {
               const f32x16 pis = rows16(tabs_s + 1 * 64 + cb);
@@ -758,7 +782,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
           // d loss / d (time embedding + input bias)[t][row] per tile: the delta row sums of each wave's trajectories
           if constexpr (OTD == 2) {
             float ds[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            stage_cols<(BPTT ? 8 : 0), RSI, 2, 2, 16>(Win_s + 4 * h * RSI + j, dl, 8, dx, planes, wR, wC, j, h, dw_in, ds);
+            stage_cols<(WDX ? 8 : 0), RSI, 2, 2, 16>(Win_s + 4 * h * RSI + j, dl, 8, dx, planes, wR, wC, j, h, dw_in, ds);
             if (live_item && wC == 0) {
 #pragma unroll
               for (int w = 0; w < 4; ++w) {
@@ -769,7 +793,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             }
           } else {
             float ds[2] = {0.0f, 0.0f};
-            stage_cols<((BPTT && !VIO) ? NGI == 0 ? 0 : 8 : 0), RSI, 1, 2, 8>(Win_s + 4 * h * RSI + j, dl, 8, dx, planes + wR * 4 * PLANE, wC, 0, j, h, dw_in, ds);
+            stage_cols<((WDX && !VIO) ? NGI == 0 ? 0 : 8 : 0), RSI, 1, 2, 8>(Win_s + 4 * h * RSI + j, dl, 8, dx, planes + wR * 4 * PLANE, wC, 0, j, h, dw_in, ds);
             if (live_item) {
 #pragma unroll
               for (int w = 0; w < 2; ++w) {
@@ -779,7 +803,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
               }
             }
           }
-          if constexpr (BPTT) {
+          if constexpr (WDX) {
             if constexpr (VIO) {
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
@@ -797,6 +821,20 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
               for (int ct = 0; ct < OTD; ++ct)
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) lam[ct][q] += dx[ct][q];
+            }
+          }
+          if constexpr (BR == 2) {  // coordinate-major [T][d][B], as load_cm reads
+            if (live) {
+#pragma unroll
+              for (int ct = 0; ct < OTD; ++ct) {
+                const int cb = 32 * ct + 4 * h;
+                unsigned off = ((unsigned)(cb < d ? cb : 0) * Bu + (unsigned)lrow) * 4u, s1 = Bu * 4u;
+                asm volatile("" : "+v"(off), "+v"(s1));
+                char* __restrict__ pb = reinterpret_cast<char*>(A.dx_out + (long long)t * d * B);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q)
+                  if (cb + rrow(q) < d) *reinterpret_cast<float*>(pb + off + (unsigned)rrow(q) * s1) = lam[ct][q];
+              }
             }
           }
         }
@@ -854,7 +892,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
 // The elementwise semantics (what is constant, what is differentiated: losses/oc.py:204-225, 319-337, 418-450; models/reparam.py) are
 // those of bwdf2_kernel's elementwise phase, statement for statement.
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int D>  // the dimension at compile time: exact loops, no predicated loads (a branch per load breaks the prefetch ring)
+template <int D, bool KLB = false>  // the dimension at compile time: exact loops, no predicated loads (a branch per load breaks the prefetch ring)
 __global__ __launch_bounds__(64) void bwdf2_scan_kernel(const BwdfArgs A) {
   const WsLayout& L = A.lay;
   const float* __restrict__ ws = A.ws;
@@ -896,7 +934,7 @@ __global__ __launch_bounds__(64) void bwdf2_scan_kernel(const BwdfArgs A) {
   }
   // (the per-step scalars travel with the row as VECTOR loads through an opaque zero offset: scalar loads return out of order, a
   // wait for one is a wait for all of them -- requested at the top of a step they cost their full latency, 1.7 us per step)
-  struct Row { float x[D], sc[D], nn[D], J[D * D], cf[8], gam[D]; };
+  struct Row { float x[D], sc[D], nn[D], J[D * D], cf[8], gam[D], cin[D], lin[D]; };
   int vz = 0;
   asm volatile("" : "+v"(vz));
   const float* __restrict__ scp = has_score ? A.sc : A.xs;
@@ -918,6 +956,12 @@ __global__ __launch_bounds__(64) void bwdf2_scan_kernel(const BwdfArgs A) {
       const float scl = scp[o];  // (unconditional: a valid plane stands in when there is no score term)
       r.sc[i] = has_score ? scl : 0.0f;
       r.nn[i] = in ? A.nn_out[o] : 0.0f;
+      if constexpr (KLB) {  // Bridge, method kl: u + v in the running cost; d loss / d x_t of the inference terms
+        r.cin[i] = in ? A.cost_in[o] : 0.0f;
+        r.lin[i] = in ? A.lam_in[o] : 0.0f;
+      } else {
+        r.cin[i] = 0.0f; r.lin[i] = 0.0f;
+      }
 #pragma unroll
       for (int k = 0; k < D; ++k) r.J[D * k + i] = in && k < d ? A.jac_out[(((long long)t * d + k) * d + i) * B + lrow] : 0.0f;
     }
@@ -969,7 +1013,7 @@ __global__ __launch_bounds__(64) void bwdf2_scan_kernel(const BwdfArgs A) {
       const float keep_s = fabsf(r.sc[i]) <= A.clip_score ? 1.0f : 0.0f;
       const float rr = refc ? sig * (pmu[i] - r.x[i]) * pis[i] : 0.0f;  // reference control sigma * prior.score(x)
       const float u = clipf(r.nn[i], A.clip_model) + mfac * csc;
-      const float gc = i < d ? wi * fmaf(u - rr, cdt, c_ie * xi[i]) : 0.0f;
+      const float gc = i < d ? wi * fmaf(KLB ? r.cin[i] : u - rr, cdt, c_ie * xi[i]) : 0.0f;
       const float gq = fmaf(c_u, lam[i], gc);
       Gc[i] = gc;
       cvec[i] = keep_s * mfac * gq;
@@ -1014,7 +1058,7 @@ __global__ __launch_bounds__(64) void bwdf2_scan_kernel(const BwdfArgs A) {
       float dx = 0.0f;  // W_in^T delta_0 = J^T (clamp mask . G)
 #pragma unroll
       for (int k = 0; k < D; ++k) dx = fmaf(r.J[D * k + i], dout[k], dx);
-      lam[i] = i < d ? v + dx : 0.0f;
+      lam[i] = i < d ? (KLB ? v + dx + r.lin[i] : v + dx) : 0.0f;
     }
    }
   }
@@ -1022,6 +1066,17 @@ __global__ __launch_bounds__(64) void bwdf2_scan_kernel(const BwdfArgs A) {
 
 int launch_bwdf2_scan(const BwdfArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)((a.batch + 63) / 64));
+  if ((a.cost_in != nullptr) != (a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;
+  if (a.cost_in != nullptr) {
+    switch (a.d) {
+      case 1: hipLaunchKernelGGL((bwdf2_scan_kernel<1, true>), grid, dim3(64), 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((bwdf2_scan_kernel<2, true>), grid, dim3(64), 0, stream, a); break;
+      case 3: hipLaunchKernelGGL((bwdf2_scan_kernel<3, true>), grid, dim3(64), 0, stream, a); break;
+      case 4: hipLaunchKernelGGL((bwdf2_scan_kernel<4, true>), grid, dim3(64), 0, stream, a); break;
+      default: return SDEH_ERR_UNSUPPORTED;
+    }
+    return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+  }
   switch (a.d) {
     case 1: hipLaunchKernelGGL(bwdf2_scan_kernel<1>, grid, dim3(64), 0, stream, a); break;
     case 2: hipLaunchKernelGGL(bwdf2_scan_kernel<2>, grid, dim3(64), 0, stream, a); break;
@@ -1054,20 +1109,24 @@ int launch_bwdf2_jac(const BwdfArgs& a, hipStream_t stream) {
   return launch_bwdf2_jac_t<2>(a, stream);
 }
 
-template <int OTD, bool BPTT, int LH, int NQ, bool VIO>
+template <int OTD, bool BPTT, int LH, int NQ, bool VIO, bool KLB = false>
 static int launch_bwdf2_q(const BwdfArgs& a, hipStream_t stream) {
+  if constexpr (BPTT && LH == 2 && !KLB) {
+    if (a.cost_in != nullptr && a.lam_in != nullptr) return launch_bwdf2_q<OTD, BPTT, LH, NQ, VIO, true>(a, stream);
+  }
+  if (!KLB && BPTT && (a.cost_in != nullptr || a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;  // (two hidden layers, both planes)
   constexpr bool RECOMP = false;  // (kept act, act-prime: with four-wave teams they fit; the re-evaluating form spills more)
   const size_t lds_bytes = (size_t)(bwdf::lds_floats<OTD, LH>() + 512) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, BPTT, LH, RECOMP, NQ, VIO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, BPTT, LH, RECOMP, NQ, VIO, false, 0, KLB>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwdf2_kernel<OTD, BPTT, LH, RECOMP, NQ, VIO>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((bwdf2_kernel<OTD, BPTT, LH, RECOMP, NQ, VIO, false, 0, KLB>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
@@ -1086,30 +1145,37 @@ static int launch_bwdf2_t(const BwdfArgs& a, hipStream_t stream) {
   }
 }
 
-template <int OTD, int NQ, bool VIO>
+template <int OTD, int NQ, bool VIO, int BR>
 static int launch_bwdf2_br(const BwdfArgs& a, hipStream_t stream) {
   const size_t lds_bytes = (size_t)(bwdf::lds_floats<OTD, 2>() + 512) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, false, 2, false, NQ, VIO, false, true>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, false, 2, false, NQ, VIO, false, BR>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwdf2_kernel<OTD, false, 2, false, NQ, VIO, false, true>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((bwdf2_kernel<OTD, false, 2, false, NQ, VIO, false, BR>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
 // the inference network of a Bridge (row-parallel; two hidden layers): first-order terms + the base chain of the divergence term
 int launch_bwdf2_bridge(const BwdfArgs& a, hipStream_t stream) {
   if (a.n_hidden != 2 || a.d > 64 || a.gextra == nullptr || a.s_in == nullptr || !(a.flags & SDEH_FLAG_CHANGE_SDE_CTRL)) return SDEH_ERR_UNSUPPORTED;
-  if (a.d <= 4) return launch_bwdf2_br<1, 4, true>(a, stream);
-  if (a.d <= 8) return launch_bwdf2_br<1, 4, false>(a, stream);
-  if (a.d <= 16) return launch_bwdf2_br<1, 8, false>(a, stream);
-  if (a.d <= 32) return launch_bwdf2_br<1, 16, false>(a, stream);
-  return launch_bwdf2_br<2, 16, false>(a, stream);
+  if (a.dx_out != nullptr) {  // method kl: + d loss / d x_t of the inference network's terms
+    if (a.d <= 4) return launch_bwdf2_br<1, 4, true, 2>(a, stream);
+    if (a.d <= 8) return launch_bwdf2_br<1, 4, false, 2>(a, stream);
+    if (a.d <= 16) return launch_bwdf2_br<1, 8, false, 2>(a, stream);
+    if (a.d <= 32) return launch_bwdf2_br<1, 16, false, 2>(a, stream);
+    return launch_bwdf2_br<2, 16, false, 2>(a, stream);
+  }
+  if (a.d <= 4) return launch_bwdf2_br<1, 4, true, 1>(a, stream);
+  if (a.d <= 8) return launch_bwdf2_br<1, 4, false, 1>(a, stream);
+  if (a.d <= 16) return launch_bwdf2_br<1, 8, false, 1>(a, stream);
+  if (a.d <= 32) return launch_bwdf2_br<1, 16, false, 1>(a, stream);
+  return launch_bwdf2_br<2, 16, false, 1>(a, stream);
 }
 
 bool bwdf2_fits(int d, int n_hidden) { return n_hidden >= 1 && n_hidden <= 2 && bwdf_fits(d, n_hidden); }  // (+ launch_bwdf2's own refusals)

@@ -234,6 +234,9 @@ struct BwdfArgs {
   const float* u_in;      // [T, d, B] (bridge_rowsf_kernel): the generative control of the forward launch
   float* gp_out;          // [T, d, B] (bridge_rowsf_kernel): u + v
   float* drnd_out;        // [T, B]    (bridge_rowsf_kernel): what the inference control adds to rnd at step t
+  float* dx_out;          // [T, d, B] or null (Bridge row-parallel kernel, method kl): d loss / d x_t of the inference network's terms
+  const float* cost_in;   // [T, d, B] or null (through time): the control entering the running cost, u + v, instead of u - reference control
+  const float* lam_in;    // [T, d, B] or null (through time): added to the adjoint at every step (the plane above)
   float* s_out;           // [3, 64, T * B] (divergence kernel): act''(Z_k) . d loss / d act'(Z_k), the term the base chain adds at layer k
   const float* s_in;      // the same planes, read by the row-parallel kernel
   float* div_hid;         // [n_slots][2][64][64]: the divergence term's direct gradient of the two hidden weights, per team

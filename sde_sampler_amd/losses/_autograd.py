@@ -55,7 +55,7 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
     return (zt, dt, dout, dgam) if xt is None else (zt, dt, dout, dgam, xt)
 
 
-def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torch.Tensor]:
+def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore, cost_ctrl=None, lam_extra=None) -> dict[int, torch.Tensor]:
     """Parameter gradients of the generative control from sdeh_ctrl_backward_fused (back-propagation and weight gradients in one
     kernel; csrc/sdeh_bwdf.hip) + sdeh_time_embed_backward on the two [T, .] tables."""
     ctrl, engine = loss.generative_ctrl, loss.engine
@@ -75,10 +75,11 @@ def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore) -> dict[int, torc
     noise = st["noise"]
     ptr = lambda t: None if t is None else t.data_ptr()
     with torch.cuda.device(dev):
-        L.check(lib.sdeh_ctrl_backward_fused(
+        # cost_ctrl / lam_extra [T, d, B] (split Bridge, method kl): the running cost on u + v, the inference terms' d loss / d x_t
+        L.check(lib.sdeh_ctrl_backward_fused_ex(
             plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
             None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
-            w.data_ptr(), ptr(sc), ptr(tscore), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
+            w.data_ptr(), ptr(sc), ptr(tscore), ptr(cost_ctrl), ptr(lam_extra), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
             torch.cuda.current_stream(dev).cuda_stream))
     return _fused_record_grads(ctrl, ts, out, d, T, Lh, g, score_model)
 
@@ -128,7 +129,7 @@ def _bridge_fused_ok(eng, inf_model, d, T, B, st) -> bool:
             and not (eng.options.get("SDEH_BWD_PLANES") or os.environ.get("SDEH_BWD_PLANES")) and 64 * T * B * 4 < 2 ** 32)
 
 
-def _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st, cm: bool = False) -> dict[int, torch.Tensor] | None:
+def _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st, cm: bool = False, dx_out=None) -> dict[int, torch.Tensor] | None:
     """Every gradient of a 64-channel Bridge's inference network from sdeh_bridge_backward_fused (csrc/sdeh_bridgef.hip: no
     per-coordinate planes), or None where that path is not compiled (then: sdeh_ctrl_backward_ex + sdeh_bridge_div_backward)."""
     base = inf.base_model
@@ -153,7 +154,7 @@ def _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st, cm: bool 
         L.check(lib.sdeh_bridge_backward_fused(
             plan.handle, C.byref(pr_v), keep_v.ptr(ts.reshape(-1), dev, "ts"), T, xs_cm.data_ptr(), B,
             None if noise is None else keep_v.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
-            w.data_ptr(), gp_cm.data_ptr(), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
+            w.data_ptr(), gp_cm.data_ptr(), None if dx_out is None else dx_out.data_ptr(), scratch.data_ptr(), scratch.numel(), out.data_ptr(),
             torch.cuda.current_stream(dev).cuda_stream))
     return _fused_record_grads(inf, ts, out, d, T, Lh, g, score_model, div=True)
 
@@ -633,19 +634,23 @@ class _BridgeSplitFn(torch.autograd.Function):
         kw.pop("inference_ctrl")
         keep = E._Keep()
         pr_u = eng.build_problem(device=dev, keep=keep, **kw)
-        grads = _fused_backward(loss, pr_u, keep, ts, xs_cm, w, st, sc, tscore)
         pr_v, keep_v, inf = _inference_problem(eng, st["problem_kwargs"], dev)
-        inf_grads = _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs_cm, gp_cm, w, st, cm=True)
+        lv = bool(kw["flags"] & L.FLAG_CHANGE_SDE_CTRL)
+        # kl / kl_ito: the inference terms' d loss / d x_t (row-parallel: v does not drive the SDE) joins the generative network's adjoint, whose
+        # running cost is taken on u + v
+        dx = None if lv else torch.empty_like(gp_cm)
+        inf_grads = _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs_cm, gp_cm, w, st, cm=True, dx_out=dx)
         if inf_grads is None:
             raise RuntimeError("split Bridge backward: sdeh_bridge_backward_fused refused a problem its forward half accepted")
+        grads = _fused_backward(loss, pr_u, keep, ts, xs_cm, w, st, sc, tscore, cost_ctrl=None if lv else gp_cm, lam_extra=dx)
         grads.update(inf_grads)
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 
 
 def _bridge_split_ok(loss, ts, x, inference_ctrl, flags: int, div_noise) -> bool:
-    """Does the split path serve this Bridge training call?  lv, exact divergence, both networks of 64 channels, the inference network with
+    """Does the split path serve this Bridge training call?  Exact divergence, both networks of 64 channels, the inference network with
     two hidden layers, the generative problem one the fused backward takes (checked on the plain problem itself by the caller)."""
-    if not (flags & L.FLAG_CHANGE_SDE_CTRL) or div_noise is not None or os.environ.get("SDEH_BRIDGE_SEQ"):  # (A/B aid: the step-sequential forward)
+    if div_noise is not None or os.environ.get("SDEH_BRIDGE_SEQ"):  # (A/B aid: the step-sequential forward)
         return False
     gen, inf_model = loss.generative_ctrl.base_model, inference_ctrl.base_model
     T, (B, d) = ts.numel() - 1, x.shape

@@ -45,25 +45,30 @@ def _grads(spec, x0_seed, mode, monkeypatch):
     return val.item(), {k: (None if p.grad is None else p.grad.clone()) for k, p in params}, prob.loss.engine.last_kernel_name()
 
 
+@pytest.mark.parametrize("method", ["lv", "kl"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
-def test_fused_bridge_backward_equals_the_plane_kernels(case, monkeypatch):
+def test_fused_bridge_backward_equals_the_plane_kernels(case, method, monkeypatch):
+    """lv: row-parallel everywhere.  kl: the generative network's back-propagation through time takes its running cost on u + v and the
+    inference terms' d loss / d x_t from the row-parallel Bridge kernel (sdeh_ctrl_backward_fused_ex)."""
     name, tspec, d, B, T, ikind, clip = case
     ictrl = dict(kind=ikind, clip_model=clip)
     if ikind == "lerp_prior":
         ictrl.update(clip_score=10.0, scale_score=1.0, gamma_dim=(d if name == "mw_d5_clamps" else 1), gamma_bias=1.0)
     spec = dict(batch=B, target=tspec, prior=dict(kind="iso_gauss", dim=d), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
                 ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
-                inference_ctrl=ictrl, net=NET, loss=dict(kind="time_reversal", method="lv", max_rnd=1e8),
+                inference_ctrl=ictrl, net=NET, loss=dict(kind="time_reversal", method=method, max_rnd=1e8 if method == "lv" else None),
                 grid=dict(start=0.0, end=1.0, steps=T))
+    bar = 5e-5  # measured: <= 1.9e-5 (lv), <= 1.1e-5 (kl)
     v_p, g_p, _ = _grads(spec, 5, "planes", monkeypatch)
-    for mode in ("split", "seq"):
+    for mode in (("split", "seq") if method == "lv" else ("split",)):
         v_f, g_f, kern = _grads(spec, 5, mode, monkeypatch)
         if mode == "seq":
             assert v_f == v_p  # the same forward launch
         else:  # rnd = plain launch + row-parallel sums: another summation order
             assert abs(v_f - v_p) <= 2e-5 * max(1.0, abs(v_p)), (v_f, v_p)
-            measured(f"bridge_split_loss/{name}", abs(v_f - v_p) / max(1.0, abs(v_p)), 2e-5)
-        assert kern.startswith("bridge_bwd_fused"), kern
+            measured(f"bridge_split_loss/{method}/{name}", abs(v_f - v_p) / max(1.0, abs(v_p)), 2e-5)
+        # (split: the generative network's fused backward is the last launch; seq: the inference network's)
+        assert kern.startswith("bwd_fused" if mode == "split" else "bridge_bwd_fused"), kern
         worst = 0.0
         for k in g_p:
             assert (g_f[k] is None) == (g_p[k] is None), (mode, k)
@@ -75,8 +80,8 @@ def test_fused_bridge_backward_equals_the_plane_kernels(case, monkeypatch):
                 continue
             err = (g_f[k] - g_p[k]).abs().max().item() / scale
             worst = max(worst, err)
-            assert err <= 5e-5, (mode, k, err)
-        measured(f"bridge_{mode}_vs_planes/{name}", worst, 5e-5)
+            assert err <= bar, (mode, k, err)
+        measured(f"bridge_{mode}_vs_planes/{method}/{name}", worst, bar)
 
 
 @pytest.mark.parametrize("case", [CASES[0], CASES[3], CASES[5]], ids=lambda c: c[0])
@@ -114,3 +119,31 @@ def test_split_bridge_evaluation_equals_the_step_sequential_kernel(case, monkeyp
     err = ((out["split"][1] - out["seq"][1]).abs() / scale).max().item()
     measured(f"bridge_split_eval_rnd/{name}", err, 1e-4)
     assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("opt", [None, "SDEH_BWD_V1", "SDEH_BWD_V2"])
+def test_split_bridge_kl_at_a_batch_of_whole_tile_teams(opt, monkeypatch):
+    """Method kl above 16 384 trajectories: the generative network's back-propagation through time runs on tiles of 32 -- trajectory-split
+    teams (csrc/sdeh_bwdf2.hip, from 513 tiles on) or channel-split ones (csrc/sdeh_bwdf.hip; plan option) -- with the running cost on u + v and the
+    inference terms' d loss / d x_t (ragged last tile: lanes beyond the batch must add nothing)."""
+    d, B, T = 10, 16400 + 7, 3
+    spec = dict(batch=B, target=dict(kind="funnel", dim=d), prior=dict(kind="iso_gauss", dim=d),
+                sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+                ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                inference_ctrl=dict(kind="lerp_prior", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                net=NET, loss=dict(kind="time_reversal", method="kl", max_rnd=None), grid=dict(start=0.0, end=1.0, steps=T))
+    v_p, g_p, _ = _grads(spec, 5, "planes", monkeypatch)
+    if opt is not None:
+        monkeypatch.setenv(opt, "1")
+    v_f, g_f, kern = _grads(spec, 5, "split", monkeypatch)
+    assert kern == ("bwd_fused<bptt,tiles=1,chan-split>" if opt == "SDEH_BWD_V1" else "bwd_fused<bptt,tiles=1,traj-split>"), kern
+    assert abs(v_f - v_p) <= 2e-5 * max(1.0, abs(v_p)), (v_f, v_p)
+    worst = 0.0
+    for k in g_p:
+        if g_p[k] is None:
+            continue
+        scale = g_p[k].abs().max().item()
+        err = (g_f[k] - g_p[k]).abs().max().item() / max(scale, 1e-30)
+        worst = max(worst, err)
+        assert err <= 5e-5, (k, err)
+    measured(f"bridge_split_vs_planes/kl/tiles32/{opt}", worst, 5e-5)

@@ -336,6 +336,38 @@ def extra_block(device, B: int) -> dict:
             "dominant_frac_executed": f_exec * rows / (min(t_k[1:]) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
             "backward_frac_algorithmic": f_bwd * rows / (min(t_b[1:]) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
         del prob, x0
+    # A 64-channel Bridge (conf/solver/bridge.yaml / basic_bridge.yaml with the shipped networks; funnel d = 10 and a d = 50 Gaussian, T = 200):
+    # loss + backward of one step, wall clock on HIP events.  Forward = plain launch + row-parallel inference pass, backward = the two fused
+    # kernels (DESIGN.md 3e'); "dominant" = the divergence backward launch group of csrc/sdeh_bridgef.hip, 6 x 2 x 64 x 64 FLOPs per (row, coordinate).
+    for d, bt, method in ((10, 2048, "lv"), (10, 2048, "kl"), (50, 16384, "lv")):
+        tspec = dict(kind="funnel", dim=d) if d == 10 else dict(kind="iso_gauss", dim=d, loc=1.0, scale=0.5)
+        ctrl = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
+        spec = dict(batch=bt, target=tspec, prior=dict(kind="iso_gauss", dim=d), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+                    ctrl=dict(kind="lerp_target", **ctrl), inference_ctrl=dict(kind="lerp_prior", **ctrl),
+                    net=dict(channels=64, num_layers=4, activation="gelu"),
+                    loss=dict(kind="time_reversal", method=method, max_rnd=1e8 if method == "lv" else None), grid=dict(start=0.0, end=1.0, steps=200))
+        prob = problems.build(spec, device=device)
+        inf = prob.loss.inference_ctrl
+        x0 = prob.prior.sample((bt,))
+        t_f, t_b = [], []
+        for rep in range(4):
+            prob.ctrl.zero_grad()
+            inf.zero_grad()
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record()
+            val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
+            e1.record()
+            val.backward()
+            e2.record()
+            e2.synchronize()
+            t_f.append(e0.elapsed_time(e1))
+            t_b.append(e1.elapsed_time(e2))
+        rows = bt * 200
+        out[f"train_step_bridge64_d{d}_b{bt}_{method}"] = {
+            "method": method, "batch": bt, "steps": 200, "dim": d, "forward_ms": min(t_f[1:]), "backward_ms": min(t_b[1:]),
+            "step_ms": min(f + b for f, b in zip(t_f[1:], t_b[1:])),
+            "backward_frac_by_divergence_flops": 6 * 2 * 64 * 64 * d * rows / (min(t_b[1:]) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+        del prob, x0
     return out
 
 

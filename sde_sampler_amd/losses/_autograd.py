@@ -654,6 +654,8 @@ def _bridge_split_ok(loss, ts, x, inference_ctrl, flags: int, div_noise) -> bool
         return False
     gen, inf_model = loss.generative_ctrl.base_model, inference_ctrl.base_model
     T, (B, d) = ts.numel() - 1, x.shape
+    if not (flags & L.FLAG_CHANGE_SDE_CTRL) and len(gen.hidden_layer) != 2:  # kl: the through-time kernels take u + v / d loss / d x_t planes
+        return False                                                          # for two hidden layers (template KLB)
     return (gen.channels == 64 and 64 * B * 4 < 2 ** 32
             and _bridge_fused_ok(loss.engine, inf_model, d, T, B, dict(div_noise=div_noise)))
 

@@ -118,6 +118,26 @@ def test_sinkhorn_converged_cost_matches_exact_1d_transport():
     assert Sinkhorn(eps=0.05, max_iters=500)(x, x.clone()).item() < 0.05  # a cloud against itself
 
 
+@pytest.mark.parametrize("d,n,eps", [(2, 128, 0.02), (5, 160, 0.05)])
+def test_sinkhorn_cost_brackets_the_exact_assignment_cost(d, n, eps):
+    """d > 1, uniform weights, n = m: the exact optimal-transport cost is an assignment problem (scipy.optimize.linear_sum_assignment on
+    the Euclidean cost matrix).  The entropic plan's transport cost <P, M> -- what eval/sinkhorn.py:169-177 returns -- lies in
+    [OT, OT + eps log n] once the potentials have settled: an anchor that depends on no restatement of the reference's iteration."""
+    import math
+
+    from scipy.optimize import linear_sum_assignment
+
+    from sde_sampler_amd.eval.sinkhorn import Sinkhorn
+
+    torch.manual_seed(d)
+    x, y = torch.randn(n, d) * 1.5, torch.randn(n, d) + 0.7
+    M = torch.cdist(x.double(), y.double()).numpy()
+    r, c = linear_sum_assignment(M)
+    exact = float(M[r, c].mean())
+    got = Sinkhorn(eps=eps, max_iters=3000, stop_thresh=1e-6)(x.to(DEV), y.to(DEV)).item()
+    assert exact - 1e-3 <= got <= exact + eps * math.log(n), (got, exact)
+
+
 def test_sinkhorn_reference_settings_against_dense_oracle():
     """conf/base.yaml:13-15 instantiates Sinkhorn() with its defaults (eps = 1e-3, at most 100 iterations) -- far from
     converged at that eps, so the value is that of the 100th iterate: compared with the fp64 dense oracle's 100th iterate."""

@@ -7,8 +7,10 @@ only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
                      be executed here.  The restatement follows the published algorithm line by line with the LazyTensor
                      reductions replaced by dense torch.logsumexp / sum / argmax, and is anchored on (a) the reference's call
                      site (`eval_sample_losses.sinkhorn(samples, gt_samples)`, eval/metrics.py:165-170, default arguments
-                     p=2, eps=1e-3, max_iters=100, stop_thresh=1e-5 from conf/base.yaml:13-15) and (b) the closed form of the
-                     1-D optimal-transport cost (tests/test_hip_eval.py).
+                     p=2, eps=1e-3, max_iters=100, stop_thresh=1e-5 from conf/base.yaml:13-15), (b) the closed form of the
+                     1-D optimal-transport cost (tests/test_hip_eval.py) and (c) the exact assignment cost in d > 1
+                     (scipy.optimize.linear_sum_assignment): the entropic plan's cost lies in [OT, OT + eps log n]
+                     (tests/test_oracle_golden.py, tests/test_hip_eval.py).
   metrics_reference_keys()  restatement of get_metrics (eval/metrics.py:70-184) -- PINNED: bit-compared (to fp32 rounding of
                      the reductions) with the output of the reference's own get_metrics in tests/golden/metrics_*.npz
                      (tests/golden/make_golden_metrics.py).

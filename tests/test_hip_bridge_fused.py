@@ -20,6 +20,12 @@ CASES = [
     ("funnel_d10", dict(kind="funnel", dim=10), 10, 1100, 6, "lerp_prior", 10.0),
     ("gauss_d20", dict(kind="iso_gauss", dim=20, loc=1.0, scale=0.5), 20, 96, 5, "lerp_prior", 10.0),
     ("gauss_d50", dict(kind="iso_gauss", dim=50, loc=1.0, scale=0.5), 50, 150, 4, "lerp_prior", 10.0),
+    # other activations, an SDE with sigma(t) and a drift, active clamps of the inference control's score term
+    ("gauss_d6_silu", dict(kind="iso_gauss", dim=6, loc=1.0, scale=0.5), 6, 130, 5, "lerp_prior", 10.0, dict(activation="silu")),
+    ("gauss_d6_relu", dict(kind="iso_gauss", dim=6, loc=1.0, scale=0.5), 6, 130, 5, "lerp_prior", 10.0, dict(activation="relu")),
+    ("gauss_d9_vp", dict(kind="iso_gauss", dim=9, loc=1.0, scale=0.5), 9, 100, 6, "lerp_prior", 10.0,
+     dict(sde=dict(kind="vp", beta_min=0.1, beta_max=6.0, scale=1.0, terminal_t=1.0, generative=True))),
+    ("gauss_d7_score_clamps", dict(kind="iso_gauss", dim=7, loc=1.0, scale=0.5), 7, 90, 5, "lerp_prior", 10.0, dict(inf_clip_score=0.4)),
 ]
 
 
@@ -50,13 +56,15 @@ def _grads(spec, x0_seed, mode, monkeypatch):
 def test_fused_bridge_backward_equals_the_plane_kernels(case, method, monkeypatch):
     """lv: row-parallel everywhere.  kl: the generative network's back-propagation through time takes its running cost on u + v and the
     inference terms' d loss / d x_t from the row-parallel Bridge kernel (sdeh_ctrl_backward_fused_ex)."""
-    name, tspec, d, B, T, ikind, clip = case
+    name, tspec, d, B, T, ikind, clip = case[:7]
+    over = case[7] if len(case) > 7 else {}
     ictrl = dict(kind=ikind, clip_model=clip)
     if ikind == "lerp_prior":
-        ictrl.update(clip_score=10.0, scale_score=1.0, gamma_dim=(d if name == "mw_d5_clamps" else 1), gamma_bias=1.0)
-    spec = dict(batch=B, target=tspec, prior=dict(kind="iso_gauss", dim=d), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+        ictrl.update(clip_score=over.get("inf_clip_score", 10.0), scale_score=1.0, gamma_dim=(d if name == "mw_d5_clamps" else 1), gamma_bias=1.0)
+    spec = dict(batch=B, target=tspec, prior=dict(kind="iso_gauss", dim=d),
+                sde=over.get("sde", dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0)),
                 ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
-                inference_ctrl=ictrl, net=NET, loss=dict(kind="time_reversal", method=method, max_rnd=1e8 if method == "lv" else None),
+                inference_ctrl=ictrl, net=dict(NET, activation=over.get("activation", "gelu")), loss=dict(kind="time_reversal", method=method, max_rnd=1e8 if method == "lv" else None),
                 grid=dict(start=0.0, end=1.0, steps=T))
     bar = 5e-5  # measured: <= 1.9e-5 (lv), <= 1.1e-5 (kl)
     v_p, g_p, _ = _grads(spec, 5, "planes", monkeypatch)
@@ -91,7 +99,7 @@ def test_split_bridge_evaluation_equals_the_step_sequential_kernel(case, monkeyp
     another summation order."""
     from sde_sampler_amd import problems
 
-    name, tspec, d, B, T, ikind, clip = case
+    name, tspec, d, B, T, ikind, clip = case[:7]
     ictrl = dict(kind=ikind, clip_model=clip, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
     spec = dict(batch=B, target=tspec, prior=dict(kind="iso_gauss", dim=d), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
                 ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),

@@ -9,8 +9,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sde_sampler_amd import problems  # noqa: E402
 
-for name in ("cfg1_dw_dis_lv", "cfg4_funnel_dds_lv", "cfg2_gmm2_dis_kl"):
-    for B in (6000, 8192, 12288, 16384, 24576):
+for name in ("cfg1_dw_dis_lv", "cfg4_funnel_dds_lv", "cfg2_gmm2_dis_kl", "cfg3_gmm50_pis_kl", "gmm50_pis_headline"):
+    for B in (512, 2048, 6000, 8192, 12288, 16384, 24576):
         line = f"{name:20s} B={B:6d}:"
         for quad in ("0", "1"):
             os.environ["SDEH_WS_QUAD"] = quad

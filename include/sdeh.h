@@ -29,7 +29,10 @@ extern "C" {
 #endif
 
 /* v4 (round 3): sdeh_ctrl_backward_ex gained xt_out / sc_in / tscore_in; wide-network training entry points
- * (sdeh_bridge_div_backward_wide[_sizes]); sdeh_simulate_fwd_aux2. */
+ * (sdeh_bridge_div_backward_wide[_sizes]); sdeh_simulate_fwd_aux2.
+ * v5 (round 4): sdeh_plan_set_option / sdeh_plan_reserve / SdehPlanDesc.max_batch (kernel-mode options and batch-dependent scratch live in
+ * the plan; nothing on the launch path reads the environment or allocates); the 64-channel Bridge as a split -- sdeh_simulate_fwd_train2u,
+ * sdeh_bridge_inference_fwd, sdeh_bridge_backward_fused[_sizes], sdeh_ctrl_backward_fused_ex. */
 #define SDEH_ABI_VERSION 5
 #define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
 

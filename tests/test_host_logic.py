@@ -330,3 +330,41 @@ def test_problem_description_cache_follows_the_objects():
         prob.target.loc[0, 0] += 1.0  # values of a table the description depends on (mixture structure): version bump
     eng.build_problem(keep=E._Keep(), **kw)
     assert len(n_described) == 5
+
+
+def test_split_bridge_path_selection(monkeypatch):
+    """Which Bridge training calls take the split (plain launch + row-parallel inference pass, fused backwards: losses/_autograd.py) --
+    decided on the host from the objects alone: 64 channels, a two-hidden-layer inference network, the exact divergence; method kl also
+    needs a two-hidden-layer generative network (the through-time kernels' KLB instantiations); the A/B switches turn it off."""
+    from sde_sampler_amd import _lib as L
+    from sde_sampler_amd import problems
+    from sde_sampler_amd.losses import _autograd as A
+
+    def bridge(num_layers_gen=4, num_layers_inf=4, channels=64):
+        lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)
+        spec = dict(batch=64, target=dict(kind="funnel", dim=10), prior=dict(kind="iso_gauss", dim=10),
+                    sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0), ctrl=dict(kind="lerp_target", **lerp),
+                    inference_ctrl=dict(kind="lerp_prior", **lerp), net=dict(channels=channels, num_layers=num_layers_gen, activation="gelu"),
+                    loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=8))
+        prob = problems.build(spec)
+        if num_layers_inf != num_layers_gen:
+            spec_i = dict(spec, net=dict(channels=channels, num_layers=num_layers_inf, activation="gelu"))
+            prob.loss.inference_ctrl = problems.build(spec_i).loss.inference_ctrl
+        return prob
+
+    monkeypatch.delenv("SDEH_BRIDGE_SEQ", raising=False)
+    monkeypatch.delenv("SDEH_BWD_PLANES", raising=False)
+    prob = bridge()
+    x = torch.zeros(64, 10)
+    lv, kl = L.FLAG_CHANGE_SDE_CTRL, 0
+    ok = lambda p, flags, dn=None: A._bridge_split_ok(p.loss, p.ts, x, p.loss.inference_ctrl, flags, dn)
+    assert ok(prob, lv) and ok(prob, kl)
+    assert not ok(prob, lv, torch.zeros(8, 64, 10))  # Hutchinson probes: the step-sequential kernel
+    deep = bridge(num_layers_gen=5)                     # three hidden layers in the generative network
+    assert ok(deep, lv) and not ok(deep, kl)
+    assert not ok(bridge(num_layers_inf=3), lv)         # a one-hidden-layer inference network
+    monkeypatch.setenv("SDEH_BRIDGE_SEQ", "1")
+    assert not ok(prob, lv)
+    monkeypatch.delenv("SDEH_BRIDGE_SEQ")
+    monkeypatch.setenv("SDEH_BWD_PLANES", "1")
+    assert not ok(prob, lv) and not ok(prob, kl)

@@ -32,8 +32,10 @@ extern "C" {
  * (sdeh_bridge_div_backward_wide[_sizes]); sdeh_simulate_fwd_aux2.
  * v5 (round 4): sdeh_plan_set_option / sdeh_plan_reserve / SdehPlanDesc.max_batch (kernel-mode options and batch-dependent scratch live in
  * the plan; nothing on the launch path reads the environment or allocates); the 64-channel Bridge as a split -- sdeh_simulate_fwd_train2u,
- * sdeh_bridge_inference_fwd, sdeh_bridge_backward_fused[_sizes], sdeh_ctrl_backward_fused_ex. */
-#define SDEH_ABI_VERSION 5
+ * sdeh_bridge_inference_fwd, sdeh_bridge_backward_fused[_sizes], sdeh_ctrl_backward_fused_ex.
+ * v6 (round 5): the training forward keeps the network's pre-activations and the fused backward reads them instead of re-evaluating the
+ * network -- sdeh_zrec_floats, sdeh_simulate_fwd_train3, sdeh_ctrl_backward_fused_z; plan option SDEH_BWD_ZREC. */
+#define SDEH_ABI_VERSION 6
 #define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
 
 typedef enum {
@@ -217,7 +219,7 @@ int32_t sdeh_plan_reserve(SdehPlan* plan, int64_t max_batch);
  *   SDEH_WS_GROUPS ("2" | "4" | "2h" | "4h" | "p")    SDEH_WS_QUAD ("0" | "1")      SDEH_WS_VOUT ("0")      SDEH_WS_BARRIER
  *   SDEH_BWD_PLANES (plane-writing backward)         SDEH_BWD_TILE ("16" | "32")   SDEH_BWD_WAVES ("2" | "4")
  *   SDEH_BWD_V1 / SDEH_BWD_V2 (channel- / trajectory-split fused backward)        SDEH_BWD_NO_VIO      SDEH_BWD_SCAN ("0" | "1": the
- *   scan form of back-propagation through time, d <= 4)
+ *   scan form of back-propagation through time, d <= 4)        SDEH_BWD_ZREC ("0": the fused backward ignores the pre-activation record)
  *   SDEH_BRIDGE_TILES ("64" | "32g")   SDEH_BRIDGE_SPLIT ("1" | "4")   SDEH_WIDE_CT ("1" | "2")   SDEH_WIDE_SPLIT ("1" | "2" | "4" | "8")
  * Unknown names: SDEH_ERR_INVALID. */
 int32_t sdeh_plan_set_option(SdehPlan* plan, const char* name, const char* value);
@@ -412,6 +414,31 @@ int32_t sdeh_bridge_div_backward(SdehPlan* plan, const SdehProblem* problem, con
 int32_t sdeh_simulate_fwd_train2u(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* x0,
                                   int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                                   float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, void* stream);
+/* ABI v6.  The training forward that also KEEPS THE NETWORK'S PRE-ACTIVATIONS, and the fused backward that reads them.  The reference's
+ * autograd keeps every layer's activations between loss(...) and loss.backward() (losses/oc.py:232-256 -> models/mlp.py:114-122 through
+ * solver/base.py:399-407); sdeh_simulate_fwd_train2 + sdeh_ctrl_backward_fused re-evaluate the network per step instead (1.7 x the
+ * algorithmic matrix work of the backward).  sdeh_simulate_fwd_train3 == sdeh_simulate_fwd_train2u (u may be NULL) that also writes
+ *   zrec [n_steps][ceil(batch / 32)][n_hidden + 1][16][32][4]   the pre-activations Z_k of the generative network: per (step, tile of 32
+ *        trajectories, layer k) channel quad cq (channels 4 cq .. 4 cq + 3) of trajectory j at [cq][j][0..3] -- the register layout of the
+ *        kernels on both sides (16-byte accesses, 1 KB contiguous per instruction); sdeh_zrec_floats(n_hidden, n_steps, batch) floats
+ *   nn   [n_steps, d, batch]   the raw network output (before the clamp), coordinate-major
+ * and returns 0 (everything kept) or 1 (served by a kernel that keeps nothing: mixture tables beyond LDS).
+ * sdeh_ctrl_backward_fused_z == sdeh_ctrl_backward_fused_ex that is also given zrec / nn (both or neither; NULL = _ex): the launches that
+ * can read the record do not re-evaluate the network (act / act' from the stored Z_k: a ReLU unit on its kink takes the forward launch's
+ * side by construction); the others ignore it.  Same scratch / out as sdeh_ctrl_backward_fused. */
+int64_t sdeh_zrec_floats(int32_t n_hidden, int32_t n_steps, int64_t batch);
+/* 1 when the launch that serves sdeh_ctrl_backward_fused_z for this problem and batch reads the record (so that the forward only keeps
+ * what will be read), 0 when it would be ignored. */
+int32_t sdeh_ctrl_backward_fused_reads_zrec(const SdehPlan* plan, const SdehProblem* problem, int64_t batch);
+int32_t sdeh_simulate_fwd_train3(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* x0,
+                                 int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                 float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, float* zrec, float* nn,
+                                 void* stream);
+int32_t sdeh_ctrl_backward_fused_z(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
+                                   int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                   const float* grad_rnd, const float* sc, const float* tscore, const float* cost_ctrl,
+                                   const float* lam_extra, const float* zrec, const float* nn, float* scratch, int64_t scratch_floats,
+                                   float* out, void* stream);
 int64_t sdeh_bridge_inference_fwd_scratch_floats(int32_t n_steps, int64_t batch);
 int32_t sdeh_bridge_inference_fwd(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
                                   int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, const float* u,

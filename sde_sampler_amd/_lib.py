@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from pathlib import Path
 
-SDEH_ABI_VERSION = 5
+SDEH_ABI_VERSION = 6
 SDEH_MAX_HIDDEN = 8
 SDEH_REDUCE_SCRATCH = 8192
 
@@ -108,7 +108,7 @@ class SdehUnsupported(SdehError, NotImplementedError):
 # override -- the binding copies them into the plan before a launch whenever they changed, the library itself never reads them on
 # the launch path
 PLAN_OPTIONS = ("SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES",
-                "SDEH_BWD_TILE", "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT",
+                "SDEH_BWD_TILE", "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BWD_ZREC", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT",
                 "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT")
 
 # every symbol include/sdeh.h declares, with its prototype
@@ -158,6 +158,12 @@ PROTOTYPES = {
                                                C.c_int64, fp, fp, fp, fp, C.c_int64, fp, C.c_void_p]),
     "sdeh_ctrl_backward_fused_ex": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64, C.c_uint64,
                                                 C.c_int64, fp, fp, fp, fp, fp, fp, C.c_int64, fp, C.c_void_p]),
+    "sdeh_zrec_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
+    "sdeh_ctrl_backward_fused_reads_zrec": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), C.c_int64]),
+    "sdeh_simulate_fwd_train3": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64, C.c_uint64,
+                                             C.c_int64, fp, fp, fp, fp, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_ctrl_backward_fused_z": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64, C.c_uint64,
+                                               C.c_int64, fp, fp, fp, fp, fp, fp, fp, fp, C.c_int64, fp, C.c_void_p]),
     "sdeh_integrate": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), C.c_int32, fp, C.c_int32, fp, C.c_int32, C.c_float,
                                    fp, C.c_int64, fp, C.c_uint64, C.c_uint64, C.c_int64, fp, C.c_void_p]),
     "sdeh_sinkhorn_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64]),

@@ -255,7 +255,7 @@ struct OptScope {
 };
 static const char* const kOptNames[OPT_COUNT] = {
     "SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES", "SDEH_BWD_TILE",
-    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT"};
+    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BWD_ZREC", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT"};
 static void opt_store(PlanOptions& o, int key, const char* value) {
   memset(o.v[key], 0, sizeof(o.v[key]));
   if (value != nullptr) strncpy(o.v[key], value, sizeof(o.v[key]) - 1);
@@ -740,7 +740,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                          float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, float* zt_out, float* nn_out,
                          bool* planes_written, void* stream, float* sc_out = nullptr, float* tsc_out = nullptr, float* xs_cm = nullptr,
-                         float* u_out = nullptr) {
+                         float* u_out = nullptr, float* zrec = nullptr, float* nn_cm = nullptr) {
   OptScope opt_scope(plan);
   if (planes_written != nullptr) *planes_written = false;
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
@@ -800,12 +800,14 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   } else {
     A.zt_out = zt_out; A.nn_out = nn_out;  // only the wave-specialised kernel writes the training planes
     A.sc_out = sc_out; A.tsc_out = tsc_out; A.xs_cm = xs_cm; A.u_out = u_out;
+    A.zrec = zrec; A.nn_cm = nn_cm;
     rc = v->fn(A, st);
     if (rc == SDEH_OK && planes_written != nullptr)
       *planes_written = (zt_out != nullptr && nn_out != nullptr) || xs_cm != nullptr;
     // image + exchange buffers beyond 160 KiB (deep networks): the single-wave kernel needs less LDS
     if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) {
       A.zt_out = nullptr; A.nn_out = nullptr; A.sc_out = nullptr; A.tsc_out = nullptr; A.xs_cm = nullptr; A.u_out = nullptr;
+      A.zrec = nullptr; A.nn_cm = nullptr;
       if (planes_written != nullptr) *planes_written = false;
       rc = plan->variant->fn_legacy(A, st);
       snprintf(plan->last_kernel, sizeof(plan->last_kernel), "traj_legacy<%s>", plan->variant->name);
@@ -876,6 +878,29 @@ int32_t sdeh_simulate_fwd_train2u(SdehPlan* plan, const SdehProblem* pr, const f
                                nullptr, nullptr, &written, stream, sc, tscore, xs, u);
   if (rc != SDEH_OK) return rc;
   return written ? SDEH_OK : 1;
+}
+
+int64_t sdeh_zrec_floats(int32_t n_hidden, int32_t n_steps, int64_t batch) {
+  if (n_hidden < 0 || n_steps < 1 || batch < 1) return 0;
+  return (int64_t)n_steps * ((batch + 31) / 32) * (n_hidden + 1) * 2048;
+}
+
+int32_t sdeh_simulate_fwd_train3(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
+                                 int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                 float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, float* zrec, float* nn,
+                                 void* stream) {
+  if (xs == nullptr || zrec == nullptr || nn == nullptr)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_train3: xs, zrec and nn are required (sdeh_simulate_fwd_train2[u] keeps the planes without them)");
+  if (pr != nullptr && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train3: the problem WITHOUT its inference control (sdeh_bridge_inference_fwd adds its terms)");
+  if (plan != nullptr && plan->wide) return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train3: 64-channel plans");
+  if (pr != nullptr && pr->ctrl_kind != SDEH_CTRL_CLIPPED && sc == nullptr)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_train3: sc is required for controls with a score term");
+  bool written = false;
+  const int rc = simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, &written, stream, sc, tscore, xs, u, zrec, nn);
+  if (rc != SDEH_OK) return rc;
+  return written ? SDEH_OK : 1;  // 1: integrated by a kernel that writes none of the planes
 }
 
 int32_t sdeh_ctrl_backward(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
@@ -1140,6 +1165,50 @@ int32_t sdeh_ctrl_backward_fused_supported(const SdehPlan* plan, const SdehProbl
   return 1;
 }
 
+// Which launch serves a fused backward (one place: sdeh_ctrl_backward_fused* and sdeh_ctrl_backward_fused_reads_zrec agree by construction)
+struct BwdfChoice {
+  int tile;    // trajectories per tile: 16 (sdeh_bwdf16.hip: small batches through time) or 32
+  bool scan;   // through time as a scan (d <= 4, sdeh_bwdf2.hip)
+  bool v2;     // tiles of 32: trajectory-split teams (sdeh_bwdf2.hip) instead of channel-split ones (sdeh_bwdf.hip)
+  bool zin;    // the launch reads the pre-activation record when it is given one
+};
+static BwdfChoice bwdf_choice(const SdehProblem* pr, long long batch, bool klb) {
+  const SdehFourierMLP& net = pr->base_model;
+  const int d = net.dim;
+  const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
+  BwdfChoice c;
+  c.tile = bwdf_tile(batch, bptt, net.activation);
+  // Through time with d <= 4 below the batch that fills the chip with whole-tile items: the SCAN form (sdeh_bwdf2.hip) -- two
+  // row-parallel network passes around a recursion on d numbers per trajectory instead of one dependent chain through the network per
+  // step.  Plan option SDEH_BWD_SCAN: "0" never, "1" at every batch.
+  const char* scan_opt = plan_opt(OPT_BWD_SCAN);
+  c.scan = bptt && bwdf2_scan_fits(d, net.n_hidden) && plan_opt(OPT_BWD_V1) == nullptr && plan_opt(OPT_BWD_TILE) == nullptr &&
+           (scan_opt != nullptr ? scan_opt[0] == '1' : batch <= 3072) && batch <= 65536;  // (measured, d = 2, T = 100: 0.20 / 0.41 / 0.65 ms at 512 / 2048 / 4096 against 0.59 / 0.59 / 0.60)
+  if (c.scan) c.tile = 32;
+  // tiles of 32: trajectory-split teams (sdeh_bwdf2.hip; at most as many partial records as the channel-split kernel, whose sizes
+  // the scratch was checked against) unless the network has three hidden layers; plan option SDEH_BWD_V1 keeps the channel-split kernel (A/B)
+  const bool force_v1 = plan_opt(OPT_BWD_V1) != nullptr, force_v2 = plan_opt(OPT_BWD_V2) != nullptr;
+  // (two coordinate tiles through time: the trajectory-split kernel still spills there and loses to the channel-split one -- 22 vs
+  // 15 ms at d = 50, B = 65 536; its funnel Jacobian would couple the two tiles)
+  // Through time an item is a whole tile: the channel-split kernel gives every 32 trajectories two SIMDs and fills the chip with 512
+  // tiles in one round (1.5 ms at d = 2, T = 100), the trajectory-split one gives them one SIMD and needs 1024 (2.2 ms for up to 1024
+  // tiles against the channel-split kernel's two rounds = 3.1 ms): the latter from 513 tiles on.  Row-parallel launches always have
+  // items to spare.
+  const long long n_tiles = (batch + c.tile - 1) / c.tile;
+  const bool enough = !bptt || n_tiles > 512 || force_v2;
+  c.v2 = c.tile == 32 && !force_v1 && enough && bwdf2_fits(d, net.n_hidden) &&
+         (d <= 32 || (!bptt) || (force_v2 && pr->target.kind != SDEH_DENS_FUNNEL));
+  const char* zo = plan_opt(OPT_BWD_ZREC);
+  c.zin = (zo == nullptr || zo[0] != '0') && !klb && !c.scan && c.tile == 32 && c.v2;
+  return c;
+}
+
+int32_t sdeh_ctrl_backward_fused_reads_zrec(const SdehPlan* plan, const SdehProblem* pr, int64_t batch) {
+  OptScope opt_scope(plan);
+  if (batch < 1 || !sdeh_ctrl_backward_fused_supported(plan, pr)) return 0;
+  return bwdf_choice(pr, batch, false).zin ? 1 : 0;
+}
+
 static void bwdf_sizes(int d, int n_hidden, int n_steps, long long batch, int g, bool bptt, int tile, long long* wpart, long long* epart,
                        long long* gpart, long long* sums, long long* out) {
   const long long tiles = (batch + tile - 1) / tile, slots = tile == 16 ? bwdf16_slots(batch) : bwdf_slots(batch, n_steps, bptt);
@@ -1178,8 +1247,11 @@ int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_
 static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                                     int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                                     const float* grad_rnd, const float* sc, const float* tscore, const float* cost_ctrl, const float* lam_extra,
-                                    float* scratch, int64_t scratch_floats, float* out, void* stream) {
+                                    float* scratch, int64_t scratch_floats, float* out, void* stream, const float* zrec = nullptr,
+                                    const float* nn_in = nullptr) {
   OptScope opt_scope(plan);
+  if ((zrec != nullptr) != (nn_in != nullptr))
+    return fail(SDEH_ERR_INVALID, "ctrl_backward_fused_z: zrec and nn come together (both written by sdeh_simulate_fwd_train3)");
   if (xs == nullptr || grad_rnd == nullptr || scratch == nullptr || out == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: null argument");
   Checked ck;
@@ -1206,14 +1278,9 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   long long n_w, n_e, n_g, n_s, n_o;
-  int tile = bwdf_tile(batch, bptt, net.activation);  // 16: small batches through time (sdeh_bwdf16.hip)
-  // Through time with d <= 4 below the batch that fills the chip with whole-tile items: the SCAN form (sdeh_bwdf2.hip) -- two
-  // row-parallel network passes around a recursion on d numbers per trajectory instead of one dependent chain through the network per
-  // step.  Plan option SDEH_BWD_SCAN: "0" never, "1" at every batch.
-  const char* scan_opt = plan_opt(OPT_BWD_SCAN);
-  const bool scan = bptt && bwdf2_scan_fits(d, net.n_hidden) && plan_opt(OPT_BWD_V1) == nullptr && plan_opt(OPT_BWD_TILE) == nullptr &&
-                    (scan_opt != nullptr ? scan_opt[0] == '1' : batch <= 3072) && batch <= 65536;  // (measured, d = 2, T = 100: 0.20 / 0.41 / 0.65 ms at 512 / 2048 / 4096 against 0.59 / 0.59 / 0.60)
-  if (scan) tile = 32;
+  const BwdfChoice choice = bwdf_choice(pr, batch, cost_ctrl != nullptr);
+  const int tile = choice.tile;
+  const bool scan = choice.scan;
   bwdf_sizes(d, net.n_hidden, n_steps, batch, L.g == 1 ? 1 : 64, bptt && !scan, tile, &n_w, &n_e, &n_g, &n_s, &n_o);
   const long long n_planes = scan ? (long long)n_steps * batch * (d * d + 2 * d) : 0;
   if (scratch_floats < n_w + n_e + n_g + n_s + n_planes)
@@ -1233,6 +1300,8 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
   A.n_hidden = net.n_hidden;
   A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.sc = sc; A.tscore = tscore;
   A.cost_in = cost_ctrl; A.lam_in = lam_extra;
+  // the pre-activation record: the kernels that can read it do not re-evaluate the network (plan option SDEH_BWD_ZREC=0: ignore it)
+  if (choice.zin) { A.zrec = zrec; A.nn_in = nn_in; }
   A.wpart = scratch; A.epart = scratch + n_w; A.gpart = scratch + n_w + n_e;
   float* sums = scratch + n_w + n_e + n_g;
   A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d; A.n_kg = (d + 7) / 8;
@@ -1242,18 +1311,7 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
   A.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   A.n_tiles = (int)((batch + tile - 1) / tile);
-  // tiles of 32: trajectory-split teams (sdeh_bwdf2.hip; at most as many partial records as the channel-split kernel, whose sizes
-  // the scratch was checked against) unless the network has three hidden layers; plan option SDEH_BWD_V1 keeps the channel-split kernel (A/B)
-  const bool force_v1 = plan_opt(OPT_BWD_V1) != nullptr, force_v2 = plan_opt(OPT_BWD_V2) != nullptr;
-  // (two coordinate tiles through time: the trajectory-split kernel still spills there and loses to the channel-split one -- 22 vs
-  // 15 ms at d = 50, B = 65 536; its funnel Jacobian would couple the two tiles)
-  // Through time an item is a whole tile: the channel-split kernel gives every 32 trajectories two SIMDs and fills the chip with 512
-  // tiles in one round (1.5 ms at d = 2, T = 100), the trajectory-split one gives them one SIMD and needs 1024 (2.2 ms for up to 1024
-  // tiles against the channel-split kernel's two rounds = 3.1 ms): the latter from 513 tiles on.  Row-parallel launches always have
-  // items to spare.
-  const bool enough = !bptt || A.n_tiles > 512 || force_v2;
-  const bool v2 = tile == 32 && !force_v1 && enough && bwdf2_fits(d, net.n_hidden) &&
-                  (d <= 32 || (!bptt) || (force_v2 && pr->target.kind != SDEH_DENS_FUNNEL));
+  const bool v2 = choice.v2;
   A.n_slots = tile == 16 ? bwdf16_slots(batch) : (v2 ? bwdf2_slots(batch, n_steps, bptt) : bwdf_slots(batch, n_steps, bptt));
   A.wsize = bwdf_wsize(d, net.n_hidden);
   if (plan->timing) (void)hipEventRecord(plan->ev0, st);
@@ -1276,8 +1334,9 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
     rc = tile == 16 ? launch_bwdf16(A, st) : (v2 ? launch_bwdf2(A, st) : launch_bwdf(A, st));
   }
   if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
-  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused%s<%s,tiles=%d%s>", tile == 16 ? "16" : "", scan ? "bptt-scan" : (bptt ? "bptt" : "rows"),
-           d <= 32 ? 1 : 2, tile == 16 ? "" : (v2 || scan ? ",traj-split" : ",chan-split"));
+  const bool zin = A.zrec != nullptr;  // (the launch read the record)
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused%s<%s,tiles=%d%s%s>", tile == 16 ? "16" : "", scan ? "bptt-scan" : (bptt ? "bptt" : "rows"),
+           d <= 32 ? 1 : 2, tile == 16 ? "" : (v2 || scan ? ",traj-split" : ",chan-split"), zin ? ",zrec" : "");
   if (rc != SDEH_OK) return fail(rc, "ctrl_backward_fused: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   // deterministic sums over the teams / tiles
   float* s1 = sums;
@@ -1304,6 +1363,15 @@ int32_t sdeh_ctrl_backward_fused_ex(SdehPlan* plan, const SdehProblem* pr, const
                                     const float* lam_extra, float* scratch, int64_t scratch_floats, float* out, void* stream) {
   return ctrl_backward_fused_impl(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, sc, tscore, cost_ctrl, lam_extra,
                                   scratch, scratch_floats, out, stream);
+}
+
+int32_t sdeh_ctrl_backward_fused_z(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
+                                   int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
+                                   const float* grad_rnd, const float* sc, const float* tscore, const float* cost_ctrl,
+                                   const float* lam_extra, const float* zrec, const float* nn, float* scratch, int64_t scratch_floats,
+                                   float* out, void* stream) {
+  return ctrl_backward_fused_impl(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, sc, tscore, cost_ctrl, lam_extra,
+                                  scratch, scratch_floats, out, stream, zrec, nn);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -47,13 +47,22 @@ __device__ unsigned long long bwdf2_prof[16];
 // BR = 2: also d loss / d x_t of the inference network's terms (W_in^T adj(Z_0) + the score term's Jacobian) as a plane [T, d, B]: with method kl the
 // generative network's back-propagation through time adds it to its adjoint at every step.
 // KLB (through time, a Bridge's generative network with method kl): the running cost on the plane cost_in = u + v, lam_in added to the adjoint.
-template <int OTD, bool BPTT, int LH, bool RECOMP, int NQ, bool VIO, bool JAC = false, int BR = 0, bool KLB = false>
+// ZIN (round 5): the network is NOT re-evaluated.  The training forward (sdeh_simulate_fwd_train3) kept the
+// pre-activations of every layer as a record in this kernel's own register layout (sdeh_traj_ws.hpp: ZRec -- lane (j, h) of the wave that
+// owns a tile loads with eight 16-byte loads per layer exactly the 32 values of its accumulator tiles) and the raw network output [T, d, B].
+// The reference's autograd keeps the activations as well (losses/oc.py:232-256 -> models/mlp.py:114-122).  Z_k is requested one stage
+// ahead of the stage that needs act(Z_k) / act'(Z_k) and activated there: of the network only ONE layer's act' (32 registers) and the next
+// layer's Z (32) are alive at any time instead of act / act' of all layers (160), and the 2 Lh C^2 + 2 d C re-evaluated products per
+// trajectory-step are gone (1.70 x the algorithmic matrix work in round 4's PMC pass).  ReLU units on their kink take the forward
+// launch's side by construction.
+template <int OTD, bool BPTT, int LH, bool ZIN, int NQ, bool VIO, bool JAC = false, int BR = 0, bool KLB = false>
 __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   using namespace bwdf2;
   static_assert(OTD == 1 || NQ == 16, "two coordinate tiles: all registers live");
   static_assert(!JAC || (VIO && !BPTT), "the Jacobian pass is row-parallel, d <= 4");
   static_assert(!VIO || (OTD == 1 && NQ == 4), "vector-pipe in / out layers: d <= 4");
-  static_assert(!BR || (!BPTT && !JAC && !RECOMP), "the Bridge form is row-parallel");
+  static_assert(!BR || (!BPTT && !JAC && !ZIN), "the Bridge form is row-parallel (and re-evaluates the inference network)");
+  static_assert(!(ZIN && JAC), "the Jacobian pass re-evaluates");
   static_assert(!KLB || BPTT, "cost_in / lam_in belong to back-propagation through time");
   constexpr bool WDX = BPTT || BR == 2;  // the chain goes on through the input layer: W_in^T delta_0
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
@@ -213,14 +222,34 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     return c;
   };
 
-  f32x16 xnext[OTD], embnext[2];
+  // ZIN: layer k of the pre-activation record of (step t, tile): eight 16-byte loads per lane from a wave-uniform base (ZRec layout:
+  // [step][tile][layer][quad 8 R + 2 g + h][trajectory j][4]); every word is read once -- non-temporal
+  typedef float f32x4z __attribute__((ext_vector_type(4)));
+  auto load_z = [&](int t, long long tile_i, int k, f32x16 (&zo)[2]) {
+    if constexpr (ZIN) {
+      const float* __restrict__ base = A.zrec + (((long long)t * n_tiles + tile_i) * (LH + 1) + k) * 2048;
+      unsigned lo = (unsigned)(h * 128 + j * 4) * 4u;
+      asm volatile("" : "+v"(lo));
+      const char* __restrict__ pb = reinterpret_cast<const char*>(base) + lo;
+#pragma unroll
+      for (int R = 0; R < 2; ++R)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4z v = __builtin_nontemporal_load(reinterpret_cast<const f32x4z*>(pb + (R * 1024 + g * 256) * 4));
+          zo[R][4 * g] = v[0]; zo[R][4 * g + 1] = v[1]; zo[R][4 * g + 2] = v[2]; zo[R][4 * g + 3] = v[3];
+        }
+    }
+  };
+
+  f32x16 xnext[OTD], embnext[2], znext[2];
   StepCoef cnext;
   {
     int t0 = it_t, p0 = it_pair;
     clamp_item(t0, p0);
     load_x(t0, tile_of(p0), xnext);
-    load_emb(t0, embnext);
+    if constexpr (!ZIN) load_emb(t0, embnext);
     cnext = load_coef(t0);
+    load_z(t0, tile_of(p0), LH, znext);
   }
   for (long long round = 0; round < n_rounds; ++round) {
     const bool live_item = item_live(it_t, it_pair);
@@ -277,16 +306,41 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       f32x16 x[OTD], embv[2];
 #pragma unroll
       for (int ct = 0; ct < OTD; ++ct) x[ct] = xnext[ct];
-      embv[0] = embnext[0]; embv[1] = embnext[1];
+      if constexpr (!ZIN) { embv[0] = embnext[0]; embv[1] = embnext[1]; }
       const StepCoef cs = cnext;
       const float sig = cs.sig, wl = cs.wl, c_i = cs.c_i, cdt = cs.cdt, c_u = cs.c_u, c_x = cs.c_x, gam0 = cs.gam0;
 
       // ======================================================================================= forward (re-evaluation at x_t)
-      // keep[k]: RECOMP ? Z_k : act'(Z_k)  (k = 0 .. LH);   akeep[k] = a_{k+1} = act(Z_k)  (k < LH; not with RECOMP)
-      f32x16 keep[LH + 1][2];
-      f32x16 akeep[RECOMP ? 1 : LH][2];
-      f32x16 cur[2];
-      {
+      // keep[k] = act'(Z_k)  (k = 0 .. LH);   akeep[k] = a_{k+1} = act(Z_k)  (k < LH)
+      // ZIN: no re-evaluation -- zcur is the record of the layer the NEXT stage activates, kz its act' once activated
+      f32x16 keep[ZIN ? 1 : LH + 1][2];
+      f32x16 akeep[ZIN ? 1 : LH][2];
+      f32x16 cur[2], zcur[2], kz[2];
+      f32x16 nn[OTD];
+      // the score entering the control: requested in front of the out layer, consumed behind it
+      f32x16 scv[OTD];
+#pragma unroll
+      for (int ct = 0; ct < OTD; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) scv[ct][q] = 0.0f;
+      if constexpr (ZIN) {
+        // raw network output and score planes first (their latency hides behind the activation of Z_LH, which arrived a step ago)
+#pragma unroll
+        for (int ct = 0; ct < OTD; ++ct) nn[ct] = load_cm(A.nn_in + (long long)t * d * B, (unsigned)lrow, ct);
+        if (has_score) {
+#pragma unroll
+          for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
+        }
+        SDEH_FENCE();
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(znext[0], cur[0], kz[0]); SDEH_FENCE(); act_both<ACT>(znext[1], cur[1], kz[1]););
+        SDEH_FENCE();
+        plane_put(Ame, 0, j, h, cur[0]);  // a_{LH+1}: free since the previous product's second barrier
+        plane_put(Ame, 1, j, h, cur[1]);
+        SDEH_FENCE();
+        if constexpr (LH >= 1) load_z(t, tile, LH - 1, zcur);  // consumed behind the out stage
+        SDEH_FENCE();
+      }
+      if constexpr (!ZIN) {
         f32x16 z[2] = {embv[0], embv[1]};
         if constexpr (VIO) {
           // emb + sum_i W_in[:, i] x_i in coordinate order: the fmaf chain the matrix instructions of the forward launch evaluate
@@ -306,47 +360,30 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         SDEH_FENCE();
         BW2_T(tpa);
         BW2_ADD(9, tp0, tpa);
-        if constexpr (RECOMP) {
-          keep[0][0] = z[0]; keep[0][1] = z[1];
-          SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(z[0]); SDEH_FENCE(); act_tile<ACT>(z[1]););
-          SDEH_FENCE();
-          cur[0] = z[0]; cur[1] = z[1];
-        } else {
-          SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[0][0]); SDEH_FENCE(); act_both<ACT>(z[1], cur[1], keep[0][1]););
-          SDEH_FENCE();
-          akeep[0][0] = cur[0]; akeep[0][1] = cur[1];
-        }
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[0][0]); SDEH_FENCE(); act_both<ACT>(z[1], cur[1], keep[0][1]););
+        SDEH_FENCE();
+        akeep[0][0] = cur[0]; akeep[0][1] = cur[1];
         SDEH_FENCE();
         BW2_T(tpb);
         BW2_ADD(10, tpa, tpb);
       }
       BW2_T(tpc);
+      if constexpr (!ZIN) {
 #pragma unroll
       for (int l = 0; l < LH; ++l) {  // hidden layer l: Z_{l+1} = W_l a_{l+1} + b_l;  a_{l+2} = act(Z_{l+1})
         f32x16 z[2] = {rows16(bh_s + l * 64 + 4 * h), rows16(bh_s + l * 64 + 32 + 4 * h)};
         fwd_rows<8, 2, 2>(Whid_s + l * 64 * RSW + j * RSW + 4 * h, RSW, cur, 8, z);
         SDEH_FENCE();
-        if constexpr (RECOMP) {
-          keep[l + 1][0] = z[0]; keep[l + 1][1] = z[1];
-          SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(z[0]); SDEH_FENCE(); act_tile<ACT>(z[1]););
-          SDEH_FENCE();
-          cur[0] = z[0]; cur[1] = z[1];
-        } else {
-          SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[l + 1][0]); SDEH_FENCE(); act_both<ACT>(z[1], cur[1], keep[l + 1][1]););
-          SDEH_FENCE();
-          if (l + 1 < LH) { akeep[l + 1 < LH ? l + 1 : 0][0] = cur[0]; akeep[l + 1 < LH ? l + 1 : 0][1] = cur[1]; }
-        }
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(z[0], cur[0], keep[l + 1][0]); SDEH_FENCE(); act_both<ACT>(z[1], cur[1], keep[l + 1][1]););
+        SDEH_FENCE();
+        if (l + 1 < LH) { akeep[l + 1 < LH ? l + 1 : 0][0] = cur[0]; akeep[l + 1 < LH ? l + 1 : 0][1] = cur[1]; }
+      }
       }
       BW2_T(tpd);
       BW2_ADD(11, tpc, tpd);
       SDEH_FENCE();
-      // the score entering the control: requested in front of the out layer, consumed behind it
-      f32x16 scv[OTD];
-#pragma unroll
-      for (int ct = 0; ct < OTD; ++ct)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) scv[ct][q] = 0.0f;
-      if constexpr (BR) {
+      if constexpr (ZIN) {
+      } else if constexpr (BR) {
         if (has_score) {  // LerpPriorCtrl: (1 - t / T) prior.score(x), closed form (models/reparam.py:160-189)
 #pragma unroll
           for (int ct = 0; ct < OTD; ++ct) {
@@ -360,11 +397,12 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
       }
       SDEH_FENCE();
+      if constexpr (ZIN) {
+      } else {
       // a_{LH+1} goes to the A plane at once (free since the previous product's second barrier); the out layer reads the registers
       plane_put(Ame, 0, j, h, cur[0]);
       plane_put(Ame, 1, j, h, cur[1]);
       SDEH_FENCE();
-      f32x16 nn[OTD];
       if constexpr (VIO) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) nn[0][q] = 0.0f;
@@ -383,6 +421,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
 #pragma unroll
         for (int ct = 0; ct < OTD; ++ct) nn[ct] = rows16(bo_s + 32 * ct + 4 * h);
         fwd_rows<8, 2, OTD>(Wout_s + j * RSW + 4 * h, RSW, cur, 8, nn);
+      }
       }
       SDEH_FENCE();
       BW2_T(tp1);
@@ -704,27 +743,19 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       for (int l = LH - 1; l >= -1; --l) {
         BW2_T(tq0);
         // dl = d loss / d a_{l+2};  delta = dl . act'(Z_{l+1});  publish with a_{l+1} (l = -1: x)
-        if constexpr (RECOMP) {
-          // act'(Z_{l+1}) and a_{l+1} = act(Z_l) are evaluated again here instead of living in registers since the forward pass
-          f32x16 gz[2];
-          SDEH_ACT_SWITCH(act, ACT, {
-            f32x16 tmp;
-            act_both<ACT>(keep[l + 1][0], tmp, gz[0]);
-            SDEH_FENCE();
-            act_both<ACT>(keep[l + 1][1], tmp, gz[1]);
-          });
-          SDEH_FENCE();
+        if constexpr (ZIN) {
+          // kz = act'(Z_{l+1}) from the previous stage; a_{l+1} = act(Z_l) and the next kz from the record requested a stage ago
 #pragma unroll
-          for (int q = 0; q < 16; ++q) { dl[0][q] *= gz[0][q]; dl[1][q] *= gz[1][q]; }
+          for (int q = 0; q < 16; ++q) { dl[0][q] *= kz[0][q]; dl[1][q] *= kz[1][q]; }
           SDEH_FENCE();
           if (l >= 0) {
-#pragma unroll
-            for (int R = 0; R < 2; ++R) {
-              f32x16 ak = keep[l >= 0 ? l : 0][R];
-              SDEH_ACT_SWITCH(act, ACT, act_tile<ACT>(ak););
-              plane_put(Ame, R, j, h, ak);
-              SDEH_FENCE();
-            }
+            f32x16 ak[2];
+            SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(zcur[0], ak[0], kz[0]); SDEH_FENCE(); act_both<ACT>(zcur[1], ak[1], kz[1]););
+            SDEH_FENCE();
+            plane_put(Ame, 0, j, h, ak[0]);
+            plane_put(Ame, 1, j, h, ak[1]);
+            SDEH_FENCE();
+            if (l >= 1) load_z(t, tile, l >= 1 ? l - 1 : 0, zcur);
           }
         } else {
           if constexpr (BR) {  // adj(Z_k) = act'(Z_k) . d loss / d a_{k+1} + S_k
@@ -769,14 +800,16 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
           // the next step's (or item's) x, time embedding and scalars: requested in front of the step's last block of matrix instructions
           if (t > t_last) {
             load_x(t - 1, (int)tile, xnext);
-            load_emb(t - 1, embnext);
+            if constexpr (!ZIN) load_emb(t - 1, embnext);
             cnext = load_coef(t - 1);
+            load_z(t - 1, tile, LH, znext);
           } else if (round + 1 < n_rounds) {
             int tn = it_t, pn = it_pair;
             clamp_item(tn, pn);
             load_x(tn, tile_of(pn), xnext);
-            load_emb(tn, embnext);
+            if constexpr (!ZIN) load_emb(tn, embnext);
             cnext = load_coef(tn);
+            load_z(tn, tile_of(pn), LH, znext);
           }
           f32x16 dx[OTD];
           // d loss / d (time embedding + input bias)[t][row] per tile: the delta row sums of each wave's trajectories
@@ -1109,13 +1142,33 @@ int launch_bwdf2_jac(const BwdfArgs& a, hipStream_t stream) {
   return launch_bwdf2_jac_t<2>(a, stream);
 }
 
+// the launch that reads the pre-activation record instead of re-evaluating the network (ZIN)
+template <int OTD, bool BPTT, int LH, int NQ, bool VIO>
+static int launch_bwdf2_z(const BwdfArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = (size_t)(bwdf::lds_floats<OTD, LH>() + 512) * sizeof(float);
+  if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
+  static bool attr_done[kMaxDevices] = {};
+  bool& attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<OTD, BPTT, LH, true, NQ, VIO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bwdf2_kernel<OTD, BPTT, LH, true, NQ, VIO>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
 template <int OTD, bool BPTT, int LH, int NQ, bool VIO, bool KLB = false>
 static int launch_bwdf2_q(const BwdfArgs& a, hipStream_t stream) {
   if constexpr (BPTT && LH == 2 && !KLB) {
     if (a.cost_in != nullptr && a.lam_in != nullptr) return launch_bwdf2_q<OTD, BPTT, LH, NQ, VIO, true>(a, stream);
   }
   if (!KLB && BPTT && (a.cost_in != nullptr || a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;  // (two hidden layers, both planes)
-  constexpr bool RECOMP = false;  // (kept act, act-prime: with four-wave teams they fit; the re-evaluating form spills more)
+  if constexpr (!KLB) {
+    if (a.zrec != nullptr && a.nn_in != nullptr) return launch_bwdf2_z<OTD, BPTT, LH, NQ, VIO>(a, stream);
+  }
+  constexpr bool RECOMP = false;  // (the slot of the ZIN parameter: this launch re-evaluates the network)
   const size_t lds_bytes = (size_t)(bwdf::lds_floats<OTD, LH>() + 512) * sizeof(float);
   if (lds_bytes > 160 * 1024) return SDEH_ERR_UNSUPPORTED;
   static bool attr_done[kMaxDevices] = {};

@@ -124,6 +124,9 @@ struct TrajArgs {
   float* sc_out;  // [T, d, B] or null: combined score entering the control, before clip_score and gamma(t)
   float* u_out;   // [T, d, B] or null: the control u_t driving the SDE (Bridge training: the inference pass is row-parallel given x_t, u_t)
   float* tsc_out; // [d, B] or null: 1[|log rho(x_T)| <= clip_target] * target.score(x_T)  (d terminal target cost / d x_T, negated)
+  // training forward that also keeps the network's pre-activations for the fused backward (sdeh_simulate_fwd_train3)
+  float* zrec;    // [T][ceil(B / 32)][Lh + 1][16][32][4] or null: the pre-activation record (sdeh_traj_ws.hpp: ZRec)
+  float* nn_cm;   // [T, d, B] or null: raw network output (before the clamp), coordinate-major
 };
 
 // sdeh_bridge_div_backward (sdeh_bridge.hpp): gradient of  sum_n w_i sigma dt div_x v(x_n)  w.r.t. the inference network
@@ -241,6 +244,9 @@ struct BwdfArgs {
   const float* s_in;      // the same planes, read by the row-parallel kernel
   float* div_hid;         // [n_slots][2][64][64]: the divergence term's direct gradient of the two hidden weights, per team
   float* div_io;          // [n_slots * 4][2][32 OTD][64] (zeroed by the caller): per wave, columns of input_embed.weight | rows of out_layer.weight
+  // the pre-activation record and the raw network output of sdeh_simulate_fwd_train3: the kernels that take them do not re-evaluate the network
+  const float* zrec;      // [T][ceil(B / 32)][Lh + 1][16][32][4] or null
+  const float* nn_in;     // [T, d, B] or null
 };
 int launch_bridge_divf(const BwdfArgs& a, hipStream_t stream);  // divergence term of a 64-channel Bridge, two hidden layers (sdeh_bridgef.hip)
 bool bridge_divf_fits(int d, int n_hidden);
@@ -324,7 +330,7 @@ struct SinkArgs {
 // environment (sdeh_plan_create copies it once).
 enum OptKey {
   OPT_LEGACY, OPT_GENERIC_ONLY, OPT_WS_GROUPS, OPT_WS_QUAD, OPT_WS_VOUT, OPT_WS_BARRIER, OPT_BWD_PLANES, OPT_BWD_TILE, OPT_BWD_WAVES,
-  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BWD_SCAN, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_COUNT
+  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BWD_SCAN, OPT_BWD_ZREC, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_COUNT
 };
 struct PlanOptions {
   char v[OPT_COUNT][8];

@@ -345,6 +345,33 @@ __device__ __forceinline__ void ws_store_z(const ZStore& Z, int layer, int C, in
   }
 }
 
+// Pre-activation RECORD of the training forward (PLANES == 3, round 5: the fused backward READS the pre-activations instead of
+// re-evaluating the network -- the reference's autograd keeps them as well, losses/oc.py:232-256 -> models/mlp.py:114-122):
+//     zrec[step][tile of 32 trajectories][layer 0 .. Lh][channel quad cq = 0 .. 15][trajectory j = 0 .. 31][4 channels]
+// Accumulator registers 4 g .. 4 g + 3 of lane (j, h), row tile ot are channels 32 ot + 8 g + 4 h .. + 3 of trajectory j, i.e. quad
+// cq = 8 ot + 2 g + h: one 16-byte store per lane, 1 KB contiguous per instruction, and the trajectory-split backward (lane (j, h) of the
+// wave that owns the tile) loads exactly what was stored.  Non-temporal: every word is written once and read once, by another kernel.
+typedef float f32x4z __attribute__((ext_vector_type(4)));
+struct ZRec {
+  float* base;   // record of (step, the group's first tile), or null
+  int tiles;     // live 32-trajectory tiles of the group (0 .. 2): tiles beyond the batch are not stored
+  int lh1;       // layers per tile (Lh + 1)
+};
+__device__ __forceinline__ void ws_store_zrec(const ZRec& Z, int layer, int ot, int col_tile, int lane, const f32x16& v) {
+  if (col_tile < Z.tiles) {
+    float* __restrict__ p = Z.base + ((long long)col_tile * Z.lh1 + layer) * 2048 + ot * 1024 + (lane >> 5) * 128 + (lane & 31) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      __builtin_nontemporal_store(f32x4z{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, reinterpret_cast<f32x4z*>(p + g * 256));
+  }
+}
+// ZS (template parameter of the network passes): 0 = nothing stored, 1 = coordinate-major planes (ZStore, round 1), 2 = the record
+template <int ZS>
+__device__ __forceinline__ void ws_keep_z(const ZStore& Z, const ZRec& Zr, int layer, int C, int ot, int col_tile, int lane, const f32x16& v) {
+  if constexpr (ZS == 1) ws_store_z(Z, layer, C, ot, col_tile, lane, v);
+  if constexpr (ZS == 2) ws_store_zrec(Zr, layer, ot, col_tile, lane, v);
+}
+
 __device__ __forceinline__ float act_apply(float v, int act) {
   return act == SDEH_ACT_GELU_ERF ? act_gelu(v) : (act == SDEH_ACT_SILU ? act_silu(v) : act_relu(v));
 }
@@ -457,9 +484,9 @@ __device__ __forceinline__ void ws_publish_act(float* __restrict__ abuf, const f
     for (int q = 0; q < 16; ++q) abuf[(32 * ot + rho(q, h)) * 64 + col] = a[ot][q];
 }
 
-template <int DP, int C, bool ZS>
+template <int DP, int C, int ZS>
 __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
-                                       int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z, float* __restrict__ abuf = nullptr) {
+                                       int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z, const ZRec& Zr, float* __restrict__ abuf = nullptr) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
   f32x16 curA[OT], curB[OT], nxtA[OT], nxtB[OT];
@@ -476,10 +503,10 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
     const float* w = lds + L.w_in + lane;
     mfma_stage<R, OT, OT>(w, [&](int s) { return xa[s]; }, curA, curB, false, act);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) if constexpr (ZS) ws_store_z(Z, 0, C, ot, 0, lane, curA[ot]);
+    for (int ot = 0; ot < OT; ++ot) ws_keep_z<ZS>(Z, Zr, 0, C, ot, 0, lane, curA[ot]);
     mfma_stage<R, OT, OT>(w, [&](int s) { return xb[s]; }, curB, curA, true, act);  // + act(A0)
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) if constexpr (ZS) ws_store_z(Z, 0, C, ot, 1, lane, curB[ot]);
+    for (int ot = 0; ot < OT; ++ot) ws_keep_z<ZS>(Z, Zr, 0, C, ot, 1, lane, curB[ot]);
   }
   // invariant at the top of each layer: curA activated, curB not yet
   for (int l = 0; l < L.n_hidden; ++l) {
@@ -489,10 +516,10 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
     const float* w = lds + L.w_hid + l * L.w_hid_stride + lane;
     mfma_stage<C / 2, OT, OT>(w, [&](int s) { return curA[s / 16][s % 16]; }, nxtA, curB, true, act);  // + act(B)
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) if constexpr (ZS) ws_store_z(Z, l + 1, C, ot, 0, lane, nxtA[ot]);
+    for (int ot = 0; ot < OT; ++ot) ws_keep_z<ZS>(Z, Zr, l + 1, C, ot, 0, lane, nxtA[ot]);
     mfma_stage<C / 2, OT, OT>(w, [&](int s) { return curB[s / 16][s % 16]; }, nxtB, nxtA, true, act);  // + act(A')
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) { if constexpr (ZS) ws_store_z(Z, l + 1, C, ot, 1, lane, nxtB[ot]); curA[ot] = nxtA[ot]; curB[ot] = nxtB[ot]; }
+    for (int ot = 0; ot < OT; ++ot) { ws_keep_z<ZS>(Z, Zr, l + 1, C, ot, 1, lane, nxtB[ot]); curA[ot] = nxtA[ot]; curB[ot] = nxtB[ot]; }
   }
   if constexpr (DP <= 4) {
     if (abuf != nullptr) {  // out layer on the V wave: activate tile B (tile A is) and publish both
@@ -523,9 +550,9 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
 
 // Single-tile variant for small batches (TrajArgs::half): the group is 32 trajectories = one MFMA column tile, so the chain of
 // dependent layers is half as long (the launch is latency-bound: a handful of wavefronts on 1024 SIMDs).
-template <int DP, int C, bool ZS>
+template <int DP, int C, int ZS>
 __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
-                                            int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z, float* __restrict__ abuf = nullptr) {
+                                            int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z, const ZRec& Zr, float* __restrict__ abuf = nullptr) {
   constexpr int OT = C / 32, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
   f32x16 cur[OT], nxt[OT], none[1];
@@ -541,7 +568,7 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
     for (int ot = 0; ot < OT; ++ot) cur[ot] = emb[ot];
     mfma_stage<R, OT, 1>(lds + L.w_in + lane, [&](int s) { return xa[s]; }, cur, none, false, act);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) if constexpr (ZS) ws_store_z(Z, 0, C, ot, 0, lane, cur[ot]);
+    for (int ot = 0; ot < OT; ++ot) ws_keep_z<ZS>(Z, Zr, 0, C, ot, 0, lane, cur[ot]);
   }
   for (int l = 0; l < L.n_hidden; ++l) {
     activate_all();
@@ -551,7 +578,7 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
     mfma_stage<C / 2, OT, 1>(lds + L.w_hid + l * L.w_hid_stride + lane, [&](int s) { return cur[s / 16][s % 16]; }, nxt, none,
                              false, act);
 #pragma unroll
-    for (int ot = 0; ot < OT; ++ot) { cur[ot] = nxt[ot]; if constexpr (ZS) ws_store_z(Z, l + 1, C, ot, 0, lane, cur[ot]); }
+    for (int ot = 0; ot < OT; ++ot) { cur[ot] = nxt[ot]; ws_keep_z<ZS>(Z, Zr, l + 1, C, ot, 0, lane, cur[ot]); }
   }
   activate_all();
   if constexpr (DP <= 4) {
@@ -592,10 +619,10 @@ __device__ __forceinline__ void mfma_stage_one(const float* __restrict__ w, IN&&
 // workgroup barrier makes both tiles visible, and the other tile is read back in the same (register, lane) arrangement.  The
 // k-steps of the hidden layers run in the order of ws_mlp_half (tile 0's channels, then tile 1's): their pre-activations are bit-identical
 // to it (the fused backward re-evaluates them); the output layer is the sum of two per-wave partial sums (see below).
-template <int DP, int C, int ACT, bool ZS>
+template <int DP, int C, int ACT, int ZS>
 __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float* __restrict__ xbuf, float* __restrict__ abuf,
                                             float* __restrict__ xbuf2, const WsLayout& L, const f32x16& emb_mine, int lane, int mw,
-                                            int& parity, const ZStore& Z) {
+                                            int& parity, const ZStore& Z, const ZRec& Zr) {
   static_assert(C == 64, "pair mode splits the two 32-channel tiles of a 64-channel network");
   constexpr int OT = 2, OTD = row_tiles(DP), R = mregs(DP);
   const int h = lane >> 5, j = lane & 31;
@@ -605,7 +632,7 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
 #pragma unroll
     for (int r = 0; r < R; ++r) xa[r] = xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j];
     mfma_stage_one<R, OT>(lds + L.w_in + mw * 64 + lane, [&](int s) { return xa[s]; }, mine);
-    if constexpr (ZS) ws_store_z(Z, 0, C, mw, 0, lane, mine);
+    ws_keep_z<ZS>(Z, Zr, 0, C, mw, 0, lane, mine);
   }
   auto exchange = [&]() {  // mine <- act(mine); other <- the partner's activated tile
     act_tile<ACT>(mine);
@@ -634,7 +661,7 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
     f32x16 nxt = load16(lds + L.b_hid + l * C + (mw * 2 + h) * 16);
     layer(lds + L.w_hid + l * L.w_hid_stride + mw * 64 + lane, std::integral_constant<int, OT>{}, nxt);
     mine = nxt;
-    if constexpr (ZS) ws_store_z(Z, l + 1, C, mw, 0, lane, mine);
+    ws_keep_z<ZS>(Z, Zr, l + 1, C, mw, 0, lane, mine);
   }
   if constexpr (OTD == 1) {
     // d <= 32, one output tile: no further exchange -- each wave contracts over ITS OWN 32 channels (16 MFMAs; wave 1 used to idle
@@ -687,10 +714,10 @@ __device__ __forceinline__ void act_tile4(f32x4q& v) {
   }
 }
 
-template <int DP, int C, int ACT>
+template <int DP, int C, int ACT, bool ZQ = false>
 __device__ __forceinline__ void ws_mlp_quad(const float* __restrict__ lds, const float* __restrict__ xbuf, float* __restrict__ planes,
                                             float* __restrict__ pout, const WsLayout& L, const f32x4q& emb_mine, int lane, int mw,
-                                            int& parity) {
+                                            int& parity, const ZRec& Zr = ZRec{nullptr, 0, 0}) {
   static_assert(C == 64 && DP <= 32, "quad mode: 64 channels as four 16-row tiles, one 32-coordinate output tile");
   constexpr int OT = 2, R = mregs(DP), XR = xrows<DP>(), PRS = kQuadPRS;
   const int n = lane & 15, kk = lane >> 4;
@@ -699,6 +726,16 @@ __device__ __forceinline__ void ws_mlp_quad(const float* __restrict__ lds, const
   // ... and the channel that entry multiplies: mdim(2t + (kk >> 1), kk & 1) = mdim(2t, 0) + (kk >> 1) + 4 (kk & 1)
   const int koff = (kk >> 1) + 4 * (kk & 1);
   f32x4q acc[2] = {emb_mine, emb_mine};
+  // the pre-activation record (ZRec): register q of lane (n, kk) is channel 16 mw + 4 kk + q, i.e. quad 4 mw + kk, of trajectory n / 16 + n
+  auto keep_z = [&](int layer) {
+    if constexpr (ZQ) {
+      if (Zr.tiles > 0) {
+        float* __restrict__ p = Zr.base + layer * 2048 + (4 * mw + kk) * 128 + n * 4;
+        __builtin_nontemporal_store(acc[0], reinterpret_cast<f32x4q*>(p));
+        __builtin_nontemporal_store(acc[1], reinterpret_cast<f32x4q*>(p + 64));
+      }
+    }
+  };
   {  // input layer: k runs over the coordinates, B from the exchange buffer [coordinate][64]
     const float* __restrict__ w = lds + L.w_in + aoff;
 #pragma unroll
@@ -710,6 +747,7 @@ __device__ __forceinline__ void ws_mlp_quad(const float* __restrict__ lds, const
       acc[0] = SDEH_MFMA16Q(a, b0, acc[0]);
       acc[1] = SDEH_MFMA16Q(a, b1, acc[1]);
     }
+    keep_z(0);
   }
   for (int l = 0; l < L.n_hidden; ++l) {
     act_tile4<ACT>(acc[0]);
@@ -734,6 +772,7 @@ __device__ __forceinline__ void ws_mlp_quad(const float* __restrict__ lds, const
       acc[0] = SDEH_MFMA16Q(a, b0, acc[0]);
       acc[1] = SDEH_MFMA16Q(a, b1, acc[1]);
     }
+    keep_z(l + 1);
   }
   act_tile4<ACT>(acc[0]);
   act_tile4<ACT>(acc[1]);
@@ -771,7 +810,9 @@ __device__ __forceinline__ void ws_mlp_quad(const float* __restrict__ lds, const
 // network output; a separate instantiation so that the evaluation kernel carries none of it.
 // PLANES: 0 = evaluation; 1 = training forward that keeps the pre-activation planes and raw network outputs (sdeh_simulate_fwd_train);
 // 2 = training forward for the fused backward (sdeh_simulate_fwd_train2: coordinate-major trajectory / score planes from the V wave
-// only -- the M waves run the evaluation code: with the plane stores compiled in they lose 1 ms per 100 steps at B = 65 536).
+// only -- the M waves run the evaluation code: with the plane stores compiled in they lose 1 ms per 100 steps at B = 65 536);
+// 3 = 2 + the pre-activation RECORD from the M waves (ZRec: 16-byte non-temporal stores, 1 KB per instruction) and the raw network
+// output [T, d, B] from the V wave (sdeh_simulate_fwd_train3: the fused backward reads them instead of re-evaluating the network).
 template <int DP, int C, bool PAD, int LOSS, int CTRL, int TGT, int GMMV, int ACT, int REFC, int GNV, int PLANES>
 __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ ws, const float* __restrict__ x0,
                                                       const float* __restrict__ noise, float* __restrict__ xT,
@@ -825,6 +866,10 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     __builtin_amdgcn_s_setprio(SDEH_MPRIO);
 #endif
     __syncthreads();  // LDS image staged
+    // the pre-activation record (PLANES == 3): tiles of 32 trajectories, (Lh + 1) layers of 2048 floats per tile and step
+    const long long zr_tiles = (A.batch + 31) >> 5;
+    const int zr_lh1 = L.n_hidden + 1;
+    const long long zr_step = zr_tiles * zr_lh1 * 2048;
     if constexpr (C == 64 && DP <= 32 && PLANES != 1) {
       if (quad) {
         const int mw = wave - 1;
@@ -835,8 +880,13 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         int parity = 0;
         f32x4q emb1 = *reinterpret_cast<const f32x4q*>(ws + L.emb + epos);
         ws_barrier();  // barrier A: x_0 published
+        ZRec Zr{nullptr, 0, zr_lh1};
+        if constexpr (PLANES == 3) {
+          if (A.zrec != nullptr) { Zr.base = A.zrec + (long long)blockIdx.x * zr_lh1 * 2048; Zr.tiles = 1; }
+        }
         for (int i = 0; i < n_steps; ++i) {
-          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_quad<DP, C, ACTC>(lds, xbuf, planes, pout, L, emb1, lane, mw, parity););
+          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_quad<DP, C, ACTC, (PLANES == 3)>(lds, xbuf, planes, pout, L, emb1, lane, mw, parity, Zr););
+          if constexpr (PLANES == 3) Zr.base += zr_step;
           ws_barrier();  // barrier B: network output published
           if (i + 1 < n_steps) emb1 = *reinterpret_cast<const f32x4q*>(ws + L.emb + (i + 1) * C + epos);
           ws_barrier();  // barrier A: x_{i+1} published
@@ -853,9 +903,14 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         ws_barrier();  // barrier A: x_0 published
         const long long row0 = (long long)blockIdx.x * 32;
         ZStore Z{nullptr, (long long)n_steps * A.batch, A.zt_out == nullptr ? 0 : (int)(A.batch - row0 < 32 ? A.batch - row0 : 32)};
+        ZRec Zr{nullptr, 0, zr_lh1};
+        if constexpr (PLANES == 3) {
+          if (A.zrec != nullptr) { Zr.base = A.zrec + (long long)blockIdx.x * zr_lh1 * 2048; Zr.tiles = 1; }
+        }
         for (int i = 0; i < n_steps; ++i) {
           if constexpr (PLANES == 1) Z.base = A.zt_out + (long long)i * A.batch + row0;
-          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, (PLANES == 1)>(lds, xbuf, abuf, abuf + 2 * 2 * 16 * 64, L, emb1, lane, mw, parity, Z););
+          SDEH_ACT_SWITCH(act, ACTC, ws_mlp_pair<DP, C, ACTC, (PLANES == 1 ? 1 : (PLANES == 3 ? 2 : 0))>(lds, xbuf, abuf, abuf + 2 * 2 * 16 * 64, L, emb1, lane, mw, parity, Z, Zr););
+          if constexpr (PLANES == 3) Zr.base += zr_step;
           ws_barrier();  // barrier B: network output published
           if (i + 1 < n_steps) emb1 = load16(ws + L.emb + (i + 1) * C + (mw * 2 + h) * 16);
           ws_barrier();  // barrier A: x_{i+1} published
@@ -877,14 +932,24 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       Z.rows = (int)(A.batch - row0 < rpg_m ? (A.batch - row0 > 0 ? A.batch - row0 : 0) : rpg_m);
       if (A.zt_out == nullptr) Z.rows = 0;  // fused backward (sdeh_simulate_fwd_train2): no pre-activation planes
     }
+    ZRec Zr{nullptr, 0, zr_lh1};
+    if constexpr (PLANES == 3) {
+      if (A.zrec != nullptr) {
+        const int tpg = A.half ? 1 : 2;  // 32-trajectory tiles per group
+        const long long tile0 = ((long long)blockIdx.x * n_groups + group) * tpg;
+        Zr.base = A.zrec + tile0 * zr_lh1 * 2048;
+        Zr.tiles = (int)(zr_tiles - tile0 < tpg ? (zr_tiles - tile0 > 0 ? zr_tiles - tile0 : 0) : tpg);
+      }
+    }
     for (int i = 0; i < n_steps; ++i) {
       WS_T(tm0);
       if constexpr (PLANES == 1) Z.base = A.zt_out + (long long)i * A.batch + row0;
       // generic variants (ACT < 0): the activation id becomes a compile-time constant of three copies of the network --
       // selecting it per element costs a scalar branch per element pair inside the MFMA stages (1.5x on the whole kernel)
       SDEH_ACT_SWITCH(act, ACTC,
-        if (A.half) ws_mlp_half<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z, abuf);
-        else ws_mlp<DP, C, (PLANES == 1)>(lds, xbuf, L, ACTC, emb, lane, Z, abuf););
+        if (A.half) ws_mlp_half<DP, C, (PLANES == 1 ? 1 : (PLANES == 3 ? 2 : 0))>(lds, xbuf, L, ACTC, emb, lane, Z, Zr, abuf);
+        else ws_mlp<DP, C, (PLANES == 1 ? 1 : (PLANES == 3 ? 2 : 0))>(lds, xbuf, L, ACTC, emb, lane, Z, Zr, abuf););
+      if constexpr (PLANES == 3) Zr.base += zr_step;
       if (fsync) ws_flag_set(hand + 1, i + 1);
       else ws_barrier();  // barrier B: network output published
       WS_T(tm1);
@@ -933,7 +998,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j)
       if (!PAD || j < d) xs[lrow * d + j] = x[j];
   }
-  if constexpr (PLANES == 2) {
+  if constexpr (PLANES >= 2) {
     if (A.xs_cm != nullptr && live) {  // the trajectory for the fused backward, coordinate-major [T+1][d][B]
 #pragma unroll
       for (int j = 0; j < DP; ++j)
@@ -991,7 +1056,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #pragma unroll
         for (int j = 0; j < DP; ++j) sterm[j] = w1 * psc[j];
       }
-      if constexpr (PLANES == 2) {  // the fused backward reads the combined score instead of re-evaluating the densities
+      if constexpr (PLANES >= 2) {  // the fused backward reads the combined score instead of re-evaluating the densities
         if (A.sc_out != nullptr && live) {  // coordinate-major [T][d][B]: consecutive lanes, consecutive addresses
           float* __restrict__ sp = A.sc_out + (long long)i * d * A.batch + lrow;
 #pragma unroll
@@ -1126,13 +1191,16 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       if constexpr (PLANES == 1) {
         if (A.nn_out != nullptr && live && (!PAD || j < d)) A.nn_out[((long long)i * A.batch + lrow) * d + j] = nn;
       }
+      if constexpr (PLANES == 3) {  // raw network output, coordinate-major [T, d, B]: the clamp's mask (and u, through time) of the backward
+        if (A.nn_cm != nullptr && live && (!PAD || j < d)) A.nn_cm[((long long)i * d + j) * A.batch + lrow] = nn;
+      }
       u[j] = clipf(nn, A.clip_model) + sterm[j];
       if (PAD) u[j] = j < d ? u[j] : 0.0f;
       x[j] = fmaf(c_u, u[j], x[j]);
       if (PAD) x[j] = j < d ? x[j] : 0.0f;
       xbuf[j * 64 + lane] = x[j];
     }
-    if constexpr (PLANES == 2) {  // Bridge training: the inference pass (sdeh_bridgef.hip) is row-parallel given x_t and u_t
+    if constexpr (PLANES >= 2) {  // Bridge training: the inference pass (sdeh_bridgef.hip) is row-parallel given x_t and u_t
       if (A.u_out != nullptr && live) {
         float* __restrict__ up = A.u_out + (long long)i * d * A.batch + lrow;
 #pragma unroll
@@ -1180,7 +1248,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       for (int j = 0; j < DP; ++j)
         if (!PAD || j < d) xp[j] = x[j];
     }
-    if constexpr (PLANES == 2) {
+    if constexpr (PLANES >= 2) {
       if (A.xs_cm != nullptr && live) {
         float* __restrict__ xp = A.xs_cm + (long long)(i + 1) * d * A.batch + lrow;
 #pragma unroll
@@ -1201,7 +1269,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     for (int j = 0; j < DP; ++j)
       if (!PAD || j < d) xT[row * d + j] = x[j];
   }
-  if constexpr (PLANES == 2) {  // d(terminal target cost)/dx_T, negated: the clamp's mask times target.score(x_T)  (oc.py:225)
+  if constexpr (PLANES >= 2) {  // d(terminal target cost)/dx_T, negated: the clamp's mask times target.score(x_T)  (oc.py:225)
     if (A.tsc_out != nullptr && (flags & SDEH_FLAG_TERMINAL_TARGET)) {
       float st[DP];
       ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, st);
@@ -1245,7 +1313,8 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   // (pair / quad mode: at least one hidden layer -- its exchange barrier is what separates the M waves' reads of x from the write of the
   // first partial network output into the same buffer)
   const bool pair_fits = C == 64 && a.lay.n_hidden >= 1 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
-  const int planes = (a.zt_out != nullptr && a.nn_out != nullptr) ? 1 : (a.sc_out != nullptr || a.tsc_out != nullptr || a.xs_cm != nullptr ? 2 : 0);
+  const int planes = (a.zt_out != nullptr && a.nn_out != nullptr) ? 1 : (a.zrec != nullptr && a.nn_cm != nullptr ? 3 :
+                     (a.sc_out != nullptr || a.tsc_out != nullptr || a.xs_cm != nullptr ? 2 : 0));
   static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
@@ -1256,6 +1325,9 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess)
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 3>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return SDEH_ERR_HIP;
     attr_set = true;
@@ -1304,6 +1376,9 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   const unsigned grid = (unsigned)((a.batch + rows - 1) / rows);
   if (planes == 1)
     hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 1>), dim3(grid),
+                       dim3(half == 3 ? 320 : (half == 2 ? 192 : 128 * groups)), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
+  else if (planes == 3)
+    hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 3>), dim3(grid),
                        dim3(half == 3 ? 320 : (half == 2 ? 192 : 128 * groups)), lds_bytes, stream, a.ws, a.x0, a.noise, a.xT, a.rnd, a.xs, b);
   else if (planes == 2)
     hipLaunchKernelGGL((traj_ws_kernel<DP, C, PAD, LOSS, CTRL, TGT, GMMV, ACT, REFC, GNV, 2>), dim3(grid),

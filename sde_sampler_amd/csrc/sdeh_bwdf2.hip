@@ -241,7 +241,10 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     }
   };
 
-  f32x16 xnext[OTD], embnext[2], znext[2];
+  // ZIN: two record buffers in flight -- layer k of a step lives in zA when LH - k is even, else in zB, and is requested where the
+  // buffer's previous content was activated: Z_LH of the NEXT step in front of this step's last hidden stage, Z_{LH-1} of the next step in
+  // front of the in stage, Z_{LH-2} of this step at its top -- every request a whole stage (8-10 k cycles of matrix work) ahead of its use
+  f32x16 xnext[OTD], embnext[2], zA[2], zB[2];
   StepCoef cnext;
   {
     int t0 = it_t, p0 = it_pair;
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     load_x(t0, tile_of(p0), xnext);
     if constexpr (!ZIN) load_emb(t0, embnext);
     cnext = load_coef(t0);
-    load_z(t0, tile_of(p0), LH, znext);
+    load_z(t0, tile_of(p0), LH, zA);
+    load_z(t0, tile_of(p0), LH - 1, zB);
   }
   for (long long round = 0; round < n_rounds; ++round) {
     const bool live_item = item_live(it_t, it_pair);
@@ -312,10 +316,10 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
 
       // ======================================================================================= forward (re-evaluation at x_t)
       // keep[k] = act'(Z_k)  (k = 0 .. LH);   akeep[k] = a_{k+1} = act(Z_k)  (k < LH)
-      // ZIN: no re-evaluation -- zcur is the record of the layer the NEXT stage activates, kz its act' once activated
+      // ZIN: no re-evaluation -- zA / zB hold the records in flight, kz = act' of the layer activated last
       f32x16 keep[ZIN ? 1 : LH + 1][2];
       f32x16 akeep[ZIN ? 1 : LH][2];
-      f32x16 cur[2], zcur[2], kz[2];
+      f32x16 cur[2], kz[2];
       f32x16 nn[OTD];
       // the score entering the control: requested in front of the out layer, consumed behind it
       f32x16 scv[OTD];
@@ -332,12 +336,12 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
           for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
         }
         SDEH_FENCE();
-        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(znext[0], cur[0], kz[0]); SDEH_FENCE(); act_both<ACT>(znext[1], cur[1], kz[1]););
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(zA[0], cur[0], kz[0]); SDEH_FENCE(); act_both<ACT>(zA[1], cur[1], kz[1]););
         SDEH_FENCE();
         plane_put(Ame, 0, j, h, cur[0]);  // a_{LH+1}: free since the previous product's second barrier
         plane_put(Ame, 1, j, h, cur[1]);
         SDEH_FENCE();
-        if constexpr (LH >= 1) load_z(t, tile, LH - 1, zcur);  // consumed behind the out stage
+        if constexpr (LH >= 2) load_z(t, tile, LH - 2, zA);  // consumed two stages on
         SDEH_FENCE();
       }
       if constexpr (!ZIN) {
@@ -750,12 +754,28 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
           SDEH_FENCE();
           if (l >= 0) {
             f32x16 ak[2];
-            SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(zcur[0], ak[0], kz[0]); SDEH_FENCE(); act_both<ACT>(zcur[1], ak[1], kz[1]););
+            if (((LH - l) & 1) == 0) {
+              SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(zA[0], ak[0], kz[0]); SDEH_FENCE(); act_both<ACT>(zA[1], ak[1], kz[1]););
+            } else {
+              SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(zB[0], ak[0], kz[0]); SDEH_FENCE(); act_both<ACT>(zB[1], ak[1], kz[1]););
+            }
             SDEH_FENCE();
             plane_put(Ame, 0, j, h, ak[0]);
             plane_put(Ame, 1, j, h, ak[1]);
             SDEH_FENCE();
-            if (l >= 1) load_z(t, tile, l >= 1 ? l - 1 : 0, zcur);
+            if (l >= 2) {  // (deeper networks: layer l - 2 takes the buffer just activated)
+              if (((LH - l) & 1) == 0) load_z(t, tile, l >= 2 ? l - 2 : 0, zA);
+              else load_z(t, tile, l >= 2 ? l - 2 : 0, zB);
+            }
+            if (l == 0) {  // the next step's (or item's) top layer: zA is free (LH even: its Z_0 was just activated; odd: since the top)
+              if (t > t_last) {
+                load_z(t - 1, tile, LH, zA);
+              } else if (round + 1 < n_rounds) {
+                int tn = it_t, pn = it_pair;
+                clamp_item(tn, pn);
+                load_z(tn, tile_of(pn), LH, zA);
+              }
+            }
           }
         } else {
           if constexpr (BR) {  // adj(Z_k) = act'(Z_k) . d loss / d a_{k+1} + S_k
@@ -802,14 +822,14 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             load_x(t - 1, (int)tile, xnext);
             if constexpr (!ZIN) load_emb(t - 1, embnext);
             cnext = load_coef(t - 1);
-            load_z(t - 1, tile, LH, znext);
+            load_z(t - 1, tile, LH - 1, zB);
           } else if (round + 1 < n_rounds) {
             int tn = it_t, pn = it_pair;
             clamp_item(tn, pn);
             load_x(tn, tile_of(pn), xnext);
             if constexpr (!ZIN) load_emb(tn, embnext);
             cnext = load_coef(tn);
-            load_z(tn, tile_of(pn), LH, znext);
+            load_z(tn, tile_of(pn), LH - 1, zB);
           }
           f32x16 dx[OTD];
           // d loss / d (time embedding + input bias)[t][row] per tile: the delta row sums of each wave's trajectories

@@ -418,27 +418,27 @@ int32_t sdeh_simulate_fwd_train2u(SdehPlan* plan, const SdehProblem* problem, co
  * autograd keeps every layer's activations between loss(...) and loss.backward() (losses/oc.py:232-256 -> models/mlp.py:114-122 through
  * solver/base.py:399-407); sdeh_simulate_fwd_train2 + sdeh_ctrl_backward_fused re-evaluate the network per step instead (1.7 x the
  * algorithmic matrix work of the backward).  sdeh_simulate_fwd_train3 == sdeh_simulate_fwd_train2u (u may be NULL) that also writes
- *   zrec [n_steps][ceil(batch / 32)][n_hidden + 1][16][32][4]   the pre-activations Z_k of the generative network: per (step, tile of 32
- *        trajectories, layer k) channel quad cq (channels 4 cq .. 4 cq + 3) of trajectory j at [cq][j][0..3] -- the register layout of the
- *        kernels on both sides (16-byte accesses, 1 KB contiguous per instruction); sdeh_zrec_floats(n_hidden, n_steps, batch) floats
- *   nn   [n_steps, d, batch]   the raw network output (before the clamp), coordinate-major
+ *   zrec [n_steps][ceil(batch / 32)] { [n_hidden + 1][16][32][4] ; [ceil(d / 32)][8][32][4] }     (sdeh_zrec_floats floats)
+ *        per (step, tile of 32 trajectories): the pre-activations Z_k of the generative network -- layer k, channel quad cq (channels
+ *        4 cq .. 4 cq + 3) of trajectory j at [k][cq][j][0..3] -- followed by the raw network output (before the clamp), coordinate quad
+ *        cq of trajectory j at [cq / 8][cq % 8][j][0..3].  This is the register layout of the kernels on both sides (16-byte accesses,
+ *        1 KB contiguous per instruction); quads that hold only coordinates >= d may be left unwritten.
  * and returns 0 (everything kept) or 1 (served by a kernel that keeps nothing: mixture tables beyond LDS).
- * sdeh_ctrl_backward_fused_z == sdeh_ctrl_backward_fused_ex that is also given zrec / nn (both or neither; NULL = _ex): the launches that
- * can read the record do not re-evaluate the network (act / act' from the stored Z_k: a ReLU unit on its kink takes the forward launch's
- * side by construction); the others ignore it.  Same scratch / out as sdeh_ctrl_backward_fused. */
-int64_t sdeh_zrec_floats(int32_t n_hidden, int32_t n_steps, int64_t batch);
+ * sdeh_ctrl_backward_fused_z == sdeh_ctrl_backward_fused_ex that is also given zrec (NULL = _ex): the launches that can read the record
+ * do not re-evaluate the network (act / act' from the stored Z_k: a ReLU unit on its kink takes the forward launch's side by
+ * construction); the others ignore it.  Same scratch / out as sdeh_ctrl_backward_fused. */
+int64_t sdeh_zrec_floats(int32_t dim, int32_t n_hidden, int32_t n_steps, int64_t batch);
 /* 1 when the launch that serves sdeh_ctrl_backward_fused_z for this problem and batch reads the record (so that the forward only keeps
  * what will be read), 0 when it would be ignored. */
 int32_t sdeh_ctrl_backward_fused_reads_zrec(const SdehPlan* plan, const SdehProblem* problem, int64_t batch);
 int32_t sdeh_simulate_fwd_train3(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* x0,
                                  int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                                 float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, float* zrec, float* nn,
-                                 void* stream);
+                                 float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, float* zrec, void* stream);
 int32_t sdeh_ctrl_backward_fused_z(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
                                    int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                                    const float* grad_rnd, const float* sc, const float* tscore, const float* cost_ctrl,
-                                   const float* lam_extra, const float* zrec, const float* nn, float* scratch, int64_t scratch_floats,
-                                   float* out, void* stream);
+                                   const float* lam_extra, const float* zrec, float* scratch, int64_t scratch_floats, float* out,
+                                   void* stream);
 int64_t sdeh_bridge_inference_fwd_scratch_floats(int32_t n_steps, int64_t batch);
 int32_t sdeh_bridge_inference_fwd(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, const float* xs,
                                   int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, const float* u,

@@ -740,7 +740,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
                          int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                          float* x_T, float* rnd, float* xs, float* gp, const float* div_noise, float* zt_out, float* nn_out,
                          bool* planes_written, void* stream, float* sc_out = nullptr, float* tsc_out = nullptr, float* xs_cm = nullptr,
-                         float* u_out = nullptr, float* zrec = nullptr, float* nn_cm = nullptr) {
+                         float* u_out = nullptr, float* zrec = nullptr) {
   OptScope opt_scope(plan);
   if (planes_written != nullptr) *planes_written = false;
   if (x0 == nullptr || x_T == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd: null argument");
@@ -800,14 +800,14 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   } else {
     A.zt_out = zt_out; A.nn_out = nn_out;  // only the wave-specialised kernel writes the training planes
     A.sc_out = sc_out; A.tsc_out = tsc_out; A.xs_cm = xs_cm; A.u_out = u_out;
-    A.zrec = zrec; A.nn_cm = nn_cm;
+    A.zrec = zrec;
     rc = v->fn(A, st);
     if (rc == SDEH_OK && planes_written != nullptr)
       *planes_written = (zt_out != nullptr && nn_out != nullptr) || xs_cm != nullptr;
     // image + exchange buffers beyond 160 KiB (deep networks): the single-wave kernel needs less LDS
     if (rc == SDEH_ERR_UNSUPPORTED && pr->target.kind != SDEH_DENS_GMM) {
       A.zt_out = nullptr; A.nn_out = nullptr; A.sc_out = nullptr; A.tsc_out = nullptr; A.xs_cm = nullptr; A.u_out = nullptr;
-      A.zrec = nullptr; A.nn_cm = nullptr;
+      A.zrec = nullptr;
       if (planes_written != nullptr) *planes_written = false;
       rc = plan->variant->fn_legacy(A, st);
       snprintf(plan->last_kernel, sizeof(plan->last_kernel), "traj_legacy<%s>", plan->variant->name);
@@ -880,17 +880,16 @@ int32_t sdeh_simulate_fwd_train2u(SdehPlan* plan, const SdehProblem* pr, const f
   return written ? SDEH_OK : 1;
 }
 
-int64_t sdeh_zrec_floats(int32_t n_hidden, int32_t n_steps, int64_t batch) {
-  if (n_hidden < 0 || n_steps < 1 || batch < 1) return 0;
-  return (int64_t)n_steps * ((batch + 31) / 32) * (n_hidden + 1) * 2048;
+int64_t sdeh_zrec_floats(int32_t dim, int32_t n_hidden, int32_t n_steps, int64_t batch) {
+  if (dim < 1 || n_hidden < 0 || n_steps < 1 || batch < 1) return 0;
+  return (int64_t)n_steps * ((batch + 31) / 32) * zrec_tile_floats(n_hidden, dim);
 }
 
 int32_t sdeh_simulate_fwd_train3(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                                  int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
-                                 float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, float* zrec, float* nn,
-                                 void* stream) {
-  if (xs == nullptr || zrec == nullptr || nn == nullptr)
-    return fail(SDEH_ERR_INVALID, "simulate_fwd_train3: xs, zrec and nn are required (sdeh_simulate_fwd_train2[u] keeps the planes without them)");
+                                 float* x_T, float* rnd, float* xs, float* sc, float* tscore, float* u, float* zrec, void* stream) {
+  if (xs == nullptr || zrec == nullptr)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_train3: xs and zrec are required (sdeh_simulate_fwd_train2[u] keeps the planes without the record)");
   if (pr != nullptr && (pr->flags & SDEH_FLAG_INFERENCE_CTRL))
     return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train3: the problem WITHOUT its inference control (sdeh_bridge_inference_fwd adds its terms)");
   if (plan != nullptr && plan->wide) return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_train3: 64-channel plans");
@@ -898,7 +897,7 @@ int32_t sdeh_simulate_fwd_train3(SdehPlan* plan, const SdehProblem* pr, const fl
     return fail(SDEH_ERR_INVALID, "simulate_fwd_train3: sc is required for controls with a score term");
   bool written = false;
   const int rc = simulate_impl(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, nullptr, nullptr, nullptr,
-                               nullptr, nullptr, &written, stream, sc, tscore, xs, u, zrec, nn);
+                               nullptr, nullptr, &written, stream, sc, tscore, xs, u, zrec);
   if (rc != SDEH_OK) return rc;
   return written ? SDEH_OK : 1;  // 1: integrated by a kernel that writes none of the planes
 }
@@ -1199,7 +1198,7 @@ static BwdfChoice bwdf_choice(const SdehProblem* pr, long long batch, bool klb) 
   c.v2 = c.tile == 32 && !force_v1 && enough && bwdf2_fits(d, net.n_hidden) &&
          (d <= 32 || (!bptt) || (force_v2 && pr->target.kind != SDEH_DENS_FUNNEL));
   const char* zo = plan_opt(OPT_BWD_ZREC);
-  c.zin = (zo == nullptr || zo[0] != '0') && !klb && !c.scan && c.tile == 32 && c.v2;
+  c.zin = (zo == nullptr || zo[0] != '0') && !klb && !c.scan && c.tile == 32;  // (both tilings of 32 read the record)
   return c;
 }
 
@@ -1247,11 +1246,8 @@ int32_t sdeh_ctrl_backward_fused_sizes(int32_t dim, int32_t n_hidden, int32_t n_
 static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                                     int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                                     const float* grad_rnd, const float* sc, const float* tscore, const float* cost_ctrl, const float* lam_extra,
-                                    float* scratch, int64_t scratch_floats, float* out, void* stream, const float* zrec = nullptr,
-                                    const float* nn_in = nullptr) {
+                                    float* scratch, int64_t scratch_floats, float* out, void* stream, const float* zrec = nullptr) {
   OptScope opt_scope(plan);
-  if ((zrec != nullptr) != (nn_in != nullptr))
-    return fail(SDEH_ERR_INVALID, "ctrl_backward_fused_z: zrec and nn come together (both written by sdeh_simulate_fwd_train3)");
   if (xs == nullptr || grad_rnd == nullptr || scratch == nullptr || out == nullptr)
     return fail(SDEH_ERR_INVALID, "ctrl_backward_fused: null argument");
   Checked ck;
@@ -1301,7 +1297,7 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
   A.xs = xs; A.noise = noise; A.grad_rnd = grad_rnd; A.sc = sc; A.tscore = tscore;
   A.cost_in = cost_ctrl; A.lam_in = lam_extra;
   // the pre-activation record: the kernels that can read it do not re-evaluate the network (plan option SDEH_BWD_ZREC=0: ignore it)
-  if (choice.zin) { A.zrec = zrec; A.nn_in = nn_in; }
+  if (choice.zin) A.zrec = zrec;
   A.wpart = scratch; A.epart = scratch + n_w; A.gpart = scratch + n_w + n_e;
   float* sums = scratch + n_w + n_e + n_g;
   A.batch = batch; A.row_offset = row_offset; A.n_steps = n_steps; A.d = d; A.n_kg = (d + 7) / 8;
@@ -1368,10 +1364,10 @@ int32_t sdeh_ctrl_backward_fused_ex(SdehPlan* plan, const SdehProblem* pr, const
 int32_t sdeh_ctrl_backward_fused_z(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* xs,
                                    int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                                    const float* grad_rnd, const float* sc, const float* tscore, const float* cost_ctrl,
-                                   const float* lam_extra, const float* zrec, const float* nn, float* scratch, int64_t scratch_floats,
-                                   float* out, void* stream) {
+                                   const float* lam_extra, const float* zrec, float* scratch, int64_t scratch_floats, float* out,
+                                   void* stream) {
   return ctrl_backward_fused_impl(plan, pr, ts, n_steps, xs, batch, noise, seed, offset, row_offset, grad_rnd, sc, tscore, cost_ctrl, lam_extra,
-                                  scratch, scratch_floats, out, stream, zrec, nn);
+                                  scratch, scratch_floats, out, stream, zrec);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -42,16 +42,24 @@ namespace sdeh {
 #ifdef SDEH_BWDF_PROFILE
 __device__ unsigned long long bwdf_prof[16];
 #define BWDF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define BWDF_DECL(var) unsigned long long var = __builtin_readcyclecounter()
+#define BWDF_SET(var) var = __builtin_readcyclecounter()
 #define BWDF_ADD(k, t0, t1) do { if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&bwdf_prof[k], (t1) - (t0)); } while (0)
 #else
 #define BWDF_T(var) do {} while (0)
+#define BWDF_DECL(var) do {} while (0)
+#define BWDF_SET(var) do {} while (0)
 #define BWDF_ADD(k, t0, t1) do {} while (0)
 #endif
 
 
 
 // KLB (through time, a Bridge's generative network with method kl): the running cost on the plane cost_in = u + v, lam_in added to the adjoint
-template <int OTD, bool BPTT, int LH, bool KLB = false>
+// ZIN (round 5): no re-evaluation -- the pre-activations come from the record the training forward kept (sdeh_traj_ws.hpp: ZRec; wave r
+// loads row tile r of a layer with four 16-byte loads per lane, in its accumulator layout), the raw network output from its plane.  A
+// layer's record is requested a stage ahead of the stage that activates it (two 16-register buffers); the three layer exchanges of the
+// forward pass and their barriers are gone (one barrier at the top of a step keeps the planes' reuse ordered).
+template <int OTD, bool BPTT, int LH, bool KLB = false, bool ZIN = false>
 __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   using namespace bwdf;
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
@@ -169,12 +177,29 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   // (the time embedding of the next step travels with it: it must be the FIRST addend of the input layer's sum -- the re-evaluated
   // pre-activations then are bit for bit the forward launch's, so a ReLU unit near its kink is on the same side in both passes --
   // and must not hold up the first MFMA of the step)
-  f32x16 xnext, embnext;
+  // ZIN: row tile r of layer k of the record of (step, tile); layer k lives in zA when LH - k is even, else in zB (sdeh_bwdf2.hip)
+  typedef float f32x4z __attribute__((ext_vector_type(4)));
+  auto load_z = [&](int t, long long tile_i, int k, f32x16& zo) {
+    if constexpr (ZIN) {
+      const float* __restrict__ base = A.zrec + ((long long)t * n_tiles + tile_i) * ((LH + 1) * 2048 + OTD * 1024) + k * 2048 + r * 1024;
+      unsigned lo = (unsigned)(h * 128 + j * 4) * 4u;
+      asm volatile("" : "+v"(lo));
+      const char* __restrict__ pb = reinterpret_cast<const char*>(base) + lo;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4z v = __builtin_nontemporal_load(reinterpret_cast<const f32x4z*>(pb + g * 1024));
+        zo[4 * g] = v[0]; zo[4 * g + 1] = v[1]; zo[4 * g + 2] = v[2]; zo[4 * g + 3] = v[3];
+      }
+    }
+  };
+  f32x16 xnext, embnext, zA, zB;
   {
     int t0 = it_t, tl0 = it_tile;
     clamp_item(t0, tl0);
     xnext = load_x(t0, tl0);
-    embnext = load16(ws + L.emb + t0 * C + (r * 2 + h) * 16);
+    if constexpr (!ZIN) embnext = load16(ws + L.emb + t0 * C + (r * 2 + h) * 16);
+    load_z(t0, tl0, LH, zA);
+    load_z(t0, tl0, LH - 1, zB);
   }
   for (long long round = 0; round < n_rounds; ++round) {
     const bool live_item = item_live(it_t, it_tile);
@@ -219,15 +244,18 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
 
     for (int t = t_first; t >= t_last; --t) {
       const f32x16 x = xnext;
-      const f32x16 embv = embnext;  // timestep_embed(t) + input bias of this wave's channels
-      if (t > t_last) {
-        xnext = load_x(t - 1, cur_tile);
-        embnext = load16(ws + L.emb + (t - 1) * C + (r * 2 + h) * 16);
-      } else if (round + 1 < n_rounds) {
-        int tn = it_t, tln = it_tile;
-        clamp_item(tn, tln);
-        xnext = load_x(tn, tln);
-        embnext = load16(ws + L.emb + tn * C + (r * 2 + h) * 16);
+      f32x16 embv;  // timestep_embed(t) + input bias of this wave's channels
+      if constexpr (!ZIN) embv = embnext;
+      int nxt_t = t - 1, nxt_tile = cur_tile;  // the step (or item) that comes next
+      bool has_next = true;
+      if (t <= t_last) {
+        nxt_t = it_t; nxt_tile = it_tile;
+        clamp_item(nxt_t, nxt_tile);
+        has_next = round + 1 < n_rounds;
+      }
+      if (has_next) {
+        xnext = load_x(nxt_t, nxt_tile);
+        if constexpr (!ZIN) embnext = load16(ws + L.emb + nxt_t * C + (r * 2 + h) * 16);
       }
       // the step's other inputs: requested first, consumed after the forward pass
       f32x16 scv, xi;
@@ -265,10 +293,34 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       float* __restrict__ Ap[2] = {pl + par * PLANE, pl + (1 - par) * PLANE};
       float* __restrict__ Dp[2] = {pl + 2 * PLANE, pl + 3 * PLANE};
       BWDF_T(tp0);
+      BWDF_DECL(tp1);
+      BWDF_DECL(tp2);
+      f32x16 g[ZIN ? 1 : LH + 1], aown[LH > 1 ? LH - 1 : 1];
+      f32x16 gz;  // ZIN: act'(Z) of the layer activated last
+      f32x16 nn;
+      const int bofs = 4 * h * RS + j;  // this lane's column of a plane as an MFMA B operand
+      if constexpr (ZIN) {
+        {  // the raw network output of this wave's coordinate tile: the record's last part (coordinates >= d, unwritten quads: zeros)
+          const float* __restrict__ base = A.zrec + ((long long)t * n_tiles + tile) * ((LH + 1) * 2048 + OTD * 1024) + (LH + 1) * 2048 + ct * 1024;
+          unsigned lo = (unsigned)(h * 128 + j * 4) * 4u;
+          asm volatile("" : "+v"(lo));
+          const char* __restrict__ pb = reinterpret_cast<const char*>(base) + lo;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const bool okq = cb + 8 * g < d;
+            const f32x4z v = __builtin_nontemporal_load(reinterpret_cast<const f32x4z*>(pb + (okq ? g * 256 * 4 : 0)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nn[4 * g + e] = cb + 8 * g + e < d ? v[e] : 0.0f;
+          }
+        }
+        ws_barrier();  // every read of the previous step's planes is done
+        f32x16 atop;
+        SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(zA, atop, gz););
+        plane_put(Ap[(LH + 1) & 1], r, j, h, atop);  // a_{LH+1}
+        if constexpr (LH >= 2) load_z(t, tile, LH - 2, zA);
+      } else {
       plane_put(Ap[0], ct, j, h, x);
       ws_barrier();
-      f32x16 g[LH + 1], aown[LH > 1 ? LH - 1 : 1];
-      const int bofs = 4 * h * RS + j;  // this lane's column of a plane as an MFMA B operand
       {
         const f32x16 z0 = mm_rows<4 * OTD>(Win + (32 * r + j) * RSI + 4 * h, Ap[0] + bofs, A.n_kg, embv);
         f32x16 a1;
@@ -277,7 +329,7 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         plane_put(Ap[1], r, j, h, a1);
       }
       ws_barrier();
-      BWDF_T(tp1);
+      BWDF_SET(tp1);
 #pragma unroll
       for (int l = 0; l < LH; ++l) {  // hidden layer l: Z_{l+1} = W_l a_{l+1} + b_l;  a_{l+2} = act(Z_{l+1})
         const f32x16 z = mm_rows<8>(Whid + l * 64 * RSW + (32 * r + j) * RSW + 4 * h, Ap[(l + 1) & 1] + bofs, 8, rows16(bh + l * 64 + 32 * r + 4 * h));
@@ -287,8 +339,9 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
         plane_put(Ap[l & 1], r, j, h, an);
         ws_barrier();
       }
-      BWDF_T(tp2);
-      const f32x16 nn = mm_rows<8>(Wout + (32 * ct + j) * RSW + 4 * h, Ap[(LH + 1) & 1] + bofs, 8, rows16(bo + cb));
+      BWDF_SET(tp2);
+      nn = mm_rows<8>(Wout + (32 * ct + j) * RSW + 4 * h, Ap[(LH + 1) & 1] + bofs, 8, rows16(bo + cb));
+      }
       BWDF_T(tp3);
 
       // ======================================================================================= upstream gradient of the control
@@ -357,22 +410,38 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
       f32x16 dl;
       if constexpr (OTD == 2) dw_acc<true>(Dp[0], r, Ap[(LH + 1) & 1], 0, dw[OTD + 2 * LH], dw[NDW - 1], bs_out, j, h);
       else dw_acc<false>(Dp[0], 0, Ap[(LH + 1) & 1], r, dw[OTD + 2 * LH], dw[OTD + 2 * LH], bs_out, j, h);
-      dl = mm_cols<4 * OTD, RSW>(Wout + (4 * h) * RSW + 32 * r + j, Dp[0] + bofs, A.n_kg) * g[LH];
+      dl = mm_cols<4 * OTD, RSW>(Wout + (4 * h) * RSW + 32 * r + j, Dp[0] + bofs, A.n_kg) * (ZIN ? gz : g[ZIN ? 0 : LH]);
       BWDF_T(tp5);
 #pragma unroll
       for (int l = LH - 1; l >= 0; --l) {  // hidden layer l: dl = d loss / d Z_{l+1}
         float* __restrict__ Dl = Dp[(LH - l) & 1];
         float* __restrict__ Al = Ap[(l + 1) & 1];
         plane_put(Dl, r, j, h, dl);
-        if (l + 1 <= LH - 1) plane_put(Al, r, j, h, aown[l + 1 <= LH - 1 ? l : 0]);  // a_{l+1}: its plane was overwritten by a_{l+3}
+        if constexpr (ZIN) {
+          // a_{l+1} = act(Z_l) and act'(Z_l) from the record requested a stage ago
+          f32x16 al;
+          if (((LH - l) & 1) == 0) { SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(zA, al, gz);); }
+          else { SDEH_ACT_SWITCH(act, ACT, act_both<ACT>(zB, al, gz);); }
+          plane_put(Al, r, j, h, al);
+          if (l >= 2) {
+            if (((LH - l) & 1) == 0) load_z(t, tile, l >= 2 ? l - 2 : 0, zA);
+            else load_z(t, tile, l >= 2 ? l - 2 : 0, zB);
+          }
+          if (l == 0 && has_next) load_z(nxt_t, nxt_tile, LH, zA);  // the next step's top layer (zA has been free since its last activation)
+        } else {
+          if (l + 1 <= LH - 1) plane_put(Al, r, j, h, aown[l + 1 <= LH - 1 ? l : 0]);  // a_{l+1}: its plane was overwritten by a_{l+3}
+        }
         ws_barrier();
         dw_acc<true>(Dl, r, Al, 0, dw[OTD + 2 * l], dw[OTD + 2 * l + 1], bs_hid[l], j, h);
-        dl = mm_cols<8, RSW>(Whid + l * 64 * RSW + (4 * h) * RSW + 32 * r + j, Dl + bofs, 8) * g[l];
+        dl = mm_cols<8, RSW>(Whid + l * 64 * RSW + (4 * h) * RSW + 32 * r + j, Dl + bofs, 8) * (ZIN ? gz : g[ZIN ? 0 : l]);
       }
       BWDF_T(tp6);
       float* __restrict__ Din = Dp[(LH + 1) & 1];
       plane_put(Din, r, j, h, dl);
       plane_put(Ap[0], ct, j, h, x);
+      if constexpr (ZIN) {
+        if (has_next) load_z(nxt_t, nxt_tile, LH - 1, zB);
+      }
       ws_barrier();  // delta_0 | x
       {
         float esum = 0.0f;
@@ -487,10 +556,13 @@ __global__ __launch_bounds__(256) void bwdf_kernel(const BwdfArgs A) {
   }
 }
 
-template <int OTD, bool BPTT, int LH, bool KLB = false>
+template <int OTD, bool BPTT, int LH, bool KLB = false, bool ZIN = false>
 static int launch_bwdf_t(const BwdfArgs& a, hipStream_t stream) {
   if constexpr (BPTT && LH == 2 && !KLB) {
     if (a.cost_in != nullptr && a.lam_in != nullptr) return launch_bwdf_t<OTD, BPTT, LH, true>(a, stream);
+  }
+  if constexpr (!KLB && !ZIN) {
+    if (a.zrec != nullptr) return launch_bwdf_t<OTD, BPTT, LH, false, true>(a, stream);
   }
   if (!KLB && (a.cost_in != nullptr || a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;  // (two hidden layers, both planes)
   const size_t lds_bytes = (size_t)bwdf::lds_floats<OTD, LH>() * sizeof(float);
@@ -498,12 +570,12 @@ static int launch_bwdf_t(const BwdfArgs& a, hipStream_t stream) {
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf_kernel<OTD, BPTT, LH, KLB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf_kernel<OTD, BPTT, LH, KLB, ZIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwdf_kernel<OTD, BPTT, LH, KLB>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
+  hipLaunchKernelGGL((bwdf_kernel<OTD, BPTT, LH, KLB, ZIN>), dim3((unsigned)(a.n_slots / 2)), dim3(256), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   typedef float f32x4z __attribute__((ext_vector_type(4)));
   auto load_z = [&](int t, long long tile_i, int k, f32x16 (&zo)[2]) {
     if constexpr (ZIN) {
-      const float* __restrict__ base = A.zrec + (((long long)t * n_tiles + tile_i) * (LH + 1) + k) * 2048;
+      const float* __restrict__ base = A.zrec + ((long long)t * n_tiles + tile_i) * ((LH + 1) * 2048 + OTD * 1024) + k * 2048;
       unsigned lo = (unsigned)(h * 128 + j * 4) * 4u;
       asm volatile("" : "+v"(lo));
       const char* __restrict__ pb = reinterpret_cast<const char*>(base) + lo;
@@ -241,6 +241,30 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     }
   };
 
+  // ZIN: the raw network output of (step, tile), coordinate tile ct: the record's last part, in the accumulator layout as well (coordinate
+  // quads 2 g + h); quads the forward's vector wave did not write (d <= 4: beyond the first) and coordinates >= d: zero by a select
+  auto load_nn = [&](int t, long long tile_i, int ct, f32x16& no) {
+    if constexpr (ZIN) {
+      const float* __restrict__ base = A.zrec + ((long long)t * n_tiles + tile_i) * ((LH + 1) * 2048 + OTD * 1024) + (LH + 1) * 2048 + ct * 1024;
+      unsigned lo = (unsigned)(h * 128 + j * 4) * 4u;
+      asm volatile("" : "+v"(lo));
+      const char* __restrict__ pb = reinterpret_cast<const char*>(base) + lo;
+      const int cb = 32 * ct + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (4 * g < NQ) {
+          // (a quad beyond d was never written: read quad 0 of this lane half instead -- a valid address -- and select zeros)
+          const bool okq = cb + 8 * g < d;
+          const f32x4z v = __builtin_nontemporal_load(reinterpret_cast<const f32x4z*>(pb + (okq ? g * 256 * 4 : 0)));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) no[4 * g + e] = cb + 8 * g + e < d ? v[e] : 0.0f;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) no[4 * g + e] = 0.0f;
+        }
+      }
+    }
+  };
   // ZIN: two record buffers in flight -- layer k of a step lives in zA when LH - k is even, else in zB, and is requested where the
   // buffer's previous content was activated: Z_LH of the NEXT step in front of this step's last hidden stage, Z_{LH-1} of the next step in
   // front of the in stage, Z_{LH-2} of this step at its top -- every request a whole stage (8-10 k cycles of matrix work) ahead of its use
@@ -330,7 +354,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       if constexpr (ZIN) {
         // raw network output and score planes first (their latency hides behind the activation of Z_LH, which arrived a step ago)
 #pragma unroll
-        for (int ct = 0; ct < OTD; ++ct) nn[ct] = load_cm(A.nn_in + (long long)t * d * B, (unsigned)lrow, ct);
+        for (int ct = 0; ct < OTD; ++ct) load_nn(t, tile, ct, nn[ct]);
         if (has_score) {
 #pragma unroll
           for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
@@ -1186,7 +1210,7 @@ static int launch_bwdf2_q(const BwdfArgs& a, hipStream_t stream) {
   }
   if (!KLB && BPTT && (a.cost_in != nullptr || a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;  // (two hidden layers, both planes)
   if constexpr (!KLB) {
-    if (a.zrec != nullptr && a.nn_in != nullptr) return launch_bwdf2_z<OTD, BPTT, LH, NQ, VIO>(a, stream);
+    if (a.zrec != nullptr) return launch_bwdf2_z<OTD, BPTT, LH, NQ, VIO>(a, stream);
   }
   constexpr bool RECOMP = false;  // (the slot of the ZIN parameter: this launch re-evaluates the network)
   const size_t lds_bytes = (size_t)(bwdf::lds_floats<OTD, LH>() + 512) * sizeof(float);

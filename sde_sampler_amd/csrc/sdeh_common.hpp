@@ -23,6 +23,8 @@ __host__ __device__ constexpr int rho(int q, int h) { return (q & 3) + 8 * (q >>
 // coordinate held by M-layout register r (r counts across 32-row tiles) in lane half h
 __host__ __device__ constexpr int mdim(int r, int h) { return 32 * (r / 16) + rho(r % 16, h); }
 __host__ __device__ constexpr int row_tiles(int n) { return (n + 31) / 32; }
+// floats of one 32-trajectory tile of the pre-activation record (sdeh_traj_ws.hpp: ZRec): Lh + 1 layers, then the network output's tiles
+__host__ __device__ constexpr int zrec_tile_floats(int n_hidden, int dim) { return (n_hidden + 1) * 2048 + 1024 * ((dim + 31) / 32); }
 // number of M-layout registers needed to cover coordinates [0, n)
 __host__ __device__ constexpr int mregs(int n) {
   int c = 0;
@@ -125,8 +127,7 @@ struct TrajArgs {
   float* u_out;   // [T, d, B] or null: the control u_t driving the SDE (Bridge training: the inference pass is row-parallel given x_t, u_t)
   float* tsc_out; // [d, B] or null: 1[|log rho(x_T)| <= clip_target] * target.score(x_T)  (d terminal target cost / d x_T, negated)
   // training forward that also keeps the network's pre-activations for the fused backward (sdeh_simulate_fwd_train3)
-  float* zrec;    // [T][ceil(B / 32)][Lh + 1][16][32][4] or null: the pre-activation record (sdeh_traj_ws.hpp: ZRec)
-  float* nn_cm;   // [T, d, B] or null: raw network output (before the clamp), coordinate-major
+  float* zrec;    // [T][ceil(B / 32)]{[Lh + 1][16][32][4]; [ceil(d / 32)][8][32][4]} or null: the pre-activation record + raw network output (sdeh_traj_ws.hpp: ZRec)
 };
 
 // sdeh_bridge_div_backward (sdeh_bridge.hpp): gradient of  sum_n w_i sigma dt div_x v(x_n)  w.r.t. the inference network
@@ -245,8 +246,7 @@ struct BwdfArgs {
   float* div_hid;         // [n_slots][2][64][64]: the divergence term's direct gradient of the two hidden weights, per team
   float* div_io;          // [n_slots * 4][2][32 OTD][64] (zeroed by the caller): per wave, columns of input_embed.weight | rows of out_layer.weight
   // the pre-activation record and the raw network output of sdeh_simulate_fwd_train3: the kernels that take them do not re-evaluate the network
-  const float* zrec;      // [T][ceil(B / 32)][Lh + 1][16][32][4] or null
-  const float* nn_in;     // [T, d, B] or null
+  const float* zrec;      // [T][ceil(B / 32)]{[Lh + 1][16][32][4]; [ceil(d / 32)][8][32][4]} or null
 };
 int launch_bridge_divf(const BwdfArgs& a, hipStream_t stream);  // divergence term of a 64-channel Bridge, two hidden layers (sdeh_bridgef.hip)
 bool bridge_divf_fits(int d, int n_hidden);

@@ -347,7 +347,9 @@ __device__ __forceinline__ void ws_store_z(const ZStore& Z, int layer, int C, in
 
 // Pre-activation RECORD of the training forward (PLANES == 3, round 5: the fused backward READS the pre-activations instead of
 // re-evaluating the network -- the reference's autograd keeps them as well, losses/oc.py:232-256 -> models/mlp.py:114-122):
-//     zrec[step][tile of 32 trajectories][layer 0 .. Lh][channel quad cq = 0 .. 15][trajectory j = 0 .. 31][4 channels]
+//     zrec[step][tile of 32 trajectories]{ [layer 0 .. Lh][channel quad cq = 0 .. 15][trajectory j = 0 .. 31][4 channels] ;
+//                                          [coordinate tile 0 .. OTD - 1][coordinate quad 0 .. 7][trajectory j][4 coordinates] }
+// (the second part: the raw network output, before the clamp -- the backward's clamp mask and, through time, its control)
 // Accumulator registers 4 g .. 4 g + 3 of lane (j, h), row tile ot are channels 32 ot + 8 g + 4 h .. + 3 of trajectory j, i.e. quad
 // cq = 8 ot + 2 g + h: one 16-byte store per lane, 1 KB contiguous per instruction, and the trajectory-split backward (lane (j, h) of the
 // wave that owns the tile) loads exactly what was stored.  Non-temporal: every word is written once and read once, by another kernel.
@@ -355,14 +357,23 @@ typedef float f32x4z __attribute__((ext_vector_type(4)));
 struct ZRec {
   float* base;   // record of (step, the group's first tile), or null
   int tiles;     // live 32-trajectory tiles of the group (0 .. 2): tiles beyond the batch are not stored
-  int lh1;       // layers per tile (Lh + 1)
+  int lh1;       // layers per tile (Lh + 1); the network output's tiles follow them ("layer" lh1, ot = coordinate tile)
+  int stride;    // floats per tile: lh1 * 2048 + 1024 * coordinate tiles
 };
 __device__ __forceinline__ void ws_store_zrec(const ZRec& Z, int layer, int ot, int col_tile, int lane, const f32x16& v) {
+#ifdef SDEH_ZREC_SKIP  // (measurement builds, tools/zrec_fwd_ablation.sh)
+  return;
+#endif
   if (col_tile < Z.tiles) {
-    float* __restrict__ p = Z.base + ((long long)col_tile * Z.lh1 + layer) * 2048 + ot * 1024 + (lane >> 5) * 128 + (lane & 31) * 4;
+    float* __restrict__ p = Z.base + (long long)col_tile * Z.stride + layer * 2048 + ot * 1024 + (lane >> 5) * 128 + (lane & 31) * 4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < 4; ++g) {
+#ifdef SDEH_ZREC_NO_NT
+      *reinterpret_cast<f32x4z*>(p + g * 256) = f32x4z{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+#else
       __builtin_nontemporal_store(f32x4z{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, reinterpret_cast<f32x4z*>(p + g * 256));
+#endif
+    }
   }
 }
 // ZS (template parameter of the network passes): 0 = nothing stored, 1 = coordinate-major planes (ZStore, round 1), 2 = the record
@@ -538,6 +549,10 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
     mfma_stage<C / 2, OTD, OT>(w, [&](int s) { return curA[s / 16][s % 16]; }, uA, curB, true, act);  // + act(B)
     f32x16 none[1];
     mfma_stage<C / 2, OTD, 1>(w, [&](int s) { return curB[s / 16][s % 16]; }, uB, none, false, act);
+    if constexpr (ZS == 2) {  // the raw network output joins the record (coordinates >= d: zero weights and biases, exact zeros)
+#pragma unroll
+      for (int t = 0; t < OTD; ++t) { ws_store_zrec(Zr, Zr.lh1, t, 0, lane, uA[t]); ws_store_zrec(Zr, Zr.lh1, t, 1, lane, uB[t]); }
+    }
     // accumulator register r of lane (j,h) is coordinate mdim(r,h) of trajectory j (tile A) / 32+j (tile B)
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -591,6 +606,10 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
 #pragma unroll
   for (int t = 0; t < OTD; ++t) u[t] = load16(lds + L.b_out + (t * 2 + h) * 16);
   mfma_stage<C / 2, OTD, 1>(lds + L.w_out + lane, [&](int s) { return cur[s / 16][s % 16]; }, u, none, false, act);
+  if constexpr (ZS == 2) {
+#pragma unroll
+    for (int t = 0; t < OTD; ++t) ws_store_zrec(Zr, Zr.lh1, t, 0, lane, u[t]);
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r) xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j] = u[r / 16][r % 16];
 }
@@ -869,7 +888,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     // the pre-activation record (PLANES == 3): tiles of 32 trajectories, (Lh + 1) layers of 2048 floats per tile and step
     const long long zr_tiles = (A.batch + 31) >> 5;
     const int zr_lh1 = L.n_hidden + 1;
-    const long long zr_step = zr_tiles * zr_lh1 * 2048;
+    const int zr_stride = zrec_tile_floats(L.n_hidden, d);
+    const long long zr_step = zr_tiles * zr_stride;
     if constexpr (C == 64 && DP <= 32 && PLANES != 1) {
       if (quad) {
         const int mw = wave - 1;
@@ -880,9 +900,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         int parity = 0;
         f32x4q emb1 = *reinterpret_cast<const f32x4q*>(ws + L.emb + epos);
         ws_barrier();  // barrier A: x_0 published
-        ZRec Zr{nullptr, 0, zr_lh1};
+        ZRec Zr{nullptr, 0, zr_lh1, zr_stride};
         if constexpr (PLANES == 3) {
-          if (A.zrec != nullptr) { Zr.base = A.zrec + (long long)blockIdx.x * zr_lh1 * 2048; Zr.tiles = 1; }
+          if (A.zrec != nullptr) { Zr.base = A.zrec + (long long)blockIdx.x * zr_stride; Zr.tiles = 1; }
         }
         for (int i = 0; i < n_steps; ++i) {
           SDEH_ACT_SWITCH(act, ACTC, ws_mlp_quad<DP, C, ACTC, (PLANES == 3)>(lds, xbuf, planes, pout, L, emb1, lane, mw, parity, Zr););
@@ -903,9 +923,9 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
         ws_barrier();  // barrier A: x_0 published
         const long long row0 = (long long)blockIdx.x * 32;
         ZStore Z{nullptr, (long long)n_steps * A.batch, A.zt_out == nullptr ? 0 : (int)(A.batch - row0 < 32 ? A.batch - row0 : 32)};
-        ZRec Zr{nullptr, 0, zr_lh1};
+        ZRec Zr{nullptr, 0, zr_lh1, zr_stride};
         if constexpr (PLANES == 3) {
-          if (A.zrec != nullptr) { Zr.base = A.zrec + (long long)blockIdx.x * zr_lh1 * 2048; Zr.tiles = 1; }
+          if (A.zrec != nullptr) { Zr.base = A.zrec + (long long)blockIdx.x * zr_stride; Zr.tiles = 1; }
         }
         for (int i = 0; i < n_steps; ++i) {
           if constexpr (PLANES == 1) Z.base = A.zt_out + (long long)i * A.batch + row0;
@@ -932,12 +952,12 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       Z.rows = (int)(A.batch - row0 < rpg_m ? (A.batch - row0 > 0 ? A.batch - row0 : 0) : rpg_m);
       if (A.zt_out == nullptr) Z.rows = 0;  // fused backward (sdeh_simulate_fwd_train2): no pre-activation planes
     }
-    ZRec Zr{nullptr, 0, zr_lh1};
+    ZRec Zr{nullptr, 0, zr_lh1, zr_stride};
     if constexpr (PLANES == 3) {
       if (A.zrec != nullptr) {
         const int tpg = A.half ? 1 : 2;  // 32-trajectory tiles per group
         const long long tile0 = ((long long)blockIdx.x * n_groups + group) * tpg;
-        Zr.base = A.zrec + tile0 * zr_lh1 * 2048;
+        Zr.base = A.zrec + tile0 * zr_stride;
         Zr.tiles = (int)(zr_tiles - tile0 < tpg ? (zr_tiles - tile0 > 0 ? zr_tiles - tile0 : 0) : tpg);
       }
     }
@@ -1185,14 +1205,27 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 #pragma unroll
       for (int j = 0; j < DP; ++j) u[j] = xbuf[j * 64 + lane];
     }
+    if constexpr (PLANES == 3) {
+      // the raw network output joins the pre-activation record (ZRec: [coordinate quad][trajectory][4] behind the layers).  The M wave
+      // stores it where it forms the whole sum (ws_mlp / ws_mlp_half); here the cases in which only this wave has it: the out layer on
+      // the vector pipe (d <= 4) and the pair / quad modes' partial sums -- 16-byte stores, ceil(d / 4) per lane
+      if (A.zrec != nullptr && live && (pair || (DP <= 4 && abuf != nullptr))) {
+        const int zr_stride = zrec_tile_floats(L.n_hidden, d);
+        float* __restrict__ zp = A.zrec + ((long long)i * ((A.batch + 31) >> 5) + (row >> 5)) * zr_stride + (L.n_hidden + 1) * 2048 + (int)(row & 31) * 4;
+#pragma unroll
+        for (int g4 = 0; g4 < (DP + 3) / 4; ++g4) {
+          f32x4z v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (4 * g4 + e < DP && (!PAD || 4 * g4 + e < d)) ? u[4 * g4 + e < DP ? 4 * g4 + e : 0] : 0.0f;
+          if (!PAD || 4 * g4 < d) __builtin_nontemporal_store(v, reinterpret_cast<f32x4z*>(zp + (g4 >> 3) * 1024 + (g4 & 7) * 128));
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
       const float nn = u[j];
       if constexpr (PLANES == 1) {
         if (A.nn_out != nullptr && live && (!PAD || j < d)) A.nn_out[((long long)i * A.batch + lrow) * d + j] = nn;
-      }
-      if constexpr (PLANES == 3) {  // raw network output, coordinate-major [T, d, B]: the clamp's mask (and u, through time) of the backward
-        if (A.nn_cm != nullptr && live && (!PAD || j < d)) A.nn_cm[((long long)i * d + j) * A.batch + lrow] = nn;
       }
       u[j] = clipf(nn, A.clip_model) + sterm[j];
       if (PAD) u[j] = j < d ? u[j] : 0.0f;
@@ -1313,7 +1346,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
   // (pair / quad mode: at least one hidden layer -- its exchange barrier is what separates the M waves' reads of x from the write of the
   // first partial network output into the same buffer)
   const bool pair_fits = C == 64 && a.lay.n_hidden >= 1 && ws_pair_lds_bytes<DP>(a.lay) <= 160 * 1024;
-  const int planes = (a.zt_out != nullptr && a.nn_out != nullptr) ? 1 : (a.zrec != nullptr && a.nn_cm != nullptr ? 3 :
+  const int planes = (a.zt_out != nullptr && a.nn_out != nullptr) ? 1 : (a.zrec != nullptr ? 3 :
                      (a.sc_out != nullptr || a.tsc_out != nullptr || a.xs_cm != nullptr ? 2 : 0));
   static bool attr_done[kMaxDevices] = {};  // the raised LDS limit is a per-device function attribute
   bool& attr_set = attr_done[current_device_slot()];

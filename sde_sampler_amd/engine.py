@@ -620,7 +620,7 @@ class TrajectoryEngine:
         """Launches prep + trajectory kernels.  Returns (x_T [B,d], rnd [B,1], xs [T+1,B,d] | None); with `want_gp`
         (Bridge training) additionally the plane u + v [T,B,d] as a fourth element and, fifth, (sc [T,B,d] | None, tscore [B,d] | None)
         -- the score planes a wide Bridge on a mixture target keeps for its generative network's backward; with `want_planes` (training without an
-        inference control) a fourth element: ("fused", sc [T,d,B] | None, tscore [d,B] | None, u [T,d,B] | None, zrec | None, nn [T,d,B] | None) when the fused backward takes the
+        inference control) a fourth element: ("fused", sc [T,d,B] | None, tscore [d,B] | None, u [T,d,B] | None, zrec | None) when the fused backward takes the
         problem (xs is then the coordinate-major [T+1,d,B] plane), else (zt [(Lh+1),C,T*B], nn [T,B,d]); None when the launch kept nothing."""
         if not x.is_cuda:
             raise RuntimeError("the HIP trajectory engine needs CUDA/HIP tensors (got a CPU tensor); "
@@ -704,23 +704,21 @@ class TrajectoryEngine:
                           if bptt and (pr.flags & L.FLAG_TERMINAL_TARGET) else None)
                 # want_u (split Bridge training, losses/_autograd.py): also the control driving the SDE, [T, d, B]
                 u_cm = torch.empty((n_steps, dim, batch), device=device, dtype=torch.float32) if want_u else None
-                # the pre-activation record + raw network output (ABI v6): kept when the backward launch that will serve this problem
+                # the pre-activation record (with the raw network output; ABI v6): kept when the backward launch that will serve this problem
                 # reads them (then it does not re-evaluate the network) and the record fits the memory budget
-                zrec = nn_cm = None
-                n_z = lib.sdeh_zrec_floats(pr.base_model.n_hidden, n_steps, batch)
+                zrec = None
+                n_z = lib.sdeh_zrec_floats(dim, pr.base_model.n_hidden, n_steps, batch)
                 # (a split Bridge with method kl takes its running cost and adjoint planes through kernels that re-evaluate: nothing kept)
                 if (not (want_u and bptt) and lib.sdeh_ctrl_backward_fused_reads_zrec(plan.handle, C.byref(pr), batch)
                         and _zrec_fits(4 * n_z, device)):
                     zrec = torch.empty(n_z, device=device, dtype=torch.float32)
-                    nn_cm = torch.empty((n_steps, dim, batch), device=device, dtype=torch.float32)
                 with torch.cuda.device(device):
                     if zrec is not None:
                         status = lib.sdeh_simulate_fwd_train3(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
                                                               seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
                                                               rnd.data_ptr(), xs_cm.data_ptr(), None if sc is None else sc.data_ptr(),
                                                               None if tscore is None else tscore.data_ptr(),
-                                                              None if u_cm is None else u_cm.data_ptr(), zrec.data_ptr(),
-                                                              nn_cm.data_ptr(), stream)
+                                                              None if u_cm is None else u_cm.data_ptr(), zrec.data_ptr(), stream)
                     elif want_u:
                         status = lib.sdeh_simulate_fwd_train2u(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
                                                                seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, x_T.data_ptr(),
@@ -734,10 +732,10 @@ class TrajectoryEngine:
                 if status < 0:
                     L.check(status)
                 if status == 0:
-                    return x_T, rnd, xs_cm, ("fused", sc, tscore, u_cm, zrec, nn_cm)
+                    return x_T, rnd, xs_cm, ("fused", sc, tscore, u_cm, zrec)
                 if want_u:  # served by a kernel that keeps no planes (mixture tables beyond LDS, SDEH_LEGACY): the caller falls back
                     return x_T, rnd, None, None
-                del xs_cm, sc, tscore, zrec, nn_cm  # integrated by a kernel that keeps no planes (mixture tables beyond LDS): once more, the plane way
+                del xs_cm, sc, tscore, zrec  # integrated by a kernel that keeps no planes (mixture tables beyond LDS): once more, the plane way
             xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
             zt = torch.empty((pr.base_model.n_hidden + 1, pr.base_model.channels, n_steps * batch), device=device, dtype=torch.float32)
             nn = torch.empty((n_steps, batch, dim), device=device, dtype=torch.float32)

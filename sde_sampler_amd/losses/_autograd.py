@@ -55,10 +55,10 @@ def _ctrl_backward(engine, pr, keep, ts, xs, w, st, gextra=None, cost_ctrl=None,
     return (zt, dt, dout, dgam) if xt is None else (zt, dt, dout, dgam, xt)
 
 
-def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore, cost_ctrl=None, lam_extra=None, zrec=None, nn=None) -> dict[int, torch.Tensor]:
+def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore, cost_ctrl=None, lam_extra=None, zrec=None) -> dict[int, torch.Tensor]:
     """Parameter gradients of the generative control from sdeh_ctrl_backward_fused (back-propagation and weight gradients in one
-    kernel; csrc/sdeh_bwdf.hip) + sdeh_time_embed_backward on the two [T, .] tables.  `zrec` / `nn`: the pre-activation record and raw
-    network output of sdeh_simulate_fwd_train3 -- the launch then reads them instead of re-evaluating the network (ABI v6)."""
+    kernel; csrc/sdeh_bwdf.hip) + sdeh_time_embed_backward on the two [T, .] tables.  `zrec`: the pre-activation record of
+    sdeh_simulate_fwd_train3 -- the launch then reads it instead of re-evaluating the network (ABI v6)."""
     ctrl, engine = loss.generative_ctrl, loss.engine
     base = ctrl.base_model
     dev = xs.device
@@ -80,7 +80,7 @@ def _fused_backward(loss, pr, keep, ts, xs, w, st, sc, tscore, cost_ctrl=None, l
         L.check(lib.sdeh_ctrl_backward_fused_z(
             plan.handle, C.byref(pr), keep.ptr(ts.reshape(-1), dev, "ts"), T, xs.data_ptr(), B,
             None if noise is None else keep.ptr(noise, dev, "noise"), st["seed"], st["offset"], st["row_offset"],
-            w.data_ptr(), ptr(sc), ptr(tscore), ptr(cost_ctrl), ptr(lam_extra), ptr(zrec), ptr(nn), scratch.data_ptr(), scratch.numel(),
+            w.data_ptr(), ptr(sc), ptr(tscore), ptr(cost_ctrl), ptr(lam_extra), ptr(zrec), scratch.data_ptr(), scratch.numel(),
             out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
     return _fused_record_grads(ctrl, ts, out, d, T, Lh, g, score_model)
 
@@ -357,7 +357,7 @@ class _TrajectoryFn(torch.autograd.Function):
         pr = loss.engine.build_problem(device=xs.device, keep=keep, **st["problem_kwargs"])
         kept = st.get("planes")
         if kept is not None and kept[0] == "fused":
-            grads = _fused_backward(loss, pr, keep, ts, xs, w, st, kept[1], kept[2], zrec=kept[4], nn=kept[5])
+            grads = _fused_backward(loss, pr, keep, ts, xs, w, st, kept[1], kept[2], zrec=kept[4])
         elif kept is not None and kept[0] == "wide":  # wide network on a mixture target: the forward launch's score planes
             planes = _ctrl_backward(loss.engine, pr, keep, ts, xs, w, st, sc_in=kept[1], tscore_in=kept[2])
             grads = _weight_grads(loss.generative_ctrl, ts, xs, *planes)
@@ -618,7 +618,7 @@ class _BridgeSplitFn(torch.autograd.Function):
         if out is None:
             raise RuntimeError("sdeh_simulate_fwd_train2u kept no planes although sdeh_ctrl_backward_fused_supported said it would")
         x_T, rnd, xs_cm, gp_cm, state = out
-        ctx.loss, ctx.state, ctx.kept, ctx.zkept = loss, state, state["planes"][1:3], state["planes"][4:6]
+        ctx.loss, ctx.state, ctx.kept, ctx.zkept = loss, state, state["planes"][1:3], state["planes"][4]
         ctx.save_for_backward(ts, xs_cm, gp_cm)
         ctx.mark_non_differentiable(x_T)
         return x_T, rnd
@@ -644,7 +644,7 @@ class _BridgeSplitFn(torch.autograd.Function):
         if inf_grads is None:
             raise RuntimeError("split Bridge backward: sdeh_bridge_backward_fused refused a problem its forward half accepted")
         grads = _fused_backward(loss, pr_u, keep, ts, xs_cm, w, st, sc, tscore, cost_ctrl=None if lv else gp_cm, lam_extra=dx,
-                                zrec=ctx.zkept[0], nn=ctx.zkept[1])
+                                zrec=ctx.zkept)
         grads.update(inf_grads)
         return (None, None, None, None) + tuple(grads.get(id(p)) for p in st["params"])
 

@@ -71,12 +71,15 @@ def test_record_holds_the_networks_preactivations(name, mode):
     val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
     kept = got["out"][3]
     assert kept is not None and kept[0] == "fused" and kept[4] is not None, "the launch kept no record"
-    xs, zrec, nn = got["out"][2], kept[4], kept[5]
+    xs, zrec = got["out"][2], kept[4]
     net = prob.ctrl.base_model
-    Lh = len(net.hidden_layer)
-    tiles = (B + 31) // 32
-    z = zrec.view(T, tiles, Lh + 1, 16, 32, 4)  # [step][tile][layer][quad][trajectory][4 channels]
+    Lh, d = len(net.hidden_layer), spec["target"]["dim"]
+    tiles, otd = (B + 31) // 32, (d + 31) // 32
+    rec = zrec.view(T, tiles, (Lh + 1) * 2048 + otd * 1024)
+    z = rec[..., :(Lh + 1) * 2048].reshape(T, tiles, Lh + 1, 16, 32, 4)  # [step][tile][layer][quad][trajectory][4 channels]
     z = z.permute(0, 2, 3, 5, 1, 4).reshape(T, Lh + 1, 64, tiles * 32)[..., :B]  # [step][layer][channel][row]
+    nn = rec[..., (Lh + 1) * 2048:].reshape(T, tiles, otd * 8, 32, 4)  # [step][tile][coordinate quad][trajectory][4 coordinates]
+    nn = nn.permute(0, 2, 4, 1, 3).reshape(T, otd * 32, tiles * 32)[:, :d, :B]  # [step][coordinate][row]
     worst_z = worst_n = 0.0
     with torch.no_grad():
         for t in range(T):
@@ -120,6 +123,12 @@ CASES = [  # (spec, method, batch, steps, what the record launch is called, plan
     ("cfg4_funnel_dds_lv", "kl", 16 * 1024 + 64, 5, "bwd_fused<bptt,tiles=1,traj-split,zrec>", {}),
     ("cfg3_gmm50_pis_kl", "lv", 2048, 7, "bwd_fused<rows,tiles=2,traj-split,zrec>", {}),
     ("cfg3_gmm50_pis_kl", "lv_traj", 515, 7, "bwd_fused<rows,tiles=2,traj-split,zrec>", {}),
+    # the channel-split kernel (sdeh_bwdf.hip): two coordinate tiles through time, forced tilings, three hidden layers
+    ("cfg3_gmm50_pis_kl", "kl", 16 * 1024 + 40, 5, "bwd_fused<bptt,tiles=2,chan-split,zrec>", {}),
+    ("cfg3_gmm50_pis_kl", "kl_ito", 515, 7, "bwd_fused<bptt,tiles=2,chan-split,zrec>", {"SDEH_BWD_TILE": "32"}),
+    ("cfg4_funnel_dds_lv", "kl", 1000, 6, "bwd_fused<bptt,tiles=1,chan-split,zrec>", {"SDEH_BWD_TILE": "32"}),
+    ("cfg2_gmm2_dis_kl", "lv", 900, 6, "bwd_fused<rows,tiles=1,chan-split,zrec>", {"SDEH_BWD_V1": "1"}),
+    ("cfg1_dw_dis_lv", "kl", 700, 6, "bwd_fused<bptt,tiles=1,chan-split,zrec>", {"SDEH_BWD_V1": "1", "SDEH_BWD_TILE": "32"}),
 ]
 
 
@@ -141,6 +150,33 @@ def test_gradients_with_the_record_equal_the_reevaluating_launch(name, method, b
     # (groups of 64 / 32 re-evaluate bit for bit: row-parallel launches agree exactly, through time to the last bits of another
     # instruction order in the elementwise phase; the quad mode's pre-activations differ in rounding from their re-evaluation)
     assert worst <= 5e-6, f"{worst:.2e}"
+
+
+@pytest.mark.parametrize("layers,method", [(3, "lv"), (3, "kl"), (5, "lv"), (5, "kl")])
+def test_other_depths_through_the_record(layers, method):
+    """One hidden layer (trajectory-split teams) and three (channel-split teams: the only kernel compiled for them)."""
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec("cfg4_funnel_dds_lv")
+    B = 16 * 1024 + 70 if method == "kl" else 600
+    spec["batch"], spec["grid"]["steps"] = B, 5
+    spec["net"]["num_layers"] = layers
+    spec["loss"]["method"], spec["loss"]["max_rnd"] = method, (1e8 if method == "lv" else None)
+    torch.manual_seed(7)
+    prob = problems.build(spec, device=DEV)
+    with torch.no_grad():
+        for p in prob.ctrl.base_model.out_layer.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    x0 = prob.prior.sample((B,))
+    v1, g1, n1 = _grads(prob, x0, True)
+    v0, g0, n0 = _grads(prob, x0, False)
+    assert n1.endswith(",zrec>") and "zrec" not in n0, (n1, n0)
+    assert ("chan-split" in n1) == (layers == 5), n1
+    assert v1 == v0
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k in g0:
+        err = float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-3 * gmax, 1e-12)
+        assert err <= 5e-6, f"{k}: {err:.2e}"
 
 
 def test_relu_network_through_the_record():

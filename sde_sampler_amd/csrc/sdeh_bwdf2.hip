@@ -134,6 +134,11 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
 
   f32x16 dw_in, dw_out, dw_hid[LH];
+  f32x4b dwi4[2], dwo4[2];  // VIO: the [64, d] / [d, 64] gradients as 4 x 4 blocks over this wave's own trajectories (two chains each)
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dwi4[u][e] = 0.0f; dwo4[u][e] = 0.0f; }
 #pragma unroll
   for (int q = 0; q < 16; ++q) { dw_in[q] = 0.0f; dw_out[q] = 0.0f; }
 #pragma unroll
@@ -737,7 +742,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       load_s(LH);
 #pragma unroll
       for (int ct = 0; ct < OTD; ++ct) plane_put_n<NQ>(Dme, ct, j, h, dout[ct]);
-      ws_barrier();
+      if constexpr (!VIO) ws_barrier();  // (VIO: the out layer's gradient is a product over this wave's own planes)
       f32x16 dl[2];
       if constexpr (OTD == 2) {
         float ds[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -747,8 +752,9 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         float ds[2] = {0.0f, 0.0f};
         const float* __restrict__ pp = planes + wR * 4 * PLANE;  // the pair's planes
         if constexpr (VIO) {
-          f32x16 none[1];
-          stage_cols<0, RSW, 1, 1, 8>(Wout_s, dout, 0, none, pp, 0, wC, j, h, dw_out, ds);
+          // d out_layer.weight[i][c] += sum_k dout[i][k] a_{LH+1}[c][k]: rows = coordinates (D plane rows 0 .. 3), columns = channels
+          block_product<false>(Dme, Ame, lane, dwo4, ds[0]);
+          ds[0] = (lane & ~3) == 0 ? ds[0] : 0.0f;  // (every block forms the same row sums: lanes 0 .. 3 keep them -- d loss / d out bias)
 #pragma unroll
           for (int q = 0; q < 16; ++q) { dl[0][q] = 0.0f; dl[1][q] = 0.0f; }
 #pragma unroll
@@ -830,7 +836,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         plane_put(Dme, 1, j, h, dl[1]);
         SDEH_FENCE();
         BW2_T(tq1);
-        ws_barrier();
+        if (!(VIO && l < 0)) ws_barrier();  // (VIO: the input layer's gradient is a product over this wave's own planes)
         BW2_T(tq2);
         BW2_ADD(13, tq0, tq1); BW2_ADD(14, tq1, tq2);
         if (l >= 0) {
@@ -870,7 +876,14 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             }
           } else {
             float ds[2] = {0.0f, 0.0f};
-            stage_cols<((WDX && !VIO) ? NGI == 0 ? 0 : 8 : 0), RSI, 1, 2, 8>(Win_s + 4 * h * RSI + j, dl, 8, dx, planes + wR * 4 * PLANE, wC, 0, j, h, dw_in, ds);
+            if constexpr (VIO) {
+              // d input_embed.weight[c][i] += sum_k delta_0[c][k] x[i][k]: rows = channels (D plane), columns = coordinates (A plane rows
+              // 0 .. 3); the row sums are d loss / d (time embedding + input bias)[t][channel] of this wave's tile -- one 256-byte store
+              float esum = 0.0f;
+              block_product<true>(Dme, Ame, lane, dwi4, esum);
+              if (live_tile) A.epart[(tile * T + t) * 64 + lane] = esum;
+            } else {
+            stage_cols<(WDX ? NGI == 0 ? 0 : 8 : 0), RSI, 1, 2, 8>(Win_s + 4 * h * RSI + j, dl, 8, dx, planes + wR * 4 * PLANE, wC, 0, j, h, dw_in, ds);
             if (live_item) {
 #pragma unroll
               for (int w = 0; w < 2; ++w) {
@@ -878,6 +891,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
                 const long long tl = 4 * (long long)cur_pair + 2 * wR + w;
                 if (h == 0 && tl < n_tiles) A.epart[(tl * T + t) * 64 + 32 * wC + j] = e;
               }
+            }
             }
           }
           if constexpr (WDX) {
@@ -936,6 +950,30 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     float b = bs_out;
     b += __shfl_xor(b, 32);
     if (h == 0 && wC == 0) rec[off_bout<OTD, LH>() + 32 * wR + j] = b;
+  } else if constexpr (VIO) {
+    // the four waves' block sums meet in the (now idle) planes: sIn[wave][channel][4 coordinates], sOut[wave][4 coordinates][channel],
+    // the out bias sums behind them; the team writes whole [64][32] / [32][64] record tiles (coordinates >= 4: zeros)
+    ws_barrier();
+    float* __restrict__ sIn = planes;               // [4][64][4]
+    float* __restrict__ sOut = planes + 4 * 256;    // [4][4][64]
+    float* __restrict__ sB = planes + 8 * 256;      // [4][4]
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      // dwi4: register e of lane (b, jj) = gradient of input_embed.weight[4 b + e][jj];  dwo4: register e = out_layer.weight[e][4 b + jj]
+      sIn[wave * 256 + (4 * (lane >> 2) + e) * 4 + (lane & 3)] = dwi4[0][e] + dwi4[1][e];
+      sOut[wave * 256 + e * 64 + lane] = dwo4[0][e] + dwo4[1][e];
+    }
+    if (lane < 4) sB[wave * 4 + lane] = bs_out;
+    ws_barrier();
+    for (int idx = tid; idx < 64 * DPP; idx += 256) {
+      const int c = idx / DPP, i = idx - c * DPP;
+      rec[idx] = i < 4 ? ((sIn[c * 4 + i] + sIn[256 + c * 4 + i]) + (sIn[512 + c * 4 + i] + sIn[768 + c * 4 + i])) : 0.0f;
+    }
+    for (int idx = tid; idx < DPP * 64; idx += 256) {
+      const int i = idx >> 6, c = idx & 63;
+      rec[off_wout<OTD, LH>() + idx] = i < 4 ? ((sOut[i * 64 + c] + sOut[256 + i * 64 + c]) + (sOut[512 + i * 64 + c] + sOut[768 + i * 64 + c])) : 0.0f;
+    }
+    if (tid < DPP) rec[off_bout<OTD, LH>() + tid] = tid < 4 ? ((sB[tid] + sB[4 + tid]) + (sB[8 + tid] + sB[12 + tid])) : 0.0f;
   } else {
     // input_embed row tile wC / out_layer channel tile wC: the second wave pair hands its sums to the first through the (now idle) planes
     ws_barrier();

@@ -230,6 +230,36 @@ __device__ __forceinline__ float reduce_scatter32(const f32x16 (&v)[2], int lane
   return e[0];
 }
 
+// d <= 4 (VIO): the gradients of input_embed.weight [64, d] and out_layer.weight [d, 64] as 4 x 4 BLOCK products (v_mfma_f32_4x4x1_16b_f32:
+// 16 independent blocks per instruction, 8 cycles -- the same 32 multiply-adds per cycle as the 32 x 32 tiles, but on tiles without
+// padding: a [64, 4] gradient is 16 blocks x 4 x 4, one instruction per trajectory, 32 instructions = 256 cycles per step and wave
+// instead of 32 instructions of 64 cycles on a tile that is 7/8 zeros).  A wave contracts over ITS OWN 32 trajectories from its own two
+// planes -- no barrier, no partner -- and the team's four partial sums meet once, at the end of the launch.
+//   lane l = 4 b + i:  A operand = row value A_b[i], B operand = column value B_b[i];  result register r of lane (b, j) = D_b[r][j]
+//   rows from plane R (row index: `own` ? l : l & 3), columns from plane Cp (row index: `own` ? l & 3 : l); sum4 of the A rows -> rsum
+typedef float f32x4b __attribute__((ext_vector_type(4)));
+template <bool A_OWN>
+__device__ __forceinline__ void block_product(const float* __restrict__ Rp, const float* __restrict__ Cp, int lane, f32x4b (&acc)[2], float& rsum) {
+  const float* __restrict__ ra = Rp + (A_OWN ? lane : (lane & 3)) * RS;
+  const float* __restrict__ rb = Cp + (A_OWN ? (lane & 3) : lane) * RS;
+  float4 a[2], b[2];
+  a[0] = *reinterpret_cast<const float4*>(ra);
+  b[0] = *reinterpret_cast<const float4*>(rb);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c + 1 < 8) {
+      a[(c + 1) & 1] = *reinterpret_cast<const float4*>(ra + 4 * (c + 1));
+      b[(c + 1) & 1] = *reinterpret_cast<const float4*>(rb + 4 * (c + 1));
+    }
+    const float4 av = a[c & 1], bv = b[c & 1];
+    rsum += (av.x + av.y) + (av.z + av.w);
+    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.x, bv.x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.y, bv.y, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.z, bv.z, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av.w, bv.w, acc[1], 0, 0, 0);
+  }
+}
+
 // the transposed layer alone (no weight-gradient product next to it):  o[R] = sum_s sum_e W[(8 s + 4 h + e) * LD + 32 R + i] * b[s >> 2][4 (s & 3) + e]
 template <int LD>
 __device__ __forceinline__ void chain_cols(const float* __restrict__ wcol, const f32x16 (&b)[2], f32x16 (&o)[2]) {

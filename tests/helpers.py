@@ -34,7 +34,8 @@ def hatch(name: str, tag: str = "") -> None:
     except OSError:
         pass
 _ALL = sorted(glob.glob(str(GOLDEN_DIR / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide"))]  # loss-loop fixtures (make_golden.py)
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide", "fullsize_"))]  # loss-loop fixtures (make_golden.py)
+GOLDEN_FULLSIZE = [p for p in _ALL if Path(p).name.startswith("fullsize_")]  # the reference at B = 65 536, scalars only (make_golden_fullsize.py)
 GOLDEN_WIDE = [p for p in _ALL if Path(p).name.startswith("wide_")]              # wide-network fixtures (make_golden_wide.py)
 GOLDEN_WIDE_BRIDGE = [p for p in _ALL if Path(p).name.startswith("widebridge_")]  # wide-network Bridge fixtures
 GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]      # Euler-integrator fixtures (make_golden_integrator.py)

@@ -186,3 +186,63 @@ def test_fullsize_bridge_yaml_shape_trains_with_64_channels():
     val.backward()
     torch.cuda.synchronize()
     assert time.perf_counter() - t0 < 1.0  # measured: 0.11 s
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# a REFERENCE-held number at the headline's own size.  tests/golden/make_golden_fullsize.py ran the
+# reference once at B = 65 536 and kept the estimators, 64 rows and checksums of the inputs, which are a function of a seed.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _fullsize_fixtures():
+    from tests.helpers import GOLDEN_FULLSIZE
+
+    return GOLDEN_FULLSIZE
+
+
+@pytest.mark.parametrize("path", _fullsize_fixtures(), ids=lambda p: os.path.basename(p)[:-4])
+def test_fullsize_estimators_match_the_reference_run(path):
+    import json
+
+    import numpy as np
+
+    from tests.helpers import GOLDEN, hip_problem, load_fixture, measured
+    from tests.test_hip_contract import est_tol
+
+    fx = np.load(path)
+    meta = json.loads(bytes(fx["meta"]).decode())
+    case, B, T, seed = meta["case"], meta["B"], meta["T"], meta["seed"]
+    # the network of the small fixture of the same case (make_golden.py seeds it with torch.manual_seed(1)); its checksum is in the fixture
+    small = [p for p in GOLDEN if os.path.basename(p) == meta["base"] + ".npz"][0]
+    _, _, params, tt = load_fixture(small)
+    psum = float(sum(v.double().abs().sum() for v in params.values()))
+    assert abs(psum - meta["param_abs_sum"]) <= 1e-9 * meta["param_abs_sum"], "the small fixture's network is not the one the reference ran"
+    # the inputs: a function of the seed (tests/golden/make_golden_fullsize.py::inputs, restated)
+    d, pr = case["target"]["dim"], case["prior"]
+    torch.manual_seed(seed)
+    x0 = torch.zeros(B, d) if pr["kind"] == "delta" else pr["loc"] + pr["scale"] * torch.randn(B, d)
+    noise = torch.stack([torch.randn_like(x0) for _ in range(T)])
+    for key, val in (("x0_sum", float(x0.double().sum())), ("noise_sum", float(noise.double().sum())),
+                     ("noise_abs_sum", float(noise.double().abs().sum())), ("noise_first", float(noise[0, 0, 0])),
+                     ("noise_last", float(noise[-1, -1, -1]))):
+        # (float64 sums: their last digits depend on the host's reduction tree, i.e. its thread count; single elements are exact)
+        ok = val == meta[key] if key in ("noise_first", "noise_last") else abs(val - meta[key]) <= 1e-10 * max(1.0, abs(meta[key]))
+        assert ok, f"{key}: regenerated {val!r}, the reference run saw {meta[key]!r} (another torch build?)"
+    prob = hip_problem(case, params, tt)
+    assert prob.ts.numel() - 1 == T
+    x0d, nd = x0.to(DEV), noise.to(DEV)
+    del noise
+    r1 = prob.eval(x0d, compute_weights=True, return_traj=False, noise=nd)
+    r2 = prob.eval(x0d, compute_weights=False, return_traj=False, noise=nd)
+    tag = os.path.basename(path)[:-4]
+    for key, got, ref in (("log_norm_const_lb_ito", r1.log_norm_const_preds["log_norm_const_lb_ito"], float(fx["log_norm_const_lb_ito"])),
+                          ("log_norm_const_is", r1.log_norm_const_preds["log_norm_const_is"], float(fx["log_norm_const_is"])),
+                          ("log_norm_const_lb", r2.log_norm_const_preds["log_norm_const_lb"], float(fx["log_norm_const_lb"]))):
+        measured(f"fullsize_reference/{tag}/{key}", abs(got - ref), est_tol(ref))
+        assert abs(got - ref) <= est_tol(ref), f"{key}: {got} vs the reference's {ref}"  # 1e-4
+    lv_ref = float(fx["lv_loss"])
+    measured(f"fullsize_reference/{tag}/lv_loss_rel", abs(r1.metrics["eval/lv_loss"] - lv_ref) / max(1.0, abs(lv_ref)), 1e-4)
+    assert abs(r1.metrics["eval/lv_loss"] - lv_ref) <= 1e-4 * max(1.0, abs(lv_ref))
+    rows = torch.from_numpy(fx["rows"]).to(DEV)
+    xT = r1.samples[rows].cpu().numpy()
+    err = np.abs(xT - fx["x_T"]) / np.maximum(1.0, np.abs(fx["x_T"]))
+    measured(f"fullsize_reference/{tag}/x_T_rows_max", float(err.max()), 1e-2)
+    assert err.max() <= 1e-2 and np.median(err) <= 1e-4, (err.max(), np.median(err))

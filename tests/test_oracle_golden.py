@@ -11,7 +11,7 @@ import torch
 from oracle import em_oracle as eo
 
 _ALL = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide"))]
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide", "fullsize_"))]
 GOLDEN_WIDE = [p for p in _ALL if Path(p).name.startswith(("wide_", "widebridge_"))]
 GOLDEN_BRIDGE = [p for p in _ALL if Path(p).name.startswith("bridge_")]
 GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]

@@ -1198,7 +1198,8 @@ static BwdfChoice bwdf_choice(const SdehProblem* pr, long long batch, bool klb) 
   c.v2 = c.tile == 32 && !force_v1 && enough && bwdf2_fits(d, net.n_hidden) &&
          (d <= 32 || (!bptt) || (force_v2 && pr->target.kind != SDEH_DENS_FUNNEL));
   const char* zo = plan_opt(OPT_BWD_ZREC);
-  c.zin = (zo == nullptr || zo[0] != '0') && !klb && !c.scan && c.tile == 32;  // (both tilings of 32 read the record)
+  // (both tilings of 32 and the four-wave teams of 16 read the record)
+  c.zin = (zo == nullptr || zo[0] != '0') && !klb && (c.scan || c.tile == 32 || bwdf16_waves(batch) == 4);
   return c;
 }
 

@@ -207,7 +207,11 @@ __device__ __forceinline__ Vt<MT> mul_t(const Vt<MT>& a, const Vt<MT>& b) {
 }  // namespace bwdf16
 
 // KLB (a Bridge's generative network with method kl): the running cost on the plane cost_in = u + v, lam_in added to the adjoint
-template <int OTD, int LH, int NW, bool KLB = false>
+// ZIN (round 5): no re-evaluation -- pre-activations and raw network output come from the record of the training forward
+// (sdeh_traj_ws.hpp: ZRec; a 16-trajectory tile is one half of a record tile: ONE 16-byte load per lane, layer and row tile, all of a
+// step's requested a step ahead).  The forward pass with its layer exchanges is gone: four of a step's nine barriers, the chain of
+// dependent matrix instructions behind each of them, and the kink rule (the record IS the forward launch's pre-activation).
+template <int OTD, int LH, int NW, bool KLB = false, bool ZIN = false>
 __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
   using namespace bwdf16;
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
@@ -321,7 +325,33 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
   // a team without a tile shadows the last one (and contributes zeros)
   auto clamp_tile = [&](int tile_i) { return tile_i < n_tiles ? tile_i : n_tiles - 1; };
 
-  V xnext = load_x(T - 1, clamp_tile(team_g)), embnext = load_emb(T - 1);
+  // ZIN: this lane's share of the record of (step, 16-trajectory tile): layers 0 .. LH, then the raw network output of its coordinates
+  typedef float f32x4z __attribute__((ext_vector_type(4)));
+  struct ZStep { V z[LH + 1]; V nn; };
+  const long long zr_tiles = (B + 31) >> 5;
+  auto load_zstep = [&](int t, int tile_i, ZStep& zs) {
+    if constexpr (ZIN) {
+      const float* __restrict__ base = A.zrec + ((long long)t * zr_tiles + (tile_i >> 1)) * ((LH + 1) * 2048 + OTD * 1024);
+      unsigned lo = (unsigned)(16 * (tile_i & 1) + n) * 16u;
+      asm volatile("" : "+v"(lo));
+      const char* __restrict__ pb = reinterpret_cast<const char*>(base) + lo;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int cq = 8 * r + 4 * mb + 4 * m + g;  // channel quad of rows 32 r + 16 mb + 16 m + 4 g ..
+#pragma unroll
+        for (int k = 0; k <= LH; ++k) zs.z[k].m[m] = __builtin_nontemporal_load(reinterpret_cast<const f32x4z*>(pb + (k * 2048 + cq * 128) * 4));
+        const int nq = 4 * mb + 4 * m + g;  // coordinate quad (of this wave's coordinate tile ct) of coordinates cb + 16 m ..
+        const bool okq = cb + 16 * m < d;   // (quads beyond d may never have been written: a valid address, zeros by the select)
+        const f32x4z v = __builtin_nontemporal_load(reinterpret_cast<const f32x4z*>(pb + ((LH + 1) * 2048 + ct * 1024 + (okq ? nq : 0) * 128) * 4));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zs.nn.m[m][q] = cb + 16 * m + q < d ? v[q] : 0.0f;
+      }
+    }
+  };
+  V xnext = load_x(T - 1, clamp_tile(team_g)), embnext;
+  ZStep znext;
+  if constexpr (!ZIN) embnext = load_emb(T - 1);
+  load_zstep(T - 1, clamp_tile(team_g), znext);
   for (int round = 0; round < n_rounds; ++round) {
     const int it_tile = team_g + round * n_teams;
     const bool live_item = it_tile < n_tiles;
@@ -362,13 +392,17 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
 
     for (int t = T - 1; t >= 0; --t) {
       const V x = xnext;
-      const V embv = embnext;  // timestep_embed(t) + input bias of this wave's channels
+      V embv;  // timestep_embed(t) + input bias of this wave's channels
+      if constexpr (!ZIN) embv = embnext;
+      const ZStep zs = znext;
       if (t > 0) {
         xnext = load_x(t - 1, cur_tile);
-        embnext = load_emb(t - 1);
+        if constexpr (!ZIN) embnext = load_emb(t - 1);
+        load_zstep(t - 1, cur_tile, znext);
       } else if (round + 1 < n_rounds) {
         xnext = load_x(T - 1, clamp_tile(it_tile + n_teams));
-        embnext = load_emb(T - 1);
+        if constexpr (!ZIN) embnext = load_emb(T - 1);
+        load_zstep(T - 1, clamp_tile(it_tile + n_teams), znext);
       }
       // the step's other inputs: requested first, consumed after the forward pass
       V scv = zero_t<MT>(), xi = zero_t<MT>();
@@ -404,10 +438,24 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
       // pass, the earlier ones (and x) are re-published from registers when their weight gradient is due
       float* __restrict__ Ap[2] = {pl + par * PLANE, pl + (1 - par) * PLANE};
       float* __restrict__ Dp[2] = {pl + 2 * PLANE, pl + 3 * PLANE};
-      plane_put<MT>(Ap[0], 32 * ct + mo, n, g, x);
-      ws_barrier();
       V gr[LH + 1], aown[LH > 1 ? LH - 1 : 1];
       const int bofs = 4 * g * RS + n;  // this lane's column of a plane as an MFMA B operand
+      V nn;
+      if constexpr (ZIN) {
+        // act / act' of every layer from the record (12 values per lane); the planes are laid out as the forward pass leaves them: a_{LH+1}
+        // in A[(LH + 1) & 1], a_LH in A[LH & 1], earlier activations kept in registers until their weight gradient is due
+        ws_barrier();  // every read of the previous step's planes is done
+#pragma unroll
+        for (int k = 0; k <= LH; ++k) {
+          V ak;
+          SDEH_ACT_SWITCH(act, ACT, act_both<ACT, MT>(zs.z[k], ak, gr[k]););
+          if (k >= LH - 1) plane_put<MT>(Ap[(k + 1) & 1], 32 * r + mo, n, g, ak);
+          else aown[k < LH - 1 ? k : 0] = ak;
+        }
+        nn = zs.nn;
+      } else {
+      plane_put<MT>(Ap[0], 32 * ct + mo, n, g, x);
+      ws_barrier();
       {
         const V z0 = mm_rows<2 * OTD, MT>(Win + (32 * r + mo + n) * RSI + 4 * g, RSI, Ap[0] + bofs, n_ku, embv);
         V a1;
@@ -426,7 +474,8 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
         plane_put<MT>(Ap[l & 1], 32 * r + mo, n, g, an);
         ws_barrier();
       }
-      const V nn = mm_rows<4, MT>(Wout + (32 * ct + mo + n) * RSW + 4 * g, RSW, Ap[(LH + 1) & 1] + bofs, 4, rows_t<MT>(bo + cb));
+      nn = mm_rows<4, MT>(Wout + (32 * ct + mo + n) * RSW + 4 * g, RSW, Ap[(LH + 1) & 1] + bofs, 4, rows_t<MT>(bo + cb));
+      }
 
       // ======================================================================================= upstream gradient of the control
       V G, Gc, cvec, dout;
@@ -645,10 +694,13 @@ __global__ __launch_bounds__(64 * NW) void bwdf16_kernel(const BwdfArgs A) {
   }
 }
 
-template <int OTD, int LH, int NW, bool KLB = false>
+template <int OTD, int LH, int NW, bool KLB = false, bool ZIN = false>
 static int launch_bwdf16_t(const BwdfArgs& a, hipStream_t stream) {
   if constexpr (LH == 2 && NW == 4 && !KLB) {
     if (a.cost_in != nullptr && a.lam_in != nullptr) return launch_bwdf16_t<OTD, LH, NW, true>(a, stream);
+  }
+  if constexpr (NW == 4 && !KLB && !ZIN) {  // (teams of four read the record; the two-wave comparison form re-evaluates)
+    if (a.zrec != nullptr) return launch_bwdf16_t<OTD, LH, NW, false, true>(a, stream);
   }
   if (!KLB && (a.cost_in != nullptr || a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;  // (two hidden layers, four-wave teams, both planes)
   const size_t lds_bytes = (size_t)bwdf16::lds_floats<OTD, LH>() * sizeof(float);
@@ -656,12 +708,12 @@ static int launch_bwdf16_t(const BwdfArgs& a, hipStream_t stream) {
   static bool attr_done[kMaxDevices] = {};
   bool& attr_set = attr_done[current_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf16_kernel<OTD, LH, NW, KLB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf16_kernel<OTD, LH, NW, KLB, ZIN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return SDEH_ERR_HIP;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bwdf16_kernel<OTD, LH, NW, KLB>), dim3((unsigned)a.n_slots), dim3(64 * NW), lds_bytes, stream, a);
+  hipLaunchKernelGGL((bwdf16_kernel<OTD, LH, NW, KLB, ZIN>), dim3((unsigned)a.n_slots), dim3(64 * NW), lds_bytes, stream, a);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

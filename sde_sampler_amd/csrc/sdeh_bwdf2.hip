@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   static_assert(!JAC || (VIO && !BPTT), "the Jacobian pass is row-parallel, d <= 4");
   static_assert(!VIO || (OTD == 1 && NQ == 4), "vector-pipe in / out layers: d <= 4");
   static_assert(!BR || (!BPTT && !JAC && !ZIN), "the Bridge form is row-parallel (and re-evaluates the inference network)");
-  static_assert(!(ZIN && JAC), "the Jacobian pass re-evaluates");
+  static_assert(!(ZIN && JAC) || LH == 2, "the Jacobian pass that reads the record: two hidden layers (three buffers)");
   static_assert(!KLB || BPTT, "cost_in / lam_in belong to back-propagation through time");
   constexpr bool WDX = BPTT || BR == 2;  // the chain goes on through the input layer: W_in^T delta_0
   constexpr int RSI = rsi<OTD>(), DPP = 32 * OTD;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   // ZIN: two record buffers in flight -- layer k of a step lives in zA when LH - k is even, else in zB, and is requested where the
   // buffer's previous content was activated: Z_LH of the NEXT step in front of this step's last hidden stage, Z_{LH-1} of the next step in
   // front of the in stage, Z_{LH-2} of this step at its top -- every request a whole stage (8-10 k cycles of matrix work) ahead of its use
-  f32x16 xnext[OTD], embnext[2], zA[2], zB[2];
+  f32x16 xnext[OTD], embnext[2], zA[2], zB[2], zC[2];  // (zC: the Jacobian pass holds all three layers of the next item)
   StepCoef cnext;
   {
     int t0 = it_t, p0 = it_pair;
@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     cnext = load_coef(t0);
     load_z(t0, tile_of(p0), LH, zA);
     load_z(t0, tile_of(p0), LH - 1, zB);
+    if constexpr (ZIN && JAC) load_z(t0, tile_of(p0), 0, zC);
   }
   for (long long round = 0; round < n_rounds; ++round) {
     const bool live_item = item_live(it_t, it_pair);
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       // ======================================================================================= forward (re-evaluation at x_t)
       // keep[k] = act'(Z_k)  (k = 0 .. LH);   akeep[k] = a_{k+1} = act(Z_k)  (k < LH)
       // ZIN: no re-evaluation -- zA / zB hold the records in flight, kz = act' of the layer activated last
-      f32x16 keep[ZIN ? 1 : LH + 1][2];
+      f32x16 keep[(ZIN && !JAC) ? 1 : LH + 1][2];
       f32x16 akeep[ZIN ? 1 : LH][2];
       f32x16 cur[2], kz[2];
       f32x16 nn[OTD];
@@ -356,7 +357,19 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
       for (int ct = 0; ct < OTD; ++ct)
 #pragma unroll
         for (int q = 0; q < 16; ++q) scv[ct][q] = 0.0f;
-      if constexpr (ZIN) {
+      if constexpr (ZIN && JAC) {
+        // the Jacobian pass on the record: act' of the three layers (requested an item ago) and the raw network output, no matrix work
+        load_nn(t, tile, 0, nn[0]);
+        f32x16 unused[2];
+        SDEH_ACT_SWITCH(act, ACT, {
+          act_both<ACT>(zC[0], unused[0], keep[0][0]); act_both<ACT>(zC[1], unused[1], keep[0][1]);
+          SDEH_FENCE();
+          act_both<ACT>(zB[0], unused[0], keep[1][0]); act_both<ACT>(zB[1], unused[1], keep[1][1]);
+          SDEH_FENCE();
+          act_both<ACT>(zA[0], unused[0], keep[2][0]); act_both<ACT>(zA[1], unused[1], keep[2][1]);
+        });
+        SDEH_FENCE();
+      } else if constexpr (ZIN) {
         // raw network output and score planes first (their latency hides behind the activation of Z_LH, which arrived a step ago)
 #pragma unroll
         for (int ct = 0; ct < OTD; ++ct) load_nn(t, tile, ct, nn[ct]);
@@ -465,14 +478,15 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         // weight gradients, no planes, no barrier.  (The clamp's mask and the score terms are applied by the scan kernel.)
         if (t > t_last) {
           load_x(t - 1, (int)tile, xnext);
-          load_emb(t - 1, embnext);
+          if constexpr (!ZIN) load_emb(t - 1, embnext);
           cnext = load_coef(t - 1);
         } else if (round + 1 < n_rounds) {
           int tn = it_t, pn = it_pair;
           clamp_item(tn, pn);
           load_x(tn, tile_of(pn), xnext);
-          load_emb(tn, embnext);
+          if constexpr (!ZIN) load_emb(tn, embnext);
           cnext = load_coef(tn);
+          if constexpr (ZIN) { load_z(tn, tile_of(pn), 2, zA); load_z(tn, tile_of(pn), 1, zB); load_z(tn, tile_of(pn), 0, zC); }
         }
         const bool wr = live && h == 0;
         float* __restrict__ nno = A.nn_out + (long long)t * d * B + lrow;
@@ -1219,8 +1233,24 @@ static int launch_bwdf2_jac_t(const BwdfArgs& a, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
+template <int LH>
+static int launch_bwdf2_jacz_t(const BwdfArgs& a, hipStream_t stream) {
+  const size_t lds_bytes = (size_t)(bwdf::lds_floats<1, LH>() + 512) * sizeof(float);
+  static bool attr_done[kMaxDevices] = {};
+  bool& attr_set = attr_done[current_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&bwdf2_kernel<1, false, LH, true, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return SDEH_ERR_HIP;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bwdf2_kernel<1, false, LH, true, 4, true, true>), dim3((unsigned)a.n_slots), dim3(256), lds_bytes, stream, a);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
 int launch_bwdf2_jac(const BwdfArgs& a, hipStream_t stream) {
   if (!bwdf2_scan_fits(a.d, a.n_hidden) || a.nn_out == nullptr || a.jac_out == nullptr) return SDEH_ERR_UNSUPPORTED;
+  if (a.zrec != nullptr) return launch_bwdf2_jacz_t<2>(a, stream);  // (the record instead of the re-evaluation)
   return launch_bwdf2_jac_t<2>(a, stream);
 }
 

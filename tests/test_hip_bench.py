@@ -71,3 +71,22 @@ def test_training_workload_line():
     assert r["kernel"].startswith("bwd_fused16<bptt") and r["kernel_ms"] > 0 and r["forward_kernel_ms"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert out["config"]["method"] == "kl" and out["value"] > 0 and torch.isfinite(torch.tensor(out["final_loss"]))
+
+
+def test_one_rank_process_group_line_agrees_with_the_group_less_line():
+    """`bench.py --gpus 1 --dist` runs the code an 8-rank job runs (RCCL init with device_id, the 8-float
+    all-gather on the device tensor, barriers, the max-over-ranks all-reduce) on the one GPU.  Its N = 1 point must agree with the
+    BENCH line, so that the first SCALE run's curve starts where BENCH says; `scaling_detail` carries what a sub-linear curve would be
+    attributed to (per-rank kernel and step times, the collective's wall time)."""
+    flags = ("--steps", "200", "--warmup", "20", "--no-cpu-baseline", "--no-extra", "--no-graphed")
+    plain = _bench(*flags)
+    grouped = _bench("--dist", *flags)
+    assert grouped["config"]["process_group"] == {"backend": "nccl", "world_size": 1}
+    assert "process_group" not in plain["config"] and "scaling_detail" not in plain
+    rel = abs(grouped["value"] - plain["value"]) / plain["value"]
+    assert rel <= 0.03, (grouped["value"], plain["value"])
+    sd = grouped["scaling_detail"]
+    assert len(sd["kernel_ms_per_rank"]) == 1 and len(sd["ms_per_step_per_rank"]) == 1
+    assert 0.5 * grouped["roofline"]["kernel_ms"] <= sd["kernel_ms_per_rank"][0] <= 1.5 * grouped["roofline"]["kernel_ms"]
+    assert 0 < sd["estimator_all_gather_us"] < 5000
+    assert abs(grouped["roofline"]["frac"] - plain["roofline"]["frac"]) <= 0.03

@@ -180,10 +180,15 @@ def test_loss_contract():
     assert sd["rng_counter"] == COUNTER_START + 5 and sd["rng_replays"] == 5
     graphed.load_state_dict({"n_filtered": 0})  # a checkpoint without the keys (any earlier one) leaves the counter alone
     assert int(graphed.rng_counter) == COUNTER_START + 5
-    graphed.load_state_dict({"n_filtered": 0, "rng_calls": 12, "rng_counter": 0, "rng_replays": 0})  # eager -> graphed: COUNTER_START survives
-    assert int(graphed.rng_counter) == COUNTER_START and graphed.engine.calls == 12
-    graphed.load_state_dict(sd)  # graphed -> graphed
-    assert int(graphed.rng_counter) == COUNTER_START + 5
+    # eager -> graphed: the counter stays where the capture's warm-up steps put it (a rewind to COUNTER_START would reuse the
+    # Philox offsets those steps consumed)
+    graphed.load_state_dict({"n_filtered": 0, "rng_calls": 12, "rng_counter": 0, "rng_replays": 0})
+    assert int(graphed.rng_counter) == COUNTER_START + 5 and graphed.engine.calls == 12
+    graphed.load_state_dict(dict(sd, rng_replays=9, rng_counter=COUNTER_START + 9))  # graphed -> graphed: forward to the checkpoint's position
+    assert int(graphed.rng_counter) == COUNTER_START + 9
+    graphed.load_state_dict(sd)  # ... and never backwards
+    assert int(graphed.rng_counter) == COUNTER_START + 9
+    graphed.rng_counter.fill_(COUNTER_START + 5)
     eager = ExponentialIntegratorSDELoss(generative_ctrl=None, alpha=1.0, sigma=2.0, method="lv")
     eager.load_state_dict(dict(sd, rng_calls=3))  # graphed -> eager: only the replay count joins the calls, no carry into the stream id
     assert eager.engine.calls == 8 and eager.engine.offset() == 8

@@ -229,6 +229,10 @@ int32_t sdeh_plan_set_option(SdehPlan* plan, const char* name, const char* value
  * it is launched on; sdeh_plan_last_kernel_ms waits for the stop event and returns the elapsed time. */
 int32_t sdeh_plan_set_timing(SdehPlan* plan, int32_t enable);
 int32_t sdeh_plan_last_kernel_ms(SdehPlan* plan, float* ms);
+/* ABI v6.  The timed launches are kept in a ring of 128 event pairs: entry `back` launches ago (0 = the newest) with the name of the
+ * kernel that served it, so that a run can read its kernel durations AFTERWARDS instead of synchronising after every launch.  Returns 1
+ * when there is no such entry. */
+int32_t sdeh_plan_timing_entry(SdehPlan* plan, int32_t back, float* ms, char* name, int32_t name_len);
 /* Which compiled trajectory kernel served the plan's last sdeh_simulate_fwd* call (e.g. "traj_ws<50_0_pis_gmm4>",
  * "traj_legacy<64_1_g>", "traj_wide<C=256,CT=2>", "bridge_wide<C=256>"); "" before the first call.  The string is owned by the plan. */
 const char* sdeh_plan_last_kernel_name(SdehPlan* plan);
@@ -488,6 +492,16 @@ int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* problem
 #define SDEH_REDUCE_SCRATCH 8192
 int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, float* scratch, float* out,
                                void* stream);
+
+/* ABI v6.  The training loss over the batch AND its per-row gradient, without a host round trip (BaseOCLoss.compute_loss, losses/oc.py:72-92:
+ * `rnd[mask].mean()` for method kl / kl_ito, `rnd[mask].var()` for lv, mask = BaseOCLoss.filter, losses/oc.py:50-58): the reduction of
+ * sdeh_reduce_estimators followed by one elementwise pass,
+ *   out[0..6] as sdeh_reduce_estimators;   out[7] = loss = mean | M2 / (n - 1)
+ *   grad_rnd[i] = d loss / d rnd_i = 1 / n | 2 (rnd_i - mean) / (n - 1) on kept rows, 0 on dropped ones  -- what sdeh_ctrl_backward_fused takes
+ *   *n_filtered += rows dropped (int64 on the device, NULL to skip): the reference's running `n_filtered`
+ * Three launches; the same fp32 values as the framework's masked reductions and their autograd. */
+int32_t sdeh_loss_moment(const float* rnd, int64_t batch, float max_rnd, int32_t log_variance, int64_t* n_filtered, float* scratch,
+                         float* out, float* grad_rnd, void* stream);
 
 /* importance weights exp(-rnd - m) (losses/oc.py:101-103) with a caller-provided global maximum m (device scalar). */
 int32_t sdeh_importance_weights(const float* rnd, int64_t batch, const float* log_weight_max, float* weights,

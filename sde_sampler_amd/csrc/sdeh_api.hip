@@ -15,6 +15,8 @@ namespace sdeh {
 int launch_prep(const PrepArgs& p, hipStream_t stream);
 int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int nb, float* out, hipStream_t stream);
 int launch_weights(const float* rnd, long long n, const float* mx, float* w, hipStream_t stream);
+int launch_loss_moment(const float* rnd, long long n, float max_rnd, int lv, long long* n_filtered, float* part, int nb, float* out, float* w,
+                       hipStream_t stream);
 int launch_sink_init(float* u, float* v, float* log_a, float* log_b, const float* w_x, const float* w_y, long long n,
                      long long m, float eps, int* flags, hipStream_t st);
 int launch_sink_finalize(const float* pm, const float* ps, int splits, long long np, const float* log_w, float eps, float* pot,
@@ -240,8 +242,14 @@ struct SdehPlan {
   size_t scratch_floats;
   bool timing;
   bool timed;
-  hipEvent_t ev0, ev1;
+  hipEvent_t ev0, ev1;     // the event pair of the newest timed launch (an entry of the ring below)
   char last_kernel[96];
+  // a ring of event pairs: the durations of the last kTimingRing timed launches can be read AFTER a run (sdeh_plan_timing_entry)
+  // instead of with one host synchronisation per launch
+  static constexpr int kTimingRing = 128;
+  hipEvent_t ring0[kTimingRing], ring1[kTimingRing];
+  char ring_names[kTimingRing][96];
+  int ring_pos, ring_count;
   PlanOptions opts;  // kernel-mode options (sdeh_plan_set_option)
 };
 
@@ -317,6 +325,9 @@ int32_t sdeh_plan_create(const SdehPlanDesc* desc, SdehPlan** out) {
   p->timing = p->timed = false;
   p->ev0 = p->ev1 = nullptr;
   p->last_kernel[0] = 0;
+  for (int i = 0; i < SdehPlan::kTimingRing; ++i) { p->ring0[i] = p->ring1[i] = nullptr; p->ring_names[i][0] = 0; }
+  p->ring_pos = -1;
+  p->ring_count = 0;
   for (int k = 0; k < OPT_COUNT; ++k) opt_store(p->opts, k, getenv(kOptNames[k]));  // the environment is a test override, read ONCE here
   int prev = 0;
   hipError_t e = hipGetDevice(&prev);
@@ -372,12 +383,44 @@ int32_t sdeh_plan_set_option(SdehPlan* plan, const char* name, const char* value
 
 int32_t sdeh_plan_set_timing(SdehPlan* plan, int32_t enable) {
   if (plan == nullptr) return fail(SDEH_ERR_INVALID, "plan_set_timing: null plan");
-  if (enable && plan->ev0 == nullptr) {
-    if (hipEventCreate(&plan->ev0) != hipSuccess || hipEventCreate(&plan->ev1) != hipSuccess)
-      return fail(SDEH_ERR_HIP, "plan_set_timing: hipEventCreate failed");
+  if (enable && plan->ring0[0] == nullptr) {
+    for (int i = 0; i < SdehPlan::kTimingRing; ++i)
+      if (hipEventCreate(&plan->ring0[i]) != hipSuccess || hipEventCreate(&plan->ring1[i]) != hipSuccess)
+        return fail(SDEH_ERR_HIP, "plan_set_timing: hipEventCreate failed");
+    plan->ev0 = plan->ring0[0];
+    plan->ev1 = plan->ring1[0];
   }
   plan->timing = enable != 0;
   plan->timed = false;
+  plan->ring_pos = -1;
+  plan->ring_count = 0;
+  return SDEH_OK;
+}
+
+// the event pair of a timed launch: the next entry of the ring (the previous entry keeps the name of the launch it timed)
+static void timing_begin(SdehPlan* plan, hipStream_t st) {
+  if (!plan->timing) return;
+  if (plan->ring_pos >= 0) snprintf(plan->ring_names[plan->ring_pos], sizeof(plan->ring_names[0]), "%s", plan->last_kernel);
+  plan->ring_pos = (plan->ring_pos + 1) % SdehPlan::kTimingRing;
+  if (plan->ring_count < SdehPlan::kTimingRing) ++plan->ring_count;
+  plan->ev0 = plan->ring0[plan->ring_pos];
+  plan->ev1 = plan->ring1[plan->ring_pos];
+  (void)hipEventRecord(plan->ev0, st);
+}
+static void timing_end(SdehPlan* plan, hipStream_t st) {
+  if (!plan->timing) return;
+  (void)hipEventRecord(plan->ev1, st);
+  plan->timed = true;
+}
+
+int32_t sdeh_plan_timing_entry(SdehPlan* plan, int32_t back, float* ms, char* name, int32_t name_len) {
+  if (plan == nullptr || ms == nullptr || back < 0) return fail(SDEH_ERR_INVALID, "plan_timing_entry: bad argument");
+  if (!plan->timed || back >= plan->ring_count) return 1;  // no such entry (yet)
+  const int pos = ((plan->ring_pos - back) % SdehPlan::kTimingRing + SdehPlan::kTimingRing) % SdehPlan::kTimingRing;
+  hipError_t e = hipEventSynchronize(plan->ring1[pos]);
+  if (e == hipSuccess) e = hipEventElapsedTime(ms, plan->ring0[pos], plan->ring1[pos]);
+  if (e != hipSuccess) return fail(SDEH_ERR_HIP, "plan_timing_entry: %s", hipGetErrorString(e));
+  if (name != nullptr && name_len > 0) snprintf(name, (size_t)name_len, "%s", back == 0 ? plan->last_kernel : plan->ring_names[pos]);
   return SDEH_OK;
 }
 
@@ -393,8 +436,10 @@ const char* sdeh_plan_last_kernel_name(SdehPlan* plan) { return plan == nullptr 
 
 void sdeh_plan_destroy(SdehPlan* plan) {
   if (plan == nullptr) return;
-  if (plan->ev0) (void)hipEventDestroy(plan->ev0);
-  if (plan->ev1) (void)hipEventDestroy(plan->ev1);
+  for (int i = 0; i < SdehPlan::kTimingRing; ++i) {
+    if (plan->ring0[i]) (void)hipEventDestroy(plan->ring0[i]);
+    if (plan->ring1[i]) (void)hipEventDestroy(plan->ring1[i]);
+  }
   if (plan->ws) (void)hipFree(plan->ws);
   if (plan->scratch) (void)hipFree(plan->scratch);
   delete plan;
@@ -618,9 +663,9 @@ static int simulate_bridge(SdehPlan* plan, const SdehProblem* pr, const float* t
   A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
   A.inf_clip_model = inf.clip_model; A.inf_clip_score = inf.clip_score; A.inf_scale_score = inf.scale_score;
   A.gp = gp; A.div_noise = div_noise;
-  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  timing_begin(plan, st);
   rc = v->fn_bridge(A, st);
-  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  timing_end(plan, st);
   snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bridge<%s>", v->name);
   if (rc == SDEH_ERR_UNSUPPORTED)
     return fail(rc, "simulate_fwd (bridge): two packed networks (+ mixture scratch) exceed 160 KiB of LDS at dim=%d", d);
@@ -719,10 +764,10 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
                                      "(%zu): SdehPlanDesc.max_batch / sdeh_plan_reserve (no stream-ordered call allocates)",
                   plan->scratch_floats, need);
   }
-  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  timing_begin(plan, st);
   int detail = 0;
   rc = bridge ? launch_bridge_wide(A, st, &detail, plan->scratch) : launch_wide(A, st, &detail);
-  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  timing_end(plan, st);
   snprintf(plan->last_kernel, sizeof(plan->last_kernel), bridge ? "bridge_wide<C=%d,split=%d>" : "traj_wide<C=%d,CT=%d>", net.channels, detail);
   if (rc == SDEH_ERR_UNSUPPORTED)
     return fail(rc, "simulate_fwd (wide): the problem needs more than 160 KiB of LDS (d=%d, C=%d, K=%d mixture components)", d, net.channels, ck.k);
@@ -789,7 +834,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
   A.second = {pr->second.kind, pr->second.n_components, pr->second.log_norm_const, pr->second.p0, pr->second.p1};
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
-  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  timing_begin(plan, st);
   // The wave-specialised kernel needs GMM tables in LDS; mixtures too large for that use the single-wave kernel
   // with scalar-load tables (also selectable with SDEH_LEGACY=1 for A/B measurements).
   const bool legacy = force_legacy || (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0);
@@ -813,7 +858,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
       snprintf(plan->last_kernel, sizeof(plan->last_kernel), "traj_legacy<%s>", plan->variant->name);
     }
   }
-  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  timing_end(plan, st);
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd: trajectory kernel launch failed (dp=%d)", v->dp);
   return SDEH_OK;
 }
@@ -1012,9 +1057,9 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
     Aw.clip_target = pr->clip_target;
     Aw.target = {pr->target.kind, pr->target.n_components, pr->target.log_norm_const, pr->target.p0, pr->target.p1};
     Aw.seed = seed; Aw.offset = offset; Aw.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
-    if (plan->timing) (void)hipEventRecord(plan->ev0, stw);
+    timing_begin(plan, stw);
     rc = launch_wide_bwd(Aw, stw);
-    if (plan->timing) { (void)hipEventRecord(plan->ev1, stw); plan->timed = true; }
+    timing_end(plan, stw);
     snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_wide<C=%d,%s>", pr->base_model.channels, bptt ? "bptt" : "rows");
     if (rc == SDEH_ERR_UNSUPPORTED)
       return fail(rc, "ctrl_backward (wide): act' planes of %d layers at C=%d exceed 160 KiB of LDS", pr->base_model.n_hidden + 1, pr->base_model.channels);
@@ -1122,7 +1167,7 @@ int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, con
   A.batch = batch; A.n_steps = n_steps; A.d = d; A.inf_kind = inf.ctrl_kind; A.act = net2.activation;
   A.clip_model = inf.clip_model; A.clip_score = inf.clip_score; A.scale_score = inf.scale_score;
   float* g_in = out; float* g_out = out + (long long)d * C; float* g_hid = g_out + (long long)d * C;
-  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  timing_begin(plan, st);
   if (net2.n_hidden == 2) {  // side 1: d W_2^T, d W_out, adj z_2
     A.side = 1; A.xpart = xp1; A.cpart = cp1; A.spart = nullptr;
     rc = launch_wide_div_bwd(A, st);
@@ -1136,7 +1181,7 @@ int32_t sdeh_bridge_div_backward_wide(SdehPlan* plan, const SdehProblem* pr, con
     if (rc == SDEH_OK) rc = launch_partial_sums(cp0, 1, grid, (long long)d * C, sm, g_in, st);
     if (rc == SDEH_OK && net2.n_hidden == 1) rc = launch_partial_sums(sp0, 1, grid, (long long)d * C, sm, g_out, st);
   }
-  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  timing_end(plan, st);
   snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bridge_div_bwd_wide<C=%d>", C);
   if (rc == SDEH_ERR_UNSUPPORTED) return fail(rc, "bridge_div_backward_wide: planes of %d layers at C=%d exceed 160 KiB of LDS", net2.n_hidden + 2, C);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "bridge_div_backward_wide: kernel launch failed");
@@ -1311,7 +1356,7 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
   const bool v2 = choice.v2;
   A.n_slots = tile == 16 ? bwdf16_slots(batch) : (v2 ? bwdf2_slots(batch, n_steps, bptt) : bwdf_slots(batch, n_steps, bptt));
   A.wsize = bwdf_wsize(d, net.n_hidden);
-  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  timing_begin(plan, st);
   if (scan) {
     // nn [T, d, B] | J [T, d, d, B] | G [T, d, B] behind the partial records
     float* planes = sums + n_s;
@@ -1330,7 +1375,7 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
   } else {
     rc = tile == 16 ? launch_bwdf16(A, st) : (v2 ? launch_bwdf2(A, st) : launch_bwdf(A, st));
   }
-  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  timing_end(plan, st);
   const bool zin = A.zrec != nullptr;  // (the launch read the record)
   snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bwd_fused%s<%s,tiles=%d%s%s>", tile == 16 ? "16" : "", scan ? "bptt-scan" : (bptt ? "bptt" : "rows"),
            d <= 32 ? 1 : 2, tile == 16 ? "" : (v2 || scan ? ",traj-split" : ",chan-split"), zin ? ",zrec" : "");
@@ -1430,9 +1475,9 @@ int32_t sdeh_bridge_inference_fwd(SdehPlan* plan, const SdehProblem* pr, const f
   A.clip_model = pr->clip_model; A.clip_score = pr->clip_score; A.scale_score = pr->scale_score;
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   A.n_tiles = (int)((batch + 31) / 32);
-  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  timing_begin(plan, st);
   rc = launch_bridge_rowsf(A, st);
-  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  timing_end(plan, st);
   snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bridge_rows_fwd<tiles=%d>", d <= 32 ? 1 : 2);
   if (rc != SDEH_OK) return fail(rc, "bridge_inference_fwd: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   rc = launch_partial_sums(scratch, 1, n_steps, batch, scratch + (long long)n_steps * batch, drnd, st);
@@ -1507,11 +1552,11 @@ int32_t sdeh_bridge_backward_fused(SdehPlan* plan, const SdehProblem* pr, const 
   A.n_slots = bwdf2_slots(batch, n_steps, false);
   A.wsize = bwdf_wsize(d, net.n_hidden);
   const long long dpp = d <= 32 ? 32 : 64;
-  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  timing_begin(plan, st);
   rc = launch_divf_zero(A.div_io, n_io, st);
   if (rc == SDEH_OK) rc = launch_bridge_divf(A, st);
   if (rc == SDEH_OK) rc = launch_bwdf2_bridge(A, st);
-  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  timing_end(plan, st);
   snprintf(plan->last_kernel, sizeof(plan->last_kernel), "bridge_bwd_fused<tiles=%d>", d <= 32 ? 1 : 2);
   if (rc != SDEH_OK) return fail(rc, "bridge_backward_fused: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   float* s1 = sums;
@@ -1584,9 +1629,9 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, cons
   A.prior = {pr->prior.kind, pr->prior.n_components, pr->prior.log_norm_const, pr->prior.p0, pr->prior.p1};
   A.seed = seed; A.offset = offset; A.rng_dev = reinterpret_cast<const unsigned long long*>(pr->rng_offset_dev);
   A.int_kind = kind; A.n_out = n_out; A.ts_out = ts_out;
-  if (plan->timing) (void)hipEventRecord(plan->ev0, st);
+  timing_begin(plan, st);
   rc = plan->variant->fn_int(A, st);
-  if (plan->timing) { (void)hipEventRecord(plan->ev1, st); plan->timed = true; }
+  timing_end(plan, st);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "integrate: kernel launch failed (dp=%d)", plan->variant->dp);
 }
 
@@ -1722,6 +1767,17 @@ int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, f
   if (nb > kRedBlocks) nb = kRedBlocks;
   const int rc = launch_reduce(rnd, batch, max_rnd, scratch, (int)nb, out, (hipStream_t)stream);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "reduce_estimators: launch failed");
+}
+
+int32_t sdeh_loss_moment(const float* rnd, int64_t batch, float max_rnd, int32_t log_variance, int64_t* n_filtered, float* scratch,
+                         float* out, float* grad_rnd, void* stream) {
+  if (rnd == nullptr || out == nullptr || scratch == nullptr || grad_rnd == nullptr || batch < 1)
+    return fail(SDEH_ERR_INVALID, "loss_moment: bad argument");
+  long long nb = (batch + 255) / 256;
+  if (nb > kRedBlocks) nb = kRedBlocks;
+  const int rc = launch_loss_moment(rnd, batch, max_rnd, log_variance != 0, reinterpret_cast<long long*>(n_filtered), scratch, (int)nb, out,
+                                    grad_rnd, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "loss_moment: launch failed");
 }
 
 int32_t sdeh_importance_weights(const float* rnd, int64_t batch, const float* log_weight_max, float* weights,

@@ -416,6 +416,38 @@ int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
+// The training loss over the batch and its per-row gradient in one pass behind the reduction (losses/oc.py:72-92: rnd[mask].mean() for
+// kl, rnd[mask].var() for lv): from stats = [n, sum(-rnd), M2, ...] of the kept rows
+//     loss = mean = -stats[1] / n   |   M2 / (n - 1);      w_i = d loss / d rnd_i = 1 / n   |   2 (rnd_i - mean) / (n - 1),   0 on dropped rows
+// -- operation for operation what the framework's masked reductions and their autograd compute (the elementwise chain of
+// losses/oc.py::_MaskedMoment: same fp32 values).  stats[7] <- loss; *n_filtered += stats[6] (the reference's running count, on the device).
+__global__ __launch_bounds__(256) void moment_weights_kernel(const float* __restrict__ rnd, long long n, float max_rnd, int lv,
+                                                             float* __restrict__ stats, float* __restrict__ w,
+                                                             long long* __restrict__ n_filtered) {
+  const float cnt = stats[0];
+  const float mean = -stats[1] / cnt;
+  const float kl_w = 1.0f / cnt, den = cnt - 1.0f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float r = rnd[i];
+    const bool keep = (max_rnd != max_rnd) || (max_rnd > 3.0e38f ? fabsf(r) <= 3.4028235e38f : r < max_rnd);
+    const float per_row = lv ? 2.0f * (r - mean) / den : kl_w;
+    w[i] = keep ? per_row : 0.0f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    stats[7] = lv ? stats[2] / den : mean;
+    if (n_filtered != nullptr) *n_filtered += (long long)stats[6];
+  }
+}
+
+int launch_loss_moment(const float* rnd, long long n, float max_rnd, int lv, long long* n_filtered, float* part, int nb, float* out, float* w,
+                       hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_partial_kernel, dim3(nb), dim3(256), 0, stream, rnd, n, max_rnd, part);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, stream, part, nb, out);
+  const int nbw = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(moment_weights_kernel, dim3(nbw > 0 ? nbw : 1), dim3(256), 0, stream, rnd, n, max_rnd, lv, out, w, n_filtered);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
 __global__ __launch_bounds__(256) void weights_kernel(const float* __restrict__ rnd, long long n,
                                                       const float* __restrict__ mx, float* __restrict__ w) {
   const float m = mx[0];

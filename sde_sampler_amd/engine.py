@@ -382,6 +382,22 @@ class TrajectoryEngine:
         L.check(self._last_plan.lib.sdeh_plan_last_kernel_ms(self._last_plan.handle, C.byref(ms)))
         return ms.value
 
+    def kernel_ms_history(self, n: int = 128) -> list[tuple[str, float]]:
+        """(kernel name, ms) of up to `n` of the last timed launches of the plan that served the last call, newest first
+        (sdeh_plan_timing_entry: a ring of event pairs -- read it AFTER a run instead of synchronising after every launch)."""
+        out = []
+        if self._last_plan is None:
+            return out
+        ms, name = C.c_float(), C.create_string_buffer(96)
+        for back in range(n):
+            rc = self._last_plan.lib.sdeh_plan_timing_entry(self._last_plan.handle, back, C.byref(ms), name, 96)
+            if rc != 0:
+                if rc < 0:
+                    L.check(rc)
+                break
+            out.append((name.value.decode(), ms.value))
+        return out
+
     def last_kernel_name(self) -> str:
         """Name of the compiled kernel variant that served the last launch (sdeh_plan_last_kernel_name)."""
         if self._last_plan is None:
@@ -799,6 +815,24 @@ def estimator_stats(rnd: torch.Tensor, max_rnd: float = math.nan) -> torch.Tenso
         L.check(L.load().sdeh_reduce_estimators(rnd.data_ptr(), rnd.numel(), max_rnd, scratch.data_ptr(),
                                                 out.data_ptr(), stream))
     return out
+
+
+def loss_moment(rnd: torch.Tensor, max_rnd: float, log_variance: bool, n_filtered: torch.Tensor | None) -> tuple[torch.Tensor, torch.Tensor]:
+    """(stats [8] with stats[7] = the loss, d loss / d rnd [like rnd]) of BaseOCLoss.compute_loss for methods kl / lv over the rows the
+    filter keeps (include/sdeh.h: sdeh_loss_moment -- three launches, no host round trip); `n_filtered` (int64 device scalar) += dropped rows."""
+    dev = rnd.device
+    scratch = _SCRATCH.get(dev)
+    if scratch is None:
+        scratch = _SCRATCH[dev] = torch.empty(L.SDEH_REDUCE_SCRATCH, device=dev, dtype=torch.float32)
+    out = torch.empty(8, device=dev, dtype=torch.float32)
+    rnd = rnd.contiguous()
+    w = torch.empty_like(rnd)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        L.check(L.load().sdeh_loss_moment(rnd.data_ptr(), rnd.numel(), max_rnd, int(log_variance),
+                                          None if n_filtered is None else n_filtered.data_ptr(), scratch.data_ptr(), out.data_ptr(),
+                                          w.data_ptr(), stream))
+    return out, w
 
 
 def importance_weights(rnd: torch.Tensor, log_weight_max: torch.Tensor) -> torch.Tensor:

@@ -118,6 +118,23 @@ class _MaskedMoment(torch.autograd.Function):
         return torch.where(mask, per_row * grad_out, torch.zeros_like(rnd)), None, None, None
 
 
+class _FusedMoment(torch.autograd.Function):
+    """_MaskedMoment with filter, statistics, loss value and per-row gradient in THREE launches of the library (sdeh_loss_moment)
+    instead of ~20 framework kernels between the trajectory kernel and the fused backward: the filter of
+    losses/oc.py:50-58 is the reduction's own predicate, the running `n_filtered` is bumped on the device by the same pass."""
+
+    @staticmethod
+    def forward(ctx, rnd, max_rnd: float, lv: bool, n_filtered):
+        stats, w = E.loss_moment(rnd.detach(), max_rnd, lv, n_filtered)
+        ctx.save_for_backward(w)
+        return stats[7]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (w,) = ctx.saved_tensors
+        return w * grad_out, None, None, None
+
+
 class _SharedMoment(torch.autograd.Function):
     """This rank's additive share of the GLOBAL batch's mean (kl) or unbiased variance (lv) of the kept rows, from the local
     statistics (n_l, mean_l, M2_l about the local mean) and the global (n, mean) that ONE device-side all-reduce delivered:
@@ -198,6 +215,13 @@ class BaseOCLoss:
         holds the gradient of the global loss.  The log-variance loss needs the global mean of `rnd` first (one 3-float
         all-reduce); with the mean taken as a constant the per-row gradients 2 (rnd_i - mean) / (N - 1) are exact,
         because the omitted term is proportional to sum_i (rnd_i - mean) = 0 over the global batch."""
+        if (self.graph_safe and self.method in ("kl", "kl_ito", "lv") and rnd.is_cuda and rnd.dtype == torch.float32 and not _dist_on()
+                and (samples is None or self.filter_samples is None)):
+            # filter + statistics + loss + per-row gradient in three launches (sdeh_loss_moment); NaN-free: dropped rows get weight 0
+            if self._n_filtered_dev is None:
+                self._n_filtered_dev = torch.zeros((), device=rnd.device, dtype=torch.int64)
+            loss = _FusedMoment.apply(rnd, math.inf if self.max_rnd is None else float(self.max_rnd), self.method == "lv", self._n_filtered_dev)
+            return loss, {"train/n_filtered_cumulative": self._n_filtered_dev}
         mask = self.filter(rnd, samples=samples)
         assert mask.shape == rnd.shape
         world = _world_size(self.process_group)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN_BRIDGE, inference_params, load_fixture
+from tests.helpers import GOLDEN_BRIDGE, inference_params, load_fixture, measured
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -70,6 +70,37 @@ def _rel(a, b):
     return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
 
 
+# Bars of the Bridge training tests: 2 x the worst value measured on MI355X, every value logged by `measured`
+# (gpurun_out/parity_measured.txt -> profiles/r05_parity_measured.txt).  Loss: relative to max(1, |reference|).
+# Measured (round 5, profiles/r05_parity_measured.txt): loss <= 1.3e-5 (lv) / 2.1e-6 (kl); gradients vs the reference's fp32 gradients
+# <= 2.0e-4 (lv: bridge_gmm2's gamma network, see the float64 arbitration below) / 1.4e-4 (kl: bridge_mw5) / 7.6e-6 (Hutchinson probes)
+BRIDGE_LOSS_BAR = 3e-5
+BRIDGE_GRAD_BAR = {"lv": 4e-4, "kl": 3e-4, "hutch": 2e-5}
+# ... and against the float64 evaluation of the reference's formulas (the oracle run in double precision on the fixture's inputs): the HIP
+# gradients must be within FLOOR of it, or within FACTOR x the distance the reference's own fp32 gradients keep from it
+# (measured: HIP 1.4e-4 / 3.6e-5 / 3.6e-4 where the reference is 5.9e-5 / 1.4e-5 / 2.1e-4 from float64 -- a factor <= 2.5 -- and <= 5.7e-6
+# where the reference is <= 4.4e-6)
+BRIDGE_F64_FLOOR, BRIDGE_F64_FACTOR = 2e-5, 4.0
+
+
+def _float64_bridge_grads(fx, meta, method):
+    from oracle import em_oracle as eo
+
+    params = {k[len("param/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("param/")}
+    p64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in params.items()}
+    q64 = {k: v.double().requires_grad_(v.is_floating_point()) for k, v in inference_params(fx).items()}
+    tt64 = None
+    if meta["target"]["kind"] == "gmm":
+        tt64 = {k: torch.from_numpy(fx["target/" + k].copy()).double() for k in ("loc", "scale", "mixture_weights")}
+    spec = dict(meta, loss=dict(meta["loss"], method=method, max_rnd=(1e8 if method == "lv" else None)))
+    prob = eo.Problem(spec, p64, tt64, params_inf=q64)
+    loss, _, _, _ = prob.train_loss(prob.grid().double(), torch.from_numpy(fx["x0"]).double(), torch.from_numpy(fx["noise"]).double(), method=method)
+    loss.backward()
+    out = {("grad", k): v.grad for k, v in p64.items()}
+    out.update({("grad_inf", k): v.grad for k, v in q64.items()})
+    return out
+
+
 @pytest.mark.parametrize("method", ["lv", "kl"])
 @pytest.mark.parametrize("path", GOLDEN_BRIDGE, ids=lambda p: Path(p).stem)
 def test_bridge_training_gradients_match_reference(path, method):
@@ -86,7 +117,8 @@ def test_bridge_training_gradients_match_reference(path, method):
     val, _ = loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
     val.backward()
     ref = float(fx[f"train_{method}/loss"])
-    assert abs(val.item() - ref) <= 2e-3 * max(1.0, abs(ref)), (val.item(), ref)
+    measured(f"bridge_train_loss/{Path(path).stem}/{method}", abs(val.item() - ref) / max(1.0, abs(ref)), BRIDGE_LOSS_BAR)
+    assert abs(val.item() - ref) <= BRIDGE_LOSS_BAR * max(1.0, abs(ref)), (val.item(), ref)
     worst = {}
     for prefix, mod in (("grad", ctrl), ("grad_inf", inf)):
         for k, p in mod.named_parameters():
@@ -99,10 +131,27 @@ def test_bridge_training_gradients_match_reference(path, method):
                 assert g.abs().max() <= 1e-6, key
                 continue
             worst[key] = _rel(g, g_ref)
-    # measured: <= 5e-6, except mw5 / kl (active clamps under back-propagation through time): 1.4e-4 (profiles/r01_bridge_gradient_parity.txt)
-    tol = 2e-4 if method == "lv" else 1e-3
+    tol = BRIDGE_GRAD_BAR[method]
+    measured(f"bridge_train_grad/{Path(path).stem}/{method}", max(worst.values()), tol)
+    # What the comparison can resolve: the reference is an fp32 computation itself, and the log-variance weights 2 (rnd_i - mean) / (n - 1)
+    # amplify its rounding -- its own gradients sit up to 2e-4 of a tensor's scale from the float64 evaluation of the same formulas
+    # (oracle in float64: bridge_mw5 / kl 2.1e-4, bridge_gmm2 / lv 5.9e-5).  Logged: both sides' distance from float64.
+    g64 = _float64_bridge_grads(fx, meta, method)
+    e_hip = e_ref = 0.0
+    for prefix, mod in (("grad", ctrl), ("grad_inf", inf)):
+        for k, p in mod.named_parameters():
+            key = f"train_{method}/{prefix}/{k}"
+            if key not in fx.files or g64.get((prefix, k)) is None or p.grad is None:
+                continue
+            t64 = g64[(prefix, k)]
+            den = max(t64.abs().max().item(), 1e-12)
+            e_hip = max(e_hip, (p.grad.cpu().double() - t64).abs().max().item() / den)
+            e_ref = max(e_ref, (torch.from_numpy(fx[key]).double() - t64).abs().max().item() / den)
+    measured(f"bridge_train_grad_vs_float64/{Path(path).stem}/{method}/hip", e_hip, max(BRIDGE_F64_FLOOR, BRIDGE_F64_FACTOR * e_ref))
+    measured(f"bridge_train_grad_vs_float64/{Path(path).stem}/{method}/reference", e_ref, 0.0)
     bad = {k: v for k, v in worst.items() if v > tol}
     assert not bad, bad
+    assert e_hip <= max(BRIDGE_F64_FLOOR, BRIDGE_F64_FACTOR * e_ref), (e_hip, e_ref)
 
 
 @pytest.mark.parametrize("est", ["rademacher", "gauss"])
@@ -118,7 +167,8 @@ def test_bridge_hutchinson_training_matches_reference(path, est):
     val, _ = loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise, div_noise=probes)
     val.backward()
     ref = float(fx[f"hutch_{est}/loss"])
-    assert abs(val.item() - ref) <= 2e-3 * max(1.0, abs(ref)), (val.item(), ref)
+    measured(f"bridge_hutch_loss/{Path(path).stem}/{est}", abs(val.item() - ref) / max(1.0, abs(ref)), BRIDGE_LOSS_BAR)
+    assert abs(val.item() - ref) <= BRIDGE_LOSS_BAR * max(1.0, abs(ref)), (val.item(), ref)
     worst = {}
     for prefix, mod in (("grad", prob.ctrl), ("grad_inf", loss.inference_ctrl)):
         for k, p in mod.named_parameters():
@@ -131,7 +181,8 @@ def test_bridge_hutchinson_training_matches_reference(path, est):
                 assert g.abs().max() <= 1e-6, key
                 continue
             worst[key] = _rel(g, g_ref)
-    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    measured(f"bridge_hutch_grad/{Path(path).stem}/{est}", max(worst.values()), BRIDGE_GRAD_BAR["hutch"])
+    bad = {k: v for k, v in worst.items() if v > BRIDGE_GRAD_BAR["hutch"]}
     assert not bad, bad
     # without given probes the loss draws its own (device RNG) and still trains
     val2, _ = loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle import em_oracle as eo
-from tests.helpers import hatch
+from tests.helpers import fuzz_close, hatch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -196,7 +196,7 @@ def check_eval_case(case, spec_hook=None, expect_kernel=None):
         assert (not math.isfinite(got)) or abs(got) > 1e6, f"{tag}: {key} {got} vs {want}"
         return
     cond = cond_of(key)
-    assert _close(got, want, 2e-3 * max(1.0, abs(want)) + 2.0 * cond), f"{tag}: {key} {got} vs {want} (conditioning {cond:.2e})"
+    assert fuzz_close(f"eval/{key}", got, want, 2.0 * cond), f"{tag}: {key} {got} vs {want} (conditioning {cond:.2e})"
     if weights and math.isfinite(ref[key]):  # (non-finite rows: overflow shows as +inf or as nan depending on the order of operations)
         got, want = out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"]
         assert _close(got, want, 5e-3 * max(1.0, abs(want)) + cond_of("log_norm_const_is")), f"{tag}: log_norm_const_is {got} vs {want}"
@@ -281,7 +281,7 @@ def check_training_case(case, num_layers=None, expect_kernel=None, spec_hook=Non
             assert not math.isfinite(val.item()) or abs(val.item()) > 1e-2 * abs(ref_loss.item()), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
             return
         hatch("train:large_loss_compared_relatively", tag)
-    assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item())) + cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    assert fuzz_close("train/loss", val.item(), ref_loss.item(), cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
     if not math.isfinite(ref_loss.item()):
         hatch("train:nonfinite_reference_loss", tag)
         return
@@ -414,14 +414,14 @@ def test_random_bridge_matches_oracle(case):
     # per-row bar; measured: 1 case of 384 above 5 %)
     assert row_err.median().item() <= 1e-4 * scale and (row_err > 2e-3 * scale).float().mean().item() <= 2 * DRIFT_MAX, f"{tag}: x_T"
     got, want = out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"]
-    assert _close(got, want, 2e-3 * max(1.0, abs(want)) + cond_lb), f"{tag}: lb_ito {got} vs {want}"
+    assert fuzz_close("bridge/lb_ito", got, want, cond_lb), f"{tag}: lb_ito {got} vs {want}"
     val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
     val.backward()
     if math.isfinite(ref_loss.item()) and abs(ref_loss.item()) > 1e8 and (abs(ref_loss.item()) > 1e15 or not cond_loss <= 0.05 * abs(ref_loss.item())):
         hatch("bridge:exploded_reference_loss", tag)  # (not comparable with itself: see check_training_case)
         assert not math.isfinite(val.item()) or abs(val.item()) > 1e-2 * abs(ref_loss.item()), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
         return
-    assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item())) + cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    assert fuzz_close("bridge/loss", val.item(), ref_loss.item(), cond_loss), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
     if not math.isfinite(ref_loss.item()):
         hatch("bridge:nonfinite_reference_loss", tag)
         return

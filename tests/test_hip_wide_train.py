@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import GOLDEN_WIDE, GOLDEN_WIDE_BRIDGE, hip_problem, inference_params, load_fixture
+from tests.helpers import GOLDEN_WIDE, GOLDEN_WIDE_BRIDGE, fuzz_close, hip_problem, inference_params, load_fixture, measured
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -20,6 +20,14 @@ def _golden_grad(fx, key):
     if key in fx.files:
         return fx[key], None
     return fx[key + "@stride"], float(fx[key + "@norm"])
+
+
+# Bars: 2 x the worst value measured on MI355X over all fixtures (gpurun_out/parity_measured.txt ->
+# profiles/r05_parity_measured.txt); loss relative to max(1, |reference|), gradients relative to each tensor's scale
+# measured: loss <= 1.2e-5; gradients: plain <= 6.2e-5, Bridges lv <= 1.1e-5, Bridges kl <= 1.4e-4 (widebridge_mw44_c128: active clamps under
+# back-propagation through time)
+WIDE_LOSS_BAR = 3e-5
+WIDE_GRAD_BAR = {"plain": 1.3e-4, "bridge_lv": 3e-5, "bridge_kl": 3e-4}
 
 
 def _check_grads(fx, method, prefix, module, tol=2e-4):
@@ -52,11 +60,13 @@ def test_wide_training_gradients_match_reference(path, method):
     x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
     val, info = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
     ref = float(fx[f"train_{method}/loss"])
-    assert abs(val.item() - ref) <= 2e-4 * max(1.0, abs(ref)), (val.item(), ref)
+    measured(f"wide_train_loss/{Path(path).stem}/{method}", abs(val.item() - ref) / max(1.0, abs(ref)), WIDE_LOSS_BAR)
+    assert abs(val.item() - ref) <= WIDE_LOSS_BAR * max(1.0, abs(ref)), (val.item(), ref)
     assert int(info["train/n_filtered_cumulative"]) == int(fx[f"train_{method}/n_filtered"])
     val.backward()
     assert prob.loss.engine.last_kernel_name() == f"bwd_wide<C={meta['net']['channels']},{'rows' if method == 'lv' else 'bptt'}>"
-    worst = _check_grads(fx, method, "grad", prob.ctrl)
+    worst = _check_grads(fx, method, "grad", prob.ctrl, tol=WIDE_GRAD_BAR["plain"])
+    measured(f"wide_train_grad/{Path(path).stem}/{method}", worst[0], WIDE_GRAD_BAR["plain"])
     print(f"{Path(path).stem} {method}: worst relative gradient error {worst[0]:.2e} ({worst[1]})")
 
 
@@ -107,10 +117,13 @@ def test_wide_bridge_training_gradients_match_reference(path, method):
     x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
     val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
     ref = float(fx[f"train_{method}/loss"])
-    assert abs(val.item() - ref) <= 2e-4 * max(1.0, abs(ref)), (val.item(), ref)
+    measured(f"wide_bridge_train_loss/{Path(path).stem}/{method}", abs(val.item() - ref) / max(1.0, abs(ref)), WIDE_LOSS_BAR)
+    assert abs(val.item() - ref) <= WIDE_LOSS_BAR * max(1.0, abs(ref)), (val.item(), ref)
     val.backward()
-    worst_u = _check_grads(fx, method, "grad", prob.ctrl)
-    worst_v = _check_grads(fx, method, "grad_inf", inf)
+    bar = WIDE_GRAD_BAR["bridge_" + method]
+    worst_u = _check_grads(fx, method, "grad", prob.ctrl, tol=bar)
+    worst_v = _check_grads(fx, method, "grad_inf", inf, tol=bar)
+    measured(f"wide_bridge_train_grad/{Path(path).stem}/{method}", max(worst_u[0], worst_v[0]), bar)
     print(f"{Path(path).stem} {method}: worst relative gradient error generative {worst_u[0]:.2e} ({worst_u[1]}), inference {worst_v[0]:.2e} ({worst_v[1]})")
 
 
@@ -192,7 +205,7 @@ def test_random_wide_bridge_training_matches_oracle(case, mixture):
            f"{spec['net']} inf {spec['inference_net']}")
     # (kl: the last launch of the backward is the generative network's back-propagation through time)
     assert prob.loss.engine.last_kernel_name().startswith("bridge_div_bwd_wide" if method == "lv" else "bwd_wide"), tag
-    assert _close(val.item(), ref_loss.item(), 2e-3 * max(1.0, abs(ref_loss.item()))), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
+    assert fuzz_close("wide_bridge_train/loss", val.item(), ref_loss.item(), 0.0), f"{tag}: loss {val.item()} vs {ref_loss.item()}"
     for mod, ref, net in ((prob.ctrl, params, spec["net"]), (inf, params_inf, spec["inference_net"])):
         gmax = max((torch.nan_to_num(p.grad).abs().max().item() for p in ref.values() if p.grad is not None), default=0.0)
         for k, p in mod.named_parameters():

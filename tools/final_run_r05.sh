@@ -1,0 +1,58 @@
+#!/bin/bash
+# Round-5 measurement run (on the GPU box, from the repo root): everything whose summary is committed under profiles/r05_*.
+#   gpurun --timeout 3000 -- 'bash tools/final_run_r05.sh'
+set -u
+OUT=gpurun_out/r05
+mkdir -p $OUT
+ROOT=$(pwd)
+# 1. PMC passes of the headline trajectory kernel (separate --pmc passes, kernel trace only) + the stamped record bench.py reads
+bash tools/pmc_profile.sh $OUT/pmc_headline > $OUT/pmc.log 2>&1
+{ echo "# rocprofv3 PMC passes (tools/pmc_profile.sh, separate --pmc passes with --kernel-trace only) of the headline trajectory kernel traj_ws<50_0_pis_gmm4>,"
+  echo "# GMM-40 d=50, B=65536, T=100, round 5; per launch, averaged over the dispatches.  GRBM_GUI_ACTIVE is summed over the 8 XCDs."
+  cat $OUT/pmc_headline/summary.txt; } > $OUT/r05_pmc_headline.txt
+cp $OUT/r05_pmc_headline.txt profiles/r05_pmc_headline.txt
+python tools/pmc_headline_json.py $OUT/pmc_headline/summary.txt profiles/r05_pmc_headline.txt > /dev/null; cp profiles/pmc_headline.json $OUT/
+# 2. rocprofv3 kernel trace of the bench command
+(cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_headline -- python $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extra > $ROOT/$OUT/prof_headline.log 2>&1)
+DB=$(find $OUT/prof_headline -name "*.db" | head -1)
+python tools/rocprof_summary.py $DB > $OUT/r05_kernel_stats_headline.txt
+tail -2 $OUT/prof_headline.log | cut -c1-900 >> $OUT/r05_kernel_stats_headline.txt
+find $OUT/prof_headline -name "*.db" -delete
+# 3. the bench lines
+python bench.py > $OUT/r05_bench_headline.json 2> $OUT/bench_headline.err
+python bench.py --dist --no-extra --no-cpu-baseline > $OUT/r05_bench_headline_dist1.json 2>> $OUT/bench_headline.err
+for w in train_gmm2_dis_kl train_gmm50_pis_kl; do python bench.py --workload $w --no-cpu-baseline > $OUT/r05_bench_$w.json 2>> $OUT/bench_train.err; done
+# 4. every BASELINE configuration at its per-GPU batch; training forward + backward with the pre-activation record against the re-evaluating launches
+python tools/all_configs_timing.py 2>&1 | grep -v amdgpu.ids > $OUT/r05_all_configs_timing.txt
+{ echo "# tools/zrec_ab.py: training forward + fused backward kernel times (HIP events) WITH the pre-activation record (ABI v6, default) against the"
+  echo "# re-evaluating launches (plan option SDEH_BWD_ZREC=0), identical Philox draws; gradient difference of the two relative to each tensor's scale.  MI355X, round 5."
+  REPS=7 python tools/zrec_ab.py 2>&1 | grep -v "Warn\|loss0\|Consider"
+  echo "# small batches through time (16-trajectory teams, scan form) and mid batches"
+  REPS=7 python tools/zrec_ab.py cfg3_gmm50_pis_kl:kl:2048 cfg3_gmm50_pis_kl:kl:8192 cfg2_gmm2_dis_kl:kl:512 cfg2_gmm2_dis_kl:kl:2048 cfg1_dw_dis_lv:kl:2048 cfg4_funnel_dds_lv:kl:2048 cfg3_gmm50_pis_kl:kl:32768 cfg4_funnel_dds_lv:kl:16384 2>&1 | grep -v "Warn\|loss0\|Consider"
+  echo "# trajectory-split teams forced for two coordinate tiles through time (plan option SDEH_BWD_V2)"
+  SDEH_BWD_V2=1 REPS=5 python tools/zrec_ab.py cfg3_gmm50_pis_kl:kl:65536 2>&1 | grep -v "Warn\|loss0\|Consider"; } 2>&1 | grep -v amdgpu.ids > $OUT/r05_training_backward_roofline.txt
+# 5. phase profiles (measurement builds under prof_tmp/): fused backward with the record; forward cost of the record stores
+[ -f prof_tmp/libsdeh_prof.so ] && bash tools/bwdf_phase_profile.sh run 2>&1 | grep -v amdgpu.ids > $OUT/r05_bwd_fused_phases.txt
+[ -f prof_tmp/libsdeh_zabl_nt.so ] && bash tools/zrec_fwd_ablation.sh run 2>&1 | grep -v "amdgpu.ids\|phases" > $OUT/r05_zrec_fwd_ablation.txt
+# 6. PMC passes of the fused backward with / without the record; kernel trace of a training bench
+bash tools/pmc_bwd.sh > $OUT/pmc_bwd.log 2>&1
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/prof_train -- python $ROOT/bench.py --workload train_gmm2_dis_kl --steps 10 --warmup 3 --no-cpu-baseline > $ROOT/$OUT/prof_train.log 2>&1)
+DB=$(find $OUT/prof_train -name "*.db" | head -1)
+python tools/rocprof_summary.py $DB > $OUT/r05_kernel_stats_train_gmm2_dis_kl.txt
+find $OUT/prof_train -name "*.db" -delete
+# 7. replayed optimisation steps at the reference's training batches: kernel timelines + whole-step times
+bash tools/graph_step_trace.sh r05 > /dev/null 2>&1; cp gpurun_out/step_trace_r05.txt $OUT/r05_graph_step_trace.txt
+python tools/train_reference_schedule.py --steps 2000 --out /tmp/ref_schedule_tmp.pt 2>&1 | grep -v amdgpu.ids | tail -12 > $OUT/r05_train_reference_schedule.txt
+# 8. Bridge training steps (unchanged kernels except the generative network's record) and the quality runs
+{ echo "# Bridge training step (loss + backward), T = 200, wall clock, eager, best of 5 (tools/bridge_step_profile.py <d> <B> <method>); MI355X, round 5"
+  for a in "10 2048 lv" "2 2048 lv" "50 2048 lv" "50 16384 lv" "10 2048 kl"; do python tools/bridge_step_profile.py $a; done; } 2>&1 | grep -v amdgpu.ids > $OUT/r05_bridge_step_kernels.txt
+{ for a in "cfg1_dw_dis_lv --steps 10000 --lr 1e-3 --eval-batch 262144" "cfg1_dw_dis_lv --method kl --steps 10000 --lr 1e-3 --eval-batch 262144" "cfg2_gmm2_dis_kl --method lv --steps 6000 --lr 1e-3" "bridge_dw --steps 400"; do
+    echo "## tools/train_demo.py $a --graph --seed 1"; python tools/train_demo.py $a --graph --seed 1 2>&1 | grep -E "^\[|RESULT|step (400|6000|10000):"; done; } > $OUT/r05_train_quality.txt 2>&1
+# 9. host cost of an evaluation call
+{ python tools/eval_host_profile.py; python tools/eval_host_profile.py gmm50_pis_headline 1024; } 2>&1 | grep -v amdgpu.ids > $OUT/r05_eval_host_profile.txt
+# 10. the suite and the smoke test
+rm -f gpurun_out/parity_measured.txt gpurun_out/fuzz_hatches.txt
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $OUT/r05_pytest_gpu.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 >> $OUT/r05_pytest_gpu.txt
+sort gpurun_out/parity_measured.txt > $OUT/r05_parity_measured.txt
+cat $OUT/r05_pytest_gpu.txt; head -5 $OUT/r05_kernel_stats_headline.txt | cut -c1-170; tail -c 900 $OUT/r05_bench_headline.json; echo; cat $OUT/r05_training_backward_roofline.txt | cut -c1-330

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--method", default=None)
     ap.add_argument("--lr", type=float, default=5e-3)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--eval-batch", type=int, default=16384, help="trajectories of the log Z evaluations before / after training")
     ap.add_argument("--graph", action="store_true", help="capture the whole optimisation step into one hipGraph (utils/graphs.py)")
     ap.add_argument("--no-guard", action="store_true", help="with --graph: no device-side skip of non-finite updates")
     args = ap.parse_args()
@@ -49,7 +50,7 @@ def main():
     opt = torch.optim.Adam(groups, capturable=args.graph)
 
     def evaluate(tag):
-        x = prob.prior.sample((16384,))
+        x = prob.prior.sample((args.eval_batch,))
         r = prob.eval(x, compute_weights=True)
         lz = r.log_norm_const_preds["log_norm_const_is"]
         lb = r.log_norm_const_preds["log_norm_const_lb_ito"]

@@ -127,6 +127,12 @@ def cpu_process_parallel(spec, prob_cpu_state, chunk: int, n_intervals: int | No
     import tempfile
 
     n = int(os.environ.get("SDEH_BENCH_CPU_PROCS", physical_cores()))
+    try:  # an interpreter with torch loaded is ~0.5 GB resident: never more processes than the host's free memory holds three times over
+        import psutil
+
+        n = max(1, min(n, int(psutil.virtual_memory().available / 1.5e9)))
+    except Exception:  # pragma: no cover
+        pass
     params, tt, params_inf = prob_cpu_state
     lead = 15.0 + 0.2 * n  # interpreter + torch import + warm-up chunk of every process before the window opens
     root = os.path.dirname(os.path.abspath(__file__))

@@ -1216,7 +1216,7 @@ struct BwdfChoice {
   bool v2;     // tiles of 32: trajectory-split teams (sdeh_bwdf2.hip) instead of channel-split ones (sdeh_bwdf.hip)
   bool zin;    // the launch reads the pre-activation record when it is given one
 };
-static BwdfChoice bwdf_choice(const SdehProblem* pr, long long batch, bool klb) {
+static BwdfChoice bwdf_choice(const SdehProblem* pr, long long batch, bool klb, bool have_zrec) {
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   const bool bptt = !(pr->flags & SDEH_FLAG_CHANGE_SDE_CTRL);
@@ -1240,18 +1240,22 @@ static BwdfChoice bwdf_choice(const SdehProblem* pr, long long batch, bool klb) 
   // items to spare.
   const long long n_tiles = (batch + c.tile - 1) / c.tile;
   const bool enough = !bptt || n_tiles > 512 || force_v2;
-  c.v2 = c.tile == 32 && !force_v1 && enough && bwdf2_fits(d, net.n_hidden) &&
-         (d <= 32 || (!bptt) || (force_v2 && pr->target.kind != SDEH_DENS_FUNNEL));
   const char* zo = plan_opt(OPT_BWD_ZREC);
   // (both tilings of 32 and the four-wave teams of 16 read the record)
   c.zin = (zo == nullptr || zo[0] != '0') && !klb && (c.scan || c.tile == 32 || bwdf16_waves(batch) == 4);
+  // Two coordinate tiles through time: re-evaluating, the trajectory-split kernel spills (19.7 ms at d = 50, B = 65 536, T = 200 against the
+  // channel-split kernel's 15.2); READING THE RECORD it holds one layer's act' and the records in flight instead of the whole network and
+  // wins (11.3 against 12.4 ms, round 5) -- the default whenever the launch is given the record (a funnel's Jacobian couples the two tiles:
+  // channel-split).
+  const bool v2_two_tiles = (force_v2 || (have_zrec && c.zin)) && pr->target.kind != SDEH_DENS_FUNNEL;
+  c.v2 = c.tile == 32 && !force_v1 && enough && bwdf2_fits(d, net.n_hidden) && (d <= 32 || (!bptt) || v2_two_tiles);
   return c;
 }
 
 int32_t sdeh_ctrl_backward_fused_reads_zrec(const SdehPlan* plan, const SdehProblem* pr, int64_t batch) {
   OptScope opt_scope(plan);
   if (batch < 1 || !sdeh_ctrl_backward_fused_supported(plan, pr)) return 0;
-  return bwdf_choice(pr, batch, false).zin ? 1 : 0;
+  return bwdf_choice(pr, batch, false, true).zin ? 1 : 0;
 }
 
 static void bwdf_sizes(int d, int n_hidden, int n_steps, long long batch, int g, bool bptt, int tile, long long* wpart, long long* epart,
@@ -1320,7 +1324,7 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
   const SdehFourierMLP& net = pr->base_model;
   const int d = net.dim;
   long long n_w, n_e, n_g, n_s, n_o;
-  const BwdfChoice choice = bwdf_choice(pr, batch, cost_ctrl != nullptr);
+  const BwdfChoice choice = bwdf_choice(pr, batch, cost_ctrl != nullptr, zrec != nullptr);
   const int tile = choice.tile;
   const bool scan = choice.scan;
   bwdf_sizes(d, net.n_hidden, n_steps, batch, L.g == 1 ? 1 : 64, bptt && !scan, tile, &n_w, &n_e, &n_g, &n_s, &n_o);

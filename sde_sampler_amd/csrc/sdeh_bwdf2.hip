@@ -272,7 +272,10 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
   };
   // ZIN: two record buffers in flight -- layer k of a step lives in zA when LH - k is even, else in zB, and is requested where the
   // buffer's previous content was activated: Z_LH of the NEXT step in front of this step's last hidden stage, Z_{LH-1} of the next step in
-  // front of the in stage, Z_{LH-2} of this step at its top -- every request a whole stage (8-10 k cycles of matrix work) ahead of its use
+  // front of the in stage, Z_{LH-2} of this step at its top -- every request a whole stage (8-10 k cycles of matrix work) ahead of its use.
+  // Two coordinate tiles through time (the kernel's register peak is its two-tile elementwise phase): ONE stage shallower -- Z_LH of the next
+  // step in front of the in stage, Z_{LH-1} at the top of the step, the score plane per tile inside the elementwise phase: 412 -> 224 B of
+  // scratch per lane, 13.1 -> 11.3 ms at d = 50, B = 65 536, T = 200
   f32x16 xnext[OTD], embnext[2], zA[2], zB[2], zC[2];  // (zC: the Jacobian pass holds all three layers of the next item)
   StepCoef cnext;
   {
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
     if constexpr (!ZIN) load_emb(t0, embnext);
     cnext = load_coef(t0);
     load_z(t0, tile_of(p0), LH, zA);
-    load_z(t0, tile_of(p0), LH - 1, zB);
+    if constexpr (!(OTD == 2 && BPTT)) load_z(t0, tile_of(p0), LH - 1, zB);  // (two tiles through time: requested at the top of the step)
     if constexpr (ZIN && JAC) load_z(t0, tile_of(p0), 0, zC);
   }
   for (long long round = 0; round < n_rounds; ++round) {
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         // raw network output and score planes first (their latency hides behind the activation of Z_LH, which arrived a step ago)
 #pragma unroll
         for (int ct = 0; ct < OTD; ++ct) load_nn(t, tile, ct, nn[ct]);
-        if (has_score) {
+        if (has_score && !(OTD == 2 && BPTT)) {  // (two coordinate tiles through time: requested per tile, inside the elementwise phase)
 #pragma unroll
           for (int ct = 0; ct < OTD; ++ct) scv[ct] = load_cm(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
         }
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         plane_put(Ame, 1, j, h, cur[1]);
         SDEH_FENCE();
         if constexpr (LH >= 2) load_z(t, tile, LH - 2, zA);  // consumed two stages on
+        if constexpr (OTD == 2 && BPTT) load_z(t, tile, LH - 1, zB);  // (two coordinate tiles through time: shallower prefetch, fewer registers in flight)
         SDEH_FENCE();
       }
       if constexpr (!ZIN) {
@@ -539,6 +543,9 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
         for (int ct = 0; ct < OTD; ++ct) {
           SDEH_FENCE();
           const int cb = 32 * ct + 4 * h;
+          if constexpr (ZIN && OTD == 2 && BPTT) {
+            if (has_score) scv[ct] = load_cm(A.sc + (long long)t * d * B, (unsigned)lrow, ct);
+          }
           f32x16 cvec, Gc;
           f32x16 xe;  // x_t of this tile, where the adjoint needs it
           if constexpr (XRELOAD) {
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
               if (((LH - l) & 1) == 0) load_z(t, tile, l >= 2 ? l - 2 : 0, zA);
               else load_z(t, tile, l >= 2 ? l - 2 : 0, zB);
             }
-            if (l == 0) {  // the next step's (or item's) top layer: zA is free (LH even: its Z_0 was just activated; odd: since the top)
+            if (l == 0 && !(OTD == 2 && BPTT)) {  // the next step's (or item's) top layer: zA is free (LH even: its Z_0 was just activated; odd: since the top)
               if (t > t_last) {
                 load_z(t - 1, tile, LH, zA);
               } else if (round + 1 < n_rounds) {
@@ -866,14 +873,16 @@ __global__ __launch_bounds__(256) void bwdf2_kernel(const BwdfArgs A) {
             load_x(t - 1, (int)tile, xnext);
             if constexpr (!ZIN) load_emb(t - 1, embnext);
             cnext = load_coef(t - 1);
-            load_z(t - 1, tile, LH - 1, zB);
+            if constexpr (OTD == 2 && BPTT) load_z(t - 1, tile, LH, zA);
+            else load_z(t - 1, tile, LH - 1, zB);
           } else if (round + 1 < n_rounds) {
             int tn = it_t, pn = it_pair;
             clamp_item(tn, pn);
             load_x(tn, tile_of(pn), xnext);
             if constexpr (!ZIN) load_emb(tn, embnext);
             cnext = load_coef(tn);
-            load_z(tn, tile_of(pn), LH - 1, zB);
+            if constexpr (OTD == 2 && BPTT) load_z(tn, tile_of(pn), LH, zA);
+            else load_z(tn, tile_of(pn), LH - 1, zB);
           }
           f32x16 dx[OTD];
           // d loss / d (time embedding + input bias)[t][row] per tile: the delta row sums of each wave's trajectories
@@ -1193,6 +1202,9 @@ __global__ __launch_bounds__(64) void bwdf2_scan_kernel(const BwdfArgs A) {
   }
 }
 
+#ifdef SDEH_BWDF2_SINGLE  // (compile-only aid: ONE instantiation, e.g. '-DSDEH_BWDF2_SINGLE=2, true, 2, true, 16, false' -- register / scratch experiments)
+template __global__ void bwdf2_kernel<SDEH_BWDF2_SINGLE>(const BwdfArgs);
+#else
 int launch_bwdf2_scan(const BwdfArgs& a, hipStream_t stream) {
   const dim3 grid((unsigned)((a.batch + 63) / 64));
   if ((a.cost_in != nullptr) != (a.lam_in != nullptr)) return SDEH_ERR_UNSUPPORTED;
@@ -1382,5 +1394,7 @@ int launch_bwdf2(const BwdfArgs& a, hipStream_t stream) {
   }
   return SDEH_ERR_UNSUPPORTED;
 }
+
+#endif  // SDEH_BWDF2_SINGLE
 
 }  // namespace sdeh

@@ -790,11 +790,14 @@ _SCRATCH: dict = {}
 
 def _zrec_fits(nbytes: int, device) -> bool:
     """Memory budget of the pre-activation record (768 B per trajectory-step with two hidden layers: 5 GB at B = 65 536, T = 100): at most
-    SDEH_ZREC_BYTES (default: 40 % of what is free on the device right now)."""
+    SDEH_ZREC_BYTES (default: 40 % of what is free on the device right now, the caching allocator's idle blocks included)."""
     cap = os.environ.get("SDEH_ZREC_BYTES")
     if cap is not None:
         return nbytes <= int(float(cap))
     free, _total = torch.cuda.mem_get_info(device)
+    # (+ what the caching allocator holds but has not handed out: the record of the previous step is in there, and a budget that did not
+    # count it would flip between the two forward launches from one step to the next)
+    free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
     return nbytes <= 0.4 * free
 
 

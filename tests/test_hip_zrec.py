@@ -124,10 +124,13 @@ CASES = [  # (spec, method, batch, steps, what the record launch is called, plan
     ("cfg3_gmm50_pis_kl", "lv", 2048, 7, "bwd_fused<rows,tiles=2,traj-split,zrec>", {}),
     ("cfg3_gmm50_pis_kl", "lv_traj", 515, 7, "bwd_fused<rows,tiles=2,traj-split,zrec>", {}),
     # the channel-split kernel (sdeh_bwdf.hip): two coordinate tiles through time, forced tilings, three hidden layers
-    ("cfg3_gmm50_pis_kl", "kl", 16 * 1024 + 40, 5, "bwd_fused<bptt,tiles=2,chan-split,zrec>", {}),
+    ("cfg3_gmm50_pis_kl", "kl", 16 * 1024 + 40, 5, "bwd_fused<bptt,tiles=2,traj-split,zrec>", {}),  # (with the record: trajectory-split)
+    ("cfg3_gmm50_pis_kl", "kl", 16 * 1024 + 40, 5, "bwd_fused<bptt,tiles=2,chan-split,zrec>", {"SDEH_BWD_V1": "1"}),
     ("cfg3_gmm50_pis_kl", "kl_ito", 515, 7, "bwd_fused<bptt,tiles=2,chan-split,zrec>", {"SDEH_BWD_TILE": "32"}),
     ("cfg4_funnel_dds_lv", "kl", 1000, 6, "bwd_fused<bptt,tiles=1,chan-split,zrec>", {"SDEH_BWD_TILE": "32"}),
     ("cfg2_gmm2_dis_kl", "lv", 900, 6, "bwd_fused<rows,tiles=1,chan-split,zrec>", {"SDEH_BWD_V1": "1"}),
+    ("cfg3_gmm50_pis_kl", "kl", 16 * 1024 + 40, 5, "bwd_fused<bptt,tiles=2,traj-split,zrec>", {"SDEH_BWD_V2": "1"}),
+    ("cfg3_gmm50_pis_kl", "kl_ito", 700, 6, "bwd_fused<bptt,tiles=2,traj-split,zrec>", {"SDEH_BWD_V2": "1", "SDEH_BWD_TILE": "32"}),
     ("cfg1_dw_dis_lv", "kl", 700, 6, "bwd_fused<bptt,tiles=1,chan-split,zrec>", {"SDEH_BWD_V1": "1", "SDEH_BWD_TILE": "32"}),
     # small batches through time: teams of four waves on tiles of 16 (sdeh_bwdf16.hip; the forward ran in pair / quad mode) and the scan form
     ("cfg3_gmm50_pis_kl", "kl", 2048, 6, "bwd_fused16<bptt,tiles=2,zrec>", {}),

@@ -503,6 +503,17 @@ int32_t sdeh_reduce_estimators(const float* rnd, int64_t batch, float max_rnd, f
 int32_t sdeh_loss_moment(const float* rnd, int64_t batch, float max_rnd, int32_t log_variance, int64_t* n_filtered, float* scratch,
                          float* out, float* grad_rnd, void* stream);
 
+/* ABI v6.  The reference trainer applies an optimisation step only `if loss_ok and grad_ok` (solver/base.py:409-432), a host decision.  A
+ * captured step takes it on the device: the step runs on sanitised gradients and is UNDONE when *ok == 0 -- every tensor the optimizer may
+ * have changed is put back from its snapshot.  table [n_tensors][3] (device, uint64): destination pointer, snapshot pointer, number of 32-bit
+ * words; ok: one byte on the device (torch.bool); n_skipped (nullable): device counter, incremented when the step is undone.  One launch
+ * (utils/graphs.py: GraphedTrainStep).
+ * sdeh_guard_check takes the decision: *ok = loss_ok and grad_ok, with loss_ok = isfinite(*value) (max_loss < 0) or |*value| <= max_loss
+ * (solver/base.py:409-415) and grad_ok = every one of the n gradient entries finite (solver/base.py:416-421, over one flat copy of the
+ * gradients); when the step is rejected the n entries are zeroed in place, so that the step that still runs inside the graph sees finite input. */
+int32_t sdeh_guard_check(float* grads, int64_t n, const float* value, float max_loss, uint8_t* ok, void* stream);
+int32_t sdeh_guard_restore(const uint64_t* table, int32_t n_tensors, const uint8_t* ok, int64_t* n_skipped, void* stream);
+
 /* importance weights exp(-rnd - m) (losses/oc.py:101-103) with a caller-provided global maximum m (device scalar). */
 int32_t sdeh_importance_weights(const float* rnd, int64_t batch, const float* log_weight_max, float* weights,
                                 void* stream);

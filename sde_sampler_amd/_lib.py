@@ -159,6 +159,8 @@ PROTOTYPES = {
     "sdeh_ctrl_backward_fused_ex": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, fp, C.c_int64, fp, C.c_uint64, C.c_uint64,
                                                 C.c_int64, fp, fp, fp, fp, fp, fp, C.c_int64, fp, C.c_void_p]),
     "sdeh_loss_moment": (C.c_int32, [fp, C.c_int64, C.c_float, C.c_int32, fp, fp, fp, fp, C.c_void_p]),
+    "sdeh_guard_check": (C.c_int32, [fp, C.c_int64, fp, C.c_float, fp, C.c_void_p]),
+    "sdeh_guard_restore": (C.c_int32, [fp, C.c_int32, fp, fp, C.c_void_p]),
     "sdeh_plan_timing_entry": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.c_char_p, C.c_int32]),
     "sdeh_zrec_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
     "sdeh_ctrl_backward_fused_reads_zrec": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), C.c_int64]),

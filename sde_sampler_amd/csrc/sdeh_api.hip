@@ -17,6 +17,8 @@ int launch_reduce(const float* rnd, long long n, float max_rnd, float* part, int
 int launch_weights(const float* rnd, long long n, const float* mx, float* w, hipStream_t stream);
 int launch_loss_moment(const float* rnd, long long n, float max_rnd, int lv, long long* n_filtered, float* part, int nb, float* out, float* w,
                        hipStream_t stream);
+int launch_guard_restore(const unsigned long long* table, int n_tensors, const unsigned char* ok, long long* n_skipped, hipStream_t stream);
+int launch_guard_check(float* g, long long n, const float* value, float max_loss, unsigned char* ok, hipStream_t stream);
 int launch_sink_init(float* u, float* v, float* log_a, float* log_b, const float* w_x, const float* w_y, long long n,
                      long long m, float eps, int* flags, hipStream_t st);
 int launch_sink_finalize(const float* pm, const float* ps, int splits, long long np, const float* log_w, float eps, float* pot,
@@ -1387,11 +1389,15 @@ static int ctrl_backward_fused_impl(SdehPlan* plan, const SdehProblem* pr, const
   // deterministic sums over the teams / tiles
   float* s1 = sums;
   float* s2 = s1 + ((A.n_slots + 31) / 32) * (long long)A.wsize;
-  rc = launch_partial_sums(A.wpart, 1, A.n_slots, A.wsize, s1, out, st);
-  if (rc == SDEH_OK) rc = launch_partial_sums(A.epart, 1, A.n_tiles, (long long)n_steps * 64, s2, out + A.wsize, st);
-  if (rc == SDEH_OK && pr->ctrl_kind != SDEH_CTRL_CLIPPED)
-    rc = launch_partial_sums(A.gpart, 1, A.n_tiles, (long long)n_steps * A.gw, s2 + ((A.n_tiles + 31) / 32) * (long long)n_steps * 64,
-                             out + A.wsize + (long long)n_steps * 64, st);
+  SumJob job;
+  memset(&job, 0, sizeof(job));
+  job.s[0] = {A.wpart, s1, out, A.n_slots, A.wsize};
+  job.s[1] = {A.epart, s2, out + A.wsize, A.n_tiles, (long long)n_steps * 64};
+  job.n = 2;
+  if (pr->ctrl_kind != SDEH_CTRL_CLIPPED)
+    job.s[job.n++] = {A.gpart, s2 + ((A.n_tiles + 31) / 32) * (long long)n_steps * 64, out + A.wsize + (long long)n_steps * 64, A.n_tiles,
+                      (long long)n_steps * A.gw};
+  rc = launch_partial_sums_multi(job, st);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "ctrl_backward_fused: partial sums failed");
 }
 
@@ -1565,14 +1571,18 @@ int32_t sdeh_bridge_backward_fused(SdehPlan* plan, const SdehProblem* pr, const 
   if (rc != SDEH_OK) return fail(rc, "bridge_backward_fused: kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
   float* s1 = sums;
   float* s2 = s1 + ((A.n_slots + 31) / 32) * (long long)A.wsize;
-  rc = launch_partial_sums(A.wpart, 1, A.n_slots, A.wsize, s1, out, st);
-  if (rc == SDEH_OK) rc = launch_partial_sums(A.epart, 1, A.n_tiles, (long long)n_steps * 64, s2, out + A.wsize, st);
-  if (rc == SDEH_OK && pr->ctrl_kind != SDEH_CTRL_CLIPPED)
-    rc = launch_partial_sums(A.gpart, 1, A.n_tiles, (long long)n_steps * A.gw, s2 + ((A.n_tiles + 31) / 32) * (long long)n_steps * 64,
-                             out + A.wsize + (long long)n_steps * 64, st);
   float* o2 = out + n_o1;
-  if (rc == SDEH_OK) rc = launch_partial_sums(A.div_hid, 1, A.n_slots, 2 * 4096, sums2, o2, st);
-  if (rc == SDEH_OK) rc = launch_partial_sums(A.div_io, 1, (long long)A.n_slots * 4, 2 * dpp * 64, sums2 + ((A.n_slots + 31) / 32) * 2 * 4096, o2 + 2 * 4096, st);
+  SumJob job;
+  memset(&job, 0, sizeof(job));
+  job.s[0] = {A.wpart, s1, out, A.n_slots, A.wsize};
+  job.s[1] = {A.epart, s2, out + A.wsize, A.n_tiles, (long long)n_steps * 64};
+  job.s[2] = {A.div_hid, sums2, o2, A.n_slots, 2 * 4096};
+  job.s[3] = {A.div_io, sums2 + ((A.n_slots + 31) / 32) * 2 * 4096, o2 + 2 * 4096, (long long)A.n_slots * 4, 2 * dpp * 64};
+  job.n = 4;
+  if (pr->ctrl_kind != SDEH_CTRL_CLIPPED)
+    job.s[job.n++] = {A.gpart, s2 + ((A.n_tiles + 31) / 32) * (long long)n_steps * 64, out + A.wsize + (long long)n_steps * 64, A.n_tiles,
+                      (long long)n_steps * A.gw};
+  rc = launch_partial_sums_multi(job, st);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "bridge_backward_fused: partial sums failed");
 }
 
@@ -1782,6 +1792,19 @@ int32_t sdeh_loss_moment(const float* rnd, int64_t batch, float max_rnd, int32_t
   const int rc = launch_loss_moment(rnd, batch, max_rnd, log_variance != 0, reinterpret_cast<long long*>(n_filtered), scratch, (int)nb, out,
                                     grad_rnd, (hipStream_t)stream);
   return rc == SDEH_OK ? SDEH_OK : fail(rc, "loss_moment: launch failed");
+}
+
+int32_t sdeh_guard_restore(const uint64_t* table, int32_t n_tensors, const uint8_t* ok, int64_t* n_skipped, void* stream) {
+  if (table == nullptr || ok == nullptr || n_tensors < 1) return fail(SDEH_ERR_INVALID, "guard_restore: bad argument");
+  const int rc = launch_guard_restore(reinterpret_cast<const unsigned long long*>(table), n_tensors, ok, reinterpret_cast<long long*>(n_skipped),
+                                      (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "guard_restore: launch failed");
+}
+
+int32_t sdeh_guard_check(float* grads, int64_t n, const float* value, float max_loss, uint8_t* ok, void* stream) {
+  if (grads == nullptr || value == nullptr || ok == nullptr || n < 1) return fail(SDEH_ERR_INVALID, "guard_check: bad argument");
+  const int rc = launch_guard_check(grads, n, value, max_loss, ok, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "guard_check: launch failed");
 }
 
 int32_t sdeh_importance_weights(const float* rnd, int64_t batch, const float* log_weight_max, float* weights,

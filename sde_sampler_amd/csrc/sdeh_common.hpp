@@ -261,6 +261,10 @@ int bwdf_slots(long long batch, int n_steps, bool bptt);  // teams (partial reco
 int launch_bwdf16(const BwdfArgs& a, hipStream_t stream);
 int bwdf_tile(long long batch, bool bptt, int act);  // 16 or 32: trajectories per team of the launch that serves this problem
 int bwdf16_slots(long long batch);
+// one deterministic sum over chunks (launch_partial_sums_multi, sdeh_wgrad.hip): out[e] = sum_k in[k][e]; mid: ceil(n_chunks / 32) x width floats
+struct SumSeg { const float* in; float* mid; float* out; long long n_chunks, width; };
+struct SumJob { SumSeg s[5]; int first_block[6]; int n; };
+int launch_partial_sums_multi(SumJob job, hipStream_t stream);
 int bwdf16_waves(long long batch);  // wavefronts per 16-trajectory team (4; plan option SDEH_BWD_WAVES)
 // the same backward with trajectory-split teams (sdeh_bwdf2.hip): a wave owns 32 trajectories and all channels, no barrier in the chain
 int launch_bwdf2(const BwdfArgs& a, hipStream_t stream);

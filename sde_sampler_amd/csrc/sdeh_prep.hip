@@ -448,6 +448,50 @@ int launch_loss_moment(const float* rnd, long long n, float max_rnd, int lv, lon
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
+// Undo of a rejected optimisation step (utils/graphs.py: GraphedTrainStep(guard=True), the device-side form of the reference trainer's
+// `if loss_ok and grad_ok`, solver/base.py:409-432): every guarded tensor (parameters, optimizer moments, step counters) is put back from
+// its snapshot when *ok == 0 -- ONE launch over a table of (destination, snapshot, 32-bit words) instead of two framework kernels per tensor.
+__global__ __launch_bounds__(256) void guard_restore_kernel(const unsigned long long* __restrict__ table, const unsigned char* __restrict__ ok,
+                                                            long long* __restrict__ n_skipped) {
+  if (ok[0] != 0) return;
+  if (n_skipped != nullptr && blockIdx.x == 0 && threadIdx.x == 0) n_skipped[0] += 1;
+  unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(table[3 * blockIdx.x]);
+  const unsigned* __restrict__ src = reinterpret_cast<const unsigned*>(table[3 * blockIdx.x + 1]);
+  const unsigned long long n = table[3 * blockIdx.x + 2];
+  for (unsigned long long i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+}
+
+int launch_guard_restore(const unsigned long long* table, int n_tensors, const unsigned char* ok, long long* n_skipped, hipStream_t stream) {
+  hipLaunchKernelGGL(guard_restore_kernel, dim3(n_tensors), dim3(256), 0, stream, table, ok, n_skipped);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+// The decision itself: *ok = (loss finite, or |loss| <= max_loss when max_loss >= 0) and every gradient finite; a rejected step's gradients
+// are zeroed in place (the optimizer step still runs inside a captured graph and must not see NaN / Inf; its result is undone afterwards).
+// One workgroup: the control networks have 4e4 .. 4e5 parameters, a few microseconds of loads.
+__global__ __launch_bounds__(1024) void guard_check_kernel(float* __restrict__ g, long long n, const float* __restrict__ value, float max_loss,
+                                                           unsigned char* __restrict__ ok) {
+  __shared__ int bad_any;
+  if (threadIdx.x == 0) {
+    const float v = value[0];
+    bad_any = max_loss >= 0.0f ? !(fabsf(v) <= max_loss) : !(fabsf(v) <= 3.402823466e38f);
+  }
+  __syncthreads();
+  int bad = 0;
+  for (long long i = threadIdx.x; i < n; i += 1024) bad |= !(fabsf(g[i]) <= 3.402823466e38f);
+  if (bad) atomicOr(&bad_any, 1);
+  __syncthreads();
+  const int rejected = bad_any;
+  if (threadIdx.x == 0) ok[0] = rejected ? 0 : 1;
+  if (rejected)
+    for (long long i = threadIdx.x; i < n; i += 1024) g[i] = 0.0f;
+}
+
+int launch_guard_check(float* g, long long n, const float* value, float max_loss, unsigned char* ok, hipStream_t stream) {
+  hipLaunchKernelGGL(guard_check_kernel, dim3(1), dim3(1024), 0, stream, g, n, value, max_loss, ok);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
 __global__ __launch_bounds__(256) void weights_kernel(const float* __restrict__ rnd, long long n,
                                                       const float* __restrict__ mx, float* __restrict__ w) {
   const float m = mx[0];

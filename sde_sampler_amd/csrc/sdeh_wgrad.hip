@@ -191,6 +191,48 @@ int launch_partial_sums(const float* part, long long n_items, long long n_chunks
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 
+// Several such sums (the fused backward finishes with three to five: weight, time-embedding and scale partials) in ONE pair of launches
+// -- one launch when no sum has more than kSumGroup chunks (batches below ~1e3 trajectories, where a replayed optimisation step is a chain
+// of 5 us dispatches).  Same two-level order of additions as launch_partial_sums, sum by sum.
+__global__ __launch_bounds__(256) void multi_sum_kernel(SumJob job, int pass) {
+  int s = 0;
+  while (s + 1 < job.n && (int)blockIdx.x >= job.first_block[s + 1]) ++s;
+  const SumSeg seg = job.s[s];
+  const long long groups = (seg.n_chunks + kSumGroup - 1) / kSumGroup;
+  const long long e = (long long)((int)blockIdx.x - job.first_block[s]) * 256 + threadIdx.x;
+  const long long g = blockIdx.y;
+  if (e >= seg.width || g >= groups || (pass == 1 && groups == 1)) return;
+  const float* __restrict__ in = pass == 0 ? seg.in : seg.mid;
+  const long long n_in = pass == 0 ? seg.n_chunks : groups, group = pass == 0 ? kSumGroup : groups;
+  float* __restrict__ out = (pass == 1 || groups == 1) ? seg.out : seg.mid;
+  const long long k0 = g * group, k1 = k0 + group < n_in ? k0 + group : n_in;
+  const float* __restrict__ src = in + k0 * seg.width + e;
+  float acc0 = 0.0f, acc1 = 0.0f;
+  long long k = k0;
+  for (; k + 1 < k1; k += 2) {
+    acc0 += src[0];
+    acc1 += src[seg.width];
+    src += 2 * seg.width;
+  }
+  if (k < k1) acc0 += src[0];
+  out[(pass == 0 && groups > 1 ? g : 0) * seg.width + e] = acc0 + acc1;
+}
+
+int launch_partial_sums_multi(SumJob job, hipStream_t stream) {
+  long long max_groups = 1;
+  int blocks = 0;
+  for (int s = 0; s < job.n; ++s) {
+    job.first_block[s] = blocks;
+    blocks += (int)((job.s[s].width + 255) / 256);
+    const long long groups = (job.s[s].n_chunks + kSumGroup - 1) / kSumGroup;
+    max_groups = groups > max_groups ? groups : max_groups;
+  }
+  job.first_block[job.n] = blocks;
+  hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)blocks, (unsigned)max_groups), dim3(256), 0, stream, job, 0);
+  if (max_groups > 1) hipLaunchKernelGGL(multi_sum_kernel, dim3((unsigned)blocks, 1), dim3(256), 0, stream, job, 1);
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
 int launch_weight_grad(const float* D, int m, const float* Z, int c, long long N, int act, long long chunk, float* part_w,
                        float* part_b, hipStream_t stream) {
   const long long n_chunks = (N + chunk - 1) / chunk;

@@ -10,14 +10,14 @@ integrated by the oracle with the untrained control (the benchmark's state distr
 sampler visits).  Variants: plain product; product centred on the mixture mean; product centred per trajectory on its nearest mode (not a
 matrix product any more: the reference point differs per column).
 
-    python tools/mixture_mfma_numerics.py > profiles/r05_mixture_mfma_numerics.txt"""
+    python tests/perf/mixture_mfma_numerics.py > profiles/r05_mixture_mfma_numerics.txt"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import em_oracle as eo  # noqa: E402  (measurement infrastructure)
 from sde_sampler_amd import problems  # noqa: E402
 

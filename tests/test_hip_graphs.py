@@ -362,3 +362,50 @@ def test_graphed_eval_equals_eager_eval(name, weights):
     ge.counter.fill_(c)
     ref3 = prob.eval(x1, compute_weights=weights, return_traj=False)
     assert torch.equal(ref3.samples, res3.samples) and ref3.log_norm_const_preds == res3.log_norm_const_preds
+
+
+@pytest.mark.gpu
+def test_guard_restore_is_one_launch_that_only_acts_on_a_rejected_step():
+    """sdeh_guard_restore (include/sdeh.h): tensors come back from their snapshots bit for bit when ok == 0 and are left alone when ok == 1;
+    4- and 8-byte element types, sizes that are not a multiple of the block."""
+    from sde_sampler_amd import _lib as L
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    shapes = [(64, 64), (64,), (1,), (3, 50), (4097,)]
+    new = [torch.randn(s, device=dev) for s in shapes] + [torch.arange(7, device=dev, dtype=torch.int64), torch.randn(5, device=dev, dtype=torch.float64)]
+    old = [torch.randn_like(t) if t.is_floating_point() else t + 100 for t in new]
+    table = torch.tensor([[t.data_ptr(), s.data_ptr(), t.numel() * t.element_size() // 4] for t, s in zip(new, old)], dtype=torch.int64, device=dev)
+    kept = [t.clone() for t in new]
+    skipped = torch.zeros((), dtype=torch.int64, device=dev)
+    for ok_value in (True, False):
+        ok = torch.tensor([ok_value], device=dev)
+        L.check(L.load().sdeh_guard_restore(table.data_ptr(), len(new), ok.data_ptr(), skipped.data_ptr(), torch.cuda.current_stream(dev).cuda_stream))
+        torch.cuda.synchronize()
+        for t, k, s in zip(new, kept, old):
+            assert torch.equal(t, k if ok_value else s)
+        assert int(skipped) == (0 if ok_value else 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 1023, 50_000])
+def test_guard_check_decides_like_the_reference_trainer(n):
+    """sdeh_guard_check against solver/base.py:409-421 written in torch: loss finite (or within max_loss), every gradient finite; a rejected
+    step's gradients come back zeroed, an accepted step's untouched."""
+    from sde_sampler_amd import _lib as L
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(n)
+    lib, st = L.load(), torch.cuda.current_stream(dev).cuda_stream
+    for value, max_loss, poison in [(1.5, None, None), (float("nan"), None, None), (float("inf"), None, None), (1.5, None, "nan"),
+                                    (1.5, None, "inf"), (-7.0, 5.0, None), (-4.0, 5.0, None), (-4.0, 5.0, "-inf"), (float("nan"), 5.0, None)]:
+        g = torch.randn(n, device=dev)
+        if poison is not None:
+            g[n - 1 - (n // 3)] = float(poison)
+        v = torch.tensor([value], device=dev)
+        want = bool((torch.isfinite(v) if max_loss is None else v.abs() <= max_loss).all() and torch.isfinite(g).all())
+        kept = g.clone()
+        ok = torch.empty(1, dtype=torch.bool, device=dev)
+        L.check(lib.sdeh_guard_check(g.data_ptr(), n, v.data_ptr(), -1.0 if max_loss is None else max_loss, ok.data_ptr(), st))
+        assert bool(ok) == want, (value, max_loss, poison)
+        assert torch.equal(g, kept) if want else not g.any()

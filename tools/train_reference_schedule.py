@@ -54,7 +54,7 @@ def main():
     prob = problems.build(spec, device="cuda:0")
     torch.manual_seed(args.seed)
     params = list(prob.ctrl.parameters())
-    opt = torch.optim.Adam(params, lr=args.lr, capturable=True)
+    opt = torch.optim.Adam(params, lr=args.lr, capturable=True, fused=True)
 
     def loss_fn():
         x = prob.prior.sample((args.batch,))

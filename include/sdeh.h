@@ -94,6 +94,13 @@ enum {
  * distr/gauss.py:14-63).  Selects a cheaper evaluation (one table word per (k,d)); results are undefined if the
  * promise is false -- the Python binding checks the tensor once per (tensor, version) before setting it. */
 #define SDEH_DENS_FLAG_SHARED_SCALE 1
+/* GMM with SHARED_SCALE only (v6, round 5): the caller vouches that the component logits may be evaluated in PRODUCT form,
+ * c_k - sum_d mu_kd^2 / (2 sigma_d^2) + sum_d x_d mu_kd / sigma_d^2, whose fp32 rounding is that of sum_d |x_d mu_kd| / sigma_d^2 rather than
+ * of the squared distance -- harmless where no two components that can share a trajectory's weight lie close to each other (the
+ * Python binding's rule: engine._mixture_mm_ok).  Lets evaluation launches of 33 .. 40-component mixtures run both mixture
+ * contractions (reference: distr/gauss.py:123-140, distr/base.py:130-137) on the matrix pipe; the terminal log-density keeps the exact
+ * form.  Plan option SDEH_GMM_MM overrides ("0" never / "1" always). */
+#define SDEH_DENS_FLAG_MM_OK 2
 /* GMM with SHARED_SCALE only: the caller additionally promises that coordinates >= n are identical in every component
  * (loc[k,d] == loc[0,d] for d >= n), as in the reference's own high-dimensional mixtures, which pad a 2-d mixture with
  * zero means (distr/gauss.py:59-60).  Those coordinates factor out of the mixture as one Gaussian: they cancel in the
@@ -221,6 +228,7 @@ int32_t sdeh_plan_reserve(SdehPlan* plan, int64_t max_batch);
  *   SDEH_BWD_V1 / SDEH_BWD_V2 (channel- / trajectory-split fused backward)        SDEH_BWD_NO_VIO      SDEH_BWD_SCAN ("0" | "1": the
  *   scan form of back-propagation through time, d <= 4)        SDEH_BWD_ZREC ("0": the fused backward ignores the pre-activation record)
  *   SDEH_BRIDGE_TILES ("64" | "32g")   SDEH_BRIDGE_SPLIT ("1" | "4")   SDEH_WIDE_CT ("1" | "2")   SDEH_WIDE_SPLIT ("1" | "2" | "4" | "8")
+ *   SDEH_GMM_MM ("0": never / "1": always evaluate an eligible mixture's contractions on the matrix pipe; default: SDEH_DENS_FLAG_MM_OK decides)
  * Unknown names: SDEH_ERR_INVALID. */
 int32_t sdeh_plan_set_option(SdehPlan* plan, const char* name, const char* value);
 

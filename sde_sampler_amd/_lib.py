@@ -26,6 +26,7 @@ FLAG_INFERENCE_SDE, FLAG_INFERENCE_CTRL = 128, 256
 FLAG_DETACH_SCORE, FLAG_TARGET_SCORE_CONST = 512, 1024
 INT_LANGEVIN, INT_CONTROLLED = 0, 1
 DENS_FLAG_SHARED_SCALE = 1
+DENS_FLAG_MM_OK = 2  # the mixture's logits may be evaluated in product form (engine._mixture_mm_ok)
 
 STATUS = {0: "SDEH_OK", -1: "SDEH_ERR_INVALID", -2: "SDEH_ERR_UNSUPPORTED", -3: "SDEH_ERR_HIP", -4: "SDEH_ERR_CAPACITY"}
 
@@ -109,7 +110,7 @@ class SdehUnsupported(SdehError, NotImplementedError):
 # the launch path
 PLAN_OPTIONS = ("SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES",
                 "SDEH_BWD_TILE", "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BWD_ZREC", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT",
-                "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT")
+                "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT", "SDEH_GMM_MM")
 
 # every symbol include/sdeh.h declares, with its prototype
 PROTOTYPES = {

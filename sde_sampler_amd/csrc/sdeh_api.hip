@@ -118,12 +118,13 @@ static const Variant* pick_specialised(const Variant* cls, int loss, int ctrl, i
 }
 
 static int align4(int v) { return (v + 3) & ~3; }
+static constexpr int SDEH_MM_ROWS = 40;  // = SDEH_MM_K of sdeh_traj_ws.hpp: component rows of the matrix-pipe mixture's instruction stream
 
 // Workspace layout for one problem geometry.
 // gmm_nv: number of leading coordinates the shared-scale mixture tables cover (multiple of 4; 0 = all)
 // with_bwd: also pack the transposed weights the backward kernel needs (they join the LDS image)
 static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g, bool shared_scale = false,
-                            bool gmm_global = false, int gmm_nv = 0, bool with_bwd = false, bool with_tan = false) {
+                            bool gmm_global = false, int gmm_nv = 0, bool with_bwd = false, bool with_tan = false, bool gmm_mm = false) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.dp = dp; L.c = c; L.ot = c / 32; L.otd = row_tiles(dp); L.r_in = mregs(dp);
@@ -152,7 +153,18 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   // LDS budget of the wave-specialised kernel: image + four [coordinate][64] exchange buffers within 160 KiB
   const size_t xbuf_floats = with_bwd ? 0 : (size_t)4 * (mdim(mregs(dp) - 1, 1) + 1) * 64;
   L.gmm_lds = (k_max > 0 && !gmm_global && ((size_t)(o + gmm_floats) + xbuf_floats) * sizeof(float) <= 160 * 1024) ? 1 : 0;
-  if (L.gmm_lds && shared_scale) {
+  L.gmm_mm1 = L.gmm_mm2 = L.gmm_cc = -1;
+  // matrix-pipe mixture (shared scale, full tables): the A-operand images take the tables' place in the LDS image
+  const int mm1_floats = ((dp * (k_rows / 4) + 63) / 64) * 256, mm2_floats = ((k_rows * ((dp + 3) / 4) + 63) / 64) * 256;
+  const bool mm = gmm_mm && shared_scale && gmm_nv <= 0 && k_max > 0 && !gmm_global && !with_bwd &&
+                  ((size_t)(o + mm1_floats + mm2_floats + align4(k_rows)) + xbuf_floats) * sizeof(float) <= 160 * 1024;
+  if (mm) {
+    L.gmm_lds = 3;
+    L.gmm_row = rs;
+    L.gmm_mm1 = o; o += mm1_floats;
+    L.gmm_mm2 = o; o += mm2_floats;
+    L.gmm_cc = o; o += align4(k_rows);
+  } else if (L.gmm_lds && shared_scale) {
     L.gmm_lds = 2;
     L.gmm_row = rs;
     L.gmm_lg = o; o += k_rows * rs;
@@ -175,7 +187,13 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
     L.tan_in = o; o += dp * c;
     L.tan_out = o; o += dp * c;
   }
-  if (!L.gmm_lds) {
+  if (L.gmm_lds == 3) {  // the shared-scale tables next to the image (64-byte aligned: read as s_load_dwordx16)
+    o = (o + 15) & ~15;
+    L.gmm_lg = o; o += k_rows * rs;
+    L.gmm_sc = o; o += k_rows * rs;
+    L.gmm_vec = o; o += 4 * rs_full;
+    L.gmm_c = o; o += align4(k_rows);
+  } else if (!L.gmm_lds) {
     L.gmm_lg = o; o += k_rows * L.gmm_row;
     L.gmm_sc = o; o += k_rows * L.gmm_row;
     L.gmm_c = o; o += align4(k_rows);
@@ -265,7 +283,7 @@ struct OptScope {
 };
 static const char* const kOptNames[OPT_COUNT] = {
     "SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES", "SDEH_BWD_TILE",
-    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BWD_ZREC", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT"};
+    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BWD_ZREC", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT", "SDEH_GMM_MM"};
 static void opt_store(PlanOptions& o, int key, const char* value) {
   memset(o.v[key], 0, sizeof(o.v[key]));
   if (value != nullptr) strncpy(o.v[key], value, sizeof(o.v[key]) - 1);
@@ -809,9 +827,25 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   }
   if (pr->flags & SDEH_FLAG_INFERENCE_CTRL)
     return simulate_bridge(plan, pr, ts, n_steps, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, stream, ck, gp, div_noise);
-  const WsLayout& L = ck.L;
+  WsLayout L = ck.L;
   const Variant* v = ck.v;
   const bool force_legacy = plan_opt(OPT_LEGACY) != nullptr;
+  // The mixture's contractions on the matrix pipe (sdeh_traj_ws.hpp: gmm_mm): shared-scale mixtures of 33 .. 40 components with tables
+  // over all coordinates, where the caller vouches for the product form of the logits (SDEH_DENS_FLAG_MM_OK), on whole-wave launches
+  // (the pair / quad modes of small batches read the tables from LDS) of the evaluation kernel.  Plan option SDEH_GMM_MM: "0" never,
+  // "1" also without the caller's flag (measurements).
+  {
+    const char* mo = plan_opt(OPT_GMM_MM);
+    const bool want = mo != nullptr ? mo[0] == '1' : (pr->target.flags & SDEH_DENS_FLAG_MM_OK) != 0;
+    const bool compiled = (v->gmm == 2 || v->gmm < 0) && v->gnv <= 0 && v->dp > 8 && !v->pad;  // = gmm_mm_compiled<...>()
+    const bool training = zt_out != nullptr || nn_out != nullptr || sc_out != nullptr || tsc_out != nullptr || xs_cm != nullptr ||
+                          u_out != nullptr || zrec != nullptr;
+    if (want && compiled && !force_legacy && !training && pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 2 &&
+        ((ck.k + 7) & ~7) == SDEH_MM_ROWS && batch > 32 * 256 && plan_opt(OPT_WS_GROUPS) == nullptr && plan_opt(OPT_WS_QUAD) == nullptr) {
+      const WsLayout M = make_layout(v->dp, net.channels, net.n_hidden, n_steps, ck.k, ck.g, true, false, 0, false, false, true);
+      if (M.gmm_lds == 3 && (size_t)M.total <= plan->ws_floats) L = M;
+    }
+  }
 
   hipStream_t st = (hipStream_t)stream;
   PrepArgs P;
@@ -840,7 +874,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   // The wave-specialised kernel needs GMM tables in LDS; mixtures too large for that use the single-wave kernel
   // with scalar-load tables (also selectable with SDEH_LEGACY=1 for A/B measurements).
   const bool legacy = force_legacy || (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0);
-  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "%s<%s>", legacy ? "traj_legacy" : "traj_ws", v->name);
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "%s<%s%s>", legacy ? "traj_legacy" : "traj_ws", v->name, L.gmm_lds == 3 ? ",mm" : "");
   if (legacy) {
     rc = v->fn_legacy(A, st);
     if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);

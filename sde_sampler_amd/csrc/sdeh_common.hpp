@@ -69,6 +69,13 @@ struct WsLayout {
   int gmm_lg;     // [K][gmm_row/2][2]  (mu, 1/(2 sigma^2))
   int gmm_sc;     // [K][gmm_row/2][2]  (mu/sigma^2, 1/sigma^2)
   int gmm_c;      // [K]  log_softmax(log w)_k - sum_d (log sigma_kd + 0.5 log 2pi)
+  // gmm_lds == 3 (round 5, shared scale, full tables): the mixture's two contractions run on the matrix pipe inside the V wave
+  // (v_mfma_f32_4x4x1_16b_f32, gmm_mm in sdeh_traj_ws.hpp).  The LDS image holds their A-operand images instead of the tables
+  // above, which then live in the global part of the workspace (terminal log-density through the scalar cache):
+  //   gmm_mm1 [ceil(dp K4 / 64)][64 lanes][4]: register v = 4 q + e, lane 4 b + i: mu[4 g + i][d] / sigma_d^2, instruction n = 16 v + b = d K4 + g
+  //   gmm_mm2 [ceil(K D4 / 64)][64 lanes][4]:  register v, lane 4 b + i: mu[k][4 g + i] / sigma^2,     instruction n = 16 v + b = k D4 + g
+  //   gmm_cc  [K rows]: gmm_c[k] - sum_d mu_kd^2 / (2 sigma_d^2)   (-inf for padding rows);  K4 = rows / 4, D4 = ceil(dp / 4)
+  int gmm_mm1, gmm_mm2, gmm_cc;
   int dg[3];      // diag-gauss tables for target / prior / second: [dp][2] (mu, 1/sigma^2) then 1 float const
   int total;
   // Wide networks (sdeh_wide.hip: C in {128, 256}, d <= 256): no LDS image; the A operands stream from this workspace (L2), packed
@@ -335,7 +342,7 @@ struct SinkArgs {
 // environment (sdeh_plan_create copies it once).
 enum OptKey {
   OPT_LEGACY, OPT_GENERIC_ONLY, OPT_WS_GROUPS, OPT_WS_QUAD, OPT_WS_VOUT, OPT_WS_BARRIER, OPT_BWD_PLANES, OPT_BWD_TILE, OPT_BWD_WAVES,
-  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BWD_SCAN, OPT_BWD_ZREC, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_COUNT
+  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BWD_SCAN, OPT_BWD_ZREC, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_GMM_MM, OPT_COUNT
 };
 struct PlanOptions {
   char v[OPT_COUNT][8];

@@ -289,12 +289,289 @@ __device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const
   return logp;
 }
 
-template <int DP, int NV>
+// ---------------------------------------------------------------------------------------------------------
+// The same online softmax with the tables streamed through the SCALAR cache (round 5).  A table entry is the same for all 64
+// trajectories of the wave: as broadcast ds_read_b128 it costs the LDS four cycles and 64 x 16 bytes of register-file writes for 16
+// useful bytes, per V wave -- with four V waves per CU the table stream of a dense 40-component, 50-dimensional mixture (1040 reads
+// per wave and step) holds the LDS longer than the vector work it feeds (tools/ubench/smem_stream.hip).  Here the rows arrive as
+// s_load_dwordx16 (eight coordinate pairs per instruction) and enter v_pk_add_f32 / v_pk_fma_f32 directly as SGPR-pair operands: no
+// vector registers, no LDS cycles.  The tables are read where the prep kernel wrote them (the global copy of the LDS image), in the
+// same layout, and every floating-point operation is the one gmm_online performs, in the same order: results are bit-identical.
+//
+// Stream: a chunk of 8 rows is NQ batches of two s_load_dwordx16 (16 SGPR pairs); batch n + 1 is requested before the vector work
+// on batch n (scalar loads return out of order -- the only wait there is is lgkmcnt(0), placed in front of the request), the logit
+// stream of a chunk is followed by its score stream and that by the next chunk's logit stream without a bubble.
+typedef unsigned long long u64x8 __attribute__((ext_vector_type(8)));  // eight SGPR pairs = one s_load_dwordx16
+typedef u64x8 u64x8a __attribute__((aligned(8)));
+typedef const u64x8a __attribute__((address_space(4))) * ctab16;
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// hipcc unpacks packed fp32 operations with a scalar-register operand into two scalar-operand v_sub / v_fma: written in assembly
+__device__ __forceinline__ f2 pk_sub_s(f2 a, unsigned long long s) {  // a - s
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "s"(s));
+  return r;
+}
+__device__ __forceinline__ void pk_fma_acc_s(f2& acc, f2 a, unsigned long long s) {  // acc += a * s
+  asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(s));
+}
+__device__ __forceinline__ void s_wait_lgkm0() { __builtin_amdgcn_s_waitcnt(0xC07F); }  // lgkmcnt(0), other counters untouched
+
+template <int DP, bool SHARED, bool SCORE, int NV>
+__device__ __forceinline__ float gmm_online_s(const float* __restrict__ ws, const WsLayout& L, const float (&x)[DP],
+                                              float (&score)[DP]) {
+  static_assert(NV == DP || (SHARED && NV % 4 == 0 && NV < DP), "NV: DP, or a multiple of 4 below DP (shared scale)");
+  constexpr int CH = 8;
+  constexpr int NP = (NV + 1) / 2;                           // coordinate pairs the tables cover
+  constexpr int NQ = SHARED ? (NV + 3) / 4 : (DP + 1) / 2;  // float4 per table row
+  constexpr int PR = 2 * NQ;                                 // SGPR pairs per table row
+  constexpr int NB = NQ;                                     // batches of 16 SGPR pairs per chunk of 8 rows
+  constexpr int NA = (NQ + 1) / 2;                           // (gmm_online's split of a row, kept for its accumulator order)
+  constexpr int RSF = 4 * ((DP + 3) / 4);
+  constexpr int NS = SCORE ? 2 : 1;                          // streams per chunk
+  const int KR = L.gmm_rows;  // multiple of CH
+  cfp vec = as_const(ws + L.gmm_vec);
+  cfp pc = as_const(ws + L.gmm_c);
+  ctab16 glg = (ctab16)(unsigned long long)(ws + L.gmm_lg);
+  ctab16 gsc = (ctab16)(unsigned long long)(ws + L.gmm_sc);
+  f2 y[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const float x0 = x[2 * p], x1 = 2 * p + 1 < DP ? x[2 * p + 1] : 0.0f;
+    y[p] = SHARED ? f2{x0 * vec[2 * p], x1 * vec[2 * p + 1]} : f2{x0, x1};
+  }
+  float m = -INFINITY, z = 0.0f;
+  f2 P[NP], Q[SHARED ? 1 : NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) { P[p] = splat(0.0f); if (!SHARED) Q[p] = splat(0.0f); }
+  u64x8 buf[2][2];
+  buf[0][0] = glg[0];
+  buf[0][1] = glg[1];
+  for (int cp = 0; cp < KR; cp += CH) {
+    ctab16 lg = glg + (cp / CH) * (2 * NB), sc = gsc + (cp / CH) * (2 * NB);
+    ctab16 lg_next = glg + (cp + CH < KR ? cp / CH + 1 : 0) * (2 * NB);  // (the last chunk re-requests the first: never used)
+    float l[CH];
+    {
+      cfp c = pc + cp;
+#pragma unroll
+      for (int k = 0; k < CH; ++k) l[k] = c[k];
+    }
+    f2 acc0 = splat(0.0f), acc1 = splat(0.0f), tt = splat(0.0f);
+    // ---- logit stream
+    static_for<NB>([&](auto Bc) {
+      constexpr int b = decltype(Bc)::value;
+      constexpr int cur = b & 1, nxt = cur ^ 1;
+      s_wait_lgkm0();  // batch b has landed
+      SDEH_FENCE();
+      if constexpr (b + 1 < NB) { buf[nxt][0] = lg[2 * (b + 1)]; buf[nxt][1] = lg[2 * (b + 1) + 1]; }
+      else if constexpr (SCORE) { buf[nxt][0] = sc[0]; buf[nxt][1] = sc[1]; }
+      else { buf[nxt][0] = lg_next[0]; buf[nxt][1] = lg_next[1]; }
+      SDEH_FENCE();
+      static_for<16>([&](auto Gc) {
+        constexpr int g = 16 * b + decltype(Gc)::value;  // SGPR pair within the chunk
+        constexpr int k = g / PR, s = g % PR;
+        const unsigned long long q = buf[cur][decltype(Gc)::value / 8][decltype(Gc)::value % 8];
+        if constexpr (SHARED) {
+          if constexpr (s < NP) {
+            const f2 t = pk_sub_s(y[s], q);
+            if constexpr (s & 1) acc1 = pk_fma(t, t, acc1);
+            else acc0 = pk_fma(t, t, acc0);
+          }
+        } else {
+          constexpr int j = s / 2, jl = j < NA ? j : j - NA;
+          if constexpr ((s & 1) == 0) {
+            const f2 t = pk_sub_s(y[j], q);
+            tt = t * t;
+          } else {
+            if constexpr (jl & 1) pk_fma_acc_s(acc1, tt, q);
+            else pk_fma_acc_s(acc0, tt, q);
+          }
+        }
+        if constexpr (s == PR - 1) {  // row complete
+          const f2 a = acc0 + acc1;
+          l[k] -= a.x + a.y;
+          acc0 = acc1 = splat(0.0f);
+        }
+      });
+      SDEH_FENCE();
+    });
+    float cm = l[0];
+#pragma unroll
+    for (int k = 1; k < CH; ++k) cm = fmaxf(cm, l[k]);
+    const float mn = fmaxf(m, cm);
+    const float resc = __expf(m - mn);  // exp(-inf) = 0 on the first chunk
+    m = mn;
+    float e[CH];
+    z *= resc;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) { e[k] = __expf(l[k] - m); z += e[k]; }
+    if constexpr (SCORE) {
+      const f2 r2 = splat(resc);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { P[p] *= r2; if (!SHARED) Q[p] *= r2; }
+      static_for<NB>([&](auto Bc) {
+        constexpr int b = decltype(Bc)::value;
+        constexpr int cur = (NB + b) & 1, nxt = cur ^ 1;
+        s_wait_lgkm0();
+        SDEH_FENCE();
+        if constexpr (b + 1 < NB) { buf[nxt][0] = sc[2 * (b + 1)]; buf[nxt][1] = sc[2 * (b + 1) + 1]; }
+        else { buf[nxt][0] = lg_next[0]; buf[nxt][1] = lg_next[1]; }
+        SDEH_FENCE();
+        static_for<16>([&](auto Gc) {
+          constexpr int g = 16 * b + decltype(Gc)::value;
+          constexpr int k = g / PR, s = g % PR;
+          const unsigned long long q = buf[cur][decltype(Gc)::value / 8][decltype(Gc)::value % 8];
+          const f2 e2 = splat(e[k]);
+          if constexpr (SHARED) {
+            if constexpr (s < NP) pk_fma_acc_s(P[s], e2, q);
+          } else {
+            if constexpr ((s & 1) == 0) pk_fma_acc_s(P[s / 2], e2, q);
+            else pk_fma_acc_s(Q[s / 2], e2, q);
+          }
+        });
+        SDEH_FENCE();
+      });
+    }
+    if constexpr ((NS * NB) & 1) {  // an odd number of batches per chunk: the request for the next chunk went to the other buffer
+      buf[0][0] = buf[1][0];
+      buf[0][1] = buf[1][1];
+    }
+  }
+  s_wait_lgkm0();  // the last (unused) request
+  if constexpr (SCORE) {
+    const float iz = 1.0f / z;
+#pragma unroll
+    for (int d = 0; d < DP; ++d) {
+      if constexpr (SHARED) {
+        if (d < NV) score[d] = fmaf((d & 1) ? P[d / 2].y : P[d / 2].x, iz, -x[d] * vec[RSF + d]);
+        else score[d] = fmaf(-x[d], vec[RSF + d], vec[3 * RSF + d]);
+      } else {
+        const float Pd = (d & 1) ? P[d / 2].y : P[d / 2].x, Qd = (d & 1) ? Q[d / 2].y : Q[d / 2].x;
+        score[d] = (Pd - x[d] * Qd) * iz;
+      }
+    }
+  }
+  float logp = m + __logf(z);
+  if constexpr (SHARED && NV < DP) {
+    float rest = 0.0f;
+#pragma unroll
+    for (int d = NV; d < DP; ++d) {
+      const float t = fmaf(x[d], vec[d], -vec[2 * RSF + d]);
+      rest = fmaf(t, t, rest);
+    }
+    logp -= rest;
+  }
+  return logp;
+}
+
+// tables through the scalar cache: dense tables only (where the table stream, not the exchange, bounds the V wave), whole waves only
+#ifndef SDEH_GMM_SGPR
+#define SDEH_GMM_SGPR 1
+#endif
+template <int DP, bool SHARED, int NV>
+constexpr bool gmm_use_sgpr() { return SDEH_GMM_SGPR != 0 && (SHARED ? NV : DP) > 8; }
+
+// ---------------------------------------------------------------------------------------------------------
+// The mixture's two contractions on the MATRIX pipe, inside the V wave (round 5; WsLayout::gmm_lds == 3, shared scale, full tables).
+//
+// v_mfma_f32_4x4x1_16b_f32 is 16 independent 4 x 4 x 1 outer products: B is one value per lane (block b, column j = lane 4 b + j)
+// and D[i][j] lands in register i of the SAME lane.  With B = x_d of the lane's own trajectory, register i accumulates
+// sum_d A[i][d] x_d: four components' logits of the lane's own trajectory -- the T layout on both sides, no exchange, no layout
+// change.  A is wave-uniform table data: CBSZ = 4 broadcasts the A values of block ABID to all 16 blocks, so one operand register
+// carries the rows of 16 different instructions and a table is read from LDS once per step (8 + 9 ds_read_b128), not once per lane.
+//   logits:  l_k = cc_k + sum_d x_d mu_kd / sigma_d^2      (cc_k = c_k - sum_d mu_kd^2 / (2 sigma_d^2); the term -sum_d x_d^2 / (2 sigma_d^2)
+//            is common to all components and cancels in the responsibilities)            500 instructions for K = 40, d = 50
+//   score:   P_d = sum_k e_k mu_kd / sigma_d^2,  score_d = P_d / z - x_d / sigma_d^2      520 instructions
+// 8 cycles each on the fp32 matrix rate (64 FLOP per cycle and SIMD) against ~3100 packed vector instructions of ~5.4 cycles
+// (tools/ubench/mfma4x4.hip, valu_dep.hip).  The logits are a PRODUCT form: they carry the rounding of sum |x_d mu_kd| / sigma^2, not of
+// the squared distance -- the binding only selects this path where that cannot move a responsibility (SDEH_DENS_FLAG_MM_OK,
+// engine._mixture_mm_ok: well-separated components); the terminal log-density stays on the exact form (gmm_online_s).
+// The component count is a compile-time constant of the instruction stream: mixtures of 33 .. 40 components (SDEH_MM_K rows).
+#ifndef SDEH_MM_K
+#define SDEH_MM_K 40
+#endif
+typedef float mm4 __attribute__((ext_vector_type(4)));
+template <int DP>
+__device__ __forceinline__ void gmm_mm(const float* __restrict__ ws, const float* __restrict__ lds, const WsLayout& L,
+                                       const float (&x)[DP], float (&score)[DP]) {
+  constexpr int K4 = SDEH_MM_K / 4, D4 = (DP + 3) / 4;
+  constexpr int N1 = DP * K4, N2 = SDEH_MM_K * D4;          // instructions per contraction
+  constexpr int Q1 = (N1 + 63) / 64, Q2 = (N2 + 63) / 64;   // ds_read_b128 per contraction (64 instructions each)
+  constexpr int RSF = 4 * ((DP + 3) / 4);
+  const int lane = threadIdx.x & 63;
+  const mm4* __restrict__ a1 = reinterpret_cast<const mm4*>(lds + L.gmm_mm1) + lane;
+  const mm4* __restrict__ a2 = reinterpret_cast<const mm4*>(lds + L.gmm_mm2) + lane;
+  cfp cc = as_const(ws + L.gmm_cc);
+  cfp vec = as_const(ws + L.gmm_vec);
+  mm4 lg[K4];
+#pragma unroll
+  for (int g = 0; g < K4; ++g) lg[g] = mm4{cc[4 * g], cc[4 * g + 1], cc[4 * g + 2], cc[4 * g + 3]};
+  static_for<Q1>([&](auto Qc) {
+    constexpr int q = decltype(Qc)::value;
+    const mm4 a = a1[q * 64];
+    static_for<64>([&](auto Nc) {
+      constexpr int n = 64 * q + decltype(Nc)::value;
+      if constexpr (n < N1) {
+        constexpr int d = n / K4, g = n % K4, e = (n / 16) % 4, b = n % 16;
+        lg[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], x[d], lg[g], 4, b, 0);
+      }
+    });
+  });
+  float m = lg[0][0];
+#pragma unroll
+  for (int g = 0; g < K4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m = fmaxf(m, lg[g][i]);
+  float z = 0.0f;
+#pragma unroll
+  for (int g = 0; g < K4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float e = __expf(lg[g][i] - m);  // padding rows: exp(-inf) = 0
+      lg[g][i] = e;
+      z += e;
+    }
+  mm4 P[D4];
+#pragma unroll
+  for (int g = 0; g < D4; ++g) P[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
+  static_for<Q2>([&](auto Qc) {
+    constexpr int q = decltype(Qc)::value;
+    const mm4 a = a2[q * 64];
+    static_for<64>([&](auto Nc) {
+      constexpr int n = 64 * q + decltype(Nc)::value;
+      if constexpr (n < N2) {
+        constexpr int k = n / D4, g = n % D4, e = (n / 16) % 4, b = n % 16;
+        P[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], lg[k / 4][k % 4], P[g], 4, b, 0);
+      }
+    });
+  });
+  const float iz = 1.0f / z;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) score[d] = fmaf(P[d / 4][d % 4], iz, -x[d] * vec[RSF + d]);
+}
+// which instantiations carry the matrix-pipe mixture (the launcher asks the same question: ws_mm_compiled)
+template <int DP, bool PAD, int GMMV, int GNV>
+constexpr bool gmm_mm_compiled() { return (GMMV == 2 || GMMV < 0) && GNV <= 0 && DP > 8 && !PAD; }
+
+template <int DP, int NV, bool SG = false>
 __device__ __forceinline__ float ws_target_logp(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
                                                 int gmmv, int dreal, const float (&x)[DP]) {
   float dummy[DP];
   switch (D.kind) {
     case SDEH_DENS_GMM:
+      if constexpr (SG) {
+        if (gmmv == 2 || L.gmm_lds == 3) {  // (gmm_lds == 3: no tables in LDS -- only instantiations with this path are launched)
+          if constexpr (gmm_use_sgpr<DP, true, NV>()) return gmm_online_s<DP, true, false, NV>(ws, L, x, dummy) + D.lnc;
+        } else {
+          if constexpr (gmm_use_sgpr<DP, false, DP>()) return gmm_online_s<DP, false, false, DP>(ws, L, x, dummy) + D.lnc;
+        }
+      }
       return (gmmv == 2 ? gmm_online<DP, true, false, NV>(lds, L, D.n_comp, x, dummy)
                         : gmm_online<DP, false, false, DP>(lds, L, D.n_comp, x, dummy)) + D.lnc;
     case SDEH_DENS_DIAG_GAUSS: return dgauss_logp<DP>(ws + L.dg[0], x) + D.lnc;
@@ -304,11 +581,21 @@ __device__ __forceinline__ float ws_target_logp(const DensArgs& D, const float* 
   }
 }
 
-template <int DP, int NV, bool KS = false>
+template <int DP, int NV, bool KS = false, bool SG = false, bool MM = false>
 __device__ __forceinline__ void ws_target_score(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
                                                 int gmmv, int dreal, const float (&x)[DP], float (&s)[DP]) {
   switch (D.kind) {
     case SDEH_DENS_GMM:
+      if constexpr (MM && SG && !KS && NV == DP) {
+        if (L.gmm_lds == 3) { gmm_mm<DP>(ws, lds, L, x, s); break; }
+      }
+      if constexpr (SG && !KS) {
+        if (gmmv == 2 || L.gmm_lds == 3) {
+          if constexpr (gmm_use_sgpr<DP, true, NV>()) { (void)gmm_online_s<DP, true, true, NV>(ws, L, x, s); break; }
+        } else {
+          if constexpr (gmm_use_sgpr<DP, false, DP>()) { (void)gmm_online_s<DP, false, true, DP>(ws, L, x, s); break; }
+        }
+      }
       if (gmmv == 2) (void)gmm_online<DP, true, true, NV, KS>(lds, L, D.n_comp, x, s);
       else (void)gmm_online<DP, false, true, DP, KS>(lds, L, D.n_comp, x, s);
       break;
@@ -1053,7 +1340,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       float tsc[DP], psc[DP];
       if (need_t) {  // pair / quad mode: mixture components split over the two lane halves (gmm_online KS)
         if (pair) ws_target_score<DP, (GNV > 0 ? GNV : DP), true>(tgt, ws, lds, L, gmmv, d, x, tsc);
-        else ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, tsc);
+        else ws_target_score<DP, (GNV > 0 ? GNV : DP), false, true, gmm_mm_compiled<DP, PAD, GMMV, GNV>()>(tgt, ws, lds, L, gmmv, d, x, tsc);
       }
       if (ctrl_kind == SDEH_CTRL_LERP || ctrl_kind == SDEH_CTRL_LERP_PRIOR) dgauss_score<DP>(ws + L.dg[1], x, psc);
       const float w = cf[CF_W];
@@ -1296,7 +1583,7 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
 
   // ---- terminal costs (oc.py:225, 337, 449-450) ----------------------------------------------------------
   if (flags & SDEH_FLAG_TERMINAL_SECOND) rnd += dgauss_logp<DP>(ws + L.dg[2], x);
-  if (flags & SDEH_FLAG_TERMINAL_TARGET) rnd -= clipf(ws_target_logp<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x), A.clip_target);
+  if (flags & SDEH_FLAG_TERMINAL_TARGET) rnd -= clipf(ws_target_logp<DP, (GNV > 0 ? GNV : DP), true>(tgt, ws, lds, L, gmmv, d, x), A.clip_target);
   if (live) {
     rnd_out[row] = rnd;
 #pragma unroll
@@ -1306,10 +1593,10 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
   if constexpr (PLANES >= 2) {  // d(terminal target cost)/dx_T, negated: the clamp's mask times target.score(x_T)  (oc.py:225)
     if (A.tsc_out != nullptr && (flags & SDEH_FLAG_TERMINAL_TARGET)) {
       float st[DP];
-      ws_target_score<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x, st);
+      ws_target_score<DP, (GNV > 0 ? GNV : DP), false, true>(tgt, ws, lds, L, gmmv, d, x, st);
       float keep = 1.0f;
       if (A.clip_target < 3.0e38f)
-        keep = fabsf(ws_target_logp<DP, (GNV > 0 ? GNV : DP)>(tgt, ws, lds, L, gmmv, d, x)) <= A.clip_target ? 1.0f : 0.0f;
+        keep = fabsf(ws_target_logp<DP, (GNV > 0 ? GNV : DP), true>(tgt, ws, lds, L, gmmv, d, x)) <= A.clip_target ? 1.0f : 0.0f;
       if (live) {
 #pragma unroll
         for (int j = 0; j < DP; ++j)
@@ -1392,6 +1679,8 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
     groups = 1;
     half = 3;
   }
+  // matrix-pipe mixture layout (no tables in LDS): whole-wave modes of the instantiations that carry gmm_mm only (the API checks the same)
+  if (a.lay.gmm_lds == 3 && (half >= 2 || !gmm_mm_compiled<DP, PAD, GMMV, GNV>())) return SDEH_ERR_UNSUPPORTED;
   if (half == 2 && ws_pair_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_pair_lds_bytes<DP>(a.lay);
   if (half == 3 && ws_quad_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_quad_lds_bytes<DP>(a.lay);
   TrajArgs b = a;

@@ -259,6 +259,45 @@ def test_mixture_table_variants_vs_oracle(case):
     _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
 
 
+@pytest.mark.parametrize("mode", ["matrix_pipe", "scalar_cache_tables"])
+def test_dense_mixture_whole_wave_paths_vs_oracle(mode, monkeypatch):
+    """A well-separated 40-component mixture with means varying in all 50 coordinates at a batch that launches whole waves
+    (B > 8192): by default the binding vouches for the product form (engine._mixture_mm_ok) and both mixture contractions run on the
+    matrix pipe inside the V wave (v_mfma_f32_4x4x1, kernel name "...,mm"); with the plan option SDEH_GMM_MM=0 the exact form streams
+    its tables through the scalar cache (gmm_online_s: bit-identical to the LDS tables of the small-batch modes).  Both against the
+    oracle on identical noise, at the bars of every other mixture test."""
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import engine, problems
+
+    if mode == "scalar_cache_tables":
+        monkeypatch.setenv("SDEH_GMM_MM", "0")
+    spec = problems.baseline_spec("gmm50_dense_shared")
+    spec["grid"]["steps"] = 10
+    prob = problems.build(spec)
+    assert engine._mixture_mm_ok(prob.target.loc, prob.target.scale)
+    params = {n: v.detach().clone() for n, v in prob.ctrl.state_dict().items()}
+    tt = dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
+    B = 8192 + 320
+    torch.manual_seed(21)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(10, B, 50)
+    ref = eo.Problem(spec, params, tt).eval(prob.ts.clone(), x0.clone(), noise, compute_weights=True)
+    prob.to("cuda:0")
+    out = prob.eval(x0.cuda(), compute_weights=True, noise=noise.cuda())
+    kernel = prob.loss.engine.last_kernel_name()
+    assert kernel == ("traj_ws<50_0_pis_gmm,mm>" if mode == "matrix_pipe" else "traj_ws<50_0_pis_gmm>"), kernel
+    _row_check("x_T", out.samples.cpu().numpy(), ref["samples"].numpy())
+    _est_check("lb_ito", out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"])
+    _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
+    from tests.helpers import measured
+    from tests.test_hip_contract import est_tol
+    err = (out.samples.cpu() - ref["samples"]).abs()
+    measured(f"dense_mixture[{mode}]/x_T_max", float(err.max()), ROW_MAX)
+    measured(f"dense_mixture[{mode}]/x_T_median", float(err.median()), ROW_MEDIAN)
+    measured(f"dense_mixture[{mode}]/logZ_is", abs(out.log_norm_const_preds["log_norm_const_is"] - ref["log_norm_const_is"]),
+             est_tol(ref["log_norm_const_is"]))
+
+
 @pytest.mark.parametrize("d", [10, 20, 32, 33, 50, 64])
 @pytest.mark.parametrize("shape", ["pis", "dis", "dds"])
 def test_padded_reference_mixture_in_other_dimensions_vs_oracle(d, shape):

@@ -373,3 +373,27 @@ def test_split_bridge_path_selection(monkeypatch):
     monkeypatch.delenv("SDEH_BRIDGE_SEQ")
     monkeypatch.setenv("SDEH_BWD_PLANES", "1")
     assert not ok(prob, lv) and not ok(prob, kl)
+
+
+def test_product_form_guard_of_the_matrix_pipe_mixture():
+    """engine._mixture_mm_ok (SDEH_DENS_FLAG_MM_OK): product-form logits are admitted for mixtures near the origin (absolute rounding
+    below 1e-5) and for well-separated ones (no two components within 12 scaled units; rounding at the decision boundaries within 16 x
+    the squared-distance form's own), and refused where two nearby components sit far from the origin."""
+    from sde_sampler_amd import engine, problems
+
+    dense = problems.build(problems.baseline_spec("gmm50_dense_shared")).target
+    assert engine._mixture_mm_ok(dense.loc, dense.scale)
+    gen = torch.Generator().manual_seed(0)
+    near = (torch.rand((40, 50), generator=gen) - 0.5) * 0.5  # |m| ~ 1: rule (a)
+    assert engine._mixture_mm_ok(near, torch.ones(40, 50))
+    far_pair = (torch.rand((40, 50), generator=gen) - 0.5) * 80.0
+    far_pair[1] = far_pair[0] + 0.5  # two components half a sigma apart, ~160 sigma from the origin
+    assert not engine._mixture_mm_ok(far_pair, torch.ones(40, 50))
+    # the flag reaches the problem description only for shared-scale mixtures of 33 .. 40 components with dense tables
+    fab = problems.build(problems.baseline_spec("gmm50_pis_headline")).target
+    out = engine.L.SdehDensity()
+    engine._fill_density(fab, out, engine._Keep(), torch.device("cpu"), "target")
+    assert out.flags & engine.L.DENS_FLAG_SHARED_SCALE and not out.flags & engine.L.DENS_FLAG_MM_OK
+    out = engine.L.SdehDensity()
+    engine._fill_density(dense, out, engine._Keep(), torch.device("cpu"), "target")
+    assert out.flags & engine.L.DENS_FLAG_MM_OK

@@ -94,8 +94,8 @@ enum {
  * distr/gauss.py:14-63).  Selects a cheaper evaluation (one table word per (k,d)); results are undefined if the
  * promise is false -- the Python binding checks the tensor once per (tensor, version) before setting it. */
 #define SDEH_DENS_FLAG_SHARED_SCALE 1
-/* GMM with SHARED_SCALE only (v6, round 5): the caller vouches that the component logits may be evaluated in PRODUCT form,
- * c_k - sum_d mu_kd^2 / (2 sigma_d^2) + sum_d x_d mu_kd / sigma_d^2, whose fp32 rounding is that of sum_d |x_d mu_kd| / sigma_d^2 rather than
+/* GMM (v6, round 5): the caller vouches that the component logits may be evaluated in PRODUCT form (shared scale:
+ * c_k - sum_d mu_kd^2 / (2 sigma_d^2) + sum_d x_d mu_kd / sigma_d^2; per-component scales: additionally - sum_d x_d^2 / (2 sigma_kd^2)), whose fp32 rounding is that of sum_d |x_d mu_kd| / sigma_d^2 rather than
  * of the squared distance -- harmless where no two components that can share a trajectory's weight lie close to each other (the
  * Python binding's rule: engine._mixture_mm_ok).  Lets evaluation launches of 33 .. 40-component mixtures run both mixture
  * contractions (reference: distr/gauss.py:123-140, distr/base.py:130-137) on the matrix pipe; the terminal log-density keeps the exact

@@ -154,13 +154,15 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   const size_t xbuf_floats = with_bwd ? 0 : (size_t)4 * (mdim(mregs(dp) - 1, 1) + 1) * 64;
   L.gmm_lds = (k_max > 0 && !gmm_global && ((size_t)(o + gmm_floats) + xbuf_floats) * sizeof(float) <= 160 * 1024) ? 1 : 0;
   L.gmm_mm1 = L.gmm_mm2 = L.gmm_cc = -1;
-  // matrix-pipe mixture (shared scale, full tables): the A-operand images take the tables' place in the LDS image
-  const int mm1_floats = ((dp * (k_rows / 4) + 63) / 64) * 256, mm2_floats = ((k_rows * ((dp + 3) / 4) + 63) / 64) * 256;
-  const bool mm = gmm_mm && shared_scale && gmm_nv <= 0 && k_max > 0 && !gmm_global && !with_bwd &&
+  // matrix-pipe mixture (full tables; shared scale: form 3, per-component scales: form 4 with twice the instructions): the A-operand
+  // images take the tables' place in the LDS image
+  const int mm_f = shared_scale ? 1 : 2;
+  const int mm1_floats = ((mm_f * dp * (k_rows / 4) + 63) / 64) * 256, mm2_floats = ((mm_f * k_rows * ((dp + 3) / 4) + 63) / 64) * 256;
+  const bool mm = gmm_mm && gmm_nv <= 0 && k_max > 0 && !gmm_global && !with_bwd &&
                   ((size_t)(o + mm1_floats + mm2_floats + align4(k_rows)) + xbuf_floats) * sizeof(float) <= 160 * 1024;
   if (mm) {
-    L.gmm_lds = 3;
-    L.gmm_row = rs;
+    L.gmm_lds = shared_scale ? 3 : 4;
+    if (shared_scale) L.gmm_row = rs;
     L.gmm_mm1 = o; o += mm1_floats;
     L.gmm_mm2 = o; o += mm2_floats;
     L.gmm_cc = o; o += align4(k_rows);
@@ -192,6 +194,11 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
     L.gmm_lg = o; o += k_rows * rs;
     L.gmm_sc = o; o += k_rows * rs;
     L.gmm_vec = o; o += 4 * rs_full;
+    L.gmm_c = o; o += align4(k_rows);
+  } else if (L.gmm_lds == 4) {  // the general tables
+    o = (o + 15) & ~15;
+    L.gmm_lg = o; o += k_rows * L.gmm_row;
+    L.gmm_sc = o; o += k_rows * L.gmm_row;
     L.gmm_c = o; o += align4(k_rows);
   } else if (!L.gmm_lds) {
     L.gmm_lg = o; o += k_rows * L.gmm_row;
@@ -840,10 +847,11 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     const bool compiled = (v->gmm == 2 || v->gmm < 0) && v->gnv <= 0 && v->dp > 8 && !v->pad;  // = gmm_mm_compiled<...>()
     const bool training = zt_out != nullptr || nn_out != nullptr || sc_out != nullptr || tsc_out != nullptr || xs_cm != nullptr ||
                           u_out != nullptr || zrec != nullptr;
-    if (want && compiled && !force_legacy && !training && pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 2 &&
+    const bool general = L.gmm_lds == 1 && v->gmm < 0;  // per-component scales: the run-time switched variants carry that form
+    if (want && compiled && !force_legacy && !training && pr->target.kind == SDEH_DENS_GMM && (L.gmm_lds == 2 || general) &&
         ((ck.k + 7) & ~7) == SDEH_MM_ROWS && batch > 32 * 256 && plan_opt(OPT_WS_GROUPS) == nullptr && plan_opt(OPT_WS_QUAD) == nullptr) {
-      const WsLayout M = make_layout(v->dp, net.channels, net.n_hidden, n_steps, ck.k, ck.g, true, false, 0, false, false, true);
-      if (M.gmm_lds == 3 && (size_t)M.total <= plan->ws_floats) L = M;
+      const WsLayout M = make_layout(v->dp, net.channels, net.n_hidden, n_steps, ck.k, ck.g, !general, false, 0, false, false, true);
+      if (M.gmm_lds == (general ? 4 : 3) && (size_t)M.total <= plan->ws_floats) L = M;
     }
   }
 
@@ -874,7 +882,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   // The wave-specialised kernel needs GMM tables in LDS; mixtures too large for that use the single-wave kernel
   // with scalar-load tables (also selectable with SDEH_LEGACY=1 for A/B measurements).
   const bool legacy = force_legacy || (pr->target.kind == SDEH_DENS_GMM && L.gmm_lds == 0);
-  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "%s<%s%s>", legacy ? "traj_legacy" : "traj_ws", v->name, L.gmm_lds == 3 ? ",mm" : "");
+  snprintf(plan->last_kernel, sizeof(plan->last_kernel), "%s<%s%s>", legacy ? "traj_legacy" : "traj_ws", v->name, L.gmm_lds >= 3 ? ",mm" : "");
   if (legacy) {
     rc = v->fn_legacy(A, st);
     if (rc == SDEH_ERR_UNSUPPORTED && v != plan->variant) rc = plan->variant->fn_legacy(A, st);

@@ -279,23 +279,38 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
     const SdehDensity& G = pr.target;
     const int K = G.n_components;
     const int K2 = L.gmm_rows;  // K rounded up to a multiple of 8; padding rows have logit -inf
-    if (L.gmm_lds == 3) {  // A-operand images of the matrix-pipe mixture (layout: sdeh_common.hpp, WsLayout::gmm_mm1)
-      const int K4 = K2 / 4, D4 = (L.dp + 3) / 4;
-      const int n1 = L.dp * K4, n2 = K2 * D4;
-      auto tval = [&](int k, int j) {  // mu_kj / sigma_j^2, zero outside the mixture
+    if (L.gmm_lds >= 3) {  // A-operand images of the matrix-pipe mixture (layout: sdeh_common.hpp, WsLayout::gmm_mm1)
+      const bool gen = L.gmm_lds == 4;  // per-component scales: two tables per stream (instruction n carries table t = (n / stride) % 2)
+      const int K4 = K2 / 4, D4 = (L.dp + 3) / 4, f = gen ? 2 : 1;
+      const int n1 = f * L.dp * K4, n2 = f * K2 * D4;
+      // t = 0: mu / sigma^2 (shared form: the only table);  general form: logits t = 0: -1 / (2 sigma^2), t = 1: mu / sigma^2;
+      // score t = 0: mu / sigma^2, t = 1: 1 / sigma^2;  zero outside the mixture
+      auto tval = [&](int k, int j, int which) {  // which: 0 mu / s^2, 1 -1 / (2 s^2), 2 1 / s^2
         if (k >= K || j >= G.dim) return 0.0f;
-        const float sg = G.scale[j];
-        return G.loc[(size_t)k * G.dim + j] / (sg * sg);
+        const float sg = G.scale[gen ? (size_t)k * G.dim + j : j];
+        const float iv = 1.0f / (sg * sg);
+        if (which == 0) return gen ? G.loc[(size_t)k * G.dim + j] * iv : G.loc[(size_t)k * G.dim + j] / (sg * sg);
+        return which == 1 ? -0.5f * iv : iv;
       };
       for (int e = gid; e < ((n1 + 63) / 64) * 256; e += stride) {
         const int q = e / 256, ln = (e / 4) % 64, el = e % 4;
         const int n = 16 * (4 * q + el) + ln / 4, i = ln % 4;
-        ws[L.gmm_mm1 + e] = n < n1 ? tval(4 * (n % K4) + i, n / K4) : 0.0f;
+        float v = 0.0f;
+        if (n < n1) {
+          const int dt = n / K4, g = n % K4;  // dt = d (shared) or 2 d + t
+          v = gen ? tval(4 * g + i, dt / 2, dt % 2 == 0 ? 1 : 0) : tval(4 * g + i, dt, 0);
+        }
+        ws[L.gmm_mm1 + e] = v;
       }
       for (int e = gid; e < ((n2 + 63) / 64) * 256; e += stride) {
         const int q = e / 256, ln = (e / 4) % 64, el = e % 4;
         const int n = 16 * (4 * q + el) + ln / 4, i = ln % 4;
-        ws[L.gmm_mm2 + e] = n < n2 ? tval(n / D4, 4 * (n % D4) + i) : 0.0f;
+        float v = 0.0f;
+        if (n < n2) {
+          const int kt = n / D4, g = n % D4;  // kt = k (shared) or 2 k + t
+          v = gen ? tval(kt / 2, 4 * g + i, kt % 2 == 0 ? 0 : 2) : tval(kt, 4 * g + i, 0);
+        }
+        ws[L.gmm_mm2 + e] = v;
       }
     }
     if (L.gmm_lds == 2 || L.gmm_lds == 3) {  // shared-scale tables (SDEH_DENS_FLAG_SHARED_SCALE); rows cover the first gmm_row coordinates
@@ -339,10 +354,10 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
       float c = G.mixture_weights != nullptr ? logf(G.mixture_weights[k]) - logf(wsum) : 0.0f;
       for (int j = 0; j < G.dim; ++j) c -= logf(G.scale[(size_t)k * G.dim + j]) + 0.91893853320467274178f;
       ws[L.gmm_c + k] = c;
-      if (L.gmm_lds == 3) {  // logit of the product form: c_k - sum_j mu_kj^2 / (2 sigma_j^2) + sum_j x_j mu_kj / sigma_j^2 (- a term common to all k)
+      if (L.gmm_lds >= 3) {  // logit of the product form: c_k - sum_j mu_kj^2 / (2 sigma_j^2) + sum_j x_j mu_kj / sigma_j^2 (- a term common to all k)
         double cc = c;
         for (int j = 0; j < G.dim; ++j) {
-          const double mu = G.loc[(size_t)k * G.dim + j], sg = G.scale[j];
+          const double mu = G.loc[(size_t)k * G.dim + j], sg = G.scale[L.gmm_lds == 4 ? (size_t)k * G.dim + j : j];
           cc -= 0.5 * mu * mu / (sg * sg);
         }
         ws[L.gmm_cc + k] = (float)cc;
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
     }
     for (int k = K + gid; k < K2; k += stride) {
       ws[L.gmm_c + k] = -INFINITY;
-      if (L.gmm_lds == 3) ws[L.gmm_cc + k] = -INFINITY;
+      if (L.gmm_lds >= 3) ws[L.gmm_cc + k] = -INFINITY;
     }
   }
   pack_diag_gauss(ws + L.dg[0], pr.target, L.dp, gid, stride);

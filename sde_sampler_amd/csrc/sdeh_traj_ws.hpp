@@ -555,9 +555,70 @@ __device__ __forceinline__ void gmm_mm(const float* __restrict__ ws, const float
 #pragma unroll
   for (int d = 0; d < DP; ++d) score[d] = fmaf(P[d / 4][d % 4], iz, -x[d] * vec[RSF + d]);
 }
+// Per-component scales (WsLayout::gmm_lds == 4): four contractions, two instruction streams (layout: sdeh_common.hpp)
+//   logits:  l_k = cc_k - sum_d x_d^2 / (2 sigma_kd^2) + sum_d x_d mu_kd / sigma_kd^2      (B = x_d^2, then B = x_d: 2 x 500 instructions)
+//   score:   P_d = sum_k e_k mu_kd / sigma_kd^2,  Q_d = sum_k e_k / sigma_kd^2,  score_d = (P_d - x_d Q_d) / z      (2 x 520)
+template <int DP>
+__device__ __forceinline__ void gmm_mm_general(const float* __restrict__ ws, const float* __restrict__ lds, const WsLayout& L,
+                                               const float (&x)[DP], float (&score)[DP]) {
+  constexpr int K4 = SDEH_MM_K / 4, D4 = (DP + 3) / 4;
+  constexpr int N1 = 2 * DP * K4, N2 = 2 * SDEH_MM_K * D4;
+  constexpr int Q1 = (N1 + 63) / 64, Q2 = (N2 + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const mm4* __restrict__ a1 = reinterpret_cast<const mm4*>(lds + L.gmm_mm1) + lane;
+  const mm4* __restrict__ a2 = reinterpret_cast<const mm4*>(lds + L.gmm_mm2) + lane;
+  cfp cc = as_const(ws + L.gmm_cc);
+  mm4 lg[K4];
+#pragma unroll
+  for (int g = 0; g < K4; ++g) lg[g] = mm4{cc[4 * g], cc[4 * g + 1], cc[4 * g + 2], cc[4 * g + 3]};
+  static_for<Q1>([&](auto Qc) {
+    constexpr int q = decltype(Qc)::value;
+    const mm4 a = a1[q * 64];
+    static_for<64>([&](auto Nc) {
+      constexpr int n = 64 * q + decltype(Nc)::value;
+      if constexpr (n < N1) {  // n = (2 d + t) K4 + g;  t = 0: A = -1 / (2 sigma^2), B = x_d^2;  t = 1: A = mu / sigma^2, B = x_d
+        constexpr int d = n / (2 * K4), t = (n / K4) % 2, g = n % K4, e = (n / 16) % 4, b = n % 16;
+        lg[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], t == 0 ? x[d] * x[d] : x[d], lg[g], 4, b, 0);
+      }
+    });
+  });
+  float m = lg[0][0];
+#pragma unroll
+  for (int g = 0; g < K4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m = fmaxf(m, lg[g][i]);
+  float z = 0.0f;
+#pragma unroll
+  for (int g = 0; g < K4; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float e = __expf(lg[g][i] - m);
+      lg[g][i] = e;
+      z += e;
+    }
+  mm4 P[D4], Q[D4];
+#pragma unroll
+  for (int g = 0; g < D4; ++g) P[g] = Q[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
+  static_for<Q2>([&](auto Qc) {
+    constexpr int q = decltype(Qc)::value;
+    const mm4 a = a2[q * 64];
+    static_for<64>([&](auto Nc) {
+      constexpr int n = 64 * q + decltype(Nc)::value;
+      if constexpr (n < N2) {  // n = (2 k + t) D4 + g;  t = 0: mu / sigma^2 -> P,  t = 1: 1 / sigma^2 -> Q
+        constexpr int k = n / (2 * D4), t = (n / D4) % 2, g = n % D4, e = (n / 16) % 4, b = n % 16;
+        if constexpr (t == 0) P[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], lg[k / 4][k % 4], P[g], 4, b, 0);
+        else Q[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], lg[k / 4][k % 4], Q[g], 4, b, 0);
+      }
+    });
+  });
+  const float iz = 1.0f / z;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) score[d] = (P[d / 4][d % 4] - x[d] * Q[d / 4][d % 4]) * iz;
+}
 // which instantiations carry the matrix-pipe mixture (the launcher asks the same question: ws_mm_compiled)
+// 0: none, 1: the shared-scale form, 2: + the per-component-scale form (run-time table form only)
 template <int DP, bool PAD, int GMMV, int GNV>
-constexpr bool gmm_mm_compiled() { return (GMMV == 2 || GMMV < 0) && GNV <= 0 && DP > 8 && !PAD; }
+constexpr int gmm_mm_compiled() { return ((GMMV == 2 || GMMV < 0) && GNV <= 0 && DP > 8 && !PAD) ? (GMMV < 0 ? 2 : 1) : 0; }
 
 template <int DP, int NV, bool SG = false>
 __device__ __forceinline__ float ws_target_logp(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
@@ -581,13 +642,16 @@ __device__ __forceinline__ float ws_target_logp(const DensArgs& D, const float* 
   }
 }
 
-template <int DP, int NV, bool KS = false, bool SG = false, bool MM = false>
+template <int DP, int NV, bool KS = false, bool SG = false, int MM = 0>
 __device__ __forceinline__ void ws_target_score(const DensArgs& D, const float* ws, const float* lds, const WsLayout& L,
                                                 int gmmv, int dreal, const float (&x)[DP], float (&s)[DP]) {
   switch (D.kind) {
     case SDEH_DENS_GMM:
-      if constexpr (MM && SG && !KS && NV == DP) {
+      if constexpr (MM >= 1 && SG && !KS && NV == DP) {
         if (L.gmm_lds == 3) { gmm_mm<DP>(ws, lds, L, x, s); break; }
+      }
+      if constexpr (MM >= 2 && SG && !KS && NV == DP) {
+        if (L.gmm_lds == 4) { gmm_mm_general<DP>(ws, lds, L, x, s); break; }
       }
       if constexpr (SG && !KS) {
         if (gmmv == 2 || L.gmm_lds == 3) {
@@ -1680,7 +1744,7 @@ int launch_traj_ws(const TrajArgs& a, hipStream_t stream) {
     half = 3;
   }
   // matrix-pipe mixture layout (no tables in LDS): whole-wave modes of the instantiations that carry gmm_mm only (the API checks the same)
-  if (a.lay.gmm_lds == 3 && (half >= 2 || !gmm_mm_compiled<DP, PAD, GMMV, GNV>())) return SDEH_ERR_UNSUPPORTED;
+  if (a.lay.gmm_lds >= 3 && (half >= 2 || gmm_mm_compiled<DP, PAD, GMMV, GNV>() < a.lay.gmm_lds - 2)) return SDEH_ERR_UNSUPPORTED;
   if (half == 2 && ws_pair_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_pair_lds_bytes<DP>(a.lay);
   if (half == 3 && ws_quad_lds_bytes<DP>(a.lay) > lds_bytes) lds_bytes = ws_quad_lds_bytes<DP>(a.lay);
   TrajArgs b = a;

@@ -168,8 +168,8 @@ def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
         shared, n_vary = _mixture_structure(dist.loc, dist.scale)
         if shared:
             out.flags |= L.DENS_FLAG_SHARED_SCALE | (((n_vary + 1) & 0xFFFF) << 8)
-            if n_vary > 8 and 33 <= dist.loc.shape[0] <= 40 and _mixture_mm_ok(dist.loc, dist.scale):
-                out.flags |= L.DENS_FLAG_MM_OK
+        if n_vary > 8 and 33 <= dist.loc.shape[0] <= 40 and _mixture_mm_ok(dist.loc, dist.scale):
+            out.flags |= L.DENS_FLAG_MM_OK
     elif "DoubleWell" in names:
         out.kind, out.n_components = L.DENS_MULTI_WELL, 1
         out.p0, out.p1 = _scalar(dist.separation), _scalar(dist.shift)
@@ -210,17 +210,18 @@ def _mixture_structure(loc: torch.Tensor, scale: torch.Tensor) -> tuple[bool, in
 
 
 # Product-form logits (SDEH_DENS_FLAG_MM_OK): l_k = c_k - |m_k|^2 + 2 y . m_k with y = x / (sqrt2 sigma), m_k = mu_k / (sqrt2 sigma)
-# carries the fp32 rounding of its LARGE terms, eps ~ 6e-8 x 2 |y| |m_k| (tests/perf/mixture_mfma_numerics.py), where the squared-distance
-# form -|y - m_k|^2 carries 6e-8 x its own value.  The two only differ for a component the trajectory is CLOSE to (small squared
-# distance, large products) -- and an error in one component's logit only matters if another component has comparable weight there.
+# carries the fp32 rounding of its LARGE terms, eps ~ 6e-8 x 2 |y| |m_k| (tests/perf/mixture_mfma_numerics.py; per-component scales:
+# + 6e-8 |y|^2), where the squared-distance form -|y - m_k|^2 carries 6e-8 x its own value.  The two only differ for a component the
+# trajectory is CLOSE to (small squared distance, large products) -- and an error in one component's logit only matters where another
+# component has comparable weight.
 #   (a) eps <= MM_ABS_TOL everywhere the sampler can be (|y| <= max |m| + 6): any mixture near the origin qualifies;
-#   (b) or no two components are within MM_MIN_SEPARATION of each other in y units: then two components share a trajectory's weight
-#       (|l_j - l_k| < 20) only where BOTH squared distances exceed (sep / 2)^2 - 10, i.e. where the squared-distance form's own
-#       rounding, 6e-8 x (sep / 2)^2, is within MM_BOUNDARY_RATIO of the product form's (and eps <= MM_ABS_CAP).
+#   (b) or no two components are within MM_MIN_SEPARATION of each other (in the wider one's units): two components share a
+#       trajectory's weight (|l_j - l_k| < 20) only in the slab where BOTH squared distances exceed (sep / 2)^2 - 10 >= 26 -- there the
+#       squared-distance form's own logits are large and rounded as well -- and eps <= MM_ABS_CAP bounds what the product form can
+#       do inside that slab: a responsibility moves by at most 0.5 %.
 MM_ABS_TOL = 1.0e-5
 MM_MIN_SEPARATION = 12.0
-MM_BOUNDARY_RATIO = 16.0
-MM_ABS_CAP = 5.0e-3  # (b) never admits a logit error beyond this: a responsibility moves by at most 0.5 % where two components compete
+MM_ABS_CAP = 5.0e-3
 
 
 def _mixture_mm_ok(loc: torch.Tensor, scale: torch.Tensor) -> bool:
@@ -231,16 +232,21 @@ def _mixture_mm_ok(loc: torch.Tensor, scale: torch.Tensor) -> bool:
     if cached is not None and cached[0] == stamp:
         return cached[1]
     with torch.no_grad():
-        m = (loc.double() / (scale[:1].double() * math.sqrt(2.0)))
+        sd = scale.double().expand_as(loc) * math.sqrt(2.0)
+        m = loc.double() / sd  # every component in its own units
         norm = m.norm(dim=1)
         reach = float(norm.max().item()) + 6.0
-        eps = 6.0e-8 * 2.0 * reach * float(norm.max().item())
+        shared = bool((scale == scale[:1]).all().item())
+        # shared scale: the x^2 term is common to all components and never formed; per-component scales: it is part of every logit
+        eps = 6.0e-8 * (2.0 * reach * float(norm.max().item()) + (0.0 if shared else reach * reach))
         ok = eps <= MM_ABS_TOL
         if not ok and m.shape[0] > 1:
-            dist = torch.cdist(m, m)
+            # pairwise separation in the WIDER of the two components' units, coordinate by coordinate
+            wide = torch.maximum(sd[:, None, :], sd[None, :, :])
+            dist = ((loc.double()[:, None, :] - loc.double()[None, :, :]) / wide).norm(dim=2)
             dist.fill_diagonal_(float("inf"))
             sep = float(dist.min().item())
-            ok = sep >= MM_MIN_SEPARATION and eps <= min(MM_BOUNDARY_RATIO * 6.0e-8 * (0.5 * sep) ** 2, MM_ABS_CAP)
+            ok = sep >= MM_MIN_SEPARATION and eps <= MM_ABS_CAP
     try:
         loc._sdeh_mm_ok = (stamp, ok)
     except AttributeError:

@@ -259,8 +259,9 @@ def test_mixture_table_variants_vs_oracle(case):
     _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
 
 
+@pytest.mark.parametrize("scales", ["shared", "general"])
 @pytest.mark.parametrize("mode", ["matrix_pipe", "scalar_cache_tables"])
-def test_dense_mixture_whole_wave_paths_vs_oracle(mode, monkeypatch):
+def test_dense_mixture_whole_wave_paths_vs_oracle(mode, scales, monkeypatch):
     """A well-separated 40-component mixture with means varying in all 50 coordinates at a batch that launches whole waves
     (B > 8192): by default the binding vouches for the product form (engine._mixture_mm_ok) and both mixture contractions run on the
     matrix pipe inside the V wave (v_mfma_f32_4x4x1, kernel name "...,mm"); with the plan option SDEH_GMM_MM=0 the exact form streams
@@ -271,7 +272,7 @@ def test_dense_mixture_whole_wave_paths_vs_oracle(mode, monkeypatch):
 
     if mode == "scalar_cache_tables":
         monkeypatch.setenv("SDEH_GMM_MM", "0")
-    spec = problems.baseline_spec("gmm50_dense_shared")
+    spec = problems.baseline_spec("gmm50_dense_" + scales)
     spec["grid"]["steps"] = 10
     prob = problems.build(spec)
     assert engine._mixture_mm_ok(prob.target.loc, prob.target.scale)
@@ -285,16 +286,17 @@ def test_dense_mixture_whole_wave_paths_vs_oracle(mode, monkeypatch):
     prob.to("cuda:0")
     out = prob.eval(x0.cuda(), compute_weights=True, noise=noise.cuda())
     kernel = prob.loss.engine.last_kernel_name()
-    assert kernel == ("traj_ws<50_0_pis_gmm,mm>" if mode == "matrix_pipe" else "traj_ws<50_0_pis_gmm>"), kernel
+    variant = "50_0_pis_gmm" if scales == "shared" else "50_0_g"  # (per-component scales: the run-time switched variant)
+    assert kernel == (f"traj_ws<{variant},mm>" if mode == "matrix_pipe" else f"traj_ws<{variant}>"), kernel
     _row_check("x_T", out.samples.cpu().numpy(), ref["samples"].numpy())
     _est_check("lb_ito", out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"])
     _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
     from tests.helpers import measured
     from tests.test_hip_contract import est_tol
     err = (out.samples.cpu() - ref["samples"]).abs()
-    measured(f"dense_mixture[{mode}]/x_T_max", float(err.max()), ROW_MAX)
-    measured(f"dense_mixture[{mode}]/x_T_median", float(err.median()), ROW_MEDIAN)
-    measured(f"dense_mixture[{mode}]/logZ_is", abs(out.log_norm_const_preds["log_norm_const_is"] - ref["log_norm_const_is"]),
+    measured(f"dense_mixture[{scales},{mode}]/x_T_max", float(err.max()), ROW_MAX)
+    measured(f"dense_mixture[{scales},{mode}]/x_T_median", float(err.median()), ROW_MEDIAN)
+    measured(f"dense_mixture[{scales},{mode}]/logZ_is", abs(out.log_norm_const_preds["log_norm_const_is"] - ref["log_norm_const_is"]),
              est_tol(ref["log_norm_const_is"]))
 
 

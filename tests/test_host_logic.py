@@ -377,12 +377,14 @@ def test_split_bridge_path_selection(monkeypatch):
 
 def test_product_form_guard_of_the_matrix_pipe_mixture():
     """engine._mixture_mm_ok (SDEH_DENS_FLAG_MM_OK): product-form logits are admitted for mixtures near the origin (absolute rounding
-    below 1e-5) and for well-separated ones (no two components within 12 scaled units; rounding at the decision boundaries within 16 x
-    the squared-distance form's own), and refused where two nearby components sit far from the origin."""
+    below 1e-5) and for well-separated ones (no two components within 12 scaled units, rounding below 5e-3), and refused where two
+    nearby components sit far from the origin."""
     from sde_sampler_amd import engine, problems
 
     dense = problems.build(problems.baseline_spec("gmm50_dense_shared")).target
     assert engine._mixture_mm_ok(dense.loc, dense.scale)
+    general = problems.build(problems.baseline_spec("gmm50_dense_general")).target  # per-component scales
+    assert engine._mixture_mm_ok(general.loc, general.scale)
     gen = torch.Generator().manual_seed(0)
     near = (torch.rand((40, 50), generator=gen) - 0.5) * 0.5  # |m| ~ 1: rule (a)
     assert engine._mixture_mm_ok(near, torch.ones(40, 50))

@@ -290,12 +290,19 @@ def extra_block(device, B: int) -> dict:
     out = {}
     # (headline_generic_kernel: run-time switches for loss / control / target / activation, mixture tables over the four coordinates the
     # reference's padded mixtures differ in -- variant "50_0_g4"; ..._full_tables: the plain generic variant, tables over all 50)
-    for name, gen in (("gmm50_dense_shared", None), ("gmm50_dense_general", None), ("gmm50_pis_headline", "1"), ("gmm50_pis_headline", "2")):
+    # (the dense mixtures run their contractions on the matrix pipe where the binding vouches for the product form of the logits,
+    # engine._mixture_mm_ok -- both bench mixtures qualify; "..._exact_form": plan option SDEH_GMM_MM=0, squared-distance logits on
+    # the vector pipe with the tables streamed through the scalar cache)
+    for name, gen in (("gmm50_dense_shared", None), ("gmm50_dense_general", None), ("gmm50_dense_shared", "x"), ("gmm50_dense_general", "x"),
+                      ("gmm50_pis_headline", "1"), ("gmm50_pis_headline", "2")):
         spec = problems.baseline_spec(name)
         spec["batch"] = B
-        generic = gen is not None
+        exact = gen == "x"
+        generic = gen is not None and not exact
         if generic:
             os.environ["SDEH_GENERIC_ONLY"] = gen
+        if exact:
+            os.environ["SDEH_GMM_MM"] = "0"
         try:
             prob = problems.build(spec, device=device)
             prob.loss.engine.timing = True
@@ -303,9 +310,10 @@ def extra_block(device, B: int) -> dict:
             ms, ms_min, n = timed_kernel_ms(prob, x0)
         finally:
             os.environ.pop("SDEH_GENERIC_ONLY", None)
+            os.environ.pop("SDEH_GMM_MM", None)
         T = prob.ts.numel() - 1
         tf = algorithmic_flops(spec) * B * T / (ms * 1e-3) / 1e12
-        out[("headline_generic_kernel" if gen == "1" else "headline_generic_kernel_full_tables") if generic else name] = {"kernel_ms": ms, "kernel_ms_min": ms_min, "launches": n,
+        out[("headline_generic_kernel" if gen == "1" else "headline_generic_kernel_full_tables") if generic else name + ("_exact_form" if exact else "")] = {"kernel_ms": ms, "kernel_ms_min": ms_min, "launches": n,
                                                                "algorithmic_tflops": tf, "frac": tf / PEAK_FP32_TFLOPS,
                                                                "kernel": prob.loss.engine.last_kernel_name()}
     # the wide-network kernels (BASELINE configs[4]'s shape: C = 256, d = 196) at their workloads' own batch and T

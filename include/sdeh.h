@@ -97,7 +97,7 @@ enum {
 /* GMM (v6, round 5): the caller vouches that the component logits may be evaluated in PRODUCT form (shared scale:
  * c_k - sum_d mu_kd^2 / (2 sigma_d^2) + sum_d x_d mu_kd / sigma_d^2; per-component scales: additionally - sum_d x_d^2 / (2 sigma_kd^2)), whose fp32 rounding is that of sum_d |x_d mu_kd| / sigma_d^2 rather than
  * of the squared distance -- harmless where no two components that can share a trajectory's weight lie close to each other (the
- * Python binding's rule: engine._mixture_mm_ok).  Lets evaluation launches of 33 .. 40-component mixtures run both mixture
+ * Python binding's rule: engine._mixture_mm_ok).  Lets evaluation launches of 21 .. 40-component mixtures run both mixture
  * contractions (reference: distr/gauss.py:123-140, distr/base.py:130-137) on the matrix pipe; the terminal log-density keeps the exact
  * form.  Plan option SDEH_GMM_MM overrides ("0" never / "1" always). */
 #define SDEH_DENS_FLAG_MM_OK 2

@@ -143,7 +143,8 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
     L.wt_in = o; o += (c / 2) * L.otd * 64;
   }
   L.gmm_row = 2 * ((dp + 1) & ~1);
-  const int k_rows = (k_max + 7) & ~7;  // table rows padded to a multiple of 8 (padding rows: logit -inf)
+  // table rows padded to a multiple of 8 (padding rows: logit -inf); the matrix-pipe mixture's instruction stream has SDEH_MM_ROWS rows
+  const int k_rows = gmm_mm && k_max <= SDEH_MM_ROWS ? SDEH_MM_ROWS : (k_max + 7) & ~7;
   L.gmm_rows = k_rows;
   // shared-scale tables: one word per (k,d), rows of 4*ceil(dp/4) floats (gmm_nv > 0: of the first gmm_nv coordinates only), then the
   // per-coordinate vectors; general tables: (mu, a) pairs
@@ -837,7 +838,8 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   WsLayout L = ck.L;
   const Variant* v = ck.v;
   const bool force_legacy = plan_opt(OPT_LEGACY) != nullptr;
-  // The mixture's contractions on the matrix pipe (sdeh_traj_ws.hpp: gmm_mm): shared-scale mixtures of 33 .. 40 components with tables
+  // The mixture's contractions on the matrix pipe (sdeh_traj_ws.hpp: gmm_mm): mixtures of 21 .. 40 components (fewer rows are padded: the
+  // instruction stream is fixed; below half of it the vector pipe is as fast) with tables
   // over all coordinates, where the caller vouches for the product form of the logits (SDEH_DENS_FLAG_MM_OK), on whole-wave launches
   // (the pair / quad modes of small batches read the tables from LDS) of the evaluation kernel.  Plan option SDEH_GMM_MM: "0" never,
   // "1" also without the caller's flag (measurements).
@@ -849,7 +851,7 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
                           u_out != nullptr || zrec != nullptr;
     const bool general = L.gmm_lds == 1 && v->gmm < 0;  // per-component scales: the run-time switched variants carry that form
     if (want && compiled && !force_legacy && !training && pr->target.kind == SDEH_DENS_GMM && (L.gmm_lds == 2 || general) &&
-        ((ck.k + 7) & ~7) == SDEH_MM_ROWS && batch > 32 * 256 && plan_opt(OPT_WS_GROUPS) == nullptr && plan_opt(OPT_WS_QUAD) == nullptr) {
+        ck.k > SDEH_MM_ROWS / 2 && ck.k <= SDEH_MM_ROWS && batch > 32 * 256 && plan_opt(OPT_WS_GROUPS) == nullptr && plan_opt(OPT_WS_QUAD) == nullptr) {
       const WsLayout M = make_layout(v->dp, net.channels, net.n_hidden, n_steps, ck.k, ck.g, !general, false, 0, false, false, true);
       if (M.gmm_lds == (general ? 4 : 3) && (size_t)M.total <= plan->ws_floats) L = M;
     }

@@ -75,6 +75,8 @@ struct WsLayout {
   //   gmm_mm1 [ceil(dp K4 / 64)][64 lanes][4]: register v = 4 q + e, lane 4 b + i: mu[4 g + i][d] / sigma_d^2, instruction n = 16 v + b = d K4 + g
   //   gmm_mm2 [ceil(K D4 / 64)][64 lanes][4]:  register v, lane 4 b + i: mu[k][4 g + i] / sigma^2,     instruction n = 16 v + b = k D4 + g
   //   gmm_cc  [K rows]: gmm_c[k] - sum_d mu_kd^2 / (2 sigma_d^2)   (-inf for padding rows);  K4 = rows / 4, D4 = ceil(dp / 4)
+  // gmm_lds == 4: per-component scales, two tables per stream: mm1 instruction n = (2 d + t) K4 + g with t = 0: -1 / (2 sigma_kd^2) (against x_d^2),
+  //   t = 1: mu_kd / sigma_kd^2 (against x_d);  mm2 instruction n = (2 k + t) D4 + g with t = 0: mu / sigma^2 (-> P), t = 1: 1 / sigma^2 (-> Q)
   int gmm_mm1, gmm_mm2, gmm_cc;
   int dg[3];      // diag-gauss tables for target / prior / second: [dp][2] (mu, 1/sigma^2) then 1 float const
   int total;

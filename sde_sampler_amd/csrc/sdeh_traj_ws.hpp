@@ -492,7 +492,7 @@ constexpr bool gmm_use_sgpr() { return SDEH_GMM_SGPR != 0 && (SHARED ? NV : DP) 
 // (tools/ubench/mfma4x4.hip, valu_dep.hip).  The logits are a PRODUCT form: they carry the rounding of sum |x_d mu_kd| / sigma^2, not of
 // the squared distance -- the binding only selects this path where that cannot move a responsibility (SDEH_DENS_FLAG_MM_OK,
 // engine._mixture_mm_ok: well-separated components); the terminal log-density stays on the exact form (gmm_online_s).
-// The component count is a compile-time constant of the instruction stream: mixtures of 33 .. 40 components (SDEH_MM_K rows).
+// The component count is a compile-time constant of the instruction stream: mixtures of 21 .. 40 components (SDEH_MM_K rows).
 #ifndef SDEH_MM_K
 #define SDEH_MM_K 40
 #endif

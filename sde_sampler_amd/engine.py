@@ -168,7 +168,7 @@ def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
         shared, n_vary = _mixture_structure(dist.loc, dist.scale)
         if shared:
             out.flags |= L.DENS_FLAG_SHARED_SCALE | (((n_vary + 1) & 0xFFFF) << 8)
-        if n_vary > 8 and 33 <= dist.loc.shape[0] <= 40 and _mixture_mm_ok(dist.loc, dist.scale):
+        if n_vary > 8 and 21 <= dist.loc.shape[0] <= 40 and _mixture_mm_ok(dist.loc, dist.scale):
             out.flags |= L.DENS_FLAG_MM_OK
     elif "DoubleWell" in names:
         out.kind, out.n_components = L.DENS_MULTI_WELL, 1
@@ -450,6 +450,16 @@ class TrajectoryEngine:
         if self._last_plan is None:
             return ""
         return self._last_plan.lib.sdeh_plan_last_kernel_name(self._last_plan.handle).decode()
+
+    def invalidate(self) -> None:
+        """Forget every cached problem description (`build_problem`).  The fingerprint that revalidates a cached description covers
+        the TOP-LEVEL collaborating objects (control, SDE, target, prior / reference, inference control): the data pointers of all
+        their parameters / buffers (whole module trees), the versions of tensors whose values were read on the host, their scalar
+        attributes.  Sub-objects reached through an attribute or a bound method (`ctrl.target_score.__self__`, `dist.double_well`, an
+        activation's `approximate`) enter by identity only, and an object's attribute SET is taken as fixed after its first use:
+        after mutating a scalar of such a sub-object in place, or adding attributes / parameters to an object that was already
+        used, call this (replacing the sub-object, or any top-level mutation, is seen without it)."""
+        self._problems.clear()
 
     # ------------------------------------------------------------------------------------------------------
     def build_problem(self, *, device, keep: _Keep, **kw) -> L.SdehProblem:

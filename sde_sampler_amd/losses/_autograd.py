@@ -123,11 +123,19 @@ def _fused_record_grads(ctrl, ts, out, d, T, Lh, g, score_model, div: bool = Fal
     return grads
 
 
+def _plan_option(eng, name: str):
+    """The value a launch of `eng` would push into its plan for option `name` -- `engine.options` (an explicit None = automatic) over the
+    environment, as `engine._Plan.sync_options` resolves it; like the library (`plan_opt`), any non-empty value counts as set."""
+    if name in eng.options:
+        return eng.options[name] or None
+    return os.environ.get(name) or None
+
+
 def _bridge_fused_ok(eng, inf_model, d, T, B, st) -> bool:
     """Does the fused inference-network backward (sdeh_bridge_backward_fused) serve this Bridge?  64 channels, two hidden layers, the
     exact divergence, planes within 32-bit byte offsets; plan option / environment SDEH_BWD_PLANES keeps the plane-writing kernels."""
     return (inf_model.channels == 64 and d <= 64 and len(inf_model.hidden_layer) == 2 and st.get("div_noise") is None
-            and not (eng.options.get("SDEH_BWD_PLANES") or os.environ.get("SDEH_BWD_PLANES")) and 64 * T * B * 4 < 2 ** 32)
+            and not _plan_option(eng, "SDEH_BWD_PLANES") and 64 * T * B * 4 < 2 ** 32)
 
 
 def _bridge_fused_inference(eng, pr_v, keep_v, inf, ts, xs, gp, w, st, cm: bool = False, dx_out=None) -> dict[int, torch.Tensor] | None:
@@ -594,6 +602,12 @@ def simulate_bridge_split(loss, launch, ts, x, inference_ctrl, return_traj: bool
     B, d = x.shape
     if (os.environ.get("SDEH_BRIDGE_SEQ") or gen.channels != 64 or inf_model.channels != 64 or d > 64 or len(inf_model.hidden_layer) != 2
             or 64 * B * 4 >= 2 ** 32):
+        return None
+    # the split keeps four [T, d, B] planes (trajectory, score, u, the inference terms' gradient) where the step-sequential kernel
+    # needs O(d B): only within the memory budget of the training path's planes (evaluation batches go up to 2^24 rows)
+    T = ts.numel() - 1
+    budget = float(os.environ.get("SDEH_BRIDGE_PLANE_BYTES", 0)) or 0.5 * torch.cuda.mem_get_info(x.device)[0]
+    if 4.0 * (T + 1) * d * B * 4 > budget:
         return None
     calls = loss.engine.calls
     out = _bridge_split_forward(loss, launch, ts, x)

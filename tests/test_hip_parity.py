@@ -259,7 +259,7 @@ def test_mixture_table_variants_vs_oracle(case):
     _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
 
 
-@pytest.mark.parametrize("scales", ["shared", "general"])
+@pytest.mark.parametrize("scales", ["shared", "general", "shared_overlapping", "general_overlapping"])
 @pytest.mark.parametrize("mode", ["matrix_pipe", "scalar_cache_tables"])
 def test_dense_mixture_whole_wave_paths_vs_oracle(mode, scales, monkeypatch):
     """A well-separated 40-component mixture with means varying in all 50 coordinates at a batch that launches whole waves
@@ -272,9 +272,18 @@ def test_dense_mixture_whole_wave_paths_vs_oracle(mode, scales, monkeypatch):
 
     if mode == "scalar_cache_tables":
         monkeypatch.setenv("SDEH_GMM_MM", "0")
-    spec = problems.baseline_spec("gmm50_dense_" + scales)
+    spec = problems.baseline_spec("gmm50_dense_" + scales.split("_")[0])
     spec["grid"]["steps"] = 10
-    prob = problems.build(spec)
+    tensors = None
+    if scales.endswith("overlapping"):
+        # 28 components (the instruction stream's 40 rows are padded) within a few scaled units of the origin: every trajectory spreads
+        # its weight over several components (the product form's rounding stays below 1e-5 there: rule (a) of engine._mixture_mm_ok)
+        # -- the bench mixtures above are one-hot
+        gen = torch.Generator().manual_seed(9)
+        loc = (torch.rand((28, 50), generator=gen) - 0.5) * 1.6
+        scale = 0.9 + 0.3 * torch.rand((1, 50) if scales.startswith("shared") else (28, 50), generator=gen)
+        tensors = dict(loc=loc, scale=scale.expand(28, 50).contiguous(), mixture_weights=0.5 + torch.rand((28,), generator=gen))
+    prob = problems.build(spec, target_tensors=tensors)
     assert engine._mixture_mm_ok(prob.target.loc, prob.target.scale)
     params = {n: v.detach().clone() for n, v in prob.ctrl.state_dict().items()}
     tt = dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
@@ -286,7 +295,7 @@ def test_dense_mixture_whole_wave_paths_vs_oracle(mode, scales, monkeypatch):
     prob.to("cuda:0")
     out = prob.eval(x0.cuda(), compute_weights=True, noise=noise.cuda())
     kernel = prob.loss.engine.last_kernel_name()
-    variant = "50_0_pis_gmm" if scales == "shared" else "50_0_g"  # (per-component scales: the run-time switched variant)
+    variant = "50_0_pis_gmm" if scales.startswith("shared") else "50_0_g"  # (per-component scales: the run-time switched variant)
     assert kernel == (f"traj_ws<{variant},mm>" if mode == "matrix_pipe" else f"traj_ws<{variant}>"), kernel
     _row_check("x_T", out.samples.cpu().numpy(), ref["samples"].numpy())
     _est_check("lb_ito", out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"])

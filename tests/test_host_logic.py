@@ -335,6 +335,11 @@ def test_problem_description_cache_follows_the_objects():
         prob.target.loc[0, 0] += 1.0  # values of a table the description depends on (mixture structure): version bump
     eng.build_problem(keep=E._Keep(), **kw)
     assert len(n_described) == 5
+    eng.build_problem(keep=E._Keep(), **kw)
+    assert len(n_described) == 5  # a hit
+    eng.invalidate()  # for what the fingerprint does not follow (scalars of sub-objects mutated in place): describe again
+    eng.build_problem(keep=E._Keep(), **kw)
+    assert len(n_described) == 6
 
 
 def test_split_bridge_path_selection(monkeypatch):
@@ -391,7 +396,7 @@ def test_product_form_guard_of_the_matrix_pipe_mixture():
     far_pair = (torch.rand((40, 50), generator=gen) - 0.5) * 80.0
     far_pair[1] = far_pair[0] + 0.5  # two components half a sigma apart, ~160 sigma from the origin
     assert not engine._mixture_mm_ok(far_pair, torch.ones(40, 50))
-    # the flag reaches the problem description only for shared-scale mixtures of 33 .. 40 components with dense tables
+    # the flag reaches the problem description only for shared-scale mixtures of 21 .. 40 components with dense tables
     fab = problems.build(problems.baseline_spec("gmm50_pis_headline")).target
     out = engine.L.SdehDensity()
     engine._fill_density(fab, out, engine._Keep(), torch.device("cpu"), "target")

@@ -50,6 +50,28 @@ python tools/train_reference_schedule.py --steps 2000 --out /tmp/ref_schedule_tm
     echo "## tools/train_demo.py $a --graph --seed 1"; python tools/train_demo.py $a --graph --seed 1 2>&1 | grep -E "^\[|RESULT|step (400|6000|10000):"; done; } > $OUT/r05_train_quality.txt 2>&1
 # 9. host cost of an evaluation call
 { python tools/eval_host_profile.py; python tools/eval_host_profile.py gmm50_pis_headline 1024; } 2>&1 | grep -v amdgpu.ids > $OUT/r05_eval_host_profile.txt
+# 9b. dense mixtures: matrix-pipe contractions (default) / exact form with scalar-cache tables (SDEH_GMM_MM=0) / round 4's LDS tables (measurement
+#     build prof_tmp/libsdeh_gmmlds.so = -DSDEH_GMM_SGPR=0); PMC passes of the dense shared-scale kernel in both forms; the micro-benchmarks
+{ echo "# tools/dense_mixture_timing.py on the MI355X, round 5: B = 65 536, T = 100, kernel ms over 7 launches (HIP events); x_T hashes: identical Philox draws"
+  echo "## default: both mixture contractions on the matrix pipe where the binding vouches for the product form (kernel names ...,mm)"
+  python tools/dense_mixture_timing.py
+  echo "## plan option SDEH_GMM_MM=0: exact form, tables through the scalar cache (gmm_online_s)"
+  SDEH_GMM_MM=0 python tools/dense_mixture_timing.py
+  if [ -f prof_tmp/libsdeh_gmmlds.so ]; then
+    echo "## exact form, tables as LDS broadcast reads (-DSDEH_GMM_SGPR=0 build = round 4's path)"
+    SDEH_GMM_MM=0 SDEH_LIBRARY=$ROOT/prof_tmp/libsdeh_gmmlds.so python tools/dense_mixture_timing.py
+  fi; } 2>&1 | grep -v "amdgpu.ids\|^# library" > $OUT/r05_dense_mixture_timing.txt
+for form in mm:"" valu:0; do
+  tag=${form%%:*}; v=${form#*:}
+  SDEH_GMM_MM=$v bash tools/pmc_profile.sh $OUT/pmc_dense_$tag "python bench.py --workload gmm50_dense_shared --steps 4 --warmup 1 --no-cpu-baseline --no-extra --no-graphed" > /dev/null 2>&1
+  { echo "# PMC passes (tools/pmc_profile.sh) of traj_ws<50_0_pis_gmm> on gmm50_dense_shared, mixture form: $tag (mm = matrix pipe, valu = exact form on the vector pipe, scalar-cache tables); per launch"
+    cat $OUT/pmc_dense_$tag/summary.txt; } > $OUT/r05_pmc_dense_shared_$tag.txt
+done
+{ echo "# tools/ubench/{valu_dep,mfma4x4,smem_stream}.hip on the MI355X, round 5 (cycles at an ASSUMED 2.4 GHz: ratios are what counts)"
+  echo "## valu_dep: issue cost of packed / plain fp32 vector instructions, one and two waves per SIMD"; ./tools/ubench/valu_dep
+  echo; echo "## mfma4x4: the mixture's two contractions as v_mfma_f32_4x4x1_16b_f32 in the T layout (layout check against float64 + timing)"; ./tools/ubench/mfma4x4
+  echo; echo "## smem_stream: wave-uniform tables as scalar loads / LDS broadcast reads feeding 32 packed instructions per 32-dword batch"
+  ./tools/ubench/smem_stream | grep -E "workgroups|table  2 KB|table 16 KB|table 64 KB" | sed 's/(wave 0; memtime ticks x 21 if 100 MHz), //'; } > $OUT/r05_ubench_mixture.txt 2>&1
 # 10. the suite and the smoke test
 rm -f gpurun_out/parity_measured.txt gpurun_out/fuzz_hatches.txt
 timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $OUT/r05_pytest_gpu.txt

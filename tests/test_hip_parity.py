@@ -309,6 +309,45 @@ def test_dense_mixture_whole_wave_paths_vs_oracle(mode, scales, monkeypatch):
              est_tol(ref["log_norm_const_is"]))
 
 
+@pytest.mark.parametrize("d,k,scales,shape", [(10, 21, "shared", "pis"), (10, 40, "general", "dis"), (10, 33, "general", "pis"),
+                                              (50, 24, "general", "dis"), (50, 37, "shared", "dis"), (10, 30, "shared", "dds")])
+def test_matrix_pipe_mixture_random_cases_vs_oracle(d, k, scales, shape):
+    """The matrix-pipe mixture in both compiled dimension classes (d = 10: 100 + 120 instructions per step; d = 50), with 21 .. 40
+    components (padding rows of the 40-row stream), both table forms, under the three losses / two controls the specs bring (run-time
+    switched variants except PIS + shared scale at d = 50): random overlapping mixtures near the origin, where every trajectory spreads
+    its weight and rule (a) of engine._mixture_mm_ok admits the product form; against the oracle on identical noise."""
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import engine, problems
+
+    base = {"pis": "gmm50_pis_headline", "dis": "cfg2_gmm2_dis_kl", "dds": "cfg4_funnel_dds_lv"}[shape]
+    spec = problems.baseline_spec(base)
+    spec["target"] = dict(kind="gmm", dim=d, name="random")
+    spec["prior"] = dict(spec["prior"], dim=d)
+    spec["grid"] = dict(spec["grid"], steps=8, rescale_t=None)
+    gen = torch.Generator().manual_seed(100 * d + k)
+    loc = (torch.rand((k, d), generator=gen) - 0.5) * (3.0 if d == 10 else 1.4)
+    scale = 0.8 + 0.5 * torch.rand((1, d) if scales == "shared" else (k, d), generator=gen)
+    tt = dict(loc=loc, scale=scale.expand(k, d).contiguous(), mixture_weights=0.5 + torch.rand((k,), generator=gen))
+    prob = problems.build(spec, target_tensors=tt)
+    assert engine._mixture_mm_ok(prob.target.loc, prob.target.scale)
+    params = {n: v.detach().clone() for n, v in prob.ctrl.state_dict().items()}
+    B = 8192 + 64
+    torch.manual_seed(d + k)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(8, B, d)
+    ref = eo.Problem(spec, params, {n: v.clone() for n, v in tt.items()}).eval(prob.ts.clone(), x0.clone(), noise, compute_weights=True)
+    prob.to("cuda:0")
+    out = prob.eval(x0.cuda(), compute_weights=True, noise=noise.cuda())
+    kernel = prob.loss.engine.last_kernel_name()
+    assert kernel.endswith(",mm>"), kernel
+    _row_check("x_T", out.samples.cpu().numpy(), ref["samples"].numpy())
+    _est_check("lb_ito", out.log_norm_const_preds["log_norm_const_lb_ito"], ref["log_norm_const_lb_ito"])
+    _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
+    from tests.helpers import measured
+    err = (out.samples.cpu() - ref["samples"]).abs()
+    measured(f"matrix_pipe_mixture[d={d},k={k},{scales},{shape}]/x_T_max", float(err.max()), ROW_MAX)
+
+
 @pytest.mark.parametrize("d", [10, 20, 32, 33, 50, 64])
 @pytest.mark.parametrize("shape", ["pis", "dis", "dds"])
 def test_padded_reference_mixture_in_other_dimensions_vs_oracle(d, shape):

@@ -474,8 +474,11 @@ __device__ __forceinline__ float gmm_online_s(const float* __restrict__ ws, cons
 #ifndef SDEH_GMM_SGPR
 #define SDEH_GMM_SGPR 1
 #endif
+#ifndef SDEH_GMM_SGPR_MIN
+#define SDEH_GMM_SGPR_MIN 3  // tables over at most this many coordinates keep the LDS form (d = 2: no difference; 4 coordinates: -1.5 %, profiles/r05_dense_mixture_timing.txt)
+#endif
 template <int DP, bool SHARED, int NV>
-constexpr bool gmm_use_sgpr() { return SDEH_GMM_SGPR != 0 && (SHARED ? NV : DP) > 8; }
+constexpr bool gmm_use_sgpr() { return SDEH_GMM_SGPR != 0 && (SHARED ? NV : DP) > SDEH_GMM_SGPR_MIN; }
 
 // ---------------------------------------------------------------------------------------------------------
 // The mixture's two contractions on the MATRIX pipe, inside the V wave (round 5; WsLayout::gmm_lds == 3, shared scale, full tables).

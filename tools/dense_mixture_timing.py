@@ -17,9 +17,9 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 REPS = int(os.environ.get("REPS", "7"))
 print(f"# library: {os.environ.get('SDEH_LIBRARY', 'sde_sampler_amd/libsdeh.so')}  B = {B}")
 for name, gen in (("gmm50_pis_headline", None), ("gmm50_dense_shared", None), ("gmm50_dense_general", None), ("gmm50_pis_headline", "2"),
-                  ("cfg3_gmm50_pis_kl", None)):
+                  ("cfg3_gmm50_pis_kl", None), ("cfg2_gmm2_dis_kl", None)):
     spec = problems.baseline_spec(name)
-    spec["batch"] = B
+    spec["batch"] = B if name != "cfg3_gmm50_pis_kl" or len(sys.argv) > 1 else spec["batch"]  # (configs[2]: its per-GPU shard of 32 768)
     if gen is not None:
         os.environ["SDEH_GENERIC_ONLY"] = gen
     try:

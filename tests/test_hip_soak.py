@@ -54,6 +54,12 @@ EVAL_CASES = [
     ("cfg2_gmm2_dis_kl", 20000, 60, {"SDEH_WS_VOUT": 0}, "traj_ws<2_0_dis_gmm>"),  # ... and on the matrix pipe
     ("gmm50_pis_headline", 16384, 30, {"SDEH_GENERIC_ONLY": 2}, "traj_ws<50_0_g>"),
     ("gmm50_pis_headline", 16384, 30, {"SDEH_GENERIC_ONLY": 1}, "traj_ws<50_0_g4>"),  # run-time switches, tables over 4 coordinates
+    # dense mixtures (round 5): the contractions on the matrix pipe / the exact form with its tables streamed through the scalar cache
+    # (hand-placed lgkmcnt waits in front of every s_load_dwordx16 batch), whole waves of 64 and of 32 lanes
+    ("gmm50_dense_shared", 65536, 30, {}, "traj_ws<50_0_pis_gmm,mm>"),
+    ("gmm50_dense_shared", 65536, 30, {"SDEH_GMM_MM": 0}, "traj_ws<50_0_pis_gmm>"),
+    ("gmm50_dense_general", 24576, 30, {}, "traj_ws<50_0_g,mm>"),
+    ("gmm50_dense_general", 24576, 30, {"SDEH_GMM_MM": 0}, "traj_ws<50_0_g>"),
     ("wide_pis_funnel196", 4096, 12, {"SDEH_WIDE_CT": 1}, "traj_wide<C=256,CT=1>"),
     ("wide_pis_funnel196", 8320, 12, {"SDEH_WIDE_CT": 2}, "traj_wide<C=256,CT=2>"),
     ("cfg5_like_bridge196", 512, 6, {"SDEH_WIDE_SPLIT": 1}, "bridge_wide<C=256,split=1>"),

@@ -116,17 +116,39 @@ def physical_cores() -> int:
         return os.cpu_count() or 1
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually run on: the scheduler affinity and the cgroup CPU quota (a container on a 128-core host is often
+    given a few cores' worth of time: filling the host with 128 processes then measures the scheduler, not the reference)."""
+    n = physical_cores()
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):  # pragma: no cover
+        pass
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), None))):
+        try:
+            quota, period = parse(open(path).read())
+            if period is None:
+                period = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            if quota not in ("max", "-1") and int(quota) > 0:
+                n = min(n, max(1, int(int(quota) / int(period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
 def cpu_process_parallel(spec, prob_cpu_state, chunk: int, n_intervals: int | None, T: int, window: float = 8.0) -> dict:
     """The honest all-cores figure of the reference's CPU path: its per-step tensors are too small for intra-op
     threads (128 torch threads are SLOWER than one), so the host is filled the way a user would fill it -- N independent one-thread
-    processes (oracle/cpu_worker.py), N = physical cores, each integrating its own chunk of trajectories (`sample_time` semantics,
+    processes (oracle/cpu_worker.py), N = the cores this process may use (`usable_cpus`: affinity and cgroup quota), each integrating its own chunk of trajectories (`sample_time` semantics,
     solver/oc.py:88-97).  Aggregate rate = chunks finished by all processes inside one common time window x chunk x T / window.
     Plain subprocesses with a hard timeout: a host that cannot run them is reported, never waited for."""
     import pickle
     import subprocess
     import tempfile
 
-    n = int(os.environ.get("SDEH_BENCH_CPU_PROCS", physical_cores()))
+    n = int(os.environ.get("SDEH_BENCH_CPU_PROCS", usable_cpus()))  # (round 5: the cores this container may use, not the host's 128)
     try:  # an interpreter with torch loaded is ~0.5 GB resident: never more processes than the host's free memory holds three times over
         import psutil
 
@@ -156,7 +178,7 @@ def cpu_process_parallel(spec, prob_cpu_state, chunk: int, n_intervals: int | No
             except Exception:  # noqa: BLE001  (timeout, crash, malformed line: that process contributes nothing)
                 p.kill()
                 failed += 1
-    return {"value": chunks * chunk * T / window if chunks else None, "processes": n, "threads_per_process": 1, "chunk": chunk,
+    return {"value": chunks * chunk * T / window if chunks else None, "processes": n, "usable_cpus": usable_cpus(), "threads_per_process": 1, "chunk": chunk,
             "window_s": window, "chunks_finished": chunks, "processes_late_for_the_window": late, "processes_failed": failed}
 
 

@@ -67,6 +67,7 @@ for form in mm:"" valu:0; do
   { echo "# PMC passes (tools/pmc_profile.sh) of traj_ws<50_0_pis_gmm> on gmm50_dense_shared, mixture form: $tag (mm = matrix pipe, valu = exact form on the vector pipe, scalar-cache tables); per launch"
     cat $OUT/pmc_dense_$tag/summary.txt; } > $OUT/r05_pmc_dense_shared_$tag.txt
 done
+for u in valu_dep mfma4x4 smem_stream; do [ -x tools/ubench/$u ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o tools/ubench/$u 2> /dev/null; done
 { echo "# tools/ubench/{valu_dep,mfma4x4,smem_stream}.hip on the MI355X, round 5 (cycles at an ASSUMED 2.4 GHz: ratios are what counts)"
   echo "## valu_dep: issue cost of packed / plain fp32 vector instructions, one and two waves per SIMD"; ./tools/ubench/valu_dep
   echo; echo "## mfma4x4: the mixture's two contractions as v_mfma_f32_4x4x1_16b_f32 in the T layout (layout check against float64 + timing)"; ./tools/ubench/mfma4x4

@@ -229,6 +229,7 @@ int32_t sdeh_plan_reserve(SdehPlan* plan, int64_t max_batch);
  *   scan form of back-propagation through time, d <= 4)        SDEH_BWD_ZREC ("0": the fused backward ignores the pre-activation record)
  *   SDEH_BRIDGE_TILES ("64" | "32g")   SDEH_BRIDGE_SPLIT ("1" | "4")   SDEH_WIDE_CT ("1" | "2")   SDEH_WIDE_SPLIT ("1" | "2" | "4" | "8")
  *   SDEH_GMM_MM ("0": never / "1": always evaluate an eligible mixture's contractions on the matrix pipe; default: SDEH_DENS_FLAG_MM_OK decides)
+ *   SDEH_WS_OUT4 ("0": evaluation launches at d = 5 .. 16 keep the out layer on 32-row matrix tiles instead of 4 x 4 x 1 row groups)
  * Unknown names: SDEH_ERR_INVALID. */
 int32_t sdeh_plan_set_option(SdehPlan* plan, const char* name, const char* value);
 

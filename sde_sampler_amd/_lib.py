@@ -110,7 +110,7 @@ class SdehUnsupported(SdehError, NotImplementedError):
 # the launch path
 PLAN_OPTIONS = ("SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES",
                 "SDEH_BWD_TILE", "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BWD_ZREC", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT",
-                "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT", "SDEH_GMM_MM")
+                "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT", "SDEH_GMM_MM", "SDEH_WS_OUT4")
 
 # every symbol include/sdeh.h declares, with its prototype
 PROTOTYPES = {

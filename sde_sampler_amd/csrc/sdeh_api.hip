@@ -124,7 +124,8 @@ static constexpr int SDEH_MM_ROWS = 40;  // = SDEH_MM_K of sdeh_traj_ws.hpp: com
 // gmm_nv: number of leading coordinates the shared-scale mixture tables cover (multiple of 4; 0 = all)
 // with_bwd: also pack the transposed weights the backward kernel needs (they join the LDS image)
 static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, int g, bool shared_scale = false,
-                            bool gmm_global = false, int gmm_nv = 0, bool with_bwd = false, bool with_tan = false, bool gmm_mm = false) {
+                            bool gmm_global = false, int gmm_nv = 0, bool with_bwd = false, bool with_tan = false, bool gmm_mm = false,
+                            bool out4 = false) {
   WsLayout L;
   memset(&L, 0, sizeof(L));
   L.dp = dp; L.c = c; L.ot = c / 32; L.otd = row_tiles(dp); L.r_in = mregs(dp);
@@ -178,6 +179,16 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
     L.gmm_lg = o; o += k_rows * L.gmm_row;
     L.gmm_sc = o; o += k_rows * L.gmm_row;
     L.gmm_c = o; o += align4(k_rows);
+  }
+  // the out layer's 4 x 4 x 1 operand image (WsLayout::w_out4): whole-wave evaluation launches, when it still fits
+  L.w_out4 = -1;
+  {
+    const int g4 = (dp + 3) / 4, out4_floats = ((33 * g4 + 31) / 32) * 256;
+    if (out4 && !with_bwd && dp > 4 && dp <= 16 && c == 64 &&  // = ws_out4_compiled<DP>()
+        ((size_t)(o + out4_floats) + xbuf_floats) * sizeof(float) + 64 <= 160 * 1024) {
+      L.w_out4 = o;
+      o += out4_floats;
+    }
   }
   L.lds_floats = align4(o);
   o = L.lds_floats;
@@ -291,7 +302,7 @@ struct OptScope {
 };
 static const char* const kOptNames[OPT_COUNT] = {
     "SDEH_LEGACY", "SDEH_GENERIC_ONLY", "SDEH_WS_GROUPS", "SDEH_WS_QUAD", "SDEH_WS_VOUT", "SDEH_WS_BARRIER", "SDEH_BWD_PLANES", "SDEH_BWD_TILE",
-    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BWD_ZREC", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT", "SDEH_GMM_MM"};
+    "SDEH_BWD_WAVES", "SDEH_BWD_V1", "SDEH_BWD_V2", "SDEH_BWD_NO_VIO", "SDEH_BWD_SCAN", "SDEH_BWD_ZREC", "SDEH_BRIDGE_TILES", "SDEH_BRIDGE_SPLIT", "SDEH_WIDE_CT", "SDEH_WIDE_SPLIT", "SDEH_GMM_MM", "SDEH_WS_OUT4"};
 static void opt_store(PlanOptions& o, int key, const char* value) {
   memset(o.v[key], 0, sizeof(o.v[key]));
   if (value != nullptr) strncpy(o.v[key], value, sizeof(o.v[key]) - 1);
@@ -854,6 +865,16 @@ static int simulate_impl(SdehPlan* plan, const SdehProblem* pr, const float* ts,
         ck.k > SDEH_MM_ROWS / 2 && ck.k <= SDEH_MM_ROWS && batch > 32 * 256 && plan_opt(OPT_WS_GROUPS) == nullptr && plan_opt(OPT_WS_QUAD) == nullptr) {
       const WsLayout M = make_layout(v->dp, net.channels, net.n_hidden, n_steps, ck.k, ck.g, !general, false, 0, false, false, true);
       if (M.gmm_lds == (general ? 4 : 3) && (size_t)M.total <= plan->ws_floats) L = M;
+    }
+    // the out layer on 4 x 4 x 1 matrix instructions (d = 5 .. 16, no empty rows): every evaluation launch carries the operand image (5 KB
+    // at most); the whole-wave modes use it, the pair / quad modes of small batches have out layers of their own.  Plan option
+    // SDEH_WS_OUT4 = "0" keeps the 32-row tiles
+    const char* oo = plan_opt(OPT_WS_OUT4);
+    if (!(oo != nullptr && oo[0] == '0') && !force_legacy && !training) {
+      const bool shared_l = L.gmm_lds == 2 || L.gmm_lds == 3;
+      const WsLayout M = make_layout(v->dp, net.channels, net.n_hidden, n_steps, ck.k, ck.g, shared_l, false, v->gnv > 0 ? v->gnv : 0, false,
+                                     false, L.gmm_lds >= 3, true);
+      if (M.w_out4 >= 0 && M.gmm_lds == L.gmm_lds && (size_t)M.total <= plan->ws_floats) L = M;
     }
   }
 

@@ -50,6 +50,12 @@ struct WsLayout {
   int w_out;      // [c/2][otd][64]
   int b_hid;      // n_hidden x [c]   (M order)
   int b_out;      // [otd*32]         (M order)
+  // round 5: the out layer as v_mfma_f32_4x4x1_16b_f32 (ws_out4 in sdeh_traj_ws.hpp) for state dimensions that leave >= 8 of the 32-row
+  // tile's rows empty and few row groups (d = 5 .. 16): G = ceil(dp / 4) row groups x 33 slots (32 accumulator registers of the activation + the
+  // bias against B = 1) = 33 G instructions per column tile; instruction n = slot * G + g; CBSZ = 3 lets one operand register carry 8
+  // instructions (ABID = n % 8): register n / 8, lane l: out_w[4 g + (l & 3)][32 (slot / 16) + rho(slot % 16, l >> 5)]  (slot 32: out_b on
+  // the lanes l < 32, zero above).  -1 when not packed (training launches, small-batch modes, images beyond LDS).
+  int w_out4;
   int wt_out;     // backward only: transposed out_layer  [r_in][ot][64];  -1 when not packed
   int wt_hid;     // backward only: transposed hidden layers, n_hidden x [c/2][ot][64]
   int wt_in;      // backward only (BPTT): transposed input_embed  [c/2][otd][64]
@@ -344,7 +350,7 @@ struct SinkArgs {
 // environment (sdeh_plan_create copies it once).
 enum OptKey {
   OPT_LEGACY, OPT_GENERIC_ONLY, OPT_WS_GROUPS, OPT_WS_QUAD, OPT_WS_VOUT, OPT_WS_BARRIER, OPT_BWD_PLANES, OPT_BWD_TILE, OPT_BWD_WAVES,
-  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BWD_SCAN, OPT_BWD_ZREC, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_GMM_MM, OPT_COUNT
+  OPT_BWD_V1, OPT_BWD_V2, OPT_BWD_NO_VIO, OPT_BWD_SCAN, OPT_BWD_ZREC, OPT_BRIDGE_TILES, OPT_BRIDGE_SPLIT, OPT_WIDE_CT, OPT_WIDE_SPLIT, OPT_GMM_MM, OPT_WS_OUT4, OPT_COUNT
 };
 struct PlanOptions {
   char v[OPT_COUNT][8];

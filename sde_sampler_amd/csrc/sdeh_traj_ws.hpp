@@ -849,6 +849,79 @@ __device__ __forceinline__ void ws_publish_act(float* __restrict__ abuf, const f
     for (int q = 0; q < 16; ++q) abuf[(32 * ot + rho(q, h)) * 64 + col] = a[ot][q];
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The out layer on v_mfma_f32_4x4x1_16b_f32 (round 5; WsLayout::w_out4).  A [32 x 64] x [64 x 32] tile product spends 64 cycles per
+// k-pair on 32 output rows of which d = 50 leaves 14 empty (d = 10: 22 of 32).  Here the output rows come in groups of FOUR: the
+// instruction multiplies, block by block (4 lanes = 4 trajectories), a 4-vector of weights with ONE value per lane -- the activation the
+// lane already holds in accumulator register (ot, q) -- and adds it to that lane's four partial sums: 8 cycles for 4 rows x 64 lanes,
+// the same 64 FLOP per cycle without empty rows: 33 ceil(d / 4) instructions per column tile (d = 50: 429 x 8 = 3.4 k cycles against
+// 64 x 64 = 4.1 k; d = 10: 99 x 8 = 0.8 k against 2.0 k; compiled for d <= 16, see ws_out4_compiled).  Lanes j (h = 0) and 32 + j (h = 1) hold DIFFERENT channels of the same
+// trajectory, so their weights differ: CBSZ = 3 broadcasts block ABID of each half to the 8 blocks of that half -- one operand register
+// carries 8 instructions, 2 x 4 weights each -- and the two halves' partial sums meet in one v_permlane32_swap + add per PAIR of row
+// groups (after it the lower half holds the sums of group 2 p, the upper half those of group 2 p + 1: every lane publishes as many
+// values as before).  The bias is a 33rd slot against B = 1.  Activation of the other column tile rides in the shadow as in mfma_stage.
+template <int DP>
+constexpr bool ws_out4_compiled() { return DP > 4 && DP <= 16; }
+// (d = 50 leaves 14 of 64 rows empty as well, but there the 13 accumulator quads of a column tile on top of both tiles' activations
+// push the M wave over its 256 registers: measured 2.178 -> 2.175 ms with the spills against 2.131 ms without this code -- not compiled)
+
+template <int G4, int NSIDE>
+__device__ __forceinline__ void ws_out4_stage(const mm4* __restrict__ a4, const f32x16 (&in)[2], mm4 (&u)[G4], f32x16 (&side)[NSIDE],
+                                              bool do_side, int act) {
+  constexpr int N = 33 * G4, NQ = (N + 31) / 32;  // instructions, ds_read_b128 (32 instructions each)
+  constexpr int NE2 = NSIDE * 8;                   // element pairs of the side tile, spread over the NQ operand reads
+  mm4 aq = a4[0];
+  static_for<NQ>([&](auto Qc) {
+    constexpr int q4 = decltype(Qc)::value;
+    const mm4 a = aq;
+    if constexpr (q4 + 1 < NQ) aq = a4[(q4 + 1) * 64];
+    static_for<32>([&](auto Nc) {
+      constexpr int n = 32 * q4 + decltype(Nc)::value;
+      if constexpr (n < N) {
+        constexpr int slot = n / G4, g = n % G4, e = (n / 8) % 4, b = n % 8;
+        if constexpr (slot < 32) u[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], in[slot / 16][slot % 16], u[g], 3, b, 0);
+        else u[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[e], 1.0f, u[g], 3, b, 0);
+      }
+    });
+    if (do_side) {
+#pragma unroll
+      for (int i = q4 * NE2 / NQ; i < (q4 + 1) * NE2 / NQ; ++i) {
+        const int e = 2 * i;
+        if (act == SDEH_ACT_GELU_ERF) {
+          const f2 r = act_gelu2(f2{side[e / 16][e % 16], side[(e + 1) / 16][(e + 1) % 16]});
+          side[e / 16][e % 16] = r.x;
+          side[(e + 1) / 16][(e + 1) % 16] = r.y;
+        } else {
+          side[e / 16][e % 16] = act_apply(side[e / 16][e % 16], act);
+          side[(e + 1) / 16][(e + 1) % 16] = act_apply(side[(e + 1) / 16][(e + 1) % 16], act);
+        }
+      }
+    }
+    SDEH_FENCE();
+  });
+}
+// the two halves' partial sums -> the exchange buffer [coordinate][trajectory]; `col` = the lane's trajectory column
+template <int DP, int G4>
+__device__ __forceinline__ void ws_out4_publish(float* __restrict__ xbuf, mm4 (&u)[G4], int col, int h) {
+#pragma unroll
+  for (int p = 0; p < (G4 + 1) / 2; ++p) {
+    const int g0 = 2 * p, g1 = 2 * p + 1 < G4 ? 2 * p + 1 : 2 * p;  // (an unpaired last group meets itself: both halves get its sums)
+    float s[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(u[g0][i]), __float_as_uint(u[g1][i]), false, false);
+      // r[0] = (lower half of g0, lower half of g1), r[1] = (upper half of g0, upper half of g1)
+      s[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    const int g = h ? g1 : g0;
+    if (g0 != g1 || h == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * g + i < xrows<DP>()) xbuf[(4 * g + i) * 64 + col] = s[i];
+    }
+  }
+}
+
 template <int DP, int C, int ZS>
 __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __restrict__ xbuf, const WsLayout& L,
                                        int act, const f32x16 (&emb)[C / 32], int lane, const ZStore& Z, const ZRec& Zr, float* __restrict__ abuf = nullptr) {
@@ -892,6 +965,24 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
         _Pragma("unroll") for (int ot = 0; ot < OT; ++ot) act_tile<ACTC>(curB[ot]););
       ws_publish_act<C>(abuf, curA, j, h);
       ws_publish_act<C>(abuf, curB, j + 32, h);
+      return;
+    }
+  }
+  if constexpr (ZS == 0 && C == 64 && ws_out4_compiled<DP>()) {
+    if (L.w_out4 >= 0) {  // out layer on 4 x 4 x 1 matrix instructions (no empty rows); tile B is activated in tile A's shadow
+      constexpr int G4 = (DP + 3) / 4;
+      const mm4* a4 = reinterpret_cast<const mm4*>(lds + L.w_out4) + lane;
+      mm4 u4[G4];  // (one set of partial sums alive at a time: tile A's are published before tile B's stage starts)
+#pragma unroll
+      for (int g = 0; g < G4; ++g) u4[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
+      ws_out4_stage<G4, OT>(a4, curA, u4, curB, true, act);
+      ws_out4_publish<DP, G4>(xbuf, u4, j, h);
+      SDEH_FENCE();
+#pragma unroll
+      for (int g = 0; g < G4; ++g) u4[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
+      f32x16 none[1];
+      ws_out4_stage<G4, 1>(a4, curB, u4, none, false, act);
+      ws_out4_publish<DP, G4>(xbuf, u4, j + 32, h);
       return;
     }
   }
@@ -953,6 +1044,17 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
   if constexpr (DP <= 4) {
     if (abuf != nullptr) {  // out layer on the V wave
       ws_publish_act<C>(abuf, cur, j, h);
+      return;
+    }
+  }
+  if constexpr (ZS == 0 && C == 64 && ws_out4_compiled<DP>()) {
+    if (L.w_out4 >= 0) {
+      constexpr int G4 = (DP + 3) / 4;
+      mm4 u4[G4];
+#pragma unroll
+      for (int g = 0; g < G4; ++g) u4[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
+      ws_out4_stage<G4, 1>(reinterpret_cast<const mm4*>(lds + L.w_out4) + lane, cur, u4, none, false, act);
+      ws_out4_publish<DP, G4>(xbuf, u4, j, h);
       return;
     }
   }

@@ -348,6 +348,39 @@ def test_matrix_pipe_mixture_random_cases_vs_oracle(d, k, scales, shape):
     measured(f"matrix_pipe_mixture[d={d},k={k},{scales},{shape}]/x_T_max", float(err.max()), ROW_MAX)
 
 
+@pytest.mark.parametrize("d", [5, 8, 10, 13, 16])
+def test_out_layer_on_4x4_matrix_instructions_vs_oracle(d, monkeypatch):
+    """State dimensions 5 .. 16 at whole-wave batches: the out layer runs as v_mfma_f32_4x4x1 row groups (sdeh_traj_ws.hpp: ws_out4_stage;
+    33 ceil(d / 4) instructions per column tile instead of a 32-row tile with 16 .. 27 empty rows).  Against the oracle on identical noise
+    and against the 32-row tiles (plan option SDEH_WS_OUT4=0), groups of 32 trajectories (B = 16 640) -- the BASELINE shard sizes and
+    groups of 64 run it in tests/test_hip_fullsize.py."""
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec("cfg4_funnel_dds_lv")
+    spec["target"] = dict(kind="funnel", dim=d)
+    spec["prior"] = dict(spec["prior"], dim=d)
+    spec["grid"] = dict(spec["grid"], steps=6)
+    prob = problems.build(spec)
+    params = {n: v.detach().clone() for n, v in prob.ctrl.state_dict().items()}
+    B = 16384 + 256  # (closed-form targets keep the quad mode up to 16 384 trajectories)
+    torch.manual_seed(d)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(prob.ts.numel() - 1, B, d)
+    ref = eo.Problem(spec, params, None).eval(prob.ts.clone(), x0.clone(), noise, compute_weights=True)
+    prob.to("cuda:0")
+    out = prob.eval(x0.cuda(), compute_weights=True, noise=noise.cuda())
+    _row_check("x_T", out.samples.cpu().numpy(), ref["samples"].numpy())
+    _est_check("logZ_is", out.log_norm_const_preds["log_norm_const_is"], ref["log_norm_const_is"])
+    monkeypatch.setenv("SDEH_WS_OUT4", "0")
+    old = prob.eval(x0.cuda(), compute_weights=True, noise=noise.cuda())
+    diff = float((out.samples - old.samples).abs().max())
+    assert 0.0 < diff <= 2e-5, diff  # another summation order of the same 65 products per coordinate: not bitwise, fp32-close
+    from tests.helpers import measured
+    measured(f"out_layer_4x4[d={d}]/x_T_max_vs_oracle", float((out.samples.cpu() - ref["samples"]).abs().max()), ROW_MAX)
+    measured(f"out_layer_4x4[d={d}]/x_T_max_vs_32_row_tiles", diff, 2e-5)
+
+
 @pytest.mark.parametrize("d", [10, 20, 32, 33, 50, 64])
 @pytest.mark.parametrize("shape", ["pis", "dis", "dds"])
 def test_padded_reference_mixture_in_other_dimensions_vs_oracle(d, shape):

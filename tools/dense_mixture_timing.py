@@ -17,16 +17,16 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 REPS = int(os.environ.get("REPS", "7"))
 print(f"# library: {os.environ.get('SDEH_LIBRARY', 'sde_sampler_amd/libsdeh.so')}  B = {B}")
 for name, gen in (("gmm50_pis_headline", None), ("gmm50_dense_shared", None), ("gmm50_dense_general", None), ("gmm50_pis_headline", "2"),
-                  ("cfg3_gmm50_pis_kl", None), ("cfg2_gmm2_dis_kl", None)):
+                  ("cfg3_gmm50_pis_kl", None), ("cfg2_gmm2_dis_kl", None), ("cfg4_funnel_dds_lv", None)):
     spec = problems.baseline_spec(name)
-    spec["batch"] = B if name != "cfg3_gmm50_pis_kl" or len(sys.argv) > 1 else spec["batch"]  # (configs[2]: its per-GPU shard of 32 768)
+    spec["batch"] = B if name not in ("cfg3_gmm50_pis_kl", "cfg4_funnel_dds_lv") or len(sys.argv) > 1 else spec["batch"]  # (configs[2] / [3]: the per-GPU shards of 32 768)
     if gen is not None:
         os.environ["SDEH_GENERIC_ONLY"] = gen
     try:
         prob = problems.build(spec, device="cuda:0")
         prob.loss.engine.timing = True
         torch.manual_seed(3)
-        x0 = prob.prior.sample((B,))
+        x0 = prob.prior.sample((spec["batch"],))
         ms = []
         for i in range(REPS + 2):
             r = prob.eval(x0, compute_weights=True, return_traj=False)  # Philox seed = torch's initial seed, offset = the call count

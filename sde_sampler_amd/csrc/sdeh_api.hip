@@ -183,11 +183,10 @@ static WsLayout make_layout(int dp, int c, int n_hidden, int t_max, int k_max, i
   // the out layer's 4 x 4 x 1 operand image (WsLayout::w_out4): whole-wave evaluation launches, when it still fits
   L.w_out4 = -1;
   {
-    const int g4 = (dp + 3) / 4, out4_floats = ((33 * g4 + 31) / 32) * 256;
     if (out4 && !with_bwd && dp > 4 && dp <= 16 && c == 64 &&  // = ws_out4_compiled<DP>()
-        ((size_t)(o + out4_floats) + xbuf_floats) * sizeof(float) + 64 <= 160 * 1024) {
+        ((size_t)(o + out4_floats(dp)) + xbuf_floats) * sizeof(float) + 64 <= 160 * 1024) {
       L.w_out4 = o;
-      o += out4_floats;
+      o += out4_floats(dp);
     }
   }
   L.lds_floats = align4(o);

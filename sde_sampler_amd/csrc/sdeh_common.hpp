@@ -41,6 +41,31 @@ enum CoefSlot {
 
 // Workspace layout (float offsets from the plan's workspace base).  The first `lds_floats` floats are the
 // "LDS image": every workgroup copies them verbatim into LDS.
+// the out layer's 4 x 4 x 1 row groups are accumulated in passes (sdeh_traj_ws.hpp: ws_out4_stage); one operand image per pass
+constexpr int kOut4Pass = 7;
+__host__ __device__ constexpr int out4_passes(int dp) { return ((dp + 3) / 4 + kOut4Pass - 1) / kOut4Pass; }
+__host__ __device__ constexpr int out4_pass_groups(int dp, int p) {
+  const int g4 = (dp + 3) / 4, np = out4_passes(dp), base = g4 / np, extra = g4 % np;  // (13 -> 7 + 6)
+  return base + (p < extra ? 1 : 0);
+}
+__host__ __device__ constexpr int out4_pass_first(int dp, int p) {
+  int g = 0;
+  for (int q = 0; q < p; ++q) g += out4_pass_groups(dp, q);
+  return g;
+}
+__host__ __device__ constexpr int out4_pass_floats(int dp, int p) { return ((33 * out4_pass_groups(dp, p) + 31) / 32) * 256; }
+__host__ __device__ constexpr int out4_floats(int dp) {
+  int f = 0;
+  for (int p = 0; p < out4_passes(dp); ++p) f += out4_pass_floats(dp, p);
+  return f;
+}
+__host__ __device__ constexpr int out4_pass_offset(int dp, int p) {
+  int f = 0;
+  for (int q = 0; q < p; ++q) f += out4_pass_floats(dp, q);
+  return f;
+}
+
+
 struct WsLayout {
   int dp, c, ot, otd, r_in, n_hidden, t_max, k_max, g;  // geometry (g = gamma row length: 1 or dp)
   int lds_floats;
@@ -54,7 +79,8 @@ struct WsLayout {
   // tile's rows empty and few row groups (d = 5 .. 16): G = ceil(dp / 4) row groups x 33 slots (32 accumulator registers of the activation + the
   // bias against B = 1) = 33 G instructions per column tile; instruction n = slot * G + g; CBSZ = 3 lets one operand register carry 8
   // instructions (ABID = n % 8): register n / 8, lane l: out_w[4 g + (l & 3)][32 (slot / 16) + rho(slot % 16, l >> 5)]  (slot 32: out_b on
-  // the lanes l < 32, zero above).  -1 when not packed (training launches, small-batch modes, images beyond LDS).
+  // the lanes l < 32, zero above); per PASS of at most kOut4Pass row groups one such image, g counted within the pass.  -1 when not packed
+  // (training launches, images beyond LDS).
   int w_out4;
   int wt_out;     // backward only: transposed out_layer  [r_in][ot][64];  -1 when not packed
   int wt_hid;     // backward only: transposed hidden layers, n_hidden x [c/2][ot][64]

@@ -226,17 +226,20 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepArgs P) {
     ws[L.w_out + e] = row < d ? net.out_w[(size_t)row * C + chan] : 0.0f;
   }
   for (int c = gid; c < OTD * 32; c += stride) ws[L.b_out + morder(c)] = c < d ? net.out_b[c] : 0.0f;
-  if (L.w_out4 >= 0) {  // the out layer's 4 x 4 x 1 operand image (layout: sdeh_common.hpp, WsLayout::w_out4)
-    const int G4 = (L.dp + 3) / 4, n4 = 33 * G4;
-    for (int e = gid; e < ((n4 + 31) / 32) * 256; e += stride) {
-      const int q4 = e / 256, ln = (e / 4) % 64, el = e % 4;  // read as b128: register 4 q4 + el of lane ln
-      const int n = 8 * (4 * q4 + el) + (ln % 32) / 4, i = ln % 4, hh = ln / 32;
-      float v = 0.0f;
-      if (n < n4) {
-        const int slot = n / G4, row = 4 * (n % G4) + i;
-        if (row < d) v = slot < 32 ? net.out_w[(size_t)row * C + 32 * (slot / 16) + rho(slot % 16, hh)] : (hh == 0 ? net.out_b[row] : 0.0f);
+  if (L.w_out4 >= 0) {  // the out layer's 4 x 4 x 1 operand images, one per pass (layout: sdeh_common.hpp, WsLayout::w_out4)
+    for (int ps = 0; ps < out4_passes(L.dp); ++ps) {
+      const int GP = out4_pass_groups(L.dp, ps), g_first = out4_pass_first(L.dp, ps), n4 = 33 * GP;
+      float* img = ws + L.w_out4 + out4_pass_offset(L.dp, ps);
+      for (int e = gid; e < out4_pass_floats(L.dp, ps); e += stride) {
+        const int q4 = e / 256, ln = (e / 4) % 64, el = e % 4;  // read as b128: register 4 q4 + el of lane ln
+        const int n = 8 * (4 * q4 + el) + (ln % 32) / 4, i = ln % 4, hh = ln / 32;
+        float v = 0.0f;
+        if (n < n4) {
+          const int slot = n / GP, row = 4 * (g_first + n % GP) + i;
+          if (row < d) v = slot < 32 ? net.out_w[(size_t)row * C + 32 * (slot / 16) + rho(slot % 16, hh)] : (hh == 0 ? net.out_b[row] : 0.0f);
+        }
+        img[e] = v;
       }
-      ws[L.w_out4 + e] = v;
     }
   }
   if (L.tan_in >= 0) {  // forward-mode tangent seeds / read-outs of the Bridge divergence (sdeh_bridge.hpp)

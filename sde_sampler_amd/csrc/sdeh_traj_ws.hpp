@@ -862,9 +862,9 @@ __device__ __forceinline__ void ws_publish_act(float* __restrict__ abuf, const f
 // values as before).  The bias is a 33rd slot against B = 1.  Activation of the other column tile rides in the shadow as in mfma_stage.
 template <int DP>
 constexpr bool ws_out4_compiled() { return DP > 4 && DP <= 16; }
-// (d = 50 leaves 14 of 64 rows empty as well, but there the 13 accumulator quads of a column tile on top of both tiles' activations
-// push the M wave over its 256 registers: measured 2.178 -> 2.175 ms with the spills against 2.131 ms without this code -- not compiled)
-
+// d = 50 leaves 14 of 64 rows empty as well (429 x 8 = 3.4 k against 4.1 k cycles per column tile), measured and NOT compiled: with all 13
+// accumulator quads alive the M wave spills (2.178 -> 2.175 ms against 2.131 ms without the code); accumulated in two passes of 7 + 6 groups
+// (the pass structure below, kOut4Pass) it still spills 232 B and the 26 swaps + adds per tile eat the rest: 2.158 -> 2.153 ms.
 template <int G4, int NSIDE>
 __device__ __forceinline__ void ws_out4_stage(const mm4* __restrict__ a4, const f32x16 (&in)[2], mm4 (&u)[G4], f32x16 (&side)[NSIDE],
                                               bool do_side, int act) {
@@ -902,7 +902,7 @@ __device__ __forceinline__ void ws_out4_stage(const mm4* __restrict__ a4, const 
 }
 // the two halves' partial sums -> the exchange buffer [coordinate][trajectory]; `col` = the lane's trajectory column
 template <int DP, int G4>
-__device__ __forceinline__ void ws_out4_publish(float* __restrict__ xbuf, mm4 (&u)[G4], int col, int h) {
+__device__ __forceinline__ void ws_out4_publish(float* __restrict__ xbuf, mm4 (&u)[G4], int col, int h, int g_first) {
 #pragma unroll
   for (int p = 0; p < (G4 + 1) / 2; ++p) {
     const int g0 = 2 * p, g1 = 2 * p + 1 < G4 ? 2 * p + 1 : 2 * p;  // (an unpaired last group meets itself: both halves get its sums)
@@ -913,7 +913,7 @@ __device__ __forceinline__ void ws_out4_publish(float* __restrict__ xbuf, mm4 (&
       // r[0] = (lower half of g0, lower half of g1), r[1] = (upper half of g0, upper half of g1)
       s[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
     }
-    const int g = h ? g1 : g0;
+    const int g = g_first + (h ? g1 : g0);
     if (g0 != g1 || h == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -970,19 +970,23 @@ __device__ __forceinline__ void ws_mlp(const float* __restrict__ lds, float* __r
   }
   if constexpr (ZS == 0 && C == 64 && ws_out4_compiled<DP>()) {
     if (L.w_out4 >= 0) {  // out layer on 4 x 4 x 1 matrix instructions (no empty rows); tile B is activated in tile A's shadow
-      constexpr int G4 = (DP + 3) / 4;
       const mm4* a4 = reinterpret_cast<const mm4*>(lds + L.w_out4) + lane;
-      mm4 u4[G4];  // (one set of partial sums alive at a time: tile A's are published before tile B's stage starts)
-#pragma unroll
-      for (int g = 0; g < G4; ++g) u4[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
-      ws_out4_stage<G4, OT>(a4, curA, u4, curB, true, act);
-      ws_out4_publish<DP, G4>(xbuf, u4, j, h);
-      SDEH_FENCE();
-#pragma unroll
-      for (int g = 0; g < G4; ++g) u4[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
       f32x16 none[1];
-      ws_out4_stage<G4, 1>(a4, curB, u4, none, false, act);
-      ws_out4_publish<DP, G4>(xbuf, u4, j + 32, h);
+      // (one pass' partial sums alive at a time: they are published before the next pass starts; tile B is activated in the shadow of
+      // tile A's first pass)
+      static_for<2 * out4_passes(DP)>([&](auto Pc) {
+        constexpr int tile = decltype(Pc)::value / out4_passes(DP), p = decltype(Pc)::value % out4_passes(DP);
+        constexpr int GP = out4_pass_groups(DP, p);
+        mm4 u4[GP];
+#pragma unroll
+        for (int g = 0; g < GP; ++g) u4[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
+        const mm4* ap = a4 + out4_pass_offset(DP, p) / 4;
+        if constexpr (tile == 0 && p == 0) ws_out4_stage<GP, OT>(ap, curA, u4, curB, true, act);
+        else if constexpr (tile == 0) ws_out4_stage<GP, 1>(ap, curA, u4, none, false, act);
+        else ws_out4_stage<GP, 1>(ap, curB, u4, none, false, act);
+        ws_out4_publish<DP, GP>(xbuf, u4, j + 32 * tile, h, out4_pass_first(DP, p));
+        SDEH_FENCE();
+      });
       return;
     }
   }
@@ -1049,12 +1053,16 @@ __device__ __forceinline__ void ws_mlp_half(const float* __restrict__ lds, float
   }
   if constexpr (ZS == 0 && C == 64 && ws_out4_compiled<DP>()) {
     if (L.w_out4 >= 0) {
-      constexpr int G4 = (DP + 3) / 4;
-      mm4 u4[G4];
+      const mm4* a4 = reinterpret_cast<const mm4*>(lds + L.w_out4) + lane;
+      static_for<out4_passes(DP)>([&](auto Pc) {
+        constexpr int p = decltype(Pc)::value, GP = out4_pass_groups(DP, p);
+        mm4 u4[GP];
 #pragma unroll
-      for (int g = 0; g < G4; ++g) u4[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
-      ws_out4_stage<G4, 1>(reinterpret_cast<const mm4*>(lds + L.w_out4) + lane, cur, u4, none, false, act);
-      ws_out4_publish<DP, G4>(xbuf, u4, j, h);
+        for (int g = 0; g < GP; ++g) u4[g] = mm4{0.0f, 0.0f, 0.0f, 0.0f};
+        ws_out4_stage<GP, 1>(a4 + out4_pass_offset(DP, p) / 4, cur, u4, none, false, act);
+        ws_out4_publish<DP, GP>(xbuf, u4, j, h, out4_pass_first(DP, p));
+        SDEH_FENCE();
+      });
       return;
     }
   }

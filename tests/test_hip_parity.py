@@ -8,6 +8,7 @@ itself moves x_T by 5.8e-3 after 100 steps because the dynamics amplify 1-ulp ch
                      asserts the contract at its own batch size, B = 4096, for every BASELINE configuration)
 """
 import math
+import os
 from pathlib import Path
 
 import numpy as np
@@ -23,6 +24,25 @@ ROW_MAX, ROW_MEDIAN, ROW_RTOL = 1e-2, 1e-4, 1e-4
 # the worst error measured over all fixtures, methods and tensors (gpurun_out/parity_measured.txt of the round's GPU run; was 2e-4)
 LOSS_BAR = 1e-4
 GRAD_BAR = 1e-4
+
+
+from contextlib import contextmanager
+
+
+@contextmanager
+def _env_var(name, value):
+    old = os.environ.get(name)
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = value
+    try:
+        yield
+    finally:
+        if old is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = old
 
 
 def _row_check(name, got, ref):
@@ -307,6 +327,50 @@ def test_dense_mixture_whole_wave_paths_vs_oracle(mode, scales, monkeypatch):
     measured(f"dense_mixture[{scales},{mode}]/x_T_median", float(err.median()), ROW_MEDIAN)
     measured(f"dense_mixture[{scales},{mode}]/logZ_is", abs(out.log_norm_const_preds["log_norm_const_is"] - ref["log_norm_const_is"]),
              est_tol(ref["log_norm_const_is"]))
+
+
+def test_matrix_pipe_mixture_at_the_edge_of_the_guard():
+    """Worst case the product-form guard admits (engine._mixture_mm_ok, rule (b)): 20 PAIRS of components 12.5 scaled units apart, 140
+    sigma from the origin (logit rounding bound 1.3e-3), and trajectories started ON the mid-planes of the pairs, where both members
+    carry weight.  The matrix-pipe path against the exact form (plan option SDEH_GMM_MM=0) on identical noise: the responsibilities may
+    move by the rounding bound x r (1 - r), the score by that times the pair distance / sigma^2 -- measured and bounded here -- and the
+    estimators agree at the bars of the other mixture tests.  (On the mid-plane the exact form's own logits are ~ (12.5 / 2)^2 = 39 with
+    fp32 rounding 2e-6: the product form IS the less accurate one there -- by what the guard's constants say.)"""
+    import math
+
+    from sde_sampler_amd import engine, problems
+
+    gen = torch.Generator().manual_seed(4)
+    d, P = 50, 20
+    c = torch.randn(P, d, generator=gen)
+    c = c / c.norm(dim=1, keepdim=True) * 140.0
+    e = torch.randn(P, d, generator=gen)
+    e = e / e.norm(dim=1, keepdim=True)
+    delta = 12.5 * math.sqrt(2.0)
+    tt = dict(loc=torch.cat([c + 0.5 * delta * e, c - 0.5 * delta * e]), scale=torch.ones(2 * P, d), mixture_weights=torch.ones(2 * P))
+    assert engine._mixture_mm_ok(tt["loc"], tt["scale"])
+    spec = problems.baseline_spec("gmm50_dense_shared")
+    spec["grid"]["steps"] = 8
+    prob = problems.build(spec, target_tensors=tt, device="cuda:0")
+    B = 8192 + 512
+    torch.manual_seed(6)
+    pair = torch.randint(0, P, (B,))
+    # on the mid-plane (+- a fraction of the slab |l_j - l_k| < 20, which is 0.57 sigma wide here), scattered within it
+    x0 = (c[pair] + 0.1 * torch.randn(B, 1) * e[pair] + 0.5 * torch.randn(B, d)).cuda()
+    noise = 0.05 * torch.randn(8, B, d, device="cuda")
+    out = {}
+    for mode in ("mm", "exact"):
+        with _env_var("SDEH_GMM_MM", None if mode == "mm" else "0"):
+            r = prob.eval(x0, compute_weights=True, noise=noise)
+            out[mode] = (r.samples.clone(), r.log_norm_const_preds["log_norm_const_lb_ito"], prob.loss.engine.last_kernel_name())
+    assert out["mm"][2].endswith(",mm>") and not out["exact"][2].endswith(",mm>"), (out["mm"][2], out["exact"][2])
+    diff = (out["mm"][0] - out["exact"][0]).abs()
+    # score error <= 1.3e-3 x 1/4 x 17.7 = 6e-3 per step at worst, times the control's step (sigma^2 dt = 0.2 x 5 / 8): <= 7e-4 per step
+    from tests.helpers import measured
+    measured("matrix_pipe_guard_edge/x_T_max_vs_exact_form", float(diff.max()), 1.5e-3)
+    measured("matrix_pipe_guard_edge/x_T_median_vs_exact_form", float(diff.median()), 1e-4)
+    assert float(diff.max()) <= 1.5e-3 and float(diff.median()) <= 1e-4, (float(diff.max()), float(diff.median()))  # measured: 5.1e-4 / 0
+    assert abs(out["mm"][1] - out["exact"][1]) <= 1e-4 * max(1.0, abs(out["exact"][1]))
 
 
 @pytest.mark.parametrize("d,k,scales,shape", [(10, 21, "shared", "pis"), (10, 40, "general", "dis"), (10, 33, "general", "pis"),

@@ -73,6 +73,14 @@ for u in valu_dep mfma4x4 smem_stream; do [ -x tools/ubench/$u ] || /opt/rocm/bi
   echo; echo "## mfma4x4: the mixture's two contractions as v_mfma_f32_4x4x1_16b_f32 in the T layout (layout check against float64 + timing)"; ./tools/ubench/mfma4x4
   echo; echo "## smem_stream: wave-uniform tables as scalar loads / LDS broadcast reads feeding 32 packed instructions per 32-dword batch"
   ./tools/ubench/smem_stream | grep -E "workgroups|table  2 KB|table 16 KB|table 64 KB" | sed 's/(wave 0; memtime ticks x 21 if 100 MHz), //'; } > $OUT/r05_ubench_mixture.txt 2>&1
+# 9c. PMC passes of configs[3]'s shard with the out layer as 4 x 4 x 1 row groups / as 32-row tiles
+for form in out4:"" tiles32:0; do
+  tag=${form%%:*}; v=${form#*:}
+  KERNEL="traj_ws_kernel<10," SDEH_WS_OUT4=$v REPS=4 bash tools/pmc_profile.sh $OUT/pmc_cfg4_$tag "python tools/dense_mixture_timing.py" > /dev/null 2>&1
+  { echo "# PMC passes (tools/pmc_profile.sh, KERNEL=traj_ws_kernel<10,) of traj_ws<10_0_dds_funnel> on configs[3]'s per-GPU shard (funnel d = 10, B = 32 768, T = 401), out layer: $tag"
+    echo "# (out4 = v_mfma_f32_4x4x1 row groups, section 3j; tiles32 = plan option SDEH_WS_OUT4=0: 32-row tiles); per launch"
+    cat $OUT/pmc_cfg4_$tag/summary.txt; } > $OUT/r05_pmc_cfg4_shard_$tag.txt
+done
 # 10. the suite and the smoke test
 rm -f gpurun_out/parity_measured.txt gpurun_out/fuzz_hatches.txt
 timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -4 > $OUT/r05_pytest_gpu.txt

@@ -292,10 +292,11 @@ __device__ __forceinline__ float gmm_online(const float* __restrict__ lds, const
 // ---------------------------------------------------------------------------------------------------------
 // The same online softmax with the tables streamed through the SCALAR cache (round 5).  A table entry is the same for all 64
 // trajectories of the wave: as broadcast ds_read_b128 it costs the LDS four cycles and 64 x 16 bytes of register-file writes for 16
-// useful bytes, per V wave -- with four V waves per CU the table stream of a dense 40-component, 50-dimensional mixture (1040 reads
-// per wave and step) holds the LDS longer than the vector work it feeds (tools/ubench/smem_stream.hip).  Here the rows arrive as
-// s_load_dwordx16 (eight coordinate pairs per instruction) and enter v_pk_add_f32 / v_pk_fma_f32 directly as SGPR-pair operands: no
-// vector registers, no LDS cycles.  The tables are read where the prep kernel wrote them (the global copy of the LDS image), in the
+// useful bytes, per V wave.  Here the rows arrive as s_load_dwordx16 (eight coordinate pairs per instruction) and enter v_pk_add_f32 /
+// v_pk_fma_f32 directly as SGPR-pair operands: no vector registers, no LDS cycles, no LDS wait on the V wave's critical path.  Measured
+// (profiles/r05_dense_mixture_timing.txt): a two-wave-per-SIMD micro-benchmark is vector-issue bound in either form
+// (tools/ubench/smem_stream.hip), the kernel is not -- per-component scales (2000 reads per step) 5.64 -> 4.58 ms, the headline's 4-coordinate
+// tables 2.163 -> 2.131 ms, and on 32-lane groups (B = 32 768), where the V wave's waits are exposed, 2.82 -> 2.45 ms.  The tables are read where the prep kernel wrote them (the global copy of the LDS image), in the
 // same layout, and every floating-point operation is the one gmm_online performs, in the same order: results are bit-identical.
 //
 // Stream: a chunk of 8 rows is NQ batches of two s_load_dwordx16 (16 SGPR pairs); batch n + 1 is requested before the vector work

@@ -1675,14 +1675,17 @@ __global__ __launch_bounds__(512) void traj_ws_kernel(const float* __restrict__ 
       // the raw network output joins the pre-activation record (ZRec: [coordinate quad][trajectory][4] behind the layers).  The M wave
       // stores it where it forms the whole sum (ws_mlp / ws_mlp_half); here the cases in which only this wave has it: the out layer on
       // the vector pipe (d <= 4) and the pair / quad modes' partial sums (d <= 32) -- 16-byte stores, ceil(d / 4) per lane
-      if (DP <= 32 && A.zrec != nullptr && live && (pair || (DP <= 4 && abuf != nullptr))) {
+      // (rows of the last 32-row tile beyond the batch are written as ZEROS: the record is uninitialised memory otherwise, and a backward
+      // launch that reads it weighs those rows by 0 -- 0 x NaN would reach the d gamma / clip partial sums)
+      const bool in_tile = lane < rpg && (row >> 5) < (long long)((A.batch + 31) >> 5);
+      if (DP <= 32 && A.zrec != nullptr && in_tile && (pair || (DP <= 4 && abuf != nullptr))) {
         const int zr_stride = zrec_tile_floats(L.n_hidden, d);
         float* __restrict__ zp = A.zrec + ((long long)i * ((A.batch + 31) >> 5) + (row >> 5)) * zr_stride + (L.n_hidden + 1) * 2048 + (int)(row & 31) * 4;
 #pragma unroll
         for (int g4 = 0; g4 < (DP + 3) / 4; ++g4) {
           f32x4z v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (4 * g4 + e < DP && (!PAD || 4 * g4 + e < d)) ? u[4 * g4 + e < DP ? 4 * g4 + e : 0] : 0.0f;
+          for (int e = 0; e < 4; ++e) v[e] = (live && 4 * g4 + e < DP && (!PAD || 4 * g4 + e < d)) ? u[4 * g4 + e < DP ? 4 * g4 + e : 0] : 0.0f;
           if (!PAD || 4 * g4 < d) __builtin_nontemporal_store(v, reinterpret_cast<f32x4z*>(zp + (g4 >> 3) * 1024 + (g4 & 7) * 128));
         }
       }

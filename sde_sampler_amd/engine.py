@@ -784,7 +784,7 @@ class TrajectoryEngine:
                 # (a split Bridge with method kl takes its running cost and adjoint planes through kernels that re-evaluate: nothing kept)
                 if (not (want_u and bptt) and lib.sdeh_ctrl_backward_fused_reads_zrec(plan.handle, C.byref(pr), batch)
                         and _zrec_fits(4 * n_z, device)):
-                    zrec = torch.empty(n_z, device=device, dtype=torch.float32)
+                    zrec = _alloc_zrec(n_z, device)
                 with torch.cuda.device(device):
                     if zrec is not None:
                         status = lib.sdeh_simulate_fwd_train3(plan.handle, C.byref(pr), ts_p, n_steps, x_p, batch, noise_p,
@@ -845,17 +845,41 @@ class TrajectoryEngine:
 _SCRATCH: dict = {}
 
 
+#: (device index, record bytes) -> bool: the budget decision, taken ONCE per size (a decision re-taken from the allocator's
+#: momentary state could flip between steps or differ across ranks -- and with it the kernels that serve a step and its low-order bits)
+_ZREC_DECISION: dict = {}
+
+
 def _zrec_fits(nbytes: int, device) -> bool:
     """Memory budget of the pre-activation record (768 B per trajectory-step with two hidden layers: 5 GB at B = 65 536, T = 100): at most
-    SDEH_ZREC_BYTES (default: 40 % of what is free on the device right now, the caching allocator's idle blocks included)."""
+    SDEH_ZREC_BYTES (a fixed byte budget), by default 40 % of what was free on the device when a record of this size was first asked for
+    (the caching allocator's idle blocks included).  The decision is cached per (device, size): no driver query on the launch path after
+    the first step, the same kernels every step.  A failed allocation withdraws it (`_alloc_zrec`); `reset_zrec_budget()` forgets all."""
     cap = os.environ.get("SDEH_ZREC_BYTES")
     if cap is not None:
         return nbytes <= int(float(cap))
-    free, _total = torch.cuda.mem_get_info(device)
-    # (+ what the caching allocator holds but has not handed out: the record of the previous step is in there, and a budget that did not
-    # count it would flip between the two forward launches from one step to the next)
-    free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
-    return nbytes <= 0.4 * free
+    key = (torch.device(device).index, int(nbytes))
+    fits = _ZREC_DECISION.get(key)
+    if fits is None:
+        free, _total = torch.cuda.mem_get_info(device)
+        free += max(0, torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+        fits = _ZREC_DECISION[key] = bool(nbytes <= 0.4 * free)
+    return fits
+
+
+def _alloc_zrec(n_floats: int, device):
+    """The record's storage (uninitialised: the forward launch writes every word a backward launch reads, rows of the ragged last tile
+    included).  Out of memory -> None (the launch that re-evaluates the network serves the step) and the cached decision is withdrawn."""
+    try:
+        return torch.empty(n_floats, device=device, dtype=torch.float32)
+    except torch.OutOfMemoryError:
+        _ZREC_DECISION[(torch.device(device).index, 4 * int(n_floats))] = False
+        return None
+
+
+def reset_zrec_budget() -> None:
+    """Forget the cached record-budget decisions (after freeing or claiming a large share of the device memory)."""
+    _ZREC_DECISION.clear()
 
 
 #: set by utils.graphs.GraphedEval while it captures an evaluation: BaseOCLoss.compute_results then leaves its host half to the replay

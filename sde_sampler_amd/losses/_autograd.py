@@ -346,6 +346,22 @@ def _weight_grads(ctrl, ts, xs, zt, dt, dout, dgam, xt=None, extra=None) -> dict
     return grads
 
 
+_PLANE_BUDGET: dict = {}
+
+
+def _plane_budget(device, key) -> float:
+    """Byte budget of the Bridge paths' planes: SDEH_BRIDGE_PLANE_BYTES, else half of what was free on the device when this shape
+    (`key`) first asked -- taken once per shape, so the path that serves a step does not follow the allocator's momentary state."""
+    cap = float(os.environ.get("SDEH_BRIDGE_PLANE_BYTES", 0))
+    if cap:
+        return cap
+    k = (torch.device(device).index, key)
+    got = _PLANE_BUDGET.get(k)
+    if got is None:
+        got = _PLANE_BUDGET[k] = 0.5 * torch.cuda.mem_get_info(device)[0]
+    return got
+
+
 class _TrajectoryFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, loss, launch, ts, x, *params):
@@ -408,7 +424,7 @@ class _BridgeFn(torch.autograd.Function):
             per_traj = 4.0 * T * (3 * dd * (Lh + 1) * Cn + 6 * (Lh + 1) * Cn + 6 * d)
             if lv and _bridge_fused_ok(loss.engine, inf_model, d, T, B, st):  # fused: three [64, T B] planes + the generative network's
                 per_traj = 4.0 * T * (3 * Cn + 6 * (Lh + 1) * Cn + 8 * d)
-            budget = float(os.environ.get("SDEH_BRIDGE_PLANE_BYTES", 0)) or 0.5 * torch.cuda.mem_get_info(xs.device)[0]
+            budget = _plane_budget(xs.device, ("bwd", B, T, d))
             n_slices = max(1, -(-int(per_traj * B) // max(int(budget), 1)))
         if n_slices == 1:
             grads = _BridgeFn._backward_rows(loss, st, ts, xs, gp, w)
@@ -606,7 +622,7 @@ def simulate_bridge_split(loss, launch, ts, x, inference_ctrl, return_traj: bool
     # the split keeps four [T, d, B] planes (trajectory, score, u, the inference terms' gradient) where the step-sequential kernel
     # needs O(d B): only within the memory budget of the training path's planes (evaluation batches go up to 2^24 rows)
     T = ts.numel() - 1
-    budget = float(os.environ.get("SDEH_BRIDGE_PLANE_BYTES", 0)) or 0.5 * torch.cuda.mem_get_info(x.device)[0]
+    budget = _plane_budget(x.device, ("fwd", B, T, d))
     if 4.0 * (T + 1) * d * B * 4 > budget:
         return None
     calls = loss.engine.calls

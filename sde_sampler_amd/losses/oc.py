@@ -339,7 +339,10 @@ class BaseOCLoss:
     def eval(self, ts: torch.Tensor, x: torch.Tensor, *args, **kwargs) -> Results:
         raise NotImplementedError
 
-    def load_state_dict(self, state_dict: dict):
+    def load_state_dict(self, state_dict: dict, rewind: bool = False):
+        """The reference's {"n_filtered"} (losses/oc.py:133-137) + the position of the noise stream.  By default the Philox position NEVER
+        moves backwards (a resumed run must not reuse offsets this process has already consumed); `rewind=True` sets it exactly to the
+        checkpoint's, which is what reproducing an earlier stretch of a run in the same process needs."""
         self.n_filtered = state_dict["n_filtered"]
         if self._n_filtered_dev is not None:
             self._n_filtered_dev.zero_()
@@ -358,7 +361,10 @@ class BaseOCLoss:
             replays = int(state_dict["rng_counter"]) - _GRAPH_COUNTER_START
         if replays is not None:
             if self.rng_counter is not None:
-                self.rng_counter.copy_(torch.clamp(self.rng_counter, min=_GRAPH_COUNTER_START + int(replays)))  # never rewinds
+                if rewind:
+                    self.rng_counter.fill_(_GRAPH_COUNTER_START + int(replays))
+                else:
+                    self.rng_counter.copy_(torch.clamp(self.rng_counter, min=_GRAPH_COUNTER_START + int(replays)))  # never rewinds
             else:
                 self.engine.calls += int(replays)
 

@@ -37,13 +37,23 @@ def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None) -
         return  # (the model is replicated: no rank has anything to reduce)
     mask = tuple(p.grad is not None for p in params)
     dev = params[0].device
-    flags = _mask_tensors.get((dev, mask))
+    # the bucket travels in the widest dtype among the parameters (fp32 networks: fp32; an fp64 parameter keeps its precision --
+    # the bucket used to be cast to fp32), the flags with it
+    dtype = params[0].dtype
+    for p in params[1:]:
+        dtype = torch.promote_types(dtype, p.dtype)
+    flags = _mask_tensors.get((dev, mask, dtype))
     if flags is None:
-        flags = _mask_tensors[(dev, mask)] = torch.tensor([1.0 if m else 0.0 for m in mask], device=dev, dtype=torch.float32)
+        flags = _mask_tensors[(dev, mask, dtype)] = torch.tensor([1.0 if m else 0.0 for m in mask], device=dev, dtype=dtype)
     n_flag = len(params)
-    pieces = [p.grad.reshape(-1).float() if p.grad is not None else torch.zeros(p.numel(), device=dev, dtype=torch.float32)
-              for p in params]
-    flat = torch.cat(pieces + [flags])
+    sizes = [p.numel() for p in params]
+    # ONE zero-filled bucket; the gradients that exist are copied into their slices (no per-parameter zero tensors)
+    flat = torch.zeros(sum(sizes) + n_flag, device=dev, dtype=dtype)
+    slots = flat[:-n_flag].split(sizes)
+    have = [(slot, p.grad.reshape(-1)) for slot, p in zip(slots, params) if p.grad is not None]
+    if have:
+        torch._foreach_copy_([a for a, _ in have], [b for _, b in have])
+    flat[-n_flag:].copy_(flags)
     if dist.get_backend(group) == "gloo" and flat.is_cuda:
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
@@ -61,9 +71,6 @@ def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], group=None) -
             if bool(bad):
                 raise RuntimeError("all_reduce_gradients: the ranks disagree on which parameters have gradients")
             _checked_masks.add(key)
-    offset = 0
-    for p in params:
-        n = p.numel()
-        if p.grad is not None:
-            p.grad.copy_(grads[offset:offset + n].view_as(p))
-        offset += n
+    back = [(p.grad, g.view_as(p)) for p, g in zip(params, grads.split(sizes)) if p.grad is not None]
+    if back:
+        torch._foreach_copy_([a for a, _ in back], [b for _, b in back])  # (casts back to each gradient's own dtype)

@@ -20,8 +20,8 @@ The reference trainer skips the optimizer step when the loss or a gradient is no
 solver/base.py:409-432) -- a host decision.  Here the same decision is taken on the device (`guard=True`): parameters and
 optimizer state are snapshotted before `optimizer.step()`, the step runs on sanitised gradients, and everything is put back
 when the step was not acceptable (exactly: new = ok * new + (1 - ok) * old with ok in {0, 1}); `n_skipped` counts those steps.
-Without it a single bad batch poisons Adam's moments for good.  Not available in a captured step: data-parallel loss shares
-(they go through the host).
+Without it a single bad batch poisons Adam's moments for good.  Data parallelism: pass the gradient all-reduce as
+`reduce_gradients=` -- it runs BEFORE the check, so every rank decides on the same reduced gradients.
 
 Platform caveat (torch 2.10 + ROCm 7.x): two consecutive multi-block framework reductions captured into one hipGraph return a
 corrupted second result from the second replay on (tests/perf/rocm_graph_two_reductions.py reproduces it with PyTorch alone).
@@ -51,15 +51,20 @@ class GraphedTrainStep:
                      only read tensors that stay alive (parameters, `ts`, buffers of the prior / target)
     losses           the loss objects `loss_fn` calls (their `rng_counter` / `graph_safe` are set here)
     optimizer        for Adam/AdamW pass `capturable=True`
-    after_backward   optional () -> None between backward and the optimizer step (gradient clipping, ...), also captured
+    reduce_gradients optional () -> None right after backward, BEFORE the finite-gradient guard (data parallelism:
+                     `lambda: all_reduce_gradients(params)`): the accept / reject decision is then taken on the REDUCED gradients
+                     and is the same on every rank -- a NaN from another rank, or the disagreement poison of
+                     `all_reduce_gradients`, rejects the step everywhere; also captured
+    after_backward   optional () -> None between the guard's check and the optimizer step (gradient clipping -- the reference clips
+                     only steps it accepted, solver/base.py:421-427), also captured
     warmup           eager steps on the side stream before capturing (allocator warm-up; they DO update the parameters)
     guard            skip the update on the device when the loss or a gradient is not finite (solver/base.py:409-432)
     max_loss         with guard: additionally require |loss| <= max_loss (the reference's `max_loss`)
     """
 
     def __init__(self, loss_fn: Callable[[], torch.Tensor], losses: Iterable, optimizer: torch.optim.Optimizer, *,
-                 after_backward: Callable[[], None] | None = None, warmup: int = 3, device=None, guard: bool = True,
-                 max_loss: float | None = None):
+                 after_backward: Callable[[], None] | None = None, reduce_gradients: Callable[[], None] | None = None,
+                 warmup: int = 3, device=None, guard: bool = True, max_loss: float | None = None):
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedTrainStep needs a GPU (hipGraph capture)")
         for group in optimizer.param_groups:
@@ -68,7 +73,7 @@ class GraphedTrainStep:
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.losses = list(losses)
         self.optimizer = optimizer
-        self._loss_fn, self._after_backward = loss_fn, after_backward
+        self._loss_fn, self._after_backward, self._reduce_gradients = loss_fn, after_backward, reduce_gradients
         self.counter = torch.full((1,), COUNTER_START, dtype=torch.int64, device=self.device)
         for lo in self.losses:
             lo.rng_counter = self.counter
@@ -85,6 +90,18 @@ class GraphedTrainStep:
         with torch.cuda.stream(side):
             for _ in range(max(int(warmup), 1)):
                 self._step()
+            # guard: the (tensor, snapshot) pointer table of `_restore` must exist before the capture -- it is built by a host-to-device
+            # copy, which a capture cannot contain.  A lazily initialised optimizer state (Adam) appears in the first step and the table
+            # follows one step later: keep stepping eagerly until a step has left it alone (warmup <= 1 used to rebuild it
+            # inside the capture).  These are real optimisation steps, like the warm-up's.
+            extra = 0
+            while self.guard and not self._table_ready():
+                if extra == 4:
+                    raise RuntimeError("GraphedTrainStep(guard=True): the optimizer state keeps changing its tensors from step to step; "
+                                       "it cannot be captured")
+                self._step()
+                extra += 1
+        self.extra_warmup = extra if self.guard else 0
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
 
@@ -96,6 +113,9 @@ class GraphedTrainStep:
     def _restore(self, tensors: list[torch.Tensor], ok: torch.Tensor) -> None:
         key = tuple(t.data_ptr() for t in tensors) + tuple(s.data_ptr() for s in self._snap)
         if self._table_key != key:  # (built while the optimizer state appears; fixed from the last warm-up step on, i.e. in the capture)
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("GraphedTrainStep(guard=True): parameters or optimizer state moved between the last eager step and the "
+                                   "capture (the pointer table of the update guard cannot be built inside a capture)")
             rows = []
             for t, s in zip(tensors, self._snap):
                 if not (t.is_contiguous() and s.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0):
@@ -113,6 +133,13 @@ class GraphedTrainStep:
         for p in self._params:
             out += [v for v in self.optimizer.state.get(p, {}).values() if isinstance(v, torch.Tensor)]
         return out
+
+    def _table_ready(self) -> bool:
+        """The pointer table `_restore` will ask for in the NEXT step exists already (same tensors, same snapshots)."""
+        tensors = self._guarded()
+        if self._snap is None or len(self._snap) != len(tensors) or self._table is None:
+            return False
+        return self._table_key == tuple(t.data_ptr() for t in tensors) + tuple(s.data_ptr() for s in self._snap)
 
     def _step(self) -> torch.Tensor:
         self.optimizer.zero_grad(set_to_none=True)
@@ -134,6 +161,8 @@ class GraphedTrainStep:
         for p, g in zip(owners + rest, grads):
             if g is not None:
                 p.grad = g if p.grad is None else p.grad + g
+        if self._reduce_gradients is not None:
+            self._reduce_gradients()
         if not self.guard:
             if self._after_backward is not None:
                 self._after_backward()

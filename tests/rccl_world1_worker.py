@@ -71,7 +71,7 @@ def run_graphed(tag: str) -> dict:
             x = prob.prior.sample((2048,))
             return prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
 
-        step = GraphedTrainStep(loss_fn, [prob.loss], opt, after_backward=lambda: all_reduce_gradients(params), warmup=2, guard=True)
+        step = GraphedTrainStep(loss_fn, [prob.loss], opt, reduce_gradients=lambda: all_reduce_gradients(params), warmup=2, guard=True)
         losses = [float(step()) for _ in range(3)]
         # an eager step of the same kind must not synchronise either
         torch.cuda.synchronize()

@@ -409,3 +409,65 @@ def test_guard_check_decides_like_the_reference_trainer(n):
         L.check(lib.sdeh_guard_check(g.data_ptr(), n, v.data_ptr(), -1.0 if max_loss is None else max_loss, ok.data_ptr(), st))
         assert bool(ok) == want, (value, max_loss, poison)
         assert torch.equal(g, kept) if want else not g.any()
+
+
+@pytest.mark.gpu
+def test_guarded_capture_with_one_warmup_step_builds_its_pointer_table_first():
+    """with warmup = 1 and Adam (state appears in the first step) the update guard's pointer table used to be built -- a
+    host-to-device copy -- inside the capture.  The constructor now keeps stepping eagerly until the table the capture will ask for exists."""
+    from sde_sampler_amd.utils.graphs import GraphedTrainStep
+
+    prob = _build(4, "lv")
+    x = prob.prior.sample((512,))
+    params = _params(prob)
+    opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+    fn = lambda: prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
+    graphed = GraphedTrainStep(fn, [prob.loss], opt, warmup=1)
+    assert graphed.extra_warmup == 1 and graphed._table_ready()
+    before = [p.detach().clone() for p in params]
+    for _ in range(3):
+        assert torch.isfinite(graphed())
+    assert int(graphed.n_skipped) == 0 and any(not torch.equal(p, q) for p, q in zip(params, before))
+    # the default warm-up needs no extra step (existing runs keep their step count)
+    prob2 = _build(4, "lv")
+    opt2 = torch.optim.Adam(_params(prob2), lr=1e-3, capturable=True)
+    fn2 = lambda: prob2.loss(prob2.ts, x, prob2.target.unnorm_log_prob, prob2.second_log_prob)[0]
+    assert GraphedTrainStep(fn2, [prob2.loss], opt2, warmup=2).extra_warmup == 0
+
+
+@pytest.mark.gpu
+def test_guard_decides_on_the_reduced_gradients():
+    """`reduce_gradients` (the data-parallel all-reduce) runs BEFORE the finite-gradient check, so a NaN that arrives with the
+    reduction (another rank's, or all_reduce_gradients' disagreement poison) rejects the step; `after_backward` (clipping) runs after the
+    check, on accepted steps' gradients, as solver/base.py:409-427 orders them."""
+    from sde_sampler_amd.utils.graphs import GraphedTrainStep
+
+    prob = _build(5, "lv")
+    x = prob.prior.sample((512,))
+    params = _params(prob)
+    opt = torch.optim.Adam(params, lr=1e-3, capturable=True)
+    other_rank = torch.zeros((), device="cuda:0")  # what "arrives" with the reduction: 0 = nothing, NaN = a poisoned bucket
+    order = []
+
+    def reduce():
+        order.append("reduce")
+        for p in params:
+            if p.grad is not None:
+                p.grad.add_(other_rank)
+
+    def clip():
+        order.append("clip")
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+
+    fn = lambda: prob.loss(prob.ts, x, prob.target.unnorm_log_prob, prob.second_log_prob)[0]
+    graphed = GraphedTrainStep(fn, [prob.loss], opt, reduce_gradients=reduce, after_backward=clip, warmup=3)
+    assert order[:2] == ["reduce", "clip"]
+    graphed()
+    before = [p.detach().clone() for p in params]
+    other_rank.fill_(float("nan"))
+    graphed()
+    assert int(graphed.n_skipped) == 1 and all(torch.equal(p, q) for p, q in zip(params, before))
+    other_rank.zero_()
+    graphed()
+    assert int(graphed.n_skipped) == 1 and any(not torch.equal(p, q) for p, q in zip(params, before))
+    assert all(torch.isfinite(p).all() for p in params)

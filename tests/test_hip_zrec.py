@@ -221,3 +221,75 @@ def test_record_respects_its_memory_budget(monkeypatch):
     monkeypatch.delenv("SDEH_ZREC_BYTES")
     v1, g1, n1 = _grads(prob, x0, True)
     assert n1.endswith(",zrec>") and v1 == v
+
+
+RAGGED = [  # (spec, method, batch, steps, forward mode options): every forward mode in which the VECTOR wave writes the raw network output
+    ("cfg2_gmm2_dis_kl", "lv", 777, 6, {}),                                           # d <= 4, groups of 32: out layer on the vector pipe
+    ("cfg2_gmm2_dis_kl", "kl", 515, 6, {}),                                           # scan form (Jacobian pass reads the record)
+    ("cfg2_gmm2_dis_kl", "kl", 5003, 5, {}),                                          # teams of 16 through time
+    ("cfg1_dw_dis_lv", "kl_ito", 4097 + 13, 5, {}),                                   # d = 1
+    ("cfg4_funnel_dds_lv", "lv", 1001, 6, {"SDEH_WS_QUAD": "0", "SDEH_WS_GROUPS": "p"}),   # pair mode: the partial sums meet in the V wave
+    ("cfg4_funnel_dds_lv", "kl", 2045, 5, {"SDEH_WS_QUAD": "1"}),                     # quad mode
+    ("cfg4_funnel_dds_lv", "kl", 16 * 1024 + 70, 4, {}),                              # groups of 64 (the M wave stores whole tiles)
+    ("cfg3_gmm50_pis_kl", "kl", 1003, 4, {}),                                         # d > 32: M waves store the output tiles
+]
+
+
+@pytest.mark.parametrize("name,method,batch,steps,opts", RAGGED, ids=[f"{c[0]}-{c[1]}-{c[2]}" for c in RAGGED])
+def test_ragged_last_tile_of_an_unclipped_control_on_a_poisoned_record(name, method, batch, steps, opts, monkeypatch):
+    """the record is uninitialised memory; rows of the last 32-row tile beyond the batch used to keep whatever it
+    held, and with `clip_model = None` (the clamp is +-inf) a NaN there reached the d gamma / clip partial sums as 0 x NaN.  The forward
+    launch now writes zeros for those rows: a record PREFILLED WITH NaN gives the gradients of the re-evaluating launch."""
+    from sde_sampler_amd import engine as E
+
+    assert batch % 32 != 0
+    prob, spec = _build(name, batch, method, steps=steps)
+    prob.ctrl.clip_model = None  # no clamp on the network output: clipf(NaN, inf) stays NaN
+    prob.loss.engine.invalidate()
+    x0 = prob.prior.sample((batch,))
+    seen = {}
+
+    def poisoned(n_floats, device):
+        seen["n"] = n_floats
+        return torch.full((n_floats,), float("nan"), device=device, dtype=torch.float32)
+
+    monkeypatch.setattr(E, "_alloc_zrec", poisoned)
+    v1, g1, n1 = _grads(prob, x0, True, opts)
+    monkeypatch.undo()
+    v0, g0, n0 = _grads(prob, x0, False, opts)
+    assert "n" in seen and n1.endswith("zrec>") and "zrec" not in n0, (n1, n0)
+    assert v1 == v0 and np.isfinite(v1)
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), f"{k}: non-finite gradient from the record's rows beyond the batch"
+        err = float((g1[k] - g0[k]).abs().max()) / max(float(g0[k].abs().max()), 1e-3 * gmax, 1e-12)
+        assert err <= 2e-5, f"{k}: {err:.2e}"
+
+
+def test_record_budget_is_decided_once_per_size(monkeypatch):
+    """the 40 %-of-free-memory decision is cached per (device, record size) -- no driver query on later steps, the same
+    launches every step; a failed allocation withdraws it."""
+    from sde_sampler_amd import engine as E
+
+    monkeypatch.delenv("SDEH_ZREC_BYTES", raising=False)
+    E.reset_zrec_budget()
+    calls = {"n": 0}
+    real = torch.cuda.mem_get_info
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(torch.cuda, "mem_get_info", counting)
+    prob, spec = _build("cfg2_gmm2_dis_kl", 1024, "lv", steps=5)
+    x0 = prob.prior.sample((1024,))
+    names = [_grads(prob, x0, True)[2] for _ in range(3)]
+    assert calls["n"] == 1 and all(n.endswith(",zrec>") for n in names), (calls, names)
+    key = next(iter(E._ZREC_DECISION))
+    monkeypatch.setattr(E.torch, "empty", lambda *a, **k: (_ for _ in ()).throw(torch.OutOfMemoryError("simulated")))
+    assert E._alloc_zrec(key[1] // 4, DEV) is None
+    monkeypatch.undo()
+    assert E._ZREC_DECISION[key] is False
+    assert "zrec" not in _grads(prob, x0, True)[2]
+    E.reset_zrec_budget()
+    assert _grads(prob, x0, True)[2].endswith(",zrec>")

@@ -188,6 +188,8 @@ def test_loss_contract():
     assert int(graphed.rng_counter) == COUNTER_START + 9
     graphed.load_state_dict(sd)  # ... and never backwards
     assert int(graphed.rng_counter) == COUNTER_START + 9
+    graphed.load_state_dict(sd, rewind=True)  # ... unless asked to: reproducing an earlier stretch of the run in the same process
+    assert int(graphed.rng_counter) == COUNTER_START + 5
     graphed.rng_counter.fill_(COUNTER_START + 5)
     eager = ExponentialIntegratorSDELoss(generative_ctrl=None, alpha=1.0, sigma=2.0, method="lv")
     eager.load_state_dict(dict(sd, rng_calls=3))  # graphed -> eager: only the replay count joins the calls, no carry into the stream id

@@ -47,6 +47,15 @@ WORKLOADS = {
     "cfg5_like_bridge196": ("cfg5_like_bridge196", "trajectory-steps/sec, Bridge d=196 C=256 (BASELINE configs[4] shape)",
                             "Bridge (LerpTargetCtrl + LerpPriorCtrl inference control, exact divergence), funnel d=196 target "
                             "in place of the unfusable NICE flow, two FourierMLP C=256 L=4 GELU, ScaledBM(1, T=1)"),
+    # BASELINE configs[4] AS WRITTEN: target = nice.  The flow's score is evaluated by csrc/sdeh_nice.hip between the one-step segments of
+    # the wide Bridge kernel (engine.run: SDEH_DENS_EXTERNAL); weights: the checkpoint's geometry, seeded random (data/nice.pt is not shipped)
+    "cfg5_nice_bridge196": ("cfg5_nice_bridge196", "trajectory-steps/sec, Bridge d=196 C=256 on the NICE flow (BASELINE configs[4] as written)",
+                            "Bridge (LerpTargetCtrl on the NICE flow's score + LerpPriorCtrl inference control, exact divergence), NiceModel "
+                            "coupling=4 mid_dim=500 hidden=5 (scripts/train_nice.py geometry, seeded random weights), two FourierMLP C=256 "
+                            "L=4 GELU, ScaledBM(1, T=1)"),
+    "train_cfg5_nice": ("cfg5_nice_bridge196", "trajectory-steps/sec of one optimisation step (forward + backward + Adam), Bridge lv on the NICE flow, d=196 C=256",
+                        "BASELINE configs[4] as written: conf/solver/bridge.yaml's loss (time_reversal_lv, exact divergence) on the NICE flow, "
+                        "T=200, batch 4096 per GPU (32 768 / 8)"),
     # one optimisation step (loss forward, backward, Adam) -- the reference's Trainable.step (solver/base.py:399-454) on the HIP path
     "train_gmm2_dis_kl": ("cfg2_gmm2_dis_kl", "trajectory-steps/sec of one optimisation step (forward + backward + Adam), DIS kl, GMM-40 d=2",
                           "BASELINE configs[1]: GMM-40 d=2, basic_dis (LerpCtrl, FourierMLP C=64 L=4 GELU, VP), loss.method=kl, "
@@ -62,7 +71,7 @@ WORKLOADS = {
                           "funnel d=196, basic_pis-style, FourierMLP C=256 L=4 GELU, loss.method=lv, T=200, batch 8192"),
 }
 #: default batch / loss method of the wide training workloads (the others: 65 536 and the spec's method)
-TRAIN_DEFAULTS = {"train_cfg5_like": (4096, "lv"), "train_wide_pis_lv": (8192, "lv")}
+TRAIN_DEFAULTS = {"train_cfg5_like": (4096, "lv"), "train_wide_pis_lv": (8192, "lv"), "train_cfg5_nice": (4096, "lv")}
 
 
 #: the translation-unit sources of the headline trajectory kernel: `profiles/pmc_headline.json` is stamped with their hash, and its
@@ -104,7 +113,24 @@ def algorithmic_flops(spec: dict) -> float:
         # hidden layer 2) and a length-C dot product -- the reference's d backward passes cost about twice that.
         ci, lhi = spec.get("inference_net", spec["net"])["channels"], spec.get("inference_net", spec["net"])["num_layers"] - 2
         f += 4 * d * ci + 2 * lhi * ci * ci + d * (2 * lhi * ci * ci + 2 * ci)
+    f += nice_flops(spec["target"])
     return f
+
+
+def nice_flops(tspec: dict) -> float:
+    """The NICE flow's score per trajectory-step (distr/nice.py): every coupling's MLP forward and its reverse pass (d / d x only: the
+    weights are constants), 2 FLOPs per multiply-add: 2 x 2 x coupling x (2 (d / 2) mid + (hidden - 1) mid^2)."""
+    if tspec.get("kind") != "nice":
+        return 0.0
+    half, mid, hidden, n_c = tspec["dim"] // 2, tspec.get("mid_dim", 500), tspec.get("hidden", 5), tspec.get("coupling", 4)
+    return 4.0 * n_c * (2 * half * mid + (hidden - 1) * mid * mid)
+
+
+def target_state(spec: dict, prob):
+    """What the CPU oracle needs of a target besides its spec: the NICE flow's weights (oracle/em_oracle.py Density("nice"))."""
+    if spec["target"]["kind"] == "nice":
+        return {k: v.detach().cpu().clone() for k, v in prob.target.model.state_dict().items()}
+    return None
 
 
 def physical_cores() -> int:
@@ -519,7 +545,7 @@ def run_train(args, device):
     params_cpu = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
     params_inf_cpu = {k: v.detach().clone() for k, v in inf.state_dict().items()} if inf is not None else None
     tt = (dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(), mixture_weights=prob.target.mixture_weights.clone())
-          if spec["target"]["kind"] == "gmm" else None)
+          if spec["target"]["kind"] == "gmm" else target_state(spec, prob))
     prob.to(device)
     B, T, d = spec["batch"], prob.ts.numel() - 1, spec["target"]["dim"]
     c, lh = spec["net"]["channels"], spec["net"]["num_layers"] - 2
@@ -644,7 +670,7 @@ def run(args, rank: int, world: int, local_rank: int):
     inf = getattr(prob.loss, "inference_ctrl", None)
     cpu_state = ({k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()},
                  dict(loc=prob.target.loc.clone(), scale=prob.target.scale.clone(),
-                      mixture_weights=prob.target.mixture_weights.clone()) if spec["target"]["kind"] == "gmm" else None,
+                      mixture_weights=prob.target.mixture_weights.clone()) if spec["target"]["kind"] == "gmm" else target_state(spec, prob),
                  {k: v.detach().clone() for k, v in inf.state_dict().items()} if inf is not None else None)
     prob.to(device)
     B, T, d = spec["batch"], prob.ts.numel() - 1, spec["target"]["dim"]
@@ -670,14 +696,25 @@ def run(args, rank: int, world: int, local_rank: int):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # a target evaluated between one-step segments (the NICE flow): the "kernel" of the roofline is the whole evaluation -- T segment
+    # launches + T evaluations of the flow's score, every one on torch's current stream -- between two events on that stream
+    stepped = spec["target"]["kind"] == "nice"
     for _ in range(args.warmup):
         step()
     kernel_ms = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if stepped:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         res = step()
-        kernel_ms.append(prob.loss.engine.last_kernel_ms())
+        if stepped:
+            e1.record()
+            e1.synchronize()
+            kernel_ms.append(e0.elapsed_time(e1))
+        else:
+            kernel_ms.append(prob.loss.engine.last_kernel_ms())
     fence()
     elapsed = time.perf_counter() - t0
     scaling_detail = None
@@ -743,7 +780,9 @@ def run(args, rank: int, world: int, local_rank: int):
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "traffic": (2.0 * pmc["FETCH_SIZE_KiB"] + pmc["WRITE_SIZE_KiB"]) * 1024.0 if pmc else None,
                 "algorithmic_hbm_bytes": B * (8 * d + 4),
-                "kernel": prob.loss.engine.last_kernel_name(), "kernel_ms": k_ms, "kernel_ms_min": min(kernel_ms),
+                "kernel": (prob.loss.engine.last_kernel_name() + f" x {T} one-step segments + nice_gemm (csrc/sdeh_nice.hip: {T} score evaluations)"
+                           if stepped else prob.loss.engine.last_kernel_name()),
+                "kernel_ms": k_ms, "kernel_ms_min": min(kernel_ms),
                 "flops_per_traj_step": flops,
                 "note": "fp32 MFMA and fp32 VALU share one datapath on gfx950 (profiles/r01_ubench_coexec.txt): 157.3 TFLOP/s is "
                         "the budget for both; `achieved` counts SURVEY 8d's ALGORITHMIC FLOPs; `executed_tflops` counts the "
@@ -826,12 +865,12 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="testing aid: all ranks use cuda:0 (with --backend gloo) to exercise the N > 1 path on one GPU")
     args = ap.parse_args()
-    heavy = args.workload in ("wide_pis_funnel196", "cfg5_like_bridge196", "train_cfg5_like")
+    heavy = args.workload in ("wide_pis_funnel196", "cfg5_like_bridge196", "train_cfg5_like", "cfg5_nice_bridge196", "train_cfg5_nice")
     train = args.workload.startswith("train_")
     if args.steps is None:
-        args.steps = (3 if args.workload == "train_cfg5_like" else 5) if heavy else ((20 if args.workload == "train_wide_pis_lv" else 100) if train else 1000)
+        args.steps = (3 if args.workload in ("train_cfg5_like", "train_cfg5_nice") else 5) if heavy else ((20 if args.workload == "train_wide_pis_lv" else 100) if train else 1000)
     if args.warmup is None:
-        args.warmup = (1 if args.workload == "train_cfg5_like" else 2) if heavy else (5 if train else 20)
+        args.warmup = (1 if args.workload in ("train_cfg5_like", "train_cfg5_nice") else 2) if heavy else (5 if train else 20)
     if train:
         if args.gpus != 1 or os.environ.get("WORLD_SIZE") not in (None, "1"):
             raise SystemExit("the training workloads are single-GPU measurements (data-parallel training: tests/test_distributed_gloo.py)")

@@ -34,8 +34,11 @@ extern "C" {
  * the plan; nothing on the launch path reads the environment or allocates); the 64-channel Bridge as a split -- sdeh_simulate_fwd_train2u,
  * sdeh_bridge_inference_fwd, sdeh_bridge_backward_fused[_sizes], sdeh_ctrl_backward_fused_ex.
  * v6 (round 5): the training forward keeps the network's pre-activations and the fused backward reads them instead of re-evaluating the
- * network -- sdeh_zrec_floats, sdeh_simulate_fwd_train3, sdeh_ctrl_backward_fused_z; plan option SDEH_BWD_ZREC. */
-#define SDEH_ABI_VERSION 6
+ * network -- sdeh_zrec_floats, sdeh_simulate_fwd_train3, sdeh_ctrl_backward_fused_z; plan option SDEH_BWD_ZREC.
+ * v7 (round 6): BASELINE configs[4]'s target -- the NICE flow (distr/nice.py) as a row-parallel log-density + score evaluation
+ * (SdehNice, sdeh_nice_work_floats, sdeh_nice_eval), a target whose score is SUPPLIED per step (SDEH_DENS_EXTERNAL) and the wide
+ * kernels run in segments of the time grid around it (sdeh_simulate_fwd_steps). */
+#define SDEH_ABI_VERSION 7
 #define SDEH_MAX_HIDDEN 8 /* max entries of any nn.ModuleList of hidden layers */
 
 typedef enum {
@@ -62,7 +65,11 @@ typedef enum {
   SDEH_DENS_DIAG_GAUSS = 2, /* loc[d], scale[d]   (Gauss / IsotropicGauss / Delta / sde.marginal_distr) */
   SDEH_DENS_MULTI_WELL = 3, /* n_components double wells then (dim-n_components) unit Gaussians at `shift`;
                                DoubleWell == {dim 1, n_components 1} */
-  SDEH_DENS_FUNNEL = 4      /* p0 = variance of the first coordinate (default dim-1) */
+  SDEH_DENS_FUNNEL = 4,     /* p0 = variance of the first coordinate (default dim-1) */
+  SDEH_DENS_EXTERNAL = 5    /* v7, wide plans through sdeh_simulate_fwd_steps only: the target's score at x_t is SUPPLIED by the caller
+                               per step (sdeh_simulate_fwd_steps: `ext_score`), its terminal log-density is subtracted by the caller
+                               after the last segment.  What the NICE target of BASELINE configs[4] runs on (sdeh_nice_eval evaluates
+                               the flow's score between the segments) */
 } SdehDensityKind;
 /* activation callable injected by conf/model/base/fouriermlp.yaml:5-6 (default torch.nn.GELU, exact erf) */
 typedef enum { SDEH_ACT_GELU_ERF = 0, SDEH_ACT_SILU = 1, SDEH_ACT_RELU = 2,
@@ -546,6 +553,63 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* problem, int32_t kind,
                        int32_t n_steps, const float* ts_out, int32_t n_out, float eps, const float* x_init,
                        int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                        float* xs_out, void* stream);
+
+/*
+ * The NICE flow target of BASELINE configs[4] (reference distr/nice.py:233-298 `Nice` around `NiceModel` 123-231: additive couplings
+ * `Coupling` 43-97 -- in_block Linear + ReLU, hidden - 1 mid blocks, out_block Linear --, `Scaling` 100-120, `StandardLogistic` prior
+ * 17-40).  One row-parallel evaluation of what the losses ask of a target:
+ *   unnorm_log_prob(x) = sum_j -(softplus(z_j) + softplus(-z_j)) + sum_j scale_j + log_norm_const,  z = f(x) * exp(scale)
+ *                        (nice.py:176-189, 276-277)
+ *   score(x)           = d unnorm_log_prob / d x   (the reference differentiates with autograd, distr/base.py:130-137): the reverse
+ *                        pass through the couplings (weights are constants: `requires_grad_(False)`, nice.py:271-273)
+ * Every Linear is a [batch, K] x [K, N] product on the fp32 matrix pipe (csrc/sdeh_nice.hip: 64 x 128 tiles staged through LDS, bias /
+ * ReLU / ReLU-mask / residual add in the epilogue).  Parameters are read from the given pointers on every call (nn.Linear layout
+ * [out, in]); nothing is cached between calls.
+ */
+#define SDEH_NICE_MAX_COUPLING 8
+typedef struct {
+  int32_t dim;        /* in_out_dim: even, <= 256 (nice.py: 196) */
+  int32_t n_coupling; /* len(model.coupling) <= SDEH_NICE_MAX_COUPLING (train_nice.py: 4) */
+  int32_t mid_dim;    /* units of a hidden layer, a multiple of 4 (train_nice.py: 500) */
+  int32_t n_mid;      /* len(coupling[i].mid_block) = hidden - 1 <= SDEH_MAX_HIDDEN (train_nice.py: 4) */
+  int32_t mask_config[SDEH_NICE_MAX_COUPLING]; /* coupling[i].mask_config != 0: x[:, :, 0] is transformed ("on"), x[:, :, 1] feeds the MLP */
+  const float* in_w[SDEH_NICE_MAX_COUPLING];   /* coupling[i].in_block[0].weight [mid_dim, dim / 2] */
+  const float* in_b[SDEH_NICE_MAX_COUPLING];   /* [mid_dim] */
+  const float* mid_w[SDEH_NICE_MAX_COUPLING][SDEH_MAX_HIDDEN]; /* coupling[i].mid_block[l][0].weight [mid_dim, mid_dim] */
+  const float* mid_b[SDEH_NICE_MAX_COUPLING][SDEH_MAX_HIDDEN];
+  const float* out_w[SDEH_NICE_MAX_COUPLING];  /* coupling[i].out_block.weight [dim / 2, mid_dim] */
+  const float* out_b[SDEH_NICE_MAX_COUPLING];  /* [dim / 2] */
+  const float* scale;   /* scaling.scale [dim] (the reference's [1, dim]) */
+  float log_norm_const; /* Nice.log_norm_const (nice.py:240, 0.0) */
+} SdehNice;
+/* floats of caller-owned work memory for a batch: the couplings' hidden activations (kept for the reverse pass when a score is asked
+ * for) + the de-interleaved halves of x and of the gradient */
+int64_t sdeh_nice_work_floats(const SdehNice* nice, int64_t batch, int32_t want_score);
+/* x [batch, dim] -> score [batch, dim] (or NULL: log-density only) and logp [batch] (or NULL) */
+int32_t sdeh_nice_eval(const SdehNice* nice, const float* x, int64_t batch, float* score, float* logp, float* work,
+                       int64_t work_floats, void* stream);
+
+/*
+ * sdeh_simulate_fwd_aux2 in SEGMENTS of the time grid, for a target whose score is not built into the kernels (v7; wide plans).  Runs
+ * the Euler-Maruyama steps [step_begin, step_end) of the grid ts[0 .. n_steps]; the per-step tables (coefficients, time embeddings,
+ * gamma) are prepared for the WHOLE grid by the segment that starts at step 0 and live in the plan's workspace until the last segment
+ * has run (no other launch on this plan in between).  Step indices, Philox counters and the rows of xs / gp are those of the whole grid:
+ * a chain of segments draws the noise one launch over all steps would.
+ *   x_in  [batch, d]   state at ts[step_begin]                 x_out [batch, d]  state at ts[step_end] (a different buffer than x_in)
+ *   rnd   [batch]      in/out: initialised by the segment starting at step 0 (initial log-density term per the problem's flags), read
+ *                      and advanced by the others.  The terminal log-density of a built-in target is subtracted by the segment that
+ *                      ends at n_steps; with target.kind = SDEH_DENS_EXTERNAL the caller subtracts it (and applies clip_target).
+ *   ext_score          SDEH_DENS_EXTERNAL: the target's score at x_t for the steps of this segment, [step_end - step_begin, batch, d]
+ *                      starting at this segment's first step (ext_stride = batch * d), or one [batch, d] buffer for a one-step
+ *                      segment (ext_stride = 0); NULL otherwise
+ *   xs [n_steps + 1, batch, d], gp [n_steps, batch, d]: as sdeh_simulate_fwd_aux2 (rows of this segment's steps are written), or NULL
+ * The network part of a Bridge's divergence is accumulated per segment (its partial sums join rnd at the end of each segment): equal to
+ * the one-launch result up to the order of that fp32 sum.
+ */
+int32_t sdeh_simulate_fwd_steps(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, int32_t step_begin,
+                                int32_t step_end, const float* x_in, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                                int64_t row_offset, float* x_out, float* rnd, float* xs, float* gp, const float* ext_score,
+                                int64_t ext_stride, void* stream);
 
 /*
  * Entropy-regularised optimal-transport cost between two point clouds.  Replaces Sinkhorn.compute (eval/sinkhorn.py:

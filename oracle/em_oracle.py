@@ -199,6 +199,11 @@ class Density:
         elif self.kind == "funnel":
             var = spec.get("variance") or (self.dim - 1)
             self.first = Density(dict(kind="iso_gauss", dim=1, scale=math.sqrt(var)))
+        elif self.kind == "nice":  # distr/nice.py:233-298 around NiceModel 123-231; tensors = the model's state_dict
+            self.nice = {k: v for k, v in t.items()}
+            self.n_coupling = 1 + max(int(k.split(".")[1]) for k in self.nice if k.startswith("coupling."))
+            self.n_mid = 1 + max((int(k.split(".")[3]) for k in self.nice if ".mid_block." in k), default=-1)
+            self.mask_config = spec.get("mask_config", 1.0)
         else:
             raise ValueError(self.kind)
 
@@ -230,6 +235,26 @@ class Density:
             x_sq_sum = (x_other**2).sum(dim=-1, keepdim=True)
             lp_other = norm_const - 0.5 * x_sq_sum * (-x_first).exp()
             return lp_first + lp_other + self.log_norm_const
+        if k == "nice":  # nice.py:276-277 -> NiceModel.log_prob 176-189 -> f 164-174 -> Coupling.forward 64-97, Scaling 112-120
+            p, F = self.nice, torch.nn.functional
+            z = x
+            for i in range(self.n_coupling):
+                batch, width = z.shape
+                z = z.reshape((batch, width // 2, 2))
+                if (self.mask_config + i) % 2:  # NiceModel.__init__ 146: mask_config of coupling i
+                    on, off = z[:, :, 0], z[:, :, 1]
+                else:
+                    off, on = z[:, :, 0], z[:, :, 1]
+                h = F.relu(F.linear(off, p[f"coupling.{i}.in_block.0.weight"], p[f"coupling.{i}.in_block.0.bias"]))
+                for l in range(self.n_mid):
+                    h = F.relu(F.linear(h, p[f"coupling.{i}.mid_block.{l}.0.weight"], p[f"coupling.{i}.mid_block.{l}.0.bias"]))
+                on = on + F.linear(h, p[f"coupling.{i}.out_block.weight"], p[f"coupling.{i}.out_block.bias"])
+                z = torch.stack((on, off), dim=2) if (self.mask_config + i) % 2 else torch.stack((off, on), dim=2)
+                z = z.reshape((batch, width))
+            scale = p["scaling.scale"]
+            z = z * torch.exp(scale)
+            log_ll = torch.sum(-(F.softplus(z) + F.softplus(-z)), dim=1)  # StandardLogistic.log_prob 21-29
+            return (log_ll + torch.sum(scale)).unsqueeze(-1) + self.log_norm_const
         raise ValueError(k)
 
     def log_prob(self, x: Tensor) -> Tensor:  # distr/base.py:116-119
@@ -249,7 +274,7 @@ class Density:
 
     def score(self, x: Tensor, create_graph=False) -> Tensor:
         k = self.kind
-        if k == "gmm" and self.w is not None:
+        if (k == "gmm" and self.w is not None) or k == "nice":  # (Nice has no score of its own: distr/base.py:130-137)
             return self.autograd_score(x, create_graph=create_graph)
         if k in ("gmm", "diag_gauss", "delta"):  # Gauss.score, distr/gauss.py:182-183
             return (self.loc - x) / self.scale**2
@@ -555,6 +580,8 @@ def problem_from_fixture(fx) -> tuple["Problem", dict]:
     tt = None
     if meta["target"]["kind"] == "gmm":
         tt = {k: torch.from_numpy(fx["target/" + k].copy()) for k in ("loc", "scale", "mixture_weights")}
+    elif meta["target"]["kind"] == "nice":
+        tt = {k[len("target/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("target/")}
     return Problem(meta, params, tt, params_inf or None), params
 
 

@@ -10,7 +10,8 @@ import ctypes as C
 import os
 from pathlib import Path
 
-SDEH_ABI_VERSION = 6
+SDEH_ABI_VERSION = 7
+SDEH_NICE_MAX_COUPLING = 8
 SDEH_MAX_HIDDEN = 8
 SDEH_REDUCE_SCRATCH = 8192
 
@@ -19,6 +20,7 @@ LOSS_TIME_REVERSAL, LOSS_REFERENCE_SDE, LOSS_EXPONENTIAL = 0, 1, 2
 CTRL_CLIPPED, CTRL_SCORE, CTRL_LERP, CTRL_LERP_TARGET, CTRL_LERP_PRIOR, CTRL_NONE = 0, 1, 2, 3, 4, 5
 SDE_NONE, SDE_VP, SDE_CONST_OU = 0, 1, 2
 DENS_NONE, DENS_GMM, DENS_DIAG_GAUSS, DENS_MULTI_WELL, DENS_FUNNEL = 0, 1, 2, 3, 4
+DENS_EXTERNAL = 5  # the target's score is supplied per step (sdeh_simulate_fwd_steps): the NICE flow of BASELINE configs[4]
 ACT_GELU_ERF, ACT_SILU, ACT_RELU, ACT_IDENTITY = 0, 1, 2, 3
 FLAG_TRAIN, FLAG_ITO, FLAG_CHANGE_SDE_CTRL, FLAG_INIT_LOGP = 1, 2, 4, 8
 FLAG_TERMINAL_TARGET, FLAG_TERMINAL_SECOND, FLAG_REFERENCE_CTRL = 16, 32, 64
@@ -79,6 +81,18 @@ class SdehProblem(C.Structure):
         ("target", SdehDensity), ("prior", SdehDensity), ("second", SdehDensity),
         ("inference", SdehInferenceCtrl),
         ("rng_offset_dev", C.c_void_p),
+    ]
+
+
+class SdehNice(C.Structure):
+    """distr/nice.py NiceModel: additive couplings (in_block / mid_block / out_block), scaling, logistic prior."""
+    _fields_ = [
+        ("dim", C.c_int32), ("n_coupling", C.c_int32), ("mid_dim", C.c_int32), ("n_mid", C.c_int32),
+        ("mask_config", C.c_int32 * SDEH_NICE_MAX_COUPLING),
+        ("in_w", fp * SDEH_NICE_MAX_COUPLING), ("in_b", fp * SDEH_NICE_MAX_COUPLING),
+        ("mid_w", (fp * SDEH_MAX_HIDDEN) * SDEH_NICE_MAX_COUPLING), ("mid_b", (fp * SDEH_MAX_HIDDEN) * SDEH_NICE_MAX_COUPLING),
+        ("out_w", fp * SDEH_NICE_MAX_COUPLING), ("out_b", fp * SDEH_NICE_MAX_COUPLING),
+        ("scale", fp), ("log_norm_const", C.c_float),
     ]
 
 
@@ -172,6 +186,10 @@ PROTOTYPES = {
     "sdeh_integrate": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), C.c_int32, fp, C.c_int32, fp, C.c_int32, C.c_float,
                                    fp, C.c_int64, fp, C.c_uint64, C.c_uint64, C.c_int64, fp, C.c_void_p]),
     "sdeh_sinkhorn_workspace_floats": (C.c_int64, [C.c_int64, C.c_int64]),
+    "sdeh_nice_work_floats": (C.c_int64, [C.POINTER(SdehNice), C.c_int64, C.c_int32]),
+    "sdeh_nice_eval": (C.c_int32, [C.POINTER(SdehNice), fp, C.c_int64, fp, fp, fp, C.c_int64, C.c_void_p]),
+    "sdeh_simulate_fwd_steps": (C.c_int32, [C.c_void_p, C.POINTER(SdehProblem), fp, C.c_int32, C.c_int32, C.c_int32, fp, C.c_int64, fp,
+                                            C.c_uint64, C.c_uint64, C.c_int64, fp, fp, fp, fp, fp, C.c_int64, C.c_void_p]),
     "sdeh_sinkhorn": (C.c_int32, [fp, C.c_int64, fp, C.c_int64, C.c_int32, fp, fp, C.c_int32, C.c_float, C.c_int32, C.c_float,
                                   fp, fp, fp, fp, C.c_void_p]),
     "sdeh_sample_stats_scratch_floats": (C.c_int64, [C.c_int32]),

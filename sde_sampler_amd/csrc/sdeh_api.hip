@@ -509,6 +509,8 @@ static int check_density(const SdehDensity& D, int d, const char* what, bool all
     case SDEH_DENS_FUNNEL:
       if (!(D.p0 > 0.0f) || d < 2) return fail(SDEH_ERR_INVALID, "%s: bad funnel", what);
       break;
+    case SDEH_DENS_EXTERNAL:  // (the score arrives per step through sdeh_simulate_fwd_steps; check_problem: wide plans only)
+      break;
     default:
       return fail(SDEH_ERR_INVALID, "%s: unknown density kind %d", what, D.kind);
   }
@@ -573,6 +575,11 @@ static int check_problem(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   const bool need_target = need_target_score || (pr->flags & SDEH_FLAG_TERMINAL_TARGET);
   rc = check_density(pr->target, d, "target", !need_target);
   if (rc != SDEH_OK) return rc;
+  if (pr->target.kind == SDEH_DENS_EXTERNAL && !plan->wide)
+    return fail(SDEH_ERR_UNSUPPORTED, "a target whose score is supplied per step (SDEH_DENS_EXTERNAL) runs on the wide kernels (d > 64 or "
+                                      "channels >= 128) through sdeh_simulate_fwd_steps");
+  if (pr->prior.kind == SDEH_DENS_EXTERNAL || pr->second.kind == SDEH_DENS_EXTERNAL)
+    return fail(SDEH_ERR_INVALID, "SDEH_DENS_EXTERNAL is a target kind");
   const bool refc = (pr->flags & SDEH_FLAG_REFERENCE_CTRL) && pr->loss_kind == SDEH_LOSS_REFERENCE_SDE;
   const bool need_prior = pr->ctrl_kind == SDEH_CTRL_LERP || pr->ctrl_kind == SDEH_CTRL_LERP_PRIOR || refc;
   if (need_prior && pr->prior.kind != SDEH_DENS_DIAG_GAUSS)
@@ -725,9 +732,19 @@ static void fill_traj_args(TrajArgs& A, const SdehProblem* pr, const float* x0, 
 }
 
 // Wide networks (C = 128 / 256, d <= 256): the channel-split kernels of sdeh_wide.hip, with or without an inference control.
+// sdeh_simulate_fwd_steps: the steps [begin, end) of the grid; the tables of the whole grid are prepared by the segment that starts at 0
+struct Segment {
+  int begin, end;
+  const float* ext_score;
+  long long ext_stride;
+};
 static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0, int64_t batch,
                          const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset, float* x_T, float* rnd, float* xs,
-                         void* stream, const Checked& ck, float* gp, const float* div_noise, float* sc_out, float* tsc_out) {
+                         void* stream, const Checked& ck, float* gp, const float* div_noise, float* sc_out, float* tsc_out,
+                         const Segment* seg = nullptr) {
+  if (pr->target.kind == SDEH_DENS_EXTERNAL && seg == nullptr)
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd (wide): a target whose score is supplied per step runs through sdeh_simulate_fwd_steps");
+  const bool prep_now = seg == nullptr || seg->begin == 0;
   // (training: the wide forward keeps no network planes -- the caller's backward re-evaluates the network at the stored trajectory,
   // sdeh_wide_bwd.hip; what it keeps for a MIXTURE target is the score entering the control, sc_out [T, B, d], and the terminal target
   // score, tsc_out [B, d] (sdeh_simulate_fwd_train2 on a wide plan; Bridges: sdeh_simulate_fwd_aux2); Hutchinson probes are a
@@ -743,12 +760,19 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
   PrepArgs P;
   P.ws = plan->ws; P.lay = ck.L; P.prob = *pr; P.ts = ts; P.n_steps = n_steps;
   P.ts_out = nullptr; P.n_out = 0; P.eps = 0.0f;
-  int rc = launch_prep(P, st);
+  int rc = prep_now ? launch_prep(P, st) : SDEH_OK;
   if (rc != SDEH_OK) return fail(rc, "simulate_fwd (wide): prep kernel launch failed");
   TrajArgs A{};
   fill_traj_args(A, pr, x0, batch, noise, seed, offset, row_offset, x_T, rnd, xs, n_steps);
   A.ws = plan->ws; A.lay = ck.L;
   A.sc_out = sc_out; A.tsc_out = tsc_out;  // (only the mixture instantiations write them)
+  if (seg != nullptr) {
+    A.n_steps = seg->end - seg->begin; A.step0 = seg->begin; A.seg_continue = seg->begin > 0 ? 1 : 0;
+    A.ext_score = seg->ext_score; A.ext_stride = seg->ext_stride;
+    if (seg->begin > 0) A.flags &= ~SDEH_FLAG_INIT_LOGP;                                                  // rnd carries on
+    if (seg->end < n_steps) A.flags &= ~(SDEH_FLAG_TERMINAL_TARGET | SDEH_FLAG_TERMINAL_SECOND);         // terminal terms: last segment
+    if (pr->target.kind == SDEH_DENS_EXTERNAL) A.flags &= ~SDEH_FLAG_TERMINAL_TARGET;                     // ... of a supplied target: the caller
+  }
   if (bridge) {
     const SdehInferenceCtrl& inf = pr->inference;
     const SdehFourierMLP& net2 = inf.base_model;
@@ -787,7 +811,7 @@ static int simulate_wide(SdehPlan* plan, const SdehProblem* pr, const float* ts,
     P2.prob.ctrl_kind = inf.ctrl_kind; P2.prob.clip_model = inf.clip_model; P2.prob.clip_score = inf.clip_score;
     P2.prob.scale_score = inf.scale_score; P2.prob.base_model = inf.base_model; P2.prob.score_model = inf.score_model;
     P2.prob.target.kind = P2.prob.prior.kind = P2.prob.second.kind = SDEH_DENS_NONE;  // the density tables live in region 1
-    rc = launch_prep(P2, st);
+    rc = prep_now ? launch_prep(P2, st) : SDEH_OK;
     if (rc != SDEH_OK) return fail(rc, "simulate_fwd (wide bridge): second prep kernel launch failed");
     A.ws2 = plan->ws + ck.L.total; A.lay2 = L2;
     A.inf_kind = inf.ctrl_kind; A.inf_act = net2.activation;
@@ -947,6 +971,33 @@ int32_t sdeh_simulate_fwd_aux2(SdehPlan* plan, const SdehProblem* pr, const floa
                        nullptr, nullptr, stream, sc, tscore);
 }
 
+int32_t sdeh_simulate_fwd_steps(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, int32_t step_begin,
+                                int32_t step_end, const float* x_in, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,
+                                int64_t row_offset, float* x_out, float* rnd, float* xs, float* gp, const float* ext_score,
+                                int64_t ext_stride, void* stream) {
+  OptScope opt_scope(plan);
+  if (x_in == nullptr || x_out == nullptr || rnd == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd_steps: null argument");
+  if (x_in == x_out) return fail(SDEH_ERR_INVALID, "simulate_fwd_steps: x_out must not be x_in (workgroups that share a tile read x_in)");
+  if (gp != nullptr && (pr == nullptr || !(pr->flags & SDEH_FLAG_INFERENCE_CTRL)))
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_steps: gp only exists for problems with an inference control");
+  Checked ck;
+  int rc = check_problem(plan, pr, ts, n_steps, batch, row_offset, false, &ck);
+  if (rc != SDEH_OK) return rc;
+  if (!plan->wide)
+    return fail(SDEH_ERR_UNSUPPORTED, "simulate_fwd_steps: segments of the grid are a feature of the wide kernels (d > 64 or channels >= 128)");
+  if (step_begin < 0 || step_end <= step_begin || step_end > n_steps)
+    return fail(SDEH_ERR_INVALID, "simulate_fwd_steps: steps [%d, %d) of a grid of %d", step_begin, step_end, n_steps);
+  const bool need_t = pr->ctrl_kind == SDEH_CTRL_SCORE || pr->ctrl_kind == SDEH_CTRL_LERP || pr->ctrl_kind == SDEH_CTRL_LERP_TARGET;
+  if (pr->target.kind == SDEH_DENS_EXTERNAL && need_t) {
+    if (ext_score == nullptr) return fail(SDEH_ERR_INVALID, "simulate_fwd_steps: SDEH_DENS_EXTERNAL without ext_score");
+    if (ext_stride == 0 ? step_end - step_begin != 1 : ext_stride < batch * pr->base_model.dim)
+      return fail(SDEH_ERR_INVALID, "simulate_fwd_steps: ext_stride=%lld (0 for a one-step segment, else >= batch * dim)", (long long)ext_stride);
+  }
+  const Segment seg{step_begin, step_end, pr->target.kind == SDEH_DENS_EXTERNAL ? ext_score : nullptr, ext_stride};
+  return simulate_wide(plan, pr, ts, n_steps, x_in, batch, noise, seed, offset, row_offset, x_out, rnd, xs, stream, ck, gp, nullptr, nullptr,
+                       nullptr, &seg);
+}
+
 int32_t sdeh_simulate_fwd_train(SdehPlan* plan, const SdehProblem* pr, const float* ts, int32_t n_steps, const float* x0,
                                 int64_t batch, const float* noise, uint64_t seed, uint64_t offset, int64_t row_offset,
                                 float* x_T, float* rnd, float* xs, float* zt, float* nn, void* stream) {
@@ -1096,7 +1147,11 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
   if ((xt_out != nullptr || sc_in != nullptr || tscore_in != nullptr) && !plan->wide)
     return fail(SDEH_ERR_INVALID, "ctrl_backward_ex: xt_out / sc_in / tscore_in belong to the wide-network kernels");
   if (plan->wide) {  // channel-split chain kernel of sdeh_wide_bwd.hip (same planes; nn_in is not used: the wide forward keeps none)
-    if (pr->target.kind == SDEH_DENS_GMM) {  // the chain kernel evaluates no mixture: the forward launch's planes stand in
+    const bool planes_stand_in = pr->target.kind == SDEH_DENS_GMM || pr->target.kind == SDEH_DENS_EXTERNAL;
+    if (pr->target.kind == SDEH_DENS_EXTERNAL && bptt)
+      return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward (wide): back-propagation through time needs d score / d x of the target; a target whose "
+                                        "score is supplied per step trains with the log-variance methods (the reference's bridge.yaml)");
+    if (planes_stand_in) {  // the chain kernel evaluates no mixture / no supplied target: the forward launch's planes stand in
       const bool ctrl_t = pr->ctrl_kind == SDEH_CTRL_SCORE || pr->ctrl_kind == SDEH_CTRL_LERP || pr->ctrl_kind == SDEH_CTRL_LERP_TARGET;
       if ((ctrl_t && sc_in == nullptr) || (bptt && (pr->flags & SDEH_FLAG_TERMINAL_TARGET) && tscore_in == nullptr))
         return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward (wide): a mixture target needs the planes of sdeh_simulate_fwd_train2 (sc_in: the score "
@@ -1116,7 +1171,7 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
     Aw.ws = plan->ws; Aw.lay = L; Aw.xs = xs; Aw.noise = noise; Aw.grad_rnd = grad_rnd; Aw.gextra = gextra;
     Aw.cost_ctrl = cost_ctrl; Aw.lam_extra = lam_extra; Aw.dx = dx_out;
     Aw.zt = zt; Aw.dt = dt; Aw.dout = dout; Aw.dgam = dgam; Aw.nn_in = nullptr; Aw.xt_out = xt_out;
-    Aw.sc_in = pr->target.kind == SDEH_DENS_GMM ? sc_in : nullptr; Aw.tscore_in = pr->target.kind == SDEH_DENS_GMM ? tscore_in : nullptr;
+    Aw.sc_in = planes_stand_in ? sc_in : nullptr; Aw.tscore_in = planes_stand_in ? tscore_in : nullptr;
     Aw.batch = batch; Aw.row_offset = row_offset; Aw.n_steps = n_steps; Aw.d = pr->base_model.dim;
     Aw.loss_kind = pr->loss_kind; Aw.ctrl_kind = pr->ctrl_kind; Aw.flags = pr->flags; Aw.act = pr->base_model.activation;
     Aw.clip_model = pr->clip_model; Aw.clip_score = pr->clip_score; Aw.scale_score = pr->scale_score;
@@ -1715,6 +1770,41 @@ int32_t sdeh_integrate(SdehPlan* plan, const SdehProblem* pr, int32_t kind, cons
 
 static constexpr int kSinkMaxSplits = 64;
 static constexpr int kStatBlocks = 256;
+
+// ---- the NICE flow target (BASELINE configs[4]; reference distr/nice.py) ---------------------------------------------------------------
+static int check_nice(const SdehNice* nn) {
+  if (nn == nullptr) return fail(SDEH_ERR_INVALID, "nice: null description");
+  if (nn->dim < 2 || (nn->dim & 1) || nn->dim > 256) return fail(SDEH_ERR_INVALID, "nice: dim=%d (even, <= 256)", nn->dim);
+  if (nn->n_coupling < 1 || nn->n_coupling > SDEH_NICE_MAX_COUPLING) return fail(SDEH_ERR_INVALID, "nice: %d couplings", nn->n_coupling);
+  if (nn->mid_dim < 4 || (nn->mid_dim & 3)) return fail(SDEH_ERR_UNSUPPORTED, "nice: mid_dim=%d (a multiple of 4)", nn->mid_dim);
+  if (nn->n_mid < 0 || nn->n_mid > SDEH_MAX_HIDDEN) return fail(SDEH_ERR_INVALID, "nice: %d mid blocks", nn->n_mid);
+  if (nn->scale == nullptr) return fail(SDEH_ERR_INVALID, "nice: null scale");
+  for (int c = 0; c < nn->n_coupling; ++c) {
+    if (nn->in_w[c] == nullptr || nn->in_b[c] == nullptr || nn->out_w[c] == nullptr || nn->out_b[c] == nullptr)
+      return fail(SDEH_ERR_INVALID, "nice: null parameter of coupling %d", c);
+    for (int l = 0; l < nn->n_mid; ++l)
+      if (nn->mid_w[c][l] == nullptr || nn->mid_b[c][l] == nullptr) return fail(SDEH_ERR_INVALID, "nice: null mid block %d of coupling %d", l, c);
+  }
+  return SDEH_OK;
+}
+
+int64_t sdeh_nice_work_floats(const SdehNice* nice, int64_t batch, int32_t want_score) {
+  if (check_nice(nice) != SDEH_OK || batch < 1) return -1;
+  return nice_work_floats(*nice, batch, want_score != 0);
+}
+
+int32_t sdeh_nice_eval(const SdehNice* nice, const float* x, int64_t batch, float* score, float* logp, float* work, int64_t work_floats,
+                       void* stream) {
+  int rc = check_nice(nice);
+  if (rc != SDEH_OK) return rc;
+  if (x == nullptr || work == nullptr || batch < 1 || (score == nullptr && logp == nullptr)) return fail(SDEH_ERR_INVALID, "nice_eval: null argument");
+  if (work_floats < nice_work_floats(*nice, batch, score != nullptr))
+    return fail(SDEH_ERR_CAPACITY, "nice_eval: work memory of %lld floats < sdeh_nice_work_floats = %lld", (long long)work_floats,
+                nice_work_floats(*nice, batch, score != nullptr));
+  if ((reinterpret_cast<unsigned long long>(work) & 15) != 0) return fail(SDEH_ERR_INVALID, "nice_eval: work memory must be 16-byte aligned");
+  rc = launch_nice_eval(*nice, x, batch, score, logp, work, (hipStream_t)stream);
+  return rc == SDEH_OK ? SDEH_OK : fail(rc, "nice_eval: kernel launch failed");
+}
 
 int64_t sdeh_sinkhorn_workspace_floats(int64_t n, int64_t m) {
   if (n < 1 || m < 1) return 0;

@@ -169,6 +169,12 @@ struct TrajArgs {
   float* tsc_out; // [d, B] or null: 1[|log rho(x_T)| <= clip_target] * target.score(x_T)  (d terminal target cost / d x_T, negated)
   // training forward that also keeps the network's pre-activations for the fused backward (sdeh_simulate_fwd_train3)
   float* zrec;    // [T][ceil(B / 32)]{[Lh + 1][16][32][4]; [ceil(d / 32)][8][32][4]} or null: the pre-activation record + raw network output (sdeh_traj_ws.hpp: ZRec)
+  // sdeh_simulate_fwd_steps (wide kernels): this launch runs the steps [step0, step0 + n_steps) of the grid the tables were prepared for;
+  // table rows, Philox counters and the rows of xs / gp are indexed by the GRID's step
+  int step0;
+  int seg_continue;        // != 0: not the first segment -- rnd continues from A.rnd, x_0's row of xs is not written
+  const float* ext_score;  // SDEH_DENS_EXTERNAL: the target's score at x_t for the steps of this launch
+  long long ext_stride;    // floats between consecutive steps of ext_score (0: one [B, d] buffer, one-step segments)
 };
 
 // sdeh_bridge_div_backward (sdeh_bridge.hpp): gradient of  sum_n w_i sigma dt div_x v(x_n)  w.r.t. the inference network
@@ -314,6 +320,10 @@ int bwdf2_slots(long long batch, int n_steps, bool bptt);  // teams of four 32-t
 int launch_bwdf2_jac(const BwdfArgs& a, hipStream_t stream);   // row-parallel: nn_out, jac_out (d <= 4, two hidden layers)
 int launch_bwdf2_scan(const BwdfArgs& a, hipStream_t stream);  // the adjoint recursion over the steps: gq_out
 bool bwdf2_scan_fits(int d, int n_hidden);
+
+// the NICE flow target (sdeh_nice.hip): log-density and score of a batch of rows
+long long nice_work_floats(const SdehNice& nn, long long batch, bool want_score);
+int launch_nice_eval(const SdehNice& nn, const float* x, long long batch, float* score, float* logp, float* work, hipStream_t stream);
 
 // effective Philox offset of a launch: by-value part + the optional device-resident counter (hipGraph replays)
 __device__ __forceinline__ unsigned long long philox_offset(unsigned long long offset, const unsigned long long* dev) {

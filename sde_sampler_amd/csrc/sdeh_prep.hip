@@ -80,9 +80,12 @@ __device__ void pack_diag_gauss(float* tab, const SdehDensity& D, int dp, int gi
     tab[2 * j + 1] = ok ? 1.0f / (s * s) : 0.0f;
   }
   if (gid == 0) {
-    float c = 0.0f;
-    for (int j = 0; j < D.dim; ++j) c += -logf(D.scale[j]) - 0.91893853320467274178f;
-    tab[2 * dp] = c;
+    // the normaliser -sum_j (log sigma_j + log(2 pi) / 2), accumulated in double: summed term by term in fp32 it carried up to ~3e-4 of
+    // rounding at d = 196 (|c| = 180: 18 ulp) straight into every trajectory's rnd -- the reference forms it as ONE product for an
+    // isotropic Gaussian (distr/gauss.py:215-220), i.e. to one ulp
+    double c = 0.0;
+    for (int j = 0; j < D.dim; ++j) c -= log((double)D.scale[j]) + 0.91893853320467274178;
+    tab[2 * dp] = (float)c;
   }
 }
 

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
         const int cc = 32 * (w + 4 * k) + rho(q, h);
         xr[k][c][q] = (k < nto && cc < d) ? A.x0[lrow[c] * d + cc] : 0.0f;
       }
-  if (A.xs != nullptr) {
+  if (A.xs != nullptr && !A.seg_continue) {
 #pragma unroll
     for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     rnd[c] = 0.0f;
     // Distribution.log_prob = unnorm_log_prob - log_norm_const (distr/base.py:116-119): the constants cancel
     if (flags & SDEH_FLAG_INIT_LOGP) rnd[c] = cx.tab2[2 * L.dp] - 0.5f * wide_slot_sum(cx, WSL_LOGP_A, 32 * c + j);
+    if (A.seg_continue) rnd[c] = live[c] ? A.rnd[row0 + 32 * c + j] : 0.0f;  // a later segment of the grid (sdeh_simulate_fwd_steps)
   }
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
   const int wt = w & (L.ot - 1);  // hidden-layer tile of this wave (C = 64: waves 2, 3 double the tiles of waves 0, 1; see wide_mlp)
@@ -142,9 +143,10 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
   wide_prefetch<OTW>(pre_in, ws + L.w_in, L.ot * 256, L.dp8 / 8, voff_in);
   f32x16 emb[OTW];  // FourierMLP.timestep_embed(t_i) + input_embed.bias for this wave's channels (added when layer 0 is activated)
 #pragma unroll
-  for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + ((wt + 4 * k) * 2 + h) * 16);
+  for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + A.step0 * C + ((wt + 4 * k) * 2 + h) * 16);
 
-  for (int i = 0; i < A.n_steps; ++i) {
+  const int step_end = A.step0 + A.n_steps;
+  for (int i = A.step0; i < step_end; ++i) {
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
     const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
     // funnel statistics of x_i (published with it); read before the planes move on
@@ -186,6 +188,11 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     WideScore sq;
     sq.ctrl_kind = ctrl_kind; sq.g = L.g; sq.need_t = need_t; sq.need_p = need_p; sq.tgt = tgt; sq.wl = wl; sq.mult = mult;
     sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = g0; sq.d = d; sq.gmm = &gm;
+    if (tgt.kind == SDEH_DENS_EXTERNAL && need_t) {
+      sq.ext = A.ext_score + (long long)(i - A.step0) * A.ext_stride;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) sq.ext_off[c] = lrow[c] * d;
+    }
     auto vtile = [&](f32x16& x, const f32x16& nnv, int t, int c) {
       const int cb = 32 * t + 4 * hv;  // register q <-> coordinate cb + (q & 3) + 8 (q >> 2)
       auto coord = [&](int q) { return cb + (q & 3) + 8 * (q >> 2); };
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void traj_wide_kernel(const TrajArgs A) {
     // the next step's first operands (input layer A groups, time embedding of step i + 1) travel across the publish barrier
     wide_prefetch<OTW>(pre_in, ws + L.w_in, L.ot * 256, L.dp8 / 8, voff_in);
 #pragma unroll
-    for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + (i + 1 < A.n_steps ? i + 1 : i) * C + ((wt + 4 * k) * 2 + h) * 16);
+    for (int k = 0; k < OTW; ++k) emb[k] = load16(ws + L.emb + (i + 1 < step_end ? i + 1 : i) * C + ((wt + 4 * k) * 2 + h) * 16);
     wide_publish<CT>(cx, cx.plane(p), xr, nto);
     if constexpr (GMM) wide_gmm_partials<CT>(cx, gm, xr, nto);
     wide_barrier();  // x_{i+1}, its statistics and this step's cost partials are visible
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
     for (int q = 0; q < 16; ++q) {
       const int cc = 32 * (w + 4 * k) + rho(q, h);
       xr[k][0][q] = (k < nto && cc < d) ? A.x0[lrow * d + cc] : 0.0f;
-      if (A.xs != nullptr && lead && k < nto && cc < d && live) A.xs[lrow * d + cc] = xr[k][0][q];
+      if (A.xs != nullptr && lead && k < nto && cc < d && live && !A.seg_continue) A.xs[lrow * d + cc] = xr[k][0][q];
     }
   __syncthreads();  // tables staged
   wide_publish<CT>(cx, cx.plane(0), xr, nto);
@@ -617,6 +624,7 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
   __syncthreads();
   float rnd = 0.0f;  // wave 0, lane half 0 of the lead workgroup
   if (flags & SDEH_FLAG_INIT_LOGP) rnd = cx.tab2[2 * L.dp] - 0.5f * wide_slot_sum(cx, WSL_LOGP_A, j);
+  if (A.seg_continue) rnd = live ? A.rnd[row0 + j] : 0.0f;  // a later segment of the grid (sdeh_simulate_fwd_steps): rnd carries on
   const unsigned long long rng_off = philox_offset(A.offset, A.rng_dev);
   const unsigned long long grow = (unsigned long long)(A.row_offset + lrow);
   unsigned voff_in[OTW];
@@ -625,7 +633,7 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
   // coordinate groups of this wave: g = gw, gw + TW, ... (gw = global wave index among the TW waves sharing the tile)
   const int TW = 4 * split, gw = sp * 4 + w, ngw = kDivGroups / TW;
 
-  for (int i = 0; i < A.n_steps; ++i) {
+  for (int i = A.step0; i < A.step0 + A.n_steps; ++i) {
     cfp cf = as_const(ws + L.coef + i * kCoefStride);
     const float dt = cf[CF_DT], sqdt = cf[CF_SQDT], sig = cf[CF_SIGMA];
     float fs = 0.0f, fx0 = 0.0f, fiv = 0.0f;  // funnel statistics of x_i
@@ -812,6 +820,10 @@ __global__ __launch_bounds__(256) void bridge_wide_kernel(const TrajArgs A, int 
     sq.ctrl_kind = ctrl_kind; sq.g = L.g; sq.need_t = need_t; sq.need_p = need_p; sq.tgt = tgt; sq.wl = wl;
     sq.mult = ctrl_kind == SDEH_CTRL_SCORE ? 1.0f : sig;
     sq.scale_score = A.scale_score; sq.clip_score = A.clip_score; sq.g0 = as_const(ws + L.gam + i * L.g)[0]; sq.d = d; sq.gmm = &gm;
+    if (tgt.kind == SDEH_DENS_EXTERNAL && need_t) {
+      sq.ext = A.ext_score + (long long)(i - A.step0) * A.ext_stride;
+      sq.ext_off[0] = lrow * d;
+    }
     if constexpr (GMM) {
       if (need_t && tgt.kind == SDEH_DENS_GMM) {  // responsibilities of x_i (the act' planes are free: every wave is through its coordinates)
         wide_barrier();

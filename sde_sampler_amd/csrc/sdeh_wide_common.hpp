@@ -440,6 +440,8 @@ struct WideScore {
   float wl, mult, scale_score, clip_score, g0;
   int d;
   const WideGmm* gmm;  // mixture target (null otherwise)
+  const float* ext = nullptr;          // SDEH_DENS_EXTERNAL: the caller's score plane of this step, [B, d]
+  long long ext_off[4] = {0, 0, 0, 0}; // ... and the row offset (row * d) of each column tile's trajectory of this lane
 };
 // sc[16]: the combined score entering the control BEFORE clip_score and gamma(t) (target score, lerp of prior and target score, ...);
 // psc[16]: the prior score (when need_p).  Not called for ClippedCtrl.
@@ -475,6 +477,10 @@ __device__ __forceinline__ void wide_score_mix16(const WideScore& S, const WideC
       sc[0] = cb == 0 ? s0 : sc[0];
     } else if (GMM && S.tgt.kind == SDEH_DENS_GMM) {
       if constexpr (GMM) wide_gmm_score16(cx, *S.gmm, x, cb, 32 * c + cx.j, sc);
+    } else if (S.tgt.kind == SDEH_DENS_EXTERNAL) {  // supplied by the caller (sdeh_simulate_fwd_steps; e.g. the NICE flow's, sdeh_nice.hip)
+      const float* __restrict__ er = S.ext + S.ext_off[c] + cb;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sc[q] = coord(q) < S.d ? er[(q & 3) + 8 * (q >> 2)] : 0.0f;
     } else {
 #pragma unroll
       for (int q = 0; q < 16; ++q) sc[q] = 0.0f;

@@ -181,6 +181,10 @@ def _fill_density(dist, out: L.SdehDensity, keep: _Keep, device, what: str):
     elif "Funnel" in names:
         out.kind = L.DENS_FUNNEL
         out.p0 = float(dist.variance)
+    elif _external_target(dist):
+        # no closed form inside the trajectory kernels: the engine evaluates the score between step segments (TrajectoryEngine.run)
+        out.kind = L.DENS_EXTERNAL
+        keep.append(_ExternalTarget(dist))
     else:
         raise _unsupported(f"{what}: distribution {type(dist).__name__} has no fused log-density/score "
                            "(GMM, Gauss, IsotropicGauss, Delta, DoubleWell, MultiWell, Funnel are built in)")
@@ -266,6 +270,92 @@ def _has_analytic_score(dist) -> bool:
 def _known_distribution(obj) -> bool:
     names = set(_mro_names(obj))
     return bool(names & (_GAUSS_NAMES | {"GMM", "DoubleWell", "MultiWell", "Funnel"}))
+
+
+class _ExternalTarget:
+    """Rides in a problem's `_Keep`: the target object whose score the engine evaluates BETWEEN the step segments of the wide kernels
+    (SDEH_DENS_EXTERNAL, sdeh_simulate_fwd_steps) -- the NICE flow of BASELINE configs[4] (csrc/sdeh_nice.hip)."""
+
+    def __init__(self, obj):
+        self.obj = obj
+
+
+def _external_target(obj) -> bool:
+    """A `Nice` distribution (this package's or the reference's distr/nice.py:233-298) around a NiceModel."""
+    if "Nice" not in _mro_names(obj):
+        return False
+    model = getattr(obj, "model", None)
+    return model is not None and hasattr(model, "coupling") and hasattr(model, "scaling")
+
+
+def describe_nice(nice, device, keep: _Keep) -> L.SdehNice:
+    """SdehNice (include/sdeh.h) of a `Nice` distribution: raw device pointers of the couplings' nn.Linear parameters (reference
+    distr/nice.py:43-62, 100-110, 123-153), read by attribute -- works on the reference's own NiceModel as well."""
+    model = nice.model
+    prior = type(getattr(model, "prior", None)).__name__
+    if prior != "StandardLogistic":
+        raise _unsupported(f"NICE prior {prior}: the logistic prior of distr/nice.py is built in")
+    out = L.SdehNice()
+    couplings = list(model.coupling)
+    if not 1 <= len(couplings) <= L.SDEH_NICE_MAX_COUPLING:
+        raise _unsupported(f"NICE with {len(couplings)} coupling layers (1 .. {L.SDEH_NICE_MAX_COUPLING})")
+    out.dim, out.n_coupling = int(model.in_out_dim), len(couplings)
+    out.mid_dim = int(couplings[0].in_block[0].weight.shape[0])
+    out.n_mid = len(couplings[0].mid_block)
+    if out.n_mid > L.SDEH_MAX_HIDDEN or out.mid_dim % 4 or out.dim % 2 or out.dim > 256:
+        raise _unsupported(f"NICE geometry dim={out.dim} mid_dim={out.mid_dim} hidden={out.n_mid + 1}: even dim <= 256, mid_dim a multiple "
+                           f"of 4, at most {L.SDEH_MAX_HIDDEN + 1} hidden layers")
+    for c, layer in enumerate(couplings):
+        lin_in, lin_out = layer.in_block[0], layer.out_block
+        if (tuple(lin_in.weight.shape) != (out.mid_dim, out.dim // 2) or tuple(lin_out.weight.shape) != (out.dim // 2, out.mid_dim)
+                or len(layer.mid_block) != out.n_mid or type(layer.in_block[1]).__name__ != "ReLU"):
+            raise _unsupported(f"NICE coupling {c}: not the Linear + ReLU blocks of distr/nice.py:56-62")
+        out.mask_config[c] = 1 if layer.mask_config else 0
+        out.in_w[c], out.in_b[c] = keep.ptr(lin_in.weight, device, "nice in_block"), keep.ptr(lin_in.bias, device, "nice in_block")
+        for l, block in enumerate(layer.mid_block):
+            out.mid_w[c][l] = keep.ptr(block[0].weight, device, "nice mid_block")
+            out.mid_b[c][l] = keep.ptr(block[0].bias, device, "nice mid_block")
+        out.out_w[c], out.out_b[c] = keep.ptr(lin_out.weight, device, "nice out_block"), keep.ptr(lin_out.bias, device, "nice out_block")
+    out.scale = keep.ptr(model.scaling.scale.reshape(-1), device, "nice scaling")
+    lnc = getattr(nice, "log_norm_const", None)
+    out.log_norm_const = 0.0 if lnc is None else float(lnc)
+    return out
+
+
+def nice_eval(nice, x: torch.Tensor, *, want_score: bool, want_logp: bool, cache: dict | None = None, score_out: torch.Tensor | None = None,
+              desc=None):
+    """(score [B, d] | None, unnorm_log_prob [B] | None) of a `Nice` target at x on the HIP kernels (sdeh_nice_eval), on torch's
+    current stream.  `cache`: work memory per batch size; `desc`: an (SdehNice, keep) pair described once for a whole trajectory."""
+    if not x.is_cuda:
+        raise RuntimeError("nice_eval needs GPU tensors (the CPU form of the target is Nice.model.log_prob)")
+    lib = L.load()
+    device = x.device
+    xc = x.detach()
+    if xc.dtype != torch.float32 or not xc.is_contiguous():
+        xc = xc.float().contiguous()
+    batch = xc.shape[0]
+    keep = _Keep()
+    nd = describe_nice(nice, device, keep) if desc is None else desc[0]
+    n_work = lib.sdeh_nice_work_floats(C.byref(nd), batch, 1 if want_score else 0)
+    if n_work < 0:
+        raise L.SdehError(-1, L.load().sdeh_last_error().decode())
+    key = (device.index, batch, bool(want_score))
+    work = None if cache is None else cache.get(key)
+    if work is None or work.numel() < n_work:
+        work = torch.empty(n_work, device=device, dtype=torch.float32)
+        if cache is not None:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = work
+    score = None
+    if want_score:
+        score = score_out if score_out is not None else torch.empty_like(xc)
+    logp = torch.empty(batch, device=device, dtype=torch.float32) if want_logp else None
+    with torch.cuda.device(device):
+        L.check(lib.sdeh_nice_eval(C.byref(nd), xc.data_ptr(), batch, None if score is None else score.data_ptr(),
+                                   None if logp is None else logp.data_ptr(), work.data_ptr(), work.numel(),
+                                   torch.cuda.current_stream(device).cuda_stream))
+    return score, logp
 
 
 def _bound_owner(fn, method: str):
@@ -396,6 +486,7 @@ class TrajectoryEngine:
         #: environment variables of the same names
         self.options: dict = {}
         self._problems: dict = {}  # build_problem's cache
+        self._nice_work: dict = {}  # work memory of sdeh_nice_eval per batch size (NICE targets)
         self._last_plan = None
 
     # ------------------------------------------------------------------------------------------------------
@@ -546,7 +637,7 @@ class TrajectoryEngine:
                     raise _unsupported("score_model and base_model use different activations")
             if kind != L.CTRL_LERP_PRIOR:
                 owner = _bound_owner(generative_ctrl.target_score, "score")
-                if owner is None or not _known_distribution(owner):
+                if owner is None or not (_known_distribution(owner) or _external_target(owner)):
                     raise _unsupported("generative_ctrl.target_score must be the `.score` of a built-in distribution")
                 if target_obj is not None and owner is not target_obj:
                     raise _unsupported("target_score and terminal_unnorm_log_prob belong to different distributions")
@@ -736,6 +827,56 @@ class TrajectoryEngine:
             if tuple(div_noise.shape) != (n_steps, batch, dim):
                 raise ValueError(f"div_noise must be [{n_steps}, {batch}, {dim}], got {tuple(div_noise.shape)}")
             dn_p = keep.ptr(div_noise, device, "div_noise")
+        if pr.target.kind == L.DENS_EXTERNAL:
+            # a target whose score the kernels do not carry (the NICE flow, csrc/sdeh_nice.hip): the wide kernels run the grid one step
+            # at a time (sdeh_simulate_fwd_steps; tables prepared once, Philox counters of the whole grid), the engine evaluates the
+            # target's score at x_t in between -- every launch on this stream, no host synchronisation
+            if div_noise is not None:
+                raise _unsupported("Hutchinson divergence estimators with a NICE target (the wide kernels carry the exact divergence)")
+            ext = next((k for k in keep if isinstance(k, _ExternalTarget)), None)
+            if ext is None:
+                raise RuntimeError("SDEH_DENS_EXTERNAL without its target object (problem built outside build_problem?)")
+            training = want_planes or want_gp
+            if training and pr.ctrl_kind == L.CTRL_LERP:
+                raise _unsupported("training a LerpCtrl on a NICE target (LerpTargetCtrl / ScoreCtrl: conf/solver/bridge.yaml, pis.yaml)")
+            need_score = pr.ctrl_kind in (L.CTRL_SCORE, L.CTRL_LERP, L.CTRL_LERP_TARGET)
+            if return_traj or training:
+                xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
+            # the score plane: every step's row is kept when a backward pass will want it, one [B, d] buffer otherwise
+            sc = (torch.empty((n_steps if training else 1, batch, dim), device=device, dtype=torch.float32) if need_score else None)
+            ping = (torch.empty((batch, dim), device=device, dtype=torch.float32), torch.empty((batch, dim), device=device, dtype=torch.float32))
+            nkeep = _Keep()
+            desc = (describe_nice(ext.obj, device, nkeep), nkeep) if need_score else None
+            keep.extend(nkeep)
+            cur = x.detach()
+            if cur.dtype != torch.float32 or not cur.is_contiguous():
+                cur = cur.float().contiguous()
+            cur_ptr = cur.data_ptr()
+            with torch.cuda.device(device):
+                for i in range(n_steps):
+                    sc_i = None
+                    if need_score:
+                        sc_i = sc[i if training else 0]
+                        nice_eval(ext.obj, cur, want_score=True, want_logp=False, cache=self._nice_work, score_out=sc_i, desc=desc)
+                    out = x_T if i == n_steps - 1 else ping[i & 1]
+                    L.check(lib.sdeh_simulate_fwd_steps(plan.handle, C.byref(pr), ts_p, n_steps, i, i + 1, cur_ptr, batch, noise_p,
+                                                        seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, out.data_ptr(), rnd.data_ptr(),
+                                                        None if xs is None else xs.data_ptr(), None if gp is None else gp.data_ptr(),
+                                                        None if sc_i is None else sc_i.data_ptr(), 0, stream))
+                    cur, cur_ptr = out, out.data_ptr()
+            sc_in = None
+            if training and need_score:
+                # what the backward kernels take as `sc_in`: the score ENTERING the control, i.e. after the control's interpolation weight
+                # (reparam.py:185-197: t / T * target_score) and before clip_score / gamma(t) -- the kernels' own product, in fp32
+                sc_in = sc
+                if pr.ctrl_kind == L.CTRL_LERP_TARGET:
+                    wl = (ts.reshape(-1)[:-1].to(device=device, dtype=torch.float32) / torch.tensor(pr.terminal_t, dtype=torch.float32, device=device))
+                    sc_in.mul_(wl.view(-1, 1, 1))
+            if want_planes:
+                return x_T, rnd, xs, ("wide", sc_in, None)
+            if want_gp:
+                return x_T, rnd, xs, gp, (sc_in, None)
+            return x_T, rnd, (xs if return_traj else None)
         if want_planes:  # training forward: keep what the backward kernels need
             if not return_traj or want_gp or div_noise is not None:
                 raise ValueError("want_planes goes with return_traj=True and without the Bridge outputs")

@@ -81,6 +81,24 @@ def build_target(spec: dict, tensors: dict | None = None):
             loc, scale, w = random_gmm(d, 7, 1234)
             return GMM(dim=d, loc=loc, scale=scale, mixture_weights=w, n_reference_samples=1000, domain_tol=None)
         return GMM(dim=d, name=name, n_reference_samples=1000)
+    if kind == "nice":
+        # BASELINE configs[4]'s target (the reference's data/nice.pt is not shipped, so a NiceModel of the
+        # checkpoint's geometry -- scripts/train_nice.py:66-78: coupling = 4, mid_dim = 1000 * 14 / 28 = 500, hidden = 5,
+        # mask_config = 1.0 -- with seeded random weights, handed over as `Nice(model=...)`, distr/nice.py:242-243).  `tensors`: a
+        # state_dict of the model (the fixtures carry the reference model's)
+        from sde_sampler_amd.distr.nice import Nice, NiceModel, StandardLogistic
+
+        with torch.random.fork_rng():
+            torch.manual_seed(spec.get("seed", 5))
+            model = NiceModel(prior=StandardLogistic(), coupling=spec.get("coupling", 4), in_out_dim=spec["dim"],
+                              mid_dim=spec.get("mid_dim", 500), hidden=spec.get("hidden", 5), mask_config=spec.get("mask_config", 1.0))
+            with torch.no_grad():  # a live scaling layer (the shipped initialisation is zeros)
+                model.scaling.scale.normal_(0.0, spec.get("scale_std", 0.1))
+                for layer in model.coupling:  # out_block of a trained flow is not tiny: keep the couplings numerically live
+                    layer.out_block.weight.mul_(spec.get("out_gain", 1.0))
+        if tensors is not None:
+            model.load_state_dict(tensors)
+        return Nice(model=model, dim=spec["dim"], n_reference_samples=1000)
     raise ValueError(f"unknown target kind {kind}")
 
 
@@ -306,6 +324,16 @@ BASELINE_SPECS = {
     # configs[4]: solver=bridge, channels=256, batch 32 768 over 8 GPUs (4096 per GPU), 200 steps
     "cfg5_like_bridge196": dict(
         batch=4096, target=dict(kind="funnel", dim=196),
+        prior=dict(kind="iso_gauss", dim=196), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+        ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        inference_ctrl=dict(kind="lerp_prior", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        net=dict(channels=256, num_layers=4, activation="gelu"),
+        loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=200)),
+    # configs[4] AS WRITTEN: target = nice (the flow's geometry of scripts/train_nice.py with seeded random weights: SURVEY.md 8d item 5),
+    # solver = bridge, channels = 256, batch 32 768 over 8 GPUs (4096 per GPU), 200 steps.  The flow's score is evaluated by
+    # csrc/sdeh_nice.hip between the step segments of the wide Bridge kernel (engine.run: SDEH_DENS_EXTERNAL)
+    "cfg5_nice_bridge196": dict(
+        batch=4096, target=dict(kind="nice", dim=196),
         prior=dict(kind="iso_gauss", dim=196), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
         ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
         inference_ctrl=dict(kind="lerp_prior", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Golden vectors for the NICE flow target of BASELINE configs[4] (`nice_*.npz`), produced by RUNNING THE REFERENCE -- build container
+only (conventions: make_golden.py).  Reference entry points exercised:
+  distr/nice.py:17-40, 43-97, 100-120, 123-231   StandardLogistic / Coupling / Scaling / NiceModel (random-initialised, seeded)
+  distr/nice.py:233-298                          Nice(model=...)  (`unnorm_log_prob`; `score` = distr/base.py:130-137, autograd)
+  losses/oc.py:156-230 incl. 189-202             TimeReversalLoss.simulate, Bridge branch (LerpTargetCtrl on the flow's score, LerpPriorCtrl
+                                                 inference control, exact divergence) -- evaluation passes and the lv training loss with
+                                                 the reference-autograd gradients of BOTH networks (conf/solver/bridge.yaml's loss)
+  losses/oc.py:286-343                           ReferenceSDELoss.simulate (PIS: ScoreCtrl on the flow's score)
+`data/nice.pt` (the trained flow) is not shipped and `Nice.__init__` imports torchvision for its `Resize` of the MNIST mean (used by
+`plots` only): the module is imported with a stand-in for that one transform (torch's own antialiased interpolation), like the
+wandb / torchquad / torchsde stand-ins of make_golden.py.  Nothing the fixtures hold depends on it.
+
+  nice_kat_small.npz     a small flow WITH its weights: x -> unnorm_log_prob, score (rows incl. large |x|: the softplus tails)
+  nice_kat_md500.npz     the checkpoint geometry (coupling 4, mid_dim 500, hidden 5: scripts/train_nice.py:66-78) with weights that are
+                         a function of a seed (torch.manual_seed + nn.Linear's default init): seed, x, outputs and a checksum of the
+                         weights -- the test rebuilds the model on its own host and checks the checksum first
+  nicebridge196_c128.npz Bridge on the flow (d = 196, C = 128): parameters of both networks, the flow's weights, x0, noise ->
+                         x_T, rnd, estimators, lv loss + gradients
+  nicepis196_c128.npz    PIS on the flow
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import make_golden as mg  # noqa: E402  (puts /root/reference on sys.path with the wandb / torchquad / torchsde stand-ins)
+
+
+def _stub_torchvision():
+    class Resize:
+        def __init__(self, size, antialias=True):
+            self.size, self.antialias = size, antialias
+
+        def __call__(self, img):
+            return torch.nn.functional.interpolate(img.unsqueeze(0), size=self.size, mode="bilinear", antialias=self.antialias).squeeze(0)
+
+    tv, tr, ut = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.utils")
+    tr.Resize, ut.make_grid = Resize, None
+    tv.transforms, tv.utils = tr, ut
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.utils": ut})
+
+
+_stub_torchvision()
+import make_golden_wide as mgw  # noqa: E402
+from sde_sampler.distr.nice import Nice, NiceModel, StandardLogistic  # noqa: E402
+from sde_sampler.losses.oc import ReferenceSDELoss, TimeReversalLoss  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+ISO = lambda d, **kw: dict(kind="iso_gauss", dim=d, loc=0.0, scale=1.0, **kw)
+
+
+def reference_flow(tspec: dict) -> Nice:
+    """The reference's Nice around a seeded, random-initialised NiceModel (the recipe sde_sampler_amd.problems.build_target restates)."""
+    with torch.random.fork_rng():
+        torch.manual_seed(tspec.get("seed", 5))
+        model = NiceModel(prior=StandardLogistic(), coupling=tspec.get("coupling", 4), in_out_dim=tspec["dim"],
+                          mid_dim=tspec.get("mid_dim", 500), hidden=tspec.get("hidden", 5), mask_config=tspec.get("mask_config", 1.0))
+        with torch.no_grad():
+            model.scaling.scale.normal_(0.0, tspec.get("scale_std", 0.1))
+            for layer in model.coupling:
+                layer.out_block.weight.mul_(tspec.get("out_gain", 1.0))
+    return Nice(model=model, dim=tspec["dim"], n_reference_samples=1000)
+
+
+def weights_sha(model) -> str:
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().numpy().tobytes())
+    return h.hexdigest()
+
+
+def kat(name: str, tspec: dict, n: int, with_weights: bool):
+    target = reference_flow(tspec)
+    gen = torch.Generator().manual_seed(97)
+    x = torch.randn((n, tspec["dim"]), generator=gen) * torch.linspace(0.2, 6.0, n).unsqueeze(1)  # rows from near the mode to the tails
+    lp = target.unnorm_log_prob(x)
+    sc = target.score(x.clone())
+    out = {"x": x.numpy(), "unnorm_log_prob": lp.detach().numpy(), "score": sc.detach().numpy(),
+           "weights_sha256": np.frombuffer(weights_sha(target.model).encode(), dtype=np.uint8)}
+    if with_weights:
+        out.update({"target/" + k: v.numpy().copy() for k, v in target.model.state_dict().items()})
+    import json
+    out["meta"] = np.frombuffer(json.dumps(dict(target=dict(tspec, kind="nice"), name=name)).encode(), dtype=np.uint8)
+    path = OUT / f"{name}.npz"
+    np.savez_compressed(path, **out)
+    print(f"{name:26s} n={n} log p in [{lp.min():.1f}, {lp.max():.1f}] |score|max={sc.abs().max():.2f} {path.stat().st_size/1024:.1f} KB")
+
+
+FLOW_SMALL = dict(kind="nice", dim=196, coupling=4, mid_dim=64, hidden=3, mask_config=1.0, seed=11, scale_std=0.15, out_gain=3.0)
+
+CASES = {
+    # conf/solver/bridge.yaml on the flow: LerpTargetCtrl + LerpPriorCtrl (clips 10), ScaledBM(1, T = 1), loss time_reversal_lv
+    "nicebridge196_c128": dict(
+        B=24, seed=83, target=FLOW_SMALL, prior=ISO(196), sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0),
+        ctrl=dict(kind="lerp_target", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        inference_ctrl=dict(kind="lerp_prior", clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+        net=dict(channels=128, num_layers=4, activation="gelu"),
+        loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=6, rescale_t=None)),
+    # conf/solver/pis.yaml on the flow: ScoreCtrl, Delta prior, ScaledBM; an ACTIVE score clip (the flow's score is large away from its mode)
+    "nicepis196_c128": dict(
+        B=40, seed=89, target=dict(FLOW_SMALL, mid_dim=52, hidden=4, mask_config=0.0, seed=13), prior=dict(kind="delta", dim=196),
+        sde=dict(kind="scaled_bm", diff_coeff=math.sqrt(0.2), terminal_t=5.0),
+        ctrl=dict(kind="score", clip_model=1e4, clip_score=3.0, scale_score=1.0, gamma_dim=1, gamma_bias=0.01),
+        net=dict(channels=128, num_layers=4, activation="gelu"),
+        loss=dict(kind="reference_sde", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=5.0, steps=8, rescale_t=None)),
+}
+
+
+def _train_lv(out, loss, mods, ts, x0, state, terminal, second):
+    """train_lv/loss and the reference-autograd gradients (the flow's score is a constant of that graph: distr/base.py:130-137)."""
+    loss.method, loss.n_filtered = "lv", 0
+    for _, mod in mods:
+        mod.zero_grad()
+    torch.set_rng_state(state)
+    val, metrics = loss(ts, x0, terminal, second)
+    val.backward()
+    out["train_lv/loss"] = np.float64(val.item())
+    out["train_lv/n_filtered"] = np.int64(metrics["train/n_filtered_cumulative"])
+    for prefix, mod in mods:
+        for k, p in mod.named_parameters():
+            g = p.grad.detach().numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+            key = f"train_lv/{prefix}/{k}"
+            if g.size > mgw.GRAD_FULL_MAX:
+                out[key + "@stride"] = g.reshape(-1)[::mgw.GRAD_STRIDE].copy()
+                out[key + "@norm"] = np.float64(np.linalg.norm(g.astype(np.float64)))
+            else:
+                out[key] = g
+    loss.n_filtered = 0
+
+
+def run_case(name, case):
+    import json
+
+    target = reference_flow(case["target"])
+    torch.manual_seed(1)
+    prior, sde, dim = mg.build_prior(case["prior"]), mg.build_sde(case["sde"]), case["target"]["dim"]
+    ctrl = mg.build_ctrl(case["ctrl"], case["net"], dim, sde, prior, target)
+    lspec = case["loss"]
+    mods = [("grad", ctrl)]
+    if case.get("inference_ctrl"):
+        inf = mg.build_ctrl(case["inference_ctrl"], case.get("inference_net", case["net"]), dim, sde, prior, target)
+        loss = TimeReversalLoss(generative_ctrl=ctrl, sde=sde, method=lspec["method"], max_rnd=lspec["max_rnd"], inference_ctrl=inf)
+        second, train_kw = prior.log_prob, {"train": False}
+        mods.append(("grad_inf", inf))
+    else:
+        inf = None
+        reference = sde.marginal_distr(t=sde.terminal_t, x_init=prior.loc)  # solver/oc.py:189-191
+        loss = ReferenceSDELoss(generative_ctrl=ctrl, sde=sde, method=lspec["method"], max_rnd=lspec["max_rnd"])
+        second, train_kw = reference.log_prob, {}
+    g = case["grid"]
+    ts = mg.get_timesteps(g["start"], g["end"], steps=g["steps"], rescale_t=g["rescale_t"])
+    x0, noise, state = mg.draw_inputs(case, prior, ts)
+    out = {"param/" + k: v.detach().numpy().copy() for k, v in ctrl.state_dict().items()}
+    if inf is not None:
+        out.update({"param_inf/" + k: v.detach().numpy().copy() for k, v in inf.state_dict().items()})
+    out.update({"target/" + k: v.numpy().copy() for k, v in target.model.state_dict().items()})
+    out.update(ts=ts.numpy(), x0=x0.numpy(), noise=noise.numpy())
+    mgw._eval_passes(out, loss, ts, x0, state, target.unnorm_log_prob, second, train_kw)
+    _train_lv(out, loss, mods, ts, x0, state, target.unnorm_log_prob, second)
+    out["meta"] = np.frombuffer(json.dumps(dict(case, name=name)).encode(), dtype=np.uint8)
+    path = OUT / f"{name}.npz"
+    np.savez_compressed(path, **out)
+    print(f"{name:26s} B={case['B']} T={len(ts) - 1} logZ_is={out['eval1/log_norm_const_is']:+.4f} lb={out['eval2/log_norm_const_lb']:+.4f} "
+          f"train_lv={out['train_lv/loss']:+.5f} {path.stat().st_size / 1024:.1f} KB")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    only = set(sys.argv[1:])
+    if not only or "nice_kat_small" in only:
+        kat("nice_kat_small", dict(dim=196, coupling=4, mid_dim=36, hidden=3, mask_config=1.0, seed=7, scale_std=0.2, out_gain=3.0), 37, True)
+    if not only or "nice_kat_md500" in only:
+        kat("nice_kat_md500", dict(dim=196, coupling=4, mid_dim=500, hidden=5, mask_config=1.0, seed=5, scale_std=0.1, out_gain=1.0), 50, False)
+    for name, case in CASES.items():
+        if not only or name in only:
+            run_case(name, case)

@@ -55,13 +55,15 @@ def hatch(name: str, tag: str = "") -> None:
     except OSError:
         pass
 _ALL = sorted(glob.glob(str(GOLDEN_DIR / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide", "fullsize_"))]  # loss-loop fixtures (make_golden.py)
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide", "fullsize_", "nice"))]  # loss-loop fixtures (make_golden.py)
 GOLDEN_FULLSIZE = [p for p in _ALL if Path(p).name.startswith("fullsize_")]  # the reference at B = 65 536, scalars only (make_golden_fullsize.py)
 GOLDEN_WIDE = [p for p in _ALL if Path(p).name.startswith("wide_")]              # wide-network fixtures (make_golden_wide.py)
 GOLDEN_WIDE_BRIDGE = [p for p in _ALL if Path(p).name.startswith("widebridge_")]  # wide-network Bridge fixtures
 GOLDEN_INT = [p for p in _ALL if Path(p).name.startswith("int_")]      # Euler-integrator fixtures (make_golden_integrator.py)
 GOLDEN_BRIDGE = [p for p in _ALL if Path(p).name.startswith("bridge_")]    # Bridge fixtures (make_golden_bridge.py)
 GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]  # get_metrics fixtures (make_golden_metrics.py)
+GOLDEN_NICE = [p for p in _ALL if Path(p).name.startswith(("nicebridge", "nicepis"))]  # loss loops on the NICE flow (make_golden_nice.py)
+GOLDEN_NICE_KAT = [p for p in _ALL if Path(p).name.startswith("nice_kat")]            # the flow's log-density / score alone
 
 
 def load_metrics_fixture(path):
@@ -78,6 +80,8 @@ def load_fixture(path):
     tt = None
     if meta["target"]["kind"] == "gmm":
         tt = {k: torch.from_numpy(fx["target/" + k].copy()) for k in ("loc", "scale", "mixture_weights")}
+    elif meta["target"]["kind"] == "nice":  # the flow's state_dict (absent where the weights are a function of the spec's seed)
+        tt = {k[len("target/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("target/")} or None
     return fx, meta, params, tt
 
 

@@ -11,7 +11,7 @@ import torch
 from oracle import em_oracle as eo
 
 _ALL = sorted(glob.glob(str(Path(__file__).parent / "golden" / "*.npz")))
-GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide", "fullsize_"))]
+GOLDEN = [p for p in _ALL if not Path(p).name.startswith(("int_", "metrics_", "bridge_", "wide", "fullsize_", "nice"))]
 GOLDEN_WIDE = [p for p in _ALL if Path(p).name.startswith(("wide_", "widebridge_"))]
 GOLDEN_BRIDGE = [p for p in _ALL if Path(p).name.startswith("bridge_")]
 GOLDEN_METRICS = [p for p in _ALL if Path(p).name.startswith("metrics_")]
@@ -297,3 +297,65 @@ def test_sinkhorn_oracle_brackets_the_exact_assignment_cost(d, n, eps):
     assert exact - 1e-6 <= dist.item() <= exact + eps * math.log(n), (dist.item(), exact)
     # the plan's row argmax agrees with the optimal assignment for a large share of the points (measured: 0.49 / 0.7 at these eps)
     assert (corr_xy.numpy() == c[np.argsort(r)]).mean() > 0.35
+
+
+# ---- the NICE flow target of BASELINE configs[4] (tests/golden/make_golden_nice.py: outputs of the reference's distr/nice.py) --------------
+GOLDEN_NICE = [p for p in _ALL if Path(p).name.startswith(("nicebridge", "nicepis"))]
+GOLDEN_NICE_KAT = [p for p in _ALL if Path(p).name.startswith("nice_kat")]
+
+
+def _nice_density(fx, meta):
+    tspec = meta["target"]
+    tensors = {k[len("target/"):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("target/")}
+    if not tensors:  # weights = a function of the spec's seed: rebuilt by the host mirror, checked against the reference's checksum
+        import hashlib
+
+        from sde_sampler_amd import problems
+
+        model = problems.build_target(tspec).model
+        h = hashlib.sha256()
+        for k, v in model.state_dict().items():
+            h.update(k.encode())
+            h.update(v.detach().numpy().tobytes())
+        if h.hexdigest() != bytes(fx["weights_sha256"]).decode():
+            pytest.skip("this host's torch draws other initial weights than the build container's: the seed-only fixture cannot be rebuilt")
+        tensors = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return eo.Density(tspec, tensors)
+
+
+@pytest.mark.parametrize("path", GOLDEN_NICE_KAT, ids=lambda p: Path(p).stem)
+def test_nice_flow_known_answers_bit_exact(path):
+    """oracle Density("nice") = the reference's Nice.unnorm_log_prob / score (distr/nice.py:176-189, 276-277; distr/base.py:130-137) on
+    rows from the mode out to the logistic tails."""
+    fx = np.load(path)
+    meta = json.loads(bytes(fx["meta"]).decode())
+    dens = _nice_density(fx, meta)
+    x = torch.from_numpy(fx["x"])
+    assert np.array_equal(dens.unnorm_log_prob(x).numpy(), fx["unnorm_log_prob"])
+    assert np.array_equal(dens.score(x.clone()).numpy(), fx["score"])
+
+
+@pytest.mark.parametrize("path", GOLDEN_NICE, ids=lambda p: Path(p).stem)
+def test_nice_loss_loops_bit_exact(path):
+    """Bridge (losses/oc.py:189-202) and PIS on the flow: both evaluation passes, the lv training loss and its reference-autograd gradients."""
+    fx, prob, params, ts, x0, noise = load(path)
+    r1 = prob.eval(ts, x0, noise, compute_weights=True)
+    assert np.array_equal(r1["samples"].numpy(), fx["eval1/x_T"]) and np.array_equal(r1["rnd"].numpy(), fx["eval1/rnd"])
+    assert r1["log_norm_const_is"] == float(fx["eval1/log_norm_const_is"]) and r1["lv_loss"] == float(fx["eval1/lv_loss"])
+    r2 = prob.eval(ts, x0, noise, compute_weights=False)
+    assert np.array_equal(r2["rnd"].numpy(), fx["eval2/rnd"]) and r2["log_norm_const_lb"] == float(fx["eval2/log_norm_const_lb"])
+    params_inf = prob.inference_ctrl.p if getattr(prob, "inference_ctrl", None) is not None else {}
+    leaves = [(f"grad/{k}", v) for k, v in params.items() if not k.endswith("timestep_coeff")]
+    leaves += [(f"grad_inf/{k}", v) for k, v in params_inf.items() if not k.endswith("timestep_coeff")]
+    for _, v in leaves:
+        v.requires_grad_(True)
+    loss, n_filtered, _, _ = prob.train_loss(ts, x0, noise, method="lv")
+    loss.backward()
+    assert loss.item() == float(fx["train_lv/loss"]) and n_filtered == int(fx["train_lv/n_filtered"])
+    for key, v in leaves:
+        got = v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
+        full = f"train_lv/{key}"
+        if full in fx.files:
+            assert np.array_equal(got, fx[full]), key
+        else:
+            assert np.array_equal(got.reshape(-1)[::5], fx[full + "@stride"]), key

@@ -9,21 +9,26 @@
 //          (distr/base.py:130-137); the weights are constants (nice.py:271-273), so only d / d x is propagated.
 //
 // Everything is GEMM-shaped: per coupling hidden + 1 products forward and as many backward, [B, K] x [K, N] with K, N in {d/2, mid_dim}
-// (98 / 500 in the reference's checkpoint format).  One kernel serves them all: a workgroup of four waves owns a 64 (rows of the batch) x
+// (98 / 500 in the reference's checkpoint format).  One kernel serves them all: a workgroup of eight waves owns a 64 (rows of the batch) x
 // 128 (outputs) tile, both operands are staged through LDS k-major ([k][row], so that the 32x32x2 fp32 MFMA's operand fetch -- lane (j, h)
 // reads element j of k-row 2 s + h -- is one conflict-free ds_read_b32), the next k-tile's global loads are in flight while the current
-// one is multiplied.  The weight operand is read in the layout nn.Linear stores it ([out, in]): k-contiguous for a forward layer
+// one is multiplied, and is stored into the second LDS buffer behind the multiplication (one barrier per k-tile of 32).  The weight operand is read in the layout nn.Linear stores it ([out, in]): k-contiguous for a forward layer
 // (transposed on its way into LDS), n-contiguous for the reverse pass (copied as is) -- no packed or transposed copies of the parameters
 // exist, they are re-read on every call like every other parameter of this library.  Epilogue: + bias, + residual (the coupling's shift
 // joins the "on" half in place), ReLU, or the ReLU mask of the reverse pass (the stored activation of the layer below > 0).
 // fp32 throughout (the matrix instruction is bitwise an fmaf chain); the summation order of a dot product differs from the reference's
 // BLAS, which is what the parity tolerance of tests/test_hip_nice.py covers.
+#include <type_traits>
+
 #include "sdeh_traj.hpp"
 
 namespace sdeh {
 
-constexpr int kNgBM = 64, kNgBN = 128, kNgBK = 16;
-constexpr int kNgSX = kNgBM + 4, kNgSW = kNgBN + 4;  // LDS row strides (floats; multiples of 4: the n-contiguous copy is a 16-byte store)
+constexpr int kNgBM = 64, kNgBN = 128, kNgBK = 32, kNgThreads = 512;
+// LDS row strides (floats).  The transposing stores put lane (row r of 8, k quad q of 8) at [4 q + e][r]: with a stride = 2 (mod 8) the 64 lanes
+// of a wave land on every bank exactly twice (the minimum for 64 lanes on 32 banks); the n-contiguous copy is a 16-byte store: stride = 0 (mod 4)
+constexpr int kNgSX = kNgBM + 2;
+template <bool TRANS_B> constexpr int kNgSW = TRANS_B ? kNgBN + 2 : kNgBN + 4;
 
 struct NiceGemm {
   const float* X; long long ldx;    // [M, K], k contiguous
@@ -47,10 +52,13 @@ __device__ __forceinline__ float4 ng_load4(const float* __restrict__ row, int k,
   return v;
 }
 
+// Eight waves (two per SIMD: one wave's LDS / global latency is the other's matrix time) own a 64 x 128 tile as a 2 x 4 arrangement of 32 x 32
+// accumulator tiles; k-tiles of 32, two LDS buffers (the next tile is stored while the current one is multiplied: one barrier per k-tile).
 template <bool TRANS_B>
-__global__ __launch_bounds__(256) void nice_gemm_kernel(const NiceGemm G) {
-  __shared__ __attribute__((aligned(16))) float Xs[kNgBK * kNgSX];
-  __shared__ __attribute__((aligned(16))) float Ws[kNgBK * kNgSW];
+__global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G) {
+  __shared__ __attribute__((aligned(16))) float Xs[2][kNgBK * kNgSX];
+  constexpr int SW = kNgSW<TRANS_B>;
+  __shared__ __attribute__((aligned(16))) float Ws[2][kNgBK * SW];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 1, wn = w >> 1;
@@ -61,121 +69,130 @@ __global__ __launch_bounds__(256) void nice_gemm_kernel(const NiceGemm G) {
   const bool aw = (G.ldw & 3) == 0 && (reinterpret_cast<unsigned long long>(G.W) & 15) == 0;
 
   // this thread's share of a k-tile: one float4 of X (row xm, k quad xq), two float4 of W
-  const int xm = tid >> 2, xq = tid & 3;
+  const int xm = tid >> 3, xq = tid & 7;
   const bool xok = m0 + xm < G.M;
   const float* __restrict__ xrow = G.X + (xok ? m0 + xm : 0) * G.ldx;
-  float4 rx, rw[2];
-  auto load_tile = [&](int kt) {
+  // two register sets: the global loads of k-tile kt + 2 are issued while tile kt is multiplied and tile kt + 1 (loaded an iteration
+  // earlier) moves into the other LDS buffer -- two iterations of latency tolerance for a chain that has one workgroup per CU at B = 4096
+  float4 rx[2], rw[2][2];
+  auto load_tile = [&](int kt, auto SET) {
+    constexpr int S = decltype(SET)::value;
     const int k0 = kt * kNgBK;
-    rx = ng_load4(xrow, k0 + 4 * xq, K, xok, ax);
+    rx[S] = ng_load4(xrow, k0 + 4 * xq, K, xok, ax);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      if constexpr (TRANS_B) {  // W [N, K]: row n = n0 + tid / 4 + 64 r, k quad tid % 4
+      if constexpr (TRANS_B) {  // W [N, K]: row n = n0 + tid / 8 + 64 r, k quad tid % 8
         const int n = n0 + xm + 64 * r;
-        rw[r] = ng_load4(G.W + (long long)(n < N ? n : 0) * G.ldw, k0 + 4 * xq, K, n < N, aw);
-      } else {                  // W [K, N]: k row tid / 32 + 8 r, n quad tid % 32
-        const int k = k0 + (tid >> 5) + 8 * r;
-        rw[r] = ng_load4(G.W + (long long)(k < K ? k : 0) * G.ldw, n0 + 4 * (tid & 31), N, k < K, aw);
+        rw[S][r] = ng_load4(G.W + (long long)(n < N ? n : 0) * G.ldw, k0 + 4 * xq, K, n < N, aw);
+      } else {                  // W [K, N]: k row tid / 32 + 16 r, n quad tid % 32
+        const int k = k0 + (tid >> 5) + 16 * r;
+        rw[S][r] = ng_load4(G.W + (long long)(k < K ? k : 0) * G.ldw, n0 + 4 * (tid & 31), N, k < K, aw);
       }
     }
   };
-  auto store_tile = [&]() {
-    Xs[(4 * xq + 0) * kNgSX + xm] = rx.x;
-    Xs[(4 * xq + 1) * kNgSX + xm] = rx.y;
-    Xs[(4 * xq + 2) * kNgSX + xm] = rx.z;
-    Xs[(4 * xq + 3) * kNgSX + xm] = rx.w;
+  auto store_tile = [&](auto SET) {  // register set S -> LDS buffer S
+    constexpr int S = decltype(SET)::value;
+    float* __restrict__ xs = Xs[S];
+    float* __restrict__ wsb = Ws[S];
+    xs[(4 * xq + 0) * kNgSX + xm] = rx[S].x;
+    xs[(4 * xq + 1) * kNgSX + xm] = rx[S].y;
+    xs[(4 * xq + 2) * kNgSX + xm] = rx[S].z;
+    xs[(4 * xq + 3) * kNgSX + xm] = rx[S].w;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if constexpr (TRANS_B) {
         const int n = xm + 64 * r;
-        Ws[(4 * xq + 0) * kNgSW + n] = rw[r].x;
-        Ws[(4 * xq + 1) * kNgSW + n] = rw[r].y;
-        Ws[(4 * xq + 2) * kNgSW + n] = rw[r].z;
-        Ws[(4 * xq + 3) * kNgSW + n] = rw[r].w;
+        wsb[(4 * xq + 0) * SW + n] = rw[S][r].x;
+        wsb[(4 * xq + 1) * SW + n] = rw[S][r].y;
+        wsb[(4 * xq + 2) * SW + n] = rw[S][r].z;
+        wsb[(4 * xq + 3) * SW + n] = rw[S][r].w;
       } else {
-        *reinterpret_cast<float4*>(Ws + ((tid >> 5) + 8 * r) * kNgSW + 4 * (tid & 31)) = rw[r];
+        *reinterpret_cast<float4*>(wsb + ((tid >> 5) + 16 * r) * SW + 4 * (tid & 31)) = rw[S][r];
       }
     }
   };
 
-  f32x16 acc[2];
+  f32x16 acc;
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
 
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
   const int nk = (K + kNgBK - 1) / kNgBK;
-  load_tile(0);
-  store_tile();
+  load_tile(0, I0{});
+  if (nk > 1) load_tile(1, I1{});
+  store_tile(I0{});
   __syncthreads();
-  const float* __restrict__ xa = Xs + h * kNgSX + 32 * wm + j;
-  const float* __restrict__ wa = Ws + h * kNgSW + 64 * wn + j;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_tile(kt + 1);
-    // D rows = outputs n (A operand: the weights), D columns = batch rows m (B operand): lane (j, h) ends up with 16 outputs of row m0 + 32 wm + j
+  const int xoff = h * kNgSX + 32 * wm + j, woff = h * SW + 32 * wn + j;
+  // D rows = outputs n (A operand: the weights), D columns = batch rows m (B operand): lane (j, h) ends up with 16 outputs of row m0 + 32 wm + j
+  auto step = [&](int kt, auto CUR, auto NXT) {
+    constexpr int B = decltype(CUR)::value;
+    if (kt + 2 < nk) load_tile(kt + 2, CUR);  // (set B held tile kt: in LDS since the previous iteration)
+    const float* __restrict__ xa = Xs[B] + xoff;
+    const float* __restrict__ wa = Ws[B] + woff;
+    float av[kNgBK / 2], bv[kNgBK / 2];
 #pragma unroll
     for (int s = 0; s < kNgBK / 2; ++s) {
-      const float b = xa[2 * s * kNgSX];
-      const float a0 = wa[2 * s * kNgSW], a1 = wa[2 * s * kNgSW + 32];
-      acc[0] = SDEH_MFMA(a0, b, acc[0]);
-      acc[1] = SDEH_MFMA(a1, b, acc[1]);
+      av[s] = wa[2 * s * SW];
+      bv[s] = xa[2 * s * kNgSX];
     }
+#pragma unroll
+    for (int s = 0; s < kNgBK / 2; ++s) acc = SDEH_MFMA(av[s], bv[s], acc);
+    if (kt + 1 < nk) store_tile(NXT);  // (LDS buffer 1 - B was last read in iteration kt - 1, behind that iteration's barrier)
     __syncthreads();
-    if (kt + 1 < nk) {
-      store_tile();
-      __syncthreads();
-    }
+  };
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(kt, I0{}, I1{});
+    if (kt + 1 < nk) step(kt + 1, I1{}, I0{});
   }
 
-  // ---- epilogue: lane (j, h) holds outputs n = n0 + 64 wn + 32 t + 8 g + 4 h + e of batch row m -----------------------------------
+  // ---- epilogue: lane (j, h) holds outputs n = n0 + 32 wn + 8 g + 4 h + e of batch row m ----------------------------------------------
   const long long m = m0 + 32 * wm + j;
   if (m >= G.M) return;
   const bool vec = (N & 3) == 0 && (G.ldy & 3) == 0 && (G.addend == nullptr || (G.lda & 3) == 0) && (G.mask == nullptr || (G.ldm & 3) == 0);
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int g = 0; g < 4; ++g) {
+    const int n = n0 + 32 * wn + 8 * g + 4 * h;
+    if (n >= N) continue;
+    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+    if (vec) {  // (n + 3 < N: both multiples of 4)
+      if (G.bias != nullptr) {
+        const float4 bb = *reinterpret_cast<const float4*>(G.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (G.addend != nullptr) {
+        const float4 aa = *reinterpret_cast<const float4*>(G.addend + m * G.lda + n);
+        v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
+      }
+      if (G.relu) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int n = n0 + 64 * wn + 32 * t + 8 * g + 4 * h;
-      if (n >= N) continue;
-      float v[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-      if (vec) {  // (n + 3 < N: both multiples of 4)
-        if (G.bias != nullptr) {
-          const float4 bb = *reinterpret_cast<const float4*>(G.bias + n);
-          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-        }
-        if (G.addend != nullptr) {
-          const float4 aa = *reinterpret_cast<const float4*>(G.addend + m * G.lda + n);
-          v[0] += aa.x; v[1] += aa.y; v[2] += aa.z; v[3] += aa.w;
-        }
-        if (G.relu) {
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+      }
+      if (G.mask != nullptr) {
+        const float4 mm = *reinterpret_cast<const float4*>(G.mask + m * G.ldm + n);
+        v[0] = mm.x > 0.0f ? v[0] : 0.0f; v[1] = mm.y > 0.0f ? v[1] : 0.0f;
+        v[2] = mm.z > 0.0f ? v[2] : 0.0f; v[3] = mm.w > 0.0f ? v[3] : 0.0f;
+      }
+      *reinterpret_cast<float4*>(G.Y + m * G.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-        }
-        if (G.mask != nullptr) {
-          const float4 mm = *reinterpret_cast<const float4*>(G.mask + m * G.ldm + n);
-          v[0] = mm.x > 0.0f ? v[0] : 0.0f; v[1] = mm.y > 0.0f ? v[1] : 0.0f;
-          v[2] = mm.z > 0.0f ? v[2] : 0.0f; v[3] = mm.w > 0.0f ? v[3] : 0.0f;
-        }
-        *reinterpret_cast<float4*>(G.Y + m * G.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (n + e >= N) continue;
-          float y = v[e];
-          if (G.bias != nullptr) y += G.bias[n + e];
-          if (G.addend != nullptr) y += G.addend[m * G.lda + n + e];
-          if (G.relu) y = fmaxf(y, 0.0f);
-          if (G.mask != nullptr) y = G.mask[m * G.ldm + n + e] > 0.0f ? y : 0.0f;
-          G.Y[m * G.ldy + n + e] = y;
-        }
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= N) continue;
+        float y = v[e];
+        if (G.bias != nullptr) y += G.bias[n + e];
+        if (G.addend != nullptr) y += G.addend[m * G.lda + n + e];
+        if (G.relu) y = fmaxf(y, 0.0f);
+        if (G.mask != nullptr) y = G.mask[m * G.ldm + n + e] > 0.0f ? y : 0.0f;
+        G.Y[m * G.ldy + n + e] = y;
       }
     }
+  }
 }
 
 static int nice_gemm(const NiceGemm& g, bool trans_b, hipStream_t st) {
   const dim3 grid((unsigned)((g.M + kNgBM - 1) / kNgBM), (unsigned)((g.N + kNgBN - 1) / kNgBN));
-  if (trans_b) hipLaunchKernelGGL(nice_gemm_kernel<true>, grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL(nice_gemm_kernel<false>, grid, dim3(256), 0, st, g);
+  if (trans_b) hipLaunchKernelGGL(nice_gemm_kernel<true>, grid, dim3(kNgThreads), 0, st, g);
+  else hipLaunchKernelGGL(nice_gemm_kernel<false>, grid, dim3(kNgThreads), 0, st, g);
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

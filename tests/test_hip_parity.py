@@ -238,6 +238,9 @@ def test_alternative_kernels_also_match(env_var):
         pytest.skip("already an alternative-kernel run")
     name, _, value = env_var.partition("=")
     env = dict(os.environ, **{name: value or "1"})
+    # (the nested session starts with fresh logs of its own: it must not unlink this session's escape-hatch / measured-parity records)
+    import tempfile
+    env["SDEH_HATCH_REPORT"] = os.path.join(tempfile.mkdtemp(prefix="sdeh_nested_"), "fuzz_hatches.txt")
     out = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-m", "gpu", "-k",
                           "eval_matches_reference_golden or rnd_rows_match_oracle"],
                          env=env, capture_output=True, text=True, cwd=str(Path(__file__).parents[1]))

@@ -152,3 +152,64 @@ def test_shipped_integrator_yaml_mirrors_the_reference_yaml():
 
     assert ours["_target_"] == "sde_sampler_amd.eq.integrator.EulerIntegrator"
     EulerIntegrator(**{k: v for k, v in ours.items() if k != "_target_"})
+
+
+def _reference_nice():
+    """The reference's distr/nice.py with a stand-in for the one torchvision transform its constructor calls (a display-only resize)."""
+    if "torchvision" not in sys.modules:
+        class Resize:
+            def __init__(self, size, antialias=True):
+                self.size = size
+
+            def __call__(self, img):
+                return torch.nn.functional.interpolate(img.unsqueeze(0), size=self.size, mode="bilinear", antialias=True).squeeze(0)
+
+        tv, tr, ut = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms"), types.ModuleType("torchvision.utils")
+        tr.Resize, ut.make_grid = Resize, None
+        tv.transforms, tv.utils = tr, ut
+        sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.utils": ut})
+    return importlib.import_module("sde_sampler.distr.nice")
+
+
+def test_reference_nice_objects_map_onto_sdeh_nice(ref):
+    """BASELINE configs[4] as written: the REFERENCE's Nice(model=NiceModel(...)) behind a LerpTargetCtrl is described like this package's --
+    SdehNice pointers are the reference modules' own parameters, the problem's target is SDEH_DENS_EXTERNAL with the object riding along."""
+    from sde_sampler_amd import _lib as L
+    from sde_sampler_amd import engine as E
+
+    sys.path.insert(0, str(REFERENCE))
+    try:
+        rn = _reference_nice()
+    finally:
+        sys.path.remove(str(REFERENCE))
+    torch.manual_seed(5)
+    model = rn.NiceModel(prior=rn.StandardLogistic(), coupling=4, in_out_dim=196, mid_dim=500, hidden=5, mask_config=1.0)
+    target = rn.Nice(model=model, dim=196, n_reference_samples=1000)
+    keep = E._Keep()
+    nd = E.describe_nice(target, torch.device("cpu"), keep)
+    assert (nd.dim, nd.n_coupling, nd.mid_dim, nd.n_mid) == (196, 4, 500, 4)
+    assert [nd.mask_config[i] for i in range(4)] == [1, 0, 1, 0]
+    assert nd.in_w[2] == model.coupling[2].in_block[0].weight.data_ptr() and nd.mid_b[3][1] == model.coupling[3].mid_block[1][0].bias.data_ptr()
+    assert nd.out_w[0] == model.coupling[0].out_block.weight.data_ptr() and nd.scale == model.scaling.scale.data_ptr()
+    # the same seed through this package's mirror gives the same weights (the seed-only fixtures rely on it)
+    from sde_sampler_amd.distr import nice as mine
+    torch.manual_seed(5)
+    twin = mine.NiceModel(prior=mine.StandardLogistic(), coupling=4, in_out_dim=196, mid_dim=500, hidden=5, mask_config=1.0)
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), twin.state_dict().values()))
+    assert list(model.state_dict()) == list(twin.state_dict())
+    prior, sde = ref.gauss.IsotropicGauss(dim=196), ref.sdes.ScaledBM(diff_coeff=1.0, terminal_t=1.0)
+    base, gamma = _nets(ref, 196, channels=256)
+    gen = ref.reparam.LerpTargetCtrl(base_model=base, score_model=gamma, target_score=target.score, prior_score=prior.score, sde=sde,
+                                     detach_score=False, clip_score=10.0, clip_model=10.0)
+    keep = E._Keep()
+    pr = E.TrajectoryEngine().build_problem(loss_kind=L.LOSS_TIME_REVERSAL, generative_ctrl=gen, sde=sde, flags=0, device=torch.device("cpu"),
+                                            keep=keep, terminal_target=None, second=prior)
+    assert pr.target.kind == L.DENS_EXTERNAL and pr.target.dim == 196 and pr.ctrl_kind == L.CTRL_LERP_TARGET
+    assert [k.obj for k in keep if isinstance(k, E._ExternalTarget)] == [target]
+
+
+def test_shipped_target_yaml_mirrors_the_reference_yaml():
+    ours = yaml.safe_load((ROOT / "conf" / "target" / "nice_hip.yaml").read_text())
+    theirs = yaml.safe_load((REFERENCE / "conf" / "target" / "nice.yaml").read_text())
+    assert ours["_target_"] == "sde_sampler_amd.distr.nice.Nice" and theirs["_target_"].endswith(".Nice")
+    assert {k: v for k, v in theirs.items() if k != "_target_"}.items() <= ours.items()  # + `checkpoint`: the reference's default file is not shipped

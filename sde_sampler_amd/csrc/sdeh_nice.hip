@@ -54,7 +54,12 @@ __device__ __forceinline__ float4 ng_load4(const float* __restrict__ row, int k,
 
 // Eight waves (two per SIMD: one wave's LDS / global latency is the other's matrix time) own a 64 x 128 tile as a 2 x 4 arrangement of 32 x 32
 // accumulator tiles; k-tiles of 32, two LDS buffers (the next tile is stored while the current one is multiplied: one barrier per k-tile).
-template <bool TRANS_B>
+// VEC: every operand row is 16-byte aligned and whole float4s are in or out of range (all but the two products per coupling that read
+// in_block.weight, whose rows are 98 floats): the loads of a k-tile are then UNCONDITIONAL 16-byte loads from clamped addresses with the
+// out-of-range values selected to zero afterwards -- a fixed instruction sequence, so that the compiler can count the loads in flight
+// (`s_waitcnt vmcnt(3)`: wait for the older tile, leave the newer one in flight).  With loads under branches it waited for ALL of them
+// in every iteration (vmcnt(0)): 1.77 us per k-tile = the memory latency, 0.55 of the matrix rate inside the loop.
+template <bool TRANS_B, bool VEC>
 __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G) {
   __shared__ __attribute__((aligned(16))) float Xs[2][kNgBK * kNgSX];
   constexpr int SW = kNgSW<TRANS_B>;
@@ -71,43 +76,73 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
   // this thread's share of a k-tile: one float4 of X (row xm, k quad xq), two float4 of W
   const int xm = tid >> 3, xq = tid & 7;
   const bool xok = m0 + xm < G.M;
-  const float* __restrict__ xrow = G.X + (xok ? m0 + xm : 0) * G.ldx;
+  const float* __restrict__ xrow = G.X + (xok ? m0 + xm : G.M - 1) * G.ldx;
   // two register sets: the global loads of k-tile kt + 2 are issued while tile kt is multiplied and tile kt + 1 (loaded an iteration
   // earlier) moves into the other LDS buffer -- two iterations of latency tolerance for a chain that has one workgroup per CU at B = 4096
   float4 rx[2], rw[2][2];
+  const int K4 = (K + 3) & ~3;  // (X rows are padded with zeros to a multiple of 4; VEC weights have K % 4 == 0 resp. N % 4 == 0)
   auto load_tile = [&](int kt, auto SET) {
     constexpr int S = decltype(SET)::value;
     const int k0 = kt * kNgBK;
-    rx[S] = ng_load4(xrow, k0 + 4 * xq, K, xok, ax);
+    if constexpr (VEC) {  // raw loads from clamped addresses; out-of-range values are zeroed where the tile is stored (store_tile)
+      const int kq = k0 + 4 * xq;
+      const int kc = kq < K4 ? kq : K4 - 4;
+      rx[S] = *reinterpret_cast<const float4*>(xrow + kc);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if constexpr (TRANS_B) {  // W [N, K]: row n = n0 + tid / 8 + 64 r, k quad tid % 8
-        const int n = n0 + xm + 64 * r;
-        rw[S][r] = ng_load4(G.W + (long long)(n < N ? n : 0) * G.ldw, k0 + 4 * xq, K, n < N, aw);
-      } else {                  // W [K, N]: k row tid / 32 + 16 r, n quad tid % 32
-        const int k = k0 + (tid >> 5) + 16 * r;
-        rw[S][r] = ng_load4(G.W + (long long)(k < K ? k : 0) * G.ldw, n0 + 4 * (tid & 31), N, k < K, aw);
+      for (int r = 0; r < 2; ++r) {
+        if constexpr (TRANS_B) {  // W [N, K]: row n = n0 + tid / 8 + 64 r, k quad tid % 8
+          const int n = n0 + xm + 64 * r;
+          rw[S][r] = *reinterpret_cast<const float4*>(G.W + (long long)(n < N ? n : N - 1) * G.ldw + kc);
+        } else {                  // W [K, N]: k row tid / 32 + 16 r, n quad tid % 32
+          const int k = k0 + (tid >> 5) + 16 * r, nq = n0 + 4 * (tid & 31);
+          rw[S][r] = *reinterpret_cast<const float4*>(G.W + (long long)(k < K ? k : K - 1) * G.ldw + (nq < N ? nq : N - 4));
+        }
+      }
+    } else {
+      rx[S] = ng_load4(xrow, k0 + 4 * xq, K, xok, ax);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if constexpr (TRANS_B) {
+          const int n = n0 + xm + 64 * r;
+          rw[S][r] = ng_load4(G.W + (long long)(n < N ? n : 0) * G.ldw, k0 + 4 * xq, K, n < N, aw);
+        } else {
+          const int k = k0 + (tid >> 5) + 16 * r;
+          rw[S][r] = ng_load4(G.W + (long long)(k < K ? k : 0) * G.ldw, n0 + 4 * (tid & 31), N, k < K, aw);
+        }
       }
     }
   };
-  auto store_tile = [&](auto SET) {  // register set S -> LDS buffer S
+  auto store_tile = [&](auto SET, int kt) {  // register set S (holding k-tile kt) -> LDS buffer S
     constexpr int S = decltype(SET)::value;
+    float4 vx = rx[S], vw[2] = {rw[S][0], rw[S][1]};
+    if constexpr (VEC) {  // (component-wise selects: a ternary on the float4 struct is lowered to a select of ADDRESSES, i.e. scratch)
+      const int k0 = kt * kNgBK, kq = k0 + 4 * xq;
+      const bool okx = xok && kq < K4;
+      vx.x = okx ? vx.x : 0.0f; vx.y = okx ? vx.y : 0.0f; vx.z = okx ? vx.z : 0.0f; vx.w = okx ? vx.w : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        bool ok;
+        if constexpr (TRANS_B) ok = n0 + xm + 64 * r < N && kq < K;
+        else ok = k0 + (tid >> 5) + 16 * r < K && n0 + 4 * (tid & 31) < N;
+        vw[r].x = ok ? vw[r].x : 0.0f; vw[r].y = ok ? vw[r].y : 0.0f; vw[r].z = ok ? vw[r].z : 0.0f; vw[r].w = ok ? vw[r].w : 0.0f;
+      }
+    }
     float* __restrict__ xs = Xs[S];
     float* __restrict__ wsb = Ws[S];
-    xs[(4 * xq + 0) * kNgSX + xm] = rx[S].x;
-    xs[(4 * xq + 1) * kNgSX + xm] = rx[S].y;
-    xs[(4 * xq + 2) * kNgSX + xm] = rx[S].z;
-    xs[(4 * xq + 3) * kNgSX + xm] = rx[S].w;
+    xs[(4 * xq + 0) * kNgSX + xm] = vx.x;
+    xs[(4 * xq + 1) * kNgSX + xm] = vx.y;
+    xs[(4 * xq + 2) * kNgSX + xm] = vx.z;
+    xs[(4 * xq + 3) * kNgSX + xm] = vx.w;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if constexpr (TRANS_B) {
         const int n = xm + 64 * r;
-        wsb[(4 * xq + 0) * SW + n] = rw[S][r].x;
-        wsb[(4 * xq + 1) * SW + n] = rw[S][r].y;
-        wsb[(4 * xq + 2) * SW + n] = rw[S][r].z;
-        wsb[(4 * xq + 3) * SW + n] = rw[S][r].w;
+        wsb[(4 * xq + 0) * SW + n] = vw[r].x;
+        wsb[(4 * xq + 1) * SW + n] = vw[r].y;
+        wsb[(4 * xq + 2) * SW + n] = vw[r].z;
+        wsb[(4 * xq + 3) * SW + n] = vw[r].w;
       } else {
-        *reinterpret_cast<float4*>(wsb + ((tid >> 5) + 16 * r) * SW + 4 * (tid & 31)) = rw[S][r];
+        *reinterpret_cast<float4*>(wsb + ((tid >> 5) + 16 * r) * SW + 4 * (tid & 31)) = vw[r];
       }
     }
   };
@@ -120,14 +155,15 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
   using I1 = std::integral_constant<int, 1>;
   const int nk = (K + kNgBK - 1) / kNgBK;
   load_tile(0, I0{});
-  if (nk > 1) load_tile(1, I1{});
-  store_tile(I0{});
+  load_tile(nk > 1 ? 1 : 0, I1{});
+  store_tile(I0{}, 0);
   __syncthreads();
   const int xoff = h * kNgSX + 32 * wm + j, woff = h * SW + 32 * wn + j;
   // D rows = outputs n (A operand: the weights), D columns = batch rows m (B operand): lane (j, h) ends up with 16 outputs of row m0 + 32 wm + j
   auto step = [&](int kt, auto CUR, auto NXT) {
     constexpr int B = decltype(CUR)::value;
-    if (kt + 2 < nk) load_tile(kt + 2, CUR);  // (set B held tile kt: in LDS since the previous iteration)
+    load_tile(kt + 2 < nk ? kt + 2 : nk - 1, CUR);  // (set B held tile kt: in LDS since the previous iteration; past the end: the last tile again)
+    SDEH_FENCE();  // the loads stay at the top of the iteration (the scheduler otherwise sinks them behind the matrix instructions)
     const float* __restrict__ xa = Xs[B] + xoff;
     const float* __restrict__ wa = Ws[B] + woff;
     float av[kNgBK / 2], bv[kNgBK / 2];
@@ -138,7 +174,8 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
     }
 #pragma unroll
     for (int s = 0; s < kNgBK / 2; ++s) acc = SDEH_MFMA(av[s], bv[s], acc);
-    if (kt + 1 < nk) store_tile(NXT);  // (LDS buffer 1 - B was last read in iteration kt - 1, behind that iteration's barrier)
+    SDEH_FENCE();  // ... and the only wait on global memory at its bottom, for the tile loaded an iteration ago (vmcnt(3): the newer tile stays in flight)
+    store_tile(NXT, kt + 1 < nk ? kt + 1 : nk - 1);  // (LDS buffer 1 - B was last read in iteration kt - 1, behind that iteration's barrier; past the end: nobody reads it)
     __syncthreads();
   };
   for (int kt = 0; kt < nk; kt += 2) {
@@ -191,8 +228,16 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
 
 static int nice_gemm(const NiceGemm& g, bool trans_b, hipStream_t st) {
   const dim3 grid((unsigned)((g.M + kNgBM - 1) / kNgBM), (unsigned)((g.N + kNgBN - 1) / kNgBN));
-  if (trans_b) hipLaunchKernelGGL(nice_gemm_kernel<true>, grid, dim3(kNgThreads), 0, st, g);
-  else hipLaunchKernelGGL(nice_gemm_kernel<false>, grid, dim3(kNgThreads), 0, st, g);
+  const bool al = (g.ldx & 3) == 0 && (g.ldw & 3) == 0 && ((reinterpret_cast<unsigned long long>(g.X) | reinterpret_cast<unsigned long long>(g.W)) & 15) == 0;
+  // whole float4s in or out of range: the weights' contiguous extent a multiple of 4, at least one quad; X rows are zero-padded to a multiple of 4 by their owner
+  const bool vec = al && (trans_b ? (g.K & 3) == 0 : (g.N & 3) == 0 && g.N >= 4) && g.K >= 4 && g.ldx >= ((g.K + 3) & ~3);
+  if (trans_b) {
+    if (vec) hipLaunchKernelGGL((nice_gemm_kernel<true, true>), grid, dim3(kNgThreads), 0, st, g);
+    else hipLaunchKernelGGL((nice_gemm_kernel<true, false>), grid, dim3(kNgThreads), 0, st, g);
+  } else {
+    if (vec) hipLaunchKernelGGL((nice_gemm_kernel<false, true>), grid, dim3(kNgThreads), 0, st, g);
+    else hipLaunchKernelGGL((nice_gemm_kernel<false, false>), grid, dim3(kNgThreads), 0, st, g);
+  }
   return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
 }
 

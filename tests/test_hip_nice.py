@@ -356,3 +356,78 @@ def test_configs4_as_written_runs_at_reduced_size():
     eng.calls, prob.loss.row_offset = 4, 32
     hi = prob.eval(x0[32:], compute_weights=False)
     assert torch.equal(torch.cat([lo.samples, hi.samples]), a.samples)
+
+
+OTHER_SOLVERS = {
+    # conf/solver/dis.yaml's shape: LerpCtrl (prior AND target score: the supplied score meets the built-in prior score in torch.lerp's form), VP
+    "dis_lerp": dict(prior=dict(kind="iso_gauss", dim=196, loc=0.0, scale=1.0), sde=dict(kind="vp", beta_min=0.1, beta_max=6.0, scale=1.0, terminal_t=1.0),
+                     ctrl=dict(kind="lerp", clip_model=1e4, clip_score=1e4, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                     loss=dict(kind="time_reversal", method="kl", max_rnd=None), grid=dict(start=0.0, end=1.0, steps=7, rescale_t=None)),
+    # conf/solver/dds.yaml's shape: exponential integrator, ScoreCtrl with per-coordinate gamma and active clips, cosine grid
+    "dds_score": dict(prior=dict(kind="iso_gauss", dim=196, loc=0.0, scale=1.0, truncate_quartile=1e-4), sde=None,
+                      ctrl=dict(kind="score", clip_model=0.5, clip_score=1.0, scale_score=0.7, gamma_dim=196, gamma_bias=0.3),
+                      loss=dict(kind="exponential", method="lv", max_rnd=1e8, alpha=1.0, sigma=1.0),
+                      grid=dict(start=0.0, end=6.4, steps=9, rescale_t="cosine")),
+}
+
+
+@gpu
+@pytest.mark.parametrize("name", sorted(OTHER_SOLVERS))
+@pytest.mark.parametrize("channels,batch", [(128, 48), (64, 70)])
+def test_other_solvers_on_the_flow_match_the_oracle(name, channels, batch):
+    """DIS and DDS on the flow (the plain wide kernel in one-step segments; 64 channels at d = 196 run on it as well) against the CPU oracle
+    -- which is bit-exact on the reference-generated NICE fixtures (tests/test_oracle_golden.py) -- on identical noise; ragged batches."""
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
+
+    spec = dict(OTHER_SOLVERS[name], batch=batch, net=dict(channels=channels, num_layers=4, activation="gelu"),
+                target=dict(kind="nice", dim=196, coupling=3, mid_dim=44, hidden=3, mask_config=1.0, seed=17, scale_std=0.15, out_gain=3.0))
+    prob = problems.build(spec)
+    with torch.no_grad():
+        for mod in (prob.ctrl.base_model.out_layer, prob.ctrl.score_model.out_layer):
+            mod.weight.normal_(0.0, 0.05)
+    params = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
+    tt = {k: v.detach().clone() for k, v in prob.target.model.state_dict().items()}
+    torch.manual_seed(23)
+    x0 = prob.prior.sample((batch,))
+    T = prob.ts.numel() - 1
+    noise = torch.randn(T, batch, 196)
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        ref = eo.Problem(spec, params, tt).eval(prob.ts.clone(), x0.clone(), noise, compute_weights=True)
+    finally:
+        torch.set_num_threads(n)
+    prob.to(DEV)
+    got = prob.eval(x0.to(DEV), compute_weights=True, return_traj=False, noise=noise.to(DEV))
+    assert prob.loss.engine.last_kernel_name().startswith(f"traj_wide<C={channels}")
+    e_x = _rows("x_T", got.samples.cpu().numpy(), ref["samples"].numpy())
+    measured(f"nice_other_solvers/{name}/C{channels}/x_T", e_x, 1e-2)
+    for key in ("log_norm_const_lb_ito", "log_norm_const_is"):
+        want = ref[key]
+        tol = max(1e-4, 1e-5 * abs(want))
+        measured(f"nice_other_solvers/{name}/C{channels}/{key}", abs(got.log_norm_const_preds[key] - want), tol)
+        assert abs(got.log_norm_const_preds[key] - want) <= tol, (key, got.log_norm_const_preds[key], want)
+
+
+@gpu
+def test_stepped_evaluation_is_stable_under_repetition():
+    """200 back-to-back evaluations of the stepped path (5 segments + 5 score evaluations each, work memory reused from the engine's cache):
+    bitwise repeatable for a fixed (seed, call), no drift of the allocator-backed planes."""
+    from sde_sampler_amd import problems
+
+    spec = problems.baseline_spec("cfg5_nice_bridge196")
+    spec["batch"], spec["grid"]["steps"] = 160, 5
+    spec["net"]["channels"] = 128
+    spec["target"] = dict(kind="nice", dim=196, coupling=2, mid_dim=64, hidden=3)
+    prob = problems.build(spec, device=DEV)
+    torch.manual_seed(9)
+    x0 = prob.prior.sample((160,))
+    eng = prob.loss.engine
+    eng.calls = 11
+    first = prob.eval(x0, compute_weights=True)
+    for _ in range(200):
+        eng.calls = 11
+        again = prob.eval(x0, compute_weights=True)
+    assert torch.equal(first.samples, again.samples) and torch.equal(first.weights, again.weights)
+    assert len(eng._nice_work) <= 2

@@ -431,3 +431,78 @@ def test_stepped_evaluation_is_stable_under_repetition():
         again = prob.eval(x0, compute_weights=True)
     assert torch.equal(first.samples, again.samples) and torch.equal(first.weights, again.weights)
     assert len(eng._nice_work) <= 2
+
+
+def _random_flow_problem(case: int):
+    """A random (solver, control, network, flow geometry, batch) combination on the flow; the geometry spans one to four couplings, widths that
+    fill one, part of two and more than two output tiles, k-ranges that are and are not multiples of the k-tile, one to four hidden layers."""
+    import random
+
+    rng = random.Random(1000 + case)
+    d = 196
+    flow = dict(kind="nice", dim=d, coupling=rng.randint(1, 4), mid_dim=4 * rng.randint(2, 66), hidden=rng.randint(1, 4),
+                mask_config=float(rng.randint(0, 1)), seed=rng.randint(1, 99), scale_std=rng.choice([0.05, 0.2]), out_gain=rng.choice([1.0, 3.0]))
+    channels = rng.choice([64, 128, 256])
+    solver = rng.choice(["bridge", "pis", "dis", "dds"] if channels >= 128 else ["pis", "dis", "dds"])
+    clips = dict(clip_model=rng.choice([1e4, 0.3]), clip_score=rng.choice([1e4, 0.8]), scale_score=rng.choice([1.0, 0.6]))
+    gamma = dict(gamma_dim=rng.choice([1, d]), gamma_bias=rng.choice([1.0, 0.2]))
+    iso = dict(kind="iso_gauss", dim=d, loc=0.0, scale=1.0)
+    steps = rng.randint(2, 6)
+    spec = dict(batch=rng.choice([1, 31, 33, 64, 90]), target=flow, net=dict(channels=channels, num_layers=rng.choice([3, 4]), activation=rng.choice(["gelu", "silu", "relu"])))
+    if solver == "bridge":
+        spec.update(prior=iso, sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0), ctrl=dict(kind="lerp_target", **clips, **gamma),
+                    inference_ctrl=dict(kind=rng.choice(["lerp_prior", "clipped"]), clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0),
+                    loss=dict(kind="time_reversal", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=1.0, steps=steps, rescale_t=None))
+    elif solver == "pis":
+        spec.update(prior=dict(kind="delta", dim=d), sde=dict(kind="scaled_bm", diff_coeff=0.45, terminal_t=5.0), ctrl=dict(kind="score", **clips, **gamma),
+                    loss=dict(kind="reference_sde", method="lv", max_rnd=1e8), grid=dict(start=0.0, end=5.0, steps=steps, rescale_t=None))
+    elif solver == "dis":
+        spec.update(prior=iso, sde=dict(kind="vp", beta_min=0.1, beta_max=6.0, scale=1.0, terminal_t=1.0),
+                    ctrl=dict(kind=rng.choice(["lerp", "lerp_target", "score"]), **clips, **gamma),
+                    loss=dict(kind="time_reversal", method="kl", max_rnd=None), grid=dict(start=0.0, end=1.0, steps=steps, rescale_t=None))
+    else:
+        spec.update(prior=dict(iso, truncate_quartile=1e-4), sde=None, ctrl=dict(kind="score", **clips, **gamma),
+                    loss=dict(kind="exponential", method="lv", max_rnd=1e8, alpha=1.0, sigma=1.0),
+                    grid=dict(start=0.0, end=6.4, steps=steps + 2, rescale_t="cosine"))
+    return solver, spec
+
+
+@gpu
+@pytest.mark.parametrize("case", range(16))
+def test_random_problems_on_the_flow_match_the_oracle(case):
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
+
+    solver, spec = _random_flow_problem(case)
+    prob = problems.build(spec)
+    inf = getattr(prob.loss, "inference_ctrl", None)
+    with torch.no_grad():
+        for ctrl in (prob.ctrl, inf):
+            if ctrl is None:
+                continue
+            ctrl.base_model.out_layer.weight.normal_(0.0, 0.05)
+            if getattr(ctrl, "score_model", None) is not None:
+                ctrl.score_model.out_layer.weight.normal_(0.0, 0.05)
+    params = {k: v.detach().clone() for k, v in prob.ctrl.state_dict().items()}
+    params_inf = {k: v.detach().clone() for k, v in inf.state_dict().items()} if inf is not None else None
+    tt = {k: v.detach().clone() for k, v in prob.target.model.state_dict().items()}
+    B, T = spec["batch"], prob.ts.numel() - 1
+    torch.manual_seed(case)
+    x0 = prob.prior.sample((B,))
+    noise = torch.randn(T, B, 196)
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        ref = eo.Problem(spec, params, tt, params_inf=params_inf).eval(prob.ts.clone(), x0.clone(), noise, compute_weights=True)
+    finally:
+        torch.set_num_threads(n)
+    prob.to(DEV)
+    got = prob.eval(x0.to(DEV), compute_weights=True, return_traj=False, noise=noise.to(DEV))
+    tag = f"{solver}/C{spec['net']['channels']}/c{spec['target']['coupling']}m{spec['target']['mid_dim']}h{spec['target']['hidden']}/B{B}"
+    # (ReLU networks / flows put single units on their kink: rows are judged with the wide kernels' row criterion, the estimators with SURVEY 8d's bar)
+    e_x = _rows("x_T " + tag, got.samples.cpu().numpy(), ref["samples"].numpy())
+    measured(f"nice_fuzz/{case}/{tag}/x_T", e_x, 1e-2)
+    want = ref["log_norm_const_lb_ito"]
+    tol = max(2e-4, 2e-5 * abs(want)) * (4.0 if B < 8 else 1.0)
+    measured(f"nice_fuzz/{case}/{tag}/lb_ito", abs(got.log_norm_const_preds["log_norm_const_lb_ito"] - want), tol)
+    assert abs(got.log_norm_const_preds["log_norm_const_lb_ito"] - want) <= tol, (tag, got.log_norm_const_preds["log_norm_const_lb_ito"], want)

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--eval-batch", type=int, default=16384, help="trajectories of the log Z evaluations before / after training")
     ap.add_argument("--graph", action="store_true", help="capture the whole optimisation step into one hipGraph (utils/graphs.py)")
     ap.add_argument("--no-guard", action="store_true", help="with --graph: no device-side skip of non-finite updates")
+    ap.add_argument("--em-steps", type=int, default=None, help="Euler-Maruyama steps of the grid (default: the specification's)")
+    ap.add_argument("--channels", type=int, default=None, help="network width (default: the specification's)")
+    ap.add_argument("--print-every", type=int, default=100)
     args = ap.parse_args()
     if args.name == "bridge_dw":  # a Bridge (conf/solver/bridge.yaml style) on the shifted double well
         lerp = dict(clip_model=10.0, clip_score=10.0, scale_score=1.0, gamma_dim=1, gamma_bias=1.0)  # conf/solver/bridge.yaml
@@ -36,9 +39,13 @@ def main():
         spec = problems.baseline_spec(args.name)
     if args.method:
         spec["loss"]["method"] = args.method
+    if args.em_steps:
+        spec["grid"]["steps"] = args.em_steps
+    if args.channels:
+        spec["net"]["channels"] = args.channels
     prob = problems.build(spec, device="cuda:0")
     torch.manual_seed(args.seed)
-    if hasattr(prob.target, "compute_stats"):
+    if hasattr(prob.target, "compute_stats") and spec["target"]["kind"] != "nice":  # (a flow: normalised by construction, log Z = 0)
         prob.target.compute_stats()
     true_logz = prob.target.log_norm_const
     train_params = list(prob.ctrl.parameters())
@@ -81,10 +88,10 @@ def main():
             loss.backward()
             torch.nn.utils.clip_grad_norm_(train_params, 1.0)
             opt.step()
-        if (step + 1) % 100 == 0:
+        if (step + 1) % args.print_every == 0:
             torch.cuda.synchronize()
             now = time.perf_counter()
-            print(f"step {step + 1}: loss {loss.item():.4f}  ({1e3 * (now - t_last) / 100:.2f} ms/step over the last 100 steps, "
+            print(f"step {step + 1}: loss {loss.item():.4f}  ({1e3 * (now - t_last) / args.print_every:.2f} ms/step over the last {args.print_every} steps, "
                   f"{1e3 * (now - t0) / (step + 1):.2f} since the start)", flush=True)
             t_last = now
     if graphed is not None:

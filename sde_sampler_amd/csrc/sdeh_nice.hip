@@ -24,10 +24,9 @@
 
 namespace sdeh {
 
-constexpr int kNgBM = 64, kNgBN = 128, kNgBK = 32, kNgThreads = 512;
+constexpr int kNgBN = 128, kNgBK = 32;
 // LDS row strides (floats).  The transposing stores put lane (row r of 8, k quad q of 8) at [4 q + e][r]: with a stride = 2 (mod 8) the 64 lanes
 // of a wave land on every bank exactly twice (the minimum for 64 lanes on 32 banks); the n-contiguous copy is a 16-byte store: stride = 0 (mod 4)
-constexpr int kNgSX = kNgBM + 2;
 template <bool TRANS_B> constexpr int kNgSW = TRANS_B ? kNgBN + 2 : kNgBN + 4;
 
 struct NiceGemm {
@@ -59,14 +58,17 @@ __device__ __forceinline__ float4 ng_load4(const float* __restrict__ row, int k,
 // out-of-range values selected to zero afterwards -- a fixed instruction sequence, so that the compiler can count the loads in flight
 // (`s_waitcnt vmcnt(3)`: wait for the older tile, leave the newer one in flight).  With loads under branches it waited for ALL of them
 // in every iteration (vmcnt(0)): 1.77 us per k-tile = the memory latency, 0.55 of the matrix rate inside the loop.
-template <bool TRANS_B, bool VEC>
-__global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G) {
+// BM = 64: eight waves (2 x 4 accumulator tiles); BM = 32: four waves (1 x 4) -- twice the workgroups with half the work each, for batches
+// whose 64-row tiles would not fill the chip (nice_gemm: batch <= kNgSmallBatch).  A row's arithmetic does not depend on the tile height.
+template <bool TRANS_B, bool VEC, int BM>
+__global__ __launch_bounds__(8 * BM) void nice_gemm_kernel(const NiceGemm G) {
+  constexpr int kNgBM = BM, kNgSX = BM + 2, NR = kNgBN / BM;  // NR: passes of the workgroup over the 128 weight rows (TRANS_B) / 32 k-rows of a tile
   __shared__ __attribute__((aligned(16))) float Xs[2][kNgBK * kNgSX];
   constexpr int SW = kNgSW<TRANS_B>;
   __shared__ __attribute__((aligned(16))) float Ws[2][kNgBK * SW];
   const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = w & 1, wn = w >> 1;
+  const int wm = BM == 64 ? (w & 1) : 0, wn = BM == 64 ? (w >> 1) : w;
   const long long m0 = (long long)blockIdx.x * kNgBM;
   const int n0 = (int)blockIdx.y * kNgBN;
   const int K = G.K, N = G.N;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
   const float* __restrict__ xrow = G.X + (xok ? m0 + xm : G.M - 1) * G.ldx;
   // two register sets: the global loads of k-tile kt + 2 are issued while tile kt is multiplied and tile kt + 1 (loaded an iteration
   // earlier) moves into the other LDS buffer -- two iterations of latency tolerance for a chain that has one workgroup per CU at B = 4096
-  float4 rx[2], rw[2][2];
+  float4 rx[2], rw[2][NR];
   const int K4 = (K + 3) & ~3;  // (X rows are padded with zeros to a multiple of 4; VEC weights have K % 4 == 0 resp. N % 4 == 0)
   auto load_tile = [&](int kt, auto SET) {
     constexpr int S = decltype(SET)::value;
@@ -89,24 +91,24 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
       const int kc = kq < K4 ? kq : K4 - 4;
       rx[S] = *reinterpret_cast<const float4*>(xrow + kc);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < NR; ++r) {
         if constexpr (TRANS_B) {  // W [N, K]: row n = n0 + tid / 8 + 64 r, k quad tid % 8
-          const int n = n0 + xm + 64 * r;
+          const int n = n0 + xm + BM * r;
           rw[S][r] = *reinterpret_cast<const float4*>(G.W + (long long)(n < N ? n : N - 1) * G.ldw + kc);
         } else {                  // W [K, N]: k row tid / 32 + 16 r, n quad tid % 32
-          const int k = k0 + (tid >> 5) + 16 * r, nq = n0 + 4 * (tid & 31);
+          const int k = k0 + (tid >> 5) + (BM / 4) * r, nq = n0 + 4 * (tid & 31);
           rw[S][r] = *reinterpret_cast<const float4*>(G.W + (long long)(k < K ? k : K - 1) * G.ldw + (nq < N ? nq : N - 4));
         }
       }
     } else {
       rx[S] = ng_load4(xrow, k0 + 4 * xq, K, xok, ax);
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < NR; ++r) {
         if constexpr (TRANS_B) {
-          const int n = n0 + xm + 64 * r;
+          const int n = n0 + xm + BM * r;
           rw[S][r] = ng_load4(G.W + (long long)(n < N ? n : 0) * G.ldw, k0 + 4 * xq, K, n < N, aw);
         } else {
-          const int k = k0 + (tid >> 5) + 16 * r;
+          const int k = k0 + (tid >> 5) + (BM / 4) * r;
           rw[S][r] = ng_load4(G.W + (long long)(k < K ? k : 0) * G.ldw, n0 + 4 * (tid & 31), N, k < K, aw);
         }
       }
@@ -114,16 +116,18 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
   };
   auto store_tile = [&](auto SET, int kt) {  // register set S (holding k-tile kt) -> LDS buffer S
     constexpr int S = decltype(SET)::value;
-    float4 vx = rx[S], vw[2] = {rw[S][0], rw[S][1]};
+    float4 vx = rx[S], vw[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) vw[r] = rw[S][r];
     if constexpr (VEC) {  // (component-wise selects: a ternary on the float4 struct is lowered to a select of ADDRESSES, i.e. scratch)
       const int k0 = kt * kNgBK, kq = k0 + 4 * xq;
       const bool okx = xok && kq < K4;
       vx.x = okx ? vx.x : 0.0f; vx.y = okx ? vx.y : 0.0f; vx.z = okx ? vx.z : 0.0f; vx.w = okx ? vx.w : 0.0f;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
+      for (int r = 0; r < NR; ++r) {
         bool ok;
-        if constexpr (TRANS_B) ok = n0 + xm + 64 * r < N && kq < K;
-        else ok = k0 + (tid >> 5) + 16 * r < K && n0 + 4 * (tid & 31) < N;
+        if constexpr (TRANS_B) ok = n0 + xm + BM * r < N && kq < K;
+        else ok = k0 + (tid >> 5) + (BM / 4) * r < K && n0 + 4 * (tid & 31) < N;
         vw[r].x = ok ? vw[r].x : 0.0f; vw[r].y = ok ? vw[r].y : 0.0f; vw[r].z = ok ? vw[r].z : 0.0f; vw[r].w = ok ? vw[r].w : 0.0f;
       }
     }
@@ -134,15 +138,15 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
     xs[(4 * xq + 2) * kNgSX + xm] = vx.z;
     xs[(4 * xq + 3) * kNgSX + xm] = vx.w;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NR; ++r) {
       if constexpr (TRANS_B) {
-        const int n = xm + 64 * r;
+        const int n = xm + BM * r;
         wsb[(4 * xq + 0) * SW + n] = vw[r].x;
         wsb[(4 * xq + 1) * SW + n] = vw[r].y;
         wsb[(4 * xq + 2) * SW + n] = vw[r].z;
         wsb[(4 * xq + 3) * SW + n] = vw[r].w;
       } else {
-        *reinterpret_cast<float4*>(wsb + ((tid >> 5) + 16 * r) * SW + 4 * (tid & 31)) = vw[r];
+        *reinterpret_cast<float4*>(wsb + ((tid >> 5) + (BM / 4) * r) * SW + 4 * (tid & 31)) = vw[r];
       }
     }
   };
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
     }
 #pragma unroll
     for (int s = 0; s < kNgBK / 2; ++s) acc = SDEH_MFMA(av[s], bv[s], acc);
-    SDEH_FENCE();  // ... and the only wait on global memory at its bottom, for the tile loaded an iteration ago (vmcnt(3): the newer tile stays in flight)
+    SDEH_FENCE();  // ... and the only wait on global memory at its bottom, for the tile loaded an iteration ago (vmcnt(1 + NR): the newer tile stays in flight)
     store_tile(NXT, kt + 1 < nk ? kt + 1 : nk - 1);  // (LDS buffer 1 - B was last read in iteration kt - 1, behind that iteration's barrier; past the end: nobody reads it)
     __syncthreads();
   };
@@ -226,19 +230,28 @@ __global__ __launch_bounds__(kNgThreads) void nice_gemm_kernel(const NiceGemm G)
   }
 }
 
+template <int BM>
+static int nice_gemm_bm(const NiceGemm& g, bool trans_b, bool vec, hipStream_t st) {
+  const dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + kNgBN - 1) / kNgBN));
+  if (trans_b) {
+    if (vec) hipLaunchKernelGGL((nice_gemm_kernel<true, true, BM>), grid, dim3(8 * BM), 0, st, g);
+    else hipLaunchKernelGGL((nice_gemm_kernel<true, false, BM>), grid, dim3(8 * BM), 0, st, g);
+  } else {
+    if (vec) hipLaunchKernelGGL((nice_gemm_kernel<false, true, BM>), grid, dim3(8 * BM), 0, st, g);
+    else hipLaunchKernelGGL((nice_gemm_kernel<false, false, BM>), grid, dim3(8 * BM), 0, st, g);
+  }
+  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+}
+
+constexpr long long kNgSmallBatch = 4096;  // up to here 32-row tiles (measured, profiles/r06_nice_score_timing.txt; SDEH_NICE_BM forces a height: 0.92 vs 1.23 ms at B <= 2048, 1.30 vs 1.33 at 4096, 2.14 vs 2.02 at 8192)
+
 static int nice_gemm(const NiceGemm& g, bool trans_b, hipStream_t st) {
-  const dim3 grid((unsigned)((g.M + kNgBM - 1) / kNgBM), (unsigned)((g.N + kNgBN - 1) / kNgBN));
   const bool al = (g.ldx & 3) == 0 && (g.ldw & 3) == 0 && ((reinterpret_cast<unsigned long long>(g.X) | reinterpret_cast<unsigned long long>(g.W)) & 15) == 0;
   // whole float4s in or out of range: the weights' contiguous extent a multiple of 4, at least one quad; X rows are zero-padded to a multiple of 4 by their owner
   const bool vec = al && (trans_b ? (g.K & 3) == 0 : (g.N & 3) == 0 && g.N >= 4) && g.K >= 4 && g.ldx >= ((g.K + 3) & ~3);
-  if (trans_b) {
-    if (vec) hipLaunchKernelGGL((nice_gemm_kernel<true, true>), grid, dim3(kNgThreads), 0, st, g);
-    else hipLaunchKernelGGL((nice_gemm_kernel<true, false>), grid, dim3(kNgThreads), 0, st, g);
-  } else {
-    if (vec) hipLaunchKernelGGL((nice_gemm_kernel<false, true>), grid, dim3(kNgThreads), 0, st, g);
-    else hipLaunchKernelGGL((nice_gemm_kernel<false, false>), grid, dim3(kNgThreads), 0, st, g);
-  }
-  return hipGetLastError() == hipSuccess ? SDEH_OK : SDEH_ERR_HIP;
+  static const char* const force = getenv("SDEH_NICE_BM");  // measurement aid, read once: "32" | "64"
+  const bool small = force != nullptr ? force[0] == '3' : g.M <= kNgSmallBatch;
+  return small ? nice_gemm_bm<32>(g, trans_b, vec, st) : nice_gemm_bm<64>(g, trans_b, vec, st);
 }
 
 // x [B, d] -> E = x[:, :, 0], O = x[:, :, 1] as [B, hp] (columns >= d / 2 zero)

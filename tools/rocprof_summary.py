@@ -16,8 +16,12 @@ def main(path):
     row = con.execute("select name from top_kernels order by total_duration desc limit 1").fetchone()
     cur = con.execute("select duration, grid_x, workgroup_x, lds_size, scratch_size, vgpr_count, accum_vgpr_count, sgpr_count "
                       "from kernels where name = ? order by start", (row[0],))
-    for r in cur:
+    rows = cur.fetchall()
+    for r in rows[:40]:
         print("  duration_ns=%d grid=%d wg=%d lds=%d scratch=%d vgpr=%d agpr=%d sgpr=%d" % r)
+    if len(rows) > 40:  # (a stepped evaluation launches its segment kernel thousands of times)
+        ds = sorted(r[0] for r in rows)
+        print(f"  ... {len(rows) - 40} more dispatches; all {len(rows)}: min {ds[0]} ns, median {ds[len(ds) // 2]} ns, max {ds[-1]} ns")
 
 
 if __name__ == "__main__":

@@ -605,6 +605,10 @@ int32_t sdeh_nice_eval(const SdehNice* nice, const float* x, int64_t batch, floa
  *   xs [n_steps + 1, batch, d], gp [n_steps, batch, d]: as sdeh_simulate_fwd_aux2 (rows of this segment's steps are written), or NULL
  * The network part of a Bridge's divergence is accumulated per segment (its partial sums join rnd at the end of each segment): equal to
  * the one-launch result up to the order of that fp32 sum.
+ * Training on a supplied target: sdeh_ctrl_backward_ex takes the score ENTERING the control per step as `sc_in` [n_steps, batch, d] (the
+ * supplied score after the control's interpolation weight) and, for the methods that back-propagate through time, `tscore_in` [batch, d] =
+ * 1[|log rho(x_T)| <= clip_target] score(x_T); the supplied score is a constant of the adjoint recursion (the reference obtains such
+ * scores by autograd without a graph: distr/base.py:130-137 under models/reparam.py:56-66, 185-197).
  */
 int32_t sdeh_simulate_fwd_steps(SdehPlan* plan, const SdehProblem* problem, const float* ts, int32_t n_steps, int32_t step_begin,
                                 int32_t step_end, const float* x_in, int64_t batch, const float* noise, uint64_t seed, uint64_t offset,

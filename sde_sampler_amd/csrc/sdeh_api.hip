@@ -1148,9 +1148,9 @@ int32_t sdeh_ctrl_backward_ex(SdehPlan* plan, const SdehProblem* pr, const float
     return fail(SDEH_ERR_INVALID, "ctrl_backward_ex: xt_out / sc_in / tscore_in belong to the wide-network kernels");
   if (plan->wide) {  // channel-split chain kernel of sdeh_wide_bwd.hip (same planes; nn_in is not used: the wide forward keeps none)
     const bool planes_stand_in = pr->target.kind == SDEH_DENS_GMM || pr->target.kind == SDEH_DENS_EXTERNAL;
-    if (pr->target.kind == SDEH_DENS_EXTERNAL && bptt)
-      return fail(SDEH_ERR_UNSUPPORTED, "ctrl_backward (wide): back-propagation through time needs d score / d x of the target; a target whose "
-                                        "score is supplied per step trains with the log-variance methods (the reference's bridge.yaml)");
+    // (a supplied score is a CONSTANT of the adjoint recursion, like a mixture's: the reference obtains such scores by autograd without a
+    // graph -- distr/base.py:130-137 under reparam.py:56-66, 185-197 -- so back-propagation through time needs no derivative of it; the
+    // terminal cost's derivative arrives as tscore_in)
     if (planes_stand_in) {  // the chain kernel evaluates no mixture / no supplied target: the forward launch's planes stand in
       const bool ctrl_t = pr->ctrl_kind == SDEH_CTRL_SCORE || pr->ctrl_kind == SDEH_CTRL_LERP || pr->ctrl_kind == SDEH_CTRL_LERP_TARGET;
       if ((ctrl_t && sc_in == nullptr) || (bptt && (pr->flags & SDEH_FLAG_TERMINAL_TARGET) && tscore_in == nullptr))

@@ -272,6 +272,14 @@ def _known_distribution(obj) -> bool:
     return bool(names & (_GAUSS_NAMES | {"GMM", "DoubleWell", "MultiWell", "Funnel"}))
 
 
+class _PriorRef:
+    """Rides in a problem's `_Keep` next to an `_ExternalTarget`: the Gaussian prior whose score a LerpCtrl interpolates with the supplied
+    target score (the backward's `sc_in` plane is that interpolation, formed on the stored trajectory)."""
+
+    def __init__(self, obj):
+        self.obj = obj
+
+
 class _ExternalTarget:
     """Rides in a problem's `_Keep`: the target object whose score the engine evaluates BETWEEN the step segments of the wide kernels
     (SDEH_DENS_EXTERNAL, sdeh_simulate_fwd_steps) -- the NICE flow of BASELINE configs[4] (csrc/sdeh_nice.hip)."""
@@ -669,6 +677,8 @@ class TrajectoryEngine:
             _fill_density(reference_prior, pr.prior, keep, device, "prior")
             if pr.prior.kind != L.DENS_DIAG_GAUSS:
                 raise _unsupported("only Gaussian priors have a fused score")
+            if pr.target.kind == L.DENS_EXTERNAL:
+                keep.append(_PriorRef(reference_prior))
         if second is not None:
             _fill_density(second, pr.second, keep, device, "initial/reference density")
             if pr.second.kind != L.DENS_DIAG_GAUSS:
@@ -837,45 +847,67 @@ class TrajectoryEngine:
             if ext is None:
                 raise RuntimeError("SDEH_DENS_EXTERNAL without its target object (problem built outside build_problem?)")
             training = want_planes or want_gp
-            if training and pr.ctrl_kind == L.CTRL_LERP:
-                raise _unsupported("training a LerpCtrl on a NICE target (LerpTargetCtrl / ScoreCtrl: conf/solver/bridge.yaml, pis.yaml)")
             need_score = pr.ctrl_kind in (L.CTRL_SCORE, L.CTRL_LERP, L.CTRL_LERP_TARGET)
+            bptt = training and not (pr.flags & L.FLAG_CHANGE_SDE_CTRL)
+            terminal = bool(pr.flags & L.FLAG_TERMINAL_TARGET)
             if return_traj or training:
                 xs = torch.empty((n_steps + 1, batch, dim), device=device, dtype=torch.float32)
             # the score plane: every step's row is kept when a backward pass will want it, one [B, d] buffer otherwise
             sc = (torch.empty((n_steps if training else 1, batch, dim), device=device, dtype=torch.float32) if need_score else None)
             ping = (torch.empty((batch, dim), device=device, dtype=torch.float32), torch.empty((batch, dim), device=device, dtype=torch.float32))
             nkeep = _Keep()
-            desc = (describe_nice(ext.obj, device, nkeep), nkeep) if need_score else None
+            desc = (describe_nice(ext.obj, device, nkeep), nkeep)
             keep.extend(nkeep)
             cur = x.detach()
             if cur.dtype != torch.float32 or not cur.is_contiguous():
                 cur = cur.float().contiguous()
             cur_ptr = cur.data_ptr()
+            # a control without a score term (ClippedCtrl on the flow) only meets the flow in its terminal cost: the whole grid is one segment
+            seg = 1 if need_score else n_steps
             with torch.cuda.device(device):
-                for i in range(n_steps):
+                for i in range(0, n_steps, seg):
                     sc_i = None
                     if need_score:
                         sc_i = sc[i if training else 0]
                         nice_eval(ext.obj, cur, want_score=True, want_logp=False, cache=self._nice_work, score_out=sc_i, desc=desc)
-                    out = x_T if i == n_steps - 1 else ping[i & 1]
-                    L.check(lib.sdeh_simulate_fwd_steps(plan.handle, C.byref(pr), ts_p, n_steps, i, i + 1, cur_ptr, batch, noise_p,
+                    out = x_T if i + seg >= n_steps else ping[i & 1]
+                    L.check(lib.sdeh_simulate_fwd_steps(plan.handle, C.byref(pr), ts_p, n_steps, i, min(i + seg, n_steps), cur_ptr, batch, noise_p,
                                                         seed & 0xFFFFFFFFFFFFFFFF, offset, row_offset, out.data_ptr(), rnd.data_ptr(),
                                                         None if xs is None else xs.data_ptr(), None if gp is None else gp.data_ptr(),
                                                         None if sc_i is None else sc_i.data_ptr(), 0, stream))
                     cur, cur_ptr = out, out.data_ptr()
+                tscore = None
+                if terminal:
+                    # the terminal cost rnd -= clip(target.unnorm_log_prob(x_T), clip_target) (losses/oc.py:225, solver/oc.py:48-54) -- the
+                    # segments leave it to the caller of a supplied target -- and, for back-propagation through time, its derivative
+                    # 1[|log rho| <= clip_target] score(x_T) (torch.clamp's backward), the plane the wide backward takes as `tscore_in`
+                    score_T, lp = nice_eval(ext.obj, x_T, want_score=bptt, want_logp=True, cache=self._nice_work, desc=desc)
+                    ct = pr.clip_target
+                    rnd.sub_((lp.clamp(-ct, ct) if math.isfinite(ct) else lp).unsqueeze(-1))
+                    if bptt:
+                        tscore = score_T if not math.isfinite(ct) else score_T * (lp.abs() <= ct).unsqueeze(-1).to(score_T.dtype)
             sc_in = None
             if training and need_score:
                 # what the backward kernels take as `sc_in`: the score ENTERING the control, i.e. after the control's interpolation weight
-                # (reparam.py:185-197: t / T * target_score) and before clip_score / gamma(t) -- the kernels' own product, in fp32
+                # (reparam.py:185-197: t / T * target_score) and before clip_score / gamma(t) -- the kernels' own product, in fp32.  The flow's
+                # score is a constant of the reference's autograd graph (Distribution.score: create_graph = False, or x detached), also
+                # under back-propagation through time: no derivative of the flow's score is ever needed
                 sc_in = sc
-                if pr.ctrl_kind == L.CTRL_LERP_TARGET:
+                if pr.ctrl_kind in (L.CTRL_LERP_TARGET, L.CTRL_LERP):
                     wl = (ts.reshape(-1)[:-1].to(device=device, dtype=torch.float32) / torch.tensor(pr.terminal_t, dtype=torch.float32, device=device))
-                    sc_in.mul_(wl.view(-1, 1, 1))
+                    if pr.ctrl_kind == L.CTRL_LERP_TARGET:
+                        sc_in.mul_(wl.view(-1, 1, 1))
+                    else:  # LerpCtrl (reparam.py:131-144): torch.lerp(prior_score(x_t), target_score(x_t), t / T) on the stored trajectory
+                        pref = next((k for k in keep if isinstance(k, _PriorRef)), None)
+                        if pref is None:
+                            raise RuntimeError("LerpCtrl on a supplied target without its prior (problem built outside build_problem?)")
+                        with torch.no_grad():
+                            psc = pref.obj.score(xs[:-1].reshape(-1, dim)).reshape(n_steps, batch, dim)
+                        sc_in = torch.lerp(psc, sc, wl.view(-1, 1, 1))
             if want_planes:
-                return x_T, rnd, xs, ("wide", sc_in, None)
+                return x_T, rnd, xs, ("wide", sc_in, tscore)
             if want_gp:
-                return x_T, rnd, xs, gp, (sc_in, None)
+                return x_T, rnd, xs, gp, (sc_in, tscore)
             return x_T, rnd, (xs if return_traj else None)
         if want_planes:  # training forward: keep what the backward kernels need
             if not return_traj or want_gp or div_noise is not None:

@@ -43,9 +43,12 @@ def _resolve_terminal(fn: Callable):
     name = getattr(fn, "__name__", None)
     if owner is None:
         return None, None
-    if name == "unnorm_log_prob" and E._known_distribution(owner):
+    # (a NICE flow is "known" too: its log-density / score are HIP kernels of their own, evaluated by the engine around the trajectory
+    # kernels' step segments -- engine.run, SDEH_DENS_EXTERNAL)
+    if name == "unnorm_log_prob" and (E._known_distribution(owner) or E._external_target(owner)):
         return owner, None
-    if name == "clipped_target_unnorm_log_prob" and hasattr(owner, "target") and E._known_distribution(owner.target):
+    if name == "clipped_target_unnorm_log_prob" and hasattr(owner, "target") and (
+            E._known_distribution(owner.target) or E._external_target(owner.target)):
         return owner.target, getattr(owner, "clip_target", None)
     return None, None
 

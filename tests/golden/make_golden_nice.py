@@ -4,8 +4,8 @@ only (conventions: make_golden.py).  Reference entry points exercised:
   distr/nice.py:17-40, 43-97, 100-120, 123-231   StandardLogistic / Coupling / Scaling / NiceModel (random-initialised, seeded)
   distr/nice.py:233-298                          Nice(model=...)  (`unnorm_log_prob`; `score` = distr/base.py:130-137, autograd)
   losses/oc.py:156-230 incl. 189-202             TimeReversalLoss.simulate, Bridge branch (LerpTargetCtrl on the flow's score, LerpPriorCtrl
-                                                 inference control, exact divergence) -- evaluation passes and the lv training loss with
-                                                 the reference-autograd gradients of BOTH networks (conf/solver/bridge.yaml's loss)
+                                                 inference control, exact divergence) -- evaluation passes and the kl AND lv training losses with
+                                                 the reference-autograd gradients of BOTH networks (conf/solver/basic_bridge.yaml's / bridge.yaml's loss)
   losses/oc.py:286-343                           ReferenceSDELoss.simulate (PIS: ScoreCtrl on the flow's score)
 `data/nice.pt` (the trained flow) is not shipped and `Nice.__init__` imports torchvision for its `Resize` of the MNIST mean (used by
 `plots` only): the module is imported with a stand-in for that one transform (torch's own antialiased interpolation), like the
@@ -115,28 +115,6 @@ CASES = {
 }
 
 
-def _train_lv(out, loss, mods, ts, x0, state, terminal, second):
-    """train_lv/loss and the reference-autograd gradients (the flow's score is a constant of that graph: distr/base.py:130-137)."""
-    loss.method, loss.n_filtered = "lv", 0
-    for _, mod in mods:
-        mod.zero_grad()
-    torch.set_rng_state(state)
-    val, metrics = loss(ts, x0, terminal, second)
-    val.backward()
-    out["train_lv/loss"] = np.float64(val.item())
-    out["train_lv/n_filtered"] = np.int64(metrics["train/n_filtered_cumulative"])
-    for prefix, mod in mods:
-        for k, p in mod.named_parameters():
-            g = p.grad.detach().numpy().copy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
-            key = f"train_lv/{prefix}/{k}"
-            if g.size > mgw.GRAD_FULL_MAX:
-                out[key + "@stride"] = g.reshape(-1)[::mgw.GRAD_STRIDE].copy()
-                out[key + "@norm"] = np.float64(np.linalg.norm(g.astype(np.float64)))
-            else:
-                out[key] = g
-    loss.n_filtered = 0
-
-
 def run_case(name, case):
     import json
 
@@ -165,7 +143,7 @@ def run_case(name, case):
     out.update({"target/" + k: v.numpy().copy() for k, v in target.model.state_dict().items()})
     out.update(ts=ts.numpy(), x0=x0.numpy(), noise=noise.numpy())
     mgw._eval_passes(out, loss, ts, x0, state, target.unnorm_log_prob, second, train_kw)
-    _train_lv(out, loss, mods, ts, x0, state, target.unnorm_log_prob, second)
+    mgw._train_passes(out, loss, mods, ts, x0, state, target.unnorm_log_prob, second)  # methods kl AND lv: loss + reference-autograd gradients
     out["meta"] = np.frombuffer(json.dumps(dict(case, name=name)).encode(), dtype=np.uint8)
     path = OUT / f"{name}.npz"
     np.savez_compressed(path, **out)

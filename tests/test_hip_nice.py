@@ -290,43 +290,118 @@ def test_loss_loops_on_the_flow_match_the_reference(path):
     assert np.array_equal(xs[0], fx["x0"]) and np.array_equal(xs[-1], r1.samples.cpu().numpy())
 
 
-NICE_LOSS_BAR, NICE_GRAD_BAR = 3e-5, 1.3e-4  # the wide kernels' bars (tests/test_hip_wide_train.py)
+NICE_LOSS_BAR, NICE_GRAD_BAR = 3e-5, {"lv": 1.3e-4, "kl": 3e-4}  # the wide kernels' bars (tests/test_hip_wide_train.py: plain / Bridge kl)
 
 
 @gpu
+@pytest.mark.parametrize("method", ["lv", "kl"])
 @pytest.mark.parametrize("path", GOLDEN_NICE, ids=lambda p: Path(p).stem)
-def test_training_on_the_flow_matches_the_reference_autograd(path):
-    """conf/solver/bridge.yaml's loss (time_reversal_lv) / pis with lv on the flow: loss value and the parameter gradients of every network
-    against the reference's autograd -- the flow's score is a constant of that graph (distr/base.py:130-137 under x.detach()-free
-    LerpTargetCtrl: create_graph = False), which is what the score plane handed to the backward kernels is."""
+def test_training_on_the_flow_matches_the_reference_autograd(path, method):
+    """conf/solver/bridge.yaml's loss (time_reversal_lv), basic_bridge.yaml's (kl) and pis.yaml's (kl) on the flow: loss value and the parameter
+    gradients of every network against the reference's autograd.  The flow's score is a CONSTANT of that graph (distr/base.py:130-137:
+    `create_graph = False`, or x detached: reparam.py:56-66, 185-197), also under back-propagation through time -- which is what the score
+    plane handed to the backward kernels is; the terminal cost's derivative 1[|log rho| <= clip] score(x_T) arrives as a second plane."""
     from tests.test_hip_wide_train import _check_grads
 
     fx, meta, prob = _problem(path)
-    prob.loss.method = "lv"
+    prob.loss.method = method
     x0, noise = torch.from_numpy(fx["x0"]).to(DEV), torch.from_numpy(fx["noise"]).to(DEV)
     val, info = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise)
-    ref = float(fx["train_lv/loss"])
-    measured(f"nice_train_loss/{Path(path).stem}", abs(val.item() - ref) / max(1.0, abs(ref)), NICE_LOSS_BAR)
+    ref = float(fx[f"train_{method}/loss"])
+    measured(f"nice_train_loss/{Path(path).stem}/{method}", abs(val.item() - ref) / max(1.0, abs(ref)), NICE_LOSS_BAR)
     assert abs(val.item() - ref) <= NICE_LOSS_BAR * max(1.0, abs(ref)), (val.item(), ref)
-    assert int(info["train/n_filtered_cumulative"]) == int(fx["train_lv/n_filtered"])
+    assert int(info["train/n_filtered_cumulative"]) == int(fx[f"train_{method}/n_filtered"])
     val.backward()
-    worst = _check_grads(fx, "lv", "grad", prob.ctrl, tol=NICE_GRAD_BAR)
+    worst = _check_grads(fx, method, "grad", prob.ctrl, tol=NICE_GRAD_BAR[method])
     inf = getattr(prob.loss, "inference_ctrl", None)
     if inf is not None:
-        worst = max(worst, _check_grads(fx, "lv", "grad_inf", inf, tol=NICE_GRAD_BAR))
-    measured(f"nice_train_grad/{Path(path).stem}", worst[0], NICE_GRAD_BAR)
+        worst = max(worst, _check_grads(fx, method, "grad_inf", inf, tol=NICE_GRAD_BAR[method]))
+    measured(f"nice_train_grad/{Path(path).stem}/{method}", worst[0], NICE_GRAD_BAR[method])
 
 
 @gpu
-def test_back_propagation_through_time_on_the_flow_fails_loudly():
-    from sde_sampler_amd import SdehUnsupported
+@pytest.mark.parametrize("name,method", [("dis_lerp", "kl"), ("dis_lerp", "lv"), ("dds_score", "kl")])
+def test_training_other_solvers_on_the_flow_matches_the_oracle_autograd(name, method):
+    """conf/solver/dis.yaml (LerpCtrl: the backward's score plane is torch.lerp(prior score, flow score, t / T) on the stored trajectory; the
+    prior's part carries its Jacobian through time) and dds.yaml on the flow: gradients against the oracle's autograd on identical noise."""
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
 
-    fx, meta, prob = _problem([p for p in GOLDEN_NICE if "nicepis" in p][0])
-    prob.loss.method = "kl"
-    x0 = torch.from_numpy(fx["x0"]).to(DEV)
-    with pytest.raises(SdehUnsupported):
-        val, _ = prob.loss(prob.ts, x0, prob.target.unnorm_log_prob, prob.second_log_prob)
-        val.backward()
+    batch = 40
+    spec = dict(OTHER_SOLVERS[name], batch=batch, net=dict(channels=128, num_layers=4, activation="gelu"),
+                target=dict(kind="nice", dim=196, coupling=3, mid_dim=44, hidden=3, mask_config=1.0, seed=17, scale_std=0.15, out_gain=3.0))
+    spec["loss"] = dict(spec["loss"], method=method, max_rnd=1e8 if method == "lv" else None)
+    if name == "dds_score":  # (inactive clips: a clamp on its edge is a coin toss between two fp32 evaluations)
+        spec["ctrl"] = dict(spec["ctrl"], clip_model=1e4, clip_score=1e4)
+    prob = problems.build(spec)
+    with torch.no_grad():
+        for mod in (prob.ctrl.base_model.out_layer, prob.ctrl.score_model.out_layer):
+            mod.weight.normal_(0.0, 0.05)
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith("timestep_coeff")) for k, v in prob.ctrl.state_dict().items()}
+    tt = {k: v.detach().clone() for k, v in prob.target.model.state_dict().items()}
+    torch.manual_seed(29)
+    x0 = prob.prior.sample((batch,))
+    T = prob.ts.numel() - 1
+    noise = torch.randn(T, batch, 196)
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        ref_loss, _, _, _ = eo.Problem(spec, params, tt).train_loss(prob.ts.clone(), x0.clone(), noise, method=method)
+        ref_loss.backward()
+    finally:
+        torch.set_num_threads(n)
+    prob.to(DEV)
+    val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
+    assert abs(val.item() - ref_loss.item()) <= NICE_LOSS_BAR * max(1.0, abs(ref_loss.item())), (val.item(), ref_loss.item())
+    val.backward()
+    worst = 0.0
+    gmax = max(float(v.grad.abs().max()) for v in params.values() if v.grad is not None)
+    for k, p in prob.ctrl.named_parameters():
+        want = params[k].grad
+        if want is None:
+            continue
+        got = p.grad.detach().cpu() if p.grad is not None else torch.zeros_like(want)
+        scale = max(float(want.abs().max()), 1e-3 * gmax, 1e-12)
+        worst = max(worst, float((got - want).abs().max()) / scale)
+    measured(f"nice_train_other/{name}/{method}", worst, NICE_GRAD_BAR["kl"])
+    assert worst <= NICE_GRAD_BAR["kl"], worst
+
+
+@gpu
+def test_a_control_without_a_score_term_meets_the_flow_in_one_segment():
+    """ClippedCtrl on the flow: no score per step -- the grid runs as ONE segment, the flow enters through the terminal cost alone; against the
+    oracle, evaluation and kl training."""
+    from oracle import em_oracle as eo
+    from sde_sampler_amd import problems
+
+    spec = dict(batch=33, target=dict(kind="nice", dim=196, coupling=2, mid_dim=40, hidden=2, seed=4, scale_std=0.1, out_gain=2.0),
+                prior=dict(kind="iso_gauss", dim=196, loc=0.0, scale=1.0), sde=dict(kind="vp", beta_min=0.1, beta_max=6.0, scale=1.0, terminal_t=1.0),
+                ctrl=dict(kind="clipped", clip_model=1e4), net=dict(channels=128, num_layers=4, activation="gelu"),
+                loss=dict(kind="time_reversal", method="kl", max_rnd=None), grid=dict(start=0.0, end=1.0, steps=5, rescale_t=None))
+    prob = problems.build(spec)
+    with torch.no_grad():
+        prob.ctrl.base_model.out_layer.weight.normal_(0.0, 0.05)
+    params = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith("timestep_coeff")) for k, v in prob.ctrl.state_dict().items()}
+    tt = {k: v.detach().clone() for k, v in prob.target.model.state_dict().items()}
+    torch.manual_seed(31)
+    x0, noise = prob.prior.sample((33,)), torch.randn(5, 33, 196)
+    oracle = eo.Problem(spec, params, tt)
+    ref = oracle.eval(prob.ts.clone(), x0.clone(), noise, compute_weights=True)
+    ref_loss, _, _, _ = oracle.train_loss(prob.ts.clone(), x0.clone(), noise, method="kl")
+    ref_loss.backward()
+    prob.to(DEV)
+    got = prob.eval(x0.to(DEV), compute_weights=True, noise=noise.to(DEV))
+    assert prob.loss.engine.last_kernel_name().startswith("traj_wide<C=128")
+    assert abs(got.log_norm_const_preds["log_norm_const_lb_ito"] - ref["log_norm_const_lb_ito"]) <= max(1e-4, 1e-5 * abs(ref["log_norm_const_lb_ito"]))
+    val, _ = prob.loss(prob.ts, x0.to(DEV), prob.target.unnorm_log_prob, prob.second_log_prob, noise=noise.to(DEV))
+    assert abs(val.item() - ref_loss.item()) <= NICE_LOSS_BAR * max(1.0, abs(ref_loss.item()))
+    val.backward()
+    for k, p in prob.ctrl.named_parameters():
+        want = params[k].grad
+        if want is None:
+            continue
+        err = float((p.grad.detach().cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-9)
+        assert err <= 3e-4, (k, err)
 
 
 @gpu

@@ -349,13 +349,16 @@ def test_nice_loss_loops_bit_exact(path):
     leaves += [(f"grad_inf/{k}", v) for k, v in params_inf.items() if not k.endswith("timestep_coeff")]
     for _, v in leaves:
         v.requires_grad_(True)
-    loss, n_filtered, _, _ = prob.train_loss(ts, x0, noise, method="lv")
-    loss.backward()
-    assert loss.item() == float(fx["train_lv/loss"]) and n_filtered == int(fx["train_lv/n_filtered"])
-    for key, v in leaves:
-        got = v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
-        full = f"train_lv/{key}"
-        if full in fx.files:
-            assert np.array_equal(got, fx[full]), key
-        else:
-            assert np.array_equal(got.reshape(-1)[::5], fx[full + "@stride"]), key
+    for method in ("kl", "lv"):
+        for _, v in leaves:
+            v.grad = None
+        loss, n_filtered, _, _ = prob.train_loss(ts, x0, noise, method=method)
+        loss.backward()
+        assert loss.item() == float(fx[f"train_{method}/loss"]) and n_filtered == int(fx[f"train_{method}/n_filtered"])
+        for key, v in leaves:
+            got = v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)
+            full = f"train_{method}/{key}"
+            if full in fx.files:
+                assert np.array_equal(got, fx[full]), (method, key)
+            else:
+                assert np.array_equal(got.reshape(-1)[::5], fx[full + "@stride"]), (method, key)

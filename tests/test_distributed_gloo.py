@@ -183,6 +183,41 @@ def _mask_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _dtype_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sde_sampler_amd.utils.distributed import all_reduce_gradients
+
+    a = torch.nn.Parameter(torch.ones(3, dtype=torch.float64))
+    b = torch.nn.Parameter(torch.ones(2, dtype=torch.float32))
+    c = torch.nn.Parameter(torch.ones(4, dtype=torch.float32))  # never has a gradient
+    tiny = 1.0 + 2.0 ** -40  # not representable in fp32
+    a.grad, b.grad, c.grad = torch.full((3,), tiny * (rank + 1), dtype=torch.float64), torch.full((2,), 0.5 * (rank + 1)), None
+    all_reduce_gradients([a, b, c])
+    q.put((rank, (str(a.grad.dtype), a.grad.tolist(), str(b.grad.dtype), b.grad.tolist(), c.grad is None)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_keeps_the_parameters_dtype():
+    """the bucket travels in the widest dtype among the parameters -- an fp64 gradient is reduced in fp64 (the bucket used to be
+    cast to fp32), fp32 gradients come back as fp32, a parameter without a gradient keeps `grad = None`."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dtype_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    tiny = 1.0 + 2.0 ** -40
+    for r in range(world):
+        dt_a, ga, dt_b, gb, c_none = got[r]
+        assert dt_a == "torch.float64" and ga == [3.0 * tiny] * 3 and 3.0 * tiny != 3.0
+        assert dt_b == "torch.float32" and gb == [1.5, 1.5] and c_none
+
+
 def test_gradient_all_reduce_with_diverging_gradient_patterns_never_mismatches_collectives():
     """every call joins ONE collective of a fixed shape; a disagreement about which parameters have gradients is an error
     on the rank that sees the new pattern and NaN gradients (for the trainer's finite-gradient guard) on the others -- never a hang."""

@@ -46,7 +46,7 @@ WORKLOADS = {
                            "funnel d=196, basic_pis-style (ScoreCtrl, FourierMLP C=256 L=4 GELU, ScaledBM), wide-network kernel"),
     "cfg5_like_bridge196": ("cfg5_like_bridge196", "trajectory-steps/sec, Bridge d=196 C=256 (BASELINE configs[4] shape)",
                             "Bridge (LerpTargetCtrl + LerpPriorCtrl inference control, exact divergence), funnel d=196 target "
-                            "in place of the unfusable NICE flow, two FourierMLP C=256 L=4 GELU, ScaledBM(1, T=1)"),
+                            "in place of the NICE flow (a closed-form target: the whole grid in ONE launch; the flow itself: cfg5_nice_bridge196), two FourierMLP C=256 L=4 GELU, ScaledBM(1, T=1)"),
     # BASELINE configs[4] AS WRITTEN: target = nice.  The flow's score is evaluated by csrc/sdeh_nice.hip between the one-step segments of
     # the wide Bridge kernel (engine.run: SDEH_DENS_EXTERNAL); weights: the checkpoint's geometry, seeded random (data/nice.pt is not shipped)
     "cfg5_nice_bridge196": ("cfg5_nice_bridge196", "trajectory-steps/sec, Bridge d=196 C=256 on the NICE flow (BASELINE configs[4] as written)",

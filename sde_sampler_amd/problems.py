@@ -314,8 +314,8 @@ BASELINE_SPECS = {
         loss=dict(kind="exponential", method="lv", max_rnd=1e8, alpha=1.0, sigma=1.0),
         grid=dict(start=0.0, end=12.8, steps=400, rescale_t="cosine")),
     # Wide-network workloads (bench.py --workload): the geometry of configs[4] -- d = 196 (MNIST 14 x 14 after NICE's preprocessing
-    # would be 784; the task's configs[4] is quoted with channels = 256), two FourierMLP C = 256 -- on a FUSABLE target (the NICE flow
-    # of distr/nice.py needs torchvision and data/nice.pt; SURVEY.md section 2 marks it out of scope); clips of conf/solver/bridge.yaml
+    # would be 784; the task's configs[4] is quoted with channels = 256), two FourierMLP C = 256 -- on a target the kernels carry in closed form (one
+    # launch over all steps; the NICE flow itself: "cfg5_nice_bridge196" below, stepped around csrc/sdeh_nice.hip); clips of conf/solver/bridge.yaml
     "wide_pis_funnel196": dict(
         batch=32768, target=dict(kind="funnel", dim=196),
         prior=dict(kind="delta", dim=196), sde=dict(kind="scaled_bm", diff_coeff=math.sqrt(0.2), terminal_t=5.0),

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(8 * BM) void nice_gemm_kernel(const NiceGemm G) {
   // ---- epilogue: lane (j, h) holds outputs n = n0 + 32 wn + 8 g + 4 h + e of batch row m ----------------------------------------------
   const long long m = m0 + 32 * wm + j;
   if (m >= G.M) return;
-  const bool vec = (N & 3) == 0 && (G.ldy & 3) == 0 && (G.addend == nullptr || (G.lda & 3) == 0) && (G.mask == nullptr || (G.ldm & 3) == 0);
+  const bool vec = (N & 3) == 0 && (G.ldy & 3) == 0 && (G.addend == nullptr || (G.lda & 3) == 0) && (G.mask == nullptr || (G.ldm & 3) == 0) &&
+                   (G.bias == nullptr || (reinterpret_cast<unsigned long long>(G.bias) & 15) == 0);  // (a bias that is a view at an odd offset: element-wise)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int n = n0 + 32 * wn + 8 * g + 4 * h;

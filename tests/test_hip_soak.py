@@ -65,6 +65,10 @@ EVAL_CASES = [
     ("cfg5_like_bridge196", 512, 6, {"SDEH_WIDE_SPLIT": 1}, "bridge_wide<C=256,split=1>"),
     ("cfg5_like_bridge196", 512, 6, {"SDEH_WIDE_SPLIT": 2}, "bridge_wide<C=256,split=2>"),
     ("cfg5_like_bridge196", 256, 6, {"SDEH_WIDE_SPLIT": 8}, "bridge_wide<C=256,split=8>"),
+    # BASELINE configs[4] as written (round 6): one-step segments of the Bridge kernel around the NICE flow's GEMM chain (csrc/sdeh_nice.hip:
+    # loads two k-tiles ahead behind scheduling fences), 32-row tiles and -- beyond 4096 rows, ragged -- 64-row tiles
+    ("cfg5_nice_bridge196", 512, 4, {}, "bridge_wide<C=256,split=8>"),
+    ("cfg5_nice_bridge196", 4160, 3, {}, "bridge_wide<C=256,split=2>"),
 ]
 
 

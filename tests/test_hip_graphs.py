@@ -325,7 +325,8 @@ def test_random_problem_replayed_gradients_equal_eager(case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,weights", [("gmm50_pis_headline", False), ("cfg2_gmm2_dis_kl", True), ("cfg4_funnel_dds_lv", True)])
+@pytest.mark.parametrize("name,weights", [("gmm50_pis_headline", False), ("cfg2_gmm2_dis_kl", True), ("cfg4_funnel_dds_lv", True),
+                                          ("cfg5_nice_bridge196", True)])  # (the stepped path: segments + the flow's GEMM chain in one graph)
 def test_graphed_eval_equals_eager_eval(name, weights):
     """utils.graphs.GraphedEval: the replayed evaluation (one launch + the 8-float copy) returns bit for bit what the eager
     `loss.eval` returns at the same Philox offset -- samples, importance weights and every estimator -- draws fresh noise per replay,
@@ -334,6 +335,8 @@ def test_graphed_eval_equals_eager_eval(name, weights):
 
     spec = problems.baseline_spec(name)
     spec["batch"] = 4096
+    if name == "cfg5_nice_bridge196":
+        spec["grid"]["steps"] = 4
     prob = problems.build(spec, device="cuda:0")
     torch.manual_seed(5)
     x0 = prob.prior.sample((4096,))

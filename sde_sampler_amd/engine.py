@@ -894,7 +894,8 @@ class TrajectoryEngine:
                 # under back-propagation through time: no derivative of the flow's score is ever needed
                 sc_in = sc
                 if pr.ctrl_kind in (L.CTRL_LERP_TARGET, L.CTRL_LERP):
-                    wl = (ts.reshape(-1)[:-1].to(device=device, dtype=torch.float32) / torch.tensor(pr.terminal_t, dtype=torch.float32, device=device))
+                    # (tensor / tensor: a true fp32 division like the kernels' `s / terminal_t`; torch.full is a fill kernel -- capture-safe, no host copy)
+                    wl = ts.reshape(-1)[:-1].to(device=device, dtype=torch.float32) / torch.full((1,), pr.terminal_t, dtype=torch.float32, device=device)
                     if pr.ctrl_kind == L.CTRL_LERP_TARGET:
                         sc_in.mul_(wl.view(-1, 1, 1))
                     else:  # LerpCtrl (reparam.py:131-144): torch.lerp(prior_score(x_t), target_score(x_t), t / T) on the stored trajectory

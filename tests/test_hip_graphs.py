@@ -48,6 +48,13 @@ def _build(seed=0, method="lv"):
                     sde=dict(kind="scaled_bm", diff_coeff=1.0, terminal_t=1.0), ctrl=dict(kind="lerp_target", **lerp),
                     inference_ctrl=dict(kind="lerp_prior", **lerp), net=dict(channels=128, num_layers=4, activation="gelu"),
                     loss=dict(kind="time_reversal", method="kl"), grid=dict(start=0.0, end=1.0, steps=6))
+    elif method in ("nice_bridge", "nice_bridge_kl"):  # BASELINE configs[4] as written at a small size: the stepped forward around the flow's score
+        spec = problems.baseline_spec("cfg5_nice_bridge196")
+        spec["grid"]["steps"], spec["net"]["channels"] = 5, 128
+        spec["target"] = dict(kind="nice", dim=196, coupling=2, mid_dim=64, hidden=3)
+        spec["loss"]["method"] = "kl" if method.endswith("kl") else "lv"
+        if method.endswith("kl"):
+            spec["loss"]["max_rnd"] = None
     elif method.startswith("wide"):  # wide networks (csrc/sdeh_wide_bwd.hip): "wide_lv" / "wide_kl" plain, "wide_bridge" configs[4]'s shape
         spec = problems.baseline_spec("cfg5_like_bridge196" if method == "wide_bridge" else "wide_pis_funnel196")
         spec["grid"]["steps"] = 6 if method == "wide_bridge" else 12
@@ -169,7 +176,8 @@ def test_graphed_step_skips_non_finite_updates_on_device():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("method,batch", [("lv", 2048), ("kl", 2048), ("bridge", 2048), ("lv", 65536), ("kl", 40000), ("bridge", 16384),
-                                          ("wide_lv", 2048), ("wide_kl", 1000), ("wide_bridge", 256), ("wide_bridge_gmm", 200)])
+                                          ("wide_lv", 2048), ("wide_kl", 1000), ("wide_bridge", 256), ("wide_bridge_gmm", 200),
+                                          ("nice_bridge", 200), ("nice_bridge_kl", 100)])
 def test_replayed_gradients_equal_eager_gradients(method, batch):
     """Every parameter gradient of forward + backward replayed from a hipGraph (three replays) against the eager launch at the
     same Philox offset.  Guards against ordering / buffer-reuse hazards of captured steps (a multi-block framework reduction
